@@ -1,0 +1,163 @@
+/*
+ * uhc_amd.h -- C-ABI of libuhc_amd.so: batched SMPL-humanoid rigid-body simulation on MI355X.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json (north_star).  The
+ * reference (ZhengyiLuo/UHC) reaches its physics through the mujoco-py object API; each entry
+ * point below names the reference call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; uhc_last_error() gives the message
+ *     (thread-local).  No exception crosses this boundary.  A physics blow-up is NOT an error: it
+ *     raises the per-env `fail` flag, mirroring uhc/envs/humanoid_im.py:1207-1211.
+ *   - handles are opaque; the library owns all device buffers it allocates.
+ *   - `double* d_*` / `int* d_*` arguments are DEVICE pointers (HBM resident) unless the name
+ *     starts with `h_`; all arrays are dense row-major, env-major ([n_env][dim]).
+ *   - a UhcBatch is bound to one device and one HIP stream; calls on one batch are not
+ *     re-entrant, different batches are independent (one per GPU / rank).
+ *   - all arithmetic is float64, like the reference (scripts/train_uhc.py:80-81).
+ */
+#ifndef UHC_AMD_H
+#define UHC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UHC_ABI_VERSION 1
+
+/* joint / geom type codes (MuJoCo numbering) */
+enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
+enum { UHC_GEOM_PLANE = 0, UHC_GEOM_SPHERE = 2, UHC_GEOM_BOX = 6, UHC_GEOM_MESH = 7 };
+
+/*
+ * Flat description of one compiled model (host arrays, copied by uhc_model_create).
+ * Produced by uhc_amd/model/mjcf.py; replaces mujoco_py.load_model_from_xml
+ * (uhc/khrylib/rl/envs/common/mujoco_env.py:18, uhc/envs/humanoid_im.py:1448).
+ */
+typedef struct UhcModelDesc {
+    int32_t nq, nv, nu, nbody, njnt, ngeom, nmeshvert, nmeshadj, nexclude;
+    int32_t iterations;        /* solver sweeps cap (MuJoCo opt.iterations, default 100) */
+    int32_t plane_mesh_maxcon; /* max contacts a plane-mesh pair may emit */
+    int32_t _pad;
+    double timestep, tolerance, meaninertia;
+    double gravity[3];
+    /* bodies [nbody] */
+    const int32_t *body_parentid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
+    const double *body_pos /*[nbody][3]*/, *body_quat /*[nbody][4]*/, *body_ipos, *body_iquat;
+    const double *body_mass, *body_inertia /*[nbody][3]*/, *body_invweight0 /*[nbody][2]*/;
+    /* joints [njnt] */
+    const int32_t *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
+    const double *jnt_pos, *jnt_axis /*[njnt][3]*/, *jnt_range /*[njnt][2]*/, *jnt_stiffness, *jnt_margin;
+    const double *qpos0, *qpos_spring; /*[nq]*/
+    /* dofs [nv] */
+    const int32_t *dof_bodyid, *dof_jntid, *dof_parentid, *dof_madr /*[nv+1]*/;
+    const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0;
+    /* geoms [ngeom] */
+    const int32_t *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim;
+    const int32_t *geom_vertadr, *geom_vertnum;
+    const double *geom_pos, *geom_quat, *geom_size /*[ngeom][3]*/, *geom_friction /*[ngeom][3]*/;
+    const double *geom_margin, *geom_gap, *geom_solref /*[ngeom][2]*/, *geom_solimp /*[ngeom][5]*/;
+    const double *geom_rbound, *geom_center /*[ngeom][3] body frame*/;
+    const double *mesh_vert;       /* [nmeshvert][3], body frame */
+    const int32_t *mesh_adjadr;    /* [nmeshvert+1] CSR */
+    const int32_t *mesh_adj;       /* [nmeshadj] global vertex ids */
+    const int32_t *exclude_pair;   /* [nexclude][2] body ids */
+    /* actuators [nu]: motors on scalar joints */
+    const int32_t *actuator_dofid;
+    const double *actuator_gear;
+} UhcModelDesc;
+
+/*
+ * Controller constants of HumanoidEnv.do_simulation / compute_torque / rfc_implicit
+ * (uhc/envs/humanoid_im.py:1014-1076, 1136-1190).
+ */
+typedef struct UhcCtrlDesc {
+    int32_t n_substeps;   /* frame_skip, 15 (humanoid_im.py:64) */
+    int32_t action_type;  /* 0 = "position" (stable PD), 1 = "torque" (humanoid_im.py:1157-1160) */
+    int32_t meta_pd;      /* 0 none, 1 per-substep gains (30 numbers), 2 per-joint (humanoid_im.py:1054-1067) */
+    int32_t rfc_mode;     /* 0 none, 1 implicit root wrench (humanoid_im.py:1136-1143) */
+    int32_t action_dim;   /* nu + vf_dim + meta_pd_dim (humanoid_im.py:250) */
+    int32_t _pad;
+    double rfc_scale;     /* residual_force_scale * rfc_rate */
+    double rfc_lim;       /* residual_force_lim */
+    double base_rot[4];   /* data_specs.base_rot (humanoid_im.py:85) */
+    const double *jkp, *jkd, *torque_lim, *a_scale; /* [nu] host arrays */
+} UhcCtrlDesc;
+
+typedef struct UhcModel UhcModel;
+typedef struct UhcBatch UhcBatch;
+
+/* per-env state fields addressable through uhc_batch_field() */
+enum UhcField {
+    UHC_F_QPOS = 0,      /* [n_env][nq]   data.qpos */
+    UHC_F_QVEL = 1,      /* [n_env][nv]   data.qvel */
+    UHC_F_XPOS = 2,      /* [n_env][nbody][3] data.body_xpos (as left by the last forward pass) */
+    UHC_F_XQUAT = 3,     /* [n_env][nbody][4] data.body_xquat */
+    UHC_F_XIPOS = 4,     /* [n_env][nbody][3] data.xipos */
+    UHC_F_QM = 5,        /* [n_env][nM]   data.qM (tree-sparse) */
+    UHC_F_QFRC_BIAS = 6, /* [n_env][nv]   data.qfrc_bias */
+    UHC_F_QACC = 7,      /* [n_env][nv]   data.qacc (== qacc_warmstart of the next step) */
+    UHC_F_CTRL = 8,      /* [n_env][nu]   data.ctrl of the last substep */
+    UHC_F_NCON = 9,      /* int32 [n_env] data.ncon of the last forward pass */
+    UHC_F_NEFC = 10,     /* int32 [n_env] data.nefc */
+    UHC_F_FAIL = 11,     /* int32 [n_env] sticky physics-failure flag (NaN / huge qacc, qpos, qvel) */
+    UHC_F_SOLVER_ITER = 12, /* int32 [n_env] PGS sweeps used by the last solve */
+    UHC_F_QFRC_APPLIED = 13, /* [n_env][nv] data.qfrc_applied of the last substep */
+    UHC_F_EFC_OVERFLOW = 14  /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
+};
+
+const char* uhc_last_error(void);
+int32_t uhc_abi_version(void);
+
+/* model lifetime (host side) */
+int32_t uhc_model_create(const UhcModelDesc* desc, UhcModel** out);
+void uhc_model_free(UhcModel* m);
+int32_t uhc_model_nM(const UhcModel* m);
+
+/*
+ * Create a batch of n_env environments on `device_id`.
+ *   models[n_models]: distinct models; env_model[n_env] (host, may be NULL => all envs use
+ *   models[0]) selects each env's model.  All models must share topology (sizes, tree, types);
+ *   bodies may differ in geometry/inertia (the reference rebuilds the model per episode from
+ *   SMPL shape: uhc/envs/humanoid_im.py:154-180).
+ */
+int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_models, const int32_t* h_env_model,
+                         int32_t n_env, int32_t device_id, const UhcCtrlDesc* ctrl, UhcBatch** out);
+void uhc_batch_free(UhcBatch* b);
+/* bind to an existing hipStream_t (e.g. torch's current stream); NULL => the batch's own stream */
+int32_t uhc_batch_set_stream(UhcBatch* b, void* hip_stream);
+int32_t uhc_batch_sync(UhcBatch* b);
+/* change rfc_scale between iterations (rfc_decay: uhc/agents/agent_copycat.py:283-290) */
+int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
+
+/* device pointer + element count of a state field (valid until uhc_batch_free) */
+int32_t uhc_batch_field(UhcBatch* b, int32_t field, void** d_ptr, int64_t* count);
+
+/*
+ * MujocoEnv.set_state + sim.forward() (uhc/khrylib/rl/envs/common/mujoco_env.py:106-113) for the
+ * envs listed in d_env_ids[n] (device int32; NULL => all n_env envs in order, n must be n_env).
+ * d_qpos [n][nq], d_qvel [n][nv] are indexed by position in the list.  Clears the fail flag and
+ * the warm start (sim.reset(): mujoco_env.py:96) of those envs.
+ */
+int32_t uhc_batch_set_state(UhcBatch* b, const int32_t* d_env_ids, int32_t n, const double* d_qpos,
+                            const double* d_qvel);
+
+/*
+ * HumanoidEnv.do_simulation(action, frame_skip) (uhc/envs/humanoid_im.py:1145-1190) for every env:
+ * n_substeps x { compute_torque -> clip -> ctrl; rfc_implicit -> qfrc_applied; sim.step() }.
+ *   d_action      [n_env][action_dim]  policy output (joint residuals | residual force | meta-PD)
+ *   d_target_base [n_env][nu]          expert joint pose of the next frame (get_expert_kin_pose(delta_t=1))
+ *   d_active      int32 [n_env] or NULL: envs with 0 are left untouched (finished episodes)
+ */
+int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const double* d_target_base,
+                           const int32_t* d_active);
+
+/* mj_forward only (no control, no integration) on all envs: refreshes xpos/xquat/xipos/qM/qfrc_bias */
+int32_t uhc_batch_forward(UhcBatch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UHC_AMD_H */

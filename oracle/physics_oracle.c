@@ -1,0 +1,888 @@
+/*
+ * physics_oracle.c -- TEST INFRASTRUCTURE.  CPU float64 restatement, one environment, of the
+ * rigid-body step the reference obtains from MuJoCo 2.1.0 (`self.sim.step()`,
+ * uhc/envs/humanoid_im.py:1177; `sim.forward()`, uhc/khrylib/rl/envs/common/mujoco_env.py:113)
+ * plus the Python-side controller wrapped around it (uhc/envs/humanoid_im.py:1014-1190).
+ *
+ * PARITY UNPINNED for the MuJoCo stages: MuJoCo 2.1.0 (mujoco-py>=2.1,<2.2, requirements.txt:11)
+ * is an un-vendored binary dependency that is absent from /root/reference and from this image, and
+ * the reference ships no physics golden vectors.  Every stage tagged [MJ-ext]
+ * restates MuJoCo's published algorithm (engine_core_smooth / engine_core_constraint /
+ * engine_collision_convex / engine_solver / engine_forward) from its documentation; what pins it
+ * here are analytic known-answer tests (tests/test_oracle_physics.py) and the reference's own
+ * independent FK (uhc/smpllib/torch_smpl_humanoid.py:303-362, golden fixture).
+ * The controller part IS pinned against the imported reference (tests/golden/ctrl_*.npz).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object.  The product path (uhc_amd/csrc) never links or calls it.
+ *
+ * Written for readability, not speed: dense loops over nv where MuJoCo uses chains, no SIMD.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "../include/uhc_amd.h"
+#include "physics_oracle.h"
+
+#define MINVAL 1e-15   /* [MJ-ext] mjMINVAL */
+#define MAXVAL 1e10    /* [MJ-ext] mjMAXVAL */
+
+/* ------------------------------------------------------------------ small math */
+static void cross3(double r[3], const double a[3], const double b[3]) {
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double dot6(const double a[6], const double b[6]) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+static void quat_mul(double r[4], const double a[4], const double b[4]) {
+    double t[4];
+    t[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    t[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    t[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    t[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    memcpy(r, t, sizeof t);
+}
+static void quat_normalize(double q[4]) {
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void quat_to_mat(double m[9], const double q[4]) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+    m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+    m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+static void mat_vec(double r[3], const double m[9], const double v[3]) {
+    double t0 = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+    double t1 = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+    double t2 = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+    r[0] = t0; r[1] = t1; r[2] = t2;
+}
+static void axis_angle_quat(double q[4], const double axis[3], double angle) {
+    double s = sin(0.5 * angle);
+    q[0] = cos(0.5 * angle); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+/* spatial vectors are [angular(3); linear(3)] */
+static void cross_motion(double r[6], const double v[6], const double m[6]) { /* [MJ-ext] mju_crossMotion */
+    double a[3], b[3];
+    cross3(r, v, m);
+    cross3(a, v, m + 3);
+    cross3(b, v + 3, m);
+    r[3] = a[0] + b[0]; r[4] = a[1] + b[1]; r[5] = a[2] + b[2];
+}
+static void cross_force(double r[6], const double v[6], const double f[6]) { /* [MJ-ext] mju_crossForce */
+    double a[3], b[3];
+    cross3(a, v, f);
+    cross3(b, v + 3, f + 3);
+    r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+    cross3(r + 3, v, f + 3);
+}
+/* 10-number spatial inertia about a reference point: Ixx Iyy Izz Ixy Ixz Iyz | m*c (3) | m */
+static void inert_mul(double r[6], const double I[10], const double v[6]) { /* [MJ-ext] mju_mulInertVec */
+    const double *w = v, *l = v + 3, *h = I + 6;
+    double hxl[3], wxh[3];
+    cross3(hxl, h, l);
+    cross3(wxh, w, h);
+    r[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2] + hxl[0];
+    r[1] = I[3] * w[0] + I[1] * w[1] + I[5] * w[2] + hxl[1];
+    r[2] = I[4] * w[0] + I[5] * w[1] + I[2] * w[2] + hxl[2];
+    r[3] = I[9] * l[0] + wxh[0];
+    r[4] = I[9] * l[1] + wxh[1];
+    r[5] = I[9] * l[2] + wxh[2];
+}
+
+/* ------------------------------------------------------------------ data */
+OrcData* orc_data_create(const UhcModelDesc* m) {
+    OrcData* d = (OrcData*)calloc(1, sizeof(OrcData));
+    int nb = m->nbody, nv = m->nv, nM = m->dof_madr[nv];
+    d->nM = nM;
+    d->qpos = calloc(m->nq, 8); d->qvel = calloc(nv, 8); d->qacc = calloc(nv, 8);
+    d->qacc_warmstart = calloc(nv, 8); d->ctrl = calloc(m->nu > 0 ? m->nu : 1, 8);
+    d->qfrc_applied = calloc(nv, 8);
+    d->xpos = calloc(nb * 3, 8); d->xquat = calloc(nb * 4, 8); d->xmat = calloc(nb * 9, 8);
+    d->xipos = calloc(nb * 3, 8); d->ximat = calloc(nb * 9, 8);
+    d->xanchor = calloc(m->njnt * 3, 8); d->xaxis = calloc(m->njnt * 3, 8);
+    d->subtree_com = calloc(nb * 3, 8); d->cinert = calloc(nb * 10, 8); d->crb = calloc(nb * 10, 8);
+    d->cdof = calloc(nv * 6, 8); d->cdof_dot = calloc(nv * 6, 8); d->cvel = calloc(nb * 6, 8);
+    d->qM = calloc(nM, 8); d->qLD = calloc(nM, 8);
+    d->qfrc_bias = calloc(nv, 8); d->qfrc_passive = calloc(nv, 8); d->qfrc_actuator = calloc(nv, 8);
+    d->qfrc_smooth = calloc(nv, 8); d->qacc_smooth = calloc(nv, 8); d->qfrc_constraint = calloc(nv, 8);
+    d->con_pos = calloc(ORC_MAXCON * 3, 8); d->con_frame = calloc(ORC_MAXCON * 9, 8);
+    d->con_dist = calloc(ORC_MAXCON, 8); d->con_margin = calloc(ORC_MAXCON, 8);
+    d->con_friction = calloc(ORC_MAXCON * 3, 8); d->con_solref = calloc(ORC_MAXCON * 2, 8);
+    d->con_solimp = calloc(ORC_MAXCON * 5, 8);
+    d->con_geom1 = calloc(ORC_MAXCON, 4); d->con_geom2 = calloc(ORC_MAXCON, 4); d->con_dim = calloc(ORC_MAXCON, 4);
+    d->efc_J = calloc((size_t)ORC_MAXEFC * nv, 8); d->efc_pos = calloc(ORC_MAXEFC, 8);
+    d->efc_margin = calloc(ORC_MAXEFC, 8); d->efc_R = calloc(ORC_MAXEFC, 8); d->efc_D = calloc(ORC_MAXEFC, 8);
+    d->efc_aref = calloc(ORC_MAXEFC, 8); d->efc_b = calloc(ORC_MAXEFC, 8); d->efc_force = calloc(ORC_MAXEFC, 8);
+    d->efc_vel = calloc(ORC_MAXEFC, 8); d->efc_diagApprox = calloc(ORC_MAXEFC, 8);
+    d->efc_floss = calloc(ORC_MAXEFC, 8);
+    d->efc_type = calloc(ORC_MAXEFC, 4); d->efc_id = calloc(ORC_MAXEFC, 4); d->efc_edge = calloc(ORC_MAXEFC, 4);
+    d->efc_AR = calloc((size_t)ORC_MAXEFC * ORC_MAXEFC, 8);
+    d->work = calloc((size_t)ORC_MAXEFC * nv + 16 * nv, 8);
+    memcpy(d->qpos, m->qpos0, m->nq * 8);
+    return d;
+}
+void orc_data_free(OrcData* d) {
+    if (!d) return;
+    free(d->qpos); free(d->qvel); free(d->qacc); free(d->qacc_warmstart); free(d->ctrl); free(d->qfrc_applied);
+    free(d->xpos); free(d->xquat); free(d->xmat); free(d->xipos); free(d->ximat); free(d->xanchor); free(d->xaxis);
+    free(d->subtree_com); free(d->cinert); free(d->crb); free(d->cdof); free(d->cdof_dot); free(d->cvel);
+    free(d->qM); free(d->qLD); free(d->qfrc_bias); free(d->qfrc_passive); free(d->qfrc_actuator);
+    free(d->qfrc_smooth); free(d->qacc_smooth); free(d->qfrc_constraint);
+    free(d->con_pos); free(d->con_frame); free(d->con_dist); free(d->con_margin); free(d->con_friction);
+    free(d->con_solref); free(d->con_solimp); free(d->con_geom1); free(d->con_geom2); free(d->con_dim);
+    free(d->efc_J); free(d->efc_pos); free(d->efc_margin); free(d->efc_R); free(d->efc_D); free(d->efc_aref);
+    free(d->efc_b); free(d->efc_force); free(d->efc_vel); free(d->efc_diagApprox); free(d->efc_floss);
+    free(d->efc_type); free(d->efc_id); free(d->efc_edge); free(d->efc_AR); free(d->work);
+    free(d);
+}
+
+/* ------------------------------------------------------------------ P1: mj_kinematics [MJ-ext] */
+void orc_kinematics(const UhcModelDesc* m, OrcData* d) {
+    d->xpos[0] = d->xpos[1] = d->xpos[2] = 0;
+    d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
+    quat_to_mat(d->xmat, d->xquat);
+    memset(d->xipos, 0, 24); quat_to_mat(d->ximat, d->xquat);
+    for (int b = 1; b < m->nbody; b++) {
+        int p = m->body_parentid[b], ja = m->body_jntadr[b], jn = m->body_jntnum[b];
+        double pos[3], quat[4], R[9], t[3];
+        if (jn == 1 && m->jnt_type[ja] == UHC_JNT_FREE) {
+            const double* q = d->qpos + m->jnt_qposadr[ja];
+            memcpy(pos, q, 24); memcpy(quat, q + 3, 32);
+            quat_normalize(quat);
+            memcpy(d->xanchor + 3 * ja, pos, 24);
+            d->xaxis[3 * ja] = 0; d->xaxis[3 * ja + 1] = 0; d->xaxis[3 * ja + 2] = 1;
+        } else {
+            mat_vec(t, d->xmat + 9 * p, m->body_pos + 3 * b);
+            for (int k = 0; k < 3; k++) pos[k] = d->xpos[3 * p + k] + t[k];
+            quat_mul(quat, d->xquat + 4 * p, m->body_quat + 4 * b);
+            for (int j = ja; j < ja + jn; j++) {
+                int qa = m->jnt_qposadr[j];
+                double qloc[4];
+                quat_to_mat(R, quat);
+                mat_vec(t, R, m->jnt_pos + 3 * j);
+                for (int k = 0; k < 3; k++) d->xanchor[3 * j + k] = pos[k] + t[k];
+                mat_vec(d->xaxis + 3 * j, R, m->jnt_axis + 3 * j);
+                switch (m->jnt_type[j]) {
+                case UHC_JNT_SLIDE:
+                    for (int k = 0; k < 3; k++) pos[k] += d->xaxis[3 * j + k] * (d->qpos[qa] - m->qpos0[qa]);
+                    continue;
+                case UHC_JNT_HINGE:
+                    axis_angle_quat(qloc, m->jnt_axis + 3 * j, d->qpos[qa] - m->qpos0[qa]);
+                    quat_mul(quat, quat, qloc);
+                    break;
+                case UHC_JNT_BALL:
+                    memcpy(qloc, d->qpos + qa, 32);
+                    quat_normalize(qloc);
+                    quat_mul(quat, quat, qloc);
+                    break;
+                default: break;
+                }
+                /* keep the anchor fixed under the joint's rotation */
+                quat_to_mat(R, quat);
+                mat_vec(t, R, m->jnt_pos + 3 * j);
+                for (int k = 0; k < 3; k++) pos[k] = d->xanchor[3 * j + k] - t[k];
+            }
+        }
+        quat_normalize(quat);
+        memcpy(d->xpos + 3 * b, pos, 24); memcpy(d->xquat + 4 * b, quat, 32);
+        quat_to_mat(d->xmat + 9 * b, quat);
+        mat_vec(t, d->xmat + 9 * b, m->body_ipos + 3 * b);
+        for (int k = 0; k < 3; k++) d->xipos[3 * b + k] = pos[k] + t[k];
+        double qi[4];
+        quat_mul(qi, quat, m->body_iquat + 4 * b);
+        quat_to_mat(d->ximat + 9 * b, qi);
+    }
+}
+
+/* ------------------------------------------------------------------ P2: mj_comPos [MJ-ext] */
+static int body_rootid(const UhcModelDesc* m, int b) {
+    while (b > 0 && m->body_parentid[b] > 0) b = m->body_parentid[b];
+    return b;
+}
+void orc_com_pos(const UhcModelDesc* m, OrcData* d) {
+    int nb = m->nbody;
+    double* mass = d->work; /* subtree masses */
+    for (int b = 0; b < nb; b++) {
+        mass[b] = m->body_mass[b];
+        for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = m->body_mass[b] * d->xipos[3 * b + k];
+    }
+    for (int b = nb - 1; b > 0; b--) {
+        int p = m->body_parentid[b];
+        mass[p] += mass[b];
+        for (int k = 0; k < 3; k++) d->subtree_com[3 * p + k] += d->subtree_com[3 * b + k];
+    }
+    for (int b = 0; b < nb; b++)
+        for (int k = 0; k < 3; k++)
+            d->subtree_com[3 * b + k] = mass[b] < MINVAL ? d->xipos[3 * b + k] : d->subtree_com[3 * b + k] / mass[b];
+    /* body inertias about the subtree COM of the kinematic-tree root, world-aligned */
+    memset(d->cinert, 0, 80);
+    for (int b = 1; b < nb; b++) {
+        const double* c0 = d->subtree_com + 3 * body_rootid(m, b);
+        const double* R = d->ximat + 9 * b;
+        const double* I = m->body_inertia + 3 * b;
+        double ms = m->body_mass[b], c[3], *ci = d->cinert + 10 * b;
+        for (int k = 0; k < 3; k++) c[k] = d->xipos[3 * b + k] - c0[k];
+        /* R diag(I) R^T */
+        double J[9];
+        for (int r = 0; r < 3; r++)
+            for (int s = 0; s < 3; s++)
+                J[3 * r + s] = R[3 * r] * I[0] * R[3 * s] + R[3 * r + 1] * I[1] * R[3 * s + 1] + R[3 * r + 2] * I[2] * R[3 * s + 2];
+        double cc = dot3(c, c);
+        ci[0] = J[0] + ms * (cc - c[0] * c[0]);
+        ci[1] = J[4] + ms * (cc - c[1] * c[1]);
+        ci[2] = J[8] + ms * (cc - c[2] * c[2]);
+        ci[3] = J[1] - ms * c[0] * c[1];
+        ci[4] = J[2] - ms * c[0] * c[2];
+        ci[5] = J[5] - ms * c[1] * c[2];
+        ci[6] = ms * c[0]; ci[7] = ms * c[1]; ci[8] = ms * c[2]; ci[9] = ms;
+    }
+    /* motion axes of the dofs, expressed at that same point */
+    for (int j = 0; j < m->njnt; j++) {
+        int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j];
+        const double* c0 = d->subtree_com + 3 * body_rootid(m, b);
+        double off[3], *cd = d->cdof + 6 * da;
+        for (int k = 0; k < 3; k++) off[k] = c0[k] - d->xanchor[3 * j + k];
+        switch (m->jnt_type[j]) {
+        case UHC_JNT_FREE:
+            memset(cd, 0, 18 * 8);
+            cd[3] = 1; cd[6 + 4] = 1; cd[12 + 5] = 1;
+            cd += 18; /* then rotations about the body axes */
+            /* fall through */
+        case UHC_JNT_BALL:
+            for (int k = 0; k < 3; k++) {
+                double ax[3] = {d->xmat[9 * b + k], d->xmat[9 * b + 3 + k], d->xmat[9 * b + 6 + k]};
+                memcpy(cd + 6 * k, ax, 24);
+                cross3(cd + 6 * k + 3, ax, off);
+            }
+            break;
+        case UHC_JNT_SLIDE:
+            memset(cd, 0, 24); memcpy(cd + 3, d->xaxis + 3 * j, 24);
+            break;
+        case UHC_JNT_HINGE:
+            memcpy(cd, d->xaxis + 3 * j, 24);
+            cross3(cd + 3, d->xaxis + 3 * j, off);
+            break;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ P3: mj_crb + mj_factorM [MJ-ext] */
+void orc_crb(const UhcModelDesc* m, OrcData* d) {
+    int nb = m->nbody, nv = m->nv;
+    memcpy(d->crb, d->cinert, nb * 80);
+    for (int b = nb - 1; b > 0; b--) {
+        int p = m->body_parentid[b];
+        if (p > 0) for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k];
+    }
+    for (int i = 0; i < nv; i++) {
+        double buf[6];
+        int adr = m->dof_madr[i];
+        inert_mul(buf, d->crb + 10 * m->dof_bodyid[i], d->cdof + 6 * i);
+        for (int j = i; j >= 0; j = m->dof_parentid[j]) d->qM[adr++] = dot6(d->cdof + 6 * j, buf);
+        d->qM[m->dof_madr[i]] += m->dof_armature[i];
+    }
+}
+/* in-place L^T D L of a tree-sparse matrix given in qM layout */
+void orc_factor_sparse(const UhcModelDesc* m, double* LD) {
+    for (int k = m->nv - 1; k >= 0; k--) {
+        int kk = m->dof_madr[k], ki = kk + 1;
+        for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i], ki++) {
+            double a = LD[ki] / LD[kk];
+            int n = m->dof_madr[i + 1] - m->dof_madr[i]; /* entries of row i == tail of row k from ki */
+            for (int t = 0; t < n; t++) LD[m->dof_madr[i] + t] -= a * LD[ki + t];
+            LD[ki] = a;
+        }
+    }
+}
+void orc_solve_sparse(const UhcModelDesc* m, const double* LD, double* x) {
+    int nv = m->nv;
+    for (int i = nv - 1; i >= 0; i--) {
+        int adr = m->dof_madr[i] + 1;
+        for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[j] -= LD[adr++] * x[i];
+    }
+    for (int i = 0; i < nv; i++) x[i] /= LD[m->dof_madr[i]];
+    for (int i = 0; i < nv; i++) {
+        int adr = m->dof_madr[i] + 1;
+        for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[i] -= LD[adr++] * x[j];
+    }
+}
+void orc_factor_m(const UhcModelDesc* m, OrcData* d) {
+    memcpy(d->qLD, d->qM, d->nM * 8);
+    orc_factor_sparse(m, d->qLD);
+}
+void orc_full_m(const UhcModelDesc* m, const double* qM, double* dense) { /* [MJ-ext] mj_fullM */
+    int nv = m->nv;
+    memset(dense, 0, (size_t)nv * nv * 8);
+    for (int i = 0; i < nv; i++) {
+        int adr = m->dof_madr[i];
+        for (int j = i; j >= 0; j = m->dof_parentid[j], adr++) dense[i * nv + j] = dense[j * nv + i] = qM[adr];
+    }
+}
+
+/* ------------------------------------------------------------------ Jacobian of a world point on a body */
+static void jac_point(const UhcModelDesc* m, const OrcData* d, int body, const double p[3], double* jacp /*3*nv*/) {
+    int nv = m->nv;
+    memset(jacp, 0, 3 * nv * 8);
+    if (body <= 0) return;
+    const double* c0 = d->subtree_com + 3 * body_rootid(m, body);
+    double off[3] = {p[0] - c0[0], p[1] - c0[1], p[2] - c0[2]};
+    /* last dof of the nearest ancestor that has dofs, then walk the dof chain */
+    int b = body;
+    while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+    if (b <= 0) return;
+    for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parentid[i]) {
+        double t[3];
+        cross3(t, d->cdof + 6 * i, off);
+        for (int k = 0; k < 3; k++) jacp[k * nv + i] = d->cdof[6 * i + 3 + k] + t[k];
+    }
+}
+
+/* ------------------------------------------------------------------ P4: mj_collision [MJ-ext] */
+static void make_frame(double f[9]) { /* [MJ-ext] mju_makeFrame: x given, y picked, z = x cross y */
+    double n = sqrt(dot3(f, f));
+    f[0] /= n; f[1] /= n; f[2] /= n;
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+    double dp = dot3(f, f + 3);
+    for (int k = 0; k < 3; k++) f[3 + k] -= f[k] * dp;
+    n = sqrt(dot3(f + 3, f + 3));
+    f[3] /= n; f[4] /= n; f[5] /= n;
+    cross3(f + 6, f, f + 3);
+}
+static int bodies_filtered(const UhcModelDesc* m, int b1, int b2) {
+    if (b1 == b2) return 1;
+    /* parent-child filter applies only when neither body is the world */
+    if (b1 != 0 && b2 != 0 && (m->body_parentid[b1] == b2 || m->body_parentid[b2] == b1)) return 1;
+    for (int e = 0; e < m->nexclude; e++) {
+        int x = m->exclude_pair[2 * e], y = m->exclude_pair[2 * e + 1];
+        if ((x == b1 && y == b2) || (x == b2 && y == b1)) return 1;
+    }
+    return 0;
+}
+static void add_contact(const UhcModelDesc* m, OrcData* d, int g1, int g2, const double pos[3],
+                        const double normal[3], double dist, double margin) {
+    if (d->ncon >= ORC_MAXCON) return;
+    int c = d->ncon++;
+    memcpy(d->con_pos + 3 * c, pos, 24);
+    memcpy(d->con_frame + 9 * c, normal, 24);
+    make_frame(d->con_frame + 9 * c);
+    d->con_dist[c] = dist;
+    d->con_margin[c] = margin; /* includemargin = margin - gap; gap handled by caller */
+    d->con_geom1[c] = g1; d->con_geom2[c] = g2;
+    d->con_dim[c] = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    for (int k = 0; k < 3; k++)
+        d->con_friction[3 * c + k] = fmax(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
+    /* equal solmix weights: plain average [MJ-ext] */
+    for (int k = 0; k < 2; k++) d->con_solref[2 * c + k] = 0.5 * (m->geom_solref[2 * g1 + k] + m->geom_solref[2 * g2 + k]);
+    for (int k = 0; k < 5; k++) d->con_solimp[5 * c + k] = 0.5 * (m->geom_solimp[5 * g1 + k] + m->geom_solimp[5 * g2 + k]);
+}
+/* plane (g1) vs convex mesh (g2): support vertex, then hull-graph neighbours within margin */
+static void collide_plane_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2, double margin, double gap) {
+    int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    double pR[9], pq[4], ppos[3], t[3];
+    /* plane pose */
+    quat_mul(pq, d->xquat + 4 * b1, m->geom_quat + 4 * g1);
+    quat_to_mat(pR, pq);
+    mat_vec(t, d->xmat + 9 * b1, m->geom_pos + 3 * g1);
+    for (int k = 0; k < 3; k++) ppos[k] = d->xpos[3 * b1 + k] + t[k];
+    double n[3] = {pR[2], pR[5], pR[8]};
+    /* bounding-sphere cull */
+    mat_vec(t, d->xmat + 9 * b2, m->geom_center + 3 * g2);
+    double cdist = 0;
+    for (int k = 0; k < 3; k++) cdist += n[k] * (d->xpos[3 * b2 + k] + t[k] - ppos[k]);
+    if (cdist - m->geom_rbound[g2] > margin) return;
+    /* support vertex along -normal (first minimum wins) */
+    int va = m->geom_vertadr[g2], vn = m->geom_vertnum[g2], best = -1;
+    double bestd = 0, bw[3] = {0, 0, 0};
+    for (int v = va; v < va + vn; v++) {
+        double w[3];
+        mat_vec(w, d->xmat + 9 * b2, m->mesh_vert + 3 * v);
+        double dist = 0;
+        for (int k = 0; k < 3; k++) { w[k] += d->xpos[3 * b2 + k]; dist += n[k] * (w[k] - ppos[k]); }
+        if (best < 0 || dist < bestd) { best = v; bestd = dist; memcpy(bw, w, 24); }
+    }
+    if (best < 0 || bestd > margin) return;
+    double cp[3];
+    for (int k = 0; k < 3; k++) cp[k] = bw[k] - 0.5 * bestd * n[k];
+    add_contact(m, d, g1, g2, cp, n, bestd, margin - gap);
+    int cnt = 1;
+    for (int e = m->mesh_adjadr[best]; e < m->mesh_adjadr[best + 1] && cnt < m->plane_mesh_maxcon; e++) {
+        int v = m->mesh_adj[e];
+        double w[3], dist = 0;
+        mat_vec(w, d->xmat + 9 * b2, m->mesh_vert + 3 * v);
+        for (int k = 0; k < 3; k++) { w[k] += d->xpos[3 * b2 + k]; dist += n[k] * (w[k] - ppos[k]); }
+        if (dist <= margin) {
+            for (int k = 0; k < 3; k++) cp[k] = w[k] - 0.5 * dist * n[k];
+            add_contact(m, d, g1, g2, cp, n, dist, margin - gap);
+            cnt++;
+        }
+    }
+}
+void orc_collision(const UhcModelDesc* m, OrcData* d) {
+    d->ncon = 0;
+    for (int g1 = 0; g1 < m->ngeom; g1++)
+        for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+            int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+            if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
+            if (bodies_filtered(m, b1, b2)) continue;
+            double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+            double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+            int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+            if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g1, g2, margin, gap);
+            else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g2, g1, margin, gap);
+            /* mesh-mesh (self-collision of generated models) is a later row: SURVEY.md 8a P4 */
+        }
+}
+
+/* ------------------------------------------------------------------ P5: mj_makeConstraint [MJ-ext] */
+static double impedance(const double solimp[5], double pos, double margin) { /* [MJ-ext] getimpedance */
+    double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+    dmin = fmin(fmax(dmin, 0.0001), 0.9999); dmax = fmin(fmax(dmax, 0.0001), 0.9999);
+    if (width < MINVAL) return 0.5 * (dmin + dmax);
+    mid = fmin(fmax(mid, 0.0001), 0.9999);
+    if (power < 1) power = 1;
+    double x = fabs(pos - margin) / width, y;
+    if (x >= 1) return dmax;
+    if (x <= 0) return dmin;
+    if (power == 1) y = x;
+    else if (x <= mid) y = pow(x / mid, power) * mid;          /* a*x^p, a = 1/mid^(p-1) */
+    else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);  /* 1 - b*(1-x)^p */
+    return dmin + y * (dmax - dmin);
+}
+static int add_row(const UhcModelDesc* m, OrcData* d, int type, double pos, double margin, double diagApprox,
+                   const double solref[2], const double solimp[5], double floss) {
+    if (d->nefc >= ORC_MAXEFC) { d->efc_overflow = 1; return -1; }
+    int r = d->nefc++;
+    memset(d->efc_J + (size_t)r * m->nv, 0, m->nv * 8);
+    d->efc_type[r] = type; d->efc_pos[r] = pos; d->efc_margin[r] = margin; d->efc_diagApprox[r] = diagApprox;
+    d->efc_floss[r] = floss; d->efc_id[r] = -1; d->efc_edge[r] = 0;
+    /* reference acceleration parameters, stored temporarily in aref (K) / b (B) / D (imp) */
+    double timeconst = fmax(solref[0], 2 * m->timestep), dampratio = solref[1];
+    double dmax = fmin(fmax(solimp[1], 0.0001), 0.9999);
+    d->efc_aref[r] = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio); /* K */
+    d->efc_b[r] = 2.0 / (dmax * timeconst);                                                 /* B */
+    d->efc_D[r] = impedance(solimp, pos, margin);                                           /* imp */
+    return r;
+}
+void orc_make_constraint(const UhcModelDesc* m, OrcData* d) {
+    static const double dsolref[2] = {0.02, 1.0}, dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+    int nv = m->nv;
+    d->nefc = 0;
+    /* (1) dof friction loss */
+    for (int i = 0; i < nv; i++)
+        if (m->dof_frictionloss[i] > 0) {
+            int r = add_row(m, d, ORC_EFC_FRICTION, 0, 0, m->dof_invweight0[i], dsolref, dsolimp, m->dof_frictionloss[i]);
+            if (r >= 0) d->efc_J[(size_t)r * nv + i] = 1;
+        }
+    /* (2) joint limits */
+    for (int j = 0; j < m->njnt; j++) {
+        if (!m->jnt_limited[j]) continue;
+        int t = m->jnt_type[j];
+        if (t != UHC_JNT_HINGE && t != UHC_JNT_SLIDE) continue; /* ball limits: later row */
+        double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+        for (int side = -1; side <= 1; side += 2) {
+            double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);
+            if (dist < margin) {
+                int r = add_row(m, d, ORC_EFC_LIMIT, dist, margin, m->dof_invweight0[m->jnt_dofadr[j]], dsolref, dsolimp, 0);
+                if (r >= 0) d->efc_J[(size_t)r * nv + m->jnt_dofadr[j]] = -side;
+            }
+        }
+    }
+    /* (3) contacts, pyramidal friction cones */
+    double* jp1 = d->work; double* jp2 = d->work + 3 * nv; double* jc = d->work + 6 * nv;
+    for (int c = 0; c < d->ncon; c++) {
+        if (d->con_dist[c] >= d->con_margin[c]) continue;
+        int b1 = m->geom_bodyid[d->con_geom1[c]], b2 = m->geom_bodyid[d->con_geom2[c]], dim = d->con_dim[c];
+        const double* f = d->con_frame + 9 * c;
+        jac_point(m, d, b1, d->con_pos + 3 * c, jp1);
+        jac_point(m, d, b2, d->con_pos + 3 * c, jp2);
+        int ndir = dim >= 3 ? 3 : 1;
+        for (int r = 0; r < ndir; r++)
+            for (int i = 0; i < nv; i++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += f[3 * r + k] * (jp2[k * nv + i] - jp1[k * nv + i]);
+                jc[r * nv + i] = s;
+            }
+        double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+        if (dim == 1) {
+            int r = add_row(m, d, ORC_EFC_CONTACT, d->con_dist[c], d->con_margin[c], tran, d->con_solref + 2 * c, d->con_solimp + 5 * c, 0);
+            if (r >= 0) { memcpy(d->efc_J + (size_t)r * nv, jc, nv * 8); d->efc_id[r] = c; }
+        } else {
+            /* condim 3 only (torsional/rolling pyramid edges are not produced by these models) */
+            for (int e = 0; e < 4; e++) {
+                double mu = d->con_friction[3 * c + e / 2], sgn = (e & 1) ? -1.0 : 1.0;
+                int r = add_row(m, d, ORC_EFC_CONTACT_PYR, d->con_dist[c], d->con_margin[c], tran + mu * mu * tran,
+                                d->con_solref + 2 * c, d->con_solimp + 5 * c, 0);
+                if (r < 0) break;
+                d->efc_id[r] = c; d->efc_edge[r] = e;
+                for (int i = 0; i < nv; i++) d->efc_J[(size_t)r * nv + i] = jc[i] + sgn * mu * jc[(1 + e / 2) * nv + i];
+            }
+        }
+    }
+    /* impedance -> R, D, aref  ([MJ-ext] mj_makeImpedance) */
+    for (int r = 0; r < d->nefc; r++) {
+        double vel = 0, K = d->efc_aref[r], B = d->efc_b[r], imp = d->efc_D[r];
+        for (int i = 0; i < nv; i++) vel += d->efc_J[(size_t)r * nv + i] * d->qvel[i];
+        d->efc_vel[r] = vel;
+        d->efc_R[r] = fmax(MINVAL, (1 - imp) * d->efc_diagApprox[r] / imp);
+        d->efc_aref[r] = -B * vel - K * imp * (d->efc_pos[r] - d->efc_margin[r]);
+    }
+    /* pyramidal contacts: all edges share R = 2 mu^2 R(first edge) */
+    for (int r = 0; r < d->nefc; r++)
+        if (d->efc_type[r] == ORC_EFC_CONTACT_PYR && d->efc_edge[r] == 0) {
+            double mu = d->con_friction[3 * d->efc_id[r]], Rpy = 2 * mu * mu * d->efc_R[r];
+            for (int e = 0; e < 4 && r + e < d->nefc && d->efc_id[r + e] == d->efc_id[r]; e++) d->efc_R[r + e] = Rpy;
+        }
+    for (int r = 0; r < d->nefc; r++) d->efc_D[r] = 1.0 / d->efc_R[r];
+}
+
+/* ------------------------------------------------------------------ P7: mj_fwdVelocity [MJ-ext] */
+void orc_com_vel(const UhcModelDesc* m, OrcData* d) {
+    memset(d->cvel, 0, 48);
+    for (int b = 1; b < m->nbody; b++) {
+        double cvel[6], t[6];
+        memcpy(cvel, d->cvel + 6 * m->body_parentid[b], 48);
+        for (int j = m->body_jntadr[b]; j >= 0 && j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+            int da = m->jnt_dofadr[j];
+            switch (m->jnt_type[j]) {
+            case UHC_JNT_FREE:
+                memset(d->cdof_dot + 6 * da, 0, 18 * 8);
+                for (int k = 0; k < 3; k++)
+                    for (int s = 0; s < 6; s++) cvel[s] += d->cdof[6 * (da + k) + s] * d->qvel[da + k];
+                da += 3;
+                /* fall through */
+            case UHC_JNT_BALL:
+                for (int k = 0; k < 3; k++) cross_motion(d->cdof_dot + 6 * (da + k), cvel, d->cdof + 6 * (da + k));
+                for (int k = 0; k < 3; k++)
+                    for (int s = 0; s < 6; s++) cvel[s] += d->cdof[6 * (da + k) + s] * d->qvel[da + k];
+                break;
+            default:
+                cross_motion(t, cvel, d->cdof + 6 * da);
+                memcpy(d->cdof_dot + 6 * da, t, 48);
+                for (int s = 0; s < 6; s++) cvel[s] += d->cdof[6 * da + s] * d->qvel[da];
+            }
+        }
+        memcpy(d->cvel + 6 * b, cvel, 48);
+    }
+}
+void orc_passive(const UhcModelDesc* m, OrcData* d) {
+    memset(d->qfrc_passive, 0, m->nv * 8);
+    for (int j = 0; j < m->njnt; j++) {
+        double k = m->jnt_stiffness[j];
+        int t = m->jnt_type[j];
+        if (k == 0 || (t != UHC_JNT_HINGE && t != UHC_JNT_SLIDE)) continue;
+        d->qfrc_passive[m->jnt_dofadr[j]] -= k * (d->qpos[m->jnt_qposadr[j]] - m->qpos_spring[m->jnt_qposadr[j]]);
+    }
+    for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+}
+void orc_rne_bias(const UhcModelDesc* m, OrcData* d) { /* mj_rne(flg_acc=0) */
+    int nb = m->nbody;
+    double* cacc = d->work;          /* nb*6 */
+    double* cfrc = d->work + 6 * nb; /* nb*6 */
+    memset(cacc, 0, 48);
+    for (int k = 0; k < 3; k++) cacc[3 + k] = -m->gravity[k];
+    memset(cfrc, 0, 48);
+    for (int b = 1; b < nb; b++) {
+        double t[6], u[6];
+        memcpy(cacc + 6 * b, cacc + 6 * m->body_parentid[b], 48);
+        for (int i = m->body_dofadr[b]; i >= 0 && i < m->body_dofadr[b] + m->body_dofnum[b]; i++)
+            for (int s = 0; s < 6; s++) cacc[6 * b + s] += d->cdof_dot[6 * i + s] * d->qvel[i];
+        inert_mul(t, d->cinert + 10 * b, cacc + 6 * b);
+        inert_mul(u, d->cinert + 10 * b, d->cvel + 6 * b);
+        cross_force(cfrc + 6 * b, d->cvel + 6 * b, u);
+        for (int s = 0; s < 6; s++) cfrc[6 * b + s] += t[s];
+    }
+    for (int b = nb - 1; b > 0; b--) {
+        int p = m->body_parentid[b];
+        if (p > 0) for (int s = 0; s < 6; s++) cfrc[6 * p + s] += cfrc[6 * b + s];
+    }
+    for (int i = 0; i < m->nv; i++) d->qfrc_bias[i] = dot6(d->cdof + 6 * i, cfrc + 6 * m->dof_bodyid[i]);
+}
+
+/* ------------------------------------------------------------------ P8: actuation + smooth acceleration */
+void orc_fwd_acceleration(const UhcModelDesc* m, OrcData* d) {
+    int nv = m->nv;
+    memset(d->qfrc_actuator, 0, nv * 8);
+    for (int a = 0; a < m->nu; a++) d->qfrc_actuator[m->actuator_dofid[a]] += m->actuator_gear[a] * d->ctrl[a];
+    for (int i = 0; i < nv; i++) {
+        d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_applied[i] + d->qfrc_actuator[i];
+        d->qacc_smooth[i] = d->qfrc_smooth[i];
+    }
+    orc_solve_sparse(m, d->qLD, d->qacc_smooth);
+}
+
+/* ------------------------------------------------------------------ P6 + P9: dual problem and PGS [MJ-ext] */
+void orc_project_constraint(const UhcModelDesc* m, OrcData* d) {
+    int nv = m->nv, n = d->nefc;
+    double* MinvJt = d->work; /* n*nv: row r = M^-1 J_r^T */
+    for (int r = 0; r < n; r++) {
+        memcpy(MinvJt + (size_t)r * nv, d->efc_J + (size_t)r * nv, nv * 8);
+        orc_solve_sparse(m, d->qLD, MinvJt + (size_t)r * nv);
+    }
+    for (int r = 0; r < n; r++)
+        for (int s = 0; s < n; s++) {
+            double a = 0;
+            for (int i = 0; i < nv; i++) a += d->efc_J[(size_t)r * nv + i] * MinvJt[(size_t)s * nv + i];
+            d->efc_AR[(size_t)r * n + s] = a;
+        }
+    for (int r = 0; r < n; r++) d->efc_AR[(size_t)r * n + r] += d->efc_R[r];
+    for (int r = 0; r < n; r++) {
+        double a = 0;
+        for (int i = 0; i < nv; i++) a += d->efc_J[(size_t)r * nv + i] * d->qacc_smooth[i];
+        d->efc_b[r] = a - d->efc_aref[r];
+    }
+}
+static double project_force(const OrcData* d, int r, double f) {
+    switch (d->efc_type[r]) {
+    case ORC_EFC_FRICTION: return fmin(fmax(f, -d->efc_floss[r]), d->efc_floss[r]);
+    default: return f < 0 ? 0 : f; /* limits, frictionless and pyramidal contacts: f >= 0 */
+    }
+}
+void orc_solve_pgs(const UhcModelDesc* m, OrcData* d) {
+    int nv = m->nv, n = d->nefc;
+    const double* AR = d->efc_AR;
+    double* f = d->efc_force;
+    d->solver_iter = 0;
+    if (n == 0) {
+        memset(d->qfrc_constraint, 0, nv * 8);
+        memcpy(d->qacc, d->qacc_smooth, nv * 8);
+        return;
+    }
+    /* warm start: forces implied by qacc_warmstart ([MJ-ext] warmstart + mj_constraintUpdate) */
+    for (int r = 0; r < n; r++) {
+        double jar = -d->efc_aref[r];
+        for (int i = 0; i < nv; i++) jar += d->efc_J[(size_t)r * nv + i] * d->qacc_warmstart[i];
+        if (d->efc_type[r] == ORC_EFC_FRICTION) f[r] = fmin(fmax(-d->efc_D[r] * jar, -d->efc_floss[r]), d->efc_floss[r]);
+        else f[r] = jar < 0 ? -d->efc_D[r] * jar : 0;
+    }
+    double cost = 0;
+    for (int r = 0; r < n; r++) {
+        double a = 0;
+        for (int s = 0; s < n; s++) a += AR[(size_t)r * n + s] * f[s];
+        cost += f[r] * (0.5 * a + d->efc_b[r]);
+    }
+    if (cost > 0) memset(f, 0, n * 8);
+    double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+    for (int it = 0; it < m->iterations; it++) {
+        double improvement = 0;
+        for (int r = 0; r < n; r++) {
+            double res = d->efc_b[r], old = f[r];
+            for (int s = 0; s < n; s++) res += AR[(size_t)r * n + s] * f[s];
+            f[r] = project_force(d, r, old - res / AR[(size_t)r * n + r]);
+            double delta = f[r] - old;
+            double change = 0.5 * delta * delta * AR[(size_t)r * n + r] + delta * res;
+            if (change > 1e-10) { f[r] = old; change = 0; }
+            improvement -= change;
+        }
+        d->solver_iter = it + 1;
+        if (improvement * scale < m->tolerance) break;
+    }
+    for (int i = 0; i < nv; i++) {
+        double a = 0;
+        for (int r = 0; r < n; r++) a += d->efc_J[(size_t)r * nv + i] * f[r];
+        d->qfrc_constraint[i] = a;
+        d->qacc[i] = a;
+    }
+    orc_solve_sparse(m, d->qLD, d->qacc);
+    for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
+}
+
+/* ------------------------------------------------------------------ mj_forward / mj_step [MJ-ext] */
+void orc_forward(const UhcModelDesc* m, OrcData* d) {
+    orc_kinematics(m, d);
+    orc_com_pos(m, d);
+    orc_crb(m, d);
+    orc_factor_m(m, d);
+    orc_collision(m, d);
+    orc_make_constraint(m, d);
+    orc_com_vel(m, d);
+    orc_passive(m, d);
+    orc_rne_bias(m, d);
+    orc_fwd_acceleration(m, d);
+    orc_project_constraint(m, d);
+    orc_solve_pgs(m, d);
+}
+static int bad(double x) { return isnan(x) || x > MAXVAL || x < -MAXVAL; }
+void orc_euler(const UhcModelDesc* m, OrcData* d) { /* P10: mj_Euler (no joint damping -> explicit in qacc) */
+    double h = m->timestep;
+    for (int i = 0; i < m->nv; i++) d->qvel[i] += h * d->qacc[i];
+    for (int j = 0; j < m->njnt; j++) {
+        int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+        switch (m->jnt_type[j]) {
+        case UHC_JNT_FREE:
+            for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k];
+            qa += 3; da += 3;
+                /* fall through */
+        case UHC_JNT_BALL: { /* [MJ-ext] mju_quatIntegrate: q <- q * exp(h w / 2), w in body frame */
+            double w[3] = {d->qvel[da], d->qvel[da + 1], d->qvel[da + 2]}, qr[4];
+            double n = sqrt(dot3(w, w));
+            if (n < MINVAL) { w[0] = 1; w[1] = w[2] = 0; } else { w[0] /= n; w[1] /= n; w[2] /= n; }
+            axis_angle_quat(qr, w, h * n);
+            quat_mul(d->qpos + qa, d->qpos + qa, qr);
+            quat_normalize(d->qpos + qa);
+            break; }
+        default:
+            d->qpos[qa] += h * d->qvel[da];
+        }
+    }
+    memcpy(d->qacc_warmstart, d->qacc, m->nv * 8);
+}
+void orc_step(const UhcModelDesc* m, OrcData* d) {
+    if (d->fail) return;
+    for (int i = 0; i < m->nq; i++) if (bad(d->qpos[i])) d->fail = 1;  /* mj_checkPos */
+    for (int i = 0; i < m->nv; i++) if (bad(d->qvel[i])) d->fail = 1;  /* mj_checkVel */
+    if (d->fail) return;
+    orc_forward(m, d);
+    for (int i = 0; i < m->nv; i++) if (bad(d->qacc[i])) d->fail = 1;  /* mj_checkAcc */
+    if (d->fail) return; /* mujoco-py raises -> HumanoidEnv.step sets fail (humanoid_im.py:1207-1211) */
+    orc_euler(m, d);
+}
+void orc_set_state(const UhcModelDesc* m, OrcData* d, const double* qpos, const double* qvel) {
+    /* sim.reset() + set_state + sim.forward(): mujoco_env.py:95-113 */
+    memcpy(d->qpos, qpos, m->nq * 8);
+    memcpy(d->qvel, qvel, m->nv * 8);
+    memset(d->qacc_warmstart, 0, m->nv * 8);
+    memset(d->qfrc_applied, 0, m->nv * 8);
+    memset(d->ctrl, 0, (m->nu > 0 ? m->nu : 1) * 8);
+    d->fail = 0; d->efc_overflow = 0;
+    orc_forward(m, d);
+}
+
+/* ------------------------------------------------------------------ controller (pinned by the reference) */
+/* get_heading_q: uhc/utils/math_utils.py:134-139 */
+static void heading_q(double hq[4], const double q[4]) {
+    hq[0] = q[0]; hq[1] = 0; hq[2] = 0; hq[3] = q[3];
+    double n = sqrt(hq[0] * hq[0] + hq[3] * hq[3]);
+    hq[0] /= n; hq[3] /= n;
+}
+/* quat_mul_vec (uhc/utils/transformation.py quat_mul_vec): v' = R(q) v */
+static void quat_rot(double r[3], const double q[4], const double v[3]) {
+    double R[9];
+    quat_to_mat(R, q);
+    mat_vec(r, R, v);
+}
+/*
+ * One HumanoidEnv.do_simulation (humanoid_im.py:1145-1190).  action layout: humanoid_im.py:226-255.
+ * M and C used by the PD solve are the ones left in `d` by the previous forward pass
+ * (humanoid_im.py:1019-1022 reads data.qM / data.qfrc_bias before sim.step()).
+ */
+void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
+                       const double* target_base) {
+    int nv = m->nv, nu = m->nu, nq = m->nq;
+    double dt = m->timestep;
+    int vf_dim = c->rfc_mode == 1 ? 6 : 0;
+    double* kp = calloc(nv, 8); double* kd = calloc(nv, 8); double* qerr = calloc(nv, 8);
+    double* rhs = calloc(nv, 8); double* MK = malloc(d->nM * 8); double* torque = calloc(nu, 8);
+    for (int it = 0; it < c->n_substeps && !d->fail; it++) {
+        if (c->action_type == 0) {
+            /* compute_torque: humanoid_im.py:1033-1076 */
+            double skp = 1, skd = 1;
+            if (c->meta_pd == 1) {
+                skp = fmin(fmax(action[nu + vf_dim + it] + 1, 0), 10);
+                skd = fmin(fmax(action[nu + vf_dim + it + c->n_substeps] + 1, 0), 10);
+            }
+            for (int a = 0; a < nu; a++) {
+                double cur = d->qpos[7 + a], base = target_base[a];
+                while (base - cur > M_PI) base -= 2 * M_PI;   /* :1042-1045 */
+                while (base - cur < -M_PI) base += 2 * M_PI;
+                double target = base + action[a];
+                double gkp = c->jkp[a], gkd = c->jkd[a];
+                if (c->meta_pd == 1) { gkp *= skp; gkd *= skd; }
+                else if (c->meta_pd == 2) {
+                    gkp *= fmin(fmax(action[nu + vf_dim + a] + 1, 0), 10);
+                    gkd *= fmin(fmax(action[nu + vf_dim + nu + a] + 1, 0), 10);
+                }
+                kp[6 + a] = gkp; kd[6 + a] = gkd;
+                qerr[6 + a] = cur + d->qvel[6 + a] * dt - target;  /* :1071 */
+            }
+            /* compute_desired_accel: (M + Kd dt) qdd = -C - Kp e_q - Kd e_v   (:1014-1031) */
+            memcpy(MK, d->qM, d->nM * 8);
+            for (int i = 0; i < nv; i++) {
+                MK[m->dof_madr[i]] += kd[i] * dt;
+                rhs[i] = -d->qfrc_bias[i] - kp[i] * qerr[i] - kd[i] * d->qvel[i];
+            }
+            orc_factor_sparse(m, MK);
+            orc_solve_sparse(m, MK, rhs);
+            for (int a = 0; a < nu; a++)
+                torque[a] = -kp[6 + a] * qerr[6 + a] - kd[6 + a] * (d->qvel[6 + a] + rhs[6 + a] * dt); /* :1073-1075 */
+        } else {
+            for (int a = 0; a < nu; a++) torque[a] = action[a] * c->a_scale[a] * 100; /* :1160 */
+        }
+        for (int a = 0; a < nu; a++) d->ctrl[a] = fmin(fmax(torque[a], -c->torque_lim[a]), c->torque_lim[a]); /* :1161 */
+        if (c->rfc_mode == 1) { /* rfc_implicit: :1136-1143 */
+            double vf[6], q[4], binv[4] = {c->base_rot[0], -c->base_rot[1], -c->base_rot[2], -c->base_rot[3]}, hq[4], r[3];
+            double bn = c->base_rot[0] * c->base_rot[0] + c->base_rot[1] * c->base_rot[1] + c->base_rot[2] * c->base_rot[2] + c->base_rot[3] * c->base_rot[3];
+            for (int k = 0; k < 4; k++) binv[k] /= bn; /* quaternion_inverse divides by |q|^2 (transformation.py:1505-1517) */
+            for (int k = 0; k < 6; k++) vf[k] = action[nu + k] * c->rfc_scale;
+            quat_mul(q, d->qpos + 3, binv);
+            heading_q(hq, q);
+            quat_rot(r, hq, vf);
+            memcpy(vf, r, 24);
+            for (int k = 0; k < 6; k++) d->qfrc_applied[k] = fmin(fmax(vf[k], -c->rfc_lim), c->rfc_lim);
+        }
+        (void)nq;
+        orc_step(m, d);
+    }
+    free(kp); free(kd); free(qerr); free(rhs); free(MK); free(torque);
+}
+
+/* ------------------------------------------------------------------ field access for tests */
+int orc_get(const UhcModelDesc* m, const OrcData* d, const char* name, double* out, int max) {
+    struct { const char* n; const double* p; int cnt; } tab[] = {
+        {"qpos", d->qpos, m->nq}, {"qvel", d->qvel, m->nv}, {"qacc", d->qacc, m->nv},
+        {"qacc_smooth", d->qacc_smooth, m->nv}, {"qacc_warmstart", d->qacc_warmstart, m->nv},
+        {"xpos", d->xpos, 3 * m->nbody}, {"xquat", d->xquat, 4 * m->nbody}, {"xipos", d->xipos, 3 * m->nbody},
+        {"xmat", d->xmat, 9 * m->nbody}, {"ximat", d->ximat, 9 * m->nbody},
+        {"subtree_com", d->subtree_com, 3 * m->nbody}, {"cinert", d->cinert, 10 * m->nbody},
+        {"cdof", d->cdof, 6 * m->nv}, {"cvel", d->cvel, 6 * m->nbody},
+        {"qM", d->qM, d->nM}, {"qLD", d->qLD, d->nM}, {"qfrc_bias", d->qfrc_bias, m->nv},
+        {"qfrc_smooth", d->qfrc_smooth, m->nv}, {"qfrc_constraint", d->qfrc_constraint, m->nv},
+        {"qfrc_applied", d->qfrc_applied, m->nv}, {"qfrc_actuator", d->qfrc_actuator, m->nv},
+        {"ctrl", d->ctrl, m->nu},
+        {"con_pos", d->con_pos, 3 * d->ncon}, {"con_dist", d->con_dist, d->ncon}, {"con_frame", d->con_frame, 9 * d->ncon},
+        {"efc_J", d->efc_J, d->nefc * m->nv}, {"efc_R", d->efc_R, d->nefc}, {"efc_aref", d->efc_aref, d->nefc},
+        {"efc_b", d->efc_b, d->nefc}, {"efc_force", d->efc_force, d->nefc}, {"efc_pos", d->efc_pos, d->nefc},
+        {"efc_AR", d->efc_AR, d->nefc * d->nefc}, {"efc_D", d->efc_D, d->nefc},
+    };
+    for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++)
+        if (!strcmp(tab[i].n, name)) {
+            int n = tab[i].cnt < max ? tab[i].cnt : max;
+            memcpy(out, tab[i].p, (size_t)n * 8);
+            return tab[i].cnt;
+        }
+    return -1;
+}
+int orc_get_int(const OrcData* d, const char* name) {
+    if (!strcmp(name, "ncon")) return d->ncon;
+    if (!strcmp(name, "nefc")) return d->nefc;
+    if (!strcmp(name, "fail")) return d->fail;
+    if (!strcmp(name, "solver_iter")) return d->solver_iter;
+    if (!strcmp(name, "efc_overflow")) return d->efc_overflow;
+    if (!strcmp(name, "nM")) return d->nM;
+    return -1;
+}
+void orc_set(const UhcModelDesc* m, OrcData* d, const char* name, const double* in) {
+    if (!strcmp(name, "qpos")) memcpy(d->qpos, in, m->nq * 8);
+    else if (!strcmp(name, "qvel")) memcpy(d->qvel, in, m->nv * 8);
+    else if (!strcmp(name, "ctrl")) memcpy(d->ctrl, in, m->nu * 8);
+    else if (!strcmp(name, "qfrc_applied")) memcpy(d->qfrc_applied, in, m->nv * 8);
+    else if (!strcmp(name, "qacc_warmstart")) memcpy(d->qacc_warmstart, in, m->nv * 8);
+    else if (!strcmp(name, "qM")) memcpy(d->qM, in, d->nM * 8);
+    else if (!strcmp(name, "qfrc_bias")) memcpy(d->qfrc_bias, in, m->nv * 8);
+}
+
+/* ------------------------------------------------------------------ batch driver for the CPU baseline */
+void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData** ds, int n_env,
+                             const double* actions, const double* target_base) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int e = 0; e < n_env; e++)
+        orc_do_simulation(m, c, ds[e], actions + (size_t)e * c->action_dim, target_base + (size_t)e * m->nu);
+}

@@ -1,0 +1,78 @@
+"""ctypes mirror of include/uhc_amd.h (structs only; the loader lives in uhc_amd/_lib.py)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import numpy as np
+
+_I32P = C.POINTER(C.c_int32)
+_F64P = C.POINTER(C.c_double)
+
+_MODEL_INT_SCALARS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nmeshvert", "nmeshadj", "nexclude",
+                      "iterations", "plane_mesh_maxcon", "_pad"]
+_MODEL_PTRS = [
+    ("body_parentid", "i"), ("body_jntadr", "i"), ("body_jntnum", "i"), ("body_dofadr", "i"), ("body_dofnum", "i"),
+    ("body_pos", "d"), ("body_quat", "d"), ("body_ipos", "d"), ("body_iquat", "d"),
+    ("body_mass", "d"), ("body_inertia", "d"), ("body_invweight0", "d"),
+    ("jnt_type", "i"), ("jnt_bodyid", "i"), ("jnt_qposadr", "i"), ("jnt_dofadr", "i"), ("jnt_limited", "i"),
+    ("jnt_pos", "d"), ("jnt_axis", "d"), ("jnt_range", "d"), ("jnt_stiffness", "d"), ("jnt_margin", "d"),
+    ("qpos0", "d"), ("qpos_spring", "d"),
+    ("dof_bodyid", "i"), ("dof_jntid", "i"), ("dof_parentid", "i"), ("dof_madr", "i"),
+    ("dof_armature", "d"), ("dof_damping", "d"), ("dof_frictionloss", "d"), ("dof_invweight0", "d"),
+    ("geom_type", "i"), ("geom_bodyid", "i"), ("geom_contype", "i"), ("geom_conaffinity", "i"), ("geom_condim", "i"),
+    ("geom_vertadr", "i"), ("geom_vertnum", "i"),
+    ("geom_pos", "d"), ("geom_quat", "d"), ("geom_size", "d"), ("geom_friction", "d"),
+    ("geom_margin", "d"), ("geom_gap", "d"), ("geom_solref", "d"), ("geom_solimp", "d"),
+    ("geom_rbound", "d"), ("geom_center", "d"),
+    ("mesh_vert", "d"), ("mesh_adjadr", "i"), ("mesh_adj", "i"), ("exclude_pair", "i"),
+    ("actuator_dofid", "i"), ("actuator_gear", "d"),
+]
+
+
+class UhcModelDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in _MODEL_INT_SCALARS]
+                + [("timestep", C.c_double), ("tolerance", C.c_double), ("meaninertia", C.c_double),
+                   ("gravity", C.c_double * 3)]
+                + [(n, _I32P if t == "i" else _F64P) for n, t in _MODEL_PTRS])
+
+
+class UhcCtrlDesc(C.Structure):
+    _fields_ = [("n_substeps", C.c_int32), ("action_type", C.c_int32), ("meta_pd", C.c_int32),
+                ("rfc_mode", C.c_int32), ("action_dim", C.c_int32), ("_pad", C.c_int32),
+                ("rfc_scale", C.c_double), ("rfc_lim", C.c_double), ("base_rot", C.c_double * 4),
+                ("jkp", _F64P), ("jkd", _F64P), ("torque_lim", _F64P), ("a_scale", _F64P)]
+
+
+def model_desc(model) -> UhcModelDesc:
+    """Build a UhcModelDesc whose pointers reference contiguous copies kept alive on the struct."""
+    d = UhcModelDesc()
+    keep: List[np.ndarray] = []
+    for n in _MODEL_INT_SCALARS:
+        if n != "_pad":
+            setattr(d, n, int(getattr(model, n)))
+    d.timestep, d.tolerance, d.meaninertia = float(model.timestep), float(model.tolerance), float(model.meaninertia)
+    d.gravity = (C.c_double * 3)(*[float(x) for x in model.gravity])
+    for n, t in _MODEL_PTRS:
+        arr = np.ascontiguousarray(getattr(model, n), dtype=np.int32 if t == "i" else np.float64)
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=arr.dtype)
+        keep.append(arr)
+        setattr(d, n, arr.ctypes.data_as(_I32P if t == "i" else _F64P))
+    d._keep = keep
+    return d
+
+
+def ctrl_desc(n_substeps=15, action_type=0, meta_pd=0, rfc_mode=0, action_dim=0, rfc_scale=0.0, rfc_lim=100.0,
+              base_rot=(0.7071, 0.7071, 0.0, 0.0), jkp=None, jkd=None, torque_lim=None, a_scale=None) -> UhcCtrlDesc:
+    c = UhcCtrlDesc()
+    c.n_substeps, c.action_type, c.meta_pd, c.rfc_mode, c.action_dim = n_substeps, action_type, meta_pd, rfc_mode, action_dim
+    c.rfc_scale, c.rfc_lim = float(rfc_scale), float(rfc_lim)
+    c.base_rot = (C.c_double * 4)(*[float(x) for x in base_rot])
+    keep = []
+    for n, v in (("jkp", jkp), ("jkd", jkd), ("torque_lim", torque_lim), ("a_scale", a_scale)):
+        arr = np.ascontiguousarray(v if v is not None else np.zeros(1), dtype=np.float64)
+        keep.append(arr)
+        setattr(c, n, arr.ctypes.data_as(_F64P))
+    c._keep = keep
+    return c

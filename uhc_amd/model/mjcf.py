@@ -1,0 +1,859 @@
+"""MJCF(+binary STL) -> flat rigid-body model arrays (host-side model compiler).
+
+Replaces what the reference obtains from ``mujoco_py.load_model_from_xml``
+(reference: uhc/khrylib/rl/envs/common/mujoco_env.py:18,34 and
+uhc/envs/humanoid_im.py:1441-1454) for the MJCF subset the SMPL humanoid
+models use (reference fixtures: assets/mujoco_models/humanoid_smpl_neutral_mesh.xml,
+assets/mujoco_models/template/humanoid_template.xml, test.xml):
+
+  compiler(angle, coordinate, inertiafromgeom) / default(joint, geom, motor)
+  option(timestep, gravity, iterations, tolerance) / asset(mesh file=)
+  worldbody -> nested body(name,pos,quat) { joint(free|ball|hinge), geom(plane|mesh|box|sphere) }
+  contact/exclude(body1, body2) / actuator/motor(joint, gear)
+
+MuJoCo 2.1.0 itself is not available to this build; every
+convention taken from MuJoCo is tagged [MJ-ext].
+
+The output is a ``Model`` of numpy arrays (float64 / int32) that the C-ABI
+(include/uhc_amd.h: ``UhcModelDesc``) consumes verbatim.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field, fields
+from typing import Dict, List, Optional
+
+import numpy as np
+
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3  # [MJ-ext] mjtJoint order
+GEOM_PLANE, GEOM_SPHERE, GEOM_BOX, GEOM_MESH = 0, 2, 6, 7  # [MJ-ext] mjtGeom values
+
+MINVAL = 1e-15  # [MJ-ext] mjMINVAL
+
+
+# --------------------------------------------------------------------------- #
+# small quaternion helpers (w, x, y, z)
+# --------------------------------------------------------------------------- #
+def quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([
+        aw * bw - ax * bx - ay * by - az * bz,
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+    ])
+
+
+def quat_conj(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def quat_to_mat(q):
+    w, x, y, z = q
+    return np.array([
+        [w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z],
+    ])
+
+
+def mat_to_quat(R):
+    """Rotation matrix -> unit quaternion (w>=0 branch by largest pivot)."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    q /= np.linalg.norm(q)
+    if q[0] < 0:
+        q = -q
+    return q
+
+
+# --------------------------------------------------------------------------- #
+# meshes
+# --------------------------------------------------------------------------- #
+def load_binary_stl(path: str) -> np.ndarray:
+    """Binary STL -> (ntri, 3, 3) float64 triangle soup (file floats are f32)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    (ntri,) = struct.unpack("<I", data[80:84])
+    if len(data) < 84 + 50 * ntri:
+        raise ValueError(f"{path}: truncated binary STL")
+    rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+    arr = np.frombuffer(data, dtype=rec, count=ntri, offset=84)
+    return arr["v"].astype(np.float64)
+
+
+def write_binary_stl(path: str, tris: np.ndarray) -> None:
+    tris = np.asarray(tris, dtype=np.float32)
+    rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+    arr = np.zeros(len(tris), dtype=rec)
+    arr["v"] = tris
+    with open(path, "wb") as f:
+        f.write(b"uhc_amd stl".ljust(80, b" "))
+        f.write(struct.pack("<I", len(tris)))
+        f.write(arr.tobytes())
+
+
+def weld(tris: np.ndarray):
+    """Triangle soup -> (unique verts (nv,3), faces (ntri,3) int) keeping first-seen order."""
+    flat = tris.reshape(-1, 3)
+    seen: Dict[bytes, int] = {}
+    verts: List[np.ndarray] = []
+    idx = np.empty(len(flat), dtype=np.int32)
+    for i, v in enumerate(flat):
+        key = v.tobytes()
+        j = seen.get(key)
+        if j is None:
+            j = len(verts)
+            seen[key] = j
+            verts.append(v)
+        idx[i] = j
+    return np.array(verts), idx.reshape(-1, 3)
+
+
+def polyhedron_mass_properties(verts: np.ndarray, faces: np.ndarray):
+    """Exact volume, centre of mass and unit-density inertia (about the COM) of a
+    closed triangulated surface, by signed tetrahedra against a reference point
+    inside the mesh.  [MJ-ext] MuJoCo 2.1 (user_mesh.cc, mjCMesh::Process) uses the
+    same decomposition around the area-weighted face centroid; the result for a
+    closed surface is unique, so the two agree up to rounding."""
+    ref = verts.mean(axis=0)
+    a = verts[faces[:, 0]] - ref
+    b = verts[faces[:, 1]] - ref
+    c = verts[faces[:, 2]] - ref
+    vol6 = np.einsum("ij,ij->i", a, np.cross(b, c))
+    if vol6.sum() < 0:  # inward-facing winding
+        vol6 = -vol6
+    vol = vol6.sum() / 6.0
+    com_rel = (vol6[:, None] * (a + b + c)).sum(axis=0) / (24.0 * vol)
+    # second moments  integral x_i x_j dV over each tetra (0,a,b,c)
+    # = vol6/120 * ( sum_p p_i p_j + (sum_p p_i)(sum_p p_j) ),  p in {a,b,c}
+    s = a + b + c
+    P = (np.einsum("ni,nj->nij", a, a) + np.einsum("ni,nj->nij", b, b)
+         + np.einsum("ni,nj->nij", c, c) + np.einsum("ni,nj->nij", s, s))
+    C = (vol6[:, None, None] * P).sum(axis=0) / 120.0  # about ref
+    C -= vol * np.outer(com_rel, com_rel)  # about the COM
+    inertia = np.trace(C) * np.eye(3) - C
+    return vol, ref + com_rel, inertia
+
+
+def hull_adjacency(nvert: int, faces: np.ndarray):
+    """CSR vertex adjacency of a triangulated convex hull (edge graph). [MJ-ext] MuJoCo
+    builds the same kind of graph from qhull output for hill-climbing support queries
+    and for the plane-mesh multi-contact rule."""
+    nbr: List[List[int]] = [[] for _ in range(nvert)]
+    for f in faces:
+        for a, b in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0])):
+            if b not in nbr[a]:
+                nbr[a].append(int(b))
+            if a not in nbr[b]:
+                nbr[b].append(int(a))
+    adr = np.zeros(nvert + 1, dtype=np.int32)
+    for i in range(nvert):
+        adr[i + 1] = adr[i] + len(nbr[i])
+    idx = np.array([j for l in nbr for j in l], dtype=np.int32)
+    return adr, idx
+
+
+# --------------------------------------------------------------------------- #
+# the compiled model
+# --------------------------------------------------------------------------- #
+@dataclass
+class Model:
+    # sizes
+    nq: int = 0
+    nv: int = 0
+    nu: int = 0
+    nbody: int = 0
+    njnt: int = 0
+    ngeom: int = 0
+    nmeshvert: int = 0
+    nmeshadj: int = 0
+    nexclude: int = 0
+    # options
+    timestep: float = 0.002
+    gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
+    iterations: int = 100
+    tolerance: float = 1e-8
+    meaninertia: float = 1.0
+    plane_mesh_maxcon: int = 4
+    # names
+    body_names: List[str] = field(default_factory=list)
+    joint_names: List[str] = field(default_factory=list)
+    geom_names: List[str] = field(default_factory=list)
+    actuator_names: List[str] = field(default_factory=list)
+    # bodies
+    body_parentid: np.ndarray = None
+    body_jntadr: np.ndarray = None
+    body_jntnum: np.ndarray = None
+    body_dofadr: np.ndarray = None
+    body_dofnum: np.ndarray = None
+    body_pos: np.ndarray = None
+    body_quat: np.ndarray = None
+    body_ipos: np.ndarray = None
+    body_iquat: np.ndarray = None
+    body_mass: np.ndarray = None
+    body_inertia: np.ndarray = None
+    body_invweight0: np.ndarray = None
+    # joints
+    jnt_type: np.ndarray = None
+    jnt_bodyid: np.ndarray = None
+    jnt_qposadr: np.ndarray = None
+    jnt_dofadr: np.ndarray = None
+    jnt_pos: np.ndarray = None
+    jnt_axis: np.ndarray = None
+    jnt_limited: np.ndarray = None
+    jnt_range: np.ndarray = None
+    jnt_stiffness: np.ndarray = None
+    jnt_margin: np.ndarray = None
+    qpos0: np.ndarray = None
+    qpos_spring: np.ndarray = None
+    # dofs
+    dof_bodyid: np.ndarray = None
+    dof_jntid: np.ndarray = None
+    dof_parentid: np.ndarray = None
+    dof_madr: np.ndarray = None
+    dof_armature: np.ndarray = None
+    dof_damping: np.ndarray = None
+    dof_frictionloss: np.ndarray = None
+    dof_invweight0: np.ndarray = None
+    # geoms
+    geom_type: np.ndarray = None
+    geom_bodyid: np.ndarray = None
+    geom_contype: np.ndarray = None
+    geom_conaffinity: np.ndarray = None
+    geom_condim: np.ndarray = None
+    geom_pos: np.ndarray = None
+    geom_quat: np.ndarray = None
+    geom_size: np.ndarray = None
+    geom_friction: np.ndarray = None
+    geom_margin: np.ndarray = None
+    geom_gap: np.ndarray = None
+    geom_solref: np.ndarray = None
+    geom_solimp: np.ndarray = None
+    geom_rbound: np.ndarray = None
+    geom_center: np.ndarray = None  # bounding-sphere centre in body frame
+    geom_vertadr: np.ndarray = None
+    geom_vertnum: np.ndarray = None
+    mesh_vert: np.ndarray = None  # (nmeshvert,3) in BODY frame
+    mesh_adjadr: np.ndarray = None  # (nmeshvert+1,) CSR, global vertex ids
+    mesh_adj: np.ndarray = None
+    # contact excludes (body pairs)
+    exclude_pair: np.ndarray = None
+    # actuators (motors on joints)
+    actuator_dofid: np.ndarray = None
+    actuator_gear: np.ndarray = None
+    actuator_ctrlrange: np.ndarray = None
+
+    @property
+    def nM(self) -> int:
+        return int(self.dof_madr[-1])
+
+    # ---- convenience ----
+    def body_id(self, name: str) -> int:
+        return self.body_names.index(name)
+
+    @property
+    def _body_name2id(self) -> Dict[str, int]:
+        return {n: i for i, n in enumerate(self.body_names)}
+
+    def to_npz_dict(self) -> Dict[str, np.ndarray]:
+        out = {}
+        for f in fields(self):
+            v = getattr(self, f.name)
+            if isinstance(v, list):
+                out[f.name] = np.array(v, dtype=object if not v else "U")
+            elif isinstance(v, np.ndarray):
+                out[f.name] = v
+            else:
+                out[f.name] = np.array(v)
+        return out
+
+    def save(self, path: str) -> None:
+        np.savez_compressed(path, **self.to_npz_dict())
+
+    @staticmethod
+    def load(path: str) -> "Model":
+        z = np.load(path, allow_pickle=False)
+        m = Model()
+        for f in fields(Model):
+            if f.name not in z.files:
+                continue
+            v = z[f.name]
+            cur = getattr(m, f.name)
+            if isinstance(cur, list):
+                setattr(m, f.name, [str(s) for s in v.tolist()])
+            elif isinstance(cur, (int,)) and not isinstance(cur, bool) and v.shape == ():
+                setattr(m, f.name, int(v))
+            elif isinstance(cur, float) and v.shape == ():
+                setattr(m, f.name, float(v))
+            else:
+                setattr(m, f.name, v)
+        return m
+
+    def copy(self) -> "Model":
+        m = Model()
+        for f in fields(Model):
+            v = getattr(self, f.name)
+            setattr(m, f.name, v.copy() if isinstance(v, np.ndarray) else (list(v) if isinstance(v, list) else v))
+        return m
+
+
+# --------------------------------------------------------------------------- #
+# XML helpers
+# --------------------------------------------------------------------------- #
+def _floats(s: Optional[str], n: Optional[int] = None, default=None):
+    if s is None:
+        return None if default is None else np.array(default, dtype=np.float64)
+    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    if n is not None and len(v) != n:
+        if len(v) < n and default is not None:  # partial spec, fill from default
+            d = np.array(default, dtype=np.float64)
+            d[: len(v)] = v
+            return d
+        raise ValueError(f"expected {n} numbers, got '{s}'")
+    return v
+
+
+def _bool(s: Optional[str], default: bool) -> bool:
+    if s is None:
+        return default
+    return s.strip().lower() == "true"
+
+
+class _Defaults:
+    def __init__(self, root):
+        self.joint: Dict[str, str] = {}
+        self.geom: Dict[str, str] = {}
+        self.motor: Dict[str, str] = {}
+        d = root.find("default")
+        if d is not None:
+            for tag, store in (("joint", self.joint), ("geom", self.geom), ("motor", self.motor)):
+                e = d.find(tag)
+                if e is not None:
+                    store.update(e.attrib)
+
+    def get(self, kind: str, elem, key: str, fallback=None):
+        v = elem.attrib.get(key)
+        if v is not None:
+            return v
+        v = getattr(self, kind).get(key)
+        return fallback if v is None else v
+
+
+# --------------------------------------------------------------------------- #
+# numpy kinematics + CRBA at a given qpos (needed at compile time for the
+# constants MuJoCo's mj_setConst derives at qpos0: dof_invweight0,
+# body_invweight0, stat.meaninertia [MJ-ext])
+# --------------------------------------------------------------------------- #
+def _axis_angle_quat(axis, angle):
+    s = np.sin(angle * 0.5)
+    return np.array([np.cos(angle * 0.5), axis[0] * s, axis[1] * s, axis[2] * s])
+
+
+def kinematics_np(m: Model, qpos: np.ndarray):
+    """World poses of bodies, joint anchors/axes (same recursion as [MJ-ext] mj_kinematics)."""
+    xpos = np.zeros((m.nbody, 3))
+    xquat = np.zeros((m.nbody, 4))
+    xquat[0, 0] = 1.0
+    xanchor = np.zeros((m.njnt, 3))
+    xaxis = np.zeros((m.njnt, 3))
+    for b in range(1, m.nbody):
+        p = m.body_parentid[b]
+        ja, jn = m.body_jntadr[b], m.body_jntnum[b]
+        if jn == 1 and m.jnt_type[ja] == JNT_FREE:
+            qa = m.jnt_qposadr[ja]
+            pos = qpos[qa:qa + 3].copy()
+            quat = qpos[qa + 3:qa + 7] / np.linalg.norm(qpos[qa + 3:qa + 7])
+            xanchor[ja] = pos
+            xaxis[ja] = [0, 0, 1]
+        else:
+            Rp = quat_to_mat(xquat[p])
+            pos = xpos[p] + Rp @ m.body_pos[b]
+            quat = quat_mul(xquat[p], m.body_quat[b])
+            for j in range(ja, ja + jn):
+                R = quat_to_mat(quat)
+                xanchor[j] = pos + R @ m.jnt_pos[j]
+                xaxis[j] = R @ m.jnt_axis[j]
+                qa = m.jnt_qposadr[j]
+                t = m.jnt_type[j]
+                if t == JNT_HINGE:
+                    quat = quat_mul(quat, _axis_angle_quat(m.jnt_axis[j], qpos[qa] - m.qpos0[qa]))
+                elif t == JNT_BALL:
+                    qb = qpos[qa:qa + 4] / np.linalg.norm(qpos[qa:qa + 4])
+                    quat = quat_mul(quat, qb)
+                elif t == JNT_SLIDE:
+                    pos = pos + xaxis[j] * (qpos[qa] - m.qpos0[qa])
+                    continue
+                pos = xanchor[j] - quat_to_mat(quat) @ m.jnt_pos[j]
+        quat = quat / np.linalg.norm(quat)
+        xpos[b], xquat[b] = pos, quat
+    return xpos, xquat, xanchor, xaxis
+
+
+def dof_motion_axes_np(m: Model, xpos, xquat, xanchor, xaxis):
+    """Per dof: (angular axis w, a point on the axis) in world frame; translational dofs have w=0
+    and the direction stored separately."""
+    w = np.zeros((m.nv, 3))
+    lin = np.zeros((m.nv, 3))
+    pt = np.zeros((m.nv, 3))
+    for j in range(m.njnt):
+        d = m.jnt_dofadr[j]
+        b = m.jnt_bodyid[j]
+        t = m.jnt_type[j]
+        if t == JNT_FREE:
+            lin[d:d + 3] = np.eye(3)
+            R = quat_to_mat(xquat[b])
+            for k in range(3):
+                w[d + 3 + k] = R[:, k]
+                pt[d + 3 + k] = xpos[b]
+        elif t == JNT_BALL:
+            R = quat_to_mat(xquat[b])
+            for k in range(3):
+                w[d + k] = R[:, k]
+                pt[d + k] = xanchor[j]
+        elif t == JNT_HINGE:
+            w[d] = xaxis[j]
+            pt[d] = xanchor[j]
+        elif t == JNT_SLIDE:
+            lin[d] = xaxis[j]
+    return w, lin, pt
+
+
+def point_jacobian_np(m: Model, w, lin, pt, body: int, point: np.ndarray):
+    """(jacp 3xnv, jacr 3xnv) of a world point rigidly attached to ``body``."""
+    jacp = np.zeros((3, m.nv))
+    jacr = np.zeros((3, m.nv))
+    b = body
+    while b > 0:
+        for d in range(m.body_dofadr[b], m.body_dofadr[b] + m.body_dofnum[b]):
+            jacr[:, d] = w[d]
+            jacp[:, d] = lin[d] + np.cross(w[d], point - pt[d])
+        b = m.body_parentid[b]
+    return jacp, jacr
+
+
+def mass_matrix_np(m: Model, qpos: np.ndarray) -> np.ndarray:
+    """Dense joint-space inertia (CRBA result + armature) via M = sum_b J_b^T I_b J_b."""
+    xpos, xquat, xanchor, xaxis = kinematics_np(m, qpos)
+    w, lin, pt = dof_motion_axes_np(m, xpos, xquat, xanchor, xaxis)
+    M = np.zeros((m.nv, m.nv))
+    for b in range(1, m.nbody):
+        R = quat_to_mat(xquat[b])
+        com = xpos[b] + R @ m.body_ipos[b]
+        Ri = R @ quat_to_mat(m.body_iquat[b])
+        I = Ri @ np.diag(m.body_inertia[b]) @ Ri.T
+        jp, jr = point_jacobian_np(m, w, lin, pt, b, com)
+        M += m.body_mass[b] * jp.T @ jp + jr.T @ I @ jr
+    M += np.diag(m.dof_armature)
+    return M
+
+
+def set_const(m: Model) -> None:
+    """[MJ-ext] mj_setConst restatement: dof_invweight0, body_invweight0, meaninertia at qpos0."""
+    M = mass_matrix_np(m, m.qpos0)
+    Minv = np.linalg.inv(M)
+    m.meaninertia = float(np.trace(M) / max(1, m.nv))
+    m.dof_invweight0 = np.zeros(m.nv)
+    for j in range(m.njnt):
+        d = m.jnt_dofadr[j]
+        t = m.jnt_type[j]
+        if t == JNT_FREE:
+            m.dof_invweight0[d:d + 3] = np.mean(np.diag(Minv)[d:d + 3])
+            m.dof_invweight0[d + 3:d + 6] = np.mean(np.diag(Minv)[d + 3:d + 6])
+        elif t == JNT_BALL:
+            m.dof_invweight0[d:d + 3] = np.mean(np.diag(Minv)[d:d + 3])
+        else:
+            m.dof_invweight0[d] = Minv[d, d]
+    xpos, xquat, xanchor, xaxis = kinematics_np(m, m.qpos0)
+    w, lin, pt = dof_motion_axes_np(m, xpos, xquat, xanchor, xaxis)
+    m.body_invweight0 = np.zeros((m.nbody, 2))
+    for b in range(1, m.nbody):
+        com = xpos[b] + quat_to_mat(xquat[b]) @ m.body_ipos[b]
+        jp, jr = point_jacobian_np(m, w, lin, pt, b, com)
+        m.body_invweight0[b, 0] = max(MINVAL, np.trace(jp @ Minv @ jp.T) / 3.0)
+        m.body_invweight0[b, 1] = max(MINVAL, np.trace(jr @ Minv @ jr.T) / 3.0)
+
+
+# --------------------------------------------------------------------------- #
+# compiler
+# --------------------------------------------------------------------------- #
+DEFAULT_SOLREF = (0.02, 1.0)  # [MJ-ext]
+DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)  # [MJ-ext]
+DEFAULT_FRICTION = (1.0, 0.005, 0.0001)  # [MJ-ext]
+DEFAULT_DENSITY = 1000.0  # [MJ-ext]
+
+
+def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.ndarray]] = None) -> Model:
+    """Compile an MJCF string.  ``meshes`` optionally maps mesh name -> (ntri,3,3) triangles
+    (bypasses file loading; used for per-env scaled bodies and tests)."""
+    root = ET.fromstring(xml)
+    comp = root.find("compiler")
+    comp = comp.attrib if comp is not None else {}
+    degree = comp.get("angle", "degree") == "degree"
+    global_coord = comp.get("coordinate", "local") == "global"
+    dfl = _Defaults(root)
+
+    m = Model()
+    opt = root.find("option")
+    if opt is not None:
+        m.timestep = float(opt.attrib.get("timestep", m.timestep))
+        if "gravity" in opt.attrib:
+            m.gravity = _floats(opt.attrib["gravity"], 3)
+        m.iterations = int(opt.attrib.get("iterations", m.iterations))
+        m.tolerance = float(opt.attrib.get("tolerance", m.tolerance))
+
+    # ---- mesh assets ----
+    mesh_tris: Dict[str, np.ndarray] = dict(meshes or {})
+    asset = root.find("asset")
+    if asset is not None:
+        for me in asset.findall("mesh"):
+            f = me.attrib.get("file")
+            name = me.attrib.get("name") or os.path.splitext(os.path.basename(f))[0]
+            if name in mesh_tris:
+                continue
+            tri = load_binary_stl(os.path.join(asset_dir, f))
+            if "scale" in me.attrib:
+                tri = tri * _floats(me.attrib["scale"], 3)
+            mesh_tris[name] = tri
+
+    # ---- walk the body tree (MJCF order == depth-first == MuJoCo body ids) ----
+    bodies = [dict(name="world", parent=0, gpos=np.zeros(3), gquat=np.array([1.0, 0, 0, 0]), joints=[], geoms=[])]
+
+    def parse_geom(e, bid):
+        g = dict(body=bid, name=e.attrib.get("name", ""))
+        t = dfl.get("geom", e, "type", "sphere")
+        g["type"] = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "box": GEOM_BOX, "mesh": GEOM_MESH}[t]
+        g["mesh"] = e.attrib.get("mesh")
+        g["pos"] = _floats(e.attrib.get("pos"), 3, [0, 0, 0])
+        g["quat"] = _floats(e.attrib.get("quat"), 4, [1, 0, 0, 0])
+        g["size"] = _floats(dfl.get("geom", e, "size"), 3, [0, 0, 0])
+        g["contype"] = int(dfl.get("geom", e, "contype", 1))
+        g["conaffinity"] = int(dfl.get("geom", e, "conaffinity", 1))
+        g["condim"] = int(dfl.get("geom", e, "condim", 3))
+        g["friction"] = _floats(dfl.get("geom", e, "friction"), 3, DEFAULT_FRICTION)
+        g["margin"] = float(dfl.get("geom", e, "margin", 0.0))
+        g["gap"] = float(dfl.get("geom", e, "gap", 0.0))
+        g["solref"] = _floats(dfl.get("geom", e, "solref"), 2, DEFAULT_SOLREF)
+        g["solimp"] = _floats(dfl.get("geom", e, "solimp"), 5, DEFAULT_SOLIMP)
+        g["density"] = float(dfl.get("geom", e, "density", DEFAULT_DENSITY))
+        return g
+
+    def parse_joint(e, bid):
+        j = dict(body=bid, name=e.attrib.get("name", ""))
+        t = dfl.get("joint", e, "type", "hinge")
+        j["type"] = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}[t]
+        j["pos"] = _floats(e.attrib.get("pos"), 3, [0, 0, 0])
+        j["axis"] = _floats(dfl.get("joint", e, "axis"), 3, [0, 0, 1])
+        j["limited"] = _bool(dfl.get("joint", e, "limited"), False)
+        rng = _floats(dfl.get("joint", e, "range"), 2, [0, 0])
+        if degree and j["type"] in (JNT_HINGE, JNT_BALL):
+            rng = np.deg2rad(rng)
+        j["range"] = rng
+        j["armature"] = float(dfl.get("joint", e, "armature", 0.0))
+        j["damping"] = float(dfl.get("joint", e, "damping", 0.0))
+        j["stiffness"] = float(dfl.get("joint", e, "stiffness", 0.0))
+        j["frictionloss"] = float(dfl.get("joint", e, "frictionloss", 0.0))
+        j["margin"] = float(dfl.get("joint", e, "margin", 0.0))
+        if j["type"] == JNT_FREE:
+            j["limited"] = False
+        return j
+
+    def walk(elem, parent_id):
+        for e in elem:
+            if e.tag == "geom":
+                bodies[parent_id]["geoms"].append(parse_geom(e, parent_id))
+            elif e.tag == "joint" or e.tag == "freejoint":
+                if e.tag == "freejoint":
+                    e.attrib["type"] = "free"
+                bodies[parent_id]["joints"].append(parse_joint(e, parent_id))
+            elif e.tag == "body":
+                bid = len(bodies)
+                b = dict(name=e.attrib.get("name", f"body{bid}"), parent=parent_id,
+                         gpos=_floats(e.attrib.get("pos"), 3, [0, 0, 0]),
+                         gquat=_floats(e.attrib.get("quat"), 4, [1, 0, 0, 0]), joints=[], geoms=[])
+                b["gquat"] = b["gquat"] / np.linalg.norm(b["gquat"])
+                bodies.append(b)
+                walk(e, bid)
+
+    walk(root.find("worldbody"), 0)
+
+    # ---- global -> local frames ([MJ-ext] compiler coordinate="global") ----
+    # after this every body has: pos/quat relative to parent, joints/geoms relative to body
+    if global_coord:
+        for b in bodies:
+            b["wpos"], b["wquat"] = b["gpos"], b["gquat"]
+    else:
+        for i, b in enumerate(bodies):
+            if i == 0:
+                b["wpos"], b["wquat"] = b["gpos"], b["gquat"]
+            else:
+                p = bodies[b["parent"]]
+                b["wpos"] = p["wpos"] + quat_to_mat(p["wquat"]) @ b["gpos"]
+                b["wquat"] = quat_mul(p["wquat"], b["gquat"])
+    for i, b in enumerate(bodies):
+        if i == 0:
+            b["pos"], b["quat"] = np.zeros(3), np.array([1.0, 0, 0, 0])
+            continue
+        p = bodies[b["parent"]]
+        Rp = quat_to_mat(p["wquat"])
+        b["pos"] = Rp.T @ (b["wpos"] - p["wpos"])
+        b["quat"] = quat_mul(quat_conj(p["wquat"]), b["wquat"])
+        Rb = quat_to_mat(b["wquat"])
+        for j in b["joints"]:
+            if global_coord:
+                j["pos"] = Rb.T @ (j["pos"] - b["wpos"])
+                j["axis"] = Rb.T @ j["axis"]
+            n = np.linalg.norm(j["axis"])
+            j["axis"] = j["axis"] / n if n > 0 else np.array([0, 0, 1.0])
+            if j["type"] == JNT_FREE:
+                j["pos"] = np.zeros(3)
+    for i, b in enumerate(bodies):
+        Rb = quat_to_mat(b["wquat"])
+        for g in b["geoms"]:
+            if global_coord and i > 0:
+                g["pos"] = Rb.T @ (g["pos"] - b["wpos"])
+                g["quat"] = quat_mul(quat_conj(b["wquat"]), g["quat"])
+
+    # ---- sizes ----
+    m.nbody = len(bodies)
+    m.body_names = [b["name"] for b in bodies]
+    joints = [j for b in bodies for j in b["joints"]]
+    geoms = [g for b in bodies for g in b["geoms"]]
+    m.njnt, m.ngeom = len(joints), len(geoms)
+    m.joint_names = [j["name"] for j in joints]
+    m.geom_names = [g["name"] for g in geoms]
+
+    qn = {JNT_FREE: 7, JNT_BALL: 4, JNT_SLIDE: 1, JNT_HINGE: 1}
+    vn = {JNT_FREE: 6, JNT_BALL: 3, JNT_SLIDE: 1, JNT_HINGE: 1}
+    m.nq = sum(qn[j["type"]] for j in joints)
+    m.nv = sum(vn[j["type"]] for j in joints)
+
+    m.body_parentid = np.array([b["parent"] for b in bodies], dtype=np.int32)
+    m.body_pos = np.array([b["pos"] for b in bodies])
+    m.body_quat = np.array([b["quat"] for b in bodies])
+    m.body_jntadr = np.zeros(m.nbody, dtype=np.int32)
+    m.body_jntnum = np.zeros(m.nbody, dtype=np.int32)
+    m.body_dofadr = np.zeros(m.nbody, dtype=np.int32)
+    m.body_dofnum = np.zeros(m.nbody, dtype=np.int32)
+
+    m.jnt_type = np.zeros(m.njnt, dtype=np.int32)
+    m.jnt_bodyid = np.zeros(m.njnt, dtype=np.int32)
+    m.jnt_qposadr = np.zeros(m.njnt, dtype=np.int32)
+    m.jnt_dofadr = np.zeros(m.njnt, dtype=np.int32)
+    m.jnt_pos = np.zeros((m.njnt, 3))
+    m.jnt_axis = np.zeros((m.njnt, 3))
+    m.jnt_limited = np.zeros(m.njnt, dtype=np.int32)
+    m.jnt_range = np.zeros((m.njnt, 2))
+    m.jnt_stiffness = np.zeros(m.njnt)
+    m.jnt_margin = np.zeros(m.njnt)
+    m.qpos0 = np.zeros(m.nq)
+    m.dof_bodyid = np.zeros(m.nv, dtype=np.int32)
+    m.dof_jntid = np.zeros(m.nv, dtype=np.int32)
+    m.dof_parentid = np.full(m.nv, -1, dtype=np.int32)
+    m.dof_armature = np.zeros(m.nv)
+    m.dof_damping = np.zeros(m.nv)
+    m.dof_frictionloss = np.zeros(m.nv)
+
+    jid = qa = da = 0
+    last_dof_of_body = np.full(m.nbody, -1, dtype=np.int32)
+    for bid, b in enumerate(bodies):
+        m.body_jntadr[bid] = jid if b["joints"] else -1
+        m.body_jntnum[bid] = len(b["joints"])
+        m.body_dofadr[bid] = da if b["joints"] else -1
+        # first dof's parent = last dof of nearest ancestor that has dofs
+        anc = b["parent"]
+        prev = -1
+        while bid > 0:
+            if last_dof_of_body[anc] >= 0:
+                prev = int(last_dof_of_body[anc])
+                break
+            if anc == 0:
+                break
+            anc = bodies[anc]["parent"]
+        for j in b["joints"]:
+            t = j["type"]
+            m.jnt_type[jid] = t
+            m.jnt_bodyid[jid] = bid
+            m.jnt_qposadr[jid] = qa
+            m.jnt_dofadr[jid] = da
+            m.jnt_pos[jid] = j["pos"]
+            m.jnt_axis[jid] = j["axis"]
+            m.jnt_limited[jid] = int(j["limited"])
+            m.jnt_range[jid] = j["range"]
+            m.jnt_stiffness[jid] = j["stiffness"]
+            m.jnt_margin[jid] = j["margin"]
+            if t == JNT_FREE:
+                m.qpos0[qa:qa + 3] = b["pos"]
+                m.qpos0[qa + 3:qa + 7] = b["quat"]
+            elif t == JNT_BALL:
+                m.qpos0[qa] = 1.0
+            for k in range(vn[t]):
+                m.dof_bodyid[da] = bid
+                m.dof_jntid[da] = jid
+                m.dof_parentid[da] = prev
+                m.dof_armature[da] = j["armature"]
+                m.dof_damping[da] = j["damping"]
+                m.dof_frictionloss[da] = j["frictionloss"]
+                prev = da
+                da += 1
+            qa += qn[t]
+            jid += 1
+        m.body_dofnum[bid] = da - m.body_dofadr[bid] if b["joints"] else 0
+        if b["joints"]:
+            last_dof_of_body[bid] = da - 1
+    m.qpos_spring = m.qpos0.copy()
+    # sparse-M row addresses: row i holds (i, parent(i), parent(parent(i)), ...) [MJ-ext qM layout]
+    m.dof_madr = np.zeros(m.nv + 1, dtype=np.int32)
+    for i in range(m.nv):
+        depth, k = 0, i
+        while k >= 0:
+            depth += 1
+            k = m.dof_parentid[k]
+        m.dof_madr[i + 1] = m.dof_madr[i] + depth
+
+    # ---- geoms + meshes; body inertial from geoms (inertiafromgeom) ----
+    G = m.ngeom
+    m.geom_type = np.array([g["type"] for g in geoms], dtype=np.int32)
+    m.geom_bodyid = np.array([g["body"] for g in geoms], dtype=np.int32)
+    m.geom_contype = np.array([g["contype"] for g in geoms], dtype=np.int32)
+    m.geom_conaffinity = np.array([g["conaffinity"] for g in geoms], dtype=np.int32)
+    m.geom_condim = np.array([g["condim"] for g in geoms], dtype=np.int32)
+    m.geom_pos = np.array([g["pos"] for g in geoms]).reshape(G, 3)
+    m.geom_quat = np.array([g["quat"] for g in geoms]).reshape(G, 4)
+    m.geom_size = np.array([g["size"] for g in geoms]).reshape(G, 3)
+    m.geom_friction = np.array([g["friction"] for g in geoms]).reshape(G, 3)
+    m.geom_margin = np.array([g["margin"] for g in geoms])
+    m.geom_gap = np.array([g["gap"] for g in geoms])
+    m.geom_solref = np.array([g["solref"] for g in geoms]).reshape(G, 2)
+    m.geom_solimp = np.array([g["solimp"] for g in geoms]).reshape(G, 5)
+    m.geom_rbound = np.zeros(G)
+    m.geom_center = np.zeros((G, 3))
+    m.geom_vertadr = np.full(G, -1, dtype=np.int32)
+    m.geom_vertnum = np.zeros(G, dtype=np.int32)
+
+    m.body_mass = np.zeros(m.nbody)
+    m.body_ipos = np.zeros((m.nbody, 3))
+    m.body_iquat = np.tile(np.array([1.0, 0, 0, 0]), (m.nbody, 1))
+    m.body_inertia = np.zeros((m.nbody, 3))
+    acc = [dict(mass=0.0, mc=np.zeros(3), parts=[]) for _ in bodies]
+    all_verts: List[np.ndarray] = []
+    adj_adr: List[np.ndarray] = []
+    adj_idx: List[np.ndarray] = []
+    vbase = abase = 0
+    for gi, g in enumerate(geoms):
+        bid = g["body"]
+        Rg = quat_to_mat(g["quat"])
+        if g["type"] == GEOM_MESH:
+            verts, faces = weld(mesh_tris[g["mesh"]])
+            verts = verts @ Rg.T + g["pos"]  # -> body frame
+            vol, com, I = polyhedron_mass_properties(verts, faces)
+            mass = g["density"] * vol
+            I = g["density"] * I
+            adr, idx = hull_adjacency(len(verts), faces)
+            m.geom_vertadr[gi] = vbase
+            m.geom_vertnum[gi] = len(verts)
+            all_verts.append(verts)
+            adj_adr.append(adr[:-1] + abase)
+            adj_idx.append(idx + vbase)
+            vbase += len(verts)
+            abase += len(idx)
+            m.geom_center[gi] = com
+            m.geom_rbound[gi] = np.linalg.norm(verts - com, axis=1).max()
+            # geom frame == body frame for meshes in this build (vertices already moved)
+            m.geom_pos[gi] = 0.0
+            m.geom_quat[gi] = [1, 0, 0, 0]
+        elif g["type"] == GEOM_BOX:
+            sx, sy, sz = g["size"]
+            mass = g["density"] * 8 * sx * sy * sz
+            Il = mass / 3.0 * np.diag([sy * sy + sz * sz, sx * sx + sz * sz, sx * sx + sy * sy])
+            I, com = Rg @ Il @ Rg.T, g["pos"]
+            m.geom_center[gi] = com
+            m.geom_rbound[gi] = np.linalg.norm(g["size"])
+        elif g["type"] == GEOM_SPHERE:
+            r = g["size"][0]
+            mass = g["density"] * 4.0 / 3.0 * np.pi * r ** 3
+            I, com = 0.4 * mass * r * r * np.eye(3), g["pos"]
+            m.geom_center[gi] = com
+            m.geom_rbound[gi] = r
+        else:  # plane: massless, unbounded
+            continue
+        if bid > 0:
+            acc[bid]["mass"] += mass
+            acc[bid]["mc"] += mass * com
+            acc[bid]["parts"].append((mass, com, I))
+    m.nmeshvert = vbase
+    m.mesh_vert = np.concatenate(all_verts) if all_verts else np.zeros((0, 3))
+    m.mesh_adjadr = np.concatenate(adj_adr + [np.array([abase], dtype=np.int32)]).astype(np.int32) if all_verts else np.zeros(1, dtype=np.int32)
+    m.mesh_adj = np.concatenate(adj_idx).astype(np.int32) if all_verts else np.zeros(0, dtype=np.int32)
+    m.nmeshadj = abase
+
+    for bid in range(1, m.nbody):
+        a = acc[bid]
+        if a["mass"] <= 0:
+            raise ValueError(f"body '{bodies[bid]['name']}' has no mass (inertiafromgeom needs a geom)")
+        com = a["mc"] / a["mass"]
+        I = np.zeros((3, 3))
+        for mass, c, Ic in a["parts"]:
+            d = c - com
+            I += Ic + mass * (d @ d * np.eye(3) - np.outer(d, d))
+        evals, evecs = np.linalg.eigh(I)
+        order = np.argsort(-evals)  # [MJ-ext] principal moments in decreasing order
+        evals, evecs = evals[order], evecs[:, order]
+        if np.linalg.det(evecs) < 0:
+            evecs[:, 2] = -evecs[:, 2]
+        m.body_mass[bid] = a["mass"]
+        m.body_ipos[bid] = com
+        m.body_iquat[bid] = mat_to_quat(evecs)
+        m.body_inertia[bid] = evals
+
+    # ---- contact excludes ----
+    ex = []
+    c = root.find("contact")
+    if c is not None:
+        for e in c.findall("exclude"):
+            ex.append([m.body_names.index(e.attrib["body1"]), m.body_names.index(e.attrib["body2"])])
+    m.exclude_pair = np.array(ex, dtype=np.int32).reshape(-1, 2)
+    m.nexclude = len(ex)
+
+    # ---- actuators: motors on joints ----
+    dofid, gear, names, crange = [], [], [], []
+    act = root.find("actuator")
+    if act is not None:
+        for e in act:
+            if e.tag not in ("motor", "general"):
+                continue
+            jn = e.attrib["joint"]
+            j = m.joint_names.index(jn)
+            if m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
+                raise ValueError("only scalar-joint motors are supported")
+            dofid.append(m.jnt_dofadr[j])
+            gear.append(float(_floats(dfl.get("motor", e, "gear", "1"))[0]))
+            names.append(e.attrib.get("name", jn))
+            crange.append(_floats(dfl.get("motor", e, "ctrlrange"), 2, [0, 0]))
+    m.nu = len(dofid)
+    m.actuator_dofid = np.array(dofid, dtype=np.int32)
+    m.actuator_gear = np.array(gear, dtype=np.float64)
+    m.actuator_names = names
+    m.actuator_ctrlrange = np.array(crange, dtype=np.float64).reshape(-1, 2)
+
+    set_const(m)
+    return m
+
+
+def compile_mjcf_file(path: str) -> Model:
+    with open(path) as f:
+        return compile_mjcf(f.read(), os.path.dirname(os.path.abspath(path)))
