@@ -98,7 +98,7 @@ enum UhcField {
     UHC_F_XIPOS = 4,     /* [n_env][nbody][3] data.xipos */
     UHC_F_QM = 5,        /* [n_env][nM]   data.qM (tree-sparse) */
     UHC_F_QFRC_BIAS = 6, /* [n_env][nv]   data.qfrc_bias */
-    UHC_F_QACC = 7,      /* [n_env][nv]   data.qacc (== qacc_warmstart of the next step) */
+    UHC_F_QACC = 7,      /* [n_env][nv]   data.qacc of the last forward pass (the warm start is kept separately) */
     UHC_F_CTRL = 8,      /* [n_env][nu]   data.ctrl of the last substep */
     UHC_F_NCON = 9,      /* int32 [n_env] data.ncon of the last forward pass */
     UHC_F_NEFC = 10,     /* int32 [n_env] data.nefc */
@@ -126,7 +126,8 @@ int32_t uhc_model_nM(const UhcModel* m);
 int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_models, const int32_t* h_env_model,
                          int32_t n_env, int32_t device_id, const UhcCtrlDesc* ctrl, UhcBatch** out);
 void uhc_batch_free(UhcBatch* b);
-/* bind to an existing hipStream_t (e.g. torch's current stream); NULL => the batch's own stream */
+/* bind to an existing hipStream_t (e.g. torch's current stream); NULL = the device's null stream.
+ * A new batch starts on a private non-blocking stream. */
 int32_t uhc_batch_set_stream(UhcBatch* b, void* hip_stream);
 int32_t uhc_batch_sync(UhcBatch* b);
 /* change rfc_scale between iterations (rfc_decay: uhc/agents/agent_copycat.py:283-290) */

@@ -518,7 +518,7 @@ void orc_make_constraint(const UhcModelDesc* m, OrcData* d) {
         } else {
             /* condim 3 only (torsional/rolling pyramid edges are not produced by these models) */
             for (int e = 0; e < 4; e++) {
-                double mu = d->con_friction[3 * c + e / 2], sgn = (e & 1) ? -1.0 : 1.0;
+                double mu = d->con_friction[3 * c] /* both tangents slide with friction[0] */, sgn = (e & 1) ? -1.0 : 1.0;
                 int r = add_row(m, d, ORC_EFC_CONTACT_PYR, d->con_dist[c], d->con_margin[c], tran + mu * mu * tran,
                                 d->con_solref + 2 * c, d->con_solimp + 5 * c, 0);
                 if (r < 0) break;

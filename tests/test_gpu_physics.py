@@ -1,0 +1,115 @@
+"""GPU parity: the HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(model, ctrl, n):
+    from uhc_amd.sim import SimBatch
+    return SimBatch(model, ctrl, n)
+
+
+def _states(standing, model, n, seed, noise=0.1, vel=0.5, lift=0.0):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(standing["qpos"], (n, 1))
+    qpos[:, 7:] += rng.normal(scale=noise, size=(n, model.nu))
+    qpos[:, 2] += lift
+    qvel = rng.normal(scale=vel, size=(n, model.nv))
+    return qpos, qvel
+
+
+def test_forward_fields_match_oracle(model, ctrl, standing):
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    n = 16
+    qpos, qvel = _states(standing, model, n, 1)
+    b = _sim(model, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    b.sync()
+    g = {k: b.field(f).cpu().numpy() for k, f in dict(xpos=S.F_XPOS, xquat=S.F_XQUAT, xipos=S.F_XIPOS, qM=S.F_QM,
+                                                     bias=S.F_QFRC_BIAS, qacc=S.F_QACC, ncon=S.F_NCON, nefc=S.F_NEFC).items()}
+    for e in range(n):
+        o = OracleSim(model, ctrl)
+        o.set_state(qpos[e], qvel[e])
+        assert g["ncon"][e] == o.geti("ncon") and g["nefc"][e] == o.geti("nefc")
+        np.testing.assert_allclose(g["xpos"][e], o.get("xpos"), atol=1e-13)
+        np.testing.assert_allclose(g["xquat"][e], o.get("xquat"), atol=1e-13)
+        np.testing.assert_allclose(g["xipos"][e], o.get("xipos"), atol=1e-13)
+        np.testing.assert_allclose(g["qM"][e], o.get("qM"), atol=1e-11)
+        np.testing.assert_allclose(g["bias"][e], o.get("qfrc_bias"), atol=1e-9)
+        # constrained acceleration: PGS is run to the same tolerance on both sides
+        np.testing.assert_allclose(g["qacc"][e], o.get("qacc"), atol=1e-5, rtol=1e-6)
+
+
+def test_free_flight_trajectory(model, ctrl, standing):
+    """No contacts (lifted 100 m, falls ~14 m): smooth dynamics + PD + RFC, 50 env-steps, tight tolerance."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    n = 4
+    qpos, qvel = _states(standing, model, n, 2, lift=100.0)
+    rng = np.random.default_rng(3)
+    act = rng.normal(scale=0.2, size=(n, ctrl.action_dim))
+    b = _sim(model, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    a, tb = torch.from_numpy(act).cuda(), torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(model, ctrl) for _ in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    for t in range(50):
+        b.simulate(a, tb)
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:])
+    b.sync()
+    gq, gv = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy()
+    for e in range(n):
+        np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-8)
+        np.testing.assert_allclose(gv[e], os_[e].get("qvel"), atol=1e-7)
+
+
+def test_contact_trajectory_200_steps(model, ctrl, standing):
+    """north_star bar: per-step qpos/qvel within 1e-4 of the CPU path over 200 env-steps, same seed."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    n = 4
+    qpos, qvel = _states(standing, model, n, 4, noise=0.02, vel=0.05)
+    rng = np.random.default_rng(5)
+    b = _sim(model, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(model, ctrl) for _ in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    worst_q = worst_v = 0.0
+    for t in range(200):
+        act = rng.normal(scale=0.05, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq, gv = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy()
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:])
+            worst_q = max(worst_q, np.abs(gq[e] - os_[e].get("qpos")).max())
+            worst_v = max(worst_v, np.abs(gv[e] - os_[e].get("qvel")).max())
+    print(f"200-step parity: max|dqpos|={worst_q:.3e} max|dqvel|={worst_v:.3e}")
+    assert worst_q < 1e-4 and worst_v < 1e-4
+
+
+def test_inactive_envs_untouched(model, ctrl, standing):
+    import torch
+    from uhc_amd import sim as S
+    n = 8
+    qpos, qvel = _states(standing, model, n, 6)
+    b = _sim(model, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    act = torch.zeros(n, ctrl.action_dim, dtype=torch.float64, device="cuda")
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    active = torch.tensor([1, 0] * 4, dtype=torch.int32, device="cuda")
+    before = b.field(S.F_QPOS).clone()
+    b.simulate(act, tb, active)
+    b.sync()
+    after = b.field(S.F_QPOS)
+    assert torch.equal(before[1::2], after[1::2])
+    assert not torch.equal(before[0::2], after[0::2])

@@ -1,0 +1,61 @@
+"""Loader for libuhc_amd.so (the HIP product library).  There is NO fallback: if the library is
+missing or does not load, importing the compute path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._capi import UhcCtrlDesc, UhcModelDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libuhc_amd.so")
+_lib = None
+
+# every symbol include/uhc_amd.h declares
+SYMBOLS = [
+    "uhc_last_error", "uhc_abi_version", "uhc_model_create", "uhc_model_free", "uhc_model_nM",
+    "uhc_batch_create", "uhc_batch_free", "uhc_batch_set_stream", "uhc_batch_sync", "uhc_batch_set_rfc_scale",
+    "uhc_batch_field", "uhc_batch_set_state", "uhc_batch_simulate", "uhc_batch_forward",
+]
+
+
+class UhcError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own HIP runtime; it must be the one already resident when this library
+    # resolves libamdhip64 (two runtimes in one process cannot both see the device)
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise UhcError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950).  uhc_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    L.uhc_last_error.restype = C.c_char_p
+    L.uhc_abi_version.restype = C.c_int32
+    L.uhc_model_create.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(P)]
+    L.uhc_model_free.argtypes = [P]
+    L.uhc_model_free.restype = None
+    L.uhc_model_nM.argtypes = [P]
+    L.uhc_batch_create.argtypes = [C.POINTER(P), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                   C.POINTER(UhcCtrlDesc), C.POINTER(P)]
+    L.uhc_batch_free.argtypes = [P]
+    L.uhc_batch_free.restype = None
+    L.uhc_batch_set_stream.argtypes = [P, P]
+    L.uhc_batch_sync.argtypes = [P]
+    L.uhc_batch_set_rfc_scale.argtypes = [P, C.c_double]
+    L.uhc_batch_field.argtypes = [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int64)]
+    L.uhc_batch_set_state.argtypes = [P, P, C.c_int32, P, P]
+    L.uhc_batch_simulate.argtypes = [P, P, P, P]
+    L.uhc_batch_forward.argtypes = [P]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise UhcError(lib().uhc_last_error().decode())

@@ -1,0 +1,419 @@
+// uhc_capi.cpp -- host side of libuhc_amd.so: the C-ABI declared in include/uhc_amd.h.
+// Owns model copies, derived topology tables, device buffers and kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uhc_amd.h"
+#include "uhc_device.h"
+
+extern "C" hipError_t uhc_launch_step(int mode, const KernelArgs* A, const double* d_action, const double* d_tbase,
+                                      const int* d_active, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes);
+extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
+                                           const double* qpos, const double* qvel, int* mask, hipStream_t stream);
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIP_OK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e__));      \
+    } while (0)
+
+extern "C" const char* uhc_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t uhc_abi_version(void) { return UHC_ABI_VERSION; }
+
+// ------------------------------------------------------------------ model (host copy)
+struct UhcModel {
+    UhcModelDesc d;  // scalars; pointers re-targeted at the vectors below
+    std::vector<int32_t> body_parentid, body_jntadr, body_jntnum, body_dofadr, body_dofnum;
+    std::vector<double> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0;
+    std::vector<int32_t> jnt_type, jnt_bodyid, jnt_qposadr, jnt_dofadr, jnt_limited;
+    std::vector<double> jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_margin, qpos0, qpos_spring;
+    std::vector<int32_t> dof_bodyid, dof_jntid, dof_parentid, dof_madr;
+    std::vector<double> dof_armature, dof_damping, dof_frictionloss, dof_invweight0;
+    std::vector<int32_t> geom_type, geom_bodyid, geom_contype, geom_conaffinity, geom_condim, geom_vertadr, geom_vertnum;
+    std::vector<double> geom_pos, geom_quat, geom_size, geom_friction, geom_margin, geom_gap, geom_solref, geom_solimp,
+        geom_rbound, geom_center, mesh_vert;
+    std::vector<int32_t> mesh_adjadr, mesh_adj, exclude_pair, actuator_dofid;
+    std::vector<double> actuator_gear;
+};
+template <class T>
+static void take(std::vector<T>& v, const T*& p, size_t n) {
+    v.assign(p, p + n);
+    if (v.empty()) v.push_back(T());
+    p = v.data();
+}
+
+extern "C" int32_t uhc_model_create(const UhcModelDesc* in, UhcModel** out) {
+    if (!in || !out) return fail("uhc_model_create: null argument");
+    if (in->nbody < 1 || in->nbody > UHC_WAVE) return fail("uhc_model_create: nbody=%d outside [1,64]", in->nbody);
+    if (in->nv < 1 || in->nv > 2 * UHC_WAVE) return fail("uhc_model_create: nv=%d outside [1,128]", in->nv);
+    if (in->njnt > 2 * UHC_WAVE) return fail("uhc_model_create: njnt=%d > 128", in->njnt);
+    UhcModel* m = new UhcModel();
+    m->d = *in;
+    UhcModelDesc& d = m->d;
+    const size_t nb = d.nbody, nj = d.njnt, nv = d.nv, ng = d.ngeom;
+    take(m->body_parentid, d.body_parentid, nb); take(m->body_jntadr, d.body_jntadr, nb);
+    take(m->body_jntnum, d.body_jntnum, nb); take(m->body_dofadr, d.body_dofadr, nb); take(m->body_dofnum, d.body_dofnum, nb);
+    take(m->body_pos, d.body_pos, 3 * nb); take(m->body_quat, d.body_quat, 4 * nb); take(m->body_ipos, d.body_ipos, 3 * nb);
+    take(m->body_iquat, d.body_iquat, 4 * nb); take(m->body_mass, d.body_mass, nb); take(m->body_inertia, d.body_inertia, 3 * nb);
+    take(m->body_invweight0, d.body_invweight0, 2 * nb);
+    take(m->jnt_type, d.jnt_type, nj); take(m->jnt_bodyid, d.jnt_bodyid, nj); take(m->jnt_qposadr, d.jnt_qposadr, nj);
+    take(m->jnt_dofadr, d.jnt_dofadr, nj); take(m->jnt_limited, d.jnt_limited, nj);
+    take(m->jnt_pos, d.jnt_pos, 3 * nj); take(m->jnt_axis, d.jnt_axis, 3 * nj); take(m->jnt_range, d.jnt_range, 2 * nj);
+    take(m->jnt_stiffness, d.jnt_stiffness, nj); take(m->jnt_margin, d.jnt_margin, nj);
+    take(m->qpos0, d.qpos0, d.nq); take(m->qpos_spring, d.qpos_spring, d.nq);
+    take(m->dof_bodyid, d.dof_bodyid, nv); take(m->dof_jntid, d.dof_jntid, nv); take(m->dof_parentid, d.dof_parentid, nv);
+    take(m->dof_madr, d.dof_madr, nv + 1);
+    take(m->dof_armature, d.dof_armature, nv); take(m->dof_damping, d.dof_damping, nv);
+    take(m->dof_frictionloss, d.dof_frictionloss, nv); take(m->dof_invweight0, d.dof_invweight0, nv);
+    take(m->geom_type, d.geom_type, ng); take(m->geom_bodyid, d.geom_bodyid, ng); take(m->geom_contype, d.geom_contype, ng);
+    take(m->geom_conaffinity, d.geom_conaffinity, ng); take(m->geom_condim, d.geom_condim, ng);
+    take(m->geom_vertadr, d.geom_vertadr, ng); take(m->geom_vertnum, d.geom_vertnum, ng);
+    take(m->geom_pos, d.geom_pos, 3 * ng); take(m->geom_quat, d.geom_quat, 4 * ng); take(m->geom_size, d.geom_size, 3 * ng);
+    take(m->geom_friction, d.geom_friction, 3 * ng); take(m->geom_margin, d.geom_margin, ng); take(m->geom_gap, d.geom_gap, ng);
+    take(m->geom_solref, d.geom_solref, 2 * ng); take(m->geom_solimp, d.geom_solimp, 5 * ng);
+    take(m->geom_rbound, d.geom_rbound, ng); take(m->geom_center, d.geom_center, 3 * ng);
+    take(m->mesh_vert, d.mesh_vert, 3 * (size_t)d.nmeshvert);
+    take(m->mesh_adjadr, d.mesh_adjadr, (size_t)d.nmeshvert + 1); take(m->mesh_adj, d.mesh_adj, d.nmeshadj);
+    take(m->exclude_pair, d.exclude_pair, 2 * (size_t)d.nexclude);
+    take(m->actuator_dofid, d.actuator_dofid, d.nu); take(m->actuator_gear, d.actuator_gear, d.nu);
+    // structural checks the kernels rely on
+    for (size_t b = 1; b < nb; b++)
+        if (d.body_parentid[b] >= (int)b) { delete m; return fail("uhc_model_create: bodies must be in depth-first order"); }
+    for (size_t i = 0; i < nv; i++)
+        if (d.dof_parentid[i] >= (int)i) { delete m; return fail("uhc_model_create: dofs must be in depth-first order"); }
+    *out = m;
+    return 0;
+}
+extern "C" void uhc_model_free(UhcModel* m) { delete m; }
+extern "C" int32_t uhc_model_nM(const UhcModel* m) { return m ? m->d.dof_madr[m->d.nv] : -1; }
+
+// ------------------------------------------------------------------ batch
+struct UhcBatch {
+    int n_env = 0, device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    KernelArgs A;
+    size_t lds_bytes = 0;
+    std::vector<void*> allocs;
+    int nM = 0;
+    int* reset_mask = nullptr;
+    // field table
+    void* field_ptr[16] = {nullptr};
+    int64_t field_count[16] = {0};
+};
+
+template <class T>
+static int upload(UhcBatch* b, const std::vector<T>& h, const T** dptr) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_OK(hipMalloc(&p, bytes));
+    b->allocs.push_back(p);
+    if (!h.empty()) HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dptr = (const T*)p;
+    return 0;
+}
+template <class T>
+static int dalloc(UhcBatch* b, size_t n, T** dptr) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    HIP_OK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    b->allocs.push_back(p);
+    *dptr = (T*)p;
+    return 0;
+}
+#define TRY(x) do { if (x) return 1; } while (0)
+
+static bool same_topology(const UhcModelDesc& a, const UhcModelDesc& b) {
+    if (a.nq != b.nq || a.nv != b.nv || a.nu != b.nu || a.nbody != b.nbody || a.njnt != b.njnt || a.ngeom != b.ngeom ||
+        a.nmeshvert != b.nmeshvert || a.nmeshadj != b.nmeshadj || a.nexclude != b.nexclude)
+        return false;
+    auto eq = [](const int32_t* x, const int32_t* y, size_t n) { return !memcmp(x, y, n * 4); };
+    return eq(a.body_parentid, b.body_parentid, a.nbody) && eq(a.jnt_type, b.jnt_type, a.njnt) &&
+           eq(a.jnt_bodyid, b.jnt_bodyid, a.njnt) && eq(a.dof_parentid, b.dof_parentid, a.nv) &&
+           eq(a.geom_type, b.geom_type, a.ngeom) && eq(a.geom_bodyid, b.geom_bodyid, a.ngeom) &&
+           eq(a.geom_vertadr, b.geom_vertadr, a.ngeom) && eq(a.geom_vertnum, b.geom_vertnum, a.ngeom) &&
+           eq(a.mesh_adjadr, b.mesh_adjadr, a.nmeshvert + 1) && eq(a.mesh_adj, b.mesh_adj, a.nmeshadj) &&
+           eq(a.geom_contype, b.geom_contype, a.ngeom) && eq(a.geom_conaffinity, b.geom_conaffinity, a.ngeom) &&
+           eq(a.jnt_limited, b.jnt_limited, a.njnt) && eq(a.geom_condim, b.geom_condim, a.ngeom);
+}
+
+static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>& blob) {
+    blob.clear();
+    auto put = [&](const double* p, size_t n) { int off = (int)blob.size(); blob.insert(blob.end(), p, p + n); return off; };
+    o.body_pos = put(d.body_pos, 3 * d.nbody); o.body_quat = put(d.body_quat, 4 * d.nbody);
+    o.body_ipos = put(d.body_ipos, 3 * d.nbody); o.body_iquat = put(d.body_iquat, 4 * d.nbody);
+    o.body_mass = put(d.body_mass, d.nbody); o.body_inertia = put(d.body_inertia, 3 * d.nbody);
+    o.body_invweight0 = put(d.body_invweight0, 2 * d.nbody);
+    o.jnt_pos = put(d.jnt_pos, 3 * d.njnt); o.jnt_axis = put(d.jnt_axis, 3 * d.njnt); o.jnt_range = put(d.jnt_range, 2 * d.njnt);
+    o.jnt_stiffness = put(d.jnt_stiffness, d.njnt); o.jnt_margin = put(d.jnt_margin, d.njnt);
+    o.qpos0 = put(d.qpos0, d.nq); o.qpos_spring = put(d.qpos_spring, d.nq);
+    o.dof_armature = put(d.dof_armature, d.nv); o.dof_damping = put(d.dof_damping, d.nv);
+    o.dof_frictionloss = put(d.dof_frictionloss, d.nv); o.dof_invweight0 = put(d.dof_invweight0, d.nv);
+    o.geom_pos = put(d.geom_pos, 3 * d.ngeom); o.geom_quat = put(d.geom_quat, 4 * d.ngeom);
+    o.geom_friction = put(d.geom_friction, 3 * d.ngeom); o.geom_margin = put(d.geom_margin, d.ngeom);
+    o.geom_gap = put(d.geom_gap, d.ngeom); o.geom_solref = put(d.geom_solref, 2 * d.ngeom);
+    o.geom_solimp = put(d.geom_solimp, 5 * d.ngeom); o.geom_rbound = put(d.geom_rbound, d.ngeom);
+    o.geom_center = put(d.geom_center, 3 * d.ngeom);
+    o.mesh_vert = put(d.mesh_vert, 3 * (size_t)d.nmeshvert);
+    o.actuator_gear = put(d.actuator_gear, d.nu);
+    o.meaninertia = put(&d.meaninertia, 1);
+    while (blob.size() % 2) blob.push_back(0.0);
+    o.stride = (int)blob.size();
+}
+
+extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_models, const int32_t* h_env_model, int32_t n_env,
+                                    int32_t device_id, const UhcCtrlDesc* ctrl, UhcBatch** out) {
+    if (!models || n_models < 1 || n_env < 1 || !ctrl || !out) return fail("uhc_batch_create: bad argument");
+    const UhcModelDesc& d = models[0]->d;
+    for (int k = 1; k < n_models; k++)
+        if (!same_topology(d, models[k]->d)) return fail("uhc_batch_create: model %d differs in topology from model 0", k);
+    if (h_env_model)
+        for (int e = 0; e < n_env; e++)
+            if (h_env_model[e] < 0 || h_env_model[e] >= n_models) return fail("uhc_batch_create: env_model[%d] out of range", e);
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail("uhc_batch_create: device %d not present (%d devices)", device_id, ndev);
+    HIP_OK(hipSetDevice(device_id));
+    if (ctrl->action_type == 0 && d.nq != d.nv + 1) return fail("uhc_batch_create: PD control expects a free root + scalar joints");
+    if (ctrl->action_type == 0 && d.nu != d.nv - 6) return fail("uhc_batch_create: PD control expects one motor per non-root dof");
+
+    UhcBatch* b = new UhcBatch();
+    b->n_env = n_env;
+    b->device = device_id;
+    KernelArgs& A = b->A;
+    memset(&A, 0, sizeof A);
+    DevTopo& T = A.t;
+    const int nb = d.nbody, nv = d.nv, nj = d.njnt, ng = d.ngeom;
+    T.nq = d.nq; T.nv = nv; T.nu = d.nu; T.nbody = nb; T.njnt = nj; T.ngeom = ng; T.nmeshvert = d.nmeshvert;
+    T.nM = d.dof_madr[nv];
+    T.iterations = d.iterations; T.plane_mesh_maxcon = d.plane_mesh_maxcon;
+    T.timestep = d.timestep; T.tolerance = d.tolerance;
+    for (int k = 0; k < 3; k++) T.gravity[k] = d.gravity[k];
+    b->nM = T.nM;
+
+    // ---- derived topology tables
+    std::vector<int> body_depth(nb, 0), body_rootid(nb, 0), body_nsub(nb, 1), body_lastdof(nb, -1);
+    for (int i = 1; i < nb; i++) {
+        int p = d.body_parentid[i];
+        body_depth[i] = body_depth[p] + 1;
+        body_rootid[i] = p == 0 ? i : body_rootid[p];
+        body_lastdof[i] = d.body_dofnum[i] > 0 ? d.body_dofadr[i] + d.body_dofnum[i] - 1 : body_lastdof[p];
+    }
+    for (int i = nb - 1; i > 0; i--) body_nsub[d.body_parentid[i]] += body_nsub[i];
+    for (int i = 1; i < nb; i++) {  // DFS order check: subtree must be the contiguous range [i, i+nsub)
+        for (int c = i + 1; c < i + body_nsub[i]; c++) {
+            int p = c;
+            while (p > i) p = d.body_parentid[p];
+            if (p != i) { delete b; return fail("uhc_batch_create: bodies are not in depth-first order"); }
+        }
+    }
+    T.body_maxdepth = *std::max_element(body_depth.begin(), body_depth.end());
+    std::vector<int> dof_depth(nv, 0), dof_ndesc(nv, 0);
+    for (int i = 0; i < nv; i++) dof_depth[i] = d.dof_parentid[i] < 0 ? 0 : dof_depth[d.dof_parentid[i]] + 1;
+    for (int i = nv - 1; i >= 0; i--)
+        if (d.dof_parentid[i] >= 0) dof_ndesc[d.dof_parentid[i]] += dof_ndesc[i] + 1;
+    for (int i = 0; i < nv; i++)
+        for (int c = i + 1; c <= i + dof_ndesc[i]; c++) {
+            int p = c;
+            while (p > i) p = d.dof_parentid[p];
+            if (p != i) { delete b; return fail("uhc_batch_create: dofs are not in depth-first order"); }
+        }
+    T.maxdepth = *std::max_element(dof_depth.begin(), dof_depth.end());
+    if (T.maxdepth + 1 > 32) { delete b; return fail("uhc_batch_create: dof chain depth %d > 32 unsupported", T.maxdepth + 1); }
+    const int YS = T.maxdepth + 1;
+    std::vector<short> dof_anc((size_t)nv * YS, 0), m_row(T.nM), m_col(T.nM);
+    for (int i = 0; i < nv; i++) {
+        int k = i;
+        for (int q = dof_depth[i]; q >= 0; q--) { dof_anc[(size_t)i * YS + q] = (short)k; k = d.dof_parentid[k]; }
+        int adr = d.dof_madr[i];
+        for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) { m_row[adr] = (short)i; m_col[adr] = (short)j; }
+    }
+    // statically filtered collision pairs (plane, mesh)
+    std::vector<int> pg1, pg2;
+    int skipped_pairs = 0;
+    for (int g1 = 0; g1 < ng; g1++)
+        for (int g2 = g1 + 1; g2 < ng; g2++) {
+            int b1 = d.geom_bodyid[g1], b2 = d.geom_bodyid[g2];
+            if (!((d.geom_contype[g1] & d.geom_conaffinity[g2]) || (d.geom_contype[g2] & d.geom_conaffinity[g1]))) continue;
+            if (b1 == b2) continue;
+            if (b1 != 0 && b2 != 0 && (d.body_parentid[b1] == b2 || d.body_parentid[b2] == b1)) continue;
+            bool ex = false;
+            for (int e = 0; e < d.nexclude; e++) {
+                int x = d.exclude_pair[2 * e], y = d.exclude_pair[2 * e + 1];
+                if ((x == b1 && y == b2) || (x == b2 && y == b1)) ex = true;
+            }
+            if (ex) continue;
+            int t1 = d.geom_type[g1], t2 = d.geom_type[g2];
+            if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH && b1 == 0) { pg1.push_back(g1); pg2.push_back(g2); }
+            else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH && b2 == 0) { pg1.push_back(g2); pg2.push_back(g1); }
+            else skipped_pairs++;
+        }
+    (void)skipped_pairs;  // mesh-mesh pairs: not generated yet (SURVEY 8a P4 "later")
+    T.npair = (int)pg1.size();
+
+    auto ivec = [](const int32_t* p, size_t n) { return std::vector<int>(p, p + n); };
+    TRY(upload(b, ivec(d.body_parentid, nb), &T.body_parentid)); TRY(upload(b, ivec(d.body_jntadr, nb), &T.body_jntadr));
+    TRY(upload(b, ivec(d.body_jntnum, nb), &T.body_jntnum)); TRY(upload(b, ivec(d.body_dofadr, nb), &T.body_dofadr));
+    TRY(upload(b, ivec(d.body_dofnum, nb), &T.body_dofnum)); TRY(upload(b, body_rootid, &T.body_rootid));
+    TRY(upload(b, body_nsub, &T.body_nsub)); TRY(upload(b, body_lastdof, &T.body_lastdof)); TRY(upload(b, body_depth, &T.body_depth));
+    TRY(upload(b, ivec(d.jnt_type, nj), &T.jnt_type)); TRY(upload(b, ivec(d.jnt_bodyid, nj), &T.jnt_bodyid));
+    TRY(upload(b, ivec(d.jnt_qposadr, nj), &T.jnt_qposadr)); TRY(upload(b, ivec(d.jnt_dofadr, nj), &T.jnt_dofadr));
+    TRY(upload(b, ivec(d.jnt_limited, nj), &T.jnt_limited));
+    TRY(upload(b, ivec(d.dof_bodyid, nv), &T.dof_bodyid)); TRY(upload(b, ivec(d.dof_jntid, nv), &T.dof_jntid));
+    TRY(upload(b, ivec(d.dof_parentid, nv), &T.dof_parentid)); TRY(upload(b, ivec(d.dof_madr, nv + 1), &T.dof_madr));
+    TRY(upload(b, dof_depth, &T.dof_depth)); TRY(upload(b, dof_ndesc, &T.dof_ndesc));
+    TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
+    TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
+    TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
+    TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
+    TRY(upload(b, ivec(d.mesh_adjadr, d.nmeshvert + 1), &T.mesh_adjadr)); TRY(upload(b, ivec(d.mesh_adj, d.nmeshadj), &T.mesh_adj));
+    TRY(upload(b, pg1, &T.pair_g1)); TRY(upload(b, pg2, &T.pair_g2));
+    TRY(upload(b, ivec(d.actuator_dofid, d.nu), &T.actuator_dofid));
+
+    // ---- numeric blobs, one per model
+    std::vector<double> all, one;
+    for (int k = 0; k < n_models; k++) {
+        build_blob(models[k]->d, A.o, one);
+        all.insert(all.end(), one.begin(), one.end());
+    }
+    TRY(upload(b, all, &A.s.model_blob));
+    if (h_env_model) TRY(upload(b, std::vector<int>(h_env_model, h_env_model + n_env), &A.s.env_model));
+
+    // ---- controller
+    DevCtrl& C = A.c;
+    C.n_substeps = ctrl->n_substeps; C.action_type = ctrl->action_type; C.meta_pd = ctrl->meta_pd; C.rfc_mode = ctrl->rfc_mode;
+    C.action_dim = ctrl->action_dim; C.rfc_scale = ctrl->rfc_scale; C.rfc_lim = ctrl->rfc_lim;
+    {
+        const double* q = ctrl->base_rot;
+        double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        if (n2 <= 0) { delete b; return fail("uhc_batch_create: zero base_rot"); }
+        C.base_rot_inv[0] = q[0] / n2; C.base_rot_inv[1] = -q[1] / n2; C.base_rot_inv[2] = -q[2] / n2; C.base_rot_inv[3] = -q[3] / n2;
+    }
+    const int min_adim = d.nu + (C.rfc_mode == 1 ? 6 : 0) + (C.meta_pd == 1 ? 2 * C.n_substeps : C.meta_pd == 2 ? 2 * d.nu : 0);
+    if (C.action_dim < min_adim) { delete b; return fail("uhc_batch_create: action_dim %d < %d required by the controller", C.action_dim, min_adim); }
+    auto dvec = [&](const double* p) { return std::vector<double>(p, p + d.nu); };
+    TRY(upload(b, dvec(ctrl->jkp), &C.jkp)); TRY(upload(b, dvec(ctrl->jkd), &C.jkd));
+    TRY(upload(b, dvec(ctrl->torque_lim), &C.torque_lim)); TRY(upload(b, dvec(ctrl->a_scale), &C.a_scale));
+
+    // ---- LDS carve (doubles; every offset even => 16-byte aligned)
+    DevLds& L = A.l;
+    int off = 0;
+    auto carve = [&](int n) { int o = off; off += (n + 1) & ~1; return o; };
+    L.qpos = carve(d.nq); L.qvel = carve(nv); L.qacc = carve(nv); L.ctrl = carve(d.nu); L.applied = carve(nv);
+    L.xpos = carve(3 * nb); L.xquat = carve(4 * nb); L.xmat = carve(9 * nb); L.xipos = carve(3 * nb); L.ximat = carve(9 * nb);
+    L.rootcom = carve(3 * nb); L.cinert = carve(10 * nb); L.crb = carve(10 * nb); L.cvel = carve(6 * nb);
+    L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
+    L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
+    L.M = carve(T.nM); L.LD = carve(T.nM); L.dinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
+    L.vec = carve(nv); L.z = carve(nv);
+    L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
+    L.Y = carve(UHC_MAXEFC * YS);
+    L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
+    L.rowDa = carve(UHC_MAXEFC);
+    L.rowMisc = carve(UHC_MAXEFC * 2);  // 4 ints per row
+    L.ncon_nefc = carve(2);
+    L.total = off;
+    b->lds_bytes = (size_t)off * sizeof(double);
+    if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }
+    HIP_OK(uhc_set_lds_limit(b->lds_bytes));
+
+    // ---- state
+    DevState& S = A.s;
+    const size_t E = n_env;
+    TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
+    TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * nv, &S.applied));
+    TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
+    TRY(dalloc(b, E, &S.overflow));
+    TRY(dalloc(b, E, &b->reset_mask));
+    A.n_env = n_env;
+    // qpos <- qpos0 of each env's model
+    {
+        std::vector<double> q0(E * d.nq);
+        for (size_t e = 0; e < E; e++) {
+            const UhcModelDesc& md = models[h_env_model ? h_env_model[e] : 0]->d;
+            memcpy(&q0[e * d.nq], md.qpos0, d.nq * sizeof(double));
+        }
+        HIP_OK(hipMemcpy(S.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    void* fp[] = {S.qpos, S.qvel, S.xpos, S.xquat, S.xipos, S.qM, S.bias, S.qacc, S.ctrl, S.ncon, S.nefc, S.fail,
+                  S.solver_iter, S.applied, S.overflow};
+    int64_t fc[] = {(int64_t)E * d.nq, (int64_t)E * nv, (int64_t)E * 3 * nb, (int64_t)E * 4 * nb, (int64_t)E * 3 * nb,
+                    (int64_t)E * T.nM, (int64_t)E * nv, (int64_t)E * nv, (int64_t)E * d.nu, (int64_t)E, (int64_t)E, (int64_t)E,
+                    (int64_t)E, (int64_t)E * nv, (int64_t)E};
+    for (int k = 0; k < 15; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
+    HIP_OK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    b->stream = b->own_stream;
+    *out = b;
+    return 0;
+}
+
+extern "C" void uhc_batch_free(UhcBatch* b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    for (void* p : b->allocs) hipFree(p);
+    if (b->own_stream) hipStreamDestroy(b->own_stream);
+    delete b;
+}
+extern "C" int32_t uhc_batch_set_stream(UhcBatch* b, void* s) {
+    if (!b) return fail("uhc_batch_set_stream: null batch");
+    b->stream = (hipStream_t)s;  // NULL is the device's null (default) stream
+    return 0;
+}
+extern "C" int32_t uhc_batch_sync(UhcBatch* b) {
+    if (!b) return fail("uhc_batch_sync: null batch");
+    HIP_OK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {
+    if (!b) return fail("uhc_batch_set_rfc_scale: null batch");
+    b->A.c.rfc_scale = s;
+    return 0;
+}
+extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n) {
+    if (!b || f < 0 || f > 14 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
+    if (p) *p = b->field_ptr[f];
+    if (n) *n = b->field_count[f];
+    return 0;
+}
+extern "C" int32_t uhc_batch_forward(UhcBatch* b) {
+    if (!b) return fail("uhc_batch_forward: null batch");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(uhc_launch_step(1, &b->A, nullptr, nullptr, nullptr, b->lds_bytes, b->stream));
+    return 0;
+}
+extern "C" int32_t uhc_batch_set_state(UhcBatch* b, const int32_t* d_env_ids, int32_t n, const double* d_qpos, const double* d_qvel) {
+    if (!b || !d_qpos || !d_qvel) return fail("uhc_batch_set_state: null argument");
+    if (n < 1 || n > b->n_env) return fail("uhc_batch_set_state: n=%d outside [1,%d]", n, b->n_env);
+    if (!d_env_ids && n != b->n_env) return fail("uhc_batch_set_state: env_ids==NULL requires n == n_env");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(hipMemsetAsync(b->reset_mask, 0, sizeof(int) * b->n_env, b->stream));
+    HIP_OK(uhc_launch_set_state(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, d_env_ids, n, d_qpos, d_qvel, b->reset_mask, b->stream));
+    // sim.forward() on the listed envs only (the others keep their one-substep-stale qM / qfrc_bias)
+    HIP_OK(uhc_launch_step(1, &b->A, nullptr, nullptr, b->reset_mask, b->lds_bytes, b->stream));
+    return 0;
+}
+extern "C" int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const double* d_target_base, const int32_t* d_active) {
+    if (!b || !d_action || !d_target_base) return fail("uhc_batch_simulate: null argument");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(uhc_launch_step(0, &b->A, d_action, d_target_base, d_active, b->lds_bytes, b->stream));
+    return 0;
+}

@@ -1,0 +1,73 @@
+// uhc_device.h -- device-side model description shared by the HIP kernels and the C-ABI host code.
+// gfx950 only.  One environment per 64-lane wavefront; all per-env working state lives in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UHC_WAVE 64
+#define UHC_MAXEFC 128   // constraint rows per env (2 per lane)
+#define UHC_MAXCON 40    // contacts per env
+#define UHC_CON_STRIDE 24
+#define UHC_MINVAL 1e-15
+#define UHC_MAXVAL 1e10
+
+// topology + options: identical for every env of a batch
+struct DevTopo {
+    int nq, nv, nu, nbody, njnt, ngeom, nM, maxdepth, nmeshvert, npair, iterations, plane_mesh_maxcon;
+    double timestep, tolerance;
+    double gravity[3];
+    const int *body_parentid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_rootid, *body_nsub,
+        *body_lastdof, *body_depth;
+    const int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
+    const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_madr, *dof_depth, *dof_ndesc;
+    const short* dof_anc;  // [nv][maxdepth+1]: ancestor of dof i at depth q (q <= depth(i)), anc[i][depth(i)] = i
+    const short *m_row, *m_col;  // [nM] sparse-M entry -> (i, j)
+    const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
+    const int *mesh_adjadr, *mesh_adj;
+    const int *pair_g1, *pair_g2;  // statically filtered candidate geom pairs (g1 = plane, g2 = mesh)
+    const int* actuator_dofid;
+    int body_maxdepth;
+};
+
+// offsets (in doubles) of the numeric arrays inside one model blob
+struct DevNumOff {
+    int body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0;
+    int jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_margin, qpos0, qpos_spring;
+    int dof_armature, dof_damping, dof_frictionloss, dof_invweight0;
+    int geom_pos, geom_quat, geom_friction, geom_margin, geom_gap, geom_solref, geom_solimp, geom_rbound, geom_center;
+    int mesh_vert, actuator_gear, meaninertia;
+    int stride;  // doubles per model
+};
+
+// LDS carve (offsets in doubles from the dynamic-LDS base)
+struct DevLds {
+    int qpos, qvel, qacc, ctrl, applied;
+    int xpos, xquat, xmat, xipos, ximat, rootcom, cinert, crb, cvel, cacc, cfrc;
+    int xanchor, xaxis, cdof, cdofdot;
+    int M, LD, dinv, bias, smooth, vec, z;
+    int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
+    int total;  // doubles
+};
+
+struct DevCtrl {
+    int n_substeps, action_type, meta_pd, rfc_mode, action_dim;
+    double rfc_scale, rfc_lim;
+    double base_rot_inv[4];  // quaternion_inverse(base_rot) = conj / |q|^2
+    const double *jkp, *jkd, *torque_lim, *a_scale;
+};
+
+struct DevState {  // HBM, env-major
+    double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
+    int *ncon, *nefc, *fail, *solver_iter, *overflow;
+    const int* env_model;
+    const double* model_blob;
+};
+
+struct KernelArgs {
+    DevTopo t;
+    DevNumOff o;
+    DevLds l;
+    DevCtrl c;
+    DevState s;
+    int n_env;
+};

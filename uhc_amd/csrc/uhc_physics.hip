@@ -1,0 +1,1075 @@
+// uhc_physics.hip -- fused rigid-body step for batched SMPL humanoids on MI355X (gfx950).
+//
+// One environment per 64-lane wavefront (workgroup = 1 wave), every per-env intermediate in LDS or
+// registers, one launch per control step (n_substeps x {stable-PD, residual force, forward dynamics,
+// PGS contact solve, semi-implicit Euler}).  HBM traffic per env-step is the state only
+// (qpos, qvel, warm start, qM, qfrc_bias in; the same plus body poses out).
+//
+// Stage map: P1 k_kinematics, P2 k_com_pos, P3 k_crb + k_factor, P4 k_collision,
+// P5 k_rows, P6/P9 k_pgs, P7 k_com_vel + k_rne, P8 k_smooth, P10 k_euler, E3/E4 k_pd_torque,
+// E5 k_rfc_implicit.  The reference call sites these replace: uhc/envs/humanoid_im.py:1145-1190
+// (do_simulation), :1014-1076 (PD), :1136-1143 (RFC), and MuJoCo's mj_step behind self.sim.step().
+#include "../../include/uhc_amd.h"
+#include "uhc_device.h"
+
+extern __shared__ __attribute__((aligned(16))) double smem[];
+
+#define LANE ((int)threadIdx.x)
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+// ------------------------------------------------------------------ lane helpers
+__device__ __forceinline__ double bcast(double v, int src) {  // src must be wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ small math (registers)
+__device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
+    double r0 = a[1] * b[2] - a[2] * b[1], r1 = a[2] * b[0] - a[0] * b[2], r2 = a[0] * b[1] - a[1] * b[0];
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void quat_mul(double* r, const double* a, const double* b) {
+    double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    double t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    double t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+__device__ __forceinline__ void quat_normalize(double* q) {
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n < UHC_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+    double inv = 1.0 / n;
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+__device__ __forceinline__ void quat_to_mat(double* m, const double* q) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+    m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+    m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void mat_vec(double* r, const double* m, const double* v) {
+    double t0 = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+    double t1 = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+    double t2 = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+    r[0] = t0; r[1] = t1; r[2] = t2;
+}
+__device__ __forceinline__ void axis_angle_quat(double* q, const double* axis, double angle) {
+    double s, c;
+    sincos(0.5 * angle, &s, &c);
+    q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+__device__ __forceinline__ void cross_motion(double* r, const double* v, const double* m) {
+    double a[3], b[3];
+    cross3(r, v, m);
+    cross3(a, v, m + 3);
+    cross3(b, v + 3, m);
+    r[3] = a[0] + b[0]; r[4] = a[1] + b[1]; r[5] = a[2] + b[2];
+}
+__device__ __forceinline__ void cross_force(double* r, const double* v, const double* f) {
+    double a[3], b[3];
+    cross3(a, v, f);
+    cross3(b, v + 3, f + 3);
+    r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+    cross3(r + 3, v, f + 3);
+}
+__device__ __forceinline__ void inert_mul(double* r, const double* I, const double* v) {
+    const double *w = v, *l = v + 3, *h = I + 6;
+    double hxl[3], wxh[3];
+    cross3(hxl, h, l);
+    cross3(wxh, w, h);
+    r[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2] + hxl[0];
+    r[1] = I[3] * w[0] + I[1] * w[1] + I[5] * w[2] + hxl[1];
+    r[2] = I[4] * w[0] + I[5] * w[1] + I[2] * w[2] + hxl[2];
+    r[3] = I[9] * l[0] + wxh[0];
+    r[4] = I[9] * l[1] + wxh[1];
+    r[5] = I[9] * l[2] + wxh[2];
+}
+__device__ __forceinline__ double dot6(const double* a, const double* b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// ------------------------------------------------------------------ P1 kinematics: body-per-lane, level-synchronous
+__device__ void k_kinematics(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const int b = LANE;
+    double *xpos = S + L.xpos, *xquat = S + L.xquat, *xmat = S + L.xmat, *xipos = S + L.xipos, *ximat = S + L.ximat;
+    if (b == 0) {
+        for (int k = 0; k < 3; k++) { xpos[k] = 0; xipos[k] = 0; }
+        xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
+        for (int k = 0; k < 9; k++) { xmat[k] = (k % 4 == 0); ximat[k] = (k % 4 == 0); }
+    }
+    wsync();
+    const int depth = b < T.nbody ? T.body_depth[b] : -1;
+    for (int level = 1; level <= T.body_maxdepth; level++) {
+        if (depth == level) {
+            const int p = T.body_parentid[b], ja = T.body_jntadr[b], jn = T.body_jntnum[b];
+            double pos[3], quat[4], R[9], t[3];
+            if (jn == 1 && T.jnt_type[ja] == UHC_JNT_FREE) {
+                const double* q = S + L.qpos + T.jnt_qposadr[ja];
+                for (int k = 0; k < 3; k++) pos[k] = q[k];
+                for (int k = 0; k < 4; k++) quat[k] = q[3 + k];
+                quat_normalize(quat);
+                for (int k = 0; k < 3; k++) { S[L.xanchor + 3 * ja + k] = pos[k]; S[L.xaxis + 3 * ja + k] = (k == 2); }
+            } else {
+                double pm[9], pq[4], bp[3], bq[4];
+                for (int k = 0; k < 9; k++) pm[k] = xmat[9 * p + k];
+                for (int k = 0; k < 4; k++) { pq[k] = xquat[4 * p + k]; bq[k] = mb[A.o.body_quat + 4 * b + k]; }
+                for (int k = 0; k < 3; k++) bp[k] = mb[A.o.body_pos + 3 * b + k];
+                mat_vec(t, pm, bp);
+                for (int k = 0; k < 3; k++) pos[k] = xpos[3 * p + k] + t[k];
+                quat_mul(quat, pq, bq);
+                for (int j = ja; j < ja + jn; j++) {
+                    const int qa = T.jnt_qposadr[j], jt = T.jnt_type[j];
+                    double qloc[4], jp[3], jx[3], ax[3];
+                    for (int k = 0; k < 3; k++) { jp[k] = mb[A.o.jnt_pos + 3 * j + k]; jx[k] = mb[A.o.jnt_axis + 3 * j + k]; }
+                    quat_to_mat(R, quat);
+                    mat_vec(t, R, jp);
+                    for (int k = 0; k < 3; k++) S[L.xanchor + 3 * j + k] = pos[k] + t[k];
+                    mat_vec(ax, R, jx);
+                    for (int k = 0; k < 3; k++) S[L.xaxis + 3 * j + k] = ax[k];
+                    if (jt == UHC_JNT_SLIDE) {
+                        double dq = S[L.qpos + qa] - mb[A.o.qpos0 + qa];
+                        for (int k = 0; k < 3; k++) pos[k] += ax[k] * dq;
+                        continue;
+                    } else if (jt == UHC_JNT_HINGE) {
+                        axis_angle_quat(qloc, jx, S[L.qpos + qa] - mb[A.o.qpos0 + qa]);
+                        quat_mul(quat, quat, qloc);
+                    } else if (jt == UHC_JNT_BALL) {
+                        for (int k = 0; k < 4; k++) qloc[k] = S[L.qpos + qa + k];
+                        quat_normalize(qloc);
+                        quat_mul(quat, quat, qloc);
+                    }
+                    quat_to_mat(R, quat);
+                    mat_vec(t, R, jp);
+                    for (int k = 0; k < 3; k++) pos[k] = S[L.xanchor + 3 * j + k] - t[k];
+                }
+            }
+            quat_normalize(quat);
+            quat_to_mat(R, quat);
+            double ip[3], iq[4], qi[4], Ri[9];
+            for (int k = 0; k < 3; k++) ip[k] = mb[A.o.body_ipos + 3 * b + k];
+            for (int k = 0; k < 4; k++) iq[k] = mb[A.o.body_iquat + 4 * b + k];
+            mat_vec(t, R, ip);
+            quat_mul(qi, quat, iq);
+            quat_to_mat(Ri, qi);
+            for (int k = 0; k < 3; k++) { xpos[3 * b + k] = pos[k]; xipos[3 * b + k] = pos[k] + t[k]; }
+            for (int k = 0; k < 4; k++) xquat[4 * b + k] = quat[k];
+            for (int k = 0; k < 9; k++) { xmat[9 * b + k] = R[k]; ximat[9 * b + k] = Ri[k]; }
+        }
+        wsync();
+    }
+}
+
+// ------------------------------------------------------------------ P2 comPos: tree COM, cinert (body/lane), cdof (joint/lane)
+__device__ void k_com_pos(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const int b = LANE;
+    const bool act = b > 0 && b < T.nbody;
+    const double mass = act ? mb[A.o.body_mass + b] : 0.0;
+    const int root = act ? T.body_rootid[b] : -1;
+    double xi[3] = {0, 0, 0};
+    if (act) for (int k = 0; k < 3; k++) xi[k] = S[L.xipos + 3 * b + k];
+    // one reduction per kinematic tree (bodies whose parent is the world)
+    for (int r = 1; r < T.nbody; r++) {
+        if (T.body_parentid[r] != 0) continue;
+        const double w = root == r ? mass : 0.0;
+        double m = wave_sum(w), cx = wave_sum(w * xi[0]), cy = wave_sum(w * xi[1]), cz = wave_sum(w * xi[2]);
+        if (LANE == 0) {
+            const double inv = m < UHC_MINVAL ? 0.0 : 1.0 / m;
+            S[L.rootcom + 3 * r] = cx * inv; S[L.rootcom + 3 * r + 1] = cy * inv; S[L.rootcom + 3 * r + 2] = cz * inv;
+        }
+    }
+    wsync();
+    if (b == 0) for (int k = 0; k < 10; k++) S[L.cinert + k] = 0;
+    if (act) {
+        double c[3], R[9], I[3], J[9];
+        for (int k = 0; k < 3; k++) { c[k] = xi[k] - S[L.rootcom + 3 * root + k]; I[k] = mb[A.o.body_inertia + 3 * b + k]; }
+        for (int k = 0; k < 9; k++) R[k] = S[L.ximat + 9 * b + k];
+        for (int r = 0; r < 3; r++)
+            for (int s = 0; s < 3; s++)
+                J[3 * r + s] = R[3 * r] * I[0] * R[3 * s] + R[3 * r + 1] * I[1] * R[3 * s + 1] + R[3 * r + 2] * I[2] * R[3 * s + 2];
+        const double cc = dot3(c, c);
+        double* ci = S + L.cinert + 10 * b;
+        ci[0] = J[0] + mass * (cc - c[0] * c[0]);
+        ci[1] = J[4] + mass * (cc - c[1] * c[1]);
+        ci[2] = J[8] + mass * (cc - c[2] * c[2]);
+        ci[3] = J[1] - mass * c[0] * c[1];
+        ci[4] = J[2] - mass * c[0] * c[2];
+        ci[5] = J[5] - mass * c[1] * c[2];
+        ci[6] = mass * c[0]; ci[7] = mass * c[1]; ci[8] = mass * c[2]; ci[9] = mass;
+    }
+    for (int j = LANE; j < T.njnt; j += UHC_WAVE) {
+        const int bj = T.jnt_bodyid[j], da = T.jnt_dofadr[j], jt = T.jnt_type[j];
+        const int rj = T.body_rootid[bj];
+        double off[3], ax[3];
+        for (int k = 0; k < 3; k++) { off[k] = S[L.rootcom + 3 * rj + k] - S[L.xanchor + 3 * j + k]; ax[k] = S[L.xaxis + 3 * j + k]; }
+        double* cd = S + L.cdof + 6 * da;
+        if (jt == UHC_JNT_FREE) {
+            for (int k = 0; k < 18; k++) cd[k] = 0;
+            cd[3] = 1; cd[6 + 4] = 1; cd[12 + 5] = 1;
+            cd += 18;
+        }
+        if (jt == UHC_JNT_FREE || jt == UHC_JNT_BALL) {
+            for (int k = 0; k < 3; k++) {
+                double a3[3] = {S[L.xmat + 9 * bj + k], S[L.xmat + 9 * bj + 3 + k], S[L.xmat + 9 * bj + 6 + k]}, cr[3];
+                cross3(cr, a3, off);
+                for (int s = 0; s < 3; s++) { cd[6 * k + s] = a3[s]; cd[6 * k + 3 + s] = cr[s]; }
+            }
+        } else if (jt == UHC_JNT_SLIDE) {
+            for (int s = 0; s < 3; s++) { cd[s] = 0; cd[3 + s] = ax[s]; }
+        } else {
+            double cr[3];
+            cross3(cr, ax, off);
+            for (int s = 0; s < 3; s++) { cd[s] = ax[s]; cd[3 + s] = cr[s]; }
+        }
+    }
+    wsync();
+}
+
+// ------------------------------------------------------------------ P3 composite inertias + sparse M
+__device__ void k_crb(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const int b = LANE;
+    if (b > 0 && b < T.nbody) {  // bodies are in DFS order: subtree(b) = [b, b + nsub)
+        double acc[10];
+        const int n = T.body_nsub[b];
+        for (int k = 0; k < 10; k++) acc[k] = S[L.cinert + 10 * (b + n - 1) + k];
+        for (int c = b + n - 2; c >= b; c--)
+            for (int k = 0; k < 10; k++) acc[k] += S[L.cinert + 10 * c + k];
+        for (int k = 0; k < 10; k++) S[L.crb + 10 * b + k] = acc[k];
+    }
+    wsync();
+    // buf[i] = crb[body(i)] * cdof[i]   (kept in the cdofdot area until k_com_vel overwrites it)
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        double I[10], v[6], r[6];
+        const int bi = T.dof_bodyid[i];
+        for (int k = 0; k < 10; k++) I[k] = S[L.crb + 10 * bi + k];
+        for (int k = 0; k < 6; k++) v[k] = S[L.cdof + 6 * i + k];
+        inert_mul(r, I, v);
+        for (int k = 0; k < 6; k++) S[L.cdofdot + 6 * i + k] = r[k];
+    }
+    wsync();
+    for (int e = LANE; e < T.nM; e += UHC_WAVE) {
+        const int i = T.m_row[e], j = T.m_col[e];
+        double a[6], c[6];
+        for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
+        double v = dot6(a, c);
+        if (i == j) v += mb[A.o.dof_armature + i];
+        S[L.M + e] = v;
+    }
+    wsync();
+}
+
+// in-place L^T D L of the tree-sparse matrix at S[ld..]; also dinv[i] = 1/D[i].
+// Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t)
+// updates of one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.
+__device__ void k_factor(const KernelArgs& A, double* S, int ld) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    double* LD = S + ld;
+    const int tl = LANE & 15, al = LANE >> 4;
+    for (int k = T.nv - 1; k >= 0; k--) {
+        const int dk = T.dof_depth[k];  // number of proper ancestors
+        if (dk == 0) continue;
+        const int kk = T.dof_madr[k];
+        const double Dk = LD[kk];
+        // rows of the ancestors are updated from row k (row k itself is only read here)
+        for (int a0 = 1; a0 <= dk; a0 += 4) {
+            const int a = a0 + al;
+            if (a <= dk) {
+                const int i = T.dof_anc[k * (T.maxdepth + 1) + (dk - a)];
+                const int n = dk - a + 1;  // entries in row i
+                const double f = LD[kk + a] / Dk;
+                const int base = T.dof_madr[i];
+                if (tl < n) LD[base + tl] -= f * LD[kk + a + tl];
+                if (tl + 16 < n) LD[base + tl + 16] -= f * LD[kk + a + tl + 16];
+            }
+        }
+        wsync();
+        for (int a = 1 + LANE; a <= dk; a += UHC_WAVE) LD[kk + a] = LD[kk + a] / Dk;
+        wsync();
+    }
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.dinv + i] = 1.0 / LD[T.dof_madr[i]];
+    wsync();
+}
+
+// x = M^-1 x for one right-hand side held in registers (lane owns dofs LANE and LANE+64).
+// half: 0 = full solve, 1 = only  L^-1  (used after the constraint solve: qacc += L^-1 D^-1/2 z).
+struct DofVec { double a, b; };
+__device__ __forceinline__ double dv_get(const DofVec& x, int i) { return i < UHC_WAVE ? bcast(x.a, i) : bcast(x.b, i - UHC_WAVE); }
+__device__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const double* LD = S + ld;
+    const int i0 = LANE, i1 = LANE + UHC_WAVE;
+    const bool v0 = i0 < T.nv, v1 = i1 < T.nv;
+    const int d0 = v0 ? T.dof_depth[i0] : 0, d1 = v1 ? T.dof_depth[i1] : 0;
+    const int n0 = v0 ? T.dof_ndesc[i0] : -1, n1 = v1 ? T.dof_ndesc[i1] : -1;
+    const int m0 = v0 ? T.dof_madr[i0] : 0, m1 = v1 ? T.dof_madr[i1] : 0;
+    if (!half) {
+        // x <- L^-T x : for i descending, every ancestor j of i:  x[j] -= L[i][j] x[i]
+        for (int i = T.nv - 1; i > 0; i--) {
+            const int di = T.dof_depth[i];
+            if (di == 0) continue;
+            const double xi = dv_get(x, i);
+            const int mi = T.dof_madr[i];
+            if (v0 && i > i0 && i <= i0 + n0) x.a -= LD[mi + di - d0] * xi;
+            if (v1 && i > i1 && i <= i1 + n1) x.b -= LD[mi + di - d1] * xi;
+        }
+        if (v0) x.a *= S[L.dinv + i0];
+        if (v1) x.b *= S[L.dinv + i1];
+    }
+    // x <- L^-1 x : for j ascending, every descendant i of j:  x[i] -= L[i][j] x[j]
+    for (int j = 0; j < T.nv - 1; j++) {
+        const int nj = T.dof_ndesc[j];
+        if (nj == 0) continue;
+        const double xj = dv_get(x, j);
+        const int dj = T.dof_depth[j];
+        if (v0 && i0 > j && i0 <= j + nj) x.a -= LD[m0 + d0 - dj] * xj;
+        if (v1 && i1 > j && i1 <= j + nj) x.b -= LD[m1 + d1 - dj] * xj;
+    }
+}
+
+// ------------------------------------------------------------------ P7 velocities + bias forces
+__device__ void k_com_vel(const KernelArgs& A, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const int b = LANE;
+    if (b == 0) for (int k = 0; k < 6; k++) S[L.cvel + k] = 0;
+    wsync();
+    const int depth = b < T.nbody ? T.body_depth[b] : -1;
+    for (int level = 1; level <= T.body_maxdepth; level++) {
+        if (depth == level) {
+            double cvel[6], t[6], cd[6];
+            const int p = T.body_parentid[b];
+            for (int k = 0; k < 6; k++) cvel[k] = S[L.cvel + 6 * p + k];
+            const int ja = T.body_jntadr[b], jn = T.body_jntnum[b];
+            for (int j = ja; j < ja + jn; j++) {
+                int da = T.jnt_dofadr[j];
+                const int jt = T.jnt_type[j];
+                if (jt == UHC_JNT_FREE) {
+                    for (int k = 0; k < 18; k++) S[L.cdofdot + 6 * da + k] = 0;
+                    for (int k = 0; k < 3; k++) {
+                        const double qv = S[L.qvel + da + k];
+                        for (int s = 0; s < 6; s++) cvel[s] += S[L.cdof + 6 * (da + k) + s] * qv;
+                    }
+                    da += 3;
+                }
+                if (jt == UHC_JNT_FREE || jt == UHC_JNT_BALL) {
+                    for (int k = 0; k < 3; k++) {
+                        for (int s = 0; s < 6; s++) cd[s] = S[L.cdof + 6 * (da + k) + s];
+                        cross_motion(t, cvel, cd);
+                        for (int s = 0; s < 6; s++) S[L.cdofdot + 6 * (da + k) + s] = t[s];
+                    }
+                    for (int k = 0; k < 3; k++) {
+                        const double qv = S[L.qvel + da + k];
+                        for (int s = 0; s < 6; s++) cvel[s] += S[L.cdof + 6 * (da + k) + s] * qv;
+                    }
+                } else {
+                    for (int s = 0; s < 6; s++) cd[s] = S[L.cdof + 6 * da + s];
+                    cross_motion(t, cvel, cd);
+                    const double qv = S[L.qvel + da];
+                    for (int s = 0; s < 6; s++) { S[L.cdofdot + 6 * da + s] = t[s]; cvel[s] += cd[s] * qv; }
+                }
+            }
+            for (int k = 0; k < 6; k++) S[L.cvel + 6 * b + k] = cvel[k];
+        }
+        wsync();
+    }
+}
+__device__ void k_rne(const KernelArgs& A, double* S) {  // qfrc_bias = RNE(qacc = 0)
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const int b = LANE;
+    if (b == 0) for (int k = 0; k < 6; k++) { S[L.cacc + k] = k < 3 ? 0.0 : -T.gravity[k - 3]; S[L.cfrc + k] = 0; }
+    wsync();
+    const int depth = b < T.nbody ? T.body_depth[b] : -1;
+    for (int level = 1; level <= T.body_maxdepth; level++) {
+        if (depth == level) {
+            double cacc[6], cvel[6], I[10], t[6], u[6], f[6];
+            const int p = T.body_parentid[b];
+            for (int k = 0; k < 6; k++) { cacc[k] = S[L.cacc + 6 * p + k]; cvel[k] = S[L.cvel + 6 * b + k]; }
+            const int da = T.body_dofadr[b], dn = T.body_dofnum[b];
+            for (int i = da; i < da + dn; i++) {
+                const double qv = S[L.qvel + i];
+                for (int s = 0; s < 6; s++) cacc[s] += S[L.cdofdot + 6 * i + s] * qv;
+            }
+            for (int k = 0; k < 10; k++) I[k] = S[L.cinert + 10 * b + k];
+            inert_mul(t, I, cacc);
+            inert_mul(u, I, cvel);
+            cross_force(f, cvel, u);
+            for (int k = 0; k < 6; k++) { S[L.cacc + 6 * b + k] = cacc[k]; S[L.cfrc + 6 * b + k] = f[k] + t[k]; }
+        }
+        wsync();
+    }
+    // subtree sums of cfrc (DFS order) gathered per dof
+    double sub[6] = {0, 0, 0, 0, 0, 0};
+    if (b > 0 && b < T.nbody) {
+        const int n = T.body_nsub[b];
+        for (int k = 0; k < 6; k++) sub[k] = S[L.cfrc + 6 * (b + n - 1) + k];
+        for (int c = b + n - 2; c >= b; c--)
+            for (int k = 0; k < 6; k++) sub[k] += S[L.cfrc + 6 * c + k];
+    }
+    wsync();
+    if (b > 0 && b < T.nbody) for (int k = 0; k < 6; k++) S[L.cfrc + 6 * b + k] = sub[k];
+    wsync();
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        double a[6], c[6];
+        const int bi = T.dof_bodyid[i];
+        for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * i + k]; c[k] = S[L.cfrc + 6 * bi + k]; }
+        S[L.bias + i] = dot6(a, c);
+    }
+    wsync();
+}
+
+// ------------------------------------------------------------------ P8 smooth forces / acceleration
+__device__ void k_smooth(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    // qfrc_smooth = passive - bias + applied + actuator  -> S.smooth
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        double f = -mb[A.o.dof_damping + i] * S[L.qvel + i] - S[L.bias + i] + S[L.applied + i];
+        const int j = T.dof_jntid[i], jt = T.jnt_type[j];
+        const double k = mb[A.o.jnt_stiffness + j];
+        if (k != 0 && (jt == UHC_JNT_HINGE || jt == UHC_JNT_SLIDE)) {
+            const int qa = T.jnt_qposadr[j];
+            f -= k * (S[L.qpos + qa] - mb[A.o.qpos_spring + qa]);
+        }
+        S[L.smooth + i] = f;
+    }
+    wsync();
+    if (LANE == 0)
+        for (int a = 0; a < T.nu; a++) S[L.smooth + T.actuator_dofid[a]] += mb[A.o.actuator_gear + a] * S[L.ctrl + a];
+    wsync();
+    DofVec x;
+    x.a = LANE < T.nv ? S[L.smooth + LANE] : 0.0;
+    x.b = LANE + UHC_WAVE < T.nv ? S[L.smooth + LANE + UHC_WAVE] : 0.0;
+    k_solve(A, S, L.LD, x, 0);
+    if (LANE < T.nv) S[L.smooth + LANE] = x.a;  // now qacc_smooth
+    if (LANE + UHC_WAVE < T.nv) S[L.smooth + LANE + UHC_WAVE] = x.b;
+    wsync();
+}
+
+// ------------------------------------------------------------------ P4 collision: plane vs convex mesh
+__device__ __forceinline__ void make_frame(double* f) {
+    double n = sqrt(dot3(f, f));
+    f[0] /= n; f[1] /= n; f[2] /= n;
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+    const double dp = dot3(f, f + 3);
+    for (int k = 0; k < 3; k++) f[3 + k] -= f[k] * dp;
+    n = sqrt(dot3(f + 3, f + 3));
+    f[3] /= n; f[4] /= n; f[5] /= n;
+    cross3(f + 6, f, f + 3);
+}
+__device__ __forceinline__ double impedance(const double* si, double pos, double margin) {
+    double dmin = clampd(si[0], 0.0001, 0.9999), dmax = clampd(si[1], 0.0001, 0.9999), width = si[2];
+    double mid = clampd(si[3], 0.0001, 0.9999), power = si[4] < 1 ? 1 : si[4];
+    if (width < UHC_MINVAL) return 0.5 * (dmin + dmax);
+    const double x = fabs(pos - margin) / width;
+    double y;
+    if (x >= 1) return dmax;
+    if (x <= 0) return dmin;
+    if (power == 1) y = x;
+    else if (x <= mid) y = pow(x / mid, power) * mid;
+    else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+    return dmin + y * (dmax - dmin);
+}
+__device__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, const double* w,
+                                const double* n, double dist, double margin, double gap) {
+    const DevTopo& T = A.t;
+    double* C = S + A.l.con + c * UHC_CON_STRIDE;
+    double fr[9];
+    for (int k = 0; k < 3; k++) { C[k] = w[k] - 0.5 * dist * n[k]; fr[k] = n[k]; }
+    make_frame(fr);
+    for (int k = 0; k < 9; k++) C[3 + k] = fr[k];
+    const int b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
+    const int dim = max(T.geom_condim[g1], T.geom_condim[g2]);
+    const double inc = margin - gap;
+    double solref[2], solimp[5];
+    for (int k = 0; k < 2; k++) solref[k] = 0.5 * (mb[A.o.geom_solref + 2 * g1 + k] + mb[A.o.geom_solref + 2 * g2 + k]);
+    for (int k = 0; k < 5; k++) solimp[k] = 0.5 * (mb[A.o.geom_solimp + 5 * g1 + k] + mb[A.o.geom_solimp + 5 * g2 + k]);
+    const double timeconst = fmax(solref[0], 2 * T.timestep), dampratio = solref[1];
+    const double dmax = clampd(solimp[1], 0.0001, 0.9999);
+    C[12] = dist; C[13] = inc;
+    C[14] = fmax(mb[A.o.geom_friction + 3 * g1], mb[A.o.geom_friction + 3 * g2]);
+    C[15] = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+    C[16] = 2.0 / (dmax * timeconst);
+    C[17] = impedance(solimp, dist, inc);
+    C[18] = mb[A.o.body_invweight0 + 2 * b1] + mb[A.o.body_invweight0 + 2 * b2];
+    C[19] = b1; C[20] = b2; C[21] = dim;
+}
+// returns ncon (wave-uniform)
+__device__ int k_collision(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    int ncon = 0;
+    for (int p0 = 0; p0 < T.npair; p0 += UHC_WAVE) {
+        const int p = p0 + LANE;
+        bool keep = false;
+        if (p < T.npair) {  // bounding-sphere cull, one pair per lane
+            const int g1 = T.pair_g1[p], g2 = T.pair_g2[p], b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
+            double pq[4], gq[4], xq[4], R[9], t[3], gp[3], ce[3];
+            for (int k = 0; k < 4; k++) { gq[k] = mb[A.o.geom_quat + 4 * g1 + k]; xq[k] = S[L.xquat + 4 * b1 + k]; }
+            quat_mul(pq, xq, gq);
+            quat_to_mat(R, pq);
+            double m1[9], m2[9];
+            for (int k = 0; k < 9; k++) { m1[k] = S[L.xmat + 9 * b1 + k]; m2[k] = S[L.xmat + 9 * b2 + k]; }
+            for (int k = 0; k < 3; k++) { gp[k] = mb[A.o.geom_pos + 3 * g1 + k]; ce[k] = mb[A.o.geom_center + 3 * g2 + k]; }
+            mat_vec(t, m1, gp);
+            double ppos[3], n[3] = {R[2], R[5], R[8]};
+            for (int k = 0; k < 3; k++) ppos[k] = S[L.xpos + 3 * b1 + k] + t[k];
+            mat_vec(t, m2, ce);
+            double cd = 0;
+            for (int k = 0; k < 3; k++) cd += n[k] * (S[L.xpos + 3 * b2 + k] + t[k] - ppos[k]);
+            const double margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+            keep = !(cd - mb[A.o.geom_rbound + g2] > margin);
+        }
+        unsigned long long mask = __ballot(keep);
+        while (mask) {
+            const int pi = p0 + __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int g1 = T.pair_g1[pi], g2 = T.pair_g2[pi], b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
+            double pq[4], gq[4], xq[4], R[9], t[3], gp[3], m1[9], m2[9], xp2[3];
+            for (int k = 0; k < 4; k++) { gq[k] = mb[A.o.geom_quat + 4 * g1 + k]; xq[k] = S[L.xquat + 4 * b1 + k]; }
+            quat_mul(pq, xq, gq);
+            quat_to_mat(R, pq);
+            for (int k = 0; k < 9; k++) { m1[k] = S[L.xmat + 9 * b1 + k]; m2[k] = S[L.xmat + 9 * b2 + k]; }
+            for (int k = 0; k < 3; k++) { gp[k] = mb[A.o.geom_pos + 3 * g1 + k]; xp2[k] = S[L.xpos + 3 * b2 + k]; }
+            mat_vec(t, m1, gp);
+            double ppos[3], n[3] = {R[2], R[5], R[8]};
+            for (int k = 0; k < 3; k++) ppos[k] = S[L.xpos + 3 * b1 + k] + t[k];
+            const double margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+            const double gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
+            const int va = T.geom_vertadr[g2], vn = T.geom_vertnum[g2];
+            // support vertex along -normal: lane-local min then wave arg-min (ties -> lowest vertex id)
+            double bd = 1e300;
+            int bv = 0x7fffffff;
+            for (int v = va + LANE; v < va + vn; v += UHC_WAVE) {
+                double lv[3] = {mb[A.o.mesh_vert + 3 * v], mb[A.o.mesh_vert + 3 * v + 1], mb[A.o.mesh_vert + 3 * v + 2]}, w[3];
+                mat_vec(w, m2, lv);
+                double dist = 0;
+                for (int k = 0; k < 3; k++) dist += n[k] * (w[k] + xp2[k] - ppos[k]);
+                if (dist < bd) { bd = dist; bv = v; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double od = __shfl_xor(bd, o);
+                const int ov = __shfl_xor(bv, o);
+                if (od < bd || (od == bd && ov < bv)) { bd = od; bv = ov; }
+            }
+            if (bd > margin) continue;
+            // candidate 0 = support vertex, candidates 1.. = its hull neighbours (adjacency order)
+            const int e0 = T.mesh_adjadr[bv], deg = T.mesh_adjadr[bv + 1] - e0;
+            bool ok = false;
+            double w[3] = {0, 0, 0}, dist = 0;
+            if (LANE <= deg && LANE < UHC_WAVE) {
+                const int v = LANE == 0 ? bv : T.mesh_adj[e0 + LANE - 1];
+                double lv[3] = {mb[A.o.mesh_vert + 3 * v], mb[A.o.mesh_vert + 3 * v + 1], mb[A.o.mesh_vert + 3 * v + 2]};
+                mat_vec(w, m2, lv);
+                for (int k = 0; k < 3; k++) { w[k] += xp2[k]; dist += n[k] * (w[k] - ppos[k]); }
+                ok = LANE == 0 || dist <= margin;
+            }
+            const unsigned long long cm = __ballot(ok);
+            const int rank = __popcll(cm & ((1ull << LANE) - 1ull));
+            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < UHC_MAXCON)
+                k_write_contact(A, mb, S, ncon + rank, g1, g2, w, n, dist, margin, gap);
+            ncon = min(UHC_MAXCON, ncon + min((int)__popcll(cm), T.plane_mesh_maxcon));
+        }
+    }
+    wsync();
+    return ncon;
+}
+
+// ------------------------------------------------------------------ P5 constraint rows (row-per-lane) + half-solved Jacobian
+// row types
+#define ROW_FRICTION 1
+#define ROW_LIMIT 2
+#define ROW_CONTACT 3
+#define ROW_PYR 4
+struct RowMisc { int type, last, aux, edge; };  // aux: contact id | dof ; edge: pyramid edge | sign
+
+__device__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S, int ncon, int* overflow) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    RowMisc* RM = (RowMisc*)(S + L.rowMisc);
+    int nefc = 0;
+    // (1) friction loss
+    for (int i0 = 0; i0 < T.nv; i0 += UHC_WAVE) {
+        const int i = i0 + LANE;
+        const bool has = i < T.nv && mb[A.o.dof_frictionloss + i] > 0;
+        const unsigned long long m = __ballot(has);
+        const int r = nefc + __popcll(m & ((1ull << LANE) - 1ull));
+        if (has && r < UHC_MAXEFC) { RM[r].type = ROW_FRICTION; RM[r].last = i; RM[r].aux = i; RM[r].edge = 1; }
+        nefc += __popcll(m);
+    }
+    // (2) joint limits: lower side then upper side of each joint, joints in order
+    for (int j0 = 0; j0 < T.njnt; j0 += UHC_WAVE) {
+        const int j = j0 + LANE;
+        bool lo = false, hi = false;
+        if (j < T.njnt && T.jnt_limited[j]) {
+            const int jt = T.jnt_type[j];
+            if (jt == UHC_JNT_HINGE || jt == UHC_JNT_SLIDE) {
+                const double v = S[L.qpos + T.jnt_qposadr[j]], mg = mb[A.o.jnt_margin + j];
+                lo = (v - mb[A.o.jnt_range + 2 * j]) < mg;
+                hi = (mb[A.o.jnt_range + 2 * j + 1] - v) < mg;
+            }
+        }
+        const unsigned long long ml = __ballot(lo), mh = __ballot(hi), below = (1ull << LANE) - 1ull;
+        int r = nefc + __popcll(ml & below) + __popcll(mh & below);
+        if (lo) { if (r < UHC_MAXEFC) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = -1; } r++; }
+        if (hi) { if (r < UHC_MAXEFC) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = 1; } }
+        nefc += __popcll(ml) + __popcll(mh);
+    }
+    wsync();
+    // (3) contacts
+    if (LANE == 0) {
+        int r = nefc;
+        for (int c = 0; c < ncon; c++) {
+            const double* C = S + L.con + c * UHC_CON_STRIDE;
+            if (C[12] >= C[13]) continue;
+            const int dim = (int)C[21], b2 = (int)C[20];
+            const int nr = dim == 1 ? 1 : 4, last = T.body_lastdof[b2];
+            for (int e = 0; e < nr; e++, r++)
+                if (r < UHC_MAXEFC) { RM[r].type = dim == 1 ? ROW_CONTACT : ROW_PYR; RM[r].last = last; RM[r].aux = c; RM[r].edge = e; }
+        }
+        ((int*)(S + L.ncon_nefc))[1] = r;
+    }
+    wsync();
+    nefc = ((int*)(S + L.ncon_nefc))[1];
+    if (nefc > UHC_MAXEFC) { *overflow = 1; nefc = UHC_MAXEFC; }
+    return nefc;
+}
+
+// Per row (lane r and r+64): J over the dof chain of the row, reference acceleration, R, warm-start
+// force, and Yhat = D^-1/2 L^-T J^T stored chain-sparse (index = depth of the dof).
+__device__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nefc) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
+    const int YS = T.maxdepth + 1;
+    for (int r = LANE; r < nefc; r += UHC_WAVE) {
+        const RowMisc rm = RM[r];
+        const int last = rm.last, len = T.dof_depth[last] + 1;
+        const short* anc = T.dof_anc + last * YS;
+        double* Y = S + L.Y + r * YS;
+        double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
+        if (rm.type == ROW_FRICTION || rm.type == ROW_LIMIT) {
+            const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+            const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
+            K = 1.0 / (dmax * dmax * timeconst * timeconst);
+            B = 2.0 / (dmax * timeconst);
+            if (rm.type == ROW_LIMIT) {
+                const int j = rm.aux;
+                const double v = S[L.qpos + T.jnt_qposadr[j]];
+                margin = mb[A.o.jnt_margin + j];
+                pos = rm.edge < 0 ? v - mb[A.o.jnt_range + 2 * j] : mb[A.o.jnt_range + 2 * j + 1] - v;
+                for (int q = 0; q < len; q++) Y[q] = 0;
+                Y[len - 1] = -(double)rm.edge;
+            } else {
+                floss = mb[A.o.dof_frictionloss + last];
+                for (int q = 0; q < len; q++) Y[q] = 0;
+                Y[len - 1] = 1;
+            }
+            diagApprox = mb[A.o.dof_invweight0 + last];
+            imp = impedance(dsolimp, pos, margin);
+        } else {
+            const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
+            const int b2 = (int)C[20];
+            const int root = T.body_rootid[b2];
+            double off[3], dv[3];
+            const double mu = C[14];
+            for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
+            if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+            else {
+                const double sgn = (rm.edge & 1) ? -1.0 : 1.0;
+                const int td = 1 + rm.edge / 2;
+                for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
+            }
+            for (int q = 0; q < len; q++) {
+                const int i = anc[q];
+                double cd[6], cr[3];
+                for (int s = 0; s < 6; s++) cd[s] = S[L.cdof + 6 * i + s];
+                cross3(cr, cd, off);
+                Y[q] = dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]);
+            }
+            pos = C[12]; margin = C[13]; K = C[15]; B = C[16]; imp = C[17];
+            diagApprox = rm.type == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
+            if (rm.type == ROW_PYR) {
+                // all edges of a pyramid share R = 2 mu^2 R(first edge); first edge uses friction[0] = mu
+                const double R0 = fmax(UHC_MINVAL, (1 - imp) * (C[18] + mu * mu * C[18]) / imp);
+                diagApprox = -2 * mu * mu * R0;  // negative => final R given directly
+            }
+        }
+        double vel = 0, jas = 0, jaw = 0;
+        for (int q = 0; q < len; q++) {
+            const int i = anc[q];
+            const double j = Y[q];
+            vel += j * S[L.qvel + i];
+            jas += j * S[L.smooth + i];
+            jaw += j * S[L.qacc + i];
+        }
+        const double R = diagApprox < 0 ? -diagApprox : fmax(UHC_MINVAL, (1 - imp) * diagApprox / imp);
+        const double aref = -B * vel - K * imp * (pos - margin);
+        const double jar = jaw - aref, D = 1.0 / R;
+        double f;
+        if (rm.type == ROW_FRICTION) f = clampd(-D * jar, -floss, floss);
+        else f = jar < 0 ? -D * jar : 0.0;
+        // Y <- L^-T Y restricted to the chain, then scale by sqrt(1/D_i)
+        for (int q = len - 1; q >= 1; q--) {
+            const int i = anc[q];
+            const double xi = Y[q];
+            const int mi = T.dof_madr[i];
+            for (int q2 = q - 1; q2 >= 0; q2--) Y[q2] -= S[L.LD + mi + (q - q2)] * xi;
+        }
+        double da = R;
+        for (int q = 0; q < len; q++) {
+            const double y = Y[q] * sqrt(S[L.dinv + anc[q]]);
+            Y[q] = y;
+            da += y * y;
+        }
+        S[L.rowR + r] = R;
+        S[L.rowAref + r] = floss;        // (aref itself is folded into b; the slot keeps the friction-loss bound)
+        S[L.rowB + r] = jas - aref;
+        S[L.rowF + r] = f;
+        S[L.rowDa + r] = da;             // diagonal of A + R
+    }
+    wsync();
+}
+
+// ------------------------------------------------------------------ P9 projected Gauss-Seidel on the dual (matrix-free)
+// z = sum_r f_r Yhat_r  (nv vector in LDS);  (A f)_r = Yhat_r . z[chain_r].
+__device__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
+    const int YS = T.maxdepth + 1;
+    double* z = S + L.z;
+    // z from the warm-start forces: dof-per-lane pull over all rows
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        const int di = T.dof_depth[i], nd = T.dof_ndesc[i];
+        double acc = 0;
+        for (int r = 0; r < nefc; r++) {
+            const int last = RM[r].last;
+            if (last >= i && last <= i + nd) acc += S[L.rowF + r] * S[L.Y + r * YS + di];
+        }
+        z[i] = acc;
+    }
+    wsync();
+    // dual cost of the warm start; fall back to zero forces if it is not an improvement
+    double cost = 0;
+    for (int r = LANE; r < nefc; r += UHC_WAVE) {
+        const int last = RM[r].last, len = T.dof_depth[last] + 1;
+        const short* anc = T.dof_anc + last * YS;
+        const double f = S[L.rowF + r];
+        double af = S[L.rowR + r] * f;
+        for (int q = 0; q < len; q++) af += S[L.Y + r * YS + q] * z[anc[q]];
+        cost += f * (0.5 * af + S[L.rowB + r]);
+    }
+    cost = wave_sum(cost);
+    if (cost > 0) {
+        for (int r = LANE; r < nefc; r += UHC_WAVE) S[L.rowF + r] = 0;
+        for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0;
+    }
+    wsync();
+    const double scale = 1.0 / (mb[A.o.meaninertia] * (T.nv > 1 ? T.nv : 1));
+    int iters = 0;
+    for (int it = 0; it < T.iterations; it++) {
+        double improvement = 0;
+        for (int r = 0; r < nefc; r++) {
+            const RowMisc rm = RM[r];
+            const int len = T.dof_depth[rm.last] + 1;
+            int dof = 0;
+            double y = 0, part = 0;
+            if (LANE < len) {
+                dof = T.dof_anc[rm.last * YS + LANE];
+                y = S[L.Y + r * YS + LANE];
+                part = y * z[dof];
+            }
+            const double old = S[L.rowF + r], Rr = S[L.rowR + r], Arr = S[L.rowDa + r];
+            const double res = wave_sum(part) + Rr * old + S[L.rowB + r];
+            double f = old - res / Arr;
+            if (rm.type == ROW_FRICTION) { const double fl = S[L.rowAref + r]; f = clampd(f, -fl, fl); }
+            else f = f < 0 ? 0.0 : f;
+            double delta = f - old;
+            double change = 0.5 * delta * delta * Arr + delta * res;
+            if (change > 1e-10) { f = old; delta = 0; change = 0; }
+            improvement -= change;
+            if (delta != 0) {
+                if (LANE < len) z[dof] += delta * y;
+                if (LANE == 0) S[L.rowF + r] = f;
+            }
+            wsync();
+        }
+        iters = it + 1;
+        if (improvement * scale < T.tolerance) break;
+    }
+    return iters;
+}
+
+// ------------------------------------------------------------------ mj_forward
+struct FwdOut { int ncon, nefc, iters, overflow; };
+__device__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    FwdOut out = {0, 0, 0, 0};
+    k_kinematics(A, mb, S);
+    k_com_pos(A, mb, S);
+    k_crb(A, mb, S);
+    for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    wsync();
+    k_factor(A, S, L.LD);
+    k_com_vel(A, S);
+    k_rne(A, S);
+    k_smooth(A, mb, S);
+    out.ncon = k_collision(A, mb, S);
+    out.nefc = k_enumerate_rows(A, mb, S, out.ncon, &out.overflow);
+    DofVec x = {0.0, 0.0};
+    if (out.nefc > 0) {
+        k_rows(A, mb, S, out.nefc);
+        out.iters = k_pgs(A, mb, S, out.nefc);
+        // qacc = qacc_smooth + L^-1 D^-1/2 z
+        if (LANE < T.nv) x.a = S[L.z + LANE] * sqrt(S[L.dinv + LANE]);
+        if (LANE + UHC_WAVE < T.nv) x.b = S[L.z + LANE + UHC_WAVE] * sqrt(S[L.dinv + LANE + UHC_WAVE]);
+        k_solve(A, S, L.LD, x, 1);
+    }
+    if (LANE < T.nv) S[L.qacc + LANE] = S[L.smooth + LANE] + x.a;
+    if (LANE + UHC_WAVE < T.nv) S[L.qacc + LANE + UHC_WAVE] = S[L.smooth + LANE + UHC_WAVE] + x.b;
+    wsync();
+    return out;
+}
+
+// ------------------------------------------------------------------ P10 semi-implicit Euler
+__device__ void k_euler(const KernelArgs& A, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const double h = T.timestep;
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.qvel + i] += h * S[L.qacc + i];
+    wsync();
+    for (int j = LANE; j < T.njnt; j += UHC_WAVE) {
+        int qa = T.jnt_qposadr[j], da = T.jnt_dofadr[j];
+        const int jt = T.jnt_type[j];
+        if (jt == UHC_JNT_FREE) {
+            for (int k = 0; k < 3; k++) S[L.qpos + qa + k] += h * S[L.qvel + da + k];
+            qa += 3; da += 3;
+        }
+        if (jt == UHC_JNT_FREE || jt == UHC_JNT_BALL) {
+            double w[3] = {S[L.qvel + da], S[L.qvel + da + 1], S[L.qvel + da + 2]}, qr[4], q[4];
+            const double n = sqrt(dot3(w, w));
+            if (n < UHC_MINVAL) { w[0] = 1; w[1] = w[2] = 0; } else { w[0] /= n; w[1] /= n; w[2] /= n; }
+            axis_angle_quat(qr, w, h * n);
+            for (int k = 0; k < 4; k++) q[k] = S[L.qpos + qa + k];
+            quat_mul(q, q, qr);
+            quat_normalize(q);
+            for (int k = 0; k < 4; k++) S[L.qpos + qa + k] = q[k];
+        } else {
+            S[L.qpos + qa] += h * S[L.qvel + da];
+        }
+    }
+    wsync();
+}
+__device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVAL || x < -UHC_MAXVAL; }
+
+// ------------------------------------------------------------------ E3/E4 stable PD, E5 implicit residual force
+// compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
+// previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
+__device__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const DevCtrl& C = A.c;
+    const double dt = T.timestep;
+    const int nu = T.nu, vf = C.rfc_mode == 1 ? 6 : 0;
+    double skp = 1, skd = 1;
+    if (C.meta_pd == 1) {
+        skp = clampd(action[nu + vf + it] + 1, 0, 10);
+        skd = clampd(action[nu + vf + it + C.n_substeps] + 1, 0, 10);
+    }
+    for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    wsync();
+    // lane owns dofs LANE and LANE+64; actuator a drives dof 6+a (free root first)
+    double kp[2] = {0, 0}, kd[2] = {0, 0}, qe[2] = {0, 0}, qv[2] = {0, 0};
+    for (int h = 0; h < 2; h++) {
+        const int i = LANE + h * UHC_WAVE, a = i - 6;
+        if (i < T.nv) qv[h] = S[L.qvel + i];
+        if (a >= 0 && a < nu) {
+            const double cur = S[L.qpos + 7 + a];
+            double base = tbase[a];
+            while (base - cur > M_PI) base -= 2 * M_PI;
+            while (base - cur < -M_PI) base += 2 * M_PI;
+            double gkp = C.jkp[a], gkd = C.jkd[a];
+            if (C.meta_pd == 1) { gkp *= skp; gkd *= skd; }
+            else if (C.meta_pd == 2) {
+                gkp *= clampd(action[nu + vf + a] + 1, 0, 10);
+                gkd *= clampd(action[nu + vf + nu + a] + 1, 0, 10);
+            }
+            kp[h] = gkp; kd[h] = gkd;
+            qe[h] = cur + qv[h] * dt - (base + action[a]);
+            S[L.LD + T.dof_madr[i]] += gkd * dt;
+        }
+    }
+    wsync();
+    k_factor(A, S, L.LD);
+    DofVec x;
+    x.a = LANE < T.nv ? -S[L.bias + LANE] - kp[0] * qe[0] - kd[0] * qv[0] : 0.0;
+    x.b = LANE + UHC_WAVE < T.nv ? -S[L.bias + LANE + UHC_WAVE] - kp[1] * qe[1] - kd[1] * qv[1] : 0.0;
+    k_solve(A, S, L.LD, x, 0);
+    for (int h = 0; h < 2; h++) {
+        const int a = LANE + h * UHC_WAVE - 6;
+        if (a >= 0 && a < nu) {
+            const double qdd = h ? x.b : x.a;
+            const double tq = -kp[h] * qe[h] - kd[h] * (qv[h] + qdd * dt);
+            S[L.ctrl + a] = clampd(tq, -C.torque_lim[a], C.torque_lim[a]);
+        }
+    }
+    wsync();
+}
+__device__ void k_rfc_implicit(const KernelArgs& A, double* S, const double* action) {
+    const DevLds& L = A.l;
+    const DevCtrl& C = A.c;
+    if (LANE == 0) {
+        double vf[6], q[4], rq[4], hq[4], R[9], r[3];
+        for (int k = 0; k < 6; k++) vf[k] = action[A.t.nu + k] * C.rfc_scale;
+        for (int k = 0; k < 4; k++) rq[k] = S[L.qpos + 3 + k];
+        quat_mul(q, rq, C.base_rot_inv);
+        const double n = sqrt(q[0] * q[0] + q[3] * q[3]);  // get_heading_q: math_utils.py:134-139
+        hq[0] = q[0] / n; hq[1] = 0; hq[2] = 0; hq[3] = q[3] / n;
+        quat_to_mat(R, hq);
+        mat_vec(r, R, vf);
+        for (int k = 0; k < 3; k++) vf[k] = r[k];
+        for (int k = 0; k < 6; k++) S[L.applied + k] = clampd(vf[k], -C.rfc_lim, C.rfc_lim);
+    }
+    wsync();
+}
+
+// ------------------------------------------------------------------ the kernels
+// MODE 0: do_simulation (n_substeps of control + step);  MODE 1: forward only (after set_state)
+template <int MODE>
+__global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
+                                                            const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
+    const int env = blockIdx.x;
+    if (env >= A.n_env) return;
+    if (d_active && !d_active[env]) return;
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    double* S = smem;
+    const double* mb = A.s.model_blob + (size_t)(A.s.env_model ? A.s.env_model[env] : 0) * A.o.stride;
+    int fail = MODE == 0 ? A.s.fail[env] : 0;
+    // ---- load state (coalesced: consecutive lanes, consecutive doubles)
+    for (int i = LANE; i < T.nq; i += UHC_WAVE) S[L.qpos + i] = A.s.qpos[(size_t)env * T.nq + i];
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        S[L.qvel + i] = A.s.qvel[(size_t)env * T.nv + i];
+        S[L.qacc + i] = A.s.qacc_ws[(size_t)env * T.nv + i];  // warm start (MuJoCo qacc_warmstart)
+        S[L.applied + i] = A.s.applied[(size_t)env * T.nv + i];
+        if (MODE == 0) S[L.bias + i] = A.s.bias[(size_t)env * T.nv + i];
+    }
+    for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
+    if (MODE == 0) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
+    wsync();
+    FwdOut fo = {0, 0, 0, 0};
+    int overflow = 0;
+    bool ran = false;
+    if (MODE == 1) {
+        fo = k_forward(A, mb, S);
+        overflow |= fo.overflow;
+        ran = true;
+    } else if (!fail) {
+        const double* action = d_action + (size_t)env * A.c.action_dim;
+        const double* tbase = d_tbase + (size_t)env * T.nu;
+        for (int it = 0; it < A.c.n_substeps; it++) {
+            if (A.c.action_type == 0) k_pd_torque(A, S, action, tbase, it);
+            else {
+                for (int a = LANE; a < T.nu; a += UHC_WAVE)
+                    S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
+                wsync();
+            }
+            if (A.c.rfc_mode == 1) k_rfc_implicit(A, S, action);
+            // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
+            int b = 0;
+            for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
+            for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
+            if (wave_or(b)) { fail = 1; break; }
+            fo = k_forward(A, mb, S);
+            overflow |= fo.overflow;
+            ran = true;
+            b = 0;
+            for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
+            if (wave_or(b)) { fail = 1; break; }
+            k_euler(A, S);
+        }
+    }
+    // ---- store state
+    for (int i = LANE; i < T.nq; i += UHC_WAVE) A.s.qpos[(size_t)env * T.nq + i] = S[L.qpos + i];
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        A.s.qvel[(size_t)env * T.nv + i] = S[L.qvel + i];
+        A.s.qacc[(size_t)env * T.nv + i] = S[L.qacc + i];
+        if (MODE == 0 && ran) A.s.qacc_ws[(size_t)env * T.nv + i] = S[L.qacc + i];  // mj_forward alone leaves the warm start
+        A.s.applied[(size_t)env * T.nv + i] = S[L.applied + i];
+    }
+    for (int i = LANE; i < T.nu; i += UHC_WAVE) A.s.ctrl[(size_t)env * T.nu + i] = S[L.ctrl + i];
+    if (ran) {
+        for (int i = LANE; i < T.nv; i += UHC_WAVE) A.s.bias[(size_t)env * T.nv + i] = S[L.bias + i];
+        for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
+        for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
+            A.s.xpos[(size_t)env * 3 * T.nbody + i] = S[L.xpos + i];
+            A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
+        }
+        for (int i = LANE; i < 4 * T.nbody; i += UHC_WAVE) A.s.xquat[(size_t)env * 4 * T.nbody + i] = S[L.xquat + i];
+    }
+    if (LANE == 0) {
+        if (ran) { A.s.ncon[env] = fo.ncon; A.s.nefc[env] = fo.nefc; A.s.solver_iter[env] = fo.iters; }
+        A.s.fail[env] = fail;
+        if (overflow) A.s.overflow[env] = 1;
+    }
+}
+
+// set_state: scatter rows of (qpos, qvel) into the listed envs, clear warm start / flags
+__global__ void uhc_set_state_kernel(DevState s, int nq, int nv, int nu, const int* env_ids, int n, const double* qpos,
+                                     const double* qvel, int* mask) {
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const int env = env_ids ? env_ids[r] : r;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) s.qpos[(size_t)env * nq + i] = qpos[(size_t)r * nq + i];
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+        s.qvel[(size_t)env * nv + i] = qvel[(size_t)r * nv + i];
+        s.qacc[(size_t)env * nv + i] = 0;
+        s.qacc_ws[(size_t)env * nv + i] = 0;
+        s.applied[(size_t)env * nv + i] = 0;
+    }
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) s.ctrl[(size_t)env * nu + i] = 0;
+    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; mask[env] = 1; }
+}
+
+// host-callable launchers (defined here so the kernels stay in one translation unit)
+extern "C" hipError_t uhc_launch_step(int mode, const KernelArgs* A, const double* d_action, const double* d_tbase,
+                                      const int* d_active, size_t lds_bytes, hipStream_t stream) {
+    dim3 grid(A->n_env), block(UHC_WAVE);
+    if (mode == 0) hipLaunchKernelGGL(uhc_step_kernel<0>, grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    else hipLaunchKernelGGL(uhc_step_kernel<1>, grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    return hipGetLastError();
+}
+extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)uhc_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)uhc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
+                                           const double* qpos, const double* qvel, int* mask, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_set_state_kernel, dim3(n), dim3(UHC_WAVE), 0, stream, *s, nq, nv, nu, env_ids, n, qpos, qvel, mask);
+    return hipGetLastError();
+}

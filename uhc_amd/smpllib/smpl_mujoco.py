@@ -1,0 +1,109 @@
+"""SMPL <-> simulation-model conversion tables (mirror of uhc/smpllib/smpl_mujoco.py).
+
+``SMPLConverter`` keeps the reference's names and argument meaning
+(reference: uhc/smpllib/smpl_mujoco.py:36-281) but takes this build's compiled
+``Model`` objects (uhc_amd/model/mjcf.py) in place of mujoco-py models.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+_LOWER = ["L_Hip", "L_Knee", "L_Ankle", "L_Toe", "R_Hip", "R_Knee", "R_Ankle", "R_Toe"]
+
+# per-body [kp, kd, a_scale, torque_limit]  (smpl_mujoco.py:66-91; the L/R asymmetry of
+# Thorax/Shoulder torque limits is in the reference and is reproduced as is)
+_BODY_PARAMS_SMPL = {
+    "L_Hip": [500, 50, 1, 500], "L_Knee": [500, 50, 1, 500], "L_Ankle": [400, 40, 1, 500], "L_Toe": [200, 20, 1, 500],
+    "R_Hip": [500, 50, 1, 500], "R_Knee": [500, 50, 1, 500], "R_Ankle": [400, 40, 1, 500], "R_Toe": [200, 20, 1, 500],
+    "Torso": [1000, 100, 1, 500], "Spine": [1000, 100, 1, 500], "Chest": [1000, 100, 1, 500],
+    "Neck": [100, 10, 1, 250], "Head": [100, 10, 1, 250],
+    "L_Thorax": [400, 40, 1, 500], "L_Shoulder": [400, 40, 1, 500], "L_Elbow": [300, 30, 1, 150],
+    "L_Wrist": [100, 10, 1, 150], "L_Hand": [100, 10, 1, 150],
+    "R_Thorax": [400, 40, 1, 150], "R_Shoulder": [400, 40, 1, 250], "R_Elbow": [300, 30, 1, 150],
+    "R_Wrist": [100, 10, 1, 150], "R_Hand": [100, 10, 1, 150],
+}
+# body-position difference weights (smpl_mujoco.py:40-65): toes and hands do not count
+_BODY_WS_SMPL = {n: 1.0 for n in ["Pelvis"] + list(_BODY_PARAMS_SMPL)}
+for _n in ("L_Toe", "R_Toe", "L_Hand", "R_Hand"):
+    _BODY_WS_SMPL[_n] = 0.0
+
+
+def get_body_qposaddr(model) -> "OrderedDict[str, tuple]":
+    """body name -> (start, end) qpos slice (uhc/khrylib/utils/mujoco.py get_body_qposaddr)."""
+    out = OrderedDict()
+    for b, name in enumerate(model.body_names):
+        ja, jn = model.body_jntadr[b], model.body_jntnum[b]
+        if jn == 0 or ja < 0:
+            continue
+        start = int(model.jnt_qposadr[ja])
+        end = int(model.jnt_qposadr[ja + jn]) if ja + jn < model.njnt else int(model.nq)
+        out[name] = (start, end)
+    return out
+
+
+def get_body_qveladdr(model) -> "OrderedDict[str, tuple]":
+    out = OrderedDict()
+    for b, name in enumerate(model.body_names):
+        ja, jn = model.body_jntadr[b], model.body_jntnum[b]
+        if jn == 0 or ja < 0:
+            continue
+        start = int(model.jnt_dofadr[ja])
+        end = int(model.jnt_dofadr[ja + jn]) if ja + jn < model.njnt else int(model.nv)
+        out[name] = (start, end)
+    return out
+
+
+class SMPLConverter:
+    def __init__(self, model, new_model, smpl_model: str = "smpl"):
+        if smpl_model != "smpl":
+            raise NotImplementedError("only the 24-body SMPL layout is built (SURVEY.md 8f-4)")
+        self.body_ws = dict(_BODY_WS_SMPL)
+        self.body_params = {k: list(v) for k, v in _BODY_PARAMS_SMPL.items()}
+        self.model, self.new_model = model, new_model
+        self.smpl_qpos_addr = get_body_qposaddr(model)
+        self.smpl_qvel_addr = get_body_qveladdr(model)
+        self.new_qpos_addr = get_body_qposaddr(new_model)
+        self.new_qvel_addr = get_body_qveladdr(new_model)
+        self.smpl_joint_names = list(self.smpl_qpos_addr.keys())
+        self.new_joint_names = list(self.new_qpos_addr.keys())
+        self.smpl_nq, self.new_nq = model.nq, new_model.nq
+
+    def get_new_qpos_lim(self):
+        a = self.new_model.jnt_qposadr
+        return int(np.max(a) + a[-1] - a[-2])
+
+    def get_new_qvel_lim(self):
+        a = self.new_model.jnt_dofadr
+        return int(np.max(a) + a[-1] - a[-2])
+
+    def get_new_body_lim(self):
+        return len(self.new_model.body_names)
+
+    def get_new_diff_weight(self):
+        return np.array([self.body_ws[n] if n in self.body_ws else 0 for n in self.new_joint_names])
+
+    def _per_joint(self, col, default):
+        return np.concatenate([[self.body_params[n][col]] * 3 if n in self.body_ws else [default] * 3
+                               for n in self.new_joint_names[1:]]).astype(np.float64)
+
+    def get_new_jkp(self):
+        return self._per_joint(0, 50)
+
+    def get_new_jkd(self):
+        return self._per_joint(1, 5)
+
+    def get_new_a_scale(self):
+        return self._per_joint(2, 1)
+
+    def get_new_torque_limit(self):
+        return self._per_joint(3, 200)
+
+    def qpos_new_2_smpl(self, qpos):
+        subset = np.concatenate([np.arange(*self.new_qpos_addr[jt]) for jt in self.smpl_joint_names])
+        return qpos[:, subset] if qpos.ndim == 2 else qpos[subset]
+
+    def qvel_new_2_smpl(self, qvel):
+        subset = np.concatenate([np.arange(*self.new_qvel_addr[jt]) for jt in self.smpl_joint_names])
+        return qvel[:, subset] if qvel.ndim == 2 else qvel[subset]
