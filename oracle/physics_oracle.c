@@ -676,7 +676,7 @@ void orc_solve_pgs(const UhcModelDesc* m, OrcData* d) {
         for (int r = 0; r < n; r++) {
             double res = d->efc_b[r], old = f[r];
             for (int s = 0; s < n; s++) res += AR[(size_t)r * n + s] * f[s];
-            f[r] = project_force(d, r, old - res / AR[(size_t)r * n + r]);
+            f[r] = project_force(d, r, old - res * (1.0 / AR[(size_t)r * n + r])); /* [MJ-ext] uses a precomputed ARinv */
             double delta = f[r] - old;
             double change = 0.5 * delta * delta * AR[(size_t)r * n + r] + delta * res;
             if (change > 1e-10) { f[r] = old; change = 0; }
@@ -703,6 +703,8 @@ void orc_forward(const UhcModelDesc* m, OrcData* d) {
     orc_factor_m(m, d);
     orc_collision(m, d);
     orc_make_constraint(m, d);
+    if (d->ncon > d->max_ncon) d->max_ncon = d->ncon;
+    if (d->nefc > d->max_nefc) d->max_nefc = d->nefc;
     orc_com_vel(m, d);
     orc_passive(m, d);
     orc_rne_bias(m, d);
@@ -752,7 +754,7 @@ void orc_set_state(const UhcModelDesc* m, OrcData* d, const double* qpos, const 
     memset(d->qacc_warmstart, 0, m->nv * 8);
     memset(d->qfrc_applied, 0, m->nv * 8);
     memset(d->ctrl, 0, (m->nu > 0 ? m->nu : 1) * 8);
-    d->fail = 0; d->efc_overflow = 0;
+    d->fail = 0; d->efc_overflow = 0; d->max_ncon = 0; d->max_nefc = 0;
     orc_forward(m, d);
 }
 
@@ -867,6 +869,8 @@ int orc_get_int(const OrcData* d, const char* name) {
     if (!strcmp(name, "solver_iter")) return d->solver_iter;
     if (!strcmp(name, "efc_overflow")) return d->efc_overflow;
     if (!strcmp(name, "nM")) return d->nM;
+    if (!strcmp(name, "max_ncon")) return d->max_ncon;
+    if (!strcmp(name, "max_nefc")) return d->max_nefc;
     return -1;
 }
 void orc_set(const UhcModelDesc* m, OrcData* d, const char* name, const double* in) {

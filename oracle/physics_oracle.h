@@ -9,7 +9,7 @@
 enum { ORC_EFC_FRICTION = 1, ORC_EFC_LIMIT = 2, ORC_EFC_CONTACT = 3, ORC_EFC_CONTACT_PYR = 4 };
 
 typedef struct OrcData {
-    int nM, ncon, nefc, fail, solver_iter, efc_overflow;
+    int nM, ncon, nefc, fail, solver_iter, efc_overflow, max_ncon, max_nefc; /* max_*: running maxima since set_state */
     double *qpos, *qvel, *qacc, *qacc_warmstart, *ctrl, *qfrc_applied;
     double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis;
     double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel;

@@ -5,6 +5,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+import os
+
+
+@pytest.fixture(params=["fast", "general"], autouse=True)
+def kernel_path(request):
+    """Every parity test runs on the fast kernel (with automatic redo) and on the general kernel alone."""
+    old = os.environ.get("UHC_FORCE_GENERAL")
+    os.environ["UHC_FORCE_GENERAL"] = "1" if request.param == "general" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("UHC_FORCE_GENERAL", None)
+    else:
+        os.environ["UHC_FORCE_GENERAL"] = old
+
+
 def _sim(model, ctrl, n):
     from uhc_amd.sim import SimBatch
     return SimBatch(model, ctrl, n)
@@ -113,3 +128,42 @@ def test_inactive_envs_untouched(model, ctrl, standing):
     after = b.field(S.F_QPOS)
     assert torch.equal(before[1::2], after[1::2])
     assert not torch.equal(before[0::2], after[0::2])
+
+
+def test_many_contacts_take_the_redo_path(model, ctrl, standing, kernel_path):
+    """A humanoid lying on the floor has more than 64 constraint rows: the fast kernel must hand the env
+    to the general kernel and the result must still match the oracle."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    n = 3
+    qpos, qvel = _states(standing, model, n, 7, noise=0.02, vel=0.0)
+    # rotate the root so the body lies face-down just above the floor (world x-axis rotation by -90 deg composed on the left)
+    c, s_ = np.cos(-np.pi / 4), np.sin(-np.pi / 4)
+    for e in range(n):
+        w, x, y, z = qpos[e, 3:7]
+        qpos[e, 3:7] = [c * w - s_ * x, c * x + s_ * w, c * y - s_ * z, c * z + s_ * y]
+        qpos[e, 2] = 0.19 + 0.01 * e
+    b = _sim(model, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    act = np.zeros((n, ctrl.action_dim))
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(model, ctrl) for _ in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    max_nefc = 0
+    for t in range(5):
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:])
+    b.sync()
+    gq = b.field(S.F_QPOS).cpu().numpy()
+    gn = b.field(S.F_NEFC).cpu().numpy()
+    checked = 0
+    for e in range(n):
+        max_nefc = max(max_nefc, os_[e].geti("max_nefc"))
+        if os_[e].geti("max_nefc") <= 128 and os_[e].geti("max_ncon") <= 40:  # inside the general kernel's capacity
+            assert gn[e] == os_[e].geti("nefc")
+            np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-7)
+            checked += 1
+    assert max_nefc > 64 and checked > 0, f"scenario must exceed the fast kernel's capacity and stay inside the general one (max nefc={max_nefc}, checked={checked})"

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,9 +13,9 @@
 #include "../../include/uhc_amd.h"
 #include "uhc_device.h"
 
-extern "C" hipError_t uhc_launch_step(int mode, const KernelArgs* A, const double* d_action, const double* d_tbase,
+extern "C" hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase,
                                       const int* d_active, size_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes);
+extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast);
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream);
 
@@ -109,7 +110,8 @@ struct UhcBatch {
     int n_env = 0, device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     KernelArgs A;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_bytes_fast = 0;
+    bool use_fast = true;
     std::vector<void*> allocs;
     int nM = 0;
     int* reset_mask = nullptr;
@@ -244,6 +246,14 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         int adr = d.dof_madr[i];
         for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) { m_row[adr] = (short)i; m_col[adr] = (short)j; }
     }
+    std::vector<unsigned char> ncommon((size_t)nv * nv, 0);
+    for (int i = 0; i < nv; i++)
+        for (int j = 0; j < nv; j++) {
+            int q = 0;
+            const int lim = std::min(dof_depth[i], dof_depth[j]);
+            while (q <= lim && dof_anc[(size_t)i * YS + q] == dof_anc[(size_t)j * YS + q]) q++;
+            ncommon[(size_t)i * nv + j] = (unsigned char)q;
+        }
     // statically filtered collision pairs (plane, mesh)
     std::vector<int> pg1, pg2;
     int skipped_pairs = 0;
@@ -278,7 +288,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.dof_bodyid, nv), &T.dof_bodyid)); TRY(upload(b, ivec(d.dof_jntid, nv), &T.dof_jntid));
     TRY(upload(b, ivec(d.dof_parentid, nv), &T.dof_parentid)); TRY(upload(b, ivec(d.dof_madr, nv + 1), &T.dof_madr));
     TRY(upload(b, dof_depth, &T.dof_depth)); TRY(upload(b, dof_ndesc, &T.dof_ndesc));
-    TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
+    TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
     TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
     TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
@@ -331,14 +341,57 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.total = off;
     b->lds_bytes = (size_t)off * sizeof(double);
     if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }
-    HIP_OK(uhc_set_lds_limit(b->lds_bytes));
+    // ---- fast layout: persistent part + one region shared by the dynamics temporaries (phase 1) and the
+    //      constraint data (phase 2); target 40 KiB per workgroup => 4 workgroups (one per SIMD) per CU
+    {
+        DevLds& F = A.lf;
+        off = 0;
+        F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
+        F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.vec = F.z;
+        F.LD = carve(T.nM); F.M = F.LD;
+        F.cdof = carve(6 * nv);
+        F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);
+        const int base = off;
+        // phase 1
+        F.cinert = carve(10 * nb);
+        const int r2 = off;
+        F.ximat = carve(9 * nb); F.xanchor = carve(3 * nj); F.xaxis = carve(3 * nj);  // dead after k_com_pos
+        const int endA = off;
+        off = r2;
+        F.cdofdot = carve(6 * nv);
+        const int r3 = off;
+        F.crb = carve(10 * nb);                                                        // k_crb only
+        const int endB = off;
+        off = r3;
+        F.cvel = carve(6 * nb); F.cacc = carve(6 * nb); F.cfrc = carve(6 * nb);         // k_com_vel .. k_rne
+        const int end1 = std::max(std::max(endA, endB), off);
+        // phase 2
+        off = base;
+        F.con = carve(UHC_FAST_MAXCON * UHC_CON_STRIDE);
+        F.rowMisc = carve(UHC_WAVE * 2);
+        F.ncon_nefc = carve(2);
+        F.Y = off;
+        const int budget = 40 * 1024 / 8;
+        int ycap = budget - off;
+        const int need1 = end1 - off;  // phase 1 may need more than the constraint data
+        if (ycap < need1) ycap = need1;
+        if (ycap < 8 * YS) ycap = 8 * YS;
+        A.ycap = ycap;
+        off += ycap;
+        F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.Y;  // unused by the fast kernel
+        F.total = off;
+        b->lds_bytes_fast = (size_t)off * sizeof(double);
+        const char* env = getenv("UHC_FORCE_GENERAL");
+        b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024;
+    }
+    HIP_OK(uhc_set_lds_limit(b->lds_bytes, b->lds_bytes_fast));
 
     // ---- state
     DevState& S = A.s;
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * T.nM, &S.qM_tmp)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
     TRY(dalloc(b, E, &S.overflow));
@@ -394,11 +447,22 @@ extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n)
     if (n) *n = b->field_count[f];
     return 0;
 }
+// fast kernel on every (active) env, then the general kernel on the envs that raised redo
+static int launch(UhcBatch* b, int mode, const double* d_action, const double* d_tbase, const int* d_active) {
+    if (b->use_fast) {
+        HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env, b->stream));
+        HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
+        HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
+    } else {
+        HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
+    }
+    return 0;
+}
+
 extern "C" int32_t uhc_batch_forward(UhcBatch* b) {
     if (!b) return fail("uhc_batch_forward: null batch");
     HIP_OK(hipSetDevice(b->device));
-    HIP_OK(uhc_launch_step(1, &b->A, nullptr, nullptr, nullptr, b->lds_bytes, b->stream));
-    return 0;
+    return launch(b, 1, nullptr, nullptr, nullptr);
 }
 extern "C" int32_t uhc_batch_set_state(UhcBatch* b, const int32_t* d_env_ids, int32_t n, const double* d_qpos, const double* d_qvel) {
     if (!b || !d_qpos || !d_qvel) return fail("uhc_batch_set_state: null argument");
@@ -408,12 +472,10 @@ extern "C" int32_t uhc_batch_set_state(UhcBatch* b, const int32_t* d_env_ids, in
     HIP_OK(hipMemsetAsync(b->reset_mask, 0, sizeof(int) * b->n_env, b->stream));
     HIP_OK(uhc_launch_set_state(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, d_env_ids, n, d_qpos, d_qvel, b->reset_mask, b->stream));
     // sim.forward() on the listed envs only (the others keep their one-substep-stale qM / qfrc_bias)
-    HIP_OK(uhc_launch_step(1, &b->A, nullptr, nullptr, b->reset_mask, b->lds_bytes, b->stream));
-    return 0;
+    return launch(b, 1, nullptr, nullptr, b->reset_mask);
 }
 extern "C" int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const double* d_target_base, const int32_t* d_active) {
     if (!b || !d_action || !d_target_base) return fail("uhc_batch_simulate: null argument");
     HIP_OK(hipSetDevice(b->device));
-    HIP_OK(uhc_launch_step(0, &b->A, d_action, d_target_base, d_active, b->lds_bytes, b->stream));
-    return 0;
+    return launch(b, 0, d_action, d_target_base, d_active);
 }

@@ -6,7 +6,8 @@
 
 #define UHC_WAVE 64
 #define UHC_MAXEFC 128   // constraint rows per env (2 per lane)
-#define UHC_MAXCON 40    // contacts per env
+#define UHC_MAXCON 40    // contacts per env (general kernel)
+#define UHC_FAST_MAXCON 16  // contacts per env (fast kernel)
 #define UHC_CON_STRIDE 24
 #define UHC_MINVAL 1e-15
 #define UHC_MAXVAL 1e10
@@ -22,6 +23,7 @@ struct DevTopo {
     const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_madr, *dof_depth, *dof_ndesc;
     const short* dof_anc;  // [nv][maxdepth+1]: ancestor of dof i at depth q (q <= depth(i)), anc[i][depth(i)] = i
     const short *m_row, *m_col;  // [nM] sparse-M entry -> (i, j)
+    const unsigned char* dof_ncommon;  // [nv][nv] number of common chain entries of two dofs (depth of LCA + 1, 0 if none)
     const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
     const int *mesh_adjadr, *mesh_adj;
     const int *pair_g1, *pair_g2;  // statically filtered candidate geom pairs (g1 = plane, g2 = mesh)
@@ -57,8 +59,8 @@ struct DevCtrl {
 };
 
 struct DevState {  // HBM, env-major
-    double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
-    int *ncon, *nefc, *fail, *solver_iter, *overflow;
+    double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *qM_tmp, *bias, *ctrl, *applied;
+    int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     const int* env_model;
     const double* model_blob;
 };
@@ -66,7 +68,9 @@ struct DevState {  // HBM, env-major
 struct KernelArgs {
     DevTopo t;
     DevNumOff o;
-    DevLds l;
+    DevLds l;   // general kernel: every buffer separate, 128 rows
+    DevLds lf;  // fast kernel: phase-aliased, 64 rows, packed Yhat
+    int ycap;   // doubles available for packed Yhat rows in the fast layout
     DevCtrl c;
     DevState s;
     int n_env;

@@ -9,12 +9,15 @@
 // P5 k_rows, P6/P9 k_pgs, P7 k_com_vel + k_rne, P8 k_smooth, P10 k_euler, E3/E4 k_pd_torque,
 // E5 k_rfc_implicit.  The reference call sites these replace: uhc/envs/humanoid_im.py:1145-1190
 // (do_simulation), :1014-1076 (PD), :1136-1143 (RFC), and MuJoCo's mj_step behind self.sim.step().
+#include <type_traits>
 #include "../../include/uhc_amd.h"
 #include "uhc_device.h"
 
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
 #define LANE ((int)threadIdx.x)
+#define MAXCON_OF(FAST) ((FAST) ? UHC_FAST_MAXCON : UHC_MAXCON)
+#define MAXEFC_OF(FAST) ((FAST) ? UHC_WAVE : UHC_MAXEFC)
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
 // ------------------------------------------------------------------ lane helpers
@@ -102,9 +105,10 @@ __device__ __forceinline__ double dot6(const double* a, const double* b) {
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 // ------------------------------------------------------------------ P1 kinematics: body-per-lane, level-synchronous
-__device__ void k_kinematics(const KernelArgs& A, const double* mb, double* S) {
+template <bool FAST>
+__device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     double *xpos = S + L.xpos, *xquat = S + L.xquat, *xmat = S + L.xmat, *xipos = S + L.xipos, *ximat = S + L.ximat;
     if (b == 0) {
@@ -175,9 +179,10 @@ __device__ void k_kinematics(const KernelArgs& A, const double* mb, double* S) {
 }
 
 // ------------------------------------------------------------------ P2 comPos: tree COM, cinert (body/lane), cdof (joint/lane)
-__device__ void k_com_pos(const KernelArgs& A, const double* mb, double* S) {
+template <bool FAST>
+__device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb, double* S) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     const bool act = b > 0 && b < T.nbody;
     const double mass = act ? mb[A.o.body_mass + b] : 0.0;
@@ -242,9 +247,10 @@ __device__ void k_com_pos(const KernelArgs& A, const double* mb, double* S) {
 }
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
-__device__ void k_crb(const KernelArgs& A, const double* mb, double* S) {
+template <bool FAST>
+__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     if (b > 0 && b < T.nbody) {  // bodies are in DFS order: subtree(b) = [b, b + nsub)
         double acc[10];
@@ -272,6 +278,7 @@ __device__ void k_crb(const KernelArgs& A, const double* mb, double* S) {
         double v = dot6(a, c);
         if (i == j) v += mb[A.o.dof_armature + i];
         S[L.M + e] = v;
+        if (FAST) A.s.qM_tmp[(size_t)blockIdx.x * T.nM + e] = v;  // FAST keeps no LDS copy of M (L.M aliases L.LD)
     }
     wsync();
 }
@@ -279,9 +286,10 @@ __device__ void k_crb(const KernelArgs& A, const double* mb, double* S) {
 // in-place L^T D L of the tree-sparse matrix at S[ld..]; also dinv[i] = 1/D[i].
 // Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t)
 // updates of one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.
-__device__ void k_factor(const KernelArgs& A, double* S, int ld) {
+template <bool FAST>
+__device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     double* LD = S + ld;
     const int tl = LANE & 15, al = LANE >> 4;
     for (int k = T.nv - 1; k >= 0; k--) {
@@ -313,9 +321,10 @@ __device__ void k_factor(const KernelArgs& A, double* S, int ld) {
 // half: 0 = full solve, 1 = only  L^-1  (used after the constraint solve: qacc += L^-1 D^-1/2 z).
 struct DofVec { double a, b; };
 __device__ __forceinline__ double dv_get(const DofVec& x, int i) { return i < UHC_WAVE ? bcast(x.a, i) : bcast(x.b, i - UHC_WAVE); }
-__device__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half) {
+template <bool FAST>
+__device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const double* LD = S + ld;
     const int i0 = LANE, i1 = LANE + UHC_WAVE;
     const bool v0 = i0 < T.nv, v1 = i1 < T.nv;
@@ -347,9 +356,10 @@ __device__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x,
 }
 
 // ------------------------------------------------------------------ P7 velocities + bias forces
-__device__ void k_com_vel(const KernelArgs& A, double* S) {
+template <bool FAST>
+__device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     if (b == 0) for (int k = 0; k < 6; k++) S[L.cvel + k] = 0;
     wsync();
@@ -393,9 +403,10 @@ __device__ void k_com_vel(const KernelArgs& A, double* S) {
         wsync();
     }
 }
-__device__ void k_rne(const KernelArgs& A, double* S) {  // qfrc_bias = RNE(qacc = 0)
+template <bool FAST>
+__device__ __forceinline__ void k_rne(const KernelArgs& A, double* S) {  // qfrc_bias = RNE(qacc = 0)
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     if (b == 0) for (int k = 0; k < 6; k++) { S[L.cacc + k] = k < 3 ? 0.0 : -T.gravity[k - 3]; S[L.cfrc + k] = 0; }
     wsync();
@@ -439,9 +450,10 @@ __device__ void k_rne(const KernelArgs& A, double* S) {  // qfrc_bias = RNE(qacc
 }
 
 // ------------------------------------------------------------------ P8 smooth forces / acceleration
-__device__ void k_smooth(const KernelArgs& A, const double* mb, double* S) {
+template <bool FAST>
+__device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, double* S) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     // qfrc_smooth = passive - bias + applied + actuator  -> S.smooth
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         double f = -mb[A.o.dof_damping + i] * S[L.qvel + i] - S[L.bias + i] + S[L.applied + i];
@@ -460,7 +472,7 @@ __device__ void k_smooth(const KernelArgs& A, const double* mb, double* S) {
     DofVec x;
     x.a = LANE < T.nv ? S[L.smooth + LANE] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? S[L.smooth + LANE + UHC_WAVE] : 0.0;
-    k_solve(A, S, L.LD, x, 0);
+    k_solve<FAST>(A, S, L.LD, x, 0);
     if (LANE < T.nv) S[L.smooth + LANE] = x.a;  // now qacc_smooth
     if (LANE + UHC_WAVE < T.nv) S[L.smooth + LANE + UHC_WAVE] = x.b;
     wsync();
@@ -491,10 +503,11 @@ __device__ __forceinline__ double impedance(const double* si, double pos, double
     else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
     return dmin + y * (dmax - dmin);
 }
-__device__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, const double* w,
+template <bool FAST>
+__device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, const double* w,
                                 const double* n, double dist, double margin, double gap) {
     const DevTopo& T = A.t;
-    double* C = S + A.l.con + c * UHC_CON_STRIDE;
+    double* C = S + (FAST ? A.lf : A.l).con + c * UHC_CON_STRIDE;
     double fr[9];
     for (int k = 0; k < 3; k++) { C[k] = w[k] - 0.5 * dist * n[k]; fr[k] = n[k]; }
     make_frame(fr);
@@ -516,9 +529,10 @@ __device__ void k_write_contact(const KernelArgs& A, const double* mb, double* S
     C[19] = b1; C[20] = b2; C[21] = dim;
 }
 // returns ncon (wave-uniform)
-__device__ int k_collision(const KernelArgs& A, const double* mb, double* S) {
+template <bool FAST>
+__device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     int ncon = 0;
     for (int p0 = 0; p0 < T.npair; p0 += UHC_WAVE) {
         const int p = p0 + LANE;
@@ -588,9 +602,11 @@ __device__ int k_collision(const KernelArgs& A, const double* mb, double* S) {
             }
             const unsigned long long cm = __ballot(ok);
             const int rank = __popcll(cm & ((1ull << LANE) - 1ull));
-            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < UHC_MAXCON)
-                k_write_contact(A, mb, S, ncon + rank, g1, g2, w, n, dist, margin, gap);
-            ncon = min(UHC_MAXCON, ncon + min((int)__popcll(cm), T.plane_mesh_maxcon));
+            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < MAXCON_OF(FAST))
+                k_write_contact<FAST>(A, mb, S, ncon + rank, g1, g2, w, n, dist, margin, gap);
+            const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
+            if (want > MAXCON_OF(FAST)) *overflow = 1;
+            ncon = min(MAXCON_OF(FAST), want);
         }
     }
     wsync();
@@ -605,9 +621,10 @@ __device__ int k_collision(const KernelArgs& A, const double* mb, double* S) {
 #define ROW_PYR 4
 struct RowMisc { int type, last, aux, edge; };  // aux: contact id | dof ; edge: pyramid edge | sign
 
-__device__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S, int ncon, int* overflow) {
+template <bool FAST>
+__device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S, int ncon, int* overflow) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     RowMisc* RM = (RowMisc*)(S + L.rowMisc);
     int nefc = 0;
     // (1) friction loss
@@ -616,7 +633,7 @@ __device__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S
         const bool has = i < T.nv && mb[A.o.dof_frictionloss + i] > 0;
         const unsigned long long m = __ballot(has);
         const int r = nefc + __popcll(m & ((1ull << LANE) - 1ull));
-        if (has && r < UHC_MAXEFC) { RM[r].type = ROW_FRICTION; RM[r].last = i; RM[r].aux = i; RM[r].edge = 1; }
+        if (has && r < MAXEFC_OF(FAST)) { RM[r].type = ROW_FRICTION; RM[r].last = i; RM[r].aux = i; RM[r].edge = 1; }
         nefc += __popcll(m);
     }
     // (2) joint limits: lower side then upper side of each joint, joints in order
@@ -633,8 +650,8 @@ __device__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S
         }
         const unsigned long long ml = __ballot(lo), mh = __ballot(hi), below = (1ull << LANE) - 1ull;
         int r = nefc + __popcll(ml & below) + __popcll(mh & below);
-        if (lo) { if (r < UHC_MAXEFC) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = -1; } r++; }
-        if (hi) { if (r < UHC_MAXEFC) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = 1; } }
+        if (lo) { if (r < MAXEFC_OF(FAST)) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = -1; } r++; }
+        if (hi) { if (r < MAXEFC_OF(FAST)) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = 1; } }
         nefc += __popcll(ml) + __popcll(mh);
     }
     wsync();
@@ -647,21 +664,22 @@ __device__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S
             const int dim = (int)C[21], b2 = (int)C[20];
             const int nr = dim == 1 ? 1 : 4, last = T.body_lastdof[b2];
             for (int e = 0; e < nr; e++, r++)
-                if (r < UHC_MAXEFC) { RM[r].type = dim == 1 ? ROW_CONTACT : ROW_PYR; RM[r].last = last; RM[r].aux = c; RM[r].edge = e; }
+                if (r < MAXEFC_OF(FAST)) { RM[r].type = dim == 1 ? ROW_CONTACT : ROW_PYR; RM[r].last = last; RM[r].aux = c; RM[r].edge = e; }
         }
         ((int*)(S + L.ncon_nefc))[1] = r;
     }
     wsync();
     nefc = ((int*)(S + L.ncon_nefc))[1];
-    if (nefc > UHC_MAXEFC) { *overflow = 1; nefc = UHC_MAXEFC; }
+    if (nefc > MAXEFC_OF(FAST)) { *overflow = 1; nefc = MAXEFC_OF(FAST); }
     return nefc;
 }
 
 // Per row (lane r and r+64): J over the dof chain of the row, reference acceleration, R, warm-start
 // force, and Yhat = D^-1/2 L^-T J^T stored chain-sparse (index = depth of the dof).
-__device__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nefc) {
+template <bool FAST>
+__device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nefc) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
     const int YS = T.maxdepth + 1;
     for (int r = LANE; r < nefc; r += UHC_WAVE) {
@@ -755,9 +773,10 @@ __device__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nef
 
 // ------------------------------------------------------------------ P9 projected Gauss-Seidel on the dual (matrix-free)
 // z = sum_r f_r Yhat_r  (nv vector in LDS);  (A f)_r = Yhat_r . z[chain_r].
-__device__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc) {
+template <bool FAST>
+__device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
     const int YS = T.maxdepth + 1;
     double* z = S + L.z;
@@ -823,31 +842,238 @@ __device__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc)
     return iters;
 }
 
-// ------------------------------------------------------------------ mj_forward
-struct FwdOut { int ncon, nefc, iters, overflow; };
-__device__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S) {
+
+// ------------------------------------------------------------------ FAST path (nefc <= 64): row-per-lane, A in registers
+// Lane r owns constraint row r: its scalars live in registers, its Yhat row in LDS (variable length,
+// packed), and row r of the Delassus matrix A = Yhat Yhat^T + diag(R) in 64 VGPR pairs.  A PGS row
+// update is then: lane i computes its own step, one broadcast of delta, one FMA per lane on the
+// residual vector -- no reduction and no LDS traffic inside the sweep.
+struct FastRow { int type, last, len, yoff; double R, b, f, floss, diag; };
+
+// compile-time loop: keeps Arow[] indices constant so the array lives in VGPRs
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ int wave_excl_scan(int v, int* total) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < UHC_WAVE; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (LANE >= o) x += y;
+    }
+    *total = __builtin_amdgcn_readlane(x, UHC_WAVE - 1);
+    return x - v;
+}
+
+// returns 0 on success, 1 if the packed Yhat rows do not fit (-> the env is redone by the general kernel)
+__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
-    FwdOut out = {0, 0, 0, 0};
-    k_kinematics(A, mb, S);
-    k_com_pos(A, mb, S);
-    k_crb(A, mb, S);
-    for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    const DevLds& L = A.lf;
+    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
+    const int YS = T.maxdepth + 1;
+    const int r = LANE;
+    const bool valid = r < nefc;
+    RowMisc rm = {0, 0, 0, 0};
+    if (valid) rm = RM[r];
+    row.type = rm.type; row.last = rm.last;
+    row.len = valid ? T.dof_depth[rm.last] + 1 : 0;
+    int total;
+    row.yoff = wave_excl_scan(row.len, &total);
+    row.R = 1; row.b = 0; row.f = 0; row.floss = 0; row.diag = 1;
+    if (total > A.ycap) return 1;
+    if (valid) {
+        const int last = rm.last, len = row.len;
+        const short* anc = T.dof_anc + last * YS;
+        double* Y = S + L.Y + row.yoff;
+        double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
+        if (rm.type == ROW_FRICTION || rm.type == ROW_LIMIT) {
+            const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+            const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
+            K = 1.0 / (dmax * dmax * timeconst * timeconst);
+            B = 2.0 / (dmax * timeconst);
+            for (int q = 0; q < len; q++) Y[q] = 0;
+            if (rm.type == ROW_LIMIT) {
+                const int j = rm.aux;
+                const double v = S[L.qpos + T.jnt_qposadr[j]];
+                margin = mb[A.o.jnt_margin + j];
+                pos = rm.edge < 0 ? v - mb[A.o.jnt_range + 2 * j] : mb[A.o.jnt_range + 2 * j + 1] - v;
+                Y[len - 1] = -(double)rm.edge;
+            } else {
+                floss = mb[A.o.dof_frictionloss + last];
+                Y[len - 1] = 1;
+            }
+            diagApprox = mb[A.o.dof_invweight0 + last];
+            imp = impedance(dsolimp, pos, margin);
+        } else {
+            const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
+            const int b2 = (int)C[20];
+            const int root = T.body_rootid[b2];
+            double off[3], dv[3];
+            const double mu = C[14];
+            for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
+            if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+            else {
+                const double sgn = (rm.edge & 1) ? -1.0 : 1.0;
+                const int td = 1 + rm.edge / 2;
+                for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
+            }
+            for (int q = 0; q < len; q++) {
+                const int i = anc[q];
+                double cd[6], cr[3];
+                for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
+                cross3(cr, cd, off);
+                Y[q] = dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]);
+            }
+            pos = C[12]; margin = C[13]; K = C[15]; B = C[16]; imp = C[17];
+            diagApprox = rm.type == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
+            if (rm.type == ROW_PYR) {
+                const double R0 = fmax(UHC_MINVAL, (1 - imp) * (C[18] + mu * mu * C[18]) / imp);
+                diagApprox = -2 * mu * mu * R0;
+            }
+        }
+        double vel = 0, jas = 0, jaw = 0;
+        for (int q = 0; q < len; q++) {
+            const int i = anc[q];
+            const double j = Y[q];
+            vel += j * S[L.qvel + i];
+            jas += j * S[L.smooth + i];
+            jaw += j * S[L.qacc + i];
+        }
+        const double R = diagApprox < 0 ? -diagApprox : fmax(UHC_MINVAL, (1 - imp) * diagApprox / imp);
+        const double aref = -B * vel - K * imp * (pos - margin);
+        const double jar = jaw - aref, D = 1.0 / R;
+        row.f = rm.type == ROW_FRICTION ? clampd(-D * jar, -floss, floss) : (jar < 0 ? -D * jar : 0.0);
+        for (int q = len - 1; q >= 1; q--) {
+            const int i = anc[q];
+            const double xi = Y[q];
+            const int mi = T.dof_madr[i];
+            for (int q2 = q - 1; q2 >= 0; q2--) Y[q2] -= S[L.LD + mi + (q - q2)] * xi;
+        }
+        for (int q = 0; q < len; q++) Y[q] *= sqrt(S[L.dinv + anc[q]]);
+        row.R = R; row.b = jas - aref; row.floss = floss;
+    }
     wsync();
-    k_factor(A, S, L.LD);
-    k_com_vel(A, S);
-    k_rne(A, S);
-    k_smooth(A, mb, S);
-    out.ncon = k_collision(A, mb, S);
-    out.nefc = k_enumerate_rows(A, mb, S, out.ncon, &out.overflow);
+    return 0;
+}
+
+// PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
+__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.lf;
+    const bool valid = LANE < nefc;
+    const double* Yr = S + L.Y + row.yoff;
+    // ---- A[r][s] = sum over the common part of the two dof chains
+    double Arow[UHC_WAVE];
+    double diag = 1.0;
+    static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        double acc = 0.0;
+        if (s < nefc) {
+            const int ls = __builtin_amdgcn_readlane(row.last, s);
+            const int ys = __builtin_amdgcn_readlane(row.yoff, s);
+            const int nc = valid ? (int)A.t.dof_ncommon[row.last * T.nv + ls] : 0;
+            const double* Ys = S + L.Y + ys;
+            for (int q = 0; q < nc; q++) acc += Yr[q] * Ys[q];
+            if (s == LANE) { acc += row.R; diag = acc; }
+        }
+        Arow[s] = acc;
+    });
+    if (!valid) diag = 1.0;
+    const double dinvA = 1.0 / diag;
+    // ---- residual of the warm start, dual cost test
+    double f = row.f, res = row.b;
+    static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if (s < nefc) res += Arow[s] * bcast(f, s);
+    });
+    double cost = valid ? f * (0.5 * (res - row.b) + row.b) : 0.0;
+    cost = wave_sum(cost);
+    if (cost > 0) { f = 0; res = row.b; }
+    const double scale = 1.0 / (mb[A.o.meaninertia] * (T.nv > 1 ? T.nv : 1));
+    const bool fric = row.type == ROW_FRICTION;
+    const double floss = row.floss;
+    int iters = 0;
+    for (int it = 0; it < T.iterations; it++) {
+        double improvement = 0;
+        static_for<0, UHC_WAVE>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if (i < nefc) {
+                // every lane steps its own row; only lane i's step is taken
+                double fn = f - res * dinvA;
+                fn = fric ? clampd(fn, -floss, floss) : fmax(fn, 0.0);
+                double delta = fn - f;
+                double change = 0.5 * delta * delta * diag + delta * res;
+                if (change > 1e-10) { delta = 0; change = 0; }
+                const double di = bcast(delta, i);
+                if (LANE == i) { f += delta; improvement -= change; }
+                res += di * Arow[i];
+            }
+        });
+        iters = it + 1;
+        if (wave_sum(improvement) * scale < T.tolerance) break;
+    }
+    row.f = f;
+    // ---- z = sum_r f_r Yhat_r (dof-per-lane pull), for qacc = qacc_smooth + L^-1 D^-1/2 z
+    for (int h = 0; h < 2; h++) {
+        const int i = LANE + h * UHC_WAVE;
+        const bool vi = i < T.nv;
+        const int di = vi ? T.dof_depth[i] : 0, nd = vi ? T.dof_ndesc[i] : -1;
+        double acc = 0;
+        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            if (s < nefc) {
+                const int ls = __builtin_amdgcn_readlane(row.last, s);
+                const int ys = __builtin_amdgcn_readlane(row.yoff, s);
+                const double fs = bcast(f, s);
+                if (vi && ls >= i && ls <= i + nd) acc += fs * S[L.Y + ys + di];
+            }
+        });
+        if (vi) S[L.z + i] = acc;
+    }
+    wsync();
+    return iters;
+}
+
+// ------------------------------------------------------------------ mj_forward
+struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
+template <bool FAST>
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S) {
+    const DevTopo& T = A.t;
+    const DevLds& L = FAST ? A.lf : A.l;
+    FwdOut out = {0, 0, 0, 0};
+    k_kinematics<FAST>(A, mb, S);
+    k_com_pos<FAST>(A, mb, S);
+    k_crb<FAST>(A, mb, S);
+    if (!FAST) {
+        for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+        wsync();
+    }
+    k_factor<FAST>(A, S, L.LD);
+    k_com_vel<FAST>(A, S);
+    k_rne<FAST>(A, S);
+    k_smooth<FAST>(A, mb, S);
+    out.ncon = k_collision<FAST>(A, mb, S, &out.overflow);
+    out.nefc = k_enumerate_rows<FAST>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
+    if (FAST && out.overflow) return out;
     if (out.nefc > 0) {
-        k_rows(A, mb, S, out.nefc);
-        out.iters = k_pgs(A, mb, S, out.nefc);
+        if (FAST) {
+            FastRow row;
+            if (k_rows_fast(A, mb, S, out.nefc, row)) { out.overflow = 1; return out; }
+            out.iters = k_pgs_fast(A, mb, S, out.nefc, row);
+        } else {
+            k_rows<FAST>(A, mb, S, out.nefc);
+            out.iters = k_pgs<FAST>(A, mb, S, out.nefc);
+        }
         // qacc = qacc_smooth + L^-1 D^-1/2 z
         if (LANE < T.nv) x.a = S[L.z + LANE] * sqrt(S[L.dinv + LANE]);
         if (LANE + UHC_WAVE < T.nv) x.b = S[L.z + LANE + UHC_WAVE] * sqrt(S[L.dinv + LANE + UHC_WAVE]);
-        k_solve(A, S, L.LD, x, 1);
+        k_solve<FAST>(A, S, L.LD, x, 1);
     }
     if (LANE < T.nv) S[L.qacc + LANE] = S[L.smooth + LANE] + x.a;
     if (LANE + UHC_WAVE < T.nv) S[L.qacc + LANE + UHC_WAVE] = S[L.smooth + LANE + UHC_WAVE] + x.b;
@@ -856,9 +1082,10 @@ __device__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S) {
 }
 
 // ------------------------------------------------------------------ P10 semi-implicit Euler
-__device__ void k_euler(const KernelArgs& A, double* S) {
+template <bool FAST>
+__device__ __forceinline__ void k_euler(const KernelArgs& A, double* S) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const double h = T.timestep;
     for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.qvel + i] += h * S[L.qacc + i];
     wsync();
@@ -889,9 +1116,10 @@ __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVA
 // ------------------------------------------------------------------ E3/E4 stable PD, E5 implicit residual force
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
 // previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
-__device__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it) {
+template <bool FAST>
+__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const double* Mprev) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
     const double dt = T.timestep;
     const int nu = T.nu, vf = C.rfc_mode == 1 ? 6 : 0;
@@ -900,7 +1128,8 @@ __device__ void k_pd_torque(const KernelArgs& A, double* S, const double* action
         skp = clampd(action[nu + vf + it] + 1, 0, 10);
         skd = clampd(action[nu + vf + it + C.n_substeps] + 1, 0, 10);
     }
-    for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    if (FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = Mprev[(size_t)blockIdx.x * T.nM + e];
+    else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
     wsync();
     // lane owns dofs LANE and LANE+64; actuator a drives dof 6+a (free root first)
     double kp[2] = {0, 0}, kd[2] = {0, 0}, qe[2] = {0, 0}, qv[2] = {0, 0};
@@ -924,11 +1153,11 @@ __device__ void k_pd_torque(const KernelArgs& A, double* S, const double* action
         }
     }
     wsync();
-    k_factor(A, S, L.LD);
+    k_factor<FAST>(A, S, L.LD);
     DofVec x;
     x.a = LANE < T.nv ? -S[L.bias + LANE] - kp[0] * qe[0] - kd[0] * qv[0] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? -S[L.bias + LANE + UHC_WAVE] - kp[1] * qe[1] - kd[1] * qv[1] : 0.0;
-    k_solve(A, S, L.LD, x, 0);
+    k_solve<FAST>(A, S, L.LD, x, 0);
     for (int h = 0; h < 2; h++) {
         const int a = LANE + h * UHC_WAVE - 6;
         if (a >= 0 && a < nu) {
@@ -939,8 +1168,9 @@ __device__ void k_pd_torque(const KernelArgs& A, double* S, const double* action
     }
     wsync();
 }
-__device__ void k_rfc_implicit(const KernelArgs& A, double* S, const double* action) {
-    const DevLds& L = A.l;
+template <bool FAST>
+__device__ __forceinline__ void k_rfc_implicit(const KernelArgs& A, double* S, const double* action) {
+    const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
     if (LANE == 0) {
         double vf[6], q[4], rq[4], hq[4], R[9], r[3];
@@ -958,15 +1188,18 @@ __device__ void k_rfc_implicit(const KernelArgs& A, double* S, const double* act
 }
 
 // ------------------------------------------------------------------ the kernels
-// MODE 0: do_simulation (n_substeps of control + step);  MODE 1: forward only (after set_state)
-template <int MODE>
+// MODE 0: do_simulation (n_substeps of control + step);  MODE 1: forward only (after set_state).
+// FAST: compact LDS (4 workgroups per CU), <= 64 constraint rows, A in registers.  An env that does not
+// fit (rows, contacts or Yhat storage) leaves its state untouched and raises redo[env]; the host then
+// launches the general variant on exactly those envs.
+template <int MODE, bool FAST>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
     const int env = blockIdx.x;
     if (env >= A.n_env) return;
     if (d_active && !d_active[env]) return;
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = FAST ? A.lf : A.l;
     double* S = smem;
     const double* mb = A.s.model_blob + (size_t)(A.s.env_model ? A.s.env_model[env] : 0) * A.o.stride;
     int fail = MODE == 0 ? A.s.fail[env] : 0;
@@ -979,39 +1212,44 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         if (MODE == 0) S[L.bias + i] = A.s.bias[(size_t)env * T.nv + i];
     }
     for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
-    if (MODE == 0) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
+    if (MODE == 0 && !FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0;
     bool ran = false;
     if (MODE == 1) {
-        fo = k_forward(A, mb, S);
+        fo = k_forward<FAST>(A, mb, S);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
         for (int it = 0; it < A.c.n_substeps; it++) {
-            if (A.c.action_type == 0) k_pd_torque(A, S, action, tbase, it);
+            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, ran ? A.s.qM_tmp : A.s.qM);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
                     S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
                 wsync();
             }
-            if (A.c.rfc_mode == 1) k_rfc_implicit(A, S, action);
+            if (A.c.rfc_mode == 1) k_rfc_implicit<FAST>(A, S, action);
             // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
             int b = 0;
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
-            fo = k_forward(A, mb, S);
+            fo = k_forward<FAST>(A, mb, S);
             overflow |= fo.overflow;
+            if (FAST && overflow) break;
             ran = true;
             b = 0;
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
             if (wave_or(b)) { fail = 1; break; }
-            k_euler(A, S);
+            k_euler<FAST>(A, S);
         }
+    }
+    if (FAST && overflow) {  // nothing committed: the general kernel redoes this env from the same inputs
+        if (LANE == 0) A.s.redo[env] = 1;
+        return;
     }
     // ---- store state
     for (int i = LANE; i < T.nq; i += UHC_WAVE) A.s.qpos[(size_t)env * T.nq + i] = S[L.qpos + i];
@@ -1024,7 +1262,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     for (int i = LANE; i < T.nu; i += UHC_WAVE) A.s.ctrl[(size_t)env * T.nu + i] = S[L.ctrl + i];
     if (ran) {
         for (int i = LANE; i < T.nv; i += UHC_WAVE) A.s.bias[(size_t)env * T.nv + i] = S[L.bias + i];
-        for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
+        if (FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = A.s.qM_tmp[(size_t)env * T.nM + e];
+        else for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
         for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
             A.s.xpos[(size_t)env * 3 * T.nbody + i] = S[L.xpos + i];
             A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
@@ -1056,17 +1295,21 @@ __global__ void uhc_set_state_kernel(DevState s, int nq, int nv, int nu, const i
 }
 
 // host-callable launchers (defined here so the kernels stay in one translation unit)
-extern "C" hipError_t uhc_launch_step(int mode, const KernelArgs* A, const double* d_action, const double* d_tbase,
+extern "C" hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase,
                                       const int* d_active, size_t lds_bytes, hipStream_t stream) {
     dim3 grid(A->n_env), block(UHC_WAVE);
-    if (mode == 0) hipLaunchKernelGGL(uhc_step_kernel<0>, grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    else hipLaunchKernelGGL(uhc_step_kernel<1>, grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    if (mode == 0 && fast) hipLaunchKernelGGL((uhc_step_kernel<0, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    else if (mode == 0) hipLaunchKernelGGL((uhc_step_kernel<0, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    else if (fast) hipLaunchKernelGGL((uhc_step_kernel<1, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    else hipLaunchKernelGGL((uhc_step_kernel<1, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
 }
-extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)uhc_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)uhc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast) {
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast)) != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)uhc_step_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast);
 }
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream) {
