@@ -1,0 +1,51 @@
+"""Per-stage shader-cycle breakdown of the fused step kernel.  Builds libuhc_amd_prof.so with
+-DUHC_STAGE_PROF and runs the bench workload for a few steps.  Usage (GPU box):
+    python tools/stage_profile.py [n_env] [steps]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "uhc_amd", "csrc")
+PROF_LIB = os.path.join(CSRC, "libuhc_amd_prof.so")
+NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "smooth", "collision", "rows", "A-build",
+         "pgs-sweeps", "z+rest/pgs-general", "qacc-solve", "euler", "store"]
+
+
+def build():
+    srcs = [os.path.join(CSRC, s) for s in ("uhc_physics.hip", "uhc_capi.cpp")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-Wno-unused-value", "-DUHC_STAGE_PROF", "-o", PROF_LIB] + srcs, cwd=CSRC)
+
+
+if __name__ == "__main__":
+    if "--build-only" in sys.argv:
+        build()
+        sys.exit(0)
+    if not os.path.exists(PROF_LIB):
+        build()
+    os.environ["UHC_LIB"] = PROF_LIB
+    import numpy as np
+    import torch
+    import bench
+    from uhc_amd import sim as S
+    n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    model = S.load_asset_model()
+    ctrl = S.make_ctrl(model)
+    qpos, qvel, actions = bench.make_inputs(model, ctrl, n_env, 1)
+    b = S.SimBatch(model, ctrl, n_env)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    b.sync()
+    b.field(S.F_STAGE_PROF).zero_()
+    a = torch.from_numpy(actions).cuda()
+    tb = torch.from_numpy(np.ascontiguousarray(qpos[:, 7:])).cuda()
+    for t in range(steps):
+        b.simulate(a[t % 8], tb)
+    b.sync()
+    p = b.field(S.F_STAGE_PROF).cpu().numpy().astype(np.float64) / steps
+    tot = p.sum(1)
+    print(f"n_env={n_env} steps={steps}: mean cycles per env-step = {tot.mean():.0f} (max {tot.max():.0f}); nefc mean {b.field(S.F_NEFC).float().mean().item():.1f} iters mean {b.field(S.F_SOLVER_ITER).float().mean().item():.1f}")
+    for k, nm in enumerate(NAMES):
+        print(f"  {nm:22s} {p[:, k].mean():12.0f} cycles/env-step  {100 * p[:, k].mean() / tot.mean():5.1f}%")

@@ -8,7 +8,7 @@ import os
 from ._capi import UhcCtrlDesc, UhcModelDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libuhc_amd.so")
+LIB_PATH = os.environ.get("UHC_LIB") or os.path.join(_HERE, "csrc", "libuhc_amd.so")
 _lib = None
 
 # every symbol include/uhc_amd.h declares

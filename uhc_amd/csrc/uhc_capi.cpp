@@ -246,6 +246,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         int adr = d.dof_madr[i];
         for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) { m_row[adr] = (short)i; m_col[adr] = (short)j; }
     }
+    std::vector<unsigned short> e_adr(T.nM + 2, 0);
+    for (int i = 0; i < nv; i++) {
+        int adr = d.dof_madr[i];
+        for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) e_adr[adr] = (unsigned short)d.dof_madr[j];
+    }
     std::vector<unsigned char> ncommon((size_t)nv * nv, 0);
     for (int i = 0; i < nv; i++)
         for (int j = 0; j < nv; j++) {
@@ -288,7 +293,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.dof_bodyid, nv), &T.dof_bodyid)); TRY(upload(b, ivec(d.dof_jntid, nv), &T.dof_jntid));
     TRY(upload(b, ivec(d.dof_parentid, nv), &T.dof_parentid)); TRY(upload(b, ivec(d.dof_madr, nv + 1), &T.dof_madr));
     TRY(upload(b, dof_depth, &T.dof_depth)); TRY(upload(b, dof_ndesc, &T.dof_ndesc));
-    TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
+    TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, e_adr, &T.e_adr)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
     TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
     TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
@@ -331,7 +336,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
     L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
     L.M = carve(T.nM); L.LD = carve(T.nM); L.dinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
-    L.vec = carve(nv); L.z = carve(nv);
+    L.vec = carve(nv); L.z = carve(nv); L.eadr = carve((T.nM + 3) / 4 + 1);
     L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
     L.Y = carve(UHC_MAXEFC * YS);
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
@@ -348,6 +353,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         off = 0;
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
         F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.vec = F.z;
+        F.eadr = carve((T.nM + 3) / 4 + 1);
         F.LD = carve(T.nM); F.M = F.LD;
         F.cdof = carve(6 * nv);
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);
@@ -391,7 +397,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * T.nM, &S.qM_tmp)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * T.nM, &S.qM_tmp)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
     TRY(dalloc(b, E, &S.overflow));
@@ -407,11 +413,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         HIP_OK(hipMemcpy(S.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     void* fp[] = {S.qpos, S.qvel, S.xpos, S.xquat, S.xipos, S.qM, S.bias, S.qacc, S.ctrl, S.ncon, S.nefc, S.fail,
-                  S.solver_iter, S.applied, S.overflow};
+                  S.solver_iter, S.applied, S.overflow, S.prof};
     int64_t fc[] = {(int64_t)E * d.nq, (int64_t)E * nv, (int64_t)E * 3 * nb, (int64_t)E * 4 * nb, (int64_t)E * 3 * nb,
                     (int64_t)E * T.nM, (int64_t)E * nv, (int64_t)E * nv, (int64_t)E * d.nu, (int64_t)E, (int64_t)E, (int64_t)E,
-                    (int64_t)E, (int64_t)E * nv, (int64_t)E};
-    for (int k = 0; k < 15; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
+                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 32};
+    for (int k = 0; k < 16; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
     HIP_OK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     b->stream = b->own_stream;
     *out = b;
@@ -442,7 +448,7 @@ extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {
     return 0;
 }
 extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n) {
-    if (!b || f < 0 || f > 14 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
+    if (!b || f < 0 || f > 15 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
     if (p) *p = b->field_ptr[f];
     if (n) *n = b->field_count[f];
     return 0;

@@ -23,6 +23,7 @@ struct DevTopo {
     const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_madr, *dof_depth, *dof_ndesc;
     const short* dof_anc;  // [nv][maxdepth+1]: ancestor of dof i at depth q (q <= depth(i)), anc[i][depth(i)] = i
     const short *m_row, *m_col;  // [nM] sparse-M entry -> (i, j)
+    const unsigned short* e_adr;  // [nM (+pad)] sparse entry (k, a-th ancestor) -> row address of that ancestor
     const unsigned char* dof_ncommon;  // [nv][nv] number of common chain entries of two dofs (depth of LCA + 1, 0 if none)
     const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
     const int *mesh_adjadr, *mesh_adj;
@@ -46,7 +47,7 @@ struct DevLds {
     int qpos, qvel, qacc, ctrl, applied;
     int xpos, xquat, xmat, xipos, ximat, rootcom, cinert, crb, cvel, cacc, cfrc;
     int xanchor, xaxis, cdof, cdofdot;
-    int M, LD, dinv, bias, smooth, vec, z;
+    int M, LD, dinv, bias, smooth, vec, z, eadr;
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
     int total;  // doubles
 };
@@ -62,6 +63,7 @@ struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *qM_tmp, *bias, *ctrl, *applied;
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     const int* env_model;
+    long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)
     const double* model_blob;
 };
 

@@ -16,6 +16,18 @@
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
 #define LANE ((int)threadIdx.x)
+// optional per-stage cycle accounting (build with -DUHC_STAGE_PROF; see tools/stage_profile.py)
+#ifdef UHC_STAGE_PROF
+#define PROF_DECL long long pt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_last_ = __builtin_readcyclecounter();
+#define PROF_ARGS , long long* pt_, long long& pt_last_
+#define PROF_PASS , pt_, pt_last_
+#define PROF(i) { const long long now_ = __builtin_readcyclecounter(); pt_[i] += now_ - pt_last_; pt_last_ = now_; }
+#else
+#define PROF_DECL
+#define PROF_ARGS
+#define PROF_PASS
+#define PROF(i)
+#endif
 #define MAXCON_OF(FAST) ((FAST) ? UHC_FAST_MAXCON : UHC_MAXCON)
 #define MAXEFC_OF(FAST) ((FAST) ? UHC_WAVE : UHC_MAXEFC)
 __device__ __forceinline__ void wsync() { __syncthreads(); }
@@ -103,8 +115,16 @@ __device__ __forceinline__ double dot6(const double* a, const double* b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+__device__ __forceinline__ double max0(double x) {  // max(x, 0) without the canonicalising self-max clang adds to fmax
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
 
-// ------------------------------------------------------------------ P1 kinematics: body-per-lane, level-synchronous
+// ------------------------------------------------------------------ P1 kinematics
+// Pass 1 (all bodies in parallel): pose of each body relative to its parent frame, including its own
+// joint rotations (the expensive sincos work).  Pass 2 (level-synchronous): compose with the parent.
+// Pass 3 (all joints in parallel): joint anchors/axes to the world frame.
 template <bool FAST>
 __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S) {
     const DevTopo& T = A.t;
@@ -116,53 +136,68 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
         xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
         for (int k = 0; k < 9; k++) { xmat[k] = (k % 4 == 0); ximat[k] = (k % 4 == 0); }
     }
+    const bool act = b > 0 && b < T.nbody;
+    const int depth = act ? T.body_depth[b] : -1;
+    double lpos[3] = {0, 0, 0}, lquat[4] = {1, 0, 0, 0};
+    bool is_free = false;
+    int p = 0, ja = 0, jn = 0;
+    if (act) {
+        p = T.body_parentid[b]; ja = T.body_jntadr[b]; jn = T.body_jntnum[b];
+        is_free = jn == 1 && T.jnt_type[ja] == UHC_JNT_FREE;
+        double R[9], t[3];
+        if (is_free) {
+            const double* q = S + L.qpos + T.jnt_qposadr[ja];
+            for (int k = 0; k < 3; k++) lpos[k] = q[k];
+            for (int k = 0; k < 4; k++) lquat[k] = q[3 + k];
+            quat_normalize(lquat);
+            for (int k = 0; k < 3; k++) { S[L.xanchor + 3 * ja + k] = lpos[k]; S[L.xaxis + 3 * ja + k] = (k == 2); }
+        } else {
+            for (int k = 0; k < 3; k++) lpos[k] = mb[A.o.body_pos + 3 * b + k];
+            for (int k = 0; k < 4; k++) lquat[k] = mb[A.o.body_quat + 4 * b + k];
+            for (int j = ja; j < ja + jn; j++) {
+                const int qa = T.jnt_qposadr[j], jt = T.jnt_type[j];
+                double qloc[4], jp[3], jx[3], ax[3];
+                for (int k = 0; k < 3; k++) { jp[k] = mb[A.o.jnt_pos + 3 * j + k]; jx[k] = mb[A.o.jnt_axis + 3 * j + k]; }
+                quat_to_mat(R, lquat);
+                mat_vec(t, R, jp);
+                double anc[3];
+                for (int k = 0; k < 3; k++) { anc[k] = lpos[k] + t[k]; S[L.xanchor + 3 * j + k] = anc[k]; }  // parent frame for now
+                mat_vec(ax, R, jx);
+                for (int k = 0; k < 3; k++) S[L.xaxis + 3 * j + k] = ax[k];
+                if (jt == UHC_JNT_SLIDE) {
+                    const double dq = S[L.qpos + qa] - mb[A.o.qpos0 + qa];
+                    for (int k = 0; k < 3; k++) lpos[k] += ax[k] * dq;
+                    continue;
+                } else if (jt == UHC_JNT_HINGE) {
+                    axis_angle_quat(qloc, jx, S[L.qpos + qa] - mb[A.o.qpos0 + qa]);
+                    quat_mul(lquat, lquat, qloc);
+                } else if (jt == UHC_JNT_BALL) {
+                    for (int k = 0; k < 4; k++) qloc[k] = S[L.qpos + qa + k];
+                    quat_normalize(qloc);
+                    quat_mul(lquat, lquat, qloc);
+                }
+                quat_to_mat(R, lquat);
+                mat_vec(t, R, jp);
+                for (int k = 0; k < 3; k++) lpos[k] = anc[k] - t[k];
+            }
+        }
+    }
     wsync();
-    const int depth = b < T.nbody ? T.body_depth[b] : -1;
     for (int level = 1; level <= T.body_maxdepth; level++) {
         if (depth == level) {
-            const int p = T.body_parentid[b], ja = T.body_jntadr[b], jn = T.body_jntnum[b];
             double pos[3], quat[4], R[9], t[3];
-            if (jn == 1 && T.jnt_type[ja] == UHC_JNT_FREE) {
-                const double* q = S + L.qpos + T.jnt_qposadr[ja];
-                for (int k = 0; k < 3; k++) pos[k] = q[k];
-                for (int k = 0; k < 4; k++) quat[k] = q[3 + k];
-                quat_normalize(quat);
-                for (int k = 0; k < 3; k++) { S[L.xanchor + 3 * ja + k] = pos[k]; S[L.xaxis + 3 * ja + k] = (k == 2); }
+            if (is_free) {
+                for (int k = 0; k < 3; k++) pos[k] = lpos[k];
+                for (int k = 0; k < 4; k++) quat[k] = lquat[k];
             } else {
-                double pm[9], pq[4], bp[3], bq[4];
+                double pm[9], pq[4];
                 for (int k = 0; k < 9; k++) pm[k] = xmat[9 * p + k];
-                for (int k = 0; k < 4; k++) { pq[k] = xquat[4 * p + k]; bq[k] = mb[A.o.body_quat + 4 * b + k]; }
-                for (int k = 0; k < 3; k++) bp[k] = mb[A.o.body_pos + 3 * b + k];
-                mat_vec(t, pm, bp);
+                for (int k = 0; k < 4; k++) pq[k] = xquat[4 * p + k];
+                mat_vec(t, pm, lpos);
                 for (int k = 0; k < 3; k++) pos[k] = xpos[3 * p + k] + t[k];
-                quat_mul(quat, pq, bq);
-                for (int j = ja; j < ja + jn; j++) {
-                    const int qa = T.jnt_qposadr[j], jt = T.jnt_type[j];
-                    double qloc[4], jp[3], jx[3], ax[3];
-                    for (int k = 0; k < 3; k++) { jp[k] = mb[A.o.jnt_pos + 3 * j + k]; jx[k] = mb[A.o.jnt_axis + 3 * j + k]; }
-                    quat_to_mat(R, quat);
-                    mat_vec(t, R, jp);
-                    for (int k = 0; k < 3; k++) S[L.xanchor + 3 * j + k] = pos[k] + t[k];
-                    mat_vec(ax, R, jx);
-                    for (int k = 0; k < 3; k++) S[L.xaxis + 3 * j + k] = ax[k];
-                    if (jt == UHC_JNT_SLIDE) {
-                        double dq = S[L.qpos + qa] - mb[A.o.qpos0 + qa];
-                        for (int k = 0; k < 3; k++) pos[k] += ax[k] * dq;
-                        continue;
-                    } else if (jt == UHC_JNT_HINGE) {
-                        axis_angle_quat(qloc, jx, S[L.qpos + qa] - mb[A.o.qpos0 + qa]);
-                        quat_mul(quat, quat, qloc);
-                    } else if (jt == UHC_JNT_BALL) {
-                        for (int k = 0; k < 4; k++) qloc[k] = S[L.qpos + qa + k];
-                        quat_normalize(qloc);
-                        quat_mul(quat, quat, qloc);
-                    }
-                    quat_to_mat(R, quat);
-                    mat_vec(t, R, jp);
-                    for (int k = 0; k < 3; k++) pos[k] = S[L.xanchor + 3 * j + k] - t[k];
-                }
+                quat_mul(quat, pq, lquat);
+                quat_normalize(quat);
             }
-            quat_normalize(quat);
             quat_to_mat(R, quat);
             double ip[3], iq[4], qi[4], Ri[9];
             for (int k = 0; k < 3; k++) ip[k] = mb[A.o.body_ipos + 3 * b + k];
@@ -176,6 +211,19 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
         }
         wsync();
     }
+    // joint anchors / axes: parent frame -> world
+    for (int j = LANE; j < T.njnt; j += UHC_WAVE) {
+        if (T.jnt_type[j] == UHC_JNT_FREE) continue;
+        const int pb = T.body_parentid[T.jnt_bodyid[j]];
+        double pm[9], a[3], x[3], t[3];
+        for (int k = 0; k < 9; k++) pm[k] = xmat[9 * pb + k];
+        for (int k = 0; k < 3; k++) { a[k] = S[L.xanchor + 3 * j + k]; x[k] = S[L.xaxis + 3 * j + k]; }
+        mat_vec(t, pm, a);
+        for (int k = 0; k < 3; k++) S[L.xanchor + 3 * j + k] = xpos[3 * pb + k] + t[k];
+        mat_vec(t, pm, x);
+        for (int k = 0; k < 3; k++) S[L.xaxis + 3 * j + k] = t[k];
+    }
+    wsync();
 }
 
 // ------------------------------------------------------------------ P2 comPos: tree COM, cinert (body/lane), cdof (joint/lane)
@@ -283,75 +331,133 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
     wsync();
 }
 
+// Per-lane topology constants, loaded once per kernel: the lane owns dofs LANE and LANE+64.
+// pk packs (madr | depth << 16 | ndesc << 24) so that a wave-uniform dof index i can fetch its row
+// address / depth / descendant count with one v_readlane instead of a table load.
+struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1; bool v0, v1; };
+__device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
+    LaneConst c;
+    const int i0 = LANE, i1 = LANE + UHC_WAVE;
+    c.v0 = i0 < T.nv; c.v1 = i1 < T.nv;
+    c.d0 = c.v0 ? T.dof_depth[i0] : 0; c.d1 = c.v1 ? T.dof_depth[i1] : 0;
+    c.n0 = c.v0 ? T.dof_ndesc[i0] : -1; c.n1 = c.v1 ? T.dof_ndesc[i1] : -1;
+    c.m0 = c.v0 ? T.dof_madr[i0] : 0; c.m1 = c.v1 ? T.dof_madr[i1] : 0;
+    c.pk0 = c.m0 | (c.d0 << 16) | ((c.v0 ? c.n0 : 0) << 24);
+    c.pk1 = c.m1 | (c.d1 << 16) | ((c.v1 ? c.n1 : 0) << 24);
+    return c;
+}
+__device__ __forceinline__ int pk_of(const LaneConst& c, int i) {  // i wave-uniform
+    return i < UHC_WAVE ? __builtin_amdgcn_readlane(c.pk0, i) : __builtin_amdgcn_readlane(c.pk1, i - UHC_WAVE);
+}
+
 // in-place L^T D L of the tree-sparse matrix at S[ld..]; also dinv[i] = 1/D[i].
 // Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t)
 // updates of one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.
+// eadr[e] (LDS, 16-bit) gives for the sparse entry e = (k, a-th ancestor) the row address of that ancestor.
 template <bool FAST>
-__device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld) {
+__device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     double* LD = S + ld;
+    const unsigned short* eadr = (const unsigned short*)(S + L.eadr);
     const int tl = LANE & 15, al = LANE >> 4;
-    for (int k = T.nv - 1; k >= 0; k--) {
-        const int dk = T.dof_depth[k];  // number of proper ancestors
+    for (int k = T.nv - 1; k >= 1; k--) {
+        const int pk = pk_of(LC, k);
+        const int dk = (pk >> 16) & 0xff;  // number of proper ancestors
         if (dk == 0) continue;
-        const int kk = T.dof_madr[k];
-        const double Dk = LD[kk];
-        // rows of the ancestors are updated from row k (row k itself is only read here)
+        const int kk = pk & 0xffff;
+        const double inv = 1.0 / LD[kk];
+        // Ancestor rows are updated from row k.  Passes go up the chain; inside a pass every lane loads
+        // before any lane stores (lock-step), and a pass only normalises the row-k entries it owns, which
+        // later passes never read -- so one barrier per k suffices.
         for (int a0 = 1; a0 <= dk; a0 += 4) {
             const int a = a0 + al;
             if (a <= dk) {
-                const int i = T.dof_anc[k * (T.maxdepth + 1) + (dk - a)];
-                const int n = dk - a + 1;  // entries in row i
-                const double f = LD[kk + a] / Dk;
-                const int base = T.dof_madr[i];
-                if (tl < n) LD[base + tl] -= f * LD[kk + a + tl];
-                if (tl + 16 < n) LD[base + tl + 16] -= f * LD[kk + a + tl + 16];
+                const int n = dk - a + 1;  // entries in the ancestor's row
+                const int base = eadr[kk + a];
+                const double f = LD[kk + a] * inv;
+                const double r0 = tl < n ? LD[kk + a + tl] : 0.0;
+                const double r1 = tl + 16 < n ? LD[kk + a + tl + 16] : 0.0;
+                const double o0 = tl < n ? LD[base + tl] : 0.0;
+                const double o1 = tl + 16 < n ? LD[base + tl + 16] : 0.0;
+                if (tl < n) LD[base + tl] = o0 - f * r0;
+                if (tl + 16 < n) LD[base + tl + 16] = o1 - f * r1;
+                if (tl == 0) LD[kk + a] = f;
             }
         }
         wsync();
-        for (int a = 1 + LANE; a <= dk; a += UHC_WAVE) LD[kk + a] = LD[kk + a] / Dk;
-        wsync();
     }
-    for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.dinv + i] = 1.0 / LD[T.dof_madr[i]];
+    if (LC.v0) S[L.dinv + LANE] = 1.0 / LD[LC.m0];
+    if (LC.v1) S[L.dinv + LANE + UHC_WAVE] = 1.0 / LD[LC.m1];
     wsync();
 }
 
 // x = M^-1 x for one right-hand side held in registers (lane owns dofs LANE and LANE+64).
 // half: 0 = full solve, 1 = only  L^-1  (used after the constraint solve: qacc += L^-1 D^-1/2 z).
+// The serial chain is register-only (v_readlane + FMA); the L entries of U consecutive steps are
+// fetched from LDS up front so their latency overlaps.
 struct DofVec { double a, b; };
 __device__ __forceinline__ double dv_get(const DofVec& x, int i) { return i < UHC_WAVE ? bcast(x.a, i) : bcast(x.b, i - UHC_WAVE); }
 template <bool FAST>
-__device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half) {
+__device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const double* LD = S + ld;
     const int i0 = LANE, i1 = LANE + UHC_WAVE;
-    const bool v0 = i0 < T.nv, v1 = i1 < T.nv;
-    const int d0 = v0 ? T.dof_depth[i0] : 0, d1 = v1 ? T.dof_depth[i1] : 0;
-    const int n0 = v0 ? T.dof_ndesc[i0] : -1, n1 = v1 ? T.dof_ndesc[i1] : -1;
-    const int m0 = v0 ? T.dof_madr[i0] : 0, m1 = v1 ? T.dof_madr[i1] : 0;
+    constexpr int U = 4;
     if (!half) {
         // x <- L^-T x : for i descending, every ancestor j of i:  x[j] -= L[i][j] x[i]
-        for (int i = T.nv - 1; i > 0; i--) {
-            const int di = T.dof_depth[i];
-            if (di == 0) continue;
-            const double xi = dv_get(x, i);
-            const int mi = T.dof_madr[i];
-            if (v0 && i > i0 && i <= i0 + n0) x.a -= LD[mi + di - d0] * xi;
-            if (v1 && i > i1 && i <= i1 + n1) x.b -= LD[mi + di - d1] * xi;
+        for (int ib = T.nv - 1; ib >= 1; ib -= U) {
+            double l0[U], l1[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = ib - u;
+                l0[u] = 0; l1[u] = 0;
+                if (i >= 1) {
+                    const int pk = pk_of(LC, i), mi = pk & 0xffff, di = (pk >> 16) & 0xff;
+                    const bool c0 = LC.v0 && i > i0 && i <= i0 + LC.n0, c1 = LC.v1 && i > i1 && i <= i1 + LC.n1;
+                    const double t0 = LD[c0 ? mi + di - LC.d0 : 0], t1 = LD[c1 ? mi + di - LC.d1 : 0];
+                    l0[u] = c0 ? t0 : 0.0;
+                    l1[u] = c1 ? t1 : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = ib - u;
+                if (i >= 1) {
+                    const double xi = dv_get(x, i);
+                    x.a -= l0[u] * xi;
+                    x.b -= l1[u] * xi;
+                }
+            }
         }
-        if (v0) x.a *= S[L.dinv + i0];
-        if (v1) x.b *= S[L.dinv + i1];
+        if (LC.v0) x.a *= S[L.dinv + i0];
+        if (LC.v1) x.b *= S[L.dinv + i1];
     }
     // x <- L^-1 x : for j ascending, every descendant i of j:  x[i] -= L[i][j] x[j]
-    for (int j = 0; j < T.nv - 1; j++) {
-        const int nj = T.dof_ndesc[j];
-        if (nj == 0) continue;
-        const double xj = dv_get(x, j);
-        const int dj = T.dof_depth[j];
-        if (v0 && i0 > j && i0 <= j + nj) x.a -= LD[m0 + d0 - dj] * xj;
-        if (v1 && i1 > j && i1 <= j + nj) x.b -= LD[m1 + d1 - dj] * xj;
+    for (int jb = 0; jb < T.nv - 1; jb += U) {
+        double l0[U], l1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = jb + u;
+            l0[u] = 0; l1[u] = 0;
+            if (j < T.nv - 1) {
+                const int pk = pk_of(LC, j), dj = (pk >> 16) & 0xff, nj = (pk >> 24) & 0xff;
+                const bool c0 = LC.v0 && i0 > j && i0 <= j + nj, c1 = LC.v1 && i1 > j && i1 <= j + nj;
+                const double t0 = LD[c0 ? LC.m0 + LC.d0 - dj : 0], t1 = LD[c1 ? LC.m1 + LC.d1 - dj : 0];
+                l0[u] = c0 ? t0 : 0.0;
+                l1[u] = c1 ? t1 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = jb + u;
+            if (j < T.nv - 1) {
+                const double xj = dv_get(x, j);
+                x.a -= l0[u] * xj;
+                x.b -= l1[u] * xj;
+            }
+        }
     }
 }
 
@@ -451,7 +557,7 @@ __device__ __forceinline__ void k_rne(const KernelArgs& A, double* S) {  // qfrc
 
 // ------------------------------------------------------------------ P8 smooth forces / acceleration
 template <bool FAST>
-__device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, double* S) {
+__device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     // qfrc_smooth = passive - bias + applied + actuator  -> S.smooth
@@ -472,7 +578,7 @@ __device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, 
     DofVec x;
     x.a = LANE < T.nv ? S[L.smooth + LANE] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? S[L.smooth + LANE + UHC_WAVE] : 0.0;
-    k_solve<FAST>(A, S, L.LD, x, 0);
+    k_solve<FAST>(A, S, L.LD, x, 0, LC);
     if (LANE < T.nv) S[L.smooth + LANE] = x.a;  // now qacc_smooth
     if (LANE + UHC_WAVE < T.nv) S[L.smooth + LANE + UHC_WAVE] = x.b;
     wsync();
@@ -961,8 +1067,56 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     return 0;
 }
 
+// Lane I alone commits its row step: f <- fn, improvement += term.  Done under a one-lane exec mask so the
+// 64 unrolled steps need neither per-step lane-compare masks nor selects (exec is all-ones around this).
+template <int I>
+__device__ __forceinline__ void commit_lane(double& f, double fn, double& imp, double term) {
+    constexpr unsigned lo = I < 32 ? (1u << I) : 0u, hi = I < 32 ? 0u : (1u << (I - 32));
+    asm volatile(
+        "s_mov_b32 exec_lo, %4\n\t"
+        "s_mov_b32 exec_hi, %5\n\t"
+        "v_mov_b64 %0, %2\n\t"
+        "v_add_f64 %1, %1, %3\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(f), "+v"(imp)
+        : "v"(fn), "v"(term), "n"(lo), "n"(hi));
+}
+
+// N = rows swept (multiple of 8 >= nefc; padding rows have f = res = 0 and A = 0, so their steps are no-ops).
+// Every lane evaluates the step of ITS row at each of the N unrolled steps; only lane i commits at step i,
+// then delta_i is broadcast (two v_readlane) and all residuals move by delta_i * A[:, i] (one FMA).
+// The reference solver's "cost went up by > 1e-10 -> revert the step" guard is omitted: in exact
+// arithmetic a projected 1-D minimisation never raises the cost, and the guard would put five more
+// dependent instructions on the serial chain (the general kernel and the oracle keep it).
+template <int N, bool FRIC>
+__device__ __forceinline__ int pgs_sweeps(double (&Arow)[UHC_WAVE], double& f, double& res, double dinvA, double diag,
+                                          bool fric, double floss, int iterations, double scale, double tolerance) {
+    int iters = 0;
+    for (int it = 0; it < iterations; it++) {
+        double improvement = 0;
+        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            double fn = fma(-res, dinvA, f);
+            if (FRIC) {
+                const double a = max0(fn), c = clampd(fn, -floss, floss);
+                fn = fric ? c : a;
+            } else {
+                fn = max0(fn);
+            }
+            const double delta = fn - f;
+            const double term = -delta * fma(0.5 * delta, diag, res);
+            const double di = bcast(delta, i);
+            commit_lane<i>(f, fn, improvement, term);
+            res = fma(di, Arow[i], res);
+        });
+        iters = it + 1;
+        if (wave_sum(improvement) * scale < tolerance) break;
+    }
+    return iters;
+}
+
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
-__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row) {
+__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const bool valid = LANE < nefc;
@@ -984,6 +1138,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         Arow[s] = acc;
     });
     if (!valid) diag = 1.0;
+    PROF(10)
     const double dinvA = 1.0 / diag;
     // ---- residual of the warm start, dual cost test
     double f = row.f, res = row.b;
@@ -996,28 +1151,21 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     if (cost > 0) { f = 0; res = row.b; }
     const double scale = 1.0 / (mb[A.o.meaninertia] * (T.nv > 1 ? T.nv : 1));
     const bool fric = row.type == ROW_FRICTION;
-    const double floss = row.floss;
-    int iters = 0;
-    for (int it = 0; it < T.iterations; it++) {
-        double improvement = 0;
-        static_for<0, UHC_WAVE>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            if (i < nefc) {
-                // every lane steps its own row; only lane i's step is taken
-                double fn = f - res * dinvA;
-                fn = fric ? clampd(fn, -floss, floss) : fmax(fn, 0.0);
-                double delta = fn - f;
-                double change = 0.5 * delta * delta * diag + delta * res;
-                if (change > 1e-10) { delta = 0; change = 0; }
-                const double di = bcast(delta, i);
-                if (LANE == i) { f += delta; improvement -= change; }
-                res += di * Arow[i];
-            }
-        });
-        iters = it + 1;
-        if (wave_sum(improvement) * scale < T.tolerance) break;
+    const bool any_fric = wave_or(fric ? 1 : 0) != 0;
+    int iters;
+    if (any_fric) iters = pgs_sweeps<UHC_WAVE, true>(Arow, f, res, dinvA, diag, fric, row.floss, T.iterations, scale, T.tolerance);
+    else switch ((nefc + 7) >> 3) {
+        case 1: iters = pgs_sweeps<8, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 2: iters = pgs_sweeps<16, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 3: iters = pgs_sweeps<24, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 4: iters = pgs_sweeps<32, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 5: iters = pgs_sweeps<40, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 6: iters = pgs_sweeps<48, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 7: iters = pgs_sweeps<56, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        default: iters = pgs_sweeps<64, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
     }
     row.f = f;
+    PROF(11)
     // ---- z = sum_r f_r Yhat_r (dof-per-lane pull), for qacc = qacc_smooth + L^-1 D^-1/2 z
     for (int h = 0; h < 2; h++) {
         const int i = LANE + h * UHC_WAVE;
@@ -1042,22 +1190,30 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
 template <bool FAST>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     FwdOut out = {0, 0, 0, 0};
     k_kinematics<FAST>(A, mb, S);
+    PROF(1)
     k_com_pos<FAST>(A, mb, S);
+    PROF(2)
     k_crb<FAST>(A, mb, S);
+    PROF(3)
     if (!FAST) {
         for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
         wsync();
     }
-    k_factor<FAST>(A, S, L.LD);
+    k_factor<FAST>(A, S, L.LD, LC);
+    PROF(4)
     k_com_vel<FAST>(A, S);
+    PROF(5)
     k_rne<FAST>(A, S);
-    k_smooth<FAST>(A, mb, S);
+    PROF(6)
+    k_smooth<FAST>(A, mb, S, LC);
+    PROF(7)
     out.ncon = k_collision<FAST>(A, mb, S, &out.overflow);
+    PROF(8)
     out.nefc = k_enumerate_rows<FAST>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
     if (FAST && out.overflow) return out;
@@ -1065,15 +1221,19 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
         if (FAST) {
             FastRow row;
             if (k_rows_fast(A, mb, S, out.nefc, row)) { out.overflow = 1; return out; }
-            out.iters = k_pgs_fast(A, mb, S, out.nefc, row);
+            PROF(9)
+            out.iters = k_pgs_fast(A, mb, S, out.nefc, row PROF_PASS);
+            PROF(12)
         } else {
             k_rows<FAST>(A, mb, S, out.nefc);
+            PROF(9)
             out.iters = k_pgs<FAST>(A, mb, S, out.nefc);
+            PROF(11)
         }
         // qacc = qacc_smooth + L^-1 D^-1/2 z
         if (LANE < T.nv) x.a = S[L.z + LANE] * sqrt(S[L.dinv + LANE]);
         if (LANE + UHC_WAVE < T.nv) x.b = S[L.z + LANE + UHC_WAVE] * sqrt(S[L.dinv + LANE + UHC_WAVE]);
-        k_solve<FAST>(A, S, L.LD, x, 1);
+        k_solve<FAST>(A, S, L.LD, x, 1, LC);
     }
     if (LANE < T.nv) S[L.qacc + LANE] = S[L.smooth + LANE] + x.a;
     if (LANE + UHC_WAVE < T.nv) S[L.qacc + LANE + UHC_WAVE] = S[L.smooth + LANE + UHC_WAVE] + x.b;
@@ -1117,7 +1277,7 @@ __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVA
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
 // previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
 template <bool FAST>
-__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const double* Mprev) {
+__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const double* Mprev, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
@@ -1153,11 +1313,11 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
         }
     }
     wsync();
-    k_factor<FAST>(A, S, L.LD);
+    k_factor<FAST>(A, S, L.LD, LC);
     DofVec x;
     x.a = LANE < T.nv ? -S[L.bias + LANE] - kp[0] * qe[0] - kd[0] * qv[0] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? -S[L.bias + LANE + UHC_WAVE] - kp[1] * qe[1] - kd[1] * qv[1] : 0.0;
-    k_solve<FAST>(A, S, L.LD, x, 0);
+    k_solve<FAST>(A, S, L.LD, x, 0, LC);
     for (int h = 0; h < 2; h++) {
         const int a = LANE + h * UHC_WAVE - 6;
         if (a >= 0 && a < nu) {
@@ -1213,19 +1373,26 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
     for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
     if (MODE == 0 && !FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
+    {   // 16-bit row-address table of the sparse entries (used by the factorisation), two entries per 32-bit word
+        unsigned int* dst = (unsigned int*)(S + L.eadr);
+        const unsigned int* src = (const unsigned int*)T.e_adr;
+        for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
+    }
+    const LaneConst LC = lane_const(T);
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0;
     bool ran = false;
+    PROF_DECL
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S);
+        fo = k_forward<FAST>(A, mb, S, LC PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
         for (int it = 0; it < A.c.n_substeps; it++) {
-            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, ran ? A.s.qM_tmp : A.s.qM);
+            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, ran ? A.s.qM_tmp : A.s.qM, LC);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
                     S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
@@ -1237,7 +1404,9 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
-            fo = k_forward<FAST>(A, mb, S);
+            PROF(0)
+            fo = k_forward<FAST>(A, mb, S, LC PROF_PASS);
+            PROF(13)
             overflow |= fo.overflow;
             if (FAST && overflow) break;
             ran = true;
@@ -1245,6 +1414,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
             if (wave_or(b)) { fail = 1; break; }
             k_euler<FAST>(A, S);
+            PROF(14)
         }
     }
     if (FAST && overflow) {  // nothing committed: the general kernel redoes this env from the same inputs
@@ -1270,6 +1440,15 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         }
         for (int i = LANE; i < 4 * T.nbody; i += UHC_WAVE) A.s.xquat[(size_t)env * 4 * T.nbody + i] = S[L.xquat + i];
     }
+#ifdef UHC_STAGE_PROF
+    PROF(15)
+    if (A.s.prof) {
+        long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (LANE == k) mine = pt_[k];
+        if (LANE < 16) A.s.prof[(size_t)env * 16 + LANE] += mine;
+    }
+#endif
     if (LANE == 0) {
         if (ran) { A.s.ncon[env] = fo.ncon; A.s.nefc[env] = fo.nefc; A.s.solver_iter[env] = fo.iters; }
         A.s.fail[env] = fail;

@@ -12,7 +12,7 @@ from ._capi import UhcCtrlDesc, model_desc
 from ._lib import check, lib
 
 F_QPOS, F_QVEL, F_XPOS, F_XQUAT, F_XIPOS, F_QM, F_QFRC_BIAS, F_QACC, F_CTRL = range(9)
-F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW = range(9, 15)
+F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF = range(9, 16)
 _INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW}
 
 
@@ -75,7 +75,9 @@ class SimBatch:
         p, n = C.c_void_p(), C.c_int64()
         check(self.L.uhc_batch_field(self._b, f, C.byref(p), C.byref(n)))
         per = n.value // self.n_env
-        if f in _INT_FIELDS:
+        if f == F_STAGE_PROF:
+            t = torch.as_tensor(_DevView(p.value, (self.n_env, 16), "<i8", self), device=self.device)
+        elif f in _INT_FIELDS:
             t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<i4", self), device=self.device)
         else:
             t = torch.as_tensor(_DevView(p.value, (self.n_env, per), "<f8", self), device=self.device)
