@@ -1,0 +1,104 @@
+"""TEST INFRASTRUCTURE: numpy restatement, one environment, of the Python-side env math of the
+reference -- observation v2, local body quaternions, termination distance, imitation reward.
+Pinned by tests/golden/g4_g6_obs_reward.npz (outputs of the imported reference functions).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+
+import numpy as np
+
+from uhc_amd.utils.math_utils import (de_heading, get_angvel_fd, get_heading, get_heading_q, multi_quat_diff, multi_quat_norm,
+                                      transform_vec, transform_vec_batch)
+from uhc_amd.utils.transformation import (quaternion_from_euler_rzyx, quaternion_inverse, quaternion_inverse_batch,
+                                          quaternion_multiply, quaternion_multiply_batch)
+
+BASE_ROT = np.array([0.7071, 0.7071, 0.0, 0.0])
+EE_BODY_IDS = [4, 8, 18, 23, 14]  # L_Ankle, R_Ankle, L_Wrist, R_Wrist, Head (smpl_parser.py:228) in model body ids
+
+
+def remove_base_rot(q, base_rot=BASE_ROT):
+    return quaternion_multiply(q, quaternion_inverse(base_rot))  # humanoid_im.py:263-264
+
+
+def get_body_quat(qpos):
+    """humanoid_im.py:925-947 (hinge model): root quat + per body quaternion_from_euler(z, y, x, 'rzyx')."""
+    e = qpos[7:].reshape(-1, 3)
+    return np.concatenate([qpos[3:7], quaternion_from_euler_rzyx(e[:, 0], e[:, 1], e[:, 2]).ravel()])
+
+
+def calc_body_diff(xpos, e_wbpos, jpos_diffw):
+    """humanoid_im.py:1408-1415: mean over weighted bodies of |w (x - x_expert)|."""
+    diff = (xpos[1:].reshape(-1, 3) - e_wbpos.reshape(-1, 3)) * jpos_diffw[:, None]
+    return np.linalg.norm(diff[jpos_diffw.astype(bool)], axis=1).mean()
+
+
+def expert_index(cur_t, start_ind, length):
+    return min(start_ind + cur_t, length - 1)  # humanoid_im.py:1323-1324 (non-cyclic)
+
+
+def full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, gender=None, base_rot=BASE_ROT):
+    """humanoid_im.py:419-503 with obs_coord='root', obs_vel='full'."""
+    qpos, qvel = qpos.copy(), qvel.copy()
+    qvel[:3] = transform_vec(qvel[:3], qpos[3:7], "root")
+    obs = []
+    curr_root_quat = remove_base_rot(qpos[3:7], base_rot)
+    hq = get_heading_q(curr_root_quat)
+    obs.append(hq)
+    ind = expert_index(cur_t + 1, start_ind, expert["len"])
+    target_body_qpos = expert["qpos"][ind].copy()
+    target_quat = expert["wbquat"][ind].reshape(-1, 4)
+    target_jpos = expert["wbpos"][ind]
+    target_root_quat = remove_base_rot(target_body_qpos[3:7], base_rot)
+    qpos[3:7] = de_heading(curr_root_quat)
+    diff_qpos = target_body_qpos.copy()
+    diff_qpos[2] -= qpos[2]
+    diff_qpos[7:] -= qpos[7:]
+    diff_qpos[3:7] = quaternion_multiply(target_root_quat, quaternion_inverse(curr_root_quat))
+    obs += [target_body_qpos[2:], qpos[2:], diff_qpos[2:]]
+    qvel[:3] = transform_vec(qvel[:3], curr_root_quat, "root")  # second rotation: reproduced as in the reference (:451)
+    obs.append(qvel)
+    rel_h = get_heading(target_root_quat) - get_heading(curr_root_quat)
+    if rel_h > np.pi:
+        rel_h -= 2 * np.pi
+    if rel_h < -np.pi:
+        rel_h += 2 * np.pi
+    obs.append(np.array([rel_h]))
+    rel_pos = target_root_quat[:3] - qpos[:3]  # bug-compatible (:466)
+    obs.append(transform_vec(rel_pos, curr_root_quat, "root")[:2])
+    curr_jpos = xpos[1:].copy()
+    r_jpos = transform_vec_batch(curr_jpos - qpos[None, :3], curr_root_quat, "root")
+    obs.append(r_jpos.ravel())  # (3, 24) raveled: component-major
+    diff_jpos = transform_vec_batch(target_jpos.reshape(-1, 3) - curr_jpos, curr_root_quat, "root")
+    obs.append(diff_jpos.ravel())
+    cur_quat = xquat[1:].copy()
+    if cur_quat[0, 0] == 0:
+        cur_quat = target_quat.copy()
+    hq_inv = np.repeat(quaternion_inverse(hq)[None], cur_quat.shape[0], axis=0)
+    obs.append(quaternion_multiply_batch(hq_inv, cur_quat).ravel())
+    obs.append(quaternion_multiply_batch(quaternion_inverse_batch(cur_quat), target_quat).ravel())
+    if beta is not None:
+        obs += [beta, [gender]]
+    return np.concatenate(obs)
+
+
+def world_rfc_implicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur_t, start_ind, dt, body_diffw, w, ndof=69, vf_dim=6):
+    """reward_function.py:12-88.  `w` is the reward_weights dict; returns (reward, 5 components)."""
+    ind = expert_index(cur_t, start_ind, expert["len"])
+    cur_ee = xpos[EE_BODY_IDS].ravel()
+    cur_bquat = get_body_quat(qpos)
+    cur_bangvel = get_angvel_fd(prev_bquat, cur_bquat, dt)
+    e_ee, e_com = expert["ee_wpos"][ind], expert["com"][ind]
+    e_bquat, e_bangvel = expert["bquat"][ind], expert["bangvel"][ind]
+    pose_diff = multi_quat_norm(multi_quat_diff(cur_bquat, e_bquat))
+    pose_diff[1:] *= body_diffw
+    pose_r = math.exp(-w["k_p"] * np.linalg.norm(pose_diff) ** 2)
+    jw = np.concatenate([[1.0], body_diffw])
+    vel_dist = np.linalg.norm((cur_bangvel.reshape(-1, 3) * jw[:, None]).ravel() - (e_bangvel.reshape(-1, 3) * jw[:, None]).ravel())
+    vel_r = math.exp(-w["k_v"] * vel_dist ** 2)
+    ee_r = math.exp(-w["k_e"] * np.linalg.norm(cur_ee - e_ee) ** 2)
+    com_r = math.exp(-w["k_c"] * np.linalg.norm(xipos[1] - e_com) ** 2)
+    vf = action[ndof:ndof + vf_dim]
+    vf_r = math.exp(-w["k_vf"] * np.linalg.norm(vf) ** 2)
+    parts = np.array([pose_r, vel_r, ee_r, com_r, vf_r])
+    ws = np.array([w["w_p"], w["w_v"], w["w_e"], w["w_c"], w["w_vf"]])
+    return float((ws * parts).sum() / ws.sum()), parts

@@ -31,6 +31,8 @@ def lib():
             getattr(L, fn).restype = None
         L.orc_set_state.argtypes = [C.POINTER(UhcModelDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_do_simulation.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_pd_torque.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+        L.orc_rfc_implicit.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double)]
         L.orc_batch_do_simulation.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), C.POINTER(P), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_get.argtypes = [C.POINTER(UhcModelDesc), P, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.orc_get.restype = C.c_int
@@ -81,6 +83,17 @@ class OracleSim:
         action = np.ascontiguousarray(action, dtype=np.float64)
         target_base = np.ascontiguousarray(target_base, dtype=np.float64)
         self.L.orc_do_simulation(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action), _dp(target_base))
+
+    def pd_torque(self, action, target_base, it):
+        action = np.ascontiguousarray(action, dtype=np.float64)
+        target_base = np.ascontiguousarray(target_base, dtype=np.float64)
+        self.L.orc_pd_torque(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action), _dp(target_base), int(it))
+        return self.get("ctrl")
+
+    def rfc_implicit(self, action):
+        action = np.ascontiguousarray(action, dtype=np.float64)
+        self.L.orc_rfc_implicit(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action))
+        return self.get("qfrc_applied")
 
     def get(self, name: str) -> np.ndarray:
         n = self.L.orc_get(C.byref(self.desc), self.d, name.encode(), None, 0)

@@ -771,6 +771,59 @@ static void quat_rot(double r[3], const double q[4], const double v[3]) {
     quat_to_mat(R, q);
     mat_vec(r, R, v);
 }
+/* compute_torque + clip (humanoid_im.py:1033-1076, :1161) for substep `it`: writes d->ctrl */
+void orc_pd_torque(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
+                   const double* target_base, int it) {
+    int nv = m->nv, nu = m->nu;
+    double dt = m->timestep;
+    int vf_dim = c->rfc_mode == 1 ? 6 : 0;
+    double* kp = calloc(nv, 8); double* kd = calloc(nv, 8); double* qerr = calloc(nv, 8);
+    double* rhs = calloc(nv, 8); double* MK = malloc(d->nM * 8);
+    double skp = 1, skd = 1;
+    if (c->meta_pd == 1) { /* :1054-1057 */
+        skp = fmin(fmax(action[nu + vf_dim + it] + 1, 0), 10);
+        skd = fmin(fmax(action[nu + vf_dim + it + c->n_substeps] + 1, 0), 10);
+    }
+    for (int a = 0; a < nu; a++) {
+        double cur = d->qpos[7 + a], base = target_base[a];
+        while (base - cur > M_PI) base -= 2 * M_PI;   /* :1042-1045 */
+        while (base - cur < -M_PI) base += 2 * M_PI;
+        double target = base + action[a];
+        double gkp = c->jkp[a], gkd = c->jkd[a];
+        if (c->meta_pd == 1) { gkp *= skp; gkd *= skd; }
+        else if (c->meta_pd == 2) {
+            gkp *= fmin(fmax(action[nu + vf_dim + a] + 1, 0), 10);
+            gkd *= fmin(fmax(action[nu + vf_dim + nu + a] + 1, 0), 10);
+        }
+        kp[6 + a] = gkp; kd[6 + a] = gkd;
+        qerr[6 + a] = cur + d->qvel[6 + a] * dt - target;  /* :1071 */
+    }
+    /* compute_desired_accel: (M + Kd dt) qdd = -C - Kp e_q - Kd e_v   (:1014-1031) */
+    memcpy(MK, d->qM, d->nM * 8);
+    for (int i = 0; i < nv; i++) {
+        MK[m->dof_madr[i]] += kd[i] * dt;
+        rhs[i] = -d->qfrc_bias[i] - kp[i] * qerr[i] - kd[i] * d->qvel[i];
+    }
+    orc_factor_sparse(m, MK);
+    orc_solve_sparse(m, MK, rhs);
+    for (int a = 0; a < nu; a++) {
+        double tq = -kp[6 + a] * qerr[6 + a] - kd[6 + a] * (d->qvel[6 + a] + rhs[6 + a] * dt); /* :1073-1075 */
+        d->ctrl[a] = fmin(fmax(tq, -c->torque_lim[a]), c->torque_lim[a]);                       /* :1161 */
+    }
+    free(kp); free(kd); free(qerr); free(rhs); free(MK);
+}
+/* rfc_implicit: humanoid_im.py:1136-1143 -> d->qfrc_applied[0:6] */
+void orc_rfc_implicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action) {
+    double vf[6], q[4], binv[4] = {c->base_rot[0], -c->base_rot[1], -c->base_rot[2], -c->base_rot[3]}, hq[4], r[3];
+    double bn = c->base_rot[0] * c->base_rot[0] + c->base_rot[1] * c->base_rot[1] + c->base_rot[2] * c->base_rot[2] + c->base_rot[3] * c->base_rot[3];
+    for (int k = 0; k < 4; k++) binv[k] /= bn; /* quaternion_inverse divides by |q|^2 (transformation.py:1509-1520) */
+    for (int k = 0; k < 6; k++) vf[k] = action[m->nu + k] * c->rfc_scale;
+    quat_mul(q, d->qpos + 3, binv);
+    heading_q(hq, q);
+    quat_rot(r, hq, vf);
+    memcpy(vf, r, 24);
+    for (int k = 0; k < 6; k++) d->qfrc_applied[k] = fmin(fmax(vf[k], -c->rfc_lim), c->rfc_lim);
+}
 /*
  * One HumanoidEnv.do_simulation (humanoid_im.py:1145-1190).  action layout: humanoid_im.py:226-255.
  * M and C used by the PD solve are the ones left in `d` by the previous forward pass
@@ -778,62 +831,14 @@ static void quat_rot(double r[3], const double q[4], const double v[3]) {
  */
 void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
                        const double* target_base) {
-    int nv = m->nv, nu = m->nu, nq = m->nq;
-    double dt = m->timestep;
-    int vf_dim = c->rfc_mode == 1 ? 6 : 0;
-    double* kp = calloc(nv, 8); double* kd = calloc(nv, 8); double* qerr = calloc(nv, 8);
-    double* rhs = calloc(nv, 8); double* MK = malloc(d->nM * 8); double* torque = calloc(nu, 8);
     for (int it = 0; it < c->n_substeps && !d->fail; it++) {
-        if (c->action_type == 0) {
-            /* compute_torque: humanoid_im.py:1033-1076 */
-            double skp = 1, skd = 1;
-            if (c->meta_pd == 1) {
-                skp = fmin(fmax(action[nu + vf_dim + it] + 1, 0), 10);
-                skd = fmin(fmax(action[nu + vf_dim + it + c->n_substeps] + 1, 0), 10);
-            }
-            for (int a = 0; a < nu; a++) {
-                double cur = d->qpos[7 + a], base = target_base[a];
-                while (base - cur > M_PI) base -= 2 * M_PI;   /* :1042-1045 */
-                while (base - cur < -M_PI) base += 2 * M_PI;
-                double target = base + action[a];
-                double gkp = c->jkp[a], gkd = c->jkd[a];
-                if (c->meta_pd == 1) { gkp *= skp; gkd *= skd; }
-                else if (c->meta_pd == 2) {
-                    gkp *= fmin(fmax(action[nu + vf_dim + a] + 1, 0), 10);
-                    gkd *= fmin(fmax(action[nu + vf_dim + nu + a] + 1, 0), 10);
-                }
-                kp[6 + a] = gkp; kd[6 + a] = gkd;
-                qerr[6 + a] = cur + d->qvel[6 + a] * dt - target;  /* :1071 */
-            }
-            /* compute_desired_accel: (M + Kd dt) qdd = -C - Kp e_q - Kd e_v   (:1014-1031) */
-            memcpy(MK, d->qM, d->nM * 8);
-            for (int i = 0; i < nv; i++) {
-                MK[m->dof_madr[i]] += kd[i] * dt;
-                rhs[i] = -d->qfrc_bias[i] - kp[i] * qerr[i] - kd[i] * d->qvel[i];
-            }
-            orc_factor_sparse(m, MK);
-            orc_solve_sparse(m, MK, rhs);
-            for (int a = 0; a < nu; a++)
-                torque[a] = -kp[6 + a] * qerr[6 + a] - kd[6 + a] * (d->qvel[6 + a] + rhs[6 + a] * dt); /* :1073-1075 */
-        } else {
-            for (int a = 0; a < nu; a++) torque[a] = action[a] * c->a_scale[a] * 100; /* :1160 */
-        }
-        for (int a = 0; a < nu; a++) d->ctrl[a] = fmin(fmax(torque[a], -c->torque_lim[a]), c->torque_lim[a]); /* :1161 */
-        if (c->rfc_mode == 1) { /* rfc_implicit: :1136-1143 */
-            double vf[6], q[4], binv[4] = {c->base_rot[0], -c->base_rot[1], -c->base_rot[2], -c->base_rot[3]}, hq[4], r[3];
-            double bn = c->base_rot[0] * c->base_rot[0] + c->base_rot[1] * c->base_rot[1] + c->base_rot[2] * c->base_rot[2] + c->base_rot[3] * c->base_rot[3];
-            for (int k = 0; k < 4; k++) binv[k] /= bn; /* quaternion_inverse divides by |q|^2 (transformation.py:1505-1517) */
-            for (int k = 0; k < 6; k++) vf[k] = action[nu + k] * c->rfc_scale;
-            quat_mul(q, d->qpos + 3, binv);
-            heading_q(hq, q);
-            quat_rot(r, hq, vf);
-            memcpy(vf, r, 24);
-            for (int k = 0; k < 6; k++) d->qfrc_applied[k] = fmin(fmax(vf[k], -c->rfc_lim), c->rfc_lim);
-        }
-        (void)nq;
+        if (c->action_type == 0) orc_pd_torque(m, c, d, action, target_base, it);
+        else
+            for (int a = 0; a < m->nu; a++) /* :1160-1161 */
+                d->ctrl[a] = fmin(fmax(action[a] * c->a_scale[a] * 100, -c->torque_lim[a]), c->torque_lim[a]);
+        if (c->rfc_mode == 1) orc_rfc_implicit(m, c, d, action);
         orc_step(m, d);
     }
-    free(kp); free(kd); free(qerr); free(rhs); free(MK); free(torque);
 }
 
 /* ------------------------------------------------------------------ field access for tests */

@@ -45,6 +45,9 @@ void orc_forward(const UhcModelDesc* m, OrcData* d);
 void orc_euler(const UhcModelDesc* m, OrcData* d);
 void orc_step(const UhcModelDesc* m, OrcData* d);
 void orc_set_state(const UhcModelDesc* m, OrcData* d, const double* qpos, const double* qvel);
+void orc_pd_torque(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
+                   const double* target_base, int it);
+void orc_rfc_implicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action);
 void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
                        const double* target_base);
 void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData** ds, int n_env,

@@ -1,0 +1,145 @@
+"""CPU tests: this build's host code and the oracle against golden vectors produced by the imported
+reference (tools/gen_golden.py; fixtures under tests/golden/)."""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def expert_from(f):
+    e = {k[2:]: f[k] for k in f.files if k.startswith("f_")}
+    e["len"] = int(e["len"])
+    return e
+
+
+REWARD_W = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0)
+
+
+def test_quaternion_and_heading_helpers():
+    from uhc_amd.utils import math_utils as mu, transformation as tf
+    g = load("g1_math")
+    q, p, v, eul = g["q"], g["p"], g["v"], g["eul"]
+
+    def chk(name, val, tol=1e-13):
+        np.testing.assert_allclose(np.asarray(val), g[name], atol=tol, rtol=0, err_msg=name)
+
+    chk("quaternion_multiply", [tf.quaternion_multiply(a, b) for a, b in zip(q, p)])
+    chk("quaternion_inverse", [tf.quaternion_inverse(a * 1.3) for a in q])
+    chk("quaternion_matrix", [tf.quaternion_matrix(a)[:3, :3] for a in q])
+    chk("quaternion_from_euler_rzyx", tf.quaternion_from_euler_rzyx(eul[:, 0], eul[:, 1], eul[:, 2]))
+    chk("rotation_from_quaternion", [tf.rotation_from_quaternion(a) for a in q])
+    chk("get_heading", [mu.get_heading(a) for a in q])
+    chk("get_heading_q", [mu.get_heading_q(a) for a in q])
+    chk("de_heading", [mu.de_heading(a) for a in q])
+    chk("transform_vec_root", [mu.transform_vec(b, a, "root") for a, b in zip(q, v)])
+    chk("transform_vec_heading", [mu.transform_vec(b, a, "heading") for a, b in zip(q, v)])
+    chk("quat_mul_vec", [mu.quat_mul_vec(a, b) for a, b in zip(q, v)])
+    out = mu.transform_vec_batch(g["vb"], q[0], "root")
+    assert out.shape == (3, 24)  # component-major, SURVEY 3.5
+    chk("transform_vec_batch_root", out)
+    d = mu.multi_quat_diff(q[:24].ravel(), p[:24].ravel())
+    chk("multi_quat_diff", d)
+    chk("multi_quat_norm", mu.multi_quat_norm(d))
+    chk("get_angvel_fd", mu.get_angvel_fd(p[:24].ravel(), q[:24].ravel(), 1 / 30), tol=1e-11)
+    # doctest known answers of the reference's transformation.py
+    chk("kat_about_axis", tf.quaternion_about_axis(0.123, [1, 0, 0]))
+    chk("kat_multiply", tf.quaternion_multiply([4, 1, -2, 3], [8, -5, 6, 7]))
+    np.testing.assert_allclose(g["kat_multiply"], [28, -44, -14, 48])
+    np.testing.assert_allclose(g["kat_about_axis"], [0.99810947, 0.06146124, 0, 0], atol=1e-8)
+
+
+def test_smpl_to_qpose_matches_reference_and_shipped_clip(model):
+    from uhc_amd.smpllib.smpl_mujoco import smpl_to_qpose
+    g = load("g2_smpl_to_qpose_standing")
+    q = smpl_to_qpose(g["pose_aa"], model)
+    np.testing.assert_allclose(q, g["qpos"], atol=2e-6)
+    # implicit golden vector of the reference: standing_neutral.qpos == smpl_to_qpose(pose_aa[10])
+    np.testing.assert_allclose(q[10, 3:], g["ref_qpos"][3:], atol=2e-6)
+    g3 = load("g3_qpos_fk")
+    np.testing.assert_allclose(smpl_to_qpose(g3["pose_aa"], model, trans=g3["trans"]), g3["f_qpos"], atol=2e-6)
+
+
+def test_expert_features_qpos_fk(model):
+    import torch
+    from uhc_amd.smpllib.torch_smpl_humanoid import Humanoid
+    g = load("g3_qpos_fk")
+    f = Humanoid(model=model).qpos_fk(torch.from_numpy(g["f_qpos"]))
+    assert f["len"] == int(g["f_len"])
+    for k in ("qpos", "qvel", "wbpos", "wbquat", "bquat", "body_com", "rlinv", "rlinv_local", "rangv", "bangvel", "ee_wpos", "ee_pos",
+              "com", "height_lb"):
+        np.testing.assert_allclose(np.asarray(f[k]), g["f_" + k], atol=1e-11, rtol=0, err_msg=k)
+
+
+def test_oracle_kinematics_matches_reference_fk(model):
+    """The reference's own independent FK (torch_smpl_humanoid.py:303-362; pinned above through Humanoid.qpos_fk)
+    pins the oracle's P1 stage.  The reference FK does not normalise the root quaternion (MuJoCo does), so the
+    comparison is exact on unit quaternions and 2e-6 on the raw fixture."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd.smpllib.torch_smpl_humanoid import Humanoid
+    g = load("g3_qpos_fk")
+    o = OracleSim(model)
+    qn = g["f_qpos"].copy()
+    qn[:, 3:7] /= np.linalg.norm(qn[:, 3:7], axis=1, keepdims=True)
+    f = Humanoid(model=model).qpos_fk(torch.from_numpy(qn))
+    for t in (0, 13, 39):
+        o.set("qpos", qn[t])
+        o.call("kinematics")
+        np.testing.assert_allclose(o.get("xpos")[3:], f["wbpos"][t], atol=1e-12)
+        np.testing.assert_allclose(o.get("xipos")[3:], f["body_com"][t], atol=1e-12)
+        wq, rq = o.get("xquat")[4:].reshape(-1, 4), f["wbquat"][t].reshape(-1, 4)
+        np.testing.assert_allclose(np.abs((wq * rq).sum(1)), 1.0, atol=1e-12)  # same rotation (q ~ -q)
+        o.set("qpos", g["f_qpos"][t])
+        o.call("kinematics")
+        np.testing.assert_allclose(o.get("xpos")[3:], g["f_wbpos"][t], atol=2e-6)
+
+
+def test_env_oracle_observation_reward_termination(model):
+    from oracle import env_oracle as E
+    from uhc_amd.smpllib.smpl_mujoco import SMPLConverter
+    g, f = load("g4_g6_obs_reward"), load("g3_qpos_fk")
+    expert = expert_from(f)
+    jw = SMPLConverter(model, model).get_new_diff_weight()
+    for c in range(int(g["ncase"])):
+        p = f"c{c}_"
+        t = int(g[p + "cur_t"])
+        obs = E.full_obs_v2(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], g[p + "xquat"], expert, t, 0, g[p + "beta"], float(g["gender"]))
+        assert obs.shape == (657,)
+        np.testing.assert_allclose(obs, g[p + "obs"], atol=1e-13)
+        np.testing.assert_allclose(E.get_body_quat(g[p + "qpos"]), g[p + "bquat"], atol=1e-14)
+        bd = E.calc_body_diff(g[p + "xpos"], expert["wbpos"][E.expert_index(t, 0, expert["len"])], jw)
+        assert bd == pytest.approx(float(g[p + "body_diff"]), abs=1e-14)
+        r, parts = E.world_rfc_implicit_reward(g[p + "qpos"], g[p + "xpos"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"], expert,
+                                               t, 0, model.timestep * 15, jw[1:], REWARD_W)
+        assert r == pytest.approx(float(g[p + "reward"]), abs=1e-13)
+        np.testing.assert_allclose(parts, g[p + "reward_info"], atol=1e-12)
+
+
+def test_oracle_pd_controller_and_rfc(model, ctrl):
+    """compute_torque / compute_desired_accel / rfc_implicit of the reference vs the C oracle."""
+    from oracle.physics import OracleSim
+    g = load("g5_pd_rfc")
+    o = OracleSim(model, ctrl)
+    o.set("qpos", g["qpos"])
+    o.set("qvel", g["qvel"])
+    M, qM = g["M"], np.zeros(model.nM)
+    for i in range(model.nv):
+        adr, j = model.dof_madr[i], i
+        while j >= 0:
+            qM[adr] = M[i, j]
+            adr += 1
+            j = model.dof_parentid[j]
+    o.set("qM", qM)
+    o.set("qfrc_bias", g["C"])
+    for it in (0, 7, 14):
+        ref = np.clip(g[f"torque_{it}"], -g["torque_lim"], g["torque_lim"])
+        np.testing.assert_allclose(o.pd_torque(g["action"], g["target_base"], it), ref, atol=1e-9)
+    np.testing.assert_allclose(o.rfc_implicit(g["action"]), g["qfrc_applied"], atol=1e-12)
+    np.testing.assert_allclose(np.array([ctrl.jkp[i] for i in range(69)]), g["jkp"])
+    np.testing.assert_allclose(np.array([ctrl.torque_lim[i] for i in range(69)]), g["torque_lim"])

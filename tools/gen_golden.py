@@ -1,0 +1,308 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference (build container only).
+
+Every fixture is pure data: seeded inputs + the outputs the reference's own functions produce.
+The reference is pure Python; third-party packages it imports but this image lacks are stubbed
+(tools/ref_import.py).  MuJoCo itself is never executed (it is absent): reference functions that
+read `self.data` / `self.model` are called unbound on duck-typed objects carrying synthetic arrays.
+
+    python tools/gen_golden.py            # writes all fixtures
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_import  # noqa: E402
+
+ref_import.install()
+import torch  # noqa: E402
+
+torch.set_default_dtype(torch.float64)  # scripts/train_uhc.py:80-81
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+from uhc_amd.model.mjcf import compile_mjcf_file  # noqa: E402
+
+REF = ref_import.REF
+MODEL = compile_mjcf_file(os.path.join(REF, "assets/mujoco_models/humanoid_smpl_neutral_mesh.xml"))
+
+
+class DuckModel:
+    """What the reference reads from a mujoco-py model, served from this build's compiled model."""
+
+    def __init__(self, m):
+        self.body_names = list(m.body_names)
+        self.body_pos = m.body_pos.copy()
+        self.body_ipos = m.body_ipos.copy()
+        self.body_parentid = m.body_parentid.copy()
+        self.body_jntadr = m.body_jntadr.copy()
+        self.body_jntnum = m.body_jntnum.copy()
+        self.jnt_qposadr = m.jnt_qposadr.copy()
+        self.jnt_dofadr = m.jnt_dofadr.copy()
+        self.nq, self.nv, self.nu = m.nq, m.nv, m.nu
+        self._body_name2id = {n: i for i, n in enumerate(m.body_names)}
+        self.actuator_ctrlrange = np.zeros((m.nu, 2))
+        self.geom_bodyid = m.geom_bodyid.copy()
+        self.opt = types.SimpleNamespace(timestep=m.timestep)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print("wrote", name, {k: np.asarray(v).shape for k, v in arrs.items()})
+
+
+# --------------------------------------------------------------------------- G1 quaternion / heading helpers
+def g1_math():
+    from uhc.utils import math_utils as mu
+    from uhc.utils import transformation as tf
+    rng = np.random.default_rng(101)
+    n = 64
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    p = rng.normal(size=(n, 4)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    v = rng.normal(size=(n, 3))
+    eul = rng.uniform(-np.pi, np.pi, size=(n, 3))
+    out = dict(q=q, p=p, v=v, eul=eul)
+    out["quaternion_multiply"] = np.array([tf.quaternion_multiply(a, b) for a, b in zip(q, p)])
+    out["quaternion_inverse"] = np.array([tf.quaternion_inverse(a * 1.3) for a in q])
+    out["quaternion_matrix"] = np.array([tf.quaternion_matrix(a)[:3, :3] for a in q])
+    out["quaternion_from_euler_rzyx"] = np.array([tf.quaternion_from_euler(e[0], e[1], e[2], "rzyx") for e in eul])
+    out["rotation_from_quaternion"] = np.array([tf.rotation_from_quaternion(a) for a in q])
+    out["get_heading"] = np.array([mu.get_heading(a) for a in q])
+    out["get_heading_q"] = np.array([mu.get_heading_q(a) for a in q])
+    out["de_heading"] = np.array([mu.de_heading(a) for a in q])
+    out["transform_vec_root"] = np.array([mu.transform_vec(b, a, "root") for a, b in zip(q, v)])
+    out["transform_vec_heading"] = np.array([mu.transform_vec(b, a, "heading") for a, b in zip(q, v)])
+    out["quat_mul_vec"] = np.array([mu.quat_mul_vec(a, b) for a, b in zip(q, v)])
+    vb = rng.normal(size=(24, 3))
+    out["vb"] = vb
+    out["transform_vec_batch_root"] = mu.transform_vec_batch(vb, q[0], "root")  # shape (3, 24): see SURVEY 3.5
+    nq1, nq0 = q[:24].ravel(), p[:24].ravel()
+    out["multi_quat_diff"] = mu.multi_quat_diff(nq1, nq0)
+    out["multi_quat_norm"] = mu.multi_quat_norm(out["multi_quat_diff"])
+    out["get_angvel_fd"] = mu.get_angvel_fd(nq0, nq1, 1.0 / 30)
+    # doctest known answers of transformation.py
+    out["kat_about_axis"] = tf.quaternion_about_axis(0.123, [1, 0, 0])
+    out["kat_from_euler"] = tf.quaternion_from_euler(1, 2, 3, "ryxz")
+    out["kat_multiply"] = tf.quaternion_multiply([4, 1, -2, 3], [8, -5, 6, 7])
+    save("g1_math", **out)
+
+
+# --------------------------------------------------------------------------- G2/G3 AMASS pose -> qpos -> expert features
+def make_clip(rng, T=40):
+    """Synthetic clip: the shipped standing pose with smooth joint-space perturbations."""
+    import joblib
+    d = joblib.load(os.path.join(REF, "sample_data/standing_neutral.pkl"))
+    base = d["pose_aa"][10].copy()
+    t = np.arange(T)[:, None] / 30.0
+    amp = rng.uniform(0, 0.3, size=(1, 72)); freq = rng.uniform(0.2, 2.0, size=(1, 72)); ph = rng.uniform(0, 2 * np.pi, size=(1, 72))
+    pose = base[None] + amp * np.sin(2 * np.pi * freq * t + ph)
+    pose[:, :3] = base[:3]  # keep the root orientation (axis-angle composition is not additive)
+    trans = np.zeros((T, 3)); trans[:, 0] = 0.3 * np.sin(t[:, 0]); trans[:, 2] = 0.91437225 - MODEL.body_pos[1][2]
+    return pose, trans
+
+
+def g2_g3_expert():
+    from uhc.smpllib.smpl_mujoco import smpl_to_qpose
+    from uhc.smpllib.torch_smpl_humanoid import Humanoid
+    import joblib
+    dm = DuckModel(MODEL)
+    d = joblib.load(os.path.join(REF, "sample_data/standing_neutral.pkl"))
+    qpos_std = smpl_to_qpose(d["pose_aa"], dm, trans=None, count_offset=True)
+    save("g2_smpl_to_qpose_standing", pose_aa=d["pose_aa"], qpos=qpos_std, ref_qpos=d["qpos"])
+    rng = np.random.default_rng(202)
+    pose, trans = make_clip(rng, 40)
+    qpos = smpl_to_qpose(pose, dm, trans=trans, count_offset=True)
+    h = Humanoid(model=dm)
+    feat = h.qpos_fk(torch.from_numpy(qpos))
+    feat = {k: np.asarray(v) for k, v in feat.items()}
+    save("g3_qpos_fk", pose_aa=pose, trans=trans, **{("f_" + k): v for k, v in feat.items()})
+    return dm, qpos, feat
+
+
+# --------------------------------------------------------------------------- G4 observation / termination, G6 reward
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+    def get(self, k, d=None):
+        return dict.get(self, k, d)
+
+
+def fake_env(dm, feat, rng, cur_t=5, shape=True):
+    from uhc.envs.humanoid_im import HumanoidEnv
+    from uhc.smpllib.smpl_mujoco import SMPLConverter
+    env = object.__new__(HumanoidEnv)
+    conv = SMPLConverter(dm, dm, smpl_model="smpl")
+    env.model = dm
+    env.converter = conv
+    env.qpos_lim, env.qvel_lim, env.body_lim = conv.get_new_qpos_lim(), conv.get_new_qvel_lim(), conv.get_new_body_lim()
+    env.jpos_diffw = conv.get_new_diff_weight()[:, None]
+    env.body_diffw = conv.get_new_diff_weight()[1:]
+    env.body_qposaddr = __import__("uhc.khrylib.utils.mujoco", fromlist=["x"]).get_body_qposaddr(dm)
+    env.use_quat = False
+    env.base_rot = [0.7071, 0.7071, 0.0, 0.0]
+    env.no_root = False
+    env.cur_t, env.start_ind = cur_t, 0
+    env.frame_skip = 15  # dt is a property: model.opt.timestep * frame_skip (mujoco_env.py:115-117)
+    env.ndof, env.vf_dim, env.meta_pd_dim = 69, 6, 30
+    env.cc_cfg = Cfg(obs_coord="root", obs_vel="full", has_shape=shape, obs_v=2, residual_force=True,
+                     env_expert_trail_steps=0, env_episode_len=100000,
+                     reward_weights=dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0))
+    expert = dict(feat)
+    expert["meta"] = {"cyclic": False}
+    expert["beta"] = np.tile(rng.normal(size=(1, 16)), (feat["qpos"].shape[0], 1))
+    expert["gender"] = np.full((feat["qpos"].shape[0],), 2.0)
+    env.expert = expert
+    # simulated state: expert frame cur_t perturbed
+    T = feat["qpos"].shape[0]
+    qpos = feat["qpos"][cur_t].copy()
+    qpos[:3] += rng.normal(scale=0.05, size=3)
+    dq = rng.normal(size=4) * 0.05
+    qpos[3:7] = qpos[3:7] + dq; qpos[3:7] /= np.linalg.norm(qpos[3:7])
+    qpos[7:] += rng.normal(scale=0.1, size=69)
+    qvel = rng.normal(scale=0.5, size=75)
+    xpos = np.vstack([np.zeros(3), feat["wbpos"][cur_t].reshape(-1, 3) + rng.normal(scale=0.03, size=(24, 3))])
+    xq = feat["wbquat"][cur_t].reshape(-1, 4) + rng.normal(scale=0.05, size=(24, 4))
+    xq /= np.linalg.norm(xq, axis=1, keepdims=True)
+    xquat = np.vstack([np.array([1.0, 0, 0, 0]), xq])
+    xipos = np.vstack([np.zeros(3), feat["body_com"][cur_t].reshape(-1, 3) + rng.normal(scale=0.03, size=(24, 3))])
+
+    class Data:
+        pass
+
+    data = Data()
+    data.qpos, data.qvel, data.body_xpos, data.body_xquat, data.xipos = qpos, qvel, xpos, xquat, xipos
+    data.get_body_xipos = lambda name: xipos[dm._body_name2id[name]]
+    env.data = data
+    return env
+
+
+def g4_g6_obs_reward(dm, feat):
+    from uhc.envs.humanoid_im import HumanoidEnv
+    from uhc.losses.reward_function import world_rfc_implicit_reward
+    rng = np.random.default_rng(303)
+    cases = {}
+    for c, cur_t in enumerate([3, 7, 20, 38]):
+        env = fake_env(dm, feat, rng, cur_t=cur_t)
+        obs = HumanoidEnv.get_full_obs_v2(env)
+        bquat = HumanoidEnv.get_body_quat(env)
+        body_diff = HumanoidEnv.calc_body_diff(env)
+        ee = HumanoidEnv.get_ee_pos(env, None)
+        # reward needs prev_bquat (bquat before the step) and an action
+        prev_q = env.data.qpos.copy()
+        prev_q[7:] -= rng.normal(scale=0.02, size=69)
+        save_q = env.data.qpos
+        env.data.qpos = prev_q
+        env.prev_bquat = HumanoidEnv.get_body_quat(env)
+        env.data.qpos = save_q
+        action = rng.normal(scale=0.3, size=105)
+        r, rinfo = world_rfc_implicit_reward(env, None, action, None)
+        pre = f"c{c}_"
+        cases.update({pre + "cur_t": cur_t, pre + "qpos": env.data.qpos, pre + "qvel": env.data.qvel, pre + "xpos": env.data.body_xpos,
+                      pre + "xquat": env.data.body_xquat, pre + "xipos": env.data.xipos, pre + "obs": obs, pre + "bquat": bquat,
+                      pre + "body_diff": body_diff, pre + "ee": ee, pre + "prev_bquat": env.prev_bquat, pre + "action": action,
+                      pre + "reward": r, pre + "reward_info": rinfo, pre + "beta": env.expert["beta"][0]})
+    cases["beta"] = env.expert["beta"][0]
+    cases["gender"] = env.expert["gender"][0]
+    cases["ncase"] = 4
+    save("g4_g6_obs_reward", **cases)
+
+
+# --------------------------------------------------------------------------- G5 stable PD + implicit residual force
+def g5_pd(dm, feat):
+    from uhc.envs import humanoid_im
+    from uhc.envs.humanoid_im import HumanoidEnv
+    from uhc.smpllib.smpl_mujoco import SMPLConverter
+    rng = np.random.default_rng(404)
+    env = fake_env(dm, feat, rng, cur_t=4)
+    conv = env.converter
+    env.jkp, env.jkd = conv.get_new_jkp(), conv.get_new_jkd()
+    env.torque_lim = conv.get_new_torque_limit()
+    env.sim_iter = 15
+    env.cc_cfg.update(action_v=1, meta_pd=True, meta_pd_joint=False, residual_force_scale=100.0, residual_force_lim=100.0)
+    env.rfc_rate = 1
+    from uhc_amd.model.mjcf import mass_matrix_np
+    M = mass_matrix_np(MODEL, env.data.qpos)  # a genuine (tree-structured) joint-space inertia, handed over densely
+    C = rng.normal(scale=5.0, size=75)
+    env.data.qfrc_bias = C
+    env.data.qM = M  # the patched mj_fullM below copies this dense matrix out
+    env.data.qfrc_applied = np.zeros(75)
+
+    def fake_fullM(model, out, qM):
+        out[:] = np.asarray(qM).ravel()
+
+    humanoid_im.mjf = types.SimpleNamespace(mj_fullM=fake_fullM)
+    action = rng.normal(scale=0.5, size=105)
+    out = dict(M=M, C=C, action=action, qpos=env.data.qpos, qvel=env.data.qvel, target_base=env.expert["qpos"][env.cur_t + 1][7:])
+    for it in (0, 7, 14):
+        out[f"torque_{it}"] = HumanoidEnv.compute_torque(env, action, i_iter=it)
+    vf = action[69:75].copy()
+    HumanoidEnv.rfc_implicit(env, vf)
+    out["qfrc_applied"] = env.data.qfrc_applied.copy()
+    out["jkp"], out["jkd"], out["torque_lim"] = env.jkp, env.jkd, env.torque_lim
+    save("g5_pd_rfc", **out)
+
+
+# --------------------------------------------------------------------------- G7 ZFilter, G8 GAE / PPO pieces
+def g7_g8_learner():
+    from uhc.khrylib.utils.zfilter import ZFilter
+    from uhc.khrylib.rl.core.common import estimate_advantages
+    from uhc.khrylib.rl.core.policy_gaussian import PolicyGaussian
+    from uhc.khrylib.rl.core.critic import Value
+    from uhc.khrylib.models.mlp import MLP
+    rng = np.random.default_rng(505)
+    zf = ZFilter((12,), clip=5)
+    xs = rng.normal(loc=1.0, scale=3.0, size=(200, 12))
+    ys = np.array([zf(x) for x in xs])
+    save("g7_zfilter", xs=xs, ys=ys, mean=zf.rs.mean, std=zf.rs.std, n=zf.rs.n, y_noupdate=zf(xs[0], update=False))
+    N = 500
+    rewards = torch.from_numpy(rng.uniform(0, 1, size=(N, 1)))
+    masks = torch.from_numpy((rng.uniform(size=(N, 1)) > 0.05).astype(np.float64))
+    values = torch.from_numpy(rng.normal(size=(N, 1)))
+    adv, ret = estimate_advantages(rewards, masks, values, 0.95, 0.95)
+    save("g8_gae", rewards=rewards.numpy(), masks=masks.numpy(), values=values.numpy(), advantages=adv.numpy(), returns=ret.numpy())
+    # small actor-critic (same classes, reduced width so the fixture stays small): forward, log-prob, PPO loss, grads
+    torch.manual_seed(7)
+    sd, ad = 23, 9
+    pcfg = types.SimpleNamespace(policy_hsize=(32, 16), policy_htype="gelu", fix_std=True, log_std=-2.3)
+    pol = PolicyGaussian(pcfg, action_dim=ad, state_dim=sd)  # policy_gaussian.py:9-24
+    val = Value(MLP(sd, (32, 16), "gelu"))
+    x = torch.from_numpy(rng.normal(size=(64, sd)))
+    a = torch.from_numpy(rng.normal(scale=0.2, size=(64, ad)))
+    advs = torch.from_numpy(rng.normal(size=(64, 1)))
+    rets = torch.from_numpy(rng.normal(size=(64, 1)))
+    with torch.no_grad():
+        fixed_lp = pol.get_log_prob(x, a) + 0.01 * torch.from_numpy(rng.normal(size=(64, 1)))
+    lp = pol.get_log_prob(x, a)
+    ratio = torch.exp(lp - fixed_lp)
+    surr1 = ratio * advs
+    surr2 = torch.clamp(ratio, 0.8, 1.2) * advs
+    loss = -torch.min(surr1, surr2).mean()  # agent_ppo.py:58-65
+    loss.backward()
+    vloss = (val(x) - rets).pow(2).mean()  # agent_pg.py:18-25
+    vloss.backward()
+    arrs = dict(x=x.numpy(), a=a.numpy(), advs=advs.numpy(), rets=rets.numpy(), fixed_lp=fixed_lp.numpy(), log_prob=lp.detach().numpy(),
+                mean=pol(x).loc.detach().numpy(), value=val(x).detach().numpy(), ppo_loss=loss.item(), value_loss=vloss.item())
+    for n, p in pol.named_parameters():
+        arrs["pol_" + n] = p.detach().numpy()
+        if p.grad is not None:
+            arrs["polgrad_" + n] = p.grad.numpy()
+    for n, p in val.named_parameters():
+        arrs["val_" + n] = p.detach().numpy()
+        arrs["valgrad_" + n] = p.grad.numpy()
+    save("g8_ppo_small", **arrs)
+
+
+def main():
+    g1_math()
+    dm, qpos, feat = g2_g3_expert()
+    g4_g6_obs_reward(dm, feat)
+    g5_pd(dm, feat)
+    g7_g8_learner()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,3 +107,67 @@ class SMPLConverter:
     def qvel_new_2_smpl(self, qvel):
         subset = np.concatenate([np.arange(*self.new_qvel_addr[jt]) for jt in self.smpl_joint_names])
         return qvel[:, subset] if qvel.ndim == 2 else qvel[subset]
+
+
+# --------------------------------------------------------------------------- AMASS pose -> qpos
+# SMPL joint order vs the depth-first body order of the simulation model (uhc/smpllib/smpl_parser.py:11-40)
+SMPL_BONE_ORDER_NAMES = ["Pelvis", "L_Hip", "R_Hip", "Torso", "L_Knee", "R_Knee", "Spine", "L_Ankle", "R_Ankle", "Chest",
+                         "L_Toe", "R_Toe", "Neck", "L_Thorax", "R_Thorax", "Head", "L_Shoulder", "R_Shoulder", "L_Elbow",
+                         "R_Elbow", "L_Wrist", "R_Wrist", "L_Hand", "R_Hand"]
+SMPL_BONE_KINTREE_NAMES = ["Pelvis", "L_Hip", "L_Knee", "L_Ankle", "L_Toe", "R_Hip", "R_Knee", "R_Ankle", "R_Toe", "Torso",
+                           "Spine", "Chest", "Neck", "Head", "L_Thorax", "L_Shoulder", "L_Elbow", "L_Wrist", "L_Hand",
+                           "R_Thorax", "R_Shoulder", "R_Elbow", "R_Wrist", "R_Hand"]
+SMPL_EE_NAMES = ["L_Ankle", "R_Ankle", "L_Wrist", "R_Wrist", "Head"]
+
+
+def rotation_matrix_to_quaternion(R):
+    """(N,3,3) -> (N,4) wxyz with the branch rule of the reference's converter
+    (uhc/utils/torch_geometry_transforms.py:251-328): the branch fixes the sign of the result."""
+    R = np.asarray(R, dtype=np.float64)
+    m00, m11, m22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    d2 = m22 < 1e-6
+    d0_d1 = m00 > m11
+    d0_nd1 = m00 < -m11
+    q = np.zeros((R.shape[0], 4))
+    c0, c1, c2, c3 = d2 & d0_d1, d2 & ~d0_d1, ~d2 & d0_nd1, ~d2 & ~d0_nd1
+    t0 = 1 + m00 - m11 - m22
+    t1 = 1 - m00 + m11 - m22
+    t2 = 1 - m00 - m11 + m22
+    t3 = 1 + m00 + m11 + m22
+    cand = [
+        (c0, t0, [R[:, 2, 1] - R[:, 1, 2], t0, R[:, 1, 0] + R[:, 0, 1], R[:, 0, 2] + R[:, 2, 0]]),
+        (c1, t1, [R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] + R[:, 0, 1], t1, R[:, 2, 1] + R[:, 1, 2]]),
+        (c2, t2, [R[:, 1, 0] - R[:, 0, 1], R[:, 0, 2] + R[:, 2, 0], R[:, 2, 1] + R[:, 1, 2], t2]),
+        (c3, t3, [t3, R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]]),
+    ]
+    for mask, t, comps in cand:
+        if mask.any():
+            qq = np.stack(comps, axis=-1)[mask] / np.sqrt(t[mask])[:, None]
+            q[mask] = 0.5 * qq
+    return q
+
+
+def smpl_to_qpose(pose, mj_model, trans=None, normalize=False, random_root=False, count_offset=True, use_quat=False,
+                  euler_order="ZYX", model="smpl"):
+    """AMASS axis-angle pose (B,72) [+ trans (B,3)] -> qpos (B,76) of the hinge humanoid
+    (reference: uhc/smpllib/smpl_mujoco.py:543-607).  Per joint: axis-angle -> rotation -> intrinsic
+    ZYX Euler angles, reordered from SMPL joint order to the model's depth-first body order; the root
+    keeps a quaternion; the root position gets the model's root offset when count_offset."""
+    from scipy.spatial.transform import Rotation as sRot
+    if normalize or random_root or use_quat or model != "smpl":
+        raise NotImplementedError("only the options the copycat path uses are built (SURVEY.md 8f-4)")
+    pose = np.asarray(pose, dtype=np.float64).reshape(-1, 72)
+    B = pose.shape[0]
+    if trans is None:
+        trans = np.zeros((B, 3))
+        trans[:, 2] = 0.91437225
+    trans = np.asarray(trans, dtype=np.float64).reshape(B, 3)
+    names = SMPL_BONE_ORDER_NAMES
+    smpl_2_mujoco = [names.index(q) for q in get_body_qposaddr(mj_model).keys() if q in names]
+    rot = sRot.from_rotvec(pose.reshape(-1, 3))
+    eul = rot.as_euler(euler_order, degrees=False).reshape(B, 24, 3)[:, smpl_2_mujoco, :].reshape(B, 72)
+    root_quat = rotation_matrix_to_quaternion(rot.as_matrix().reshape(B, 24, 3, 3)[:, 0])
+    qpos = np.concatenate((trans, root_quat, eul[:, 3:]), axis=1)
+    if count_offset:
+        qpos[:, :3] = trans + np.asarray(mj_model.body_pos)[1]
+    return qpos
