@@ -159,6 +159,58 @@ int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const double* d_
 /* mj_forward only (no control, no integration) on all envs: refreshes xpos/xquat/xipos/qM/qfrc_bias */
 int32_t uhc_batch_forward(UhcBatch* b);
 
+/* ------------------------------------------------------------------------------------------------
+ * Env layer: what HumanoidEnv.step / reset / load_expert do around the physics, on device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct UhcEnv UhcEnv;
+
+/* constants of HumanoidEnv (uhc/envs/humanoid_im.py) and of the reward (uhc/losses/reward_function.py:12-36) */
+typedef struct UhcEnvDesc {
+    int32_t obs_v;               /* 2 (get_full_obs_v2, humanoid_im.py:419-503) */
+    int32_t has_shape;           /* append beta(16) + gender to the observation (humanoid_im.py:1390-1406) */
+    int32_t env_episode_len;     /* cfg.env_episode_len */
+    int32_t env_expert_trail_steps;
+    int32_t ee_body[5];          /* model body ids of SMPL_EE_NAMES (smpl_parser.py:228) */
+    int32_t _pad;
+    double body_diff_thresh;     /* humanoid_im.py:88-89 */
+    double reward_weights[10];   /* w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf */
+    const double* jpos_diffw;    /* [nbody-1] SMPLConverter.get_new_diff_weight() (host) */
+} UhcEnvDesc;
+
+/* expert frame record layout of the clip bank (doubles; see uhc_amd/csrc/uhc_device_env.h) */
+#define UHC_FRAME_STRIDE 512
+
+enum UhcEnvField {
+    UHC_E_OBS = 0,          /* [n_env][obs_dim] */
+    UHC_E_REWARD = 1,       /* [n_env] */
+    UHC_E_REWARD_PARTS = 2, /* [n_env][5] pose, vel, ee, com, vf */
+    UHC_E_DONE = 3,         /* int32 [n_env] */
+    UHC_E_FAIL = 4,         /* int32 [n_env] info["fail"] */
+    UHC_E_END = 5,          /* int32 [n_env] info["end"] */
+    UHC_E_PERCENT = 6,      /* [n_env] info["percent"] */
+    UHC_E_CUR_T = 7,        /* int32 [n_env] */
+    UHC_E_BODY_DIFF = 8,    /* [n_env] calc_body_diff() of the last step */
+    UHC_E_TARGET_BASE = 9   /* [n_env][nu] expert joint pose handed to the PD controller */
+};
+
+int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* desc, UhcEnv** out);
+void uhc_env_free(UhcEnv* e);
+int32_t uhc_env_obs_dim(const UhcEnv* e);
+int32_t uhc_env_field(UhcEnv* e, int32_t field, void** d_ptr, int64_t* count);
+/* clip bank (device pointers, borrowed: must outlive the env or the next set_bank):
+ * d_frames [n_frames][UHC_FRAME_STRIDE], d_clip_start int32 [n_clips], d_clip_beta [n_clips][17] */
+int32_t uhc_env_set_bank(UhcEnv* e, const double* d_frames, int64_t n_frames, const int32_t* d_clip_start,
+                         const double* d_clip_beta, int32_t n_clips);
+/* load_expert (humanoid_im.py:182-215): env d_env_ids[i] tracks frames [fr_start, fr_start+fr_len) of clip d_clip_ids[i] */
+int32_t uhc_env_assign(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int32_t* d_clip_ids,
+                       const int32_t* d_fr_start, const int32_t* d_fr_len);
+/* MujocoEnv.reset -> reset_model (humanoid_im.py:1245-1299): state <- expert frame 0 (+ d_noise [n][nu] on the
+ * joint angles, may be NULL), forward pass, observation written to the obs rows of those envs */
+int32_t uhc_env_reset(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const double* d_noise);
+/* HumanoidEnv.step for every env with d_active != 0 (NULL = all): PD target gather, do_simulation,
+ * cur_t += 1, termination, reward, next observation */
+int32_t uhc_env_step(UhcEnv* e, const double* d_action, const int32_t* d_active);
+
 #ifdef __cplusplus
 }
 #endif

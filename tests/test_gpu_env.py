@@ -1,0 +1,133 @@
+"""GPU parity of the env layer (PD target gather, termination, reward, observation v2, reset) through the
+C-ABI, against the CPU oracles (physics_oracle.c + env_oracle.py) on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REWARD_W = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0)
+
+
+def _expert():
+    f = np.load(os.path.join(G, "g3_qpos_fk.npz"))
+    e = {k[2:]: f[k] for k in f.files if k.startswith("f_")}
+    e["len"] = int(e["len"])
+    return e
+
+
+def _window(e, start, n):
+    w = {k: (v[start:start + n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == e["len"] else v) for k, v in e.items()}
+    w["len"] = n
+    return w
+
+
+def _make(model, ctrl, n_env, expert, beta):
+    import torch
+    from uhc_amd import sim as S
+    from uhc_amd._capi import env_desc
+    sb = S.SimBatch(model, ctrl, n_env)
+    eb = S.EnvBatch(sb, env_desc(model, has_shape=True, reward_weights=REWARD_W))
+    frames = S.pack_expert_frames(expert)
+    frames2 = np.concatenate([frames, frames[::-1].copy()])  # clip 1 = clip 0 reversed (only a second id to address)
+    clip_start = torch.tensor([0, frames.shape[0]], dtype=torch.int32)
+    clip_beta = torch.from_numpy(np.stack([np.r_[beta, 2.0], np.r_[beta * 0.5, 1.0]]))
+    eb.set_bank(torch.from_numpy(frames2), clip_start, clip_beta)
+    return sb, eb
+
+
+def test_env_rollout_matches_oracles(model, ctrl):
+    import torch
+    from oracle import env_oracle as E
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.smpllib.smpl_mujoco import SMPLConverter
+    expert = _expert()
+    rng = np.random.default_rng(11)
+    beta = rng.normal(size=16)
+    n = 4
+    sb, eb = _make(model, ctrl, n, expert, beta)
+    starts, lens = np.array([0, 3, 10, 20]), np.array([40, 30, 25, 12])
+    ids = torch.arange(n, dtype=torch.int32)
+    eb.assign(ids, torch.zeros(n, dtype=torch.int32), torch.from_numpy(starts), torch.from_numpy(lens))
+    noise = rng.normal(scale=0.05, size=(n, model.nu))
+    eb.reset(ids.cuda(), torch.from_numpy(noise))
+    sb.sync()
+    jw = SMPLConverter(model, model).get_new_diff_weight()
+    wins = [_window(expert, starts[e], lens[e]) for e in range(n)]
+    os_ = []
+    for e in range(n):
+        o = OracleSim(model, ctrl)
+        q0 = wins[e]["qpos"][0].copy()
+        q0[7:] += noise[e]
+        o.set_state(q0, wins[e]["qvel"][0])
+        os_.append(o)
+    # ---- reset observation
+    gobs = eb.field(S.E_OBS).cpu().numpy()
+    for e in range(n):
+        ref = E.full_obs_v2(os_[e].get("qpos"), os_[e].get("qvel"), os_[e].get("xpos").reshape(-1, 3), os_[e].get("xquat").reshape(-1, 4),
+                            wins[e], 0, 0, beta, 2.0)
+        np.testing.assert_allclose(gobs[e], ref, atol=1e-11)
+    assert eb.obs_dim == 657
+    # ---- steps
+    cur_t = np.zeros(n, dtype=int)
+    alive = np.ones(n, dtype=bool)
+    for t in range(14):
+        act = rng.normal(scale=0.1, size=(n, ctrl.action_dim))
+        active = torch.from_numpy(alive.astype(np.int32)).cuda()
+        eb.step(torch.from_numpy(act).cuda(), active)
+        sb.sync()
+        gobs, grew = eb.field(S.E_OBS).cpu().numpy(), eb.field(S.E_REWARD).cpu().numpy()
+        gdone, gfail, gend = (eb.field(f).cpu().numpy() for f in (S.E_DONE, S.E_FAIL, S.E_END))
+        gpct, gparts = eb.field(S.E_PERCENT).cpu().numpy(), eb.field(S.E_REWARD_PARTS).cpu().numpy()
+        gq = sb.field(S.F_QPOS).cpu().numpy()
+        for e in range(n):
+            if not alive[e]:
+                continue
+            o, w = os_[e], wins[e]
+            prev_bquat = E.get_body_quat(o.get("qpos"))
+            tb = w["qpos"][E.expert_index(cur_t[e] + 1, 0, w["len"])][7:]
+            o.do_simulation(act[e], tb)
+            cur_t[e] += 1
+            xpos, xquat, xipos = o.get("xpos").reshape(-1, 3), o.get("xquat").reshape(-1, 4), o.get("xipos").reshape(-1, 3)
+            np.testing.assert_allclose(gq[e], o.get("qpos"), atol=1e-9)
+            bd = E.calc_body_diff(xpos, w["wbpos"][E.expert_index(cur_t[e], 0, w["len"])], jw)
+            fail = bool(o.geti("fail")) or bd > 0.5
+            end = cur_t[e] >= 100000 or cur_t[e] >= w["len"] - 1
+            r, parts = E.world_rfc_implicit_reward(o.get("qpos"), xpos, xipos, prev_bquat, act[e], w, cur_t[e], 0, model.timestep * 15, jw[1:], REWARD_W)
+            obs = E.full_obs_v2(o.get("qpos"), o.get("qvel"), xpos, xquat, w, cur_t[e], 0, beta, 2.0)
+            assert (bool(gfail[e]), bool(gend[e]), bool(gdone[e])) == (fail, end, fail or end)
+            assert gpct[e] == pytest.approx(cur_t[e] / (w["len"] - 1), abs=1e-14)
+            assert grew[e] == pytest.approx(r, abs=1e-9)
+            np.testing.assert_allclose(gparts[e], parts, atol=1e-9)
+            np.testing.assert_allclose(gobs[e], obs, atol=1e-8)
+            if fail or end:
+                alive[e] = False
+    assert not alive[3]  # the 12-frame window must have ended
+
+
+def test_env_inactive_and_second_clip(model, ctrl):
+    import torch
+    from uhc_amd import sim as S
+    expert = _expert()
+    beta = np.linspace(-1, 1, 16)
+    n = 3
+    sb, eb = _make(model, ctrl, n, expert, beta)
+    ids = torch.arange(n, dtype=torch.int32)
+    eb.assign(ids, torch.tensor([0, 1, 1], dtype=torch.int32), torch.tensor([0, 0, 5], dtype=torch.int32), torch.tensor([40, 40, 20], dtype=torch.int32))
+    eb.reset(ids.cuda(), None)
+    sb.sync()
+    obs = eb.field(S.E_OBS).cpu().numpy()
+    np.testing.assert_allclose(obs[0, 640:656], beta)
+    np.testing.assert_allclose(obs[1, 640:657], np.r_[beta * 0.5, 1.0])
+    q = sb.field(S.F_QPOS).cpu().numpy()
+    np.testing.assert_allclose(q[1], expert["qpos"][39], atol=1e-15)   # clip 1 is clip 0 reversed
+    np.testing.assert_allclose(q[2], expert["qpos"][34], atol=1e-15)
+    before = eb.field(S.E_OBS).clone()
+    act = torch.zeros(n, ctrl.action_dim, dtype=torch.float64, device="cuda")
+    eb.step(act, torch.tensor([0, 1, 0], dtype=torch.int32, device="cuda"))
+    sb.sync()
+    after = eb.field(S.E_OBS)
+    assert torch.equal(before[0], after[0]) and torch.equal(before[2], after[2]) and not torch.equal(before[1], after[1])
+    assert eb.field(S.E_CUR_T).cpu().tolist() == [0, 1, 0]

@@ -14,7 +14,7 @@ NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "
 
 
 def build():
-    srcs = [os.path.join(CSRC, s) for s in ("uhc_physics.hip", "uhc_capi.cpp")]
+    srcs = [os.path.join(CSRC, s) for s in ("uhc_physics.hip", "uhc_env.hip", "uhc_capi.cpp", "uhc_env_capi.cpp")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-Wno-unused-value", "-DUHC_STAGE_PROF", "-o", PROF_LIB] + srcs, cwd=CSRC)
 

@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._capi import UhcCtrlDesc, UhcModelDesc
+from ._capi import UhcCtrlDesc, UhcEnvDesc, UhcModelDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UHC_LIB") or os.path.join(_HERE, "csrc", "libuhc_amd.so")
@@ -16,6 +16,8 @@ SYMBOLS = [
     "uhc_last_error", "uhc_abi_version", "uhc_model_create", "uhc_model_free", "uhc_model_nM",
     "uhc_batch_create", "uhc_batch_free", "uhc_batch_set_stream", "uhc_batch_sync", "uhc_batch_set_rfc_scale",
     "uhc_batch_field", "uhc_batch_set_state", "uhc_batch_simulate", "uhc_batch_forward",
+    "uhc_env_create", "uhc_env_free", "uhc_env_obs_dim", "uhc_env_field", "uhc_env_set_bank", "uhc_env_assign",
+    "uhc_env_reset", "uhc_env_step",
 ]
 
 
@@ -52,6 +54,15 @@ def lib():
     L.uhc_batch_set_state.argtypes = [P, P, C.c_int32, P, P]
     L.uhc_batch_simulate.argtypes = [P, P, P, P]
     L.uhc_batch_forward.argtypes = [P]
+    L.uhc_env_create.argtypes = [P, C.POINTER(UhcEnvDesc), C.POINTER(P)]
+    L.uhc_env_free.argtypes = [P]
+    L.uhc_env_free.restype = None
+    L.uhc_env_obs_dim.argtypes = [P]
+    L.uhc_env_field.argtypes = [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int64)]
+    L.uhc_env_set_bank.argtypes = [P, P, C.c_int64, P, P, C.c_int32]
+    L.uhc_env_assign.argtypes = [P, P, C.c_int32, P, P, P]
+    L.uhc_env_reset.argtypes = [P, P, C.c_int32, P]
+    L.uhc_env_step.argtypes = [P, P, P]
     _lib = L
     return L
 

@@ -485,3 +485,16 @@ extern "C" int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const
     HIP_OK(hipSetDevice(b->device));
     return launch(b, 0, d_action, d_target_base, d_active);
 }
+
+// ------------------------------------------------------------------ internal accessors for the env layer (uhc_env_capi.cpp)
+extern "C" int uhc_internal_set_error(const char* msg) { return fail("%s", msg); }
+extern "C" int uhc_internal_batch_info(UhcBatch* b, int* n_env, int* nq, int* nv, int* nu, int* nbody, int* action_dim, int* vf_dim,
+                                       double* dt, double* base_rot_inv, void** stream, int** reset_mask) {
+    *n_env = b->n_env; *nq = b->A.t.nq; *nv = b->A.t.nv; *nu = b->A.t.nu; *nbody = b->A.t.nbody;
+    *action_dim = b->A.c.action_dim; *vf_dim = b->A.c.rfc_mode == 1 ? 6 : 0;
+    *dt = b->A.t.timestep * b->A.c.n_substeps;
+    for (int k = 0; k < 4; k++) base_rot_inv[k] = b->A.c.base_rot_inv[k];
+    *stream = (void*)b->stream;
+    *reset_mask = b->reset_mask;
+    return 0;
+}

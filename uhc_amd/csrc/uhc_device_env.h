@@ -1,0 +1,34 @@
+// uhc_device_env.h -- device-side layout of the env layer (expert clip bank, per-env episode state).
+#pragma once
+#include <stdint.h>
+
+// one expert frame = UHC_FRAME_STRIDE doubles (features of Humanoid.qpos_fk, torch_smpl_humanoid.py:234-261)
+#define UHC_FRAME_STRIDE 512
+#define UHC_FR_QPOS 0      // 76
+#define UHC_FR_QVEL 76     // 75
+#define UHC_FR_WBPOS 151   // 72
+#define UHC_FR_WBQUAT 223  // 96
+#define UHC_FR_BQUAT 319   // 96
+#define UHC_FR_BANGVEL 415 // 72
+#define UHC_FR_EE 487      // 15
+#define UHC_FR_COM 502     // 3
+
+struct EnvArgs {
+    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, has_shape, env_episode_len, expert_trail_steps;
+    int ee_body[5];
+    double dt, body_diff_thresh;
+    double rw[10];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf
+    double base_rot_inv[4];
+    // clip bank
+    const double* bank;       // [n_frames][UHC_FRAME_STRIDE]
+    const int* clip_start;    // [n_clips] first frame of each clip
+    const double* clip_beta;  // [n_clips][17]: beta(16), gender
+    const double* jpos_diffw; // [nbody-1]
+    // simulation state (owned by the UhcBatch)
+    const double *qpos, *qvel, *xpos, *xquat, *xipos;
+    const int* sim_fail;
+    // per-env episode state and outputs (owned by the UhcEnv)
+    int *clip_id, *e_start, *e_len, *cur_t, *start_ind;
+    double *target_base, *qpos_prev, *obs, *reward, *reward_parts, *percent, *body_diff;
+    int *done, *fail, *end;
+};

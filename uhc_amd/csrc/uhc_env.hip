@@ -1,0 +1,268 @@
+// uhc_env.hip -- the Python-side env math of HumanoidEnv.step as device kernels, one env per wavefront:
+//   pre : expert target pose for the PD controller (get_expert_kin_pose(delta_t=1), humanoid_im.py:1040)
+//   post: cur_t += 1, termination (humanoid_im.py:1223-1243), imitation reward
+//         (world_rfc_implicit_reward, uhc/losses/reward_function.py:12-88) and observation v2
+//         (get_full_obs_v2, humanoid_im.py:419-503), written straight into the on-device rollout buffers.
+// Expert clips live in HBM as a bank of per-frame records (uhc_device_env.h).
+#include <hip/hip_runtime.h>
+
+#include "uhc_device_env.h"
+
+#define LANE ((int)threadIdx.x)
+#define WAVE 64
+
+namespace {
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ void qmul(double* r, const double* a, const double* b) {
+    const double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const double t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    const double t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+__device__ __forceinline__ void qinv(double* r, const double* q) {  // conj / |q|^2 (transformation.py:1509-1520)
+    const double n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    r[0] = q[0] / n; r[1] = -q[1] / n; r[2] = -q[2] / n; r[3] = -q[3] / n;
+}
+// rotation of a (not necessarily unit) quaternion: normalises like quaternion_matrix (transformation.py:1344-1368)
+__device__ __forceinline__ void qmat(double* m, const double* q) {
+    const double n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const double s = sqrt(2.0 / n);
+    const double w = q[0] * s, x = q[1] * s, y = q[2] * s, z = q[3] * s;
+    m[0] = 1.0 - y * y - z * z; m[1] = x * y - z * w; m[2] = x * z + y * w;
+    m[3] = x * y + z * w; m[4] = 1.0 - x * x - z * z; m[5] = y * z - x * w;
+    m[6] = x * z - y * w; m[7] = y * z + x * w; m[8] = 1.0 - x * x - y * y;
+}
+__device__ __forceinline__ void rotT(double* r, const double* m, const double* v) {  // R^T v
+    r[0] = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+    r[1] = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+    r[2] = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+}
+__device__ __forceinline__ void heading_q(double* hq, const double* q) {  // math_utils.py:134-139
+    const double n = sqrt(q[0] * q[0] + q[3] * q[3]);
+    hq[0] = q[0] / n; hq[1] = 0; hq[2] = 0; hq[3] = q[3] / n;
+}
+__device__ __forceinline__ double heading(const double* q) {  // math_utils.py:177-184
+    double w = q[0], z = q[3];
+    if (z < 0) { w = -w; z = -z; }
+    return 2 * acos(w / sqrt(w * w + z * z));
+}
+__device__ __forceinline__ void euler_rzyx(double* q, double az, double ay, double ax) {  // quaternion_from_euler(..., 'rzyx')
+    double sz, cz, sy, cy, sx, cx;
+    sincos(0.5 * az, &sz, &cz); sincos(0.5 * ay, &sy, &cy); sincos(0.5 * ax, &sx, &cx);
+    q[0] = cx * cy * cz + sx * sy * sz; q[1] = sx * cy * cz - cx * sy * sz;
+    q[2] = cx * sy * cz + sx * cy * sz; q[3] = cx * cy * sz - sx * sy * cz;
+}
+// local body quaternion b (0 = root) from a hinge-model qpos (humanoid_im.py:925-947)
+__device__ __forceinline__ void body_quat(double* q, const double* qpos, int b) {
+    if (b == 0) { q[0] = qpos[3]; q[1] = qpos[4]; q[2] = qpos[5]; q[3] = qpos[6]; }
+    else euler_rzyx(q, qpos[7 + 3 * (b - 1)], qpos[8 + 3 * (b - 1)], qpos[9 + 3 * (b - 1)]);
+}
+__device__ __forceinline__ int expert_index(int t, int start_ind, int len) { return min(start_ind + t, len - 1); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) uhc_env_pre_kernel(EnvArgs E, const int* __restrict__ d_active) {
+    const int env = blockIdx.x;
+    if (env >= E.n_env || (d_active && !d_active[env])) return;
+    const int len = E.e_len[env], ind = expert_index(E.cur_t[env] + 1, E.start_ind[env], len);
+    const double* fr = E.bank + (size_t)(E.e_start[env] + ind) * UHC_FRAME_STRIDE;
+    for (int a = LANE; a < E.nu; a += WAVE) E.target_base[(size_t)env * E.nu + a] = fr[UHC_FR_QPOS + 7 + a];
+    for (int i = LANE; i < E.nq; i += WAVE) E.qpos_prev[(size_t)env * E.nq + i] = E.qpos[(size_t)env * E.nq + i];
+}
+
+// MODE 0: after do_simulation (bookkeeping + reward + termination + next observation)
+// MODE 1: observation only (reset_model: humanoid_im.py:1245-1299 returns get_obs())
+template <int MODE>
+__global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const double* __restrict__ d_action, const int* __restrict__ d_active) {
+    const int env = blockIdx.x;
+    if (env >= E.n_env || (d_active && !d_active[env])) return;
+    __shared__ double s_qpos[128], s_prev[128], s_q[4 * 32];
+    const int nb = E.nbody - 1;  // bodies without the world
+    const double* qpos_g = E.qpos + (size_t)env * E.nq;
+    for (int i = LANE; i < E.nq; i += WAVE) { s_qpos[i] = qpos_g[i]; if (MODE == 0) s_prev[i] = E.qpos_prev[(size_t)env * E.nq + i]; }
+    __syncthreads();
+    const double* xpos = E.xpos + (size_t)env * 3 * E.nbody;
+    const double* xquat = E.xquat + (size_t)env * 4 * E.nbody;
+    const double* xipos = E.xipos + (size_t)env * 3 * E.nbody;
+    const double* qvel = E.qvel + (size_t)env * E.nv;
+    const int len = E.e_len[env], start_ind = E.start_ind[env];
+    int cur_t = E.cur_t[env];
+    const double* bank0 = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE;
+
+    if (MODE == 0) {
+        cur_t += 1;  // humanoid_im.py:1213
+        const double* fr = bank0 + (size_t)expert_index(cur_t, start_ind, len) * UHC_FRAME_STRIDE;
+        const double* action = d_action + (size_t)env * E.action_dim;
+        // ---- termination: mean weighted body distance (calc_body_diff, humanoid_im.py:1408-1415)
+        double dist = 0, wcount = 0, pose2 = 0, vel2 = 0;
+        if (LANE < nb) {
+            const double w = E.jpos_diffw[LANE];
+            double d[3];
+            for (int k = 0; k < 3; k++) d[k] = (xpos[3 * (LANE + 1) + k] - fr[UHC_FR_WBPOS + 3 * LANE + k]) * w;
+            if (w != 0) { dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); wcount = 1; }
+            // ---- reward terms per body (reward_function.py:44-63)
+            double cq[4], pq[4], eq[4], ei[4], dq[4], pi[4];
+            body_quat(cq, s_qpos, LANE);
+            body_quat(pq, s_prev, LANE);
+            for (int k = 0; k < 4; k++) eq[k] = fr[UHC_FR_BQUAT + 4 * LANE + k];
+            qinv(ei, eq);
+            qmul(dq, cq, ei);
+            const double wq = LANE == 0 ? 1.0 : E.jpos_diffw[LANE];  // pose_diff[1:] *= body_diffw
+            const double pd = acos(fmin(fmax(dq[0], -1.0), 1.0)) * wq;  // multi_quat_norm: no abs
+            pose2 = pd * pd;
+            qinv(pi, pq);
+            qmul(dq, cq, pi);  // get_angvel_fd: cur (x) prev^-1, axis-angle / dt (math_utils.py:92-100)
+            double av[3] = {0, 0, 0};
+            if (!(fabs(1.0 - dq[0]) < 1e-6 || fabs(1.0 + dq[0]) < 1e-6)) {
+                const double ang = 2 * acos(dq[0]);
+                const double sh = sin(0.5 * ang);
+                double ax[3] = {dq[1] / sh, dq[2] / sh, dq[3] / sh};
+                const double an = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+                for (int k = 0; k < 3; k++) av[k] = ax[k] / an * ang / E.dt;
+            }
+            for (int k = 0; k < 3; k++) {
+                const double dv = (av[k] - fr[UHC_FR_BANGVEL + 3 * LANE + k]) * w;
+                vel2 += dv * dv;
+            }
+        }
+        const double body_diff = wsum(dist) / fmax(wsum(wcount), 1.0);
+        pose2 = wsum(pose2);
+        vel2 = wsum(vel2);
+        double ee2 = 0;
+        if (LANE < 15) {
+            const int b = E.ee_body[LANE / 3];
+            const double d = xpos[3 * b + LANE % 3] - fr[UHC_FR_EE + LANE];
+            ee2 = d * d;
+        }
+        ee2 = wsum(ee2);
+        if (LANE == 0) {
+            double com2 = 0, vf2 = 0;
+            for (int k = 0; k < 3; k++) { const double d = xipos[3 + k] - fr[UHC_FR_COM + k]; com2 += d * d; }
+            for (int k = 0; k < E.vf_dim; k++) { const double a = action[E.nu + k]; vf2 += a * a; }
+            const double* W = E.rw;  // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf
+            const double rp = exp(-W[5] * pose2), rv = exp(-W[6] * vel2), re = exp(-W[7] * ee2), rc = exp(-W[8] * com2);
+            const double rf = E.vf_dim > 0 ? exp(-W[9] * vf2) : 0.0;
+            const double r = (W[0] * rp + W[1] * rv + W[2] * re + W[3] * rc + W[4] * rf) / (W[0] + W[1] + W[2] + W[3] + W[4]);
+            E.reward[env] = r;
+            double* rp_out = E.reward_parts + (size_t)env * 5;
+            rp_out[0] = rp; rp_out[1] = rv; rp_out[2] = re; rp_out[3] = rc; rp_out[4] = rf;
+            const int fail = (E.sim_fail[env] != 0) || (body_diff > E.body_diff_thresh);
+            const int end = (cur_t >= E.env_episode_len) || (cur_t + start_ind >= len + E.expert_trail_steps - 1);
+            E.fail[env] = fail; E.end[env] = end; E.done[env] = fail || end;
+            E.percent[env] = (double)cur_t / (double)(len - 1);
+            E.body_diff[env] = body_diff;
+            E.cur_t[env] = cur_t;
+        }
+    }
+
+    // ------------------------------------------------------------------ observation v2 (humanoid_im.py:419-503)
+    double* obs = E.obs + (size_t)env * E.obs_dim;
+    const double* fr = bank0 + (size_t)expert_index(cur_t + 1, start_ind, len) * UHC_FRAME_STRIDE;
+    double rootq[4] = {s_qpos[3], s_qpos[4], s_qpos[5], s_qpos[6]}, crq[4], hq[4], hqi[4], Rr[9], Rc[9], trq[4], tq[4];
+    qmul(crq, rootq, E.base_rot_inv);            // remove_base_rot (:263-264)
+    heading_q(hq, crq);
+    qinv(hqi, hq);
+    qmat(Rr, rootq);
+    qmat(Rc, crq);
+    for (int k = 0; k < 4; k++) tq[k] = fr[UHC_FR_QPOS + 3 + k];
+    qmul(trq, tq, E.base_rot_inv);
+    if (LANE == 0) {
+        double dh[4], ci[4], dr[4], v0[3], v1[3], rel[3], rl[3];
+        for (int k = 0; k < 4; k++) obs[k] = hq[k];
+        qmul(dh, hqi, crq);                      // de_heading(curr_root_quat)
+        qinv(ci, crq);
+        qmul(dr, trq, ci);
+        obs[4] = fr[UHC_FR_QPOS + 2]; obs[78] = s_qpos[2]; obs[152] = fr[UHC_FR_QPOS + 2] - s_qpos[2];
+        for (int k = 0; k < 4; k++) { obs[5 + k] = tq[k]; obs[79 + k] = dh[k]; obs[153 + k] = dr[k]; }
+        const double qv[3] = {qvel[0], qvel[1], qvel[2]};
+        rotT(v0, Rr, qv);
+        rotT(v1, Rc, v0);                        // rotated twice, as the reference does (:425, :451)
+        for (int k = 0; k < 3; k++) obs[226 + k] = v1[k];
+        double rel_h = heading(trq) - heading(crq);
+        if (rel_h > M_PI) rel_h -= 2 * M_PI;
+        if (rel_h < -M_PI) rel_h += 2 * M_PI;
+        obs[301] = rel_h;
+        for (int k = 0; k < 3; k++) rel[k] = trq[k] - s_qpos[k];  // target_root_quat[:3] - qpos[:3]: bug-compatible (:466)
+        rotT(rl, Rc, rel);
+        obs[302] = rl[0]; obs[303] = rl[1];
+    }
+    for (int i = LANE; i < E.nu; i += WAVE) {   // joint angles: target, current, difference
+        const double t = fr[UHC_FR_QPOS + 7 + i], c = s_qpos[7 + i];
+        obs[9 + i] = t; obs[83 + i] = c; obs[157 + i] = t - c;
+    }
+    for (int i = LANE + 3; i < E.nv; i += WAVE) obs[226 + i] = qvel[i];
+    if (LANE < nb) {
+        const int b = LANE;
+        double d[3], r[3], cq[4], tb[4], o[4], ci[4];
+        for (int k = 0; k < 3; k++) d[k] = xpos[3 * (b + 1) + k] - s_qpos[k];
+        rotT(r, Rc, d);
+        for (int k = 0; k < 3; k++) obs[304 + k * nb + b] = r[k];            // (3, N) raveled: component-major
+        for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
+        rotT(r, Rc, d);
+        for (int k = 0; k < 3; k++) obs[304 + 3 * nb + k * nb + b] = r[k];
+        const bool unset = xquat[4] == 0.0;                                  // cur_quat[0, 0] == 0 (:485-486)
+        for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_WBQUAT + 4 * b + k]; cq[k] = unset ? tb[k] : xquat[4 * (b + 1) + k]; }
+        qmul(o, hqi, cq);
+        for (int k = 0; k < 4; k++) obs[304 + 6 * nb + 4 * b + k] = o[k];
+        qinv(ci, cq);
+        qmul(o, ci, tb);
+        for (int k = 0; k < 4; k++) obs[304 + 10 * nb + 4 * b + k] = o[k];
+    }
+    if (E.has_shape) {
+        const int base = 304 + 14 * nb;
+        const double* cb = E.clip_beta + (size_t)E.clip_id[env] * 17;
+        if (LANE < 17) obs[base + LANE] = cb[LANE];  // beta(16), gender
+    }
+    (void)s_q;
+}
+
+extern "C" hipError_t uhc_launch_env_pre(const EnvArgs* E, const int* d_active, hipStream_t s) {
+    hipLaunchKernelGGL(uhc_env_pre_kernel, dim3(E->n_env), dim3(WAVE), 0, s, *E, d_active);
+    return hipGetLastError();
+}
+extern "C" hipError_t uhc_launch_env_post(int mode, const EnvArgs* E, const double* d_action, const int* d_active, hipStream_t s) {
+    if (mode == 0) hipLaunchKernelGGL(uhc_env_post_kernel<0>, dim3(E->n_env), dim3(WAVE), 0, s, *E, d_action, d_active);
+    else hipLaunchKernelGGL(uhc_env_post_kernel<1>, dim3(E->n_env), dim3(WAVE), 0, s, *E, d_action, d_active);
+    return hipGetLastError();
+}
+
+// reset_model (humanoid_im.py:1245-1299): qpos/qvel staging rows <- expert frame 0 (+ joint noise)
+__global__ void uhc_env_reset_stage_kernel(EnvArgs E, const int* env_ids, int n, const double* noise, double* out_qpos, double* out_qvel) {
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const int env = env_ids[r];
+    const double* fr = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE;  // ind = 0
+    for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
+        double v = fr[UHC_FR_QPOS + i];
+        if (noise && i >= 7) v += noise[(size_t)r * E.nu + (i - 7)];
+        out_qpos[(size_t)r * E.nq + i] = v;
+    }
+    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = fr[UHC_FR_QVEL + i];
+    if (threadIdx.x == 0) { E.cur_t[env] = 0; E.start_ind[env] = 0; E.done[env] = 0; E.fail[env] = 0; E.end[env] = 0; }
+}
+extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* env_ids, int n, const double* noise, double* out_qpos,
+                                                 double* out_qvel, hipStream_t s) {
+    hipLaunchKernelGGL(uhc_env_reset_stage_kernel, dim3(n), dim3(WAVE), 0, s, *E, env_ids, n, noise, out_qpos, out_qvel);
+    return hipGetLastError();
+}
+// load_expert bookkeeping (humanoid_im.py:182-215): env -> (clip, window start, window length)
+__global__ void uhc_env_assign_kernel(EnvArgs E, const int* env_ids, int n, const int* clip_ids, const int* fr_start, const int* fr_len) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int env = env_ids[r], c = clip_ids[r];
+    E.clip_id[env] = c;
+    E.e_start[env] = E.clip_start[c] + fr_start[r];
+    E.e_len[env] = fr_len[r];
+}
+extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
+                                            const int* fr_len, hipStream_t s) {
+    hipLaunchKernelGGL(uhc_env_assign_kernel, dim3((n + 63) / 64), dim3(64), 0, s, *E, env_ids, n, clip_ids, fr_start, fr_len);
+    return hipGetLastError();
+}

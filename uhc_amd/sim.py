@@ -8,7 +8,7 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from ._capi import UhcCtrlDesc, model_desc
+from ._capi import UhcCtrlDesc, UhcEnvDesc, model_desc
 from ._lib import check, lib
 
 F_QPOS, F_QVEL, F_XPOS, F_XQUAT, F_XIPOS, F_QM, F_QFRC_BIAS, F_QACC, F_CTRL = range(9)
@@ -116,6 +116,96 @@ class SimBatch:
 
     def forward(self):
         check(self.L.uhc_batch_forward(self._b))
+
+
+E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE = range(10)
+_E_INT = {E_DONE, E_FAIL, E_END, E_CUR_T}
+FRAME_STRIDE = 512
+FR = dict(qpos=(0, 76), qvel=(76, 75), wbpos=(151, 72), wbquat=(223, 96), bquat=(319, 96), bangvel=(415, 72), ee_wpos=(487, 15), com=(502, 3))
+
+
+def pack_expert_frames(feat) -> np.ndarray:
+    """Expert feature dict (Humanoid.qpos_fk output) -> (T, FRAME_STRIDE) frame records of the clip bank."""
+    T = int(feat["len"])
+    out = np.zeros((T, FRAME_STRIDE))
+    for k, (o, n) in FR.items():
+        out[:, o:o + n] = np.asarray(feat[k]).reshape(T, n)
+    return out
+
+
+class EnvBatch:
+    """Device env layer (uhc_env_* of the C-ABI) on top of a SimBatch."""
+
+    def __init__(self, sim: SimBatch, desc: UhcEnvDesc):
+        self.sim, self.L, self.desc = sim, sim.L, desc
+        self._e = C.c_void_p()
+        check(self.L.uhc_env_create(sim._b, C.byref(desc), C.byref(self._e)))
+        self.obs_dim = self.L.uhc_env_obs_dim(self._e)
+        self.n_env, self.device = sim.n_env, sim.device
+        self._fields = {}
+        self._bank = None
+
+    def close(self):
+        if getattr(self, "_e", None) is not None and self._e:
+            self.L.uhc_env_free(self._e)
+            self._e = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def field(self, f: int) -> torch.Tensor:
+        if f in self._fields:
+            return self._fields[f]
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.L.uhc_env_field(self._e, f, C.byref(p), C.byref(n)))
+        per = n.value // self.n_env
+        if f in _E_INT:
+            t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<i4", self), device=self.device)
+        elif per == 1:
+            t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<f8", self), device=self.device)
+        else:
+            t = torch.as_tensor(_DevView(p.value, (self.n_env, per), "<f8", self), device=self.device)
+        self._fields[f] = t
+        return t
+
+    def set_bank(self, frames: torch.Tensor, clip_start: torch.Tensor, clip_beta: torch.Tensor):
+        frames = frames.to(self.device, torch.float64).contiguous()
+        clip_start = clip_start.to(self.device, torch.int32).contiguous()
+        clip_beta = clip_beta.to(self.device, torch.float64).contiguous()
+        assert frames.shape[1] == FRAME_STRIDE and clip_beta.shape == (clip_start.shape[0], 17)
+        check(self.L.uhc_env_set_bank(self._e, C.c_void_p(frames.data_ptr()), frames.shape[0], C.c_void_p(clip_start.data_ptr()),
+                                      C.c_void_p(clip_beta.data_ptr()), clip_start.shape[0]))
+        self._bank = (frames, clip_start, clip_beta)  # keep alive: the library borrows the pointers
+
+    @staticmethod
+    def _i32(t, device):
+        return t.to(device, torch.int32).contiguous()
+
+    def assign(self, env_ids, clip_ids, fr_start, fr_len):
+        a, b, c, d = (self._i32(x, self.device) for x in (env_ids, clip_ids, fr_start, fr_len))
+        check(self.L.uhc_env_assign(self._e, C.c_void_p(a.data_ptr()), a.shape[0], C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr()),
+                                    C.c_void_p(d.data_ptr())))
+
+    def reset(self, env_ids, noise: Optional[torch.Tensor] = None):
+        ids = self._i32(env_ids, self.device)
+        nz = None
+        if noise is not None:
+            noise = noise.to(self.device, torch.float64).contiguous()
+            assert noise.shape == (ids.shape[0], self.sim.model.nu)
+            nz = C.c_void_p(noise.data_ptr())
+        check(self.L.uhc_env_reset(self._e, C.c_void_p(ids.data_ptr()), ids.shape[0], nz))
+        self._keep = (ids, noise)
+
+    def step(self, action: torch.Tensor, active: Optional[torch.Tensor] = None):
+        assert action.dtype == torch.float64 and action.is_contiguous() and action.shape == (self.n_env, self.sim.ctrl.action_dim)
+        a = None
+        if active is not None:
+            assert active.dtype == torch.int32 and active.is_contiguous()
+            a = C.c_void_p(active.data_ptr())
+        check(self.L.uhc_env_step(self._e, C.c_void_p(action.data_ptr()), a))
 
 
 def make_ctrl(model, *, meta_pd: bool = True, meta_pd_joint: bool = False, residual_force: bool = True,
