@@ -1,10 +1,13 @@
-"""bench.py -- hot-path throughput on MI355X (contract: see the task statement / DESIGN.md section 6).
+"""bench.py -- hot-path throughput on MI355X (contract: task statement; design notes: DESIGN.md section 6).
 
-A "step" is one control step (15 physics substeps with stable-PD + residual force, then observation,
-reward and termination when the env layer is present) of EVERY environment of the batch:
-BASELINE.json configs[1] = 1024 batched envs per GPU, synthetic clips.  value = env-steps/s summed
-over all ranks.  One process per GPU; envs shard across ranks with no data-path collective
-(scaling = weak).
+A "step" is one control step of EVERY environment of the batch, exactly as a training rollout performs it:
+observation filter -> policy MLP forward (sampling) -> PD-target gather -> fused physics kernel (15 substeps of
+stable-PD, residual force, forward dynamics, PGS contact solve, Euler) -> termination, imitation reward and next
+observation -> rollout-buffer writes -> reset of finished episodes (new clip window, set_state, forward).
+Workload = BASELINE.json configs[1]: copycat config, 1024 batched envs per GPU, synthetic clips.
+value = env-steps/s summed over all ranks (weak scaling: envs shard across ranks, no data-path collective).
+After the timed region one full PPO update (GAE + 10 full-batch epochs, gradients all-reduced over RCCL when
+n_gpus > 1) over the collected samples is timed and reported as ppo_samples_per_s.
 """
 import argparse
 import json
@@ -19,64 +22,58 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 8 * (76 + 75 + 75 + 105 + 69 + 76 + 75 + 75 + 75 + 100 + 75)  # DESIGN.md section 5
+# algorithmic HBM bytes of one env-step of the fused physics kernel:
+# read qpos, qvel, warm start, action, expert target; write qpos, qvel, qacc, body pos / quat / com
+ALGO_BYTES_PER_ENV_STEP = 8 * (76 + 75 + 75 + 105 + 69 + 76 + 75 + 75 + 75 + 100 + 75)
 HBM_PEAK_GBS = 8000.0
-EPISODE_LEN = 30  # synthetic episode length before an env is re-initialised (untrained policy falls in ~1 s)
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=60)
+    p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--envs", type=int, default=1024, help="environments per GPU")
+    p.add_argument("--clips", type=int, default=64, help="synthetic clips per rank")
+    p.add_argument("--ppo-dtype", default="float64", choices=["float64", "float32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = 4 x cores)")
+    p.add_argument("--no-ppo", action="store_true")
     return p.parse_args()
 
 
-def make_inputs(model, ctrl, n_env, seed):
-    z = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))
-    rng = np.random.default_rng(seed)
-    qpos = np.tile(z["qpos"], (n_env, 1))
-    qpos[:, 7:] += rng.normal(scale=0.05, size=(n_env, model.nu))
-    yaw = rng.uniform(-np.pi, np.pi, size=n_env)  # random heading about world z (left-multiplied)
-    qz = np.stack([np.cos(yaw / 2), np.zeros(n_env), np.zeros(n_env), np.sin(yaw / 2)], axis=1)
-    q = qpos[:, 3:7].copy()
-    qpos[:, 3] = qz[:, 0] * q[:, 0] - qz[:, 3] * q[:, 3]
-    qpos[:, 4] = qz[:, 0] * q[:, 1] - qz[:, 3] * q[:, 2]
-    qpos[:, 5] = qz[:, 0] * q[:, 2] + qz[:, 3] * q[:, 1]
-    qpos[:, 6] = qz[:, 0] * q[:, 3] + qz[:, 3] * q[:, 0]
-    qvel = rng.normal(scale=0.1, size=(n_env, model.nv))
-    # policy at initialisation: zero mean, std = exp(-2.3) (uhc_implicit_shape.yml:23)
-    actions = rng.normal(scale=np.exp(-2.3), size=(8, n_env, ctrl.action_dim))
-    return qpos, qvel, actions
-
-
-def cpu_baseline(model, ctrl, qpos, qvel, actions, n_cpu_env):
-    """The CPU oracle (own restatement of the MuJoCo step; 'port') on the host cores, bounded sample."""
+def cpu_baseline(agent, n_env_gpu):
+    """The CPU oracle (own restatement of the MuJoCo step + PD; kind 'port') on the host cores, bounded sample of
+    the same workload: physics control steps from the clips' first frames with init-policy action noise."""
     import ctypes as C
     from oracle.physics import OracleSim, lib
+    env = agent.env
     cores = os.cpu_count() or 1
-    n = n_cpu_env or min(len(qpos), 4 * cores)
-    sims = [OracleSim(model, ctrl) for _ in range(n)]
-    for e, s in enumerate(sims):
-        s.set_state(qpos[e], qvel[e])
+    n = min(n_env_gpu, 4 * cores)
+    frames = env.env._bank[0].cpu().numpy()
+    starts = env.env._bank[1].cpu().numpy()
+    rng = np.random.default_rng(0)
+    sims, tb = [], []
+    for e in range(n):
+        f0 = frames[starts[e % len(starts)]]
+        s = OracleSim(env.model, env.ctrl)
+        s.set_state(f0[0:76], frames[starts[e % len(starts)] + 1][76:151])
+        sims.append(s)
+        tb.append(frames[starts[e % len(starts)] + 1][7:76])
     L = lib()
     ptrs = (C.c_void_p * n)(*[s.d for s in sims])
-    tb = np.ascontiguousarray(qpos[:n, 7:])
-    steps = 0
-    t0 = time.perf_counter()
+    tb = np.ascontiguousarray(np.stack(tb))
+    steps, t0 = 0, time.perf_counter()
     while True:
-        a = np.ascontiguousarray(actions[steps % len(actions), :n])
-        L.orc_batch_do_simulation(C.byref(sims[0].desc), C.byref(ctrl), ptrs, n, a.ctypes.data_as(C.POINTER(C.c_double)),
+        a = np.ascontiguousarray(rng.normal(scale=np.exp(-2.3), size=(n, env.action_dim)))
+        L.orc_batch_do_simulation(C.byref(sims[0].desc), C.byref(env.ctrl), ptrs, n, a.ctypes.data_as(C.POINTER(C.c_double)),
                                   tb.ctypes.data_as(C.POINTER(C.c_double)))
         steps += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or steps >= 20:
+        if el > 12.0 or steps >= 15:
             break
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} control steps of the same workload (oracle/physics_oracle.c, OpenMP over envs)"}
+            "sample": f"{n} envs x {steps} physics control steps (15 substeps, PD + RFC) of the same clips, oracle/physics_oracle.c with "
+                      f"OpenMP over envs; MuJoCo itself is not installed"}
 
 
 def main():
@@ -84,85 +81,102 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
-    if dist:
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    if dist_on:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
+    dtype = torch.float64 if args.ppo_dtype == "float64" else torch.float32
+    torch.set_default_dtype(dtype)
+    import tempfile
     from uhc_amd import sim as S
-    model = S.load_asset_model()
-    ctrl = S.make_ctrl(model)
-    n_env = args.envs
-    qpos, qvel, actions = make_inputs(model, ctrl, n_env, seed=1 + rank)
+    from uhc_amd.agents.agent_copycat import AgentCopycat
+    from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle
+    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
+    from uhc_amd.utils.config_utils.copycat_config import Config
 
-    batch = S.SimBatch(model, ctrl, n_env, device=local)
-    d_qpos, d_qvel = torch.from_numpy(qpos).cuda(), torch.from_numpy(qvel).cuda()
-    d_act = torch.from_numpy(actions).cuda()
-    d_tb = torch.from_numpy(np.ascontiguousarray(qpos[:, 7:])).cuda()
-    batch.set_state(d_qpos, d_qvel)
-    # staggered synthetic episodes: env e is re-initialised whenever (t + e) % EPISODE_LEN == 0
-    phase = torch.arange(n_env, device="cuda") % EPISODE_LEN
-    reset_ids = [torch.nonzero(phase == k).flatten().to(torch.int32) for k in range(EPISODE_LEN)]
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    nefc_hist = []
-
-    def one_step(t, timed_idx=None):
-        ids = reset_ids[t % EPISODE_LEN]
-        if t > 0 and len(ids):
-            batch.set_state(d_qpos[ids.long()], d_qvel[ids.long()], ids)
-        a = d_act[t % d_act.shape[0]]
-        if timed_idx is not None:
-            ev[timed_idx][0].record()
-        batch.simulate(a, d_tb)
-        if timed_idx is not None:
-            ev[timed_idx][1].record()
+    cfg = Config(cfg_id="copycat_mi355x", base_dir=tempfile.mkdtemp(prefix="uhc_bench_"))
+    cfg.n_env = args.envs
+    cfg.no_log = True
+    specs = dict(cfg.data_specs)
+    specs["file_path"] = "synthetic"
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed + rank)
+    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(args.clips, seed=1 + rank))
+    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl)
+    agent.logger.handlers = [h for h in agent.logger.handlers if not isinstance(h, __import__("logging").StreamHandler) or hasattr(h, "baseFilename")]
+    agent.per_epoch_update(0)
+    env = agent.env
+    n_env = env.n_env
+    T = args.warmup + args.steps
 
     def fence():
         torch.cuda.synchronize()
-        if dist:
+        if dist_on:
             td.barrier()
             torch.cuda.synchronize()
 
-    for t in range(args.warmup):
-        one_step(t)
+    agent.rollout_begin(T)
+    for _ in range(args.warmup):
+        agent.rollout_step()
     fence()
+    env.sim.set_timing(True)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k, k)
+    for _ in range(args.steps):
+        agent.rollout_step()
     fence()
     elapsed = time.perf_counter() - t0
-    nefc_hist = batch.field(S.F_NEFC).cpu().numpy()
-    iters = batch.field(S.F_SOLVER_ITER).cpu().numpy()
-    fails = int(batch.field(S.F_FAIL).sum().item())
-    overflow = int(batch.field(S.F_EFC_OVERFLOW).sum().item())
-    if dist:
+    kern_total_ms, kern_n = env.sim.kernel_time()
+    env.sim.set_timing(False)
+    nefc = env.sim.field(S.F_NEFC).cpu().numpy()
+    iters = env.sim.field(S.F_SOLVER_ITER).cpu().numpy()
+    overflow = int(env.sim.field(S.F_EFC_OVERFLOW).sum().item())
+    batch, logger = agent.rollout_end()
+    if dist_on:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    total_env_steps = n_env * args.steps * world
-    value = total_env_steps / elapsed
+    # ---- one PPO update over the collected samples (outside the timed region of `value`)
+    ppo = None
+    if not args.no_ppo:
+        fence()
+        t1 = time.perf_counter()
+        agent.update_params(batch)
+        fence()
+        t_up = time.perf_counter() - t1
+        if dist_on:
+            tt = torch.tensor([t_up], device="cuda", dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            t_up = float(tt.item())
+        n_samples = batch.states.shape[0] * world
+        flops = n_samples * 503e6  # ~503 MFLOP per sample per iteration (10 epochs, both nets)
+        ppo = {"samples": n_samples, "update_s": t_up, "samples_per_s": n_samples / t_up, "dtype": args.ppo_dtype, "epochs": cfg.num_optim_epoch,
+               "gemm_tflops": flops / t_up / 1e12, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
     if rank == 0:
+        kern_ms = kern_total_ms / max(kern_n, 1)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: copycat (uhc_implicit_shape) control step, {n_env} batched envs/GPU, "
-                                   "standing_neutral-derived synthetic clips, staggered 30-step episodes, init-policy action noise",
-                       "envs_per_gpu": n_env, "substeps": 15, "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
-                         "note": "fused f64 step is latency/VALU bound, not HBM bound (DESIGN.md section 5)"},
-            "workload_stats": {"nefc_mean": float(nefc_hist.mean()), "nefc_max": int(nefc_hist.max()),
-                               "pgs_iters_mean": float(iters.mean()), "failed_envs": fails, "efc_overflow_envs": overflow},
+            "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
+                                   f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
+                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "launches": kern_n,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "note": "fused f64 step: state-only HBM traffic, bound by dependent f64 VALU/LDS latency (DESIGN.md section 5)"},
+            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "pgs_iters_mean": float(iters.mean()),
+                               "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
+                               "avg_reward": logger.avg_c_reward},
         }
+        if ppo:
+            out["ppo"] = ppo
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, ctrl, qpos, qvel, actions, args.cpu_envs)
+            out["cpu_baseline"] = cpu_baseline(agent, n_env)
         print(json.dumps(out))
-    if dist:
+    if dist_on:
         td.barrier()
         td.destroy_process_group()
 

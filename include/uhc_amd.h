@@ -156,6 +156,12 @@ int32_t uhc_batch_set_state(UhcBatch* b, const int32_t* d_env_ids, int32_t n, co
 int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const double* d_target_base,
                            const int32_t* d_active);
 
+/* Measurement hook: while enabled, every uhc_batch_simulate brackets its fused step kernel (the fast variant
+ * of uhc_step_kernel) with HIP events on the batch's stream; uhc_batch_kernel_time drains them (synchronising
+ * on the events) and returns the summed kernel time and the number of launches since the last call. */
+int32_t uhc_batch_set_timing(UhcBatch* b, int32_t enable);
+int32_t uhc_batch_kernel_time(UhcBatch* b, double* total_ms, int32_t* launches);
+
 /* mj_forward only (no control, no integration) on all envs: refreshes xpos/xquat/xipos/qM/qfrc_bias */
 int32_t uhc_batch_forward(UhcBatch* b);
 

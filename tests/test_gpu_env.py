@@ -17,9 +17,13 @@ def _expert():
     return e
 
 
-def _window(e, start, n):
-    w = {k: (v[start:start + n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == e["len"] else v) for k, v in e.items()}
-    w["len"] = n
+def _window(e, start, n, model=None):
+    """Expert features of the window [start, start+n) exactly as load_expert computes them: qpos_fk on the window's own
+    qpos (so its first-frame velocities are copies of the second frame's finite differences)."""
+    import torch
+    from uhc_amd.sim import load_asset_model
+    from uhc_amd.smpllib.torch_smpl_humanoid import Humanoid
+    w = Humanoid(model=model or load_asset_model()).qpos_fk(torch.from_numpy(e["qpos"][start:start + n].copy()))
     return w
 
 

@@ -1,0 +1,181 @@
+"""CPU tests of the learner: GAE / PPO pieces against reference golden vectors, the observation filter,
+the clip sampler, config, and the 2-rank gloo gradient all-reduce path."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def f64():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+
+
+def _nets(sd=23, ad=9, h=(32, 16)):
+    from uhc_amd.khrylib.models.mlp import MLP
+    from uhc_amd.khrylib.rl.core import PolicyGaussian, Value
+    pol = PolicyGaussian(types.SimpleNamespace(policy_hsize=h, policy_htype="gelu", fix_std=True, log_std=-2.3), action_dim=ad, state_dim=sd)
+    return pol, Value(MLP(sd, h, "gelu"))
+
+
+def test_gae_matches_reference_flat_and_segmented():
+    from uhc_amd.khrylib.rl.core import estimate_advantages
+    g = np.load(os.path.join(G, "g8_gae.npz"))
+    r, m, v = (torch.from_numpy(g[k]) for k in ("rewards", "masks", "values"))
+    a, ret = estimate_advantages(r, m, v, 0.95, 0.95)
+    np.testing.assert_allclose(a.numpy(), g["advantages"], atol=1e-13)
+    np.testing.assert_allclose(ret.numpy(), g["returns"], atol=1e-13)
+    # segment-parallel scan == flat scan when every segment ends with mask 0
+    m2 = m.clone()
+    m2[49::50] = 0
+    a1, r1 = estimate_advantages(r, m2, v, 0.95, 0.95)
+    a2, r2 = estimate_advantages(r, m2, v, 0.95, 0.95, seg_len=50)
+    np.testing.assert_allclose(a1.numpy(), a2.numpy(), atol=1e-13)
+    np.testing.assert_allclose(r1.numpy(), r2.numpy(), atol=1e-13)
+
+
+def test_policy_value_ppo_loss_and_grads_match_reference():
+    g = np.load(os.path.join(G, "g8_ppo_small.npz"))
+    pol, val = _nets()
+    pol.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("pol_")})
+    val.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("val_")})
+    x, a = torch.from_numpy(g["x"]), torch.from_numpy(g["a"])
+    np.testing.assert_allclose(pol(x).loc.detach().numpy(), g["mean"], atol=1e-14)
+    np.testing.assert_allclose(pol.get_log_prob(x, a).detach().numpy(), g["log_prob"], atol=1e-12)
+    np.testing.assert_allclose(val(x).detach().numpy(), g["value"], atol=1e-14)
+    from uhc_amd.khrylib.rl.agents import AgentPPO
+    ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None)
+    ind = torch.arange(64)
+    loss = ag.ppo_loss(x, a, torch.from_numpy(g["advs"]), torch.from_numpy(g["fixed_lp"]), ind)
+    assert loss.item() == pytest.approx(float(g["ppo_loss"]), abs=1e-13)
+    loss.backward()
+    for n, p in pol.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(p.grad.numpy(), g["polgrad_" + n], atol=1e-13)
+    vl = (val(x) - torch.from_numpy(g["rets"])).pow(2).mean()
+    assert vl.item() == pytest.approx(float(g["value_loss"]), abs=1e-13)
+    n_pol = sum(p.numel() for p in _nets(657, 105, (2048, 1024, 512))[0].parameters())
+    assert n_pol == 4024530  # policy parameter count at 657 -> 105
+
+
+def test_zfilter_sequential_and_batched():
+    from uhc_amd.khrylib.utils.zfilter import ZFilter
+    g = np.load(os.path.join(G, "g7_zfilter.npz"))
+    z = ZFilter((12,), clip=5)
+    ys = np.array([z(x) for x in g["xs"]])
+    np.testing.assert_allclose(ys, g["ys"], atol=1e-14)
+    np.testing.assert_allclose(z(g["xs"][0], update=False), g["y_noupdate"], atol=1e-14)
+    zb = ZFilter((12,), clip=5)
+    zb(torch.from_numpy(g["xs"][:70]))
+    zb(torch.from_numpy(g["xs"][70:]))
+    assert zb.rs.n == int(g["n"])
+    np.testing.assert_allclose(zb.rs.mean, g["mean"], atol=1e-13)
+    np.testing.assert_allclose(zb.rs.std, g["std"], atol=1e-13)
+    z1 = ZFilter((3,))
+    z1(np.array([1.0, -2.0, 3.0]))
+    np.testing.assert_allclose(z1.rs.var, [1.0, 4.0, 9.0])  # n == 1: var = mean^2 (zfilter.py:34-35)
+
+
+def test_dataset_sampling_interface():
+    import random
+    from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle
+    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
+    data = make_synthetic_amass(6, seed=3, t_range=(20, 60))
+    data["too_short"] = {k: (v[:4] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in data["0-synth_0000"].items()}
+    specs = dict(file_path="synthetic", t_min=5, t_max=30, mode="all")
+    dl = DatasetAMASSSingle(specs, "train", pickle_data=data)
+    assert dl.get_len() == 6 and "too_short" not in dl.data_keys
+    assert len(dl.sample_keys) == sum(data[k]["pose_aa"].shape[0] // 30 + 1 for k in dl.data_keys)
+    random.seed(5)
+    np.random.seed(5)
+    s = dl.sample_seq()
+    T = data[dl.curr_key]["pose_aa"].shape[0]
+    assert s["seq_name"] == dl.curr_key and 0 <= dl.fr_start < T - 5 and dl.fr_end == min(dl.fr_start + 30, T)
+    assert s["pose_aa"].shape == (dl.fr_end - dl.fr_start, 72) and s["beta"].shape[1] == 16 and s["gender"][0] == 0
+    assert s["has_obj"] is False and s["num_obj"] == 0
+    # same seeds -> same windows (the loader draws from the global generators like the reference)
+    random.seed(5)
+    np.random.seed(5)
+    s2 = dl.sample_seq()
+    assert s2["seq_name"] == s["seq_name"] and np.array_equal(s2["pose_aa"], s["pose_aa"])
+    # success-weighted sampling: clips that always succeed are picked less often
+    fd = {k: [[1.0, 0]] * 10 for k in dl.data_keys}
+    fd[dl.data_keys[0]] = [[0.2, 0]] * 10
+    np.random.seed(0)
+    picks = [dl.sample_seq(freq_dict=fd, sampling_temp=0.1, sampling_freq=1.0)["seq_name"] for _ in range(200)]
+    assert picks.count(dl.data_keys[0]) > 150
+    full = dl.iter_seq()
+    assert full["pose_aa"].shape[0] == data[dl.data_keys[0]]["pose_aa"].shape[0]
+
+
+def test_config_defaults_and_schedules(tmp_path):
+    from uhc_amd.utils.config_utils.copycat_config import Config
+    c = Config(cfg_id="copycat_mi355x", base_dir=str(tmp_path))
+    assert (c.gamma, c.tau, c.clip_epsilon, c.num_optim_epoch, c.min_batch_size) == (0.95, 0.95, 0.2, 10, 50000)
+    assert c.policy_hsize == [2048, 1024, 512] and c.policy_htype == "gelu" and c.fix_std and c.log_std == -2.3
+    assert c.obs_v == 2 and c.meta_pd and c.residual_force and c.residual_force_scale == 100 and c.residual_force_lim == 100.0
+    assert c.reward_id == "world_rfc_implicit" and c.reward_weights["k_e"] == 5.0
+    assert os.path.isdir(c.model_dir) and c.model_dir.endswith("results/motion_im/copycat_mi355x/models")
+    c2 = Config(cfg_id="x", base_dir=str(tmp_path), cfg_dict=dict(adp_iter_cp=[0, 100, 200], adp_noise_rate_cp=[1.0, 0.5], adp_policy_lr_cp=[1e-4, 5e-5, 1e-5]))
+    c2.update_adaptive_params(50)
+    assert c2.adp_noise_rate == pytest.approx(0.75) and c2.adp_policy_lr == pytest.approx(7.5e-5)
+    c2.update_adaptive_params(150)
+    assert c2.adp_noise_rate == pytest.approx(0.5) and c2.adp_policy_lr == pytest.approx(3e-5)
+    c2.update_adaptive_params(500)
+    assert c2.adp_policy_lr == pytest.approx(1e-5) and c2.adp_log_std == pytest.approx(-2.3)
+
+
+# ---- data-parallel learner: 2 gloo ranks with half the batch each == 1 process with the whole batch ----------
+def _update(rank, world, port, out_path):
+    import torch.distributed as dist
+    torch.set_default_dtype(torch.float64)
+    sys.path.insert(0, ROOT)
+    from uhc_amd.khrylib.rl.agents import AgentPPO, RolloutBatch
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    pol, val = _nets()
+    opt_p = torch.optim.Adam(pol.parameters(), lr=5e-3)
+    opt_v = torch.optim.Adam(val.parameters(), lr=3e-3)
+    ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None,
+                  tau=0.95, optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=3, clip_epsilon=0.2,
+                  policy_grad_clip=[(pol.parameters(), 0.5)])
+    rng = np.random.default_rng(0)
+    n_env, T = 8, 12
+    st = torch.from_numpy(rng.normal(size=(n_env, T, 23)))
+    ac = torch.from_numpy(rng.normal(scale=0.2, size=(n_env, T, 9)))
+    rw = torch.from_numpy(rng.uniform(size=(n_env, T)))
+    mk = torch.from_numpy((rng.uniform(size=(n_env, T)) > 0.1).astype(np.float64))
+    mk[:, -1] = 0
+    ex = torch.from_numpy((rng.uniform(size=(n_env, T)) > 0.2).astype(np.float64))
+    lo, hi = (0, n_env) if world == 1 else ((0, 3) if rank == 0 else (3, n_env))  # uneven shards on purpose
+    sl = slice(lo, hi)
+    n = (hi - lo) * T
+    batch = RolloutBatch(st[sl].reshape(n, -1), ac[sl].reshape(n, -1), rw[sl].reshape(n, 1), mk[sl].reshape(n, 1), ex[sl].reshape(n), T)
+    ag.update_params(batch)
+    if rank == 0:
+        torch.save({"pol": pol.state_dict(), "val": val.state_dict()}, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_update_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    single, multi = str(tmp_path / "single.pt"), str(tmp_path / "multi.pt")
+    _update(0, 1, 0, single)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_update, args=(2, port, multi), nprocs=2, join=True)
+    a, b = torch.load(single), torch.load(multi)
+    for net in ("pol", "val"):
+        for k in a[net]:
+            np.testing.assert_allclose(a[net][k].numpy(), b[net][k].numpy(), atol=1e-10, err_msg=f"{net}.{k}")

@@ -1,0 +1,231 @@
+"""AgentCopycat (mirror of uhc/agents/agent_copycat.py:53-605): same constructor, ``optimize_policy``,
+``sample``, ``update_params``, ``save_checkpoint`` / ``load_checkpoint`` (same file names and dict keys),
+driving the batched MI355X environment instead of forked CPU workers."""
+from __future__ import annotations
+
+import logging
+import os
+import os.path as osp
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from ..data_loaders.dataset_amass_single import DatasetAMASSSingle
+from ..envs.humanoid_im import VecHumanoidEnv
+from ..khrylib.models.mlp import MLP
+from ..khrylib.rl.agents import AgentPPO
+from ..khrylib.rl.core import PolicyGaussian, Value
+from ..khrylib.utils.torch import get_eta_str, lambda_rule, set_optimizer_lr, to_device
+from ..khrylib.utils.zfilter import ZFilter
+from ..losses.reward_function import DEVICE_REWARD_IDS
+
+
+def create_logger(filename):
+    logger = logging.getLogger(filename)
+    logger.propagate = False
+    logger.setLevel(logging.DEBUG)
+    if not logger.handlers:
+        ch = logging.StreamHandler()
+        ch.setLevel(logging.INFO)
+        ch.setFormatter(logging.Formatter("%(message)s"))
+        logger.addHandler(ch)
+        os.makedirs(osp.dirname(filename), exist_ok=True)
+        fh = logging.FileHandler(filename, mode="a")
+        fh.setFormatter(logging.Formatter("[%(asctime)s] %(message)s"))
+        logger.addHandler(fh)
+    return logger
+
+
+class AgentCopycat(AgentPPO):
+    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None):
+        self.cfg = self.cc_cfg = cfg
+        self.device, self.dtype, self.training = device, dtype, training
+        self.max_freq = 50
+        self.epoch = 0
+        self.precision_mode = cfg.get("precision_mode", False)
+        self.setup_data_loader(data_loader)
+        self.setup_env()
+        self.setup_policy()
+        self.setup_value()
+        self.setup_optimizer()
+        self.setup_logging()
+        self.setup_reward()
+        self.seed(cfg.seed)
+        if checkpoint_epoch > 0:
+            self.load_checkpoint(checkpoint_epoch)
+            self.epoch = checkpoint_epoch
+        super().__init__(env=self.env, dtype=dtype, device=device, running_state=self.running_state, custom_reward=self.expert_reward,
+                         mean_action=bool(getattr(cfg, "render", False)) and not getattr(cfg, "show_noise", False), render=False,
+                         num_threads=getattr(cfg, "num_threads", 1), data_loader=self.data_loader, policy_net=self.policy_net,
+                         value_net=self.value_net, optimizer_policy=self.optimizer_policy, optimizer_value=self.optimizer_value,
+                         opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
+                         policy_grad_clip=[(self.policy_net.parameters(), 40)], end_reward=cfg.end_reward, use_mini_batch=False,
+                         mini_batch_size=0)
+
+    # ---- setup ------------------------------------------------------------------------------------------
+    def setup_data_loader(self, data_loader=None):
+        self.data_loader = data_loader if data_loader is not None else DatasetAMASSSingle(self.cfg.data_specs, data_mode="train")
+        self.test_data_loaders = [self.data_loader]
+        if len(self.cfg.data_specs.get("test_file_path", [])) > 0 and data_loader is None:
+            self.test_data_loaders.append(DatasetAMASSSingle(self.cfg.data_specs, data_mode="test"))
+
+    def setup_env(self):
+        dev_index = self.device.index if isinstance(self.device, torch.device) and self.device.index is not None else 0
+        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train")
+        self.env.set_clip_bank_from_loader(self.data_loader)
+
+    def setup_policy(self):
+        cfg, env = self.cfg, self.env
+        self.state_dim, self.action_dim = env.observation_space.shape[0], env.action_space.shape[0]
+        if cfg.actor_type != "gauss":
+            raise NotImplementedError("PolicyMCP is a later row (SURVEY.md 8f-4)")
+        self.policy_net = PolicyGaussian(cfg, action_dim=self.action_dim, state_dim=self.state_dim)
+        self.running_state = ZFilter((self.state_dim,), clip=5)
+        to_device(self.device, self.policy_net)
+
+    def setup_value(self):
+        self.value_net = Value(MLP(self.state_dim, self.cfg.value_hsize, self.cfg.value_htype))
+        to_device(self.device, self.value_net)
+
+    def setup_optimizer(self):
+        cfg = self.cfg
+
+        def make(name, params, lr, mom, wd):
+            if name == "Adam":
+                return torch.optim.Adam(params, lr=lr, weight_decay=wd)
+            return torch.optim.SGD(params, lr=lr, momentum=mom, weight_decay=wd)
+
+        self.optimizer_policy = make(cfg.policy_optimizer, self.policy_net.parameters(), cfg.policy_lr, cfg.policy_momentum, cfg.policy_weightdecay)
+        self.optimizer_value = make(cfg.value_optimizer, self.value_net.parameters(), cfg.value_lr, cfg.value_momentum, cfg.value_weightdecay)
+
+    def setup_reward(self):
+        if self.cfg.reward_id not in DEVICE_REWARD_IDS:
+            raise NotImplementedError(f"reward '{self.cfg.reward_id}' is a later row (SURVEY.md 8f-4)")
+        self.expert_reward = self.cfg.reward_id
+
+    def setup_logging(self):
+        cfg = self.cfg
+        freq_path = osp.join(cfg.result_dir, "freq_dict.pt")
+        self.freq_dict = {k: [] for k in self.data_loader.data_keys}
+        if osp.exists(freq_path):
+            try:
+                import joblib
+                fd = joblib.load(freq_path)
+                if set(fd.keys()) == set(self.data_loader.data_keys):
+                    self.freq_dict = fd
+            except Exception:
+                pass
+        self.logger = create_logger(os.path.join(cfg.log_dir, "log.txt"))
+
+    def seed(self, seed):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        self.env.seed(seed)
+
+    # ---- checkpoints: file names, dict keys and CPU float64 state_dict layout as agent_copycat.py:190-276 ----
+    def _cp(self):
+        return {"policy_dict": {k: v.detach().cpu() for k, v in self.policy_net.state_dict().items()},
+                "value_dict": {k: v.detach().cpu() for k, v in self.value_net.state_dict().items()}, "running_state": self.running_state}
+
+    def save_checkpoint(self, epoch):
+        cfg = self.cfg
+        pickle.dump(self._cp(), open("%s/iter_%04d.p" % (cfg.model_dir, epoch + 1), "wb"))
+        try:
+            import joblib
+            joblib.dump(self.freq_dict, osp.join(cfg.result_dir, "freq_dict.pt"))
+        except ImportError:
+            pass
+
+    def save_curr(self):
+        pickle.dump(self._cp(), open(f"{self.cfg.model_dir}/iter_best.p", "wb"))
+
+    def _load(self, path):
+        self.logger.info("loading model from checkpoint: %s" % path)
+        cp = CustomUnpickler(open(path, "rb")).load()
+        self.policy_net.load_state_dict(cp["policy_dict"])
+        self.value_net.load_state_dict(cp["value_dict"])
+        self.running_state = cp["running_state"]
+        to_device(self.device, self.policy_net, self.value_net)
+
+    def load_curr(self):
+        self._load(f"{self.cfg.model_dir}/iter_best.p")
+
+    def load_checkpoint(self, iter):
+        if iter > 0:
+            self._load("%s/iter_%04d.p" % (self.cfg.model_dir, iter))
+
+    # ---- clip sampling hooks used by the vectorised rollout ----------------------------------------------------
+    def assign_new_clips(self, env_ids):
+        cfg, dl = self.cfg, self.data_loader
+        if self.precision_mode:  # per-draw path of the reference (window near a recorded failure)
+            keys, fs, fe = [], [], []
+            for _ in env_ids:
+                dl.sample_seq(freq_dict=self.freq_dict, full_sample=False, sampling_temp=cfg.sampling_temp, sampling_freq=cfg.sampling_freq,
+                              precision_mode=True)
+                keys.append(dl.curr_key)
+                fs.append(dl.fr_start)
+                fe.append(dl.fr_end)
+        else:
+            keys, fs, fe = dl.sample_windows(len(env_ids), freq_dict=self.freq_dict, sampling_temp=cfg.sampling_temp, sampling_freq=cfg.sampling_freq)
+        self._env_key = getattr(self, "_env_key", {})
+        for e, k, s in zip(env_ids, keys, fs):
+            self._env_key[int(e)] = (k, int(s))
+        self.env.assign(np.asarray(env_ids), keys, fs, fe)
+        self.env.reset(np.asarray(env_ids))
+
+    def on_episode_end(self, env_ids, percents):
+        for e, p in zip(env_ids, percents):  # freq_dict[key].append([percent, fr_start]) (agent_copycat.py:559-565)
+            k, s = self._env_key[int(e)]
+            self.freq_dict[k].append([float(p), s])
+            self.freq_dict[k] = self.freq_dict[k][-self.max_freq:]
+
+    # ---- training iteration ------------------------------------------------------------------------------
+    def per_epoch_update(self, epoch):
+        cfg = self.cfg
+        cfg.update_adaptive_params(epoch)
+        self.set_noise_rate(cfg.adp_noise_rate)
+        set_optimizer_lr(self.optimizer_policy, cfg.adp_policy_lr)
+        if cfg.rfc_decay:
+            mx = cfg.get("rfc_decay_max", 10000)
+            self.env.set_rfc_rate(lambda_rule(self.epoch, mx, cfg.num_epoch_fix) if self.epoch < mx else 0.0)
+        if cfg.fix_std:
+            self.policy_net.action_log_std.data.fill_(cfg.adp_log_std)
+
+    def optimize_policy(self, epoch, save_model=True):
+        cfg = self.cfg
+        self.epoch = epoch
+        t0 = time.time()
+        self.per_epoch_update(epoch)
+        batch, log = self.sample(cfg.min_batch_size)
+        if cfg.end_reward:
+            self.env.end_reward = log.avg_c_reward * cfg.gamma / (1 - cfg.gamma)
+        t1 = time.time()
+        self.update_params(batch)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        t2 = time.time()
+        info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
+        if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0:
+            self.save_checkpoint(epoch)
+        self.log_train(info)
+        return info
+
+    def log_train(self, info):
+        log, cfg = info["log"], self.cfg
+        c = np.array2string(log.avg_c_info, formatter={"all": lambda x: "%.4f" % x}, separator=",")
+        self.logger.info(f"Ep: {self.epoch}\t {cfg.id} \tT_s {info['T_sample']:.2f}\t T_u {info['T_update']:.2f}\tETA "
+                         f"{get_eta_str(self.epoch, cfg.num_epoch, info['T_total'])}\texpert_R_avg {log.avg_c_reward:.4f} {c}"
+                         f"\texpert_R_range ({log.min_c_reward:.4f}, {log.max_c_reward:.4f})\teps_len {log.avg_episode_len:.2f}")
+
+
+class CustomUnpickler(pickle.Unpickler):
+    """Load reference checkpoints: their pickles name ZFilter/RunningStat under the reference's module paths
+    (uhc/utils/tools.py:7-18 does the same renaming for its own history)."""
+
+    def find_class(self, module, name):
+        if name in ("ZFilter", "RunningStat"):
+            from ..khrylib.utils import zfilter
+            return getattr(zfilter, name)
+        return super().find_class(module, name)

@@ -115,6 +115,8 @@ struct UhcBatch {
     std::vector<void*> allocs;
     int nM = 0;
     int* reset_mask = nullptr;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
     // field table
     void* field_ptr[16] = {nullptr};
     int64_t field_count[16] = {0};
@@ -429,6 +431,8 @@ extern "C" void uhc_batch_free(UhcBatch* b) {
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     for (void* p : b->allocs) hipFree(p);
+    for (auto& ev : b->ev_used) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (auto& ev : b->ev_free) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     if (b->own_stream) hipStreamDestroy(b->own_stream);
     delete b;
 }
@@ -457,11 +461,40 @@ extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n)
 static int launch(UhcBatch* b, int mode, const double* d_action, const double* d_tbase, const int* d_active) {
     if (b->use_fast) {
         HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env, b->stream));
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        const bool timed = b->timing && mode == 0;
+        if (timed) {
+            if (b->ev_free.empty()) { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
+            else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
+            HIP_OK(hipEventRecord(ev.first, b->stream));
+        }
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
+        if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
         HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
     } else {
         HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
     }
+    return 0;
+}
+
+extern "C" int32_t uhc_batch_set_timing(UhcBatch* b, int32_t enable) {
+    if (!b) return fail("uhc_batch_set_timing: null batch");
+    b->timing = enable != 0;
+    return 0;
+}
+extern "C" int32_t uhc_batch_kernel_time(UhcBatch* b, double* total_ms, int32_t* launches) {
+    if (!b || !total_ms || !launches) return fail("uhc_batch_kernel_time: null argument");
+    double tot = 0;
+    for (auto& ev : b->ev_used) {
+        float ms = 0;
+        HIP_OK(hipEventSynchronize(ev.second));
+        HIP_OK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+        b->ev_free.push_back(ev);
+    }
+    *total_ms = tot;
+    *launches = (int32_t)b->ev_used.size();
+    b->ev_used.clear();
     return 0;
 }
 

@@ -239,12 +239,15 @@ __global__ void uhc_env_reset_stage_kernel(EnvArgs E, const int* env_ids, int n,
     if (r >= n) return;
     const int env = env_ids[r];
     const double* fr = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE;  // ind = 0
+    // the expert velocity of a window's first frame is a copy of its second frame's finite difference
+    // (torch_smpl_humanoid.py:202-207: qvel = cat(qvel[0:1], qvel)); the bank stores whole clips, so read frame 1
+    const double* frv = fr + (E.e_len[env] > 1 ? UHC_FRAME_STRIDE : 0);
     for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
         double v = fr[UHC_FR_QPOS + i];
         if (noise && i >= 7) v += noise[(size_t)r * E.nu + (i - 7)];
         out_qpos[(size_t)r * E.nq + i] = v;
     }
-    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = fr[UHC_FR_QVEL + i];
+    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = frv[UHC_FR_QVEL + i];
     if (threadIdx.x == 0) { E.cur_t[env] = 0; E.start_ind[env] = 0; E.done[env] = 0; E.fail[env] = 0; E.end[env] = 0; }
 }
 extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* env_ids, int n, const double* noise, double* out_qpos,

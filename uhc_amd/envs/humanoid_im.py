@@ -1,0 +1,228 @@
+"""Humanoid imitation environments.
+
+``VecHumanoidEnv`` -- n_env environments stepped together on one MI355X through the C-ABI
+(uhc_env_* / uhc_batch_*); observations, rewards and flags stay in HBM.
+``HumanoidEnv``    -- the reference's single-env gym-like surface (uhc/envs/humanoid_im.py:47-1465:
+``reset, step, load_expert, set_mode, seed, observation_space, action_space, data, model, ...``) as a
+1-env view of the same machinery, so reference-style callers (AgentCopycat, eval scripts) run unmodified.
+"""
+from __future__ import annotations
+
+import types
+
+import numpy as np
+import torch
+
+from .. import sim as S
+from .._capi import env_desc
+from ..smpllib.smpl_mujoco import SMPLConverter, smpl_to_qpose
+from ..smpllib.torch_smpl_humanoid import Humanoid
+
+
+class _Box:
+    def __init__(self, dim):
+        self.shape = (dim,)
+        self.low, self.high = -np.ones(dim), np.ones(dim)
+
+
+class VecHumanoidEnv:
+    def __init__(self, cfg, n_env, device=0, mode="train", model=None):
+        self.cc_cfg = self.cfg = cfg
+        self.mode = mode
+        self.n_env = int(n_env)
+        self.model = model if model is not None else S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh"))
+        self.base_rot = cfg.data_specs.get("base_rot", [0.7071, 0.7071, 0.0, 0.0])
+        self.rfc_rate = 1 if not cfg.rfc_decay else 0
+        self.converter = SMPLConverter(self.model, self.model, smpl_model=cfg.robot_cfg.get("model", "smpl"))
+        self.ctrl = S.make_ctrl(self.model, meta_pd=cfg.meta_pd, meta_pd_joint=cfg.meta_pd_joint, residual_force=cfg.residual_force,
+                                residual_force_mode=cfg.residual_force_mode, residual_force_scale=cfg.residual_force_scale,
+                                residual_force_lim=cfg.residual_force_lim, rfc_rate=self.rfc_rate, action_type=cfg.action_type,
+                                pd_mul=cfg.get("pd_mul", 1), tq_mul=cfg.get("tq_mul", 1), base_rot=self.base_rot)
+        self.sim = S.SimBatch(self.model, self.ctrl, self.n_env, device=device)
+        self.device = self.sim.device
+        thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
+        if cfg.env_term_body != "body":
+            raise NotImplementedError("env_term_body other than 'body' is a later row (SURVEY.md 8f-4)")
+        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
+                                                 env_episode_len=cfg.env_episode_len, env_expert_trail_steps=cfg.env_expert_trail_steps,
+                                                 body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
+                                                 jpos_diffw=self.converter.get_new_diff_weight()))
+        self.ndof = self.model.nu
+        self.vf_dim = 6 if (cfg.residual_force and cfg.residual_force_mode == "implicit") else 0
+        self.meta_pd_dim = 30 if cfg.meta_pd else (2 * self.ndof if cfg.meta_pd_joint else 0)
+        self.action_dim = self.ctrl.action_dim
+        self.obs_dim = self.env.obs_dim
+        self.observation_space, self.action_space = _Box(self.obs_dim), _Box(self.action_dim)
+        self.humanoid = Humanoid(model=self.model)
+        self.np_random = np.random.RandomState()
+        self.end_reward = 0.0
+        self.dt = self.model.timestep * 15
+        self.clip_keys, self._clip_index, self._clip_len = [], {}, None
+
+    # ---- expert clips -------------------------------------------------------------------------------------
+    def expert_features(self, sample):
+        """load_expert's feature computation (humanoid_im.py:182-215): AMASS window -> qpos -> qpos_fk."""
+        qpos = smpl_to_qpose(pose=sample["pose_aa"], mj_model=self.model, trans=np.asarray(sample["trans"]).squeeze(),
+                             model=self.cc_cfg.robot_cfg.get("model", "smpl"), count_offset=self.cc_cfg.robot_cfg.get("mesh", True))
+        return self.humanoid.qpos_fk(torch.from_numpy(qpos))
+
+    def set_clip_bank(self, clips: dict):
+        """clips: {key: sample dict with pose_aa/trans/beta/gender of the WHOLE clip}.  Builds the HBM bank once."""
+        frames, starts, betas, lens = [], [], [], []
+        n = 0
+        self.clip_keys = list(clips.keys())
+        for k in self.clip_keys:
+            c = clips[k]
+            fr = S.pack_expert_frames(self.expert_features(c))
+            frames.append(fr)
+            starts.append(n)
+            lens.append(fr.shape[0])
+            n += fr.shape[0]
+            beta = np.asarray(c["beta"], dtype=np.float64)
+            beta = beta[0] if beta.ndim == 2 else beta
+            beta = np.concatenate([beta, np.zeros(16 - beta.shape[0])]) if beta.shape[0] < 16 else beta[:16]
+            g = np.asarray(c["gender"]).reshape(-1)[0]
+            betas.append(np.r_[beta, float(g)])
+        self._clip_index = {k: i for i, k in enumerate(self.clip_keys)}
+        self._clip_len = np.array(lens)
+        self.env.set_bank(torch.from_numpy(np.concatenate(frames)), torch.tensor(starts, dtype=torch.int32), torch.from_numpy(np.stack(betas)))
+
+    def set_clip_bank_from_loader(self, data_loader):
+        clips = {k: dict(pose_aa=data_loader.data["pose_aa"][k], trans=data_loader.data["trans"][k], beta=data_loader.data["beta"][k],
+                         gender=data_loader.data["gender"][k]) for k in data_loader.data_keys}
+        self.set_clip_bank(clips)
+
+    def assign(self, env_ids, keys, fr_start, fr_end):
+        """load_expert bookkeeping for a set of envs: env i imitates frames [fr_start, fr_end) of clip keys[i]."""
+        cid = torch.tensor([self._clip_index[k] for k in keys], dtype=torch.int32)
+        fs = torch.as_tensor(np.asarray(fr_start), dtype=torch.int32)
+        fl = torch.as_tensor(np.asarray(fr_end) - np.asarray(fr_start), dtype=torch.int32)
+        self.env.assign(torch.as_tensor(env_ids, dtype=torch.int32), cid, fs, fl)
+
+    # ---- gym-like batched surface -----------------------------------------------------------------------
+    def set_mode(self, mode):
+        self.mode = mode
+
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def set_rfc_rate(self, rate):
+        self.rfc_rate = rate
+        self.sim.set_rfc_scale(self.cc_cfg.residual_force_scale * rate)
+
+    def reset(self, env_ids=None):
+        """reset_model (humanoid_im.py:1245-1299) on the listed envs; returns the obs tensor view (n_env, obs_dim)."""
+        ids = torch.arange(self.n_env, dtype=torch.int32) if env_ids is None else torch.as_tensor(env_ids, dtype=torch.int32)
+        noise = None
+        if self.mode == "train" and self.cc_cfg.env_init_noise > 0:
+            noise = torch.from_numpy(self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof)))
+        self.env.reset(ids, noise)
+        return self.obs
+
+    def step(self, action, active=None):
+        self.env.step(action, active)
+        return self.obs, self.reward, self.done, {"fail": self.env.field(S.E_FAIL), "end": self.env.field(S.E_END), "percent": self.env.field(S.E_PERCENT)}
+
+    obs = property(lambda self: self.env.field(S.E_OBS))
+    reward = property(lambda self: self.env.field(S.E_REWARD))
+    reward_parts = property(lambda self: self.env.field(S.E_REWARD_PARTS))
+    done = property(lambda self: self.env.field(S.E_DONE))
+    cur_t = property(lambda self: self.env.field(S.E_CUR_T))
+
+    def close(self):
+        self.env.close()
+        self.sim.close()
+
+
+class _Data:
+    """Host snapshot of mujoco-py's `sim.data` fields the reference reads."""
+
+    def __init__(self, venv):
+        s = venv.sim
+        nb = venv.model.nbody
+        self.qpos = s.field(S.F_QPOS)[0].cpu().numpy()
+        self.qvel = s.field(S.F_QVEL)[0].cpu().numpy()
+        self.body_xpos = s.field(S.F_XPOS)[0].cpu().numpy().reshape(nb, 3)
+        self.body_xquat = s.field(S.F_XQUAT)[0].cpu().numpy().reshape(nb, 4)
+        self.xipos = s.field(S.F_XIPOS)[0].cpu().numpy().reshape(nb, 3)
+        self.ctrl = s.field(S.F_CTRL)[0].cpu().numpy()
+        self.qfrc_applied = s.field(S.F_QFRC_APPLIED)[0].cpu().numpy()
+        self.qfrc_bias = s.field(S.F_QFRC_BIAS)[0].cpu().numpy()
+        self.ncon = int(s.field(S.F_NCON)[0].item())
+        self._names = venv.model.body_names
+
+    def get_body_xipos(self, name):
+        return self.xipos[self._names.index(name)]
+
+    def get_body_xpos(self, name):
+        return self.body_xpos[self._names.index(name)]
+
+
+class HumanoidEnv:
+    """Single-environment facade with the reference's constructor and methods (humanoid_im.py:49-70)."""
+
+    def __init__(self, cfg, init_expert, data_specs, mode="train", no_root=False, device=0):
+        self.vec = VecHumanoidEnv(cfg, 1, device=device, mode=mode)
+        self.cc_cfg, self.mode, self.no_root = cfg, mode, no_root
+        v = self.vec
+        self.model, self.converter, self.humanoid = v.model, v.converter, v.humanoid
+        self.observation_space, self.action_space = v.observation_space, v.action_space
+        self.ndof, self.vf_dim, self.meta_pd_dim, self.action_dim, self.obs_dim = v.ndof, v.vf_dim, v.meta_pd_dim, v.action_dim, v.obs_dim
+        self.body_diffw = v.converter.get_new_diff_weight()[1:]
+        self.jpos_diffw = v.converter.get_new_diff_weight()[:, None]
+        self.base_rot, self.dt, self.frame_skip = v.base_rot, v.dt, 15
+        self.np_random = v.np_random
+        self.end_reward, self.start_ind, self.expert = 0.0, 0, None
+        self.prev_bquat = None
+        self.load_expert(init_expert)
+
+    rfc_rate = property(lambda self: self.vec.rfc_rate, lambda self, r: self.vec.set_rfc_rate(r))
+    cur_t = property(lambda self: int(self.vec.cur_t[0].item()))
+    data = property(lambda self: _Data(self.vec))
+
+    def seed(self, seed=None):
+        out = self.vec.seed(seed)
+        self.np_random = self.vec.np_random
+        return out
+
+    def set_mode(self, mode):
+        self.mode = mode
+        self.vec.set_mode(mode)
+
+    def load_expert(self, expert_data, reload_robot=True):
+        self.expert = dict(expert_data)
+        self.expert["meta"] = {"cyclic": False, "seq_name": expert_data["seq_name"]}
+        self.expert.update(self.vec.expert_features(expert_data))
+        self.vec.set_clip_bank({expert_data["seq_name"]: expert_data})
+        self.vec.assign([0], [expert_data["seq_name"]], [0], [self.expert["len"]])
+
+    def reset(self):
+        return self.vec.reset()[0].cpu().numpy()
+
+    def step(self, a):
+        act = torch.as_tensor(np.asarray(a, dtype=np.float64).reshape(1, -1), device=self.vec.device)
+        self.vec.step(act)
+        info = {"fail": bool(self.vec.env.field(S.E_FAIL)[0].item()), "end": bool(self.vec.env.field(S.E_END)[0].item()),
+                "percent": float(self.vec.env.field(S.E_PERCENT)[0].item())}
+        self.last_reward = (float(self.vec.reward[0].item()), self.vec.reward_parts[0].cpu().numpy())
+        return self.vec.obs[0].cpu().numpy(), 1.0, bool(self.vec.done[0].item()), info
+
+    def get_expert_index(self, t):
+        return min(self.start_ind + t, self.expert["len"] - 1)
+
+    def get_expert_attr(self, attr, ind):
+        return self.expert[attr][ind].copy()
+
+    def get_wbody_pos(self, selectList=None):
+        d = self.data
+        return d.body_xpos[1:].copy().ravel() if selectList is None else np.concatenate([d.get_body_xpos(b) for b in selectList])
+
+    def get_humanoid_qpos(self):
+        return self.data.qpos.copy()
+
+    def get_humanoid_qvel(self):
+        return self.data.qvel.copy()
+
+    def get_world_vf(self):
+        return None

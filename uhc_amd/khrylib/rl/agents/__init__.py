@@ -1,0 +1,259 @@
+"""Agent / AgentPG / AgentPPO with the reference's structure (uhc/khrylib/rl/agents/{agent,agent_pg,agent_ppo}.py)
+re-designed around a batched on-device environment:
+
+* ``Agent.sample`` steps all n_env environments together; states, actions, rewards, masks and exps are written
+  into pre-allocated rollout tensors in HBM laid out [n_env][T] (each env's samples contiguous in time, the
+  same order as the reference's concatenated per-worker memories).
+* ``AgentPG.update_params`` runs value prediction, GAE (segment-parallel reverse scan), and the PPO epochs on
+  those tensors without a host round trip.
+* With ``torch.distributed`` initialised, every optimisation epoch all-reduces one flat buffer holding the
+  policy and value gradients (summed over ranks, then divided by the global sample counts) before clipping,
+  and the advantage statistics / observation-filter statistics are merged across ranks.
+"""
+from __future__ import annotations
+
+import math
+import time
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..core import LoggerRL, estimate_advantages
+from ...utils.torch import to_test, to_train
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class RolloutBatch:
+    """What TrajBatch (uhc/khrylib/rl/core/trajbatch.py:5-15) holds, as device tensors [n_env*T, .]."""
+
+    def __init__(self, states, actions, rewards, masks, exps, seg_len):
+        self.states, self.actions, self.rewards, self.masks, self.exps, self.seg_len = states, actions, rewards, masks, exps, seg_len
+
+
+class Agent:
+    def __init__(self, env, policy_net, value_net, dtype, device, gamma, data_loader, custom_reward=None, end_reward=True,
+                 mean_action=False, render=False, running_state=None, num_threads=1):
+        self.env, self.policy_net, self.value_net = env, policy_net, value_net
+        self.dtype, self.device, self.gamma = dtype, device, gamma
+        self.custom_reward, self.end_reward, self.mean_action = custom_reward, end_reward, mean_action
+        self.running_state, self.render, self.num_threads = running_state, render, num_threads
+        self.noise_rate = 1.0
+        self.logger_cls = LoggerRL
+        self.sample_modules = [policy_net]
+        self.update_modules = [policy_net, value_net]
+        self.data_loader = data_loader
+
+    def set_noise_rate(self, noise_rate):
+        self.noise_rate = noise_rate
+
+    def trans_policy(self, states):
+        return states
+
+    def trans_value(self, states):
+        return states
+
+    # ---- hooks the concrete agent provides -------------------------------------------------------------
+    def assign_new_clips(self, env_ids):
+        """Pick a clip window for each env in env_ids (host side: data_loader.sample_seq) and reset them."""
+        raise NotImplementedError
+
+    def on_episode_end(self, env_ids, percents):
+        pass
+
+    # ---- vectorised rollout (replaces sample_worker / sample of agent.py:42-131) -------------------------
+    @torch.no_grad()
+    def rollout_begin(self, T):
+        env = self.env
+        n_env, dev = env.n_env, env.device
+        R = self._ro = types.SimpleNamespace(T=T, t=0)
+        R.states = torch.empty(n_env, T, env.obs_dim, dtype=self.dtype, device=dev)
+        R.actions = torch.empty(n_env, T, env.action_dim, dtype=self.dtype, device=dev)
+        R.rewards = torch.zeros(n_env, T, dtype=self.dtype, device=dev)
+        R.masks = torch.ones(n_env, T, dtype=self.dtype, device=dev)
+        R.exps = torch.ones(n_env, T, dtype=self.dtype, device=dev)
+        R.logger = self.logger_cls()
+        R.ep_len = torch.zeros(n_env, dtype=torch.int64, device=dev)
+        R.ep_rew = torch.zeros(n_env, dtype=self.dtype, device=dev)
+        R.c_info_sum = torch.zeros(5, dtype=self.dtype, device=dev)
+        to_test(*self.sample_modules)
+        self.assign_new_clips(np.arange(n_env))  # every sampling pass starts fresh episodes, like each reference worker
+        obs = env.obs.to(self.dtype)
+        R.state = self.running_state(obs) if self.running_state is not None else obs
+
+    @torch.no_grad()
+    def rollout_step(self):
+        """One control step of every env: filter -> policy -> env.step -> buffers; resets finished episodes."""
+        env, R = self.env, self._ro
+        n_env, dev, t, T = env.n_env, env.device, self._ro.t, self._ro.T
+        R.states[:, t] = R.state
+        flags_np = np.ones(n_env) if self.mean_action else env.np_random.binomial(1, 1 - self.noise_rate, size=n_env)
+        mean_flag = torch.from_numpy(flags_np.astype(np.float64)).to(dev)
+        action = self.policy_net.select_action(self.trans_policy(R.state), mean_flag).to(torch.float64).contiguous()
+        R.actions[:, t] = action
+        env.step(action)
+        r = env.reward.to(self.dtype)
+        done = env.done.bool()
+        if self.end_reward:
+            r = r + env.env.field(5).to(self.dtype) * env.end_reward  # info["end"] * end_reward (agent.py:84-85)
+        R.rewards[:, t] = r
+        R.masks[:, t] = (~done).to(self.dtype)
+        R.exps[:, t] = 1 - mean_flag
+        R.ep_len += 1
+        R.ep_rew += r
+        R.c_info_sum += env.reward_parts.sum(0)
+        # one host read per step (the clip sampler is host code): done flag, episode length / return, percent
+        host = torch.stack([done.to(self.dtype), R.ep_len.to(self.dtype), R.ep_rew, env.env.field(6).to(self.dtype)]).cpu().numpy()
+        ids = np.nonzero(host[0])[0]
+        if len(ids):
+            R.logger.add_episodes(host[1][ids], host[2][ids])
+            self.on_episode_end(ids, host[3][ids])
+            idt = torch.from_numpy(ids).to(dev)
+            R.ep_len[idt] = 0
+            R.ep_rew[idt] = 0
+            if t < T - 1:
+                self.assign_new_clips(ids)
+        obs = env.obs.to(self.dtype)
+        R.state = self.running_state(obs) if self.running_state is not None else obs
+        R.t += 1
+
+    @torch.no_grad()
+    def rollout_end(self):
+        env, R = self.env, self._ro
+        T, N = R.T, env.n_env * R.T
+        # episodes cut by the end of the pass: bootstrap with V(s_T) folded into the last reward, then close the segment
+        open_ = R.masks[:, T - 1] > 0
+        if bool(open_.any()):
+            v_next = self.value_net(self.trans_value(R.state[open_])).squeeze(-1)
+            R.rewards[open_, T - 1] += self.gamma * v_next
+            R.masks[open_, T - 1] = 0
+        R.logger.add_steps(N, float(R.rewards.sum().item()), R.c_info_sum.cpu().numpy())
+        R.logger.end_sampling()
+        return RolloutBatch(R.states.reshape(N, -1), R.actions.reshape(N, -1), R.rewards.reshape(N, 1), R.masks.reshape(N, 1), R.exps.reshape(N), T), R.logger
+
+    def sample(self, min_batch_size):
+        t0 = time.time()
+        T = int(math.ceil(min_batch_size / self.env.n_env))
+        self.rollout_begin(T)
+        for _ in range(T):
+            self.rollout_step()
+        batch, logger = self.rollout_end()
+        logger.sample_time = time.time() - t0
+        return batch, logger
+
+
+class AgentPG(Agent):
+    def __init__(self, tau=0.95, optimizer_policy=None, optimizer_value=None, opt_num_epochs=1, value_opt_niter=1, **kwargs):
+        super().__init__(**kwargs)
+        self.tau, self.optimizer_policy, self.optimizer_value = tau, optimizer_policy, optimizer_value
+        self.opt_num_epochs, self.value_opt_niter = opt_num_epochs, value_opt_niter
+        self._flat_grad = None
+
+    # ---- data-parallel gradient exchange: ONE collective per optimisation step ----------------------------
+    def _allreduce_grads(self, params_and_scale):
+        """params_and_scale: list of (parameter list, local sample count) -- gradients are local means; turn them
+        into global means: sum_r (n_r * g_r) / sum_r n_r, with one all-reduce over a flat buffer."""
+        if not _dist_on():
+            return
+        plist = [p for ps, _ in params_and_scale for p in ps if p.grad is not None]
+        total = sum(p.numel() for p in plist) + len(params_and_scale)
+        if self._flat_grad is None or self._flat_grad.numel() != total or self._flat_grad.dtype != plist[0].dtype:
+            self._flat_grad = torch.empty(total, dtype=plist[0].dtype, device=plist[0].device)
+        buf, off = self._flat_grad, 0
+        for ps, n in params_and_scale:
+            for p in ps:
+                if p.grad is None:
+                    continue
+                k = p.numel()
+                buf[off:off + k] = p.grad.reshape(-1) * float(n)
+                off += k
+        for i, (_, n) in enumerate(params_and_scale):
+            buf[off + i] = float(n)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        counts = buf[off:off + len(params_and_scale)]
+        off = 0
+        for i, (ps, _) in enumerate(params_and_scale):
+            for p in ps:
+                if p.grad is None:
+                    continue
+                k = p.numel()
+                p.grad.copy_((buf[off:off + k] / counts[i].clamp(min=1.0)).view_as(p.grad))
+                off += k
+
+    def update_value(self, states, returns):
+        for _ in range(self.value_opt_niter):
+            value_loss = (self.value_net(self.trans_value(states)) - returns).pow(2).mean()
+            self.optimizer_value.zero_grad()
+            value_loss.backward()
+            self._allreduce_grads([(list(self.value_net.parameters()), states.shape[0])])
+            self.optimizer_value.step()
+        return value_loss.detach()
+
+    def update_policy(self, states, actions, returns, advantages, exps):
+        ind = exps.nonzero().squeeze(1)
+        for _ in range(self.opt_num_epochs):
+            self.update_value(states, returns)
+            log_probs = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+            policy_loss = -(log_probs * advantages[ind]).mean()
+            self.optimizer_policy.zero_grad()
+            policy_loss.backward()
+            self._allreduce_grads([(list(self.policy_net.parameters()), ind.shape[0])])
+            self.optimizer_policy.step()
+
+    def update_params(self, batch):
+        t0 = time.time()
+        to_train(*self.update_modules)
+        states, actions, rewards, masks, exps = batch.states, batch.actions, batch.rewards, batch.masks, batch.exps
+        with to_test(*self.update_modules), torch.no_grad():
+            values = self.value_net(self.trans_value(states))
+        reduce = None
+        if _dist_on():
+            def reduce(v):
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+                return v
+        advantages, returns = estimate_advantages(rewards, masks, values, self.gamma, self.tau, seg_len=getattr(batch, "seg_len", None),
+                                                  stats_reduce=reduce)
+        self.update_policy(states, actions, returns, advantages, exps)
+        return time.time() - t0
+
+
+class AgentPPO(AgentPG):
+    def __init__(self, clip_epsilon=0.2, mini_batch_size=64, use_mini_batch=False, policy_grad_clip=None, **kwargs):
+        super().__init__(**kwargs)
+        self.clip_epsilon, self.mini_batch_size, self.use_mini_batch = clip_epsilon, mini_batch_size, use_mini_batch
+        self.policy_grad_clip = policy_grad_clip
+
+    def update_policy(self, states, actions, returns, advantages, exps):
+        """agent_ppo.py:16-51, full-batch branch (use_mini_batch is False for every copycat config)."""
+        if self.use_mini_batch:
+            raise NotImplementedError("mini-batch PPO is not used by AgentCopycat (agent_copycat.py:95-96)")
+        with to_test(*self.update_modules), torch.no_grad():
+            fixed_log_probs = self.policy_net.get_log_prob(self.trans_policy(states), actions)
+        ind = exps.nonzero(as_tuple=False).squeeze(1)
+        self.last_losses = []
+        for _ in range(self.opt_num_epochs):
+            vl = self.update_value(states, returns)
+            surr_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind)
+            self.optimizer_policy.zero_grad()
+            surr_loss.backward()
+            self._allreduce_grads([([p for p in self.policy_net.parameters() if p.requires_grad], ind.shape[0])])
+            self.clip_policy_grad()
+            self.optimizer_policy.step()
+            self.last_losses.append((vl, surr_loss.detach()))
+
+    def clip_policy_grad(self):
+        if self.policy_grad_clip is not None:
+            for params, max_norm in self.policy_grad_clip:
+                torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+    def ppo_loss(self, states, actions, advantages, fixed_log_probs, ind):
+        log_probs = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+        ratio = torch.exp(log_probs - fixed_log_probs[ind])
+        adv = advantages[ind]
+        surr1 = ratio * adv
+        surr2 = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
+        return -torch.min(surr1, surr2).mean()

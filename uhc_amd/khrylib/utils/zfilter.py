@@ -1,0 +1,130 @@
+"""Running observation normaliser (mirror of uhc/khrylib/utils/zfilter.py:7-73).
+
+``RunningStat.push`` is Welford's update for one vector (reference semantics).  ``push_batch`` merges a
+whole batch of observations (Chan et al. parallel update) with torch on the device holding the batch --
+mathematically the same statistics as pushing the rows one by one.  ``ZFilter.__call__`` accepts either
+a single numpy vector (reference behaviour) or a (B, dim) torch tensor (batched env)."""
+import numpy as np
+import torch
+
+
+class RunningStat:
+    def __init__(self, shape):
+        self._n = 0
+        self._M = np.zeros(shape)
+        self._S = np.zeros(shape)
+        self._dev, self._stale = None, False  # device-resident copy used by the batched path
+
+    def push(self, x):
+        self._sync()
+        self._dev = None
+        x = np.asarray(x)
+        assert x.shape == self._M.shape
+        self._n += 1
+        if self._n == 1:
+            self._M[...] = x
+        else:
+            old = self._M.copy()
+            self._M[...] = old + (x - old) / self._n
+            self._S[...] = self._S + (x - old) * (x - self._M)
+
+    def push_batch(self, xb: torch.Tensor):
+        """Merge B rows at once: (n, M, S) <- merge((n, M, S), (B, mean_b, S_b)).  The statistics stay on the
+        device of `xb` (no host sync per rollout step); the numpy views are refreshed lazily."""
+        B = xb.shape[0]
+        if B == 0:
+            return
+        if self._dev is None or self._dev[1].device != xb.device:
+            self._dev = [float(self._n), torch.as_tensor(self._M, dtype=torch.float64, device=xb.device),
+                         torch.as_tensor(self._S, dtype=torch.float64, device=xb.device)]
+        x = xb.double()
+        mb = x.mean(0)
+        Sb = ((x - mb) ** 2).sum(0)
+        n, M, Sd = self._dev
+        tot = n + B
+        delta = mb - M
+        self._dev = [tot, M + delta * (B / tot), Sd + Sb + delta * delta * (n * B / tot)]
+        self._n = int(tot)
+        self._stale = True
+
+    def _sync(self):
+        if self._stale:
+            self._M[...] = self._dev[1].cpu().numpy()
+            self._S[...] = self._dev[2].cpu().numpy()
+            self._stale = False
+
+    def device_mean_std(self, like: torch.Tensor):
+        """(mean, std) as tensors on like.device without a host round trip."""
+        if self._dev is None or self._dev[1].device != like.device:
+            self._dev = [float(self._n), torch.as_tensor(self._M, dtype=torch.float64, device=like.device),
+                         torch.as_tensor(self._S, dtype=torch.float64, device=like.device)]
+        n, M, Sd = self._dev
+        var = Sd / (n - 1) if n > 1 else M * M
+        return M.to(like.dtype), torch.sqrt(var).to(like.dtype)
+
+    def merge(self, nb, mb, Sb):
+        self._sync()
+        n = self._n
+        tot = n + nb
+        delta = mb - self._M
+        self._S[...] = self._S + Sb + delta * delta * (n * nb / tot)
+        self._M[...] = self._M + delta * (nb / tot)
+        self._n = tot
+        self._dev = None
+
+    def __getstate__(self):  # checkpoints hold plain numpy statistics, like the reference's pickles
+        self._sync()
+        return {"_n": self._n, "_M": self._M, "_S": self._S}
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._dev, self._stale = None, False
+
+    n = property(lambda self: self._n)
+    @property
+    def mean(self):
+        self._sync()
+        return self._M
+
+    shape = property(lambda self: self._M.shape)
+
+    @property
+    def var(self):
+        self._sync()
+        return self._S / (self._n - 1) if self._n > 1 else np.square(self._M)
+
+    @property
+    def std(self):
+        return np.sqrt(self.var)
+
+
+class ZFilter:
+    """y = clip((x - mean) / (std + 1e-8), +-clip) with running estimates of mean, std."""
+
+    def __init__(self, shape, demean=True, destd=True, clip=10.0):
+        self.demean, self.destd, self.clip = demean, destd, clip
+        self.rs = RunningStat(shape)
+
+    def __call__(self, x, update=True):
+        if torch.is_tensor(x):
+            if update:
+                self.rs.push_batch(x)
+            mean, std = self.rs.device_mean_std(x)
+            if self.demean:
+                x = x - mean
+            if self.destd:
+                x = x / (std + 1e-8)
+            return torch.clamp(x, -self.clip, self.clip) if self.clip else x
+        if update:
+            self.rs.push(x)
+        if self.demean:
+            x = x - self.rs.mean
+        if self.destd:
+            x = x / (self.rs.std + 1e-8)
+        return np.clip(x, -self.clip, self.clip) if self.clip else x
+
+    def set_mean_std(self, mean, std, n):
+        self.rs._dev, self.rs._stale = None, False
+        self.rs._n = n
+        self.rs._M[...] = mean
+        self.rs._S[...] = std

@@ -117,6 +117,15 @@ class SimBatch:
     def forward(self):
         check(self.L.uhc_batch_forward(self._b))
 
+    def set_timing(self, enable: bool):
+        check(self.L.uhc_batch_set_timing(self._b, int(enable)))
+
+    def kernel_time(self):
+        """(total ms, launches) of the fused step kernel since the last call (HIP events on the batch's stream)."""
+        ms, n = C.c_double(), C.c_int32()
+        check(self.L.uhc_batch_kernel_time(self._b, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
 
 E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE = range(10)
 _E_INT = {E_DONE, E_FAIL, E_END, E_CUR_T}
