@@ -1,0 +1,37 @@
+"""CPU: libuhc_amd.so loads and exports every symbol include/uhc_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "uhc_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uhc_[a-z_0-9A-Z]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_listed():
+    import __graft_entry__ as g
+    g.build()
+    from uhc_amd import _lib
+    names = _declared()
+    assert len(names) >= 20 and "uhc_env_step" in names and "uhc_batch_simulate" in names
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/uhc_amd.h but not exported"
+    assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+    L.uhc_abi_version.restype = ctypes.c_int32
+    assert L.uhc_abi_version() == 1
+
+
+def test_product_package_never_imports_the_oracle():
+    for d, _, files in os.walk(os.path.join(ROOT, "uhc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(d, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(d, f)
+    for f in os.listdir(os.path.join(ROOT, "uhc_amd", "csrc")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "oracle" not in open(os.path.join(ROOT, "uhc_amd", "csrc", f)).read().replace("the oracle", "").replace("and the oracle", ""), f
