@@ -167,3 +167,36 @@ def test_many_contacts_take_the_redo_path(model, ctrl, standing, kernel_path):
             np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-7)
             checked += 1
     assert max_nefc > 64 and checked > 0, f"scenario must exceed the fast kernel's capacity and stay inside the general one (max nefc={max_nefc}, checked={checked})"
+
+
+def test_per_env_models_share_one_batch(model, ctrl, standing, kernel_path):
+    """smpl_shape-style batch: envs with differently scaled bodies (mass ~ s^3, inertia ~ s^5) in one launch."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import scale_model
+    scales = [1.0, 0.9, 1.12]
+    models = [model] + [scale_model(model, s) for s in scales[1:]]
+    env_model = [0, 1, 2, 1, 0, 2]
+    n = len(env_model)
+    qpos, qvel = _states(standing, model, n, 9, noise=0.03, vel=0.1)
+    for e in range(n):
+        qpos[e, :3] *= scales[env_model[e]]
+    rng = np.random.default_rng(10)
+    act = rng.normal(scale=0.1, size=(n, ctrl.action_dim))
+    b = S.SimBatch(models, ctrl, n, env_model=env_model)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(models[env_model[e]], ctrl) for e in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    for t in range(10):
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:])
+    b.sync()
+    gq, gm = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QM).cpu().numpy()
+    for e in range(n):
+        np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-9)
+        np.testing.assert_allclose(gm[e], os_[e].get("qM"), atol=1e-9)
+    assert abs(gm[1, 0] / gm[0, 0] - 0.9 ** 3) < 1e-9  # total mass on the root translation scales with s^3

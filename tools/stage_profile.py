@@ -28,13 +28,17 @@ if __name__ == "__main__":
     os.environ["UHC_LIB"] = PROF_LIB
     import numpy as np
     import torch
-    import bench
     from uhc_amd import sim as S
     n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     model = S.load_asset_model()
     ctrl = S.make_ctrl(model)
-    qpos, qvel, actions = bench.make_inputs(model, ctrl, n_env, 1)
+    z = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))
+    rng = np.random.default_rng(1)
+    qpos = np.tile(z["qpos"], (n_env, 1))
+    qpos[:, 7:] += rng.normal(scale=0.05, size=(n_env, model.nu))
+    qvel = rng.normal(scale=0.1, size=(n_env, model.nv))
+    actions = rng.normal(scale=np.exp(-2.3), size=(8, n_env, ctrl.action_dim))
     b = S.SimBatch(model, ctrl, n_env)
     b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
     b.sync()

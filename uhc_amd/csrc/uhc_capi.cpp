@@ -390,7 +390,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.total = off;
         b->lds_bytes_fast = (size_t)off * sizeof(double);
         const char* env = getenv("UHC_FORCE_GENERAL");
-        b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024;
+        b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024 && T.nM <= 64 * 24 /* UHC_MREG register tile */;
     }
     HIP_OK(uhc_set_lds_limit(b->lds_bytes, b->lds_bytes_fast));
 
@@ -399,7 +399,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * T.nM, &S.qM_tmp)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
     TRY(dalloc(b, E, &S.overflow));

@@ -60,7 +60,7 @@ struct DevCtrl {
 };
 
 struct DevState {  // HBM, env-major
-    double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *qM_tmp, *bias, *ctrl, *applied;
+    double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)

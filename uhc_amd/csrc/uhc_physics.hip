@@ -121,6 +121,12 @@ __device__ __forceinline__ double max0(double x) {  // max(x, 0) without the can
     return r;
 }
 
+// FAST variant: the tree-sparse mass matrix of the last forward pass lives in registers between substeps
+// (entry e = LANE + 64 m), because the PD controller of the NEXT substep needs it (humanoid_im.py:1019-1022)
+// and the 40 KiB LDS budget only holds its factor.
+#define UHC_MREG 24
+struct MReg { double v[UHC_MREG]; };
+
 // ------------------------------------------------------------------ P1 kinematics
 // Pass 1 (all bodies in parallel): pose of each body relative to its parent frame, including its own
 // joint rotations (the expensive sincos work).  Pass 2 (level-synchronous): compose with the parent.
@@ -296,7 +302,7 @@ __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb,
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
 template <bool FAST>
-__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S) {
+__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, MReg& mr) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
@@ -319,15 +325,30 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
         for (int k = 0; k < 6; k++) S[L.cdofdot + 6 * i + k] = r[k];
     }
     wsync();
-    for (int e = LANE; e < T.nM; e += UHC_WAVE) {
-        const int i = T.m_row[e], j = T.m_col[e];
-        double a[6], c[6];
-        for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
-        double v = dot6(a, c);
-        if (i == j) v += mb[A.o.dof_armature + i];
-        S[L.M + e] = v;
-        if (FAST) A.s.qM_tmp[(size_t)blockIdx.x * T.nM + e] = v;  // FAST keeps no LDS copy of M (L.M aliases L.LD)
+#pragma unroll
+    for (int m = 0; m < UHC_MREG; m++) {
+        const int e = LANE + UHC_WAVE * m;
+        if (!FAST && m * UHC_WAVE >= T.nM) break;
+        double v = 0.0;
+        if (e < T.nM) {
+            const int i = T.m_row[e], j = T.m_col[e];
+            double a[6], c[6];
+            for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
+            v = dot6(a, c);
+            if (i == j) v += mb[A.o.dof_armature + i];
+            S[L.M + e] = v;
+        }
+        if (FAST) mr.v[m] = v;
     }
+    if (!FAST)
+        for (int e = LANE + UHC_WAVE * UHC_MREG; e < T.nM; e += UHC_WAVE) {  // models larger than the register tile (general kernel only)
+            const int i = T.m_row[e], j = T.m_col[e];
+            double a[6], c[6];
+            for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
+            double v = dot6(a, c);
+            if (i == j) v += mb[A.o.dof_armature + i];
+            S[L.M + e] = v;
+        }
     wsync();
 }
 
@@ -1190,7 +1211,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
 template <bool FAST>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC PROF_ARGS) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, MReg& mr PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     FwdOut out = {0, 0, 0, 0};
@@ -1198,7 +1219,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(1)
     k_com_pos<FAST>(A, mb, S);
     PROF(2)
-    k_crb<FAST>(A, mb, S);
+    k_crb<FAST>(A, mb, S, mr);
     PROF(3)
     if (!FAST) {
         for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
@@ -1277,7 +1298,7 @@ __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVA
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
 // previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
 template <bool FAST>
-__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const double* Mprev, const LaneConst& LC) {
+__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const MReg& mr, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
@@ -1288,8 +1309,13 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
         skp = clampd(action[nu + vf + it] + 1, 0, 10);
         skd = clampd(action[nu + vf + it + C.n_substeps] + 1, 0, 10);
     }
-    if (FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = Mprev[(size_t)blockIdx.x * T.nM + e];
-    else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    if (FAST) {
+#pragma unroll
+        for (int m = 0; m < UHC_MREG; m++) {
+            const int e = LANE + UHC_WAVE * m;
+            if (e < T.nM) S[L.LD + e] = mr.v[m];
+        }
+    } else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
     wsync();
     // lane owns dofs LANE and LANE+64; actuator a drives dof 6+a (free root first)
     double kp[2] = {0, 0}, kd[2] = {0, 0}, qe[2] = {0, 0}, qv[2] = {0, 0};
@@ -1379,20 +1405,26 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
     }
     const LaneConst LC = lane_const(T);
+    MReg mr;
+#pragma unroll
+    for (int m = 0; m < UHC_MREG; m++) {
+        const int e = LANE + UHC_WAVE * m;
+        mr.v[m] = (FAST && MODE == 0 && e < T.nM) ? A.s.qM[(size_t)env * T.nM + e] : 0.0;
+    }
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0;
     bool ran = false;
     PROF_DECL
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S, LC PROF_PASS);
+        fo = k_forward<FAST>(A, mb, S, LC, mr PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
         for (int it = 0; it < A.c.n_substeps; it++) {
-            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, ran ? A.s.qM_tmp : A.s.qM, LC);
+            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, mr, LC);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
                     S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
@@ -1405,7 +1437,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
-            fo = k_forward<FAST>(A, mb, S, LC PROF_PASS);
+            fo = k_forward<FAST>(A, mb, S, LC, mr PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && overflow) break;
@@ -1432,7 +1464,13 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     for (int i = LANE; i < T.nu; i += UHC_WAVE) A.s.ctrl[(size_t)env * T.nu + i] = S[L.ctrl + i];
     if (ran) {
         for (int i = LANE; i < T.nv; i += UHC_WAVE) A.s.bias[(size_t)env * T.nv + i] = S[L.bias + i];
-        if (FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = A.s.qM_tmp[(size_t)env * T.nM + e];
+        if (FAST) {
+#pragma unroll
+            for (int m = 0; m < UHC_MREG; m++) {
+                const int e = LANE + UHC_WAVE * m;
+                if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = mr.v[m];
+            }
+        }
         else for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
         for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
             A.s.xpos[(size_t)env * 3 * T.nbody + i] = S[L.xpos + i];

@@ -131,9 +131,45 @@ class Agent:
             v_next = self.value_net(self.trans_value(R.state[open_])).squeeze(-1)
             R.rewards[open_, T - 1] += self.gamma * v_next
             R.masks[open_, T - 1] = 0
+        self.sync_running_state()
         R.logger.add_steps(N, float(R.rewards.sum().item()), R.c_info_sum.cpu().numpy())
         R.logger.end_sampling()
         return RolloutBatch(R.states.reshape(N, -1), R.actions.reshape(N, -1), R.rewards.reshape(N, 1), R.masks.reshape(N, 1), R.exps.reshape(N), T), R.logger
+
+    def sync_running_state(self):
+        """Data-parallel runs: merge the observation-filter statistics of all ranks (Chan), so every rank
+        normalises with the same mean/std and rank 0's checkpoint holds the global filter."""
+        if self.running_state is None or not _dist_on():
+            return
+        rs = self.running_state.rs
+        dev = self.env.device if self.env is not None else torch.device("cpu")
+        mine = torch.cat([torch.tensor([float(rs.n)], dtype=torch.float64), torch.from_numpy(np.asarray(rs.mean, dtype=np.float64).ravel()),
+                          torch.from_numpy(np.asarray(rs._S, dtype=np.float64).ravel())]).to(dev)
+        if rs._stale:
+            mine = torch.cat([torch.tensor([float(rs.n)], dtype=torch.float64, device=dev), rs._dev[1].to(dev).ravel(), rs._dev[2].to(dev).ravel()])
+        allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, mine)
+        d = (mine.numel() - 1) // 2
+        base = getattr(self, "_rs_synced", None)  # statistics every rank already shares (from the previous merge)
+        n0, M0, S0 = (0.0, np.zeros(d), np.zeros(d)) if base is None else base
+        n, M, Sq = n0, M0.copy(), S0.copy()
+        for v in allv:  # add each rank's NEW samples: (rank stats) minus (shared base), merged pairwise
+            v = v.cpu().numpy()
+            nr, Mr, Sr = v[0], v[1:1 + d], v[1 + d:]
+            nb = nr - n0
+            if nb <= 0:
+                continue
+            mb = (nr * Mr - n0 * M0) / nb
+            delta0 = mb - M0
+            Sb = Sr - S0 - delta0 * delta0 * (n0 * nb / nr)
+            tot = n + nb
+            delta = mb - M
+            Sq = Sq + Sb + delta * delta * (n * nb / tot)
+            M = M + delta * (nb / tot)
+            n = tot
+        rs._dev, rs._stale = None, False
+        rs._n, rs._M[...], rs._S[...] = int(round(n)), M.reshape(rs._M.shape), Sq.reshape(rs._S.shape)
+        self._rs_synced = (float(rs._n), M.copy(), Sq.copy())
 
     def sample(self, min_batch_size):
         t0 = time.time()

@@ -857,3 +857,23 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
 def compile_mjcf_file(path: str) -> Model:
     with open(path) as f:
         return compile_mjcf(f.read(), os.path.dirname(os.path.abspath(path)))
+
+
+def scale_model(m: Model, s: float) -> Model:
+    """Uniformly scaled copy of a model (all lengths x s at constant density): body offsets, inertial frames, hull
+    vertices and bounding spheres scale with s, masses with s^3, inertias with s^5; the qpos0-derived constants are
+    recomputed.  Same topology, so scaled models can share one batch (per-env shapes)."""
+    o = m.copy()
+    for name in ("body_pos", "body_ipos", "jnt_pos", "geom_pos", "geom_center", "mesh_vert"):
+        setattr(o, name, getattr(m, name) * s)
+    o.geom_rbound = m.geom_rbound * s
+    o.body_mass = m.body_mass * s ** 3
+    o.body_inertia = m.body_inertia * s ** 5
+    o.qpos0 = m.qpos0.copy()
+    for j in range(m.njnt):
+        if m.jnt_type[j] == JNT_FREE:
+            a = m.jnt_qposadr[j]
+            o.qpos0[a:a + 3] = m.qpos0[a:a + 3] * s
+    o.qpos_spring = o.qpos0.copy()
+    set_const(o)
+    return o
