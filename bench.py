@@ -38,6 +38,8 @@ def parse():
     p.add_argument("--ppo-dtype", default="float64", choices=["float64", "float32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
+    p.add_argument("--same-device", action="store_true", help="plumbing check: every rank uses GPU 0")
     return p.parse_args()
 
 
@@ -80,13 +82,16 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
     torch.cuda.set_device(local)
     if dist_on:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(args.backend, rank=rank, world_size=world)
     dtype = torch.float64 if args.ppo_dtype == "float64" else torch.float32
     torch.set_default_dtype(dtype)
     import tempfile

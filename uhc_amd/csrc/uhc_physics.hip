@@ -1110,25 +1110,29 @@ __device__ __forceinline__ void commit_lane(double& f, double fn, double& imp, d
 // arithmetic a projected 1-D minimisation never raises the cost, and the guard would put five more
 // dependent instructions on the serial chain (the general kernel and the oracle keep it).
 template <int N, bool FRIC>
-__device__ __forceinline__ int pgs_sweeps(double (&Arow)[UHC_WAVE], double& f, double& res, double dinvA, double diag,
+__device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, double& u, double diag,
                                           bool fric, double floss, int iterations, double scale, double tolerance) {
+    // State per lane (= per row): f and u = f - res / A_rr, the unconstrained 1-D minimiser of the row.
+    // Brow[i] = A[r][i] / A[r][r] with a zero diagonal, so a change delta_i of row i moves every u by
+    // -delta_i * Brow[i] and leaves u_i itself unchanged.  Serial chain per row: max -> sub -> readlane -> FMA.
     int iters = 0;
     for (int it = 0; it < iterations; it++) {
         double improvement = 0;
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            double fn = fma(-res, dinvA, f);
+            double fn;
             if (FRIC) {
-                const double a = max0(fn), c = clampd(fn, -floss, floss);
+                const double a = max0(u), c = clampd(u, -floss, floss);
                 fn = fric ? c : a;
             } else {
-                fn = max0(fn);
+                fn = max0(u);
             }
             const double delta = fn - f;
-            const double term = -delta * fma(0.5 * delta, diag, res);
             const double di = bcast(delta, i);
+            // cost change of the step: delta * (1/2 delta A_rr + res), res = (f - u) A_rr   (off the serial chain)
+            const double term = -delta * diag * fma(0.5, delta, f - u);
             commit_lane<i>(f, fn, improvement, term);
-            res = fma(di, Arow[i], res);
+            u = fma(-di, Brow[i], u);
         });
         iters = it + 1;
         if (wave_sum(improvement) * scale < tolerance) break;
@@ -1170,20 +1174,25 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     double cost = valid ? f * (0.5 * (res - row.b) + row.b) : 0.0;
     cost = wave_sum(cost);
     if (cost > 0) { f = 0; res = row.b; }
+    double u = fma(-res, dinvA, f);
+    static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        Arow[s] = (s == LANE) ? 0.0 : Arow[s] * dinvA;  // Arow now holds Brow
+    });
     const double scale = 1.0 / (mb[A.o.meaninertia] * (T.nv > 1 ? T.nv : 1));
     const bool fric = row.type == ROW_FRICTION;
     const bool any_fric = wave_or(fric ? 1 : 0) != 0;
     int iters;
-    if (any_fric) iters = pgs_sweeps<UHC_WAVE, true>(Arow, f, res, dinvA, diag, fric, row.floss, T.iterations, scale, T.tolerance);
+    if (any_fric) iters = pgs_sweeps<UHC_WAVE, true>(Arow, f, u, diag, fric, row.floss, T.iterations, scale, T.tolerance);
     else switch ((nefc + 7) >> 3) {
-        case 1: iters = pgs_sweeps<8, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 2: iters = pgs_sweeps<16, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 3: iters = pgs_sweeps<24, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 4: iters = pgs_sweeps<32, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 5: iters = pgs_sweeps<40, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 6: iters = pgs_sweeps<48, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 7: iters = pgs_sweeps<56, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        default: iters = pgs_sweeps<64, false>(Arow, f, res, dinvA, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 1: iters = pgs_sweeps<8, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 2: iters = pgs_sweeps<16, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 3: iters = pgs_sweeps<24, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 4: iters = pgs_sweeps<32, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 5: iters = pgs_sweeps<40, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 6: iters = pgs_sweeps<48, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 7: iters = pgs_sweeps<56, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        default: iters = pgs_sweeps<64, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
     }
     row.f = f;
     PROF(11)
