@@ -23,9 +23,10 @@ if __name__ == "__main__":
     if "--build-only" in sys.argv:
         build()
         sys.exit(0)
-    if not os.path.exists(PROF_LIB):
-        build()
-    os.environ["UHC_LIB"] = PROF_LIB
+    if "UHC_LIB" not in os.environ:
+        if not os.path.exists(PROF_LIB):
+            build()
+        os.environ["UHC_LIB"] = PROF_LIB
     import numpy as np
     import torch
     from uhc_amd import sim as S

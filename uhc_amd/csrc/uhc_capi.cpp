@@ -338,7 +338,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
     L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
     L.M = carve(T.nM); L.LD = carve(T.nM); L.dinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
-    L.vec = carve(nv); L.z = carve(nv); L.eadr = carve((T.nM + 3) / 4 + 1);
+    L.vec = carve(nv); L.z = carve(nv); L.eadr = carve((T.nM + 3) / 4 + 1); L.zero = carve(2);
     L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
     L.Y = carve(UHC_MAXEFC * YS);
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
@@ -355,7 +355,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         off = 0;
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
         F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.vec = F.z;
-        F.eadr = carve((T.nM + 3) / 4 + 1);
+        F.eadr = carve((T.nM + 3) / 4 + 1); F.zero = carve(2);
         F.LD = carve(T.nM); F.M = F.LD;
         F.cdof = carve(6 * nv);
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);

@@ -47,7 +47,7 @@ struct DevLds {
     int qpos, qvel, qacc, ctrl, applied;
     int xpos, xquat, xmat, xipos, ximat, rootcom, cinert, crb, cvel, cacc, cfrc;
     int xanchor, xaxis, cdof, cdofdot;
-    int M, LD, dinv, bias, smooth, vec, z, eadr;
+    int M, LD, dinv, bias, smooth, vec, z, eadr, zero;
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
     int total;  // doubles
 };

@@ -121,6 +121,15 @@ __device__ __forceinline__ double max0(double x) {  // max(x, 0) without the can
     return r;
 }
 
+// compile-time loop: register arrays indexed by the loop variable stay in VGPRs
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // FAST variant: the tree-sparse mass matrix of the last forward pass lives in registers between substeps
 // (entry e = LANE + 64 m), because the PD controller of the NEXT substep needs it (humanoid_im.py:1019-1022)
 // and the 40 KiB LDS budget only holds its factor.
@@ -375,37 +384,65 @@ __device__ __forceinline__ int pk_of(const LaneConst& c, int i) {  // i wave-uni
 // Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t)
 // updates of one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.
 // eadr[e] (LDS, 16-bit) gives for the sparse entry e = (k, a-th ancestor) the row address of that ancestor.
+// One elimination step restricted to NP passes of 4 ancestors each, written as three straight-line phases so
+// that the LDS latencies overlap: (1) every load that depends only on k, (2) the ancestor-row loads (their
+// base addresses come from phase 1), (3) FMAs and predicated stores.  Idle lanes read a zero slot.
+template <int NP>
+__device__ __forceinline__ void factor_step(double* LD, const unsigned short* eadr, int zero, int kk, int dk, int tl, int al) {
+    int base[NP];
+    double f[NP], r0[NP], r1[NP], o0[NP], o1[NP];
+    const double Dk = LD[kk];
+    static_for<0, NP>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        const int a = 1 + 4 * p + al, n = dk - a + 1;
+        const bool va = a <= dk;
+        base[p] = eadr[va ? kk + a : kk];
+        f[p] = LD[va ? kk + a : zero];
+        r0[p] = LD[(va && tl < n) ? kk + a + tl : zero];
+        r1[p] = LD[(va && tl + 16 < n) ? kk + a + tl + 16 : zero];
+    });
+    static_for<0, NP>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        const int a = 1 + 4 * p + al, n = dk - a + 1;
+        const bool va = a <= dk;
+        o0[p] = LD[(va && tl < n) ? base[p] + tl : zero];
+        o1[p] = LD[(va && tl + 16 < n) ? base[p] + tl + 16 : zero];
+    });
+    const double inv = 1.0 / Dk;
+    static_for<0, NP>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        const int a = 1 + 4 * p + al, n = dk - a + 1;
+        const bool va = a <= dk;
+        const double fp = f[p] * inv;
+        if (va && tl < n) LD[base[p] + tl] = fma(-fp, r0[p], o0[p]);
+        if (va && tl + 16 < n) LD[base[p] + tl + 16] = fma(-fp, r1[p], o1[p]);
+        if (va && tl == 0) LD[kk + a] = fp;
+    });
+}
+
+// in-place L^T D L of the tree-sparse matrix at S[ld..]; also dinv[i] = 1/D[i].
+// Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t) updates of
+// one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.  eadr[e] (LDS, 16-bit)
+// gives for the sparse entry e = (k, a-th ancestor) the row address of that ancestor.  Row k itself is only
+// read during its step, except for its normalisation LD[kk+a] <- LD[kk+a] / D_k, which is stored after every
+// load of the step has been issued (lock-step), so one barrier per k suffices.
 template <bool FAST>
 __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     double* LD = S + ld;
     const unsigned short* eadr = (const unsigned short*)(S + L.eadr);
+    const int zero = L.zero - ld;  // index of the zero slot relative to LD
     const int tl = LANE & 15, al = LANE >> 4;
     for (int k = T.nv - 1; k >= 1; k--) {
         const int pk = pk_of(LC, k);
         const int dk = (pk >> 16) & 0xff;  // number of proper ancestors
         if (dk == 0) continue;
         const int kk = pk & 0xffff;
-        const double inv = 1.0 / LD[kk];
-        // Ancestor rows are updated from row k.  Passes go up the chain; inside a pass every lane loads
-        // before any lane stores (lock-step), and a pass only normalises the row-k entries it owns, which
-        // later passes never read -- so one barrier per k suffices.
-        for (int a0 = 1; a0 <= dk; a0 += 4) {
-            const int a = a0 + al;
-            if (a <= dk) {
-                const int n = dk - a + 1;  // entries in the ancestor's row
-                const int base = eadr[kk + a];
-                const double f = LD[kk + a] * inv;
-                const double r0 = tl < n ? LD[kk + a + tl] : 0.0;
-                const double r1 = tl + 16 < n ? LD[kk + a + tl + 16] : 0.0;
-                const double o0 = tl < n ? LD[base + tl] : 0.0;
-                const double o1 = tl + 16 < n ? LD[base + tl + 16] : 0.0;
-                if (tl < n) LD[base + tl] = o0 - f * r0;
-                if (tl + 16 < n) LD[base + tl + 16] = o1 - f * r1;
-                if (tl == 0) LD[kk + a] = f;
-            }
-        }
+        if (dk <= 8) factor_step<2>(LD, eadr, zero, kk, dk, tl, al);
+        else if (dk <= 16) factor_step<4>(LD, eadr, zero, kk, dk, tl, al);
+        else if (dk <= 24) factor_step<6>(LD, eadr, zero, kk, dk, tl, al);
+        else factor_step<8>(LD, eadr, zero, kk, dk, tl, al);
         wsync();
     }
     if (LC.v0) S[L.dinv + LANE] = 1.0 / LD[LC.m0];
@@ -424,8 +461,9 @@ __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, in
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const double* LD = S + ld;
+    const int zero = L.zero - ld;
     const int i0 = LANE, i1 = LANE + UHC_WAVE;
-    constexpr int U = 4;
+    constexpr int U = 8;
     if (!half) {
         // x <- L^-T x : for i descending, every ancestor j of i:  x[j] -= L[i][j] x[i]
         for (int ib = T.nv - 1; ib >= 1; ib -= U) {
@@ -437,9 +475,8 @@ __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, in
                 if (i >= 1) {
                     const int pk = pk_of(LC, i), mi = pk & 0xffff, di = (pk >> 16) & 0xff;
                     const bool c0 = LC.v0 && i > i0 && i <= i0 + LC.n0, c1 = LC.v1 && i > i1 && i <= i1 + LC.n1;
-                    const double t0 = LD[c0 ? mi + di - LC.d0 : 0], t1 = LD[c1 ? mi + di - LC.d1 : 0];
-                    l0[u] = c0 ? t0 : 0.0;
-                    l1[u] = c1 ? t1 : 0.0;
+                    l0[u] = LD[c0 ? mi + di - LC.d0 : zero];
+                    l1[u] = LD[c1 ? mi + di - LC.d1 : zero];
                 }
             }
 #pragma unroll
@@ -465,9 +502,8 @@ __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, in
             if (j < T.nv - 1) {
                 const int pk = pk_of(LC, j), dj = (pk >> 16) & 0xff, nj = (pk >> 24) & 0xff;
                 const bool c0 = LC.v0 && i0 > j && i0 <= j + nj, c1 = LC.v1 && i1 > j && i1 <= j + nj;
-                const double t0 = LD[c0 ? LC.m0 + LC.d0 - dj : 0], t1 = LD[c1 ? LC.m1 + LC.d1 - dj : 0];
-                l0[u] = c0 ? t0 : 0.0;
-                l1[u] = c1 ? t1 : 0.0;
+                l0[u] = LD[c0 ? LC.m0 + LC.d0 - dj : zero];
+                l1[u] = LD[c1 ? LC.m1 + LC.d1 - dj : zero];
             }
         }
 #pragma unroll
@@ -977,14 +1013,6 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
 // residual vector -- no reduction and no LDS traffic inside the sweep.
 struct FastRow { int type, last, len, yoff; double R, b, f, floss, diag; };
 
-// compile-time loop: keeps Arow[] indices constant so the array lives in VGPRs
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
     int x = v;
@@ -1413,6 +1441,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         const unsigned int* src = (const unsigned int*)T.e_adr;
         for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
     }
+    if (LANE == 0) S[L.zero] = 0.0;  // slot idle lanes read instead of branching around LDS loads
     const LaneConst LC = lane_const(T);
     MReg mr;
 #pragma unroll
