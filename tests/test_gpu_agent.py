@@ -76,3 +76,25 @@ def test_single_env_facade_matches_batched_env(tmp_path):
         assert info["percent"] == pytest.approx((t + 1) / (env.expert["len"] - 1))
     assert env.cur_t == 5 and 0 < total <= 5 and not done
     env.vec.close()
+
+
+def test_eval_policy_reports_reference_metrics(tmp_path):
+    import torch
+    from uhc_amd.agents import agent_dict
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path, n_env=8, batch=8 * 4)
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg, n=5))
+    agent.optimize_policy(0, save_model=False)
+    out = agent.eval_policy(0)
+    assert len(out) == 1
+    (name, m), = out[0].items()
+    assert name == "coverage_synthetic" and m["all_coverage"] == 5
+    for k in ("mpjpe", "mpjpe_g", "accel_dist", "vel_dist", "root_dist", "reward", "mean_coverage"):
+        assert np.isfinite(m[k]), k
+    assert 0.0 <= m["mean_coverage"] <= 1.0 and m["mpjpe"] >= 0
+    cov = agent.eval_seqs(agent.data_loader.data_keys[:2], agent.data_loader)
+    for k, res in cov.items():
+        T = agent.data_loader.get_sample_len_from_key(k)
+        assert res["pred"].shape[1] == 76 and 2 <= res["pred"].shape[0] == res["gt"].shape[0] and (res["fail_safe"] or res["pred"].shape[0] <= T + 1)
+        assert res["pred_jpos"].shape[1] == 72 and res["succ"].shape == (1,)
+    agent.env.close()

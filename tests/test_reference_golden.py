@@ -143,3 +143,12 @@ def test_oracle_pd_controller_and_rfc(model, ctrl):
     np.testing.assert_allclose(o.rfc_implicit(g["action"]), g["qfrc_applied"], atol=1e-12)
     np.testing.assert_allclose(np.array([ctrl.jkp[i] for i in range(69)]), g["jkp"])
     np.testing.assert_allclose(np.array([ctrl.torque_lim[i] for i in range(69)]), g["torque_lim"])
+
+
+def test_eval_metrics_match_reference():
+    from uhc_amd.smpllib.smpl_eval import compute_metrics
+    g = load("g11_metrics")
+    out = compute_metrics(dict(pred=g["pred"], gt=g["gt"], pred_jpos=g["pred_jpos"], gt_jpos=g["gt_jpos"], fail_safe=False, percent=1))
+    for k, v in out.items():
+        np.testing.assert_allclose(np.asarray(v, dtype=float), g["m_" + k], atol=1e-9, err_msg=k)
+    assert bool(out["succ"][0]) is True

@@ -296,12 +296,26 @@ def g7_g8_learner():
     save("g8_ppo_small", **arrs)
 
 
+def g11_metrics(dm, feat):
+    from uhc.smpllib.smpl_eval import compute_metrics
+    rng = np.random.default_rng(606)
+    T = 30
+    gt, gj = feat["qpos"][:T].copy(), feat["wbpos"][:T].copy()
+    pred = gt + rng.normal(scale=0.02, size=gt.shape)
+    pred[:, 3:7] /= np.linalg.norm(pred[:, 3:7], axis=1, keepdims=True)
+    pj = gj + rng.normal(scale=0.03, size=gj.shape)
+    res = dict(pred=pred, gt=gt, pred_jpos=pj, gt_jpos=gj, fail_safe=False, percent=1)
+    out = compute_metrics(res, None)
+    save("g11_metrics", pred=pred, gt=gt, pred_jpos=pj, gt_jpos=gj, **{("m_" + k): np.asarray(v) for k, v in out.items()})
+
+
 def main():
     g1_math()
     dm, qpos, feat = g2_g3_expert()
     g4_g6_obs_reward(dm, feat)
     g5_pd(dm, feat)
     g7_g8_learner()
+    g11_metrics(dm, feat)
 
 
 if __name__ == "__main__":

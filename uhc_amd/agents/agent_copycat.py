@@ -220,6 +220,122 @@ class AgentCopycat(AgentPPO):
                          f"\texpert_R_range ({log.min_c_reward:.4f}, {log.max_c_reward:.4f})\teps_len {log.avg_episode_len:.2f}")
 
 
+# ---- evaluation (agent_copycat.py:354-494), batched: one env per test clip --------------------------------
+def _eval_policy(self, epoch=0, dump=False):
+    from collections import defaultdict
+    cfg = self.cfg
+    res_dicts = []
+    names = ["mpjpe", "mpjpe_g", "accel_dist", "vel_dist", "succ", "reward", "root_dist", "pentration", "skate"]
+    for loader in self.test_data_loaders:
+        cov = self.eval_seqs(loader.data_keys, loader)
+        for k, res in cov.items():
+            if k in self.freq_dict:
+                self.freq_dict[k] += [[res["succ"][0], 0]] * (1 if res["succ"][0] else 3)
+        m = defaultdict(list)
+        for res in cov.values():
+            for k, v in res.items():
+                if k in names:
+                    m[k].append(v if np.ndim(v) == 0 else np.mean(v))
+        m = {k: float(np.mean(v)) for k, v in m.items()}
+        coverage = int(m["succ"] * loader.get_len())
+        self.logger.info(f"Coverage {loader.name} of {coverage} out of {loader.get_len()} | " + " \t".join(f"{k}: {v:.3f}" for k, v in m.items()))
+        m.update({"mean_coverage": coverage / loader.get_len(), "num_coverage": coverage, "all_coverage": loader.get_len()})
+        del m["succ"]
+        res_dicts.append({f"coverage_{loader.name}": m})
+        if dump:
+            import joblib
+            joblib.dump(cov, osp.join(cfg.output_dir, f"{epoch}_{loader.name}_coverage_full.pkl"))
+    return res_dicts
+
+
+@torch.no_grad()
+def _eval_seqs(self, take_keys, loader):
+    """Run the mean-action policy over whole clips (eval_seq, agent_copycat.py:438-494), all clips of a chunk at once."""
+    from ..smpllib.smpl_eval import compute_metrics
+    from .. import sim as S
+    cfg = self.cfg
+    take_keys = list(take_keys)
+    n = min(len(take_keys), cfg.n_env)
+    ev = getattr(self, "_eval_envs", {}).get((loader.name, n))
+    if ev is None:
+        ev = VecHumanoidEnv(cfg, n_env=n, device=self.env.device.index or 0, mode="test", model=self.env.model)
+        ev.set_clip_bank_from_loader(loader)
+        self._eval_envs = getattr(self, "_eval_envs", {})
+        self._eval_envs[(loader.name, n)] = ev
+    ev.set_rfc_rate(self.env.rfc_rate)
+    out = {}
+    frames, starts = ev.env._bank[0], ev.env._bank[1].cpu().numpy()
+    for c0 in range(0, len(take_keys), n):
+        keys = take_keys[c0:c0 + n]
+        m = len(keys)
+        ids = np.arange(m)
+        lens = np.array([loader.get_sample_len_from_key(k) for k in keys])
+        ev.assign(ids, keys, np.zeros(m, dtype=int), lens)
+        ev.reset(ids)
+        # the reference filters the reset observation with update=True (agent_copycat.py:445-446); kept
+        state = self.running_state(ev.obs[:m].to(self.dtype)) if self.running_state is not None else ev.obs[:m].to(self.dtype)
+        if m < n:
+            state = torch.cat([state, state.new_zeros(n - m, state.shape[1])])
+        active = torch.zeros(n, dtype=torch.int32, device=ev.device)
+        active[:m] = 1
+        rec = {k: [[] for _ in range(m)] for k in ("gt", "pred", "gt_jpos", "pred_jpos", "reward")}
+        fail_safe = np.zeros(m, dtype=bool)
+        alive = np.ones(m, dtype=bool)
+        clip0 = np.array([starts[ev._clip_index[k]] for k in keys])
+        t = np.zeros(m, dtype=int)
+
+        def snap():
+            q = ev.sim.field(S.F_QPOS)[:m].cpu().numpy()
+            x = ev.sim.field(S.F_XPOS)[:m].cpu().numpy()[:, 3:]
+            gi = clip0 + np.minimum(t, lens - 1)
+            g = frames[torch.from_numpy(gi).to(frames.device)].cpu().numpy()
+            for e in np.nonzero(alive)[0]:
+                rec["pred"][e].append(q[e]); rec["pred_jpos"][e].append(x[e])
+                rec["gt"][e].append(g[e, 0:76]); rec["gt_jpos"][e].append(g[e, 151:223])
+            return g
+
+        percent = np.zeros(m)
+        while alive.any():
+            snap()
+            action = self.policy_net.select_action(self.trans_policy(state), True).to(torch.float64).contiguous()
+            ev.step(action, active)
+            done = ev.done[:m].cpu().numpy().astype(bool) & alive
+            r = ev.reward[:m].cpu().numpy()
+            pct = ev.env.field(S.E_PERCENT)[:m].cpu().numpy()
+            for e in np.nonzero(alive)[0]:
+                rec["reward"][e].append(r[e])
+            if done.any():
+                q = ev.sim.field(S.F_QPOS)[:m].cpu().numpy()
+                x = ev.sim.field(S.F_XPOS)[:m].cpu().numpy()[:, 3:]
+                gi = clip0 + np.minimum(t, lens - 1)
+                g = frames[torch.from_numpy(gi).to(frames.device)].cpu().numpy()
+                tele = []
+                for e in np.nonzero(done)[0]:
+                    rec["pred"][e].append(q[e]); rec["pred_jpos"][e].append(x[e])
+                    rec["gt"][e].append(g[e, 0:76]); rec["gt_jpos"][e].append(g[e, 151:223])
+                    if cfg.fail_safe and pct[e] != 1:  # teleport to the expert state and keep going (humanoid_im.py:902-905)
+                        fail_safe[e] = True
+                        tele.append(e)
+                    else:
+                        alive[e] = False
+                        active[e] = 0
+                        percent[e] = pct[e]
+                if tele:
+                    tele = np.array(tele)
+                    cur = ev.cur_t[:m].cpu().numpy()[tele]
+                    fr = frames[torch.from_numpy(clip0[tele] + np.minimum(cur, lens[tele] - 1)).to(frames.device)]
+                    ev.sim.set_state(fr[:, 0:76].contiguous(), fr[:, 76:151].contiguous(), torch.from_numpy(tele).to(torch.int32))
+            t = t + 1
+            state = self.running_state(ev.obs.to(self.dtype), update=False) if self.running_state is not None else ev.obs.to(self.dtype)
+        for e, k in enumerate(keys):
+            res = {kk: np.vstack(v[e]) for kk, v in rec.items() if kk != "reward"}
+            res["reward"] = np.array(rec["reward"][e])
+            res["percent"], res["fail_safe"] = percent[e], bool(fail_safe[e])
+            res.update(compute_metrics(res, None))
+            out[k] = res
+    return out
+
+
 class CustomUnpickler(pickle.Unpickler):
     """Load reference checkpoints: their pickles name ZFilter/RunningStat under the reference's module paths
     (uhc/utils/tools.py:7-18 does the same renaming for its own history)."""
@@ -229,3 +345,7 @@ class CustomUnpickler(pickle.Unpickler):
             from ..khrylib.utils import zfilter
             return getattr(zfilter, name)
         return super().find_class(module, name)
+
+
+AgentCopycat.eval_policy = _eval_policy
+AgentCopycat.eval_seqs = _eval_seqs
