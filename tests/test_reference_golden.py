@@ -152,3 +152,66 @@ def test_eval_metrics_match_reference():
     for k, v in out.items():
         np.testing.assert_allclose(np.asarray(v, dtype=float), g["m_" + k], atol=1e-9, err_msg=k)
     assert bool(out["succ"][0]) is True
+
+
+# ---- G9: clip sampling (dataset_amass_single.py:27-317) ---------------------------------------------------
+def _g9_loader():
+    from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle
+    g = load("g9_dataset")
+    genders = ["neutral", "male", "female"]
+    pk = {}
+    for i in range(8):
+        pk[f"0-SYN_{i:02d}_poses"] = dict(pose_aa=g[f"in{i}_pose_aa"], pose_6d=g[f"in{i}_pose_6d"], trans=g[f"in{i}_trans"], beta=g[f"in{i}_beta"],
+                                          gender=genders[i % 3], seq_name=f"SYN_{i:02d}")
+    specs = dict(file_path="syn.pkl", test_file_path="syn.pkl", t_min=15, t_max=30, mode="all")
+    return g, list(pk.keys()), DatasetAMASSSingle(specs, "train", pickle_data=pk)
+
+
+def test_dataset_sampling_sequences_match_reference():
+    import random
+    g, keys, dl = _g9_loader()
+    assert [keys.index(k) for k in dl.data_keys] == g["data_keys"].tolist()
+    assert [keys.index(k) for k, _ in dl.sample_keys] == g["sample_keys"].tolist()
+    random.seed(3); np.random.seed(3)
+    rows = []
+    for _ in range(24):
+        s = dl.sample_seq(freq_dict=None)
+        rows.append([keys.index(dl.curr_key), dl.fr_start, dl.fr_end, s["pose_aa"].shape[0], s["beta"].shape[1], s["gender"][0], int(s["has_obj"]), s["num_obj"]])
+    np.testing.assert_array_equal(np.array(rows), g["uniform"])
+    np.testing.assert_array_equal(s["pose_aa"], g["uniform_first_pose"])
+    fd = {k: [] for k in dl.data_keys}
+    for ki, p, s0 in g["fd_flat"]:
+        fd[dl.data_keys[int(ki)]].append([float(p), int(s0)])
+    for name, prec in (("weighted", False), ("precision", True)):
+        random.seed(5); np.random.seed(5)
+        rows = []
+        for _ in range(24):
+            dl.sample_seq(freq_dict=fd, sampling_temp=0.2, sampling_freq=0.5, precision_mode=prec)
+            rows.append([keys.index(dl.curr_key), dl.fr_start, dl.fr_end])
+        np.testing.assert_array_equal(np.array(rows), g[name], err_msg=name)
+    s = dl.get_sample_from_key(dl.data_keys[2], full_sample=True)
+    np.testing.assert_array_equal([dl.fr_start, dl.fr_end, s["pose_aa"].shape[0]], g["full"])
+    s = dl.get_sample_from_key(dl.data_keys[0], fr_start=7)
+    np.testing.assert_array_equal([dl.fr_start, dl.fr_end, s["pose_aa"].shape[0]], g["fixed_start"])
+    np.testing.assert_array_equal([keys.index(dl.iter_seq()["seq_name"]) for _ in range(8)], g["iter"])
+
+
+# ---- G10: configuration parsing (copycat_config.py:12-168, base_config.py:9-62) ----------------------------
+def test_config_attributes_match_reference(tmp_path):
+    import json
+    from uhc_amd.utils.config_utils.copycat_config import Config
+    g = load("g10_config")
+    ids = sorted({k.split("__")[0] for k in g.files})
+    assert len(ids) == 7
+    for cid in ids:
+        cfg = Config(cfg_id=cid, base_dir=str(tmp_path), cfg_dict=json.loads(str(g[f"{cid}__yml"])))
+        want = json.loads(str(g[f"{cid}__scalars"]))
+        assert want.pop("adv_clip_is_inf") == bool(np.isinf(cfg.adv_clip))
+        for k, v in want.items():
+            assert getattr(cfg, k) == v, (cid, k)
+        for k in g.files:
+            if k.startswith(cid + "__") and k.split("__")[1] not in ("yml", "scalars", "adaptive"):
+                np.testing.assert_allclose(np.asarray(getattr(cfg, k.split("__")[1]), dtype=float), g[k], rtol=0, atol=0, err_msg=k)
+        for it, nr, ls, lr in g[f"{cid}__adaptive"]:
+            cfg.update_adaptive_params(int(it))
+            np.testing.assert_allclose([cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr], [nr, ls, lr], rtol=1e-15, atol=0)

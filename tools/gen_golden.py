@@ -309,6 +309,106 @@ def g11_metrics(dm, feat):
     save("g11_metrics", pred=pred, gt=gt, pred_jpos=pj, gt_jpos=gj, **{("m_" + k): np.asarray(v) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------- G9 clip sampling
+def synth_pickle(rng):
+    """8 small clips: mixed lengths (one below t_min+1), beta 10/16 wide, three genders."""
+    pk = {}
+    lens = [70, 25, 41, 16, 55, 33, 90, 12]
+    for i, T in enumerate(lens):
+        pk[f"0-SYN_{i:02d}_poses"] = dict(pose_aa=rng.normal(size=(T, 72)) * 0.1, pose_6d=np.zeros((T, 144)), trans=rng.normal(size=(T, 3)),
+                                          beta=rng.normal(size=(T, 10)) if i % 2 else rng.normal(size=(16,)), gender=["neutral", "male", "female"][i % 3], seq_name=f"SYN_{i:02d}")
+    return pk
+
+
+def g9_dataset():
+    import random
+    import tempfile
+    import joblib
+    from uhc.data_loaders.dataset_amass_single import DatasetAMASSSingle
+    rng = np.random.default_rng(9)
+    pk = synth_pickle(rng)
+    d = tempfile.mkdtemp()
+    joblib.dump(pk, os.path.join(d, "syn.pkl"))
+    specs = dict(file_path=os.path.join(d, "syn.pkl"), test_file_path=os.path.join(d, "syn.pkl"), t_min=15, t_max=30, mode="all",
+                 neutral_path=os.path.join(REF, "sample_data/standing_neutral.pkl"))
+    dl = DatasetAMASSSingle(specs, "train")
+    keys = list(pk.keys())
+    out = {"n_data_keys": len(dl.data_keys), "data_keys": np.array([keys.index(k) for k in dl.data_keys]),
+           "sample_keys": np.array([keys.index(k) for k, _ in dl.sample_keys])}
+    for i, k in enumerate(keys):
+        for f in ("pose_aa", "pose_6d", "trans", "beta"):
+            out[f"in{i}_{f}"] = pk[k][f]
+    # (a) uniform mode
+    random.seed(3); np.random.seed(3)
+    seq = []
+    for _ in range(24):
+        s = dl.sample_seq(freq_dict=None)
+        seq.append([keys.index(dl.curr_key), dl.fr_start, dl.fr_end, s["pose_aa"].shape[0], s["beta"].shape[1], s["gender"][0], int(s["has_obj"]), s["num_obj"]])
+    out["uniform"] = np.array(seq)
+    out["uniform_first_pose"] = s["pose_aa"]
+    # (b) success-weighted mode with a filled freq_dict, (c) precision mode
+    frng = np.random.default_rng(4)
+    fd = {k: [[float(frng.random() < 0.6) if frng.random() < 0.8 else float(frng.random()), int(frng.integers(0, 10))] for _ in range(int(frng.integers(0, 9)))] for k in dl.data_keys}
+    out["fd_flat"] = np.array([[dl.data_keys.index(k), p, s0] for k, v in fd.items() for p, s0 in v])
+    for name, prec in (("weighted", False), ("precision", True)):
+        random.seed(5); np.random.seed(5)
+        seq = []
+        for _ in range(24):
+            dl.sample_seq(freq_dict=fd, sampling_temp=0.2, sampling_freq=0.5, precision_mode=prec)
+            seq.append([keys.index(dl.curr_key), dl.fr_start, dl.fr_end])
+        out[name] = np.array(seq)
+    s = dl.get_sample_from_key(dl.data_keys[2], full_sample=True)
+    out["full"] = np.array([dl.fr_start, dl.fr_end, s["pose_aa"].shape[0]])
+    s = dl.get_sample_from_key(dl.data_keys[0], fr_start=7)
+    out["fixed_start"] = np.array([dl.fr_start, dl.fr_end, s["pose_aa"].shape[0]])
+    out["iter"] = np.array([keys.index(dl.iter_seq()["seq_name"]) for _ in range(8)])
+    save("g9_dataset", **out)
+
+
+# --------------------------------------------------------------------------- G10 configs
+def g10_config():
+    import json
+    import tempfile
+    import yaml
+    import glob
+    from uhc.utils.config_utils.copycat_config import Config
+    ids = ["uhc_implicit", "uhc_implicit_shape", "uhc_explicit", "copycat_ball_1", "copycat_40", "copycat_44"]
+    scalars = ["gamma", "tau", "policy_htype", "policy_hsize", "policy_lr", "value_htype", "value_hsize", "value_lr", "clip_epsilon", "log_std", "fix_std",
+               "num_optim_epoch", "min_batch_size", "mini_batch_size", "save_n_epochs", "reward_id", "reward_weights", "end_reward", "actor_type",
+               "env_start_first", "env_init_noise", "env_episode_len", "env_term_body", "env_expert_trail_steps", "obs_v", "obs_type", "obs_coord",
+               "obs_phase", "obs_heading", "obs_vel", "root_deheading", "action_type", "action_v", "reactive_v", "no_root", "reactive_rate",
+               "sampling_temp", "sampling_freq", "residual_force", "residual_force_scale", "residual_force_lim", "residual_force_mode",
+               "residual_force_bodies", "residual_force_torque", "rfc_decay", "meta_pd", "meta_pd_joint", "masterfoot", "fail_safe", "robot_cfg",
+               "has_shape", "agent_name", "model_name", "seed", "notes", "num_epoch", "proj_name", "num_primitive", "composer_dim", "data_specs", "lr",
+               "eval_n_epochs", "num_samples", "batch_size"]
+    arrays = ["adp_iter_cp", "adp_noise_rate_cp", "adp_log_std_cp", "adp_policy_lr_cp", "jkp", "jkd", "a_ref", "a_scale", "torque_lim", "b_diffw", "jpos_diffw"]
+    out = {}
+    for cid in ids + ["synthetic_adaptive"]:
+        if cid == "synthetic_adaptive":  # none of the shipped configs has a multi-point schedule; exercise update_adaptive_params
+            f, = glob.glob(os.path.join(REF, "config/**/uhc_implicit_shape.yml"), recursive=True)
+            cd = yaml.safe_load(open(f))
+            cd.update(adp_iter_cp=[0, 100, 1000, 5000], adp_noise_rate_cp=[1.0, 0.5], adp_log_std_cp=[-2.3, -3.0, -3.5], adp_policy_lr_cp=[5e-5, 1e-5])
+        else:
+            f, = glob.glob(os.path.join(REF, f"config/**/{cid}.yml"), recursive=True)
+            cd = yaml.safe_load(open(f))
+        out[f"{cid}__yml"] = np.array(json.dumps(cd))
+        base = tempfile.mkdtemp()  # results/ dirs are created under base_dir; assets are found through a link
+        os.symlink(os.path.join(REF, "assets"), os.path.join(base, "assets"))
+        cfg = Config(cfg_id=cid, base_dir=base, cfg_dict=json.loads(json.dumps(cd)))
+        dump = {k: getattr(cfg, k) for k in scalars if hasattr(cfg, k)}
+        dump["adv_clip_is_inf"] = bool(np.isinf(cfg.adv_clip))
+        out[f"{cid}__scalars"] = np.array(json.dumps(dump))
+        for k in arrays:
+            if hasattr(cfg, k):
+                out[f"{cid}__{k}"] = np.asarray(getattr(cfg, k), dtype=np.float64)
+        ad = []
+        for it in (0, 1, 50, 499, 1000, 2500, 5000, 20000):
+            cfg.update_adaptive_params(it)
+            ad.append([it, cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr])
+        out[f"{cid}__adaptive"] = np.array(ad, dtype=np.float64)
+    save("g10_config", **out)
+
+
 def main():
     g1_math()
     dm, qpos, feat = g2_g3_expert()
@@ -316,6 +416,8 @@ def main():
     g5_pd(dm, feat)
     g7_g8_learner()
     g11_metrics(dm, feat)
+    g9_dataset()
+    g10_config()
 
 
 if __name__ == "__main__":

@@ -209,6 +209,7 @@ class AgentCopycat(AgentPPO):
         info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
         if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0:
             self.save_checkpoint(epoch)
+            info["log_eval"] = self.eval_policy(epoch)
         self.log_train(info)
         return info
 

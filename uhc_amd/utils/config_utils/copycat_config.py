@@ -71,6 +71,18 @@ class Config(Base_Config):
         if len(self.robot_cfg) == 0:
             self.robot_cfg = {"model": "smpl", "mesh": "mesh" in self.mujoco_model_file}
         self.has_shape = g("has_shape", False)
+        # explicit gain / body-weight tables (copycat_config.py:128-145; parsed, though HumanoidEnv.load_models takes SMPLConverter's)
+        if "joint_params" in c:
+            jp = [np.array(p) for p in zip(*c["joint_params"])]
+            self.jkp, self.jkd, self.a_ref, self.a_scale, self.torque_lim = jp[1:6]
+            self.a_ref = np.deg2rad(self.a_ref)
+            kpm = g("jkp_multiplier", 1.0)
+            self.jkp = self.jkp * kpm
+            self.jkd = self.jkd * g("jkd_multiplier", kpm)
+            self.torque_lim = self.torque_lim * g("torque_limit_multiplier", 1.0)
+        if "body_params" in c:
+            self.b_diffw = [np.array(p) for p in zip(*c["body_params"])][1]
+            self.jpos_diffw = np.concatenate([[1], self.b_diffw])
         self.agent_name, self.model_name = g("agent_name", "agent_copycat"), g("model_name", "super_net")
         # batched-env knobs of this build (not in the reference)
         self.n_env = g("n_env", 1024)
