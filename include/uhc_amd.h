@@ -172,19 +172,19 @@ typedef struct UhcEnv UhcEnv;
 
 /* constants of HumanoidEnv (uhc/envs/humanoid_im.py) and of the reward (uhc/losses/reward_function.py:12-36) */
 typedef struct UhcEnvDesc {
-    int32_t obs_v;               /* 2 (get_full_obs_v2, humanoid_im.py:419-503) */
+    int32_t obs_v;               /* 2: get_full_obs_v2 (humanoid_im.py:419-503); 1: get_full_obs_v1 (:323-417); 6: get_full_obs_v6 (:596-666) */
     int32_t has_shape;           /* append beta(16) + gender to the observation (humanoid_im.py:1390-1406) */
     int32_t env_episode_len;     /* cfg.env_episode_len */
     int32_t env_expert_trail_steps;
     int32_t ee_body[5];          /* model body ids of SMPL_EE_NAMES (smpl_parser.py:228) */
-    int32_t _pad;
+    int32_t reward_v;            /* 0: world_rfc_implicit_reward (reward_function.py:12-88); 1: world_rfc_explicit_reward (:253-341) */
     double body_diff_thresh;     /* humanoid_im.py:88-89 */
     double reward_weights[10];   /* w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf */
     const double* jpos_diffw;    /* [nbody-1] SMPLConverter.get_new_diff_weight() (host) */
 } UhcEnvDesc;
 
 /* expert frame record layout of the clip bank (doubles; see uhc_amd/csrc/uhc_device_env.h) */
-#define UHC_FRAME_STRIDE 512
+#define UHC_FRAME_STRIDE 584
 
 enum UhcEnvField {
     UHC_E_OBS = 0,          /* [n_env][obs_dim] */

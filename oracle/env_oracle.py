@@ -81,6 +81,84 @@ def full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, 
     return np.concatenate(obs)
 
 
+def full_obs_v1(qpos, qvel, xpos, xquat, xipos, expert, cur_t, start_ind=0, base_rot=BASE_ROT):
+    """humanoid_im.py:323-417: the v2 blocks plus current / difference body-COM positions before the quaternions; no shape."""
+    v2 = full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t, start_ind, None, None, base_rot)
+    nb = xpos.shape[0] - 1
+    ind = expert_index(cur_t + 1, start_ind, expert["len"])
+    curr_root_quat = remove_base_rot(qpos[3:7], base_rot)
+    curr_com = xipos[1:].copy()
+    r_com = transform_vec_batch(curr_com - qpos[None, :3], curr_root_quat, "root")
+    diff_com = transform_vec_batch(expert["body_com"][ind].reshape(-1, 3) - curr_com, curr_root_quat, "root")
+    cut = 304 + 6 * nb
+    return np.concatenate([v2[:cut], r_com.ravel(), diff_com.ravel(), v2[cut:]])
+
+
+def get_heading_new(q):
+    return math.atan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] * q[2] + q[3] * q[3]))  # math_utils.py:185-190
+
+
+def _rot_of(q):
+    n = np.dot(q, q)
+    w, x, y, z = q * math.sqrt(2.0 / n)
+    return np.array([[1 - y * y - z * z, x * y - z * w, x * z + y * w], [x * y + z * w, 1 - x * x - z * z, y * z - x * w],
+                     [x * z - y * w, y * z + x * w, 1 - x * x - y * y]])
+
+
+def full_obs_v6(qpos, qvel, xpos, expert, cur_t, start_ind=0, beta=None, gender=None, base_rot=BASE_ROT):
+    """humanoid_im.py:596-666 (obs_vel='full'), incl. the [1:] slice of the transposed current-joint block (:645)."""
+    qvel = qvel.copy()
+    curr_root_quat = remove_base_rot(qpos[3:7], base_rot)
+    yaw = get_heading_new(curr_root_quat)
+    hq = np.array([math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)])
+    R = _rot_of(hq)
+    ind = expert_index(cur_t + 1, start_ind, expert["len"])
+    target_qpos = expert["qpos"][ind]
+    target_jpos = expert["wbpos"][ind].reshape(-1, 3)
+    target_root_quat = remove_base_rot(target_qpos[3:7], base_rot)
+    rel_h = get_heading_new(target_root_quat) - yaw
+    if rel_h > np.pi:
+        rel_h -= 2 * np.pi
+    if rel_h < -np.pi:
+        rel_h += 2 * np.pi
+    obs = [(target_qpos[:3] - qpos[:3]) @ R, np.array([rel_h]), quaternion_multiply(target_root_quat, quaternion_inverse(curr_root_quat))]
+    qvel[:3] = qvel[:3] @ R
+    obs.append(qvel)
+    curr_jpos = xpos[1:]
+    obs.append((R.T @ (curr_jpos - qpos[None, :3]).T)[1:].ravel())
+    obs.append((R.T @ (target_jpos - curr_jpos)[1:].T).ravel())
+    target_bquat = expert["bquat"][ind].reshape(-1, 4)[1:]
+    cur_bquat = get_body_quat(qpos).reshape(-1, 4)[1:]
+    obs.append(cur_bquat.ravel())
+    obs.append(quaternion_multiply_batch(quaternion_inverse_batch(cur_bquat), target_bquat).ravel())
+    if beta is not None:
+        obs += [beta, [gender]]
+    return np.concatenate(obs)
+
+
+def world_rfc_explicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur_t, start_ind, dt, body_diffw, w, ndof=69, n_vf_bodies=24, body_vf_dim=9):
+    """reward_function.py:253-341 (non-cyclic expert): unweighted velocity term, per-body force/torque penalty."""
+    ind = expert_index(cur_t, start_ind, expert["len"])
+    cur_ee = xpos[EE_BODY_IDS].ravel()
+    cur_bquat = get_body_quat(qpos)
+    cur_bangvel = get_angvel_fd(prev_bquat, cur_bquat, dt)
+    e_ee, e_com = expert["ee_wpos"][ind], expert["com"][ind]
+    e_bquat, e_bangvel = expert["bquat"][ind], expert["bangvel"][ind]
+    if start_ind + cur_t >= expert["len"]:
+        e_bangvel = np.zeros_like(e_bangvel)
+    pose_diff = multi_quat_norm(multi_quat_diff(cur_bquat, e_bquat))
+    pose_diff[1:] *= body_diffw
+    pose_r = math.exp(-w["k_p"] * np.linalg.norm(pose_diff) ** 2)
+    vel_r = math.exp(-w["k_v"] * np.linalg.norm(cur_bangvel - e_bangvel) ** 2)
+    ee_r = math.exp(-w["k_e"] * np.linalg.norm(cur_ee - e_ee) ** 2)
+    com_r = math.exp(-w["k_c"] * np.linalg.norm(xipos[1] - e_com) ** 2)
+    vf = action[ndof:ndof + n_vf_bodies * body_vf_dim].reshape(n_vf_bodies, body_vf_dim)
+    vf_r = math.exp(-w["k_vf"] * float((vf[:, 3:] ** 2).sum()))
+    parts = np.array([pose_r, vel_r, ee_r, com_r, vf_r])
+    ws = np.array([w["w_p"], w["w_v"], w["w_e"], w["w_c"], w["w_vf"]])
+    return float((ws * parts).sum() / ws.sum()), parts
+
+
 def world_rfc_implicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur_t, start_ind, dt, body_diffw, w, ndof=69, vf_dim=6):
     """reward_function.py:12-88.  `w` is the reward_weights dict; returns (reward, 5 components)."""
     ind = expert_index(cur_t, start_ind, expert["len"])

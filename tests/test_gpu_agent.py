@@ -36,7 +36,9 @@ def test_agent_iteration_and_checkpoint_roundtrip(tmp_path):
     info = agent.optimize_policy(0)
     log = info["log"]
     assert log.num_steps == 64 * 8 and 0.0 < log.avg_c_reward <= 1.0 and np.isfinite(log.avg_c_info).all()
-    assert agent.running_state.rs.n == 64 * 9  # reset observation + 8 steps per env
+    # reset observation + 8 steps per env, + one reset observation per evaluated clip (eval runs after the checkpoint is
+    # written and filters its first observation with update=True, agent_copycat.py:445-446)
+    assert agent.running_state.rs.n == 64 * 9 + 6
     changed = [k for k, v in agent.policy_net.state_dict().items() if not torch.equal(v, before[k])]
     assert "action_mean.weight" in changed and "action_log_std" not in changed  # fix_std
     # standing clips + noise actions: nothing blows up

@@ -27,12 +27,12 @@ def _window(e, start, n, model=None):
     return w
 
 
-def _make(model, ctrl, n_env, expert, beta):
+def _make(model, ctrl, n_env, expert, beta, obs_v=2, reward_v=0, has_shape=True):
     import torch
     from uhc_amd import sim as S
     from uhc_amd._capi import env_desc
     sb = S.SimBatch(model, ctrl, n_env)
-    eb = S.EnvBatch(sb, env_desc(model, has_shape=True, reward_weights=REWARD_W))
+    eb = S.EnvBatch(sb, env_desc(model, obs_v=obs_v, has_shape=has_shape, reward_weights=REWARD_W, reward_v=reward_v))
     frames = S.pack_expert_frames(expert)
     frames2 = np.concatenate([frames, frames[::-1].copy()])  # clip 1 = clip 0 reversed (only a second id to address)
     clip_start = torch.tensor([0, frames.shape[0]], dtype=torch.int32)
@@ -41,7 +41,17 @@ def _make(model, ctrl, n_env, expert, beta):
     return sb, eb
 
 
-def test_env_rollout_matches_oracles(model, ctrl):
+def _oracle_obs(E, obs_v, o, w, t, beta):
+    xpos, xquat, xipos = o.get("xpos").reshape(-1, 3), o.get("xquat").reshape(-1, 4), o.get("xipos").reshape(-1, 3)
+    if obs_v == 1:
+        return E.full_obs_v1(o.get("qpos"), o.get("qvel"), xpos, xquat, xipos, w, t, 0)
+    if obs_v == 6:
+        return E.full_obs_v6(o.get("qpos"), o.get("qvel"), xpos, w, t, 0, beta, 2.0)
+    return E.full_obs_v2(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)
+
+
+@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1)])
+def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     import torch
     from oracle import env_oracle as E
     from oracle.physics import OracleSim
@@ -51,7 +61,7 @@ def test_env_rollout_matches_oracles(model, ctrl):
     rng = np.random.default_rng(11)
     beta = rng.normal(size=16)
     n = 4
-    sb, eb = _make(model, ctrl, n, expert, beta)
+    sb, eb = _make(model, ctrl, n, expert, beta, obs_v, reward_v, has_shape=obs_v != 1)
     starts, lens = np.array([0, 3, 10, 20]), np.array([40, 30, 25, 12])
     ids = torch.arange(n, dtype=torch.int32)
     eb.assign(ids, torch.zeros(n, dtype=torch.int32), torch.from_numpy(starts), torch.from_numpy(lens))
@@ -70,10 +80,8 @@ def test_env_rollout_matches_oracles(model, ctrl):
     # ---- reset observation
     gobs = eb.field(S.E_OBS).cpu().numpy()
     for e in range(n):
-        ref = E.full_obs_v2(os_[e].get("qpos"), os_[e].get("qvel"), os_[e].get("xpos").reshape(-1, 3), os_[e].get("xquat").reshape(-1, 4),
-                            wins[e], 0, 0, beta, 2.0)
-        np.testing.assert_allclose(gobs[e], ref, atol=1e-11)
-    assert eb.obs_dim == 657
+        np.testing.assert_allclose(gobs[e], _oracle_obs(E, obs_v, os_[e], wins[e], 0, beta), atol=1e-11)
+    assert eb.obs_dim == {2: 657, 1: 784, 6: 401}[obs_v]
     # ---- steps
     cur_t = np.zeros(n, dtype=int)
     alive = np.ones(n, dtype=bool)
@@ -99,8 +107,12 @@ def test_env_rollout_matches_oracles(model, ctrl):
             bd = E.calc_body_diff(xpos, w["wbpos"][E.expert_index(cur_t[e], 0, w["len"])], jw)
             fail = bool(o.geti("fail")) or bd > 0.5
             end = cur_t[e] >= 100000 or cur_t[e] >= w["len"] - 1
-            r, parts = E.world_rfc_implicit_reward(o.get("qpos"), xpos, xipos, prev_bquat, act[e], w, cur_t[e], 0, model.timestep * 15, jw[1:], REWARD_W)
-            obs = E.full_obs_v2(o.get("qpos"), o.get("qvel"), xpos, xquat, w, cur_t[e], 0, beta, 2.0)
+            if reward_v == 1:  # the explicit reward reads 24 x 9 residual entries; this controller's action carries 6 + 30 after the joints
+                r, parts = E.world_rfc_explicit_reward(o.get("qpos"), xpos, xipos, prev_bquat, np.r_[act[e][:75], np.zeros(300)], w, cur_t[e], 0,
+                                                       model.timestep * 15, jw[1:], REWARD_W)
+            else:
+                r, parts = E.world_rfc_implicit_reward(o.get("qpos"), xpos, xipos, prev_bquat, act[e], w, cur_t[e], 0, model.timestep * 15, jw[1:], REWARD_W)
+            obs = _oracle_obs(E, obs_v, o, w, cur_t[e], beta)
             assert (bool(gfail[e]), bool(gend[e]), bool(gdone[e])) == (fail, end, fail or end)
             assert gpct[e] == pytest.approx(cur_t[e] / (w["len"] - 1), abs=1e-14)
             assert grew[e] == pytest.approx(r, abs=1e-9)

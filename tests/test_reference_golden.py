@@ -121,6 +121,27 @@ def test_env_oracle_observation_reward_termination(model):
         np.testing.assert_allclose(parts, g[p + "reward_info"], atol=1e-12)
 
 
+def test_env_oracle_obs_v1_v6_and_explicit_reward(model):
+    from oracle import env_oracle as E
+    from uhc_amd.smpllib.smpl_mujoco import SMPLConverter
+    g, f = load("g4b_obs_variants"), load("g3_qpos_fk")
+    expert = expert_from(f)
+    jw = SMPLConverter(model, model).get_new_diff_weight()
+    for c in range(int(g["ncase"])):
+        p = f"c{c}_"
+        t = int(g[p + "cur_t"])
+        o1 = E.full_obs_v1(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], g[p + "xquat"], g[p + "xipos"], expert, t, 0)
+        assert o1.shape == (784,)
+        np.testing.assert_allclose(o1, g[p + "obs_v1"], atol=1e-13)
+        o6 = E.full_obs_v6(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], expert, t, 0, g[p + "beta"], float(g["gender"]))
+        assert o6.shape == (401,)
+        np.testing.assert_allclose(o6, g[p + "obs_v6"], atol=1e-13)
+        r, parts = E.world_rfc_explicit_reward(g[p + "qpos"], g[p + "xpos"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"], expert,
+                                               t, 0, model.timestep * 15, jw[1:], REWARD_W)
+        assert r == pytest.approx(float(g[p + "reward_explicit"]), abs=1e-13)
+        np.testing.assert_allclose(parts, g[p + "reward_explicit_info"], atol=1e-12)
+
+
 def test_oracle_pd_controller_and_rfc(model, ctrl):
     """compute_torque / compute_desired_accel / rfc_implicit of the reference vs the C oracle."""
     from oracle.physics import OracleSim

@@ -209,6 +209,38 @@ def g4_g6_obs_reward(dm, feat):
     cases["gender"] = env.expert["gender"][0]
     cases["ncase"] = 4
     save("g4_g6_obs_reward", **cases)
+    g4b_obs_variants(dm, feat)
+
+
+def g4b_obs_variants(dm, feat):
+    """Observation v1 / v6 and the explicit-RFC reward on the same kind of synthetic env state (own rng stream)."""
+    from uhc.envs.humanoid_im import HumanoidEnv
+    from uhc.losses.reward_function import world_rfc_explicit_reward
+    rng = np.random.default_rng(909)
+    cases = {}
+    for c, cur_t in enumerate([2, 11, 38]):
+        env = fake_env(dm, feat, rng, cur_t=cur_t)
+        env.cc_cfg.update(obs_v=1)
+        obs1 = HumanoidEnv.get_full_obs_v1(env)
+        obs6 = HumanoidEnv.get_full_obs_v6(env)
+        prev_q = env.data.qpos.copy()
+        prev_q[7:] -= rng.normal(scale=0.02, size=69)
+        save_q = env.data.qpos
+        env.data.qpos = prev_q
+        env.prev_bquat = HumanoidEnv.get_body_quat(env)
+        env.data.qpos = save_q
+        env.vf_bodies = list(dm.body_names[1:])
+        env.body_vf_dim, env.vf_dim = 9, 24 * 9
+        action = rng.normal(scale=0.1, size=69 + 216 + 30)
+        r, rinfo = world_rfc_explicit_reward(env, None, action, None)
+        pre = f"c{c}_"
+        cases.update({pre + "cur_t": cur_t, pre + "qpos": env.data.qpos, pre + "qvel": env.data.qvel, pre + "xpos": env.data.body_xpos,
+                      pre + "xquat": env.data.body_xquat, pre + "xipos": env.data.xipos, pre + "obs_v1": obs1, pre + "obs_v6": obs6,
+                      pre + "prev_bquat": env.prev_bquat, pre + "action": action, pre + "reward_explicit": r, pre + "reward_explicit_info": rinfo, pre + "beta": env.expert["beta"][0]})
+    cases["beta"] = env.expert["beta"][0]
+    cases["gender"] = env.expert["gender"][0]
+    cases["ncase"] = 3
+    save("g4b_obs_variants", **cases)
 
 
 # --------------------------------------------------------------------------- G5 stable PD + implicit residual force

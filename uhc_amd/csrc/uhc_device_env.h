@@ -3,7 +3,7 @@
 #include <stdint.h>
 
 // one expert frame = UHC_FRAME_STRIDE doubles (features of Humanoid.qpos_fk, torch_smpl_humanoid.py:234-261)
-#define UHC_FRAME_STRIDE 512
+#define UHC_FRAME_STRIDE 584
 #define UHC_FR_QPOS 0      // 76
 #define UHC_FR_QVEL 76     // 75
 #define UHC_FR_WBPOS 151   // 72
@@ -12,9 +12,10 @@
 #define UHC_FR_BANGVEL 415 // 72
 #define UHC_FR_EE 487      // 15
 #define UHC_FR_COM 502     // 3
+#define UHC_FR_BCOM 512    // 72 (body_com, used by observation v1)
 
 struct EnvArgs {
-    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, has_shape, env_episode_len, expert_trail_steps;
+    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps;
     int ee_body[5];
     double dt, body_diff_thresh;
     double rw[10];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf

@@ -52,6 +52,9 @@ __device__ __forceinline__ double heading(const double* q) {  // math_utils.py:1
     if (z < 0) { w = -w; z = -z; }
     return 2 * acos(w / sqrt(w * w + z * z));
 }
+__device__ __forceinline__ double heading_new(const double* q) {  // math_utils.py:185-190
+    return atan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] * q[2] + q[3] * q[3]));
+}
 __device__ __forceinline__ void euler_rzyx(double* q, double az, double ay, double ax) {  // quaternion_from_euler(..., 'rzyx')
     double sz, cz, sy, cy, sx, cx;
     sincos(0.5 * az, &sz, &cz); sincos(0.5 * ay, &sy, &cy); sincos(0.5 * ax, &sx, &cx);
@@ -127,8 +130,11 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
                 const double an = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
                 for (int k = 0; k < 3; k++) av[k] = ax[k] / an * ang / E.dt;
             }
+            // explicit variant: unweighted, expert velocity zero past the clip end (reward_function.py:300-301, 308)
+            const double wv = E.reward_v == 1 ? 1.0 : w;
+            const bool past = E.reward_v == 1 && start_ind + cur_t >= len;
             for (int k = 0; k < 3; k++) {
-                const double dv = (av[k] - fr[UHC_FR_BANGVEL + 3 * LANE + k]) * w;
+                const double dv = (av[k] - (past ? 0.0 : fr[UHC_FR_BANGVEL + 3 * LANE + k])) * wv;
                 vel2 += dv * dv;
             }
         }
@@ -145,10 +151,11 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
         if (LANE == 0) {
             double com2 = 0, vf2 = 0;
             for (int k = 0; k < 3; k++) { const double d = xipos[3 + k] - fr[UHC_FR_COM + k]; com2 += d * d; }
-            for (int k = 0; k < E.vf_dim; k++) { const double a = action[E.nu + k]; vf2 += a * a; }
+            // implicit: |vf|^2 (:74-76); explicit: force + torque entries of every body, contact points skipped (:320-327)
+            for (int k = 0; k < E.vf_dim; k++) { const double a = action[E.nu + k]; if (E.reward_v != 1 || k % 9 >= 3) vf2 += a * a; }
             const double* W = E.rw;  // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf
             const double rp = exp(-W[5] * pose2), rv = exp(-W[6] * vel2), re = exp(-W[7] * ee2), rc = exp(-W[8] * com2);
-            const double rf = E.vf_dim > 0 ? exp(-W[9] * vf2) : 0.0;
+            const double rf = (E.vf_dim > 0 || E.reward_v == 1) ? exp(-W[9] * vf2) : 0.0;
             const double r = (W[0] * rp + W[1] * rv + W[2] * re + W[3] * rc + W[4] * rf) / (W[0] + W[1] + W[2] + W[3] + W[4]);
             E.reward[env] = r;
             double* rp_out = E.reward_parts + (size_t)env * 5;
@@ -162,63 +169,118 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
         }
     }
 
-    // ------------------------------------------------------------------ observation v2 (humanoid_im.py:419-503)
+    // ------------------------------------------------------------------ observation
+    // v2: get_full_obs_v2 (humanoid_im.py:419-503); v1: get_full_obs_v1 (:323-417) = v2 + body-COM blocks;
+    // v6: get_full_obs_v6 (:596-666)
     double* obs = E.obs + (size_t)env * E.obs_dim;
     const double* fr = bank0 + (size_t)expert_index(cur_t + 1, start_ind, len) * UHC_FRAME_STRIDE;
     double rootq[4] = {s_qpos[3], s_qpos[4], s_qpos[5], s_qpos[6]}, crq[4], hq[4], hqi[4], Rr[9], Rc[9], trq[4], tq[4];
     qmul(crq, rootq, E.base_rot_inv);            // remove_base_rot (:263-264)
-    heading_q(hq, crq);
-    qinv(hqi, hq);
-    qmat(Rr, rootq);
-    qmat(Rc, crq);
     for (int k = 0; k < 4; k++) tq[k] = fr[UHC_FR_QPOS + 3 + k];
     qmul(trq, tq, E.base_rot_inv);
-    if (LANE == 0) {
-        double dh[4], ci[4], dr[4], v0[3], v1[3], rel[3], rl[3];
-        for (int k = 0; k < 4; k++) obs[k] = hq[k];
-        qmul(dh, hqi, crq);                      // de_heading(curr_root_quat)
-        qinv(ci, crq);
-        qmul(dr, trq, ci);
-        obs[4] = fr[UHC_FR_QPOS + 2]; obs[78] = s_qpos[2]; obs[152] = fr[UHC_FR_QPOS + 2] - s_qpos[2];
-        for (int k = 0; k < 4; k++) { obs[5 + k] = tq[k]; obs[79 + k] = dh[k]; obs[153 + k] = dr[k]; }
-        const double qv[3] = {qvel[0], qvel[1], qvel[2]};
-        rotT(v0, Rr, qv);
-        rotT(v1, Rc, v0);                        // rotated twice, as the reference does (:425, :451)
-        for (int k = 0; k < 3; k++) obs[226 + k] = v1[k];
-        double rel_h = heading(trq) - heading(crq);
-        if (rel_h > M_PI) rel_h -= 2 * M_PI;
-        if (rel_h < -M_PI) rel_h += 2 * M_PI;
-        obs[301] = rel_h;
-        for (int k = 0; k < 3; k++) rel[k] = trq[k] - s_qpos[k];  // target_root_quat[:3] - qpos[:3]: bug-compatible (:466)
-        rotT(rl, Rc, rel);
-        obs[302] = rl[0]; obs[303] = rl[1];
-    }
-    for (int i = LANE; i < E.nu; i += WAVE) {   // joint angles: target, current, difference
-        const double t = fr[UHC_FR_QPOS + 7 + i], c = s_qpos[7 + i];
-        obs[9 + i] = t; obs[83 + i] = c; obs[157 + i] = t - c;
-    }
-    for (int i = LANE + 3; i < E.nv; i += WAVE) obs[226 + i] = qvel[i];
-    if (LANE < nb) {
-        const int b = LANE;
-        double d[3], r[3], cq[4], tb[4], o[4], ci[4];
-        for (int k = 0; k < 3; k++) d[k] = xpos[3 * (b + 1) + k] - s_qpos[k];
-        rotT(r, Rc, d);
-        for (int k = 0; k < 3; k++) obs[304 + k * nb + b] = r[k];            // (3, N) raveled: component-major
-        for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
-        rotT(r, Rc, d);
-        for (int k = 0; k < 3; k++) obs[304 + 3 * nb + k * nb + b] = r[k];
-        const bool unset = xquat[4] == 0.0;                                  // cur_quat[0, 0] == 0 (:485-486)
-        for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_WBQUAT + 4 * b + k]; cq[k] = unset ? tb[k] : xquat[4 * (b + 1) + k]; }
-        qmul(o, hqi, cq);
-        for (int k = 0; k < 4; k++) obs[304 + 6 * nb + 4 * b + k] = o[k];
-        qinv(ci, cq);
-        qmul(o, ci, tb);
-        for (int k = 0; k < 4; k++) obs[304 + 10 * nb + 4 * b + k] = o[k];
+    int shape_base;
+    if (E.obs_v == 6) {
+        const double yaw = heading_new(crq);
+        sincos(0.5 * yaw, &hq[3], &hq[0]); hq[1] = 0; hq[2] = 0;  // quaternion_about_axis(yaw, z) (math_utils.py:169-172)
+        qmat(Rc, hq);
+        if (LANE == 0) {
+            double rel[3], rl[3], ci[4], dr[4], v1[3];
+            for (int k = 0; k < 3; k++) rel[k] = fr[UHC_FR_QPOS + k] - s_qpos[k];
+            rotT(rl, Rc, rel);
+            for (int k = 0; k < 3; k++) obs[k] = rl[k];
+            double rel_h = heading_new(trq) - yaw;
+            if (rel_h > M_PI) rel_h -= 2 * M_PI;
+            if (rel_h < -M_PI) rel_h += 2 * M_PI;
+            obs[3] = rel_h;
+            qinv(ci, crq);
+            qmul(dr, trq, ci);
+            for (int k = 0; k < 4; k++) obs[4 + k] = dr[k];
+            const double qv[3] = {qvel[0], qvel[1], qvel[2]};
+            rotT(v1, Rc, qv);
+            for (int k = 0; k < 3; k++) obs[8 + k] = v1[k];
+        }
+        for (int i = LANE + 3; i < E.nv; i += WAVE) obs[8 + i] = qvel[i];
+        const int o1 = 8 + E.nv, o2 = o1 + 2 * nb, o3 = o2 + 3 * (nb - 1), o4 = o3 + 4 * (nb - 1);
+        if (LANE < nb) {
+            const int b = LANE;
+            double d[3], r[3];
+            for (int k = 0; k < 3; k++) d[k] = xpos[3 * (b + 1) + k] - s_qpos[k];
+            rotT(r, Rc, d);
+            obs[o1 + b] = r[1]; obs[o1 + nb + b] = r[2];   // transform_vec_batch_new(...)[1:] slices the (3, N) result: y and z rows (:645)
+            if (b >= 1) {
+                double cq[4], tb[4], ci[4], o[4];
+                for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
+                rotT(r, Rc, d);
+                for (int k = 0; k < 3; k++) obs[o2 + k * (nb - 1) + (b - 1)] = r[k];
+                body_quat(cq, s_qpos, b);
+                for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_BQUAT + 4 * b + k]; obs[o3 + 4 * (b - 1) + k] = cq[k]; }
+                qinv(ci, cq);
+                qmul(o, ci, tb);
+                for (int k = 0; k < 4; k++) obs[o4 + 4 * (b - 1) + k] = o[k];
+            }
+        }
+        shape_base = o4 + 4 * (nb - 1);
+    } else {
+        heading_q(hq, crq);
+        qinv(hqi, hq);
+        qmat(Rr, rootq);
+        qmat(Rc, crq);
+        if (LANE == 0) {
+            double dh[4], ci[4], dr[4], v0[3], v1[3], rel[3], rl[3];
+            for (int k = 0; k < 4; k++) obs[k] = hq[k];
+            qmul(dh, hqi, crq);                      // de_heading(curr_root_quat)
+            qinv(ci, crq);
+            qmul(dr, trq, ci);
+            obs[4] = fr[UHC_FR_QPOS + 2]; obs[78] = s_qpos[2]; obs[152] = fr[UHC_FR_QPOS + 2] - s_qpos[2];
+            for (int k = 0; k < 4; k++) { obs[5 + k] = tq[k]; obs[79 + k] = dh[k]; obs[153 + k] = dr[k]; }
+            const double qv[3] = {qvel[0], qvel[1], qvel[2]};
+            rotT(v0, Rr, qv);
+            rotT(v1, Rc, v0);                        // rotated twice, as the reference does (:425, :451)
+            for (int k = 0; k < 3; k++) obs[226 + k] = v1[k];
+            double rel_h = heading(trq) - heading(crq);
+            if (rel_h > M_PI) rel_h -= 2 * M_PI;
+            if (rel_h < -M_PI) rel_h += 2 * M_PI;
+            obs[301] = rel_h;
+            for (int k = 0; k < 3; k++) rel[k] = trq[k] - s_qpos[k];  // target_root_quat[:3] - qpos[:3]: bug-compatible (:466)
+            rotT(rl, Rc, rel);
+            obs[302] = rl[0]; obs[303] = rl[1];
+        }
+        for (int i = LANE; i < E.nu; i += WAVE) {   // joint angles: target, current, difference
+            const double t = fr[UHC_FR_QPOS + 7 + i], c = s_qpos[7 + i];
+            obs[9 + i] = t; obs[83 + i] = c; obs[157 + i] = t - c;
+        }
+        for (int i = LANE + 3; i < E.nv; i += WAVE) obs[226 + i] = qvel[i];
+        const int qb = 304 + (E.obs_v == 1 ? 12 : 6) * nb;   // v1 inserts the two body-COM blocks before the quaternions
+        if (LANE < nb) {
+            const int b = LANE;
+            double d[3], r[3], cq[4], tb[4], o[4], ci[4];
+            for (int k = 0; k < 3; k++) d[k] = xpos[3 * (b + 1) + k] - s_qpos[k];
+            rotT(r, Rc, d);
+            for (int k = 0; k < 3; k++) obs[304 + k * nb + b] = r[k];            // (3, N) raveled: component-major
+            for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
+            rotT(r, Rc, d);
+            for (int k = 0; k < 3; k++) obs[304 + 3 * nb + k * nb + b] = r[k];
+            if (E.obs_v == 1) {
+                for (int k = 0; k < 3; k++) d[k] = xipos[3 * (b + 1) + k] - s_qpos[k];
+                rotT(r, Rc, d);
+                for (int k = 0; k < 3; k++) obs[304 + 6 * nb + k * nb + b] = r[k];
+                for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_BCOM + 3 * b + k] - xipos[3 * (b + 1) + k];
+                rotT(r, Rc, d);
+                for (int k = 0; k < 3; k++) obs[304 + 9 * nb + k * nb + b] = r[k];
+            }
+            const bool unset = xquat[4] == 0.0;                                  // cur_quat[0, 0] == 0 (:485-486)
+            for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_WBQUAT + 4 * b + k]; cq[k] = unset ? tb[k] : xquat[4 * (b + 1) + k]; }
+            qmul(o, hqi, cq);
+            for (int k = 0; k < 4; k++) obs[qb + 4 * b + k] = o[k];
+            qinv(ci, cq);
+            qmul(o, ci, tb);
+            for (int k = 0; k < 4; k++) obs[qb + 4 * nb + 4 * b + k] = o[k];
+        }
+        shape_base = qb + 8 * nb;
     }
     if (E.has_shape) {
-        const int base = 304 + 14 * nb;
         const double* cb = E.clip_beta + (size_t)E.clip_id[env] * 17;
-        if (LANE < 17) obs[base + LANE] = cb[LANE];  // beta(16), gender
+        if (LANE < 17) obs[shape_base + LANE] = cb[LANE];  // beta(16), gender
     }
     (void)s_q;
 }

@@ -46,7 +46,8 @@ static int dalloc(UhcEnv* e, size_t n, T** p) {
 
 extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out) {
     if (!b || !d || !out) return uhc_internal_set_error("uhc_env_create: null argument");
-    if (d->obs_v != 2) return uhc_internal_set_error("uhc_env_create: only obs_v == 2 is built (SURVEY.md 8f-4)");
+    if (d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 1, 2 or 6");
+    if (d->reward_v != 0 && d->reward_v != 1) return uhc_internal_set_error("uhc_env_create: reward_v must be 0 (implicit) or 1 (explicit)");
     UhcEnv* e = new UhcEnv();
     e->b = b;
     EnvArgs& E = e->E;
@@ -57,7 +58,9 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     if (E.nq != E.nv + 1 || E.nq > 128) { delete e; return uhc_internal_set_error("uhc_env_create: hinge humanoid (free root + scalar joints, nq <= 128) expected"); }
     const int nb = E.nbody - 1;
     E.has_shape = d->has_shape;
-    E.obs_dim = 304 + 14 * nb + (d->has_shape ? 17 : 0);
+    E.obs_v = d->obs_v;
+    E.reward_v = d->reward_v;
+    E.obs_dim = (d->obs_v == 6 ? 8 + E.nv + 2 * nb + 11 * (nb - 1) : 304 + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
     E.env_episode_len = d->env_episode_len;
     E.expert_trail_steps = d->env_expert_trail_steps;
     for (int k = 0; k < 5; k++) E.ee_body[k] = d->ee_body[k];

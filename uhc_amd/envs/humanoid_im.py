@@ -43,7 +43,10 @@ class VecHumanoidEnv:
         thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
         if cfg.env_term_body != "body":
             raise NotImplementedError("env_term_body other than 'body' is a later row (SURVEY.md 8f-4)")
-        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
+        reward_v = {"world_rfc_implicit": 0, "world_rfc_explicit": 1}.get(cfg.reward_id)
+        if reward_v is None:
+            raise NotImplementedError(f"reward_id {cfg.reward_id!r}: world_rfc_implicit and world_rfc_explicit are built (SURVEY.md 8f-4)")
+        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
                                                  env_episode_len=cfg.env_episode_len, env_expert_trail_steps=cfg.env_expert_trail_steps,
                                                  body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
                                                  jpos_diffw=self.converter.get_new_diff_weight()))

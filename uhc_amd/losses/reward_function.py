@@ -1,7 +1,7 @@
 """Imitation rewards, by the reference's ids (uhc/losses/reward_function.py:823-833).
 
 On this build the reward is evaluated inside the env step kernel (uhc_amd/csrc/uhc_env.hip, which restates
-world_rfc_implicit_reward, reward_function.py:12-88) so that rollout buffers never leave HBM; the functions
+world_rfc_implicit_reward, reward_function.py:12-88, and world_rfc_explicit_reward, :253-341) so that rollout buffers never leave HBM; the functions
 here keep the reference's call signature ``f(env, state, action, info) -> (reward, components)`` and read
 the value the kernel produced for the facade env's last step."""
 import numpy as np
@@ -12,5 +12,10 @@ def world_rfc_implicit_reward(env, state, action, info):
     return r, np.asarray(parts)
 
 
-reward_func = {"world_rfc_implicit": world_rfc_implicit_reward}
-DEVICE_REWARD_IDS = ("world_rfc_implicit",)
+def world_rfc_explicit_reward(env, state, action, info):  # reward_function.py:253-341, also evaluated in the step kernel
+    r, parts = env.last_reward
+    return r, np.asarray(parts)
+
+
+reward_func = {"world_rfc_implicit": world_rfc_implicit_reward, "world_rfc_explicit": world_rfc_explicit_reward}
+DEVICE_REWARD_IDS = ("world_rfc_implicit", "world_rfc_explicit")

@@ -129,8 +129,8 @@ class SimBatch:
 
 E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE = range(10)
 _E_INT = {E_DONE, E_FAIL, E_END, E_CUR_T}
-FRAME_STRIDE = 512
-FR = dict(qpos=(0, 76), qvel=(76, 75), wbpos=(151, 72), wbquat=(223, 96), bquat=(319, 96), bangvel=(415, 72), ee_wpos=(487, 15), com=(502, 3))
+FRAME_STRIDE = 584
+FR = dict(qpos=(0, 76), qvel=(76, 75), wbpos=(151, 72), wbquat=(223, 96), bquat=(319, 96), bangvel=(415, 72), ee_wpos=(487, 15), com=(502, 3), body_com=(512, 72))
 
 
 def pack_expert_frames(feat) -> np.ndarray:
