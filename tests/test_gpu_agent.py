@@ -100,3 +100,23 @@ def test_eval_policy_reports_reference_metrics(tmp_path):
         assert res["pred"].shape[1] == 76 and 2 <= res["pred"].shape[0] == res["gt"].shape[0] and (res["fail_safe"] or res["pred"].shape[0] <= T + 1)
         assert res["pred_jpos"].shape[1] == 72 and res["succ"].shape == (1,)
     agent.env.close()
+
+
+def test_release_implicit_variant_mcp_obs_v1(tmp_path):
+    """The `uhc_implicit` release shape: observation v1 (784), multiplicative-compositional actor, implicit RFC without
+    meta-PD (action 75); one training iteration end to end on the device."""
+    import torch
+    from uhc_amd.agents import agent_dict
+    from uhc_amd.models.policy_mcp import PolicyMCP
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path, n_env=32, batch=32 * 6)
+    cfg.obs_v, cfg.has_shape, cfg.meta_pd, cfg.actor_type, cfg.num_primitive = 1, False, False, "mcp", 8
+    cfg.cfg_dict["composer_dim"] = [64, 32]
+    cfg.save_n_epochs = 100
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
+    assert agent.state_dim == 784 and agent.action_dim == 75 and isinstance(agent.policy_net, PolicyMCP)
+    before = agent.policy_net.nets[3][1].weight.detach().clone()
+    info = agent.optimize_policy(0)
+    assert info["log"].num_steps == 32 * 6 and np.isfinite(info["log"].avg_c_info).all()
+    assert not torch.equal(before, agent.policy_net.nets[3][1].weight)
+    agent.env.close()

@@ -67,6 +67,30 @@ def test_policy_value_ppo_loss_and_grads_match_reference():
     assert n_pol == 4024530  # policy parameter count at 657 -> 105
 
 
+def test_policy_mcp_matches_reference():
+    from uhc_amd.models.policy_mcp import PolicyMCP
+
+    class C(dict):
+        __getattr__ = dict.__getitem__
+
+    g = np.load(os.path.join(G, "g12_policy_mcp.npz"))
+    cfg = C(policy_hsize=[24, 16, 12], policy_htype="gelu", fix_std=True, log_std=-2.3, num_primitive=4, composer_dim=[20, 10])
+    pol = PolicyMCP(cfg, action_dim=7, state_dim=19)
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("pol_")}
+    assert set(sd) == set(pol.state_dict())  # the reference's parameter names: released checkpoints load unchanged
+    pol.load_state_dict(sd)
+    x, a = torch.from_numpy(g["x"]), torch.from_numpy(g["a"])
+    np.testing.assert_allclose(pol.composer(x).detach().numpy(), g["weight"], atol=1e-14)
+    np.testing.assert_allclose(pol(x).loc.detach().numpy(), g["mean"], atol=1e-14)
+    lp = pol.get_log_prob(x, a)
+    np.testing.assert_allclose(lp.detach().numpy(), g["log_prob"], atol=1e-11)
+    (-lp.mean()).backward()
+    for n, p in pol.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(p.grad.numpy(), g["polgrad_" + n], atol=1e-11, err_msg=n)
+    assert pol.select_action(x, True).shape == (32, 7)
+
+
 def test_zfilter_sequential_and_batched():
     from uhc_amd.khrylib.utils.zfilter import ZFilter
     g = np.load(os.path.join(G, "g7_zfilter.npz"))

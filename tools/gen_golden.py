@@ -328,6 +328,33 @@ def g7_g8_learner():
     save("g8_ppo_small", **arrs)
 
 
+def g12_policy_mcp():
+    """PolicyMCP (uhc/models/policy_mcp.py:9-37) at reduced width: parameters, mean, log-prob and gradients."""
+    from uhc.models.policy_mcp import PolicyMCP
+    rng = np.random.default_rng(1212)
+    torch.manual_seed(12)
+    sd, ad = 19, 7
+
+    class C(dict):
+        __getattr__ = dict.__getitem__
+
+    cfg = C(policy_hsize=[24, 16, 12], policy_htype="gelu", fix_std=True, log_std=-2.3, num_primitive=4, composer_dim=[20, 10])
+    pol = PolicyMCP(cfg, action_dim=ad, state_dim=sd)
+    for n, p in pol.named_parameters():  # heads are near zero at init; make every block matter
+        if p.requires_grad:
+            p.data.add_(torch.from_numpy(rng.normal(scale=0.05, size=tuple(p.shape))))
+    x = torch.from_numpy(rng.normal(size=(32, sd)))
+    a = torch.from_numpy(rng.normal(scale=0.2, size=(32, ad)))
+    lp = pol.get_log_prob(x, a)
+    (-lp.mean()).backward()
+    arrs = dict(x=x.numpy(), a=a.numpy(), mean=pol(x).loc.detach().numpy(), log_prob=lp.detach().numpy(), weight=pol.composer(x).detach().numpy())
+    for n, p in pol.named_parameters():
+        arrs["pol_" + n] = p.detach().numpy()
+        if p.grad is not None:
+            arrs["polgrad_" + n] = p.grad.numpy()
+    save("g12_policy_mcp", **arrs)
+
+
 def g11_metrics(dm, feat):
     from uhc.smpllib.smpl_eval import compute_metrics
     rng = np.random.default_rng(606)
@@ -450,6 +477,7 @@ def main():
     g11_metrics(dm, feat)
     g9_dataset()
     g10_config()
+    g12_policy_mcp()
 
 
 if __name__ == "__main__":

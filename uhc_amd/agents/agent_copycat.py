@@ -79,9 +79,13 @@ class AgentCopycat(AgentPPO):
     def setup_policy(self):
         cfg, env = self.cfg, self.env
         self.state_dim, self.action_dim = env.observation_space.shape[0], env.action_space.shape[0]
-        if cfg.actor_type != "gauss":
-            raise NotImplementedError("PolicyMCP is a later row (SURVEY.md 8f-4)")
-        self.policy_net = PolicyGaussian(cfg, action_dim=self.action_dim, state_dim=self.state_dim)
+        if cfg.actor_type == "gauss":
+            self.policy_net = PolicyGaussian(cfg, action_dim=self.action_dim, state_dim=self.state_dim)
+        elif cfg.actor_type == "mcp":
+            from ..models.policy_mcp import PolicyMCP
+            self.policy_net = PolicyMCP(cfg, action_dim=self.action_dim, state_dim=self.state_dim)
+        else:
+            raise ValueError(f"actor_type {cfg.actor_type!r}")
         self.running_state = ZFilter((self.state_dim,), clip=5)
         to_device(self.device, self.policy_net)
 
