@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UHC_ABI_VERSION 1
+#define UHC_ABI_VERSION 2
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -77,13 +77,16 @@ typedef struct UhcCtrlDesc {
     int32_t n_substeps;   /* frame_skip, 15 (humanoid_im.py:64) */
     int32_t action_type;  /* 0 = "position" (stable PD), 1 = "torque" (humanoid_im.py:1157-1160) */
     int32_t meta_pd;      /* 0 none, 1 per-substep gains (30 numbers), 2 per-joint (humanoid_im.py:1054-1067) */
-    int32_t rfc_mode;     /* 0 none, 1 implicit root wrench (humanoid_im.py:1136-1143) */
+    int32_t rfc_mode;     /* 0 none, 1 implicit root wrench (humanoid_im.py:1136-1143), 2 explicit per-body wrenches (:1080-1132) */
     int32_t action_dim;   /* nu + vf_dim + meta_pd_dim (humanoid_im.py:250) */
-    int32_t _pad;
+    int32_t body_vf_dim;  /* explicit: 6 + 3 * residual_force_torque (humanoid_im.py:242) */
     double rfc_scale;     /* residual_force_scale * rfc_rate */
     double rfc_lim;       /* residual_force_lim */
     double base_rot[4];   /* data_specs.base_rot (humanoid_im.py:85) */
     const double *jkp, *jkd, *torque_lim, *a_scale; /* [nu] host arrays */
+    const int32_t* vf_body; /* explicit: model body id of each residual-force body, in action order (humanoid_im.py:236-241) */
+    int32_t n_vf_body;
+    int32_t _pad;
 } UhcCtrlDesc;
 
 typedef struct UhcModel UhcModel;

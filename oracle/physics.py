@@ -33,6 +33,7 @@ def lib():
         L.orc_do_simulation.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_pd_torque.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         L.orc_rfc_implicit.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double)]
+        L.orc_rfc_explicit.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double)]
         L.orc_batch_do_simulation.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), C.POINTER(P), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_get.argtypes = [C.POINTER(UhcModelDesc), P, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.orc_get.restype = C.c_int
@@ -93,6 +94,11 @@ class OracleSim:
     def rfc_implicit(self, action):
         action = np.ascontiguousarray(action, dtype=np.float64)
         self.L.orc_rfc_implicit(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action))
+        return self.get("qfrc_applied")
+
+    def rfc_explicit(self, action):
+        action = np.ascontiguousarray(action, dtype=np.float64)
+        self.L.orc_rfc_explicit(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action))
         return self.get("qfrc_applied")
 
     def get(self, name: str) -> np.ndarray:

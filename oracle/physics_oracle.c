@@ -824,6 +824,40 @@ void orc_rfc_implicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, c
     memcpy(vf, r, 24);
     for (int k = 0; k < 6; k++) d->qfrc_applied[k] = fmin(fmax(vf[k], -c->rfc_lim), c->rfc_lim);
 }
+/* rfc_explicit: humanoid_im.py:1080-1132 with the default switches (residual_contact_only = False, no projection,
+ * one wrench per body): per body a contact point, force and torque in the BODY frame -> world (mujoco_env.py:171-180),
+ * accumulated into qfrc_applied by mj_applyFT [MJ-ext]: qfrc += jacp' f + jacr' tau with the Jacobian at the world
+ * point, built from the cdof / subtree_com left by the previous forward pass. */
+void orc_rfc_explicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action) {
+    const int nv = m->nv, bvd = c->body_vf_dim;
+    double* qfrc = calloc(nv, 8);
+    for (int i = 0; i < c->n_vf_body; i++) {
+        const int body = c->vf_body[i];
+        const double* vf = action + m->nu + i * bvd;
+        const double* R = d->xmat + 9 * body;
+        double cp[3], f[3], tq[3] = {0, 0, 0}, fl[3], tl[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) { fl[k] = vf[3 + k] * c->rfc_scale; if (bvd >= 9) tl[k] = vf[6 + k] * c->rfc_scale; }
+        for (int r = 0; r < 3; r++) {
+            cp[r] = R[3 * r] * vf[0] + R[3 * r + 1] * vf[1] + R[3 * r + 2] * vf[2] + d->xpos[3 * body + r];
+            f[r] = R[3 * r] * fl[0] + R[3 * r + 1] * fl[1] + R[3 * r + 2] * fl[2];
+            tq[r] = R[3 * r] * tl[0] + R[3 * r + 1] * tl[1] + R[3 * r + 2] * tl[2];
+        }
+        if (body <= 0) continue;
+        const double* c0 = d->subtree_com + 3 * body_rootid(m, body);
+        const double off[3] = {cp[0] - c0[0], cp[1] - c0[1], cp[2] - c0[2]};
+        int b = body;
+        while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+        if (b <= 0) continue;
+        for (int j = m->body_dofadr[b] + m->body_dofnum[b] - 1; j >= 0; j = m->dof_parentid[j]) {
+            double t[3];
+            cross3(t, d->cdof + 6 * j, off);
+            const double* cd = d->cdof + 6 * j;
+            qfrc[j] += (cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2] + cd[0] * tq[0] + cd[1] * tq[1] + cd[2] * tq[2];
+        }
+    }
+    memcpy(d->qfrc_applied, qfrc, (size_t)nv * 8);
+    free(qfrc);
+}
 /*
  * One HumanoidEnv.do_simulation (humanoid_im.py:1145-1190).  action layout: humanoid_im.py:226-255.
  * M and C used by the PD solve are the ones left in `d` by the previous forward pass
@@ -837,6 +871,7 @@ void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, 
             for (int a = 0; a < m->nu; a++) /* :1160-1161 */
                 d->ctrl[a] = fmin(fmax(action[a] * c->a_scale[a] * 100, -c->torque_lim[a]), c->torque_lim[a]);
         if (c->rfc_mode == 1) orc_rfc_implicit(m, c, d, action);
+        else if (c->rfc_mode == 2) orc_rfc_explicit(m, c, d, action);
         orc_step(m, d);
     }
 }

@@ -48,6 +48,7 @@ void orc_set_state(const UhcModelDesc* m, OrcData* d, const double* qpos, const 
 void orc_pd_torque(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
                    const double* target_base, int it);
 void orc_rfc_implicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action);
+void orc_rfc_explicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action);
 void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
                        const double* target_base);
 void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData** ds, int n_env,

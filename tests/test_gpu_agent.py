@@ -120,3 +120,19 @@ def test_release_implicit_variant_mcp_obs_v1(tmp_path):
     assert info["log"].num_steps == 32 * 6 and np.isfinite(info["log"].avg_c_info).all()
     assert not torch.equal(before, agent.policy_net.nets[3][1].weight)
     agent.env.close()
+
+
+def test_release_explicit_variant(tmp_path):
+    """The `uhc_explicit` release shape: observation v2 + shape, meta-PD, explicit per-body residual forces
+    (action 69 + 24*9 + 30 = 315) and the explicit reward; one training iteration on the device."""
+    import torch
+    from uhc_amd.agents import agent_dict
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path, n_env=32, batch=32 * 6)
+    cfg.residual_force_mode, cfg.reward_id = "explicit", "world_rfc_explicit"
+    cfg.save_n_epochs = 100
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
+    assert agent.state_dim == 657 and agent.action_dim == 315 and agent.env.vf_dim == 216
+    info = agent.optimize_policy(0)
+    assert info["log"].num_steps == 32 * 6 and np.isfinite(info["log"].avg_c_info).all()
+    agent.env.close()

@@ -182,3 +182,56 @@ def test_joint_limit_constraint():
         peak = max(peak, s.get("qpos")[0])
     assert 0.3 < peak < 0.33  # soft limit: overshoot bounded by the impedance width scale
     assert s.geti("fail") == 0
+
+
+def test_explicit_rfc_equals_virtual_work(model, standing):
+    """orc_rfc_explicit (mj_applyFT through the point Jacobian) against the principle of virtual work:
+    qfrc . v = sum_b f_b . d/dt(point_b) + tau_b . omega_b, with the right side from central differences of the
+    numpy kinematics (uhc_amd/model/mjcf.py)."""
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import kinematics_np, quat_mul, quat_to_mat
+    from uhc_amd.sim import make_ctrl
+    ctrl = make_ctrl(model, residual_force_mode="explicit")
+    rng = np.random.default_rng(21)
+    qpos = standing["qpos"].copy()
+    qpos[7:] += rng.normal(scale=0.2, size=model.nu)
+    q = rng.normal(size=4)
+    qpos[3:7] = q / np.linalg.norm(q)
+    o = OracleSim(model, ctrl)
+    o.set_state(qpos, np.zeros(model.nv))
+    action = rng.normal(scale=0.3, size=ctrl.action_dim)
+    qfrc = o.rfc_explicit(action).copy()
+    assert np.abs(qfrc).max() > 1.0
+    vf = action[model.nu:model.nu + 24 * 9].reshape(24, 9)
+    bodies = [ctrl.vf_body[i] for i in range(24)]
+
+    def integrate(qp, v, h):  # free joint: world-frame translation, body-frame rotation; hinges: angle
+        out = qp.copy()
+        out[:3] += h * v[:3]
+        w = v[3:6] * h
+        ang = np.linalg.norm(w)
+        dq = np.r_[np.cos(ang / 2), np.sin(ang / 2) * w / ang] if ang > 0 else np.array([1.0, 0, 0, 0])
+        out[3:7] = quat_mul(qp[3:7], dq)
+        out[7:] += h * v[6:]
+        return out
+
+    def points_and_frames(qp):
+        xpos, xquat = kinematics_np(model, qp)[:2]
+        R = [quat_to_mat(xquat[b]) for b in bodies]
+        return np.array([xpos[b] + R[i] @ vf[i, :3] for i, b in enumerate(bodies)]), R
+
+    _, R0 = points_and_frames(qpos)
+    f = np.array([R0[i] @ (vf[i, 3:6] * ctrl.rfc_scale) for i in range(24)])
+    tq = np.array([R0[i] @ (vf[i, 6:9] * ctrl.rfc_scale) for i in range(24)])
+    h = 1e-6
+    for _ in range(5):
+        v = rng.normal(size=model.nv)
+        pp, Rp = points_and_frames(integrate(qpos, v, h))
+        pm, Rm = points_and_frames(integrate(qpos, v, -h))
+        power = 0.0
+        for i in range(24):
+            pdot = (pp[i] - pm[i]) / (2 * h)
+            dR = (Rp[i] - Rm[i]) / (2 * h) @ R0[i].T  # skew(omega)
+            omega = np.array([dR[2, 1], dR[0, 2], dR[1, 0]])
+            power += f[i] @ pdot + tq[i] @ omega
+        assert qfrc @ v == pytest.approx(power, rel=1e-6, abs=1e-6)

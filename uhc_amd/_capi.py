@@ -39,9 +39,10 @@ class UhcModelDesc(C.Structure):
 
 class UhcCtrlDesc(C.Structure):
     _fields_ = [("n_substeps", C.c_int32), ("action_type", C.c_int32), ("meta_pd", C.c_int32),
-                ("rfc_mode", C.c_int32), ("action_dim", C.c_int32), ("_pad", C.c_int32),
+                ("rfc_mode", C.c_int32), ("action_dim", C.c_int32), ("body_vf_dim", C.c_int32),
                 ("rfc_scale", C.c_double), ("rfc_lim", C.c_double), ("base_rot", C.c_double * 4),
-                ("jkp", _F64P), ("jkd", _F64P), ("torque_lim", _F64P), ("a_scale", _F64P)]
+                ("jkp", _F64P), ("jkd", _F64P), ("torque_lim", _F64P), ("a_scale", _F64P),
+                ("vf_body", _I32P), ("n_vf_body", C.c_int32), ("_pad", C.c_int32)]
 
 
 def model_desc(model) -> UhcModelDesc:
@@ -64,7 +65,8 @@ def model_desc(model) -> UhcModelDesc:
 
 
 def ctrl_desc(n_substeps=15, action_type=0, meta_pd=0, rfc_mode=0, action_dim=0, rfc_scale=0.0, rfc_lim=100.0,
-              base_rot=(0.7071, 0.7071, 0.0, 0.0), jkp=None, jkd=None, torque_lim=None, a_scale=None) -> UhcCtrlDesc:
+              base_rot=(0.7071, 0.7071, 0.0, 0.0), jkp=None, jkd=None, torque_lim=None, a_scale=None, vf_body=None,
+              body_vf_dim=9) -> UhcCtrlDesc:
     c = UhcCtrlDesc()
     c.n_substeps, c.action_type, c.meta_pd, c.rfc_mode, c.action_dim = n_substeps, action_type, meta_pd, rfc_mode, action_dim
     c.rfc_scale, c.rfc_lim = float(rfc_scale), float(rfc_lim)
@@ -74,6 +76,9 @@ def ctrl_desc(n_substeps=15, action_type=0, meta_pd=0, rfc_mode=0, action_dim=0,
         arr = np.ascontiguousarray(v if v is not None else np.zeros(1), dtype=np.float64)
         keep.append(arr)
         setattr(c, n, arr.ctypes.data_as(_F64P))
+    vb = np.ascontiguousarray(vf_body if vf_body is not None else np.zeros(1), dtype=np.int32)
+    keep.append(vb)
+    c.vf_body, c.n_vf_body, c.body_vf_dim = vb.ctypes.data_as(_I32P), (len(vf_body) if vf_body is not None else 0), int(body_vf_dim)
     c._keep = keep
     return c
 

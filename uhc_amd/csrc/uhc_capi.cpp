@@ -322,7 +322,19 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         if (n2 <= 0) { delete b; return fail("uhc_batch_create: zero base_rot"); }
         C.base_rot_inv[0] = q[0] / n2; C.base_rot_inv[1] = -q[1] / n2; C.base_rot_inv[2] = -q[2] / n2; C.base_rot_inv[3] = -q[3] / n2;
     }
-    const int min_adim = d.nu + (C.rfc_mode == 1 ? 6 : 0) + (C.meta_pd == 1 ? 2 * C.n_substeps : C.meta_pd == 2 ? 2 * d.nu : 0);
+    C.n_vf_body = 0; C.body_vf_dim = 0; C.vf_body = nullptr;
+    if (C.rfc_mode == 2) {
+        C.n_vf_body = ctrl->n_vf_body; C.body_vf_dim = ctrl->body_vf_dim;
+        if (C.n_vf_body < 1 || C.n_vf_body > 64 || !ctrl->vf_body || (C.body_vf_dim != 6 && C.body_vf_dim != 9)) {
+            delete b; return fail("uhc_batch_create: explicit RFC needs 1..64 vf bodies and body_vf_dim 6 or 9");
+        }
+        std::vector<int> vb(ctrl->vf_body, ctrl->vf_body + C.n_vf_body), seen(nb, 0);
+        for (int v : vb) {
+            if (v < 0 || v >= nb || seen[v]++) { delete b; return fail("uhc_batch_create: vf_body ids must be distinct model bodies"); }
+        }
+        TRY(upload(b, vb, &C.vf_body));
+    } else if (C.rfc_mode != 0 && C.rfc_mode != 1) { delete b; return fail("uhc_batch_create: rfc_mode must be 0, 1 or 2"); }
+    const int min_adim = d.nu + (C.rfc_mode == 1 ? 6 : C.rfc_mode == 2 ? C.n_vf_body * C.body_vf_dim : 0) + (C.meta_pd == 1 ? 2 * C.n_substeps : C.meta_pd == 2 ? 2 * d.nu : 0);
     if (C.action_dim < min_adim) { delete b; return fail("uhc_batch_create: action_dim %d < %d required by the controller", C.action_dim, min_adim); }
     auto dvec = [&](const double* p) { return std::vector<double>(p, p + d.nu); };
     TRY(upload(b, dvec(ctrl->jkp), &C.jkp)); TRY(upload(b, dvec(ctrl->jkd), &C.jkd));
@@ -401,6 +413,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
     TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
+    if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
     TRY(dalloc(b, E, &S.overflow));
     TRY(dalloc(b, E, &b->reset_mask));
@@ -524,7 +537,7 @@ extern "C" int uhc_internal_set_error(const char* msg) { return fail("%s", msg);
 extern "C" int uhc_internal_batch_info(UhcBatch* b, int* n_env, int* nq, int* nv, int* nu, int* nbody, int* action_dim, int* vf_dim,
                                        double* dt, double* base_rot_inv, void** stream, int** reset_mask) {
     *n_env = b->n_env; *nq = b->A.t.nq; *nv = b->A.t.nv; *nu = b->A.t.nu; *nbody = b->A.t.nbody;
-    *action_dim = b->A.c.action_dim; *vf_dim = b->A.c.rfc_mode == 1 ? 6 : 0;
+    *action_dim = b->A.c.action_dim; *vf_dim = b->A.c.rfc_mode == 1 ? 6 : b->A.c.rfc_mode == 2 ? b->A.c.n_vf_body * b->A.c.body_vf_dim : 0;
     *dt = b->A.t.timestep * b->A.c.n_substeps;
     for (int k = 0; k < 4; k++) base_rot_inv[k] = b->A.c.base_rot_inv[k];
     *stream = (void*)b->stream;

@@ -53,7 +53,8 @@ struct DevLds {
 };
 
 struct DevCtrl {
-    int n_substeps, action_type, meta_pd, rfc_mode, action_dim;
+    int n_substeps, action_type, meta_pd, rfc_mode, action_dim, n_vf_body, body_vf_dim;
+    const int* vf_body;  // explicit RFC: body id per residual-force slot
     double rfc_scale, rfc_lim;
     double base_rot_inv[4];  // quaternion_inverse(base_rot) = conj / |q|^2
     const double *jkp, *jkd, *torque_lim, *a_scale;
@@ -61,6 +62,7 @@ struct DevCtrl {
 
 struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
+    double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)

@@ -1410,6 +1410,49 @@ __device__ __forceinline__ void k_rfc_implicit(const KernelArgs& A, double* S, c
     wsync();
 }
 
+// rfc_explicit (humanoid_im.py:1080-1132) + mj_applyFT [MJ-ext]: one (contact point, force, torque) per listed body, given in
+// the body frame; qfrc_applied = sum_b J_b(point)^T [f; tau].  With cdof about the root's subtree COM c0 this is
+// qfrc_i = cdof_i . W_sub(body(i)), W_b = [tau + (p - c0) x f ; f] summed over the subtree of the dof's body.
+// Uses the kinematics left by the previous forward pass (xpos, xmat, cdof, subtree COM), as the reference does.
+template <bool FAST>
+__device__ __forceinline__ void k_rfc_explicit(const KernelArgs& A, double* S, const double* action) {
+    const DevLds& L = FAST ? A.lf : A.l;
+    const DevTopo& T = A.t;
+    const DevCtrl& C = A.c;
+    double* W = S + L.cfrc;  // free between substeps
+    for (int i = LANE; i < 6 * T.nbody; i += UHC_WAVE) W[i] = 0;
+    wsync();
+    if (LANE < C.n_vf_body) {
+        const int body = C.vf_body[LANE];
+        if (body > 0) {
+            const double* vf = action + T.nu + LANE * C.body_vf_dim;
+            const double* R = S + L.xmat + 9 * body;
+            const double* c0 = S + L.rootcom + 3 * T.body_rootid[body];
+            double cpl[3] = {vf[0], vf[1], vf[2]}, fl[3], tl[3] = {0, 0, 0}, off[3], f[3], tq[3], n[3];
+            for (int k = 0; k < 3; k++) { fl[k] = vf[3 + k] * C.rfc_scale; if (C.body_vf_dim >= 9) tl[k] = vf[6 + k] * C.rfc_scale; }
+            mat_vec(off, R, cpl);
+            mat_vec(f, R, fl);
+            mat_vec(tq, R, tl);
+            for (int k = 0; k < 3; k++) off[k] += S[L.xpos + 3 * body + k] - c0[k];
+            cross3(n, off, f);
+            for (int k = 0; k < 3; k++) { W[6 * body + k] = n[k] + tq[k]; W[6 * body + 3 + k] = f[k]; }
+        }
+    }
+    wsync();
+    if (LANE < 6)  // bodies are numbered depth first (parent < child): one backward sweep sums every subtree
+        for (int b = T.nbody - 1; b >= 1; b--) {
+            const int p = T.body_parentid[b];
+            if (p > 0) W[6 * p + LANE] += W[6 * b + LANE];
+        }
+    wsync();
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+        const double* cd = S + L.cdof + 6 * i;
+        const double* w = W + 6 * T.dof_bodyid[i];
+        S[L.applied + i] = cd[0] * w[0] + cd[1] * w[1] + cd[2] * w[2] + cd[3] * w[3] + cd[4] * w[4] + cd[5] * w[5];
+    }
+    wsync();
+}
+
 // ------------------------------------------------------------------ the kernels
 // MODE 0: do_simulation (n_substeps of control + step);  MODE 1: forward only (after set_state).
 // FAST: compact LDS (4 workgroups per CU), <= 64 constraint rows, A in registers.  An env that does not
@@ -1442,6 +1485,19 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
     }
     if (LANE == 0) S[L.zero] = 0.0;  // slot idle lanes read instead of branching around LDS loads
+    if (MODE == 0 && A.c.rfc_mode == 2) {  // explicit RFC reads the kinematics of the previous forward pass
+        for (int i = LANE; i < 6 * T.nv; i += UHC_WAVE) S[L.cdof + i] = A.s.cdof[(size_t)env * 6 * T.nv + i];
+        for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
+            S[L.rootcom + i] = A.s.rootcom[(size_t)env * 3 * T.nbody + i];
+            S[L.xpos + i] = A.s.xpos[(size_t)env * 3 * T.nbody + i];
+        }
+        for (int b = LANE; b < T.nbody; b += UHC_WAVE) {
+            double q[4], R[9];
+            for (int k = 0; k < 4; k++) q[k] = A.s.xquat[(size_t)env * 4 * T.nbody + 4 * b + k];
+            quat_to_mat(R, q);
+            for (int k = 0; k < 9; k++) S[L.xmat + 9 * b + k] = R[k];
+        }
+    }
     const LaneConst LC = lane_const(T);
     MReg mr;
 #pragma unroll
@@ -1469,6 +1525,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
                 wsync();
             }
             if (A.c.rfc_mode == 1) k_rfc_implicit<FAST>(A, S, action);
+            else if (A.c.rfc_mode == 2) k_rfc_explicit<FAST>(A, S, action);
             // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
             int b = 0;
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
@@ -1515,6 +1572,10 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
         }
         for (int i = LANE; i < 4 * T.nbody; i += UHC_WAVE) A.s.xquat[(size_t)env * 4 * T.nbody + i] = S[L.xquat + i];
+        if (A.c.rfc_mode == 2) {
+            for (int i = LANE; i < 6 * T.nv; i += UHC_WAVE) A.s.cdof[(size_t)env * 6 * T.nv + i] = S[L.cdof + i];
+            for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) A.s.rootcom[(size_t)env * 3 * T.nbody + i] = S[L.rootcom + i];
+        }
     }
 #ifdef UHC_STAGE_PROF
     PROF(15)

@@ -37,7 +37,8 @@ class VecHumanoidEnv:
         self.ctrl = S.make_ctrl(self.model, meta_pd=cfg.meta_pd, meta_pd_joint=cfg.meta_pd_joint, residual_force=cfg.residual_force,
                                 residual_force_mode=cfg.residual_force_mode, residual_force_scale=cfg.residual_force_scale,
                                 residual_force_lim=cfg.residual_force_lim, rfc_rate=self.rfc_rate, action_type=cfg.action_type,
-                                pd_mul=cfg.get("pd_mul", 1), tq_mul=cfg.get("tq_mul", 1), base_rot=self.base_rot)
+                                pd_mul=cfg.get("pd_mul", 1), tq_mul=cfg.get("tq_mul", 1), base_rot=self.base_rot,
+                                residual_force_bodies=cfg.residual_force_bodies, residual_force_torque=cfg.residual_force_torque)
         self.sim = S.SimBatch(self.model, self.ctrl, self.n_env, device=device)
         self.device = self.sim.device
         thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
@@ -51,7 +52,8 @@ class VecHumanoidEnv:
                                                  body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
                                                  jpos_diffw=self.converter.get_new_diff_weight()))
         self.ndof = self.model.nu
-        self.vf_dim = 6 if (cfg.residual_force and cfg.residual_force_mode == "implicit") else 0
+        self.body_vf_dim = self.ctrl.body_vf_dim
+        self.vf_dim = 0 if not cfg.residual_force else (6 if cfg.residual_force_mode == "implicit" else self.ctrl.n_vf_body * self.body_vf_dim)
         self.meta_pd_dim = 30 if cfg.meta_pd else (2 * self.ndof if cfg.meta_pd_joint else 0)
         self.action_dim = self.ctrl.action_dim
         self.obs_dim = self.env.obs_dim
@@ -112,7 +114,8 @@ class VecHumanoidEnv:
 
     def set_rfc_rate(self, rate):
         self.rfc_rate = rate
-        self.sim.set_rfc_scale(self.cc_cfg.residual_force_scale * rate)
+        if self.ctrl.rfc_mode != 2:  # rfc_explicit scales by residual_force_scale alone (humanoid_im.py:1110-1111)
+            self.sim.set_rfc_scale(self.cc_cfg.residual_force_scale * rate)
 
     def reset(self, env_ids=None):
         """reset_model (humanoid_im.py:1245-1299) on the listed envs; returns the obs tensor view (n_env, obs_dim)."""

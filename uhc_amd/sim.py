@@ -220,7 +220,8 @@ class EnvBatch:
 def make_ctrl(model, *, meta_pd: bool = True, meta_pd_joint: bool = False, residual_force: bool = True,
               residual_force_mode: str = "implicit", residual_force_scale: float = 100.0, residual_force_lim: float = 100.0,
               rfc_rate: float = 1.0, action_type: str = "position", pd_mul: float = 1.0, tq_mul: float = 1.0,
-              base_rot=(0.7071, 0.7071, 0.0, 0.0), n_substeps: int = 15) -> UhcCtrlDesc:
+              base_rot=(0.7071, 0.7071, 0.0, 0.0), n_substeps: int = 15, residual_force_bodies="all",
+              residual_force_torque: bool = True) -> UhcCtrlDesc:
     """UhcCtrlDesc from the reference's config knobs (copycat_config.py:86-113, humanoid_im.py:120-124,226-255)."""
     from ._capi import ctrl_desc
     from .smpllib.smpl_mujoco import SMPLConverter
@@ -229,14 +230,20 @@ def make_ctrl(model, *, meta_pd: bool = True, meta_pd_joint: bool = False, resid
     nu = model.nu
     rfc_mode = 0
     vf_dim = 0
+    vf_body, body_vf_dim, scale = None, 9, residual_force_scale * rfc_rate
     if residual_force:
-        if residual_force_mode != "implicit":
-            raise NotImplementedError("explicit RFC is a later row (SURVEY.md 8f-4)")
-        rfc_mode, vf_dim = 1, 6
+        if residual_force_mode == "implicit":
+            rfc_mode, vf_dim = 1, 6
+        else:  # explicit: one (contact point, force[, torque]) per body, bodies in SMPL joint order (humanoid_im.py:236-243)
+            from .smpllib.smpl_mujoco import SMPL_BONE_ORDER_NAMES
+            names = SMPL_BONE_ORDER_NAMES if residual_force_bodies == "all" else list(residual_force_bodies)
+            vf_body = [model.body_names.index(n) for n in names]
+            body_vf_dim = 6 + 3 * int(bool(residual_force_torque))
+            rfc_mode, vf_dim, scale = 2, body_vf_dim * len(vf_body), residual_force_scale  # rfc_explicit does not apply rfc_rate
     mp = 1 if meta_pd else (2 if meta_pd_joint else 0)
     mp_dim = 2 * n_substeps if mp == 1 else (2 * nu if mp == 2 else 0)
     return ctrl_desc(n_substeps=n_substeps, action_type=0 if action_type == "position" else 1, meta_pd=mp, rfc_mode=rfc_mode,
-                     action_dim=nu + vf_dim + mp_dim, rfc_scale=residual_force_scale * rfc_rate, rfc_lim=residual_force_lim,
+                     action_dim=nu + vf_dim + mp_dim, rfc_scale=scale, rfc_lim=residual_force_lim, vf_body=vf_body, body_vf_dim=body_vf_dim,
                      base_rot=base_rot, jkp=conv.get_new_jkp() * pd_mul, jkd=conv.get_new_jkd() * pd_mul,
                      torque_lim=conv.get_new_torque_limit() * tq_mul, a_scale=conv.get_new_a_scale())
 
