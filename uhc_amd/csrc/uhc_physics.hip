@@ -38,16 +38,34 @@ __device__ __forceinline__ double bcast(double v, int src) {  // src must be wav
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+// Cross-lane sums: four DPP steps (quad swaps, half-row and row mirrors: VALU-rate, no LDS crossbar round trip as
+// ds_bpermute-based shuffles have) leave each 16-lane row's sum in all of its lanes; the four rows are combined
+// through readlane.  ~5x cheaper than a shfl_xor butterfly for one wave per SIMD (tools/ubench/lat.hip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_QUAD_1032 0xB1
+#define DPP_QUAD_2301 0x4E
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f64<DPP_QUAD_1032>(v);
+    v += dpp_f64<DPP_QUAD_2301>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
 }
-__device__ __forceinline__ int wave_or(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
-    return v;
+__device__ __forceinline__ double wave_min(double v) {
+    v = fmin(v, dpp_f64<DPP_QUAD_1032>(v));
+    v = fmin(v, dpp_f64<DPP_QUAD_2301>(v));
+    v = fmin(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    v = fmin(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    return fmin(fmin(bcast(v, 0), bcast(v, 16)), fmin(bcast(v, 32), bcast(v, 48)));
 }
+__device__ __forceinline__ int wave_or(int v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }  // used as "any lane set"
 
 // ------------------------------------------------------------------ small math (registers)
 __device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
@@ -745,11 +763,16 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 for (int k = 0; k < 3; k++) dist += n[k] * (w[k] + xp2[k] - ppos[k]);
                 if (dist < bd) { bd = dist; bv = v; }
             }
+            {   // wave arg-min: DPP min, then the lowest vertex id among the lanes that hold it
+                const double mn = wave_min(bd);
+                const unsigned long long tie = __builtin_amdgcn_ballot_w64(bd == mn);
+                int cand = bd == mn ? bv : 0x7fffffff;
+                if (__popcll(tie) == 1) cand = __builtin_amdgcn_readlane(bv, __ffsll((long long)tie) - 1);
+                else {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double od = __shfl_xor(bd, o);
-                const int ov = __shfl_xor(bv, o);
-                if (od < bd || (od == bd && ov < bv)) { bd = od; bv = ov; }
+                    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+                }
+                bd = mn; bv = cand;
             }
             if (bd > margin) continue;
             // candidate 0 = support vertex, candidates 1.. = its hull neighbours (adjacency order)
@@ -1116,54 +1139,51 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     return 0;
 }
 
-// Lane I alone commits its row step: f <- fn, improvement += term.  Done under a one-lane exec mask so the
-// 64 unrolled steps need neither per-step lane-compare masks nor selects (exec is all-ones around this).
-template <int I>
-__device__ __forceinline__ void commit_lane(double& f, double fn, double& imp, double term) {
-    constexpr unsigned lo = I < 32 ? (1u << I) : 0u, hi = I < 32 ? 0u : (1u << (I - 32));
-    asm volatile(
-        "s_mov_b32 exec_lo, %4\n\t"
-        "s_mov_b32 exec_hi, %5\n\t"
-        "v_mov_b64 %0, %2\n\t"
-        "v_add_f64 %1, %1, %3\n\t"
-        "s_mov_b64 exec, -1"
-        : "+v"(f), "+v"(imp)
-        : "v"(fn), "v"(term), "n"(lo), "n"(hi));
+__device__ __forceinline__ double max_neg(double a, double b) {  // max(a, -b): one VOP3 with a source modifier
+    double r;
+    asm("v_max_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-// N = rows swept (multiple of 8 >= nefc; padding rows have f = res = 0 and A = 0, so their steps are no-ops).
-// Every lane evaluates the step of ITS row at each of the N unrolled steps; only lane i commits at step i,
-// then delta_i is broadcast (two v_readlane) and all residuals move by delta_i * A[:, i] (one FMA).
-// The reference solver's "cost went up by > 1e-10 -> revert the step" guard is omitted: in exact
-// arithmetic a projected 1-D minimisation never raises the cost, and the guard would put five more
-// dependent instructions on the serial chain (the general kernel and the oracle keep it).
+// N = rows swept (multiple of 8 >= nefc; padding rows have f = w = 0 and zero off-diagonals, so their steps are no-ops).
+// State per lane (= per row r): f_r and w_r = -res_r / A_rr, the step to the unconstrained 1-D minimiser of the row.
+// Brow[i] = A[r][i] / A[r][r] (unit diagonal).  Row step i: delta_i = max(w_i, -f_i) (the step clipped at f >= 0) is
+// computed by every lane for ITS row, lane i's value is broadcast (two v_readlane), every w moves by -delta_i * Brow[i]
+// (one FMA; lane i's own w drops by delta_i through the unit diagonal) and lane i alone adds delta_i to its f:
+// f += delta * e_i with a one-hot (1.0 in lane i) that moves up one lane per step by a DPP wave shift -- no exec
+// mask writes (an s_mov to exec between dependent VALU ops costs ~20 cycles each way with one wave per SIMD).
+// Serial chain per row: max -> readlane -> FMA; no reduction and no LDS traffic inside the sweep.
+// The dual cost 1/2 f'Af + f'b = sum_r 1/2 f_r (b_r + res_r) is evaluated once per sweep; the sweep's improvement is
+// the difference of two consecutive costs (the reference adds up the per-row decreases, which telescope to the same
+// number).  Its "cost went up by > 1e-10 -> revert the step" guard is omitted: in exact arithmetic a projected 1-D
+// minimisation never raises the cost (the general kernel and the oracle keep the guard).
 template <int N, bool FRIC>
-__device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, double& u, double diag,
+__device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, double& w, double diag, double b,
                                           bool fric, double floss, int iterations, double scale, double tolerance) {
-    // State per lane (= per row): f and u = f - res / A_rr, the unconstrained 1-D minimiser of the row.
-    // Brow[i] = A[r][i] / A[r][r] with a zero diagonal, so a change delta_i of row i moves every u by
-    // -delta_i * Brow[i] and leaves u_i itself unchanged.  Serial chain per row: max -> sub -> readlane -> FMA.
     int iters = 0;
+    double cost_prev = wave_sum(0.5 * f * fma(-w, diag, b));
+    const int hot0 = LANE == 0 ? 0x3FF00000 : 0;  // high word of 1.0
     for (int it = 0; it < iterations; it++) {
-        double improvement = 0;
+        int hot = hot0;
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            double fn;
+            double delta;
             if (FRIC) {
-                const double a = max0(u), c = clampd(u, -floss, floss);
-                fn = fric ? c : a;
+                const double lo = fric ? -floss - f : -f, hi = fric ? floss - f : 1e300;
+                delta = fmin(fmax(w, lo), hi);
             } else {
-                fn = max0(u);
+                delta = max_neg(w, f);
             }
-            const double delta = fn - f;
             const double di = bcast(delta, i);
-            // cost change of the step: delta * (1/2 delta A_rr + res), res = (f - u) A_rr   (off the serial chain)
-            const double term = -delta * diag * fma(0.5, delta, f - u);
-            commit_lane<i>(f, fn, improvement, term);
-            u = fma(-di, Brow[i], u);
+            w = fma(-di, Brow[i], w);
+            f = fma(delta, __hiloint2double(hot, 0), f);
+            hot = __builtin_amdgcn_update_dpp(0, hot, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
         });
         iters = it + 1;
-        if (wave_sum(improvement) * scale < tolerance) break;
+        const double cost = wave_sum(0.5 * f * fma(-w, diag, b));
+        const double improvement = cost_prev - cost;
+        cost_prev = cost;
+        if (improvement * scale < tolerance) break;
     }
     return iters;
 }
@@ -1202,25 +1222,27 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     double cost = valid ? f * (0.5 * (res - row.b) + row.b) : 0.0;
     cost = wave_sum(cost);
     if (cost > 0) { f = 0; res = row.b; }
-    double u = fma(-res, dinvA, f);
+    double w = valid ? -res * dinvA : 0.0;
+    if (!valid) f = 0.0;
     static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        Arow[s] = (s == LANE) ? 0.0 : Arow[s] * dinvA;  // Arow now holds Brow
+        Arow[s] = (s == LANE) ? 1.0 : Arow[s] * dinvA;  // Arow now holds Brow (unit diagonal)
     });
+    const double rb = valid ? row.b : 0.0;
     const double scale = 1.0 / (mb[A.o.meaninertia] * (T.nv > 1 ? T.nv : 1));
     const bool fric = row.type == ROW_FRICTION;
     const bool any_fric = wave_or(fric ? 1 : 0) != 0;
     int iters;
-    if (any_fric) iters = pgs_sweeps<UHC_WAVE, true>(Arow, f, u, diag, fric, row.floss, T.iterations, scale, T.tolerance);
+    if (any_fric) iters = pgs_sweeps<UHC_WAVE, true>(Arow, f, w, diag, rb, fric, row.floss, T.iterations, scale, T.tolerance);
     else switch ((nefc + 7) >> 3) {
-        case 1: iters = pgs_sweeps<8, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 2: iters = pgs_sweeps<16, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 3: iters = pgs_sweeps<24, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 4: iters = pgs_sweeps<32, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 5: iters = pgs_sweeps<40, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 6: iters = pgs_sweeps<48, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        case 7: iters = pgs_sweeps<56, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
-        default: iters = pgs_sweeps<64, false>(Arow, f, u, diag, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 1: iters = pgs_sweeps<8, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 2: iters = pgs_sweeps<16, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 3: iters = pgs_sweeps<24, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 4: iters = pgs_sweeps<32, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 5: iters = pgs_sweeps<40, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 6: iters = pgs_sweeps<48, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        case 7: iters = pgs_sweeps<56, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
+        default: iters = pgs_sweeps<64, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
     }
     row.f = f;
     PROF(11)
