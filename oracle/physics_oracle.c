@@ -776,7 +776,7 @@ void orc_pd_torque(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, cons
                    const double* target_base, int it) {
     int nv = m->nv, nu = m->nu;
     double dt = m->timestep;
-    int vf_dim = c->rfc_mode == 1 ? 6 : 0;
+    int vf_dim = c->rfc_mode == 1 ? 6 : c->rfc_mode == 2 ? c->n_vf_body * c->body_vf_dim : 0; /* humanoid_im.py:233-243 */
     double* kp = calloc(nv, 8); double* kd = calloc(nv, 8); double* qerr = calloc(nv, 8);
     double* rhs = calloc(nv, 8); double* MK = malloc(d->nM * 8);
     double skp = 1, skd = 1;

@@ -235,3 +235,21 @@ def test_explicit_rfc_equals_virtual_work(model, standing):
             omega = np.array([dR[2, 1], dR[0, 2], dR[1, 0]])
             power += f[i] @ pdot + tq[i] @ omega
         assert qfrc @ v == pytest.approx(power, rel=1e-6, abs=1e-6)
+
+
+def test_meta_pd_gains_follow_the_residual_block(model, standing):
+    """The meta-PD scales sit after the residual-force block whatever its width (humanoid_im.py:1054-1060): the same joint
+    residuals and gain scales must give the same torques under the implicit (6) and the explicit (24 x 9) layouts."""
+    from oracle.physics import OracleSim
+    from uhc_amd.sim import make_ctrl
+    ci, ce = make_ctrl(model), make_ctrl(model, residual_force_mode="explicit")
+    rng = np.random.default_rng(31)
+    joint, meta = rng.normal(scale=0.3, size=69), rng.normal(scale=0.5, size=30)
+    qpos = standing["qpos"].copy()
+    qpos[7:] += rng.normal(scale=0.1, size=69)
+    tq = []
+    for c, nvf in ((ci, 6), (ce, 216)):
+        o = OracleSim(model, c)
+        o.set_state(qpos, rng.normal(size=75) * 0)
+        tq.append(o.pd_torque(np.r_[joint, rng.normal(size=nvf), meta], standing["qpos"][7:], 7).copy())
+    np.testing.assert_array_equal(tq[0], tq[1])

@@ -295,7 +295,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.dof_bodyid, nv), &T.dof_bodyid)); TRY(upload(b, ivec(d.dof_jntid, nv), &T.dof_jntid));
     TRY(upload(b, ivec(d.dof_parentid, nv), &T.dof_parentid)); TRY(upload(b, ivec(d.dof_madr, nv + 1), &T.dof_madr));
     TRY(upload(b, dof_depth, &T.dof_depth)); TRY(upload(b, dof_ndesc, &T.dof_ndesc));
-    TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, e_adr, &T.e_adr)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
+        TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, e_adr, &T.e_adr)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
     TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
     TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
@@ -349,7 +349,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.rootcom = carve(3 * nb); L.cinert = carve(10 * nb); L.crb = carve(10 * nb); L.cvel = carve(6 * nb);
     L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
     L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
-    L.M = carve(T.nM); L.LD = carve(T.nM); L.dinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
+    L.M = carve(T.nM); L.LD = carve(T.nM + 2); L.dinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
     L.vec = carve(nv); L.z = carve(nv); L.eadr = carve((T.nM + 3) / 4 + 1); L.zero = carve(2);
     L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
     L.Y = carve(UHC_MAXEFC * YS);
@@ -368,7 +368,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
         F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.vec = F.z;
         F.eadr = carve((T.nM + 3) / 4 + 1); F.zero = carve(2);
-        F.LD = carve(T.nM); F.M = F.LD;
+        F.LD = carve(T.nM + 2); F.M = F.LD;
         F.cdof = carve(6 * nv);
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);
         const int base = off;
@@ -403,6 +403,47 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         b->lds_bytes_fast = (size_t)off * sizeof(double);
         const char* env = getenv("UHC_FORCE_GENERAL");
         b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024 && T.nM <= 64 * 24 /* UHC_MREG register tile */;
+    }
+    // ---- static schedules for the factorisation and the triangular solves (see DevTopo).  Addresses are LDS byte
+    //      addresses of the FAST layout's LD buffer (the general kernel adds its own LD offset, KernelArgs::ld_delta).
+    {
+        std::vector<unsigned int> fac_prog, sol_back((size_t)std::max(nv - 1, 1) * 64, 0), sol_fwd((size_t)std::max(nv - 1, 1) * 64, 0);
+        const unsigned ldb = (unsigned)A.lf.LD * 8u;
+        auto adr = [&](int rel) { return ldb + 8u * (unsigned)rel; };
+        const int ZERO = T.nM, DUMP = T.nM + 1;
+        if (adr(DUMP) + 8 > 65536u || (unsigned)A.l.LD * 8u + 8u * (T.nM + 2) > 65536u) { delete b; return fail("uhc_batch_create: LD buffer beyond the 16-bit schedule addresses"); }
+        for (int k = nv - 1; k >= 1; k--) {
+            const int dk = dof_depth[k], kk = d.dof_madr[k];
+            if (!dk) continue;
+            size_t n0 = fac_prog.size();
+            int anc = k;
+            for (int a = 1; a <= dk; a++) {
+                anc = d.dof_parentid[anc];
+                for (int t = 0; t <= dk - a; t++) {  // LD[row(anc) + t] -= (LD[kk + a] / D_k) * LD[kk + a + t]
+                    fac_prog.push_back(adr(kk + a) | (adr(kk + a + t) << 16));
+                    fac_prog.push_back(adr(d.dof_madr[anc] + t));
+                }
+            }
+            while ((fac_prog.size() - n0) % 128) { fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16)); fac_prog.push_back(adr(DUMP)); }
+        }
+        T.fac_nslot = (int)(fac_prog.size() / 128);
+        for (int q = 0; q < 8 * 64; q++) { fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16)); fac_prog.push_back(adr(DUMP)); }  // look-ahead slack
+        auto entry = [&](int i, int j) -> unsigned {  // address of L[i][j] if j is a proper ancestor of i, else the zero slot
+            if (i >= nv || j >= nv || j >= i || dof_depth[j] >= dof_depth[i]) return adr(ZERO);
+            return dof_anc[(size_t)i * YS + dof_depth[j]] == j ? adr(d.dof_madr[i] + dof_depth[i] - dof_depth[j]) : adr(ZERO);
+        };
+        for (int s2 = 0; s2 < nv - 1; s2++)
+            for (int l = 0; l < 64; l++) {
+                const int i = nv - 1 - s2;
+                sol_back[(size_t)s2 * 64 + l] = entry(i, l) | (entry(i, l + 64) << 16);
+                sol_fwd[(size_t)s2 * 64 + l] = entry(l, s2) | (entry(l + 64, s2) << 16);
+            }
+        if (nv > 128) { delete b; return fail("uhc_batch_create: nv %d > 128 unsupported", nv); }
+        std::vector<int> cnt(nv, 0);
+        T.act_one_per_dof = 1;
+        for (int a = 0; a < d.nu; a++) if (++cnt[d.actuator_dofid[a]] > 1) T.act_one_per_dof = 0;
+        TRY(upload(b, fac_prog, &T.fac_prog)); TRY(upload(b, sol_back, &T.sol_back)); TRY(upload(b, sol_fwd, &T.sol_fwd));
+        A.ld_delta = (A.l.LD - A.lf.LD) * 8;
     }
     HIP_OK(uhc_set_lds_limit(b->lds_bytes, b->lds_bytes_fast));
 

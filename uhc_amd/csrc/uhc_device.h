@@ -30,6 +30,13 @@ struct DevTopo {
     const int *pair_g1, *pair_g2;  // statically filtered candidate geom pairs (g1 = plane, g2 = mesh)
     const int* actuator_dofid;
     int body_maxdepth;
+    // static schedules of the tree-sparse factorisation / substitutions (uhc_capi.cpp).  Entries are LDS byte addresses
+    // inside the LD buffer, whose slots nM (always 0.0) and nM+1 (write-only dump) serve idle lanes.
+    const unsigned int* fac_prog;  // [fac_nslot (+8)][64][2]  {af | ar << 16, ao}:  LD[ao] -= (LD[af] / D_k) * LD[ar]; step k owns ceil(dk (dk+1) / 128) slots
+    const unsigned int* sol_back;  // [nv-1][64] step s <-> i = nv-1-s : address of L[i][j] for j = lane (low 16) and lane+64 (high 16)
+    const unsigned int* sol_fwd;   // [nv-1][64] step s <-> j = s      : address of L[i][j] for i = lane (low 16) and lane+64 (high 16)
+    int fac_nslot;
+    int act_one_per_dof;           // every dof is driven by at most one actuator (lane-parallel accumulation)
 };
 
 // offsets (in doubles) of the numeric arrays inside one model blob
@@ -75,6 +82,7 @@ struct KernelArgs {
     DevLds l;   // general kernel: every buffer separate, 128 rows
     DevLds lf;  // fast kernel: phase-aliased, 64 rows, packed Yhat
     int ycap;   // doubles available for packed Yhat rows in the fast layout
+    int ld_delta;  // bytes to add to the schedule tables' LDS addresses in the general layout
     DevCtrl c;
     DevState s;
     int n_env;

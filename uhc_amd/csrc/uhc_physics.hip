@@ -398,71 +398,76 @@ __device__ __forceinline__ int pk_of(const LaneConst& c, int i) {  // i wave-uni
     return i < UHC_WAVE ? __builtin_amdgcn_readlane(c.pk0, i) : __builtin_amdgcn_readlane(c.pk1, i - UHC_WAVE);
 }
 
-// in-place L^T D L of the tree-sparse matrix at S[ld..]; also dinv[i] = 1/D[i].
-// Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t)
-// updates of one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.
-// eadr[e] (LDS, 16-bit) gives for the sparse entry e = (k, a-th ancestor) the row address of that ancestor.
-// One elimination step restricted to NP passes of 4 ancestors each, written as three straight-line phases so
-// that the LDS latencies overlap: (1) every load that depends only on k, (2) the ancestor-row loads (their
-// base addresses come from phase 1), (3) FMAs and predicated stores.  Idle lanes read a zero slot.
-template <int NP>
-__device__ __forceinline__ void factor_step(double* LD, const unsigned short* eadr, int zero, int kk, int dk, int tl, int al) {
-    int base[NP];
-    double f[NP], r0[NP], r1[NP], o0[NP], o1[NP];
-    const double Dk = LD[kk];
-    static_for<0, NP>([&](auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        const int a = 1 + 4 * p + al, n = dk - a + 1;
-        const bool va = a <= dk;
-        base[p] = eadr[va ? kk + a : kk];
-        f[p] = LD[va ? kk + a : zero];
-        r0[p] = LD[(va && tl < n) ? kk + a + tl : zero];
-        r1[p] = LD[(va && tl + 16 < n) ? kk + a + tl + 16 : zero];
-    });
-    static_for<0, NP>([&](auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        const int a = 1 + 4 * p + al, n = dk - a + 1;
-        const bool va = a <= dk;
-        o0[p] = LD[(va && tl < n) ? base[p] + tl : zero];
-        o1[p] = LD[(va && tl + 16 < n) ? base[p] + tl + 16 : zero];
+// In-place L^T D L of the tree-sparse matrix in the LD buffer (same elimination order as MuJoCo's mj_factorM [MJ-ext]);
+// also dinv[i] = 1/D[i].  The updates of elimination step k,  LD[row(anc_a) + t] -= (LD[kk+a] / D_k) * LD[kk+a+t]  for
+// every ancestor a and offset t, depend on the tree only, so the host lays them out once as a dense program of
+// 64-lane slots (DevTopo::fac_prog): per slot a lane gets three ready LDS byte addresses in one 64-bit word -- no
+// per-step predicates, address arithmetic or partially filled passes.  A step issues the loads of all its NS (<= 8)
+// slots before the first store, so their LDS latencies overlap with each other and with the division 1 / D_k (D_k of
+// the next step is fetched right after this step's stores); the program words of the next step stream in from L2
+// meanwhile.  Idle lanes read the zero slot and write the dump slot.  The LDS queue of one wave is in order, so
+// consecutive steps need no barrier.
+struct FacWord { unsigned int a, o; };
+__device__ __forceinline__ double lds_at(const char* SB, unsigned int byte_off) { return *(const double*)(SB + byte_off); }
+template <int NS>
+__device__ __forceinline__ void factor_step(char* SB, const FacWord (&w)[8], double Dk, double fraw, unsigned int norm_adr) {
+    double f[NS], r[NS], o[NS];
+    static_for<0, NS>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        f[q] = lds_at(SB, w[q].a & 0xffffu); r[q] = lds_at(SB, w[q].a >> 16); o[q] = lds_at(SB, w[q].o);
     });
     const double inv = 1.0 / Dk;
-    static_for<0, NP>([&](auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        const int a = 1 + 4 * p + al, n = dk - a + 1;
-        const bool va = a <= dk;
-        const double fp = f[p] * inv;
-        if (va && tl < n) LD[base[p] + tl] = fma(-fp, r0[p], o0[p]);
-        if (va && tl + 16 < n) LD[base[p] + tl + 16] = fma(-fp, r1[p], o1[p]);
-        if (va && tl == 0) LD[kk + a] = fp;
+    static_for<0, NS>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        *(double*)(SB + w[q].o) = fma(-(f[q] * inv), r[q], o[q]);
     });
+    *(double*)(SB + norm_adr) = fraw * inv;
 }
-
-// in-place L^T D L of the tree-sparse matrix at S[ld..]; also dinv[i] = 1/D[i].
-// Sequential over k (same elimination order as MuJoCo's mj_factorM); the (ancestor a, offset t) updates of
-// one k run in parallel: lane = 16*a_sub + t_sub, 4 ancestors x 32 offsets per pass.  eadr[e] (LDS, 16-bit)
-// gives for the sparse entry e = (k, a-th ancestor) the row address of that ancestor.  Row k itself is only
-// read during its step, except for its normalisation LD[kk+a] <- LD[kk+a] / D_k, which is stored after every
-// load of the step has been issued (lock-step), so one barrier per k suffices.
 template <bool FAST>
 __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     double* LD = S + ld;
-    const unsigned short* eadr = (const unsigned short*)(S + L.eadr);
-    const int zero = L.zero - ld;  // index of the zero slot relative to LD
-    const int tl = LANE & 15, al = LANE >> 4;
-    for (int k = T.nv - 1; k >= 1; k--) {
-        const int pk = pk_of(LC, k);
-        const int dk = (pk >> 16) & 0xff;  // number of proper ancestors
-        if (dk == 0) continue;
-        const int kk = pk & 0xffff;
-        if (dk <= 8) factor_step<2>(LD, eadr, zero, kk, dk, tl, al);
-        else if (dk <= 16) factor_step<4>(LD, eadr, zero, kk, dk, tl, al);
-        else if (dk <= 24) factor_step<6>(LD, eadr, zero, kk, dk, tl, al);
-        else factor_step<8>(LD, eadr, zero, kk, dk, tl, al);
-        wsync();
+    char* SB = (char*)S + (FAST ? 0 : A.ld_delta);  // schedule addresses are byte offsets in the fast layout
+    constexpr int Q = 8;
+    const unsigned int zero_adr = (unsigned)(A.lf.LD + T.nM) * 8u, dump_adr = zero_adr + 8u, ld_adr = (unsigned)A.lf.LD * 8u;
+    auto depth_of = [&](int k) __attribute__((always_inline)) { return (pk_of(LC, k) >> 16) & 0xff; };
+    auto next_step = [&](int k) __attribute__((always_inline)) {  // next k' < k that has ancestors (0 = none)
+        do k--; while (k >= 1 && depth_of(k) == 0);
+        return k < 1 ? 0 : k;
+    };
+    const FacWord* pw = (const FacWord*)T.fac_prog + LANE;
+    FacWord wn[Q];
+    int k = next_step(T.nv);
+#pragma unroll
+    for (int q = 0; q < Q; q++) wn[q] = pw[q * UHC_WAVE];
+    double Dk = k >= 1 ? LD[pk_of(LC, k) & 0xffff] : 1.0;
+    while (k >= 1) {
+        const int pk = pk_of(LC, k), kk = pk & 0xffff, dk = (pk >> 16) & 0xff;
+        const int ns = (dk * (dk + 1) / 2 + UHC_WAVE - 1) >> 6;
+        FacWord w[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) w[q] = wn[q];
+        pw += ns * UHC_WAVE;
+#pragma unroll
+        for (int q = 0; q < Q; q++) wn[q] = pw[q * UHC_WAVE];  // the table carries 8 slots of slack
+        const bool na = LANE < dk;
+        const unsigned int norm_adr = na ? ld_adr + 8u * (unsigned)(kk + 1 + LANE) : dump_adr;
+        const double fraw = lds_at(SB, na ? norm_adr : zero_adr);
+        switch (ns) {
+            case 1: factor_step<1>(SB, w, Dk, fraw, norm_adr); break;
+            case 2: factor_step<2>(SB, w, Dk, fraw, norm_adr); break;
+            case 3: factor_step<3>(SB, w, Dk, fraw, norm_adr); break;
+            case 4: factor_step<4>(SB, w, Dk, fraw, norm_adr); break;
+            case 5: factor_step<5>(SB, w, Dk, fraw, norm_adr); break;
+            case 6: factor_step<6>(SB, w, Dk, fraw, norm_adr); break;
+            case 7: factor_step<7>(SB, w, Dk, fraw, norm_adr); break;
+            default: factor_step<8>(SB, w, Dk, fraw, norm_adr); break;
+        }
+        k = next_step(k);
+        if (k >= 1) Dk = LD[pk_of(LC, k) & 0xffff];
     }
+    wsync();
     if (LC.v0) S[L.dinv + LANE] = 1.0 / LD[LC.m0];
     if (LC.v1) S[L.dinv + LANE + UHC_WAVE] = 1.0 / LD[LC.m1];
     wsync();
@@ -470,70 +475,52 @@ __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld,
 
 // x = M^-1 x for one right-hand side held in registers (lane owns dofs LANE and LANE+64).
 // half: 0 = full solve, 1 = only  L^-1  (used after the constraint solve: qacc += L^-1 D^-1/2 z).
-// The serial chain is register-only (v_readlane + FMA); the L entries of U consecutive steps are
-// fetched from LDS up front so their latency overlaps.
+// The serial chain is register-only (v_readlane + FMA).  Which L entry a lane needs at each step is static: the
+// host tables sol_back / sol_fwd hold its LDS address (or the zero slot) for both of the lane's dofs; the words of
+// the next block of U steps are fetched while the current block runs, the block's L entries are read up front.
 struct DofVec { double a, b; };
 __device__ __forceinline__ double dv_get(const DofVec& x, int i) { return i < UHC_WAVE ? bcast(x.a, i) : bcast(x.b, i - UHC_WAVE); }
+template <bool BACK>
+__device__ __forceinline__ void solve_sweep(const unsigned int* tab, const char* SB, int n, DofVec& x) {
+    constexpr int U = 8;
+    unsigned int wn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) wn[u] = tab[(size_t)(u < n ? u : n - 1) * UHC_WAVE];
+    for (int s0 = 0; s0 < n; s0 += U) {
+        double l0[U], l1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned int ww = wn[u];
+            const int sn = s0 + U + u;
+            wn[u] = tab[(size_t)(sn < n ? sn : n - 1) * UHC_WAVE];
+            l0[u] = lds_at(SB, ww & 0xffffu);
+            l1[u] = lds_at(SB, ww >> 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u;
+            if (s < n) {
+                const double xs = dv_get(x, BACK ? n - s : s);
+                x.a = fma(-l0[u], xs, x.a);
+                x.b = fma(-l1[u], xs, x.b);
+            }
+        }
+    }
+}
 template <bool FAST>
 __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
-    const double* LD = S + ld;
-    const int zero = L.zero - ld;
-    const int i0 = LANE, i1 = LANE + UHC_WAVE;
-    constexpr int U = 8;
+    const char* SB = (const char*)S + (FAST ? 0 : A.ld_delta);
+    if (T.nv < 2) { if (!half && LC.v0) x.a *= S[L.dinv + LANE]; return; }
     if (!half) {
         // x <- L^-T x : for i descending, every ancestor j of i:  x[j] -= L[i][j] x[i]
-        for (int ib = T.nv - 1; ib >= 1; ib -= U) {
-            double l0[U], l1[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = ib - u;
-                l0[u] = 0; l1[u] = 0;
-                if (i >= 1) {
-                    const int pk = pk_of(LC, i), mi = pk & 0xffff, di = (pk >> 16) & 0xff;
-                    const bool c0 = LC.v0 && i > i0 && i <= i0 + LC.n0, c1 = LC.v1 && i > i1 && i <= i1 + LC.n1;
-                    l0[u] = LD[c0 ? mi + di - LC.d0 : zero];
-                    l1[u] = LD[c1 ? mi + di - LC.d1 : zero];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = ib - u;
-                if (i >= 1) {
-                    const double xi = dv_get(x, i);
-                    x.a -= l0[u] * xi;
-                    x.b -= l1[u] * xi;
-                }
-            }
-        }
-        if (LC.v0) x.a *= S[L.dinv + i0];
-        if (LC.v1) x.b *= S[L.dinv + i1];
+        solve_sweep<true>(T.sol_back + LANE, SB, T.nv - 1, x);
+        if (LC.v0) x.a *= S[L.dinv + LANE];
+        if (LC.v1) x.b *= S[L.dinv + LANE + UHC_WAVE];
     }
     // x <- L^-1 x : for j ascending, every descendant i of j:  x[i] -= L[i][j] x[j]
-    for (int jb = 0; jb < T.nv - 1; jb += U) {
-        double l0[U], l1[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int j = jb + u;
-            l0[u] = 0; l1[u] = 0;
-            if (j < T.nv - 1) {
-                const int pk = pk_of(LC, j), dj = (pk >> 16) & 0xff, nj = (pk >> 24) & 0xff;
-                const bool c0 = LC.v0 && i0 > j && i0 <= j + nj, c1 = LC.v1 && i1 > j && i1 <= j + nj;
-                l0[u] = LD[c0 ? LC.m0 + LC.d0 - dj : zero];
-                l1[u] = LD[c1 ? LC.m1 + LC.d1 - dj : zero];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int j = jb + u;
-            if (j < T.nv - 1) {
-                const double xj = dv_get(x, j);
-                x.a -= l0[u] * xj;
-                x.b -= l1[u] * xj;
-            }
-        }
-    }
+    solve_sweep<false>(T.sol_fwd + LANE, SB, T.nv - 1, x);
 }
 
 // ------------------------------------------------------------------ P7 velocities + bias forces
@@ -647,7 +634,9 @@ __device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, 
         S[L.smooth + i] = f;
     }
     wsync();
-    if (LANE == 0)
+    if (T.act_one_per_dof) {
+        for (int a = LANE; a < T.nu; a += UHC_WAVE) S[L.smooth + T.actuator_dofid[a]] += mb[A.o.actuator_gear + a] * S[L.ctrl + a];
+    } else if (LANE == 0)
         for (int a = 0; a < T.nu; a++) S[L.smooth + T.actuator_dofid[a]] += mb[A.o.actuator_gear + a] * S[L.ctrl + a];
     wsync();
     DofVec x;
@@ -1362,7 +1351,7 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
     const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
     const double dt = T.timestep;
-    const int nu = T.nu, vf = C.rfc_mode == 1 ? 6 : 0;
+    const int nu = T.nu, vf = C.rfc_mode == 1 ? 6 : C.rfc_mode == 2 ? C.n_vf_body * C.body_vf_dim : 0;
     double skp = 1, skd = 1;
     if (C.meta_pd == 1) {
         skp = clampd(action[nu + vf + it] + 1, 0, 10);
@@ -1506,7 +1495,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         const unsigned int* src = (const unsigned int*)T.e_adr;
         for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
     }
-    if (LANE == 0) S[L.zero] = 0.0;  // slot idle lanes read instead of branching around LDS loads
+    if (LANE == 0) { S[L.zero] = 0.0; S[L.LD + T.nM] = 0.0; S[L.LD + T.nM + 1] = 0.0; }  // slots idle lanes read / write instead of branching
     if (MODE == 0 && A.c.rfc_mode == 2) {  // explicit RFC reads the kinematics of the previous forward pass
         for (int i = LANE; i < 6 * T.nv; i += UHC_WAVE) S[L.cdof + i] = A.s.cdof[(size_t)env * 6 * T.nv + i];
         for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
