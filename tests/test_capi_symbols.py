@@ -23,7 +23,8 @@ def test_header_symbols_are_exported_and_listed():
         assert hasattr(L, n), f"{n} declared in include/uhc_amd.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     L.uhc_abi_version.restype = ctypes.c_int32
-    assert L.uhc_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "uhc_amd.h")).read()
+    assert L.uhc_abi_version() == int(re.search(r"#define UHC_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_product_package_never_imports_the_oracle():
