@@ -248,11 +248,6 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         int adr = d.dof_madr[i];
         for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) { m_row[adr] = (short)i; m_col[adr] = (short)j; }
     }
-    std::vector<unsigned short> e_adr(T.nM + 2, 0);
-    for (int i = 0; i < nv; i++) {
-        int adr = d.dof_madr[i];
-        for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) e_adr[adr] = (unsigned short)d.dof_madr[j];
-    }
     std::vector<unsigned char> ncommon((size_t)nv * nv, 0);
     for (int i = 0; i < nv; i++)
         for (int j = 0; j < nv; j++) {
@@ -295,7 +290,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.dof_bodyid, nv), &T.dof_bodyid)); TRY(upload(b, ivec(d.dof_jntid, nv), &T.dof_jntid));
     TRY(upload(b, ivec(d.dof_parentid, nv), &T.dof_parentid)); TRY(upload(b, ivec(d.dof_madr, nv + 1), &T.dof_madr));
     TRY(upload(b, dof_depth, &T.dof_depth)); TRY(upload(b, dof_ndesc, &T.dof_ndesc));
-        TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, e_adr, &T.e_adr)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
+        TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
     TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
     TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
@@ -349,8 +344,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.rootcom = carve(3 * nb); L.cinert = carve(10 * nb); L.crb = carve(10 * nb); L.cvel = carve(6 * nb);
     L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
     L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
-    L.M = carve(T.nM); L.LD = carve(T.nM + 2); L.dinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
-    L.vec = carve(nv); L.z = carve(nv); L.eadr = carve((T.nM + 3) / 4 + 1); L.zero = carve(2);
+    L.M = carve(T.nM); L.LD = carve(T.nM + 2); L.dinv = carve(nv); L.sdinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
+    L.vec = carve(nv); L.z = carve(nv); L.zero = carve(2);
     L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
     L.Y = carve(UHC_MAXEFC * YS);
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
@@ -366,8 +361,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         DevLds& F = A.lf;
         off = 0;
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
-        F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.vec = F.z;
-        F.eadr = carve((T.nM + 3) / 4 + 1); F.zero = carve(2);
+        F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.sdinv = carve(nv); F.vec = F.z;
+        F.zero = carve(2);
         F.LD = carve(T.nM + 2); F.M = F.LD;
         F.cdof = carve(6 * nv);
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);
@@ -438,6 +433,13 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
                 sol_back[(size_t)s2 * 64 + l] = entry(i, l) | (entry(i, l + 64) << 16);
                 sol_fwd[(size_t)s2 * 64 + l] = entry(l, s2) | (entry(l + 64, s2) << 16);
             }
+        std::vector<unsigned int> chain((size_t)nv * 32, adr(0) << 16);
+        for (int i = 0; i < nv; i++)
+            for (int q = 0; q <= dof_depth[i]; q++) {
+                const int a = dof_anc[(size_t)i * YS + q];
+                chain[(size_t)i * 32 + q] = (unsigned)a | (adr(d.dof_madr[a]) << 16);
+            }
+        TRY(upload(b, chain, &T.chain));
         if (nv > 128) { delete b; return fail("uhc_batch_create: nv %d > 128 unsupported", nv); }
         std::vector<int> cnt(nv, 0);
         T.act_one_per_dof = 1;
@@ -452,7 +454,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * T.nM, &S.qM_work)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));

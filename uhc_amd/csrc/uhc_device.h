@@ -23,7 +23,6 @@ struct DevTopo {
     const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_madr, *dof_depth, *dof_ndesc;
     const short* dof_anc;  // [nv][maxdepth+1]: ancestor of dof i at depth q (q <= depth(i)), anc[i][depth(i)] = i
     const short *m_row, *m_col;  // [nM] sparse-M entry -> (i, j)
-    const unsigned short* e_adr;  // [nM (+pad)] sparse entry (k, a-th ancestor) -> row address of that ancestor
     const unsigned char* dof_ncommon;  // [nv][nv] number of common chain entries of two dofs (depth of LCA + 1, 0 if none)
     const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
     const int *mesh_adjadr, *mesh_adj;
@@ -35,6 +34,7 @@ struct DevTopo {
     const unsigned int* fac_prog;  // [fac_nslot (+8)][64][2]  {af | ar << 16, ao}:  LD[ao] -= (LD[af] / D_k) * LD[ar]; step k owns ceil(dk (dk+1) / 128) slots
     const unsigned int* sol_back;  // [nv-1][64] step s <-> i = nv-1-s : address of L[i][j] for j = lane (low 16) and lane+64 (high 16)
     const unsigned int* sol_fwd;   // [nv-1][64] step s <-> j = s      : address of L[i][j] for i = lane (low 16) and lane+64 (high 16)
+    const unsigned int* chain;     // [nv][32] position q on the chain of dof i: (q-th dof from the root | LDS byte address of its L row << 16)
     int fac_nslot;
     int act_one_per_dof;           // every dof is driven by at most one actuator (lane-parallel accumulation)
 };
@@ -54,7 +54,7 @@ struct DevLds {
     int qpos, qvel, qacc, ctrl, applied;
     int xpos, xquat, xmat, xipos, ximat, rootcom, cinert, crb, cvel, cacc, cfrc;
     int xanchor, xaxis, cdof, cdofdot;
-    int M, LD, dinv, bias, smooth, vec, z, eadr, zero;
+    int M, LD, dinv, sdinv, bias, smooth, vec, z, zero;
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
     int total;  // doubles
 };
@@ -69,6 +69,7 @@ struct DevCtrl {
 
 struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
+    double* qM_work;  // fast kernel: M between the substeps of one launch
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     const int* env_model;

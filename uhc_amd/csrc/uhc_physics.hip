@@ -329,7 +329,7 @@ __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb,
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
 template <bool FAST>
-__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, MReg& mr) {
+__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, double* Mw) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
@@ -365,7 +365,7 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
             if (i == j) v += mb[A.o.dof_armature + i];
             S[L.M + e] = v;
         }
-        if (FAST) mr.v[m] = v;
+        if (FAST && e < T.nM) Mw[e] = v;  // the fast layout factorises in place: M itself waits in HBM for the next PD solve
     }
     if (!FAST)
         for (int e = LANE + UHC_WAVE * UHC_MREG; e < T.nM; e += UHC_WAVE) {  // models larger than the register tile (general kernel only)
@@ -468,8 +468,8 @@ __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld,
         if (k >= 1) Dk = LD[pk_of(LC, k) & 0xffff];
     }
     wsync();
-    if (LC.v0) S[L.dinv + LANE] = 1.0 / LD[LC.m0];
-    if (LC.v1) S[L.dinv + LANE + UHC_WAVE] = 1.0 / LD[LC.m1];
+    if (LC.v0) { const double di = 1.0 / LD[LC.m0]; S[L.dinv + LANE] = di; S[L.sdinv + LANE] = sqrt(di); }
+    if (LC.v1) { const double di = 1.0 / LD[LC.m1]; S[L.dinv + LANE + UHC_WAVE] = di; S[L.sdinv + LANE + UHC_WAVE] = sqrt(di); }
     wsync();
 }
 
@@ -933,7 +933,7 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
         }
         double da = R;
         for (int q = 0; q < len; q++) {
-            const double y = Y[q] * sqrt(S[L.dinv + anc[q]]);
+            const double y = Y[q] * S[L.sdinv + anc[q]];
             Y[q] = y;
             da += y * y;
         }
@@ -1038,11 +1038,18 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 }
 
 // returns 0 on success, 1 if the packed Yhat rows do not fit (-> the env is redone by the general kernel)
-__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row) {
+// The row's Yhat = D^-1/2 L^-T J^T entries along its dof chain are built in REGISTERS (Y[q], q = position on the chain,
+// compile-time indices): Jacobian, the three J.v products, the back substitution and the D^-1/2 scaling never round-trip
+// through LDS (a lane-serial read-modify-write chain through LDS costs ~100 cycles per update with one wave per SIMD).
+// The unrolled loops skip, uniformly, the chain positions beyond the longest row of the wave.  T.chain[dof][q] packs
+// (q-th dof of the chain | LDS byte address of that dof's L row << 16); positions past the chain end point at safe
+// finite data and meet Y = 0.  The finished rows are also stored to LDS (packed) for the A build of the other lanes.
+#define UHC_YM 32
+__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, double (&Y)[UHC_YM]) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
-    const int YS = T.maxdepth + 1;
+    const char* SB = (const char*)S;
     const int r = LANE;
     const bool valid = r < nefc;
     RowMisc rm = {0, 0, 0, 0};
@@ -1052,81 +1059,112 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     int total;
     row.yoff = wave_excl_scan(row.len, &total);
     row.R = 1; row.b = 0; row.f = 0; row.floss = 0; row.diag = 1;
-    if (total > A.ycap) return 1;
-    if (valid) {
-        const int last = rm.last, len = row.len;
-        const short* anc = T.dof_anc + last * YS;
-        double* Y = S + L.Y + row.yoff;
-        double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
-        if (rm.type == ROW_FRICTION || rm.type == ROW_LIMIT) {
-            const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
-            const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
-            K = 1.0 / (dmax * dmax * timeconst * timeconst);
-            B = 2.0 / (dmax * timeconst);
-            for (int q = 0; q < len; q++) Y[q] = 0;
-            if (rm.type == ROW_LIMIT) {
-                const int j = rm.aux;
-                const double v = S[L.qpos + T.jnt_qposadr[j]];
-                margin = mb[A.o.jnt_margin + j];
-                pos = rm.edge < 0 ? v - mb[A.o.jnt_range + 2 * j] : mb[A.o.jnt_range + 2 * j + 1] - v;
-                Y[len - 1] = -(double)rm.edge;
-            } else {
-                floss = mb[A.o.dof_frictionloss + last];
-                Y[len - 1] = 1;
-            }
-            diagApprox = mb[A.o.dof_invweight0 + last];
-            imp = impedance(dsolimp, pos, margin);
+    if (total + 8 > A.ycap) return 1;
+    const int len = row.len;
+    int maxlen = len;  // wave maximum (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    unsigned int ch[UHC_YM];
+    {
+        const unsigned int* chain = T.chain + (size_t)rm.last * UHC_YM;
+        static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { constexpr int q = decltype(qc)::value; ch[q] = chain[q]; });
+    }
+    const bool is_con = valid && (rm.type == ROW_CONTACT || rm.type == ROW_PYR);
+    double pos = 0, margin = 0, diagApprox = 0, K = 0, B = 0, imp = 1, floss = 0, unit = 0;
+    double off[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+    if (valid && !is_con) {
+        const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+        const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
+        K = 1.0 / (dmax * dmax * timeconst * timeconst);
+        B = 2.0 / (dmax * timeconst);
+        if (rm.type == ROW_LIMIT) {
+            const int j = rm.aux;
+            const double v = S[L.qpos + T.jnt_qposadr[j]];
+            margin = mb[A.o.jnt_margin + j];
+            pos = rm.edge < 0 ? v - mb[A.o.jnt_range + 2 * j] : mb[A.o.jnt_range + 2 * j + 1] - v;
+            unit = -(double)rm.edge;
         } else {
-            const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
-            const int b2 = (int)C[20];
-            const int root = T.body_rootid[b2];
-            double off[3], dv[3];
-            const double mu = C[14];
-            for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
-            if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
-            else {
-                const double sgn = (rm.edge & 1) ? -1.0 : 1.0;
-                const int td = 1 + rm.edge / 2;
-                for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
-            }
-            for (int q = 0; q < len; q++) {
-                const int i = anc[q];
-                double cd[6], cr[3];
-                for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
-                cross3(cr, cd, off);
-                Y[q] = dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]);
-            }
-            pos = C[12]; margin = C[13]; K = C[15]; B = C[16]; imp = C[17];
-            diagApprox = rm.type == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
-            if (rm.type == ROW_PYR) {
-                const double R0 = fmax(UHC_MINVAL, (1 - imp) * (C[18] + mu * mu * C[18]) / imp);
-                diagApprox = -2 * mu * mu * R0;
-            }
+            floss = mb[A.o.dof_frictionloss + rm.last];
+            unit = 1;
         }
-        double vel = 0, jas = 0, jaw = 0;
-        for (int q = 0; q < len; q++) {
-            const int i = anc[q];
-            const double j = Y[q];
-            vel += j * S[L.qvel + i];
-            jas += j * S[L.smooth + i];
-            jaw += j * S[L.qacc + i];
+        diagApprox = mb[A.o.dof_invweight0 + rm.last];
+        imp = impedance(dsolimp, pos, margin);
+    } else if (is_con) {
+        const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
+        const int b2 = (int)C[20];
+        const int root = T.body_rootid[b2];
+        const double mu = C[14];
+        for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
+        if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+        else {
+            const double sgn = (rm.edge & 1) ? -1.0 : 1.0;
+            const int td = 1 + rm.edge / 2;
+            for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
         }
+        pos = C[12]; margin = C[13]; K = C[15]; B = C[16]; imp = C[17];
+        diagApprox = rm.type == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
+        if (rm.type == ROW_PYR) {
+            // all edges of a pyramid share R = 2 mu^2 R(first edge); first edge uses friction[0] = mu
+            const double R0 = fmax(UHC_MINVAL, (1 - imp) * (C[18] + mu * mu * C[18]) / imp);
+            diagApprox = -2 * mu * mu * R0;  // negative => final R given directly
+        }
+    }
+    // ---- J along the chain, and J.qvel, J.qacc_smooth, J.qacc_warmstart
+    double vel = 0, jas = 0, jaw = 0;
+    static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        Y[q] = 0.0;
+        if (q < maxlen) {
+            const int i = ch[q] & 0xffff;
+            double cd[6], cr[3];
+            for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
+            cross3(cr, cd, off);
+            const double yc = dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]);
+            const double y = q < len ? (is_con ? yc : (q == len - 1 ? unit : 0.0)) : 0.0;
+            Y[q] = y;
+            vel = fma(y, S[L.qvel + i], vel);
+            jas = fma(y, S[L.smooth + i], jas);
+            jaw = fma(y, S[L.qacc + i], jaw);
+        }
+    });
+    if (valid) {
         const double R = diagApprox < 0 ? -diagApprox : fmax(UHC_MINVAL, (1 - imp) * diagApprox / imp);
         const double aref = -B * vel - K * imp * (pos - margin);
         const double jar = jaw - aref, D = 1.0 / R;
         row.f = rm.type == ROW_FRICTION ? clampd(-D * jar, -floss, floss) : (jar < 0 ? -D * jar : 0.0);
-        for (int q = len - 1; q >= 1; q--) {
-            const int i = anc[q];
-            const double xi = Y[q];
-            const int mi = T.dof_madr[i];
-            for (int q2 = q - 1; q2 >= 0; q2--) Y[q2] -= S[L.LD + mi + (q - q2)] * xi;
-        }
-        for (int q = 0; q < len; q++) Y[q] *= sqrt(S[L.dinv + anc[q]]);
         row.R = R; row.b = jas - aref; row.floss = floss;
     }
+    // ---- Y <- L^-T Y along the chain: for q descending, every earlier position q2: Y[q2] -= L[anc_q][anc_q2] Y[q]
+    static_for<1, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = UHC_YM - decltype(qc)::value;  // UHC_YM-1 .. 1
+        if (q < maxlen) {
+            const double xi = Y[q];
+            const unsigned int mi = ch[q] >> 16;
+            static_for<0, q>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int q2 = decltype(pc)::value;
+                Y[q2] = fma(-lds_at(SB, mi + 8u * (unsigned)(q - q2)), xi, Y[q2]);
+            });
+        }
+    });
+    if (LANE < 8) S[L.Y + total + LANE] = 0.0;  // the A build reads rows in chunks of 8: finite slack after the last row
+    double* Yst = S + L.Y + row.yoff;
+    static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        if (q < maxlen) {
+            Y[q] *= S[L.sdinv + (ch[q] & 0xffff)];
+            if (q < len) Yst[q] = Y[q];
+        }
+    });
     wsync();
     return 0;
 }
+
+// Explicit parking of values in the accumulation registers (AGPRs).  Only 256 of the 512 registers of a full-file
+// wave are directly addressable by VALU instructions; what the compiler cannot fit it shuttles through AGPRs (or
+// scratch) at its own discretion.  Parking the finished Delassus row here keeps the A build inside the VGPRs.
+__device__ __forceinline__ void agpr_put(int& a, int v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); }
+__device__ __forceinline__ int agpr_get(int a) { int v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
 
 __device__ __forceinline__ double max_neg(double a, double b) {  // max(a, -b): one VOP3 with a source modifier
     double r;
@@ -1178,29 +1216,74 @@ __device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, d
 }
 
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
-__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row PROF_ARGS) {
+__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM] PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const bool valid = LANE < nefc;
-    const double* Yr = S + L.Y + row.yoff;
-    // ---- A[r][s] = sum over the common part of the two dof chains
-    double Arow[UHC_WAVE];
+    // ---- A[r][s] = sum over the common part of the two dof chains, entirely in registers: row s is broadcast from lane
+    //      the packed LDS rows (same address in all lanes), the own row is pre-masked to the common chain prefix.  Rows of one body are
+    //      adjacent and share that prefix length, so the masked copy is rebuilt only when the body changes.
+    unsigned int ncp[UHC_WAVE / 4];  // common-prefix length of this lane's chain with every row's chain, 4 per register
+    {
+        int nraw[UHC_WAVE];
+        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            nraw[s] = 0;
+            if (s < nefc) {
+                const int ls = __builtin_amdgcn_readlane(row.last, s);
+                nraw[s] = valid ? (int)A.t.dof_ncommon[row.last * T.nv + ls] : 0;
+            }
+        });
+        static_for<0, UHC_WAVE / 4>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            ncp[j] = (unsigned)nraw[4 * j] | ((unsigned)nraw[4 * j + 1] << 8) | ((unsigned)nraw[4 * j + 2] << 16) | ((unsigned)nraw[4 * j + 3] << 24);
+        });
+    }
+    double Ym[UHC_YM];
+    int Alo[UHC_WAVE], Ahi[UHC_WAVE];  // AGPR-parked A[r][s]
     double diag = 1.0;
+    int prev = -1;
+    static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { Ym[decltype(qc)::value] = 0.0; });
     static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         double acc = 0.0;
         if (s < nefc) {
             const int ls = __builtin_amdgcn_readlane(row.last, s);
-            const int ys = __builtin_amdgcn_readlane(row.yoff, s);
-            const int nc = valid ? (int)A.t.dof_ncommon[row.last * T.nv + ls] : 0;
-            const double* Ys = S + L.Y + ys;
-            for (int q = 0; q < nc; q++) acc += Yr[q] * Ys[q];
+            const int lens = __builtin_amdgcn_readlane(row.len, s);
+            const double* Ys = S + L.Y + __builtin_amdgcn_readlane(row.yoff, s);  // row s in LDS: one broadcast read per entry
+            if (ls != prev) {
+                prev = ls;
+                const int nc = (ncp[s / 4] >> (8 * (s % 4))) & 0xff;
+                static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    Ym[q] = q < nc ? Y[q] : 0.0;
+                });
+            }
+            // chunks of 8 chain positions, skipped uniformly beyond row s's length; inside a chunk no tests are needed:
+            // Ym is zero past the common prefix (<= lens) and every row's registers are zero past its own length
+            static_for<0, UHC_YM / 8>([&](auto cc) __attribute__((always_inline)) {
+                constexpr int c = decltype(cc)::value;
+                if (8 * c < lens) {
+                    double y8[8];
+                    static_for<0, 8>([&](auto qc) __attribute__((always_inline)) { constexpr int j = decltype(qc)::value; y8[j] = Ys[8 * c + j]; });
+                    static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(qc)::value;
+                        acc = fma(Ym[8 * c + j], y8[j], acc);
+                    });
+                }
+            });
             if (s == LANE) { acc += row.R; diag = acc; }
         }
-        Arow[s] = acc;
+        agpr_put(Alo[s], __double2loint(acc));
+        agpr_put(Ahi[s], __double2hiint(acc));
     });
     if (!valid) diag = 1.0;
     PROF(10)
+    double Arow[UHC_WAVE];
+    static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        Arow[s] = __hiloint2double(agpr_get(Ahi[s]), agpr_get(Alo[s]));
+    });
     const double dinvA = 1.0 / diag;
     // ---- residual of the warm start, dual cost test
     double f = row.f, res = row.b;
@@ -1259,7 +1342,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
 template <bool FAST>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, MReg& mr PROF_ARGS) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, double* Mw PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     FwdOut out = {0, 0, 0, 0};
@@ -1267,7 +1350,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(1)
     k_com_pos<FAST>(A, mb, S);
     PROF(2)
-    k_crb<FAST>(A, mb, S, mr);
+    k_crb<FAST>(A, mb, S, Mw);
     PROF(3)
     if (!FAST) {
         for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
@@ -1289,9 +1372,10 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     if (out.nefc > 0) {
         if (FAST) {
             FastRow row;
-            if (k_rows_fast(A, mb, S, out.nefc, row)) { out.overflow = 1; return out; }
+            double Yreg[UHC_YM];
+            if (k_rows_fast(A, mb, S, out.nefc, row, Yreg)) { out.overflow = 1; return out; }
             PROF(9)
-            out.iters = k_pgs_fast(A, mb, S, out.nefc, row PROF_PASS);
+            out.iters = k_pgs_fast(A, mb, S, out.nefc, row, Yreg PROF_PASS);
             PROF(12)
         } else {
             k_rows<FAST>(A, mb, S, out.nefc);
@@ -1300,8 +1384,8 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             PROF(11)
         }
         // qacc = qacc_smooth + L^-1 D^-1/2 z
-        if (LANE < T.nv) x.a = S[L.z + LANE] * sqrt(S[L.dinv + LANE]);
-        if (LANE + UHC_WAVE < T.nv) x.b = S[L.z + LANE + UHC_WAVE] * sqrt(S[L.dinv + LANE + UHC_WAVE]);
+        if (LANE < T.nv) x.a = S[L.z + LANE] * S[L.sdinv + LANE];
+        if (LANE + UHC_WAVE < T.nv) x.b = S[L.z + LANE + UHC_WAVE] * S[L.sdinv + LANE + UHC_WAVE];
         k_solve<FAST>(A, S, L.LD, x, 1, LC);
     }
     if (LANE < T.nv) S[L.qacc + LANE] = S[L.smooth + LANE] + x.a;
@@ -1346,7 +1430,7 @@ __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVA
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
 // previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
 template <bool FAST>
-__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const MReg& mr, const LaneConst& LC) {
+__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const double* Mr, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
@@ -1361,7 +1445,7 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
 #pragma unroll
         for (int m = 0; m < UHC_MREG; m++) {
             const int e = LANE + UHC_WAVE * m;
-            if (e < T.nM) S[L.LD + e] = mr.v[m];
+            if (e < T.nM) S[L.LD + e] = Mr[e];
         }
     } else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
     wsync();
@@ -1490,11 +1574,6 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
     for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
     if (MODE == 0 && !FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
-    {   // 16-bit row-address table of the sparse entries (used by the factorisation), two entries per 32-bit word
-        unsigned int* dst = (unsigned int*)(S + L.eadr);
-        const unsigned int* src = (const unsigned int*)T.e_adr;
-        for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
-    }
     if (LANE == 0) { S[L.zero] = 0.0; S[L.LD + T.nM] = 0.0; S[L.LD + T.nM + 1] = 0.0; }  // slots idle lanes read / write instead of branching
     if (MODE == 0 && A.c.rfc_mode == 2) {  // explicit RFC reads the kinematics of the previous forward pass
         for (int i = LANE; i < 6 * T.nv; i += UHC_WAVE) S[L.cdof + i] = A.s.cdof[(size_t)env * 6 * T.nv + i];
@@ -1510,26 +1589,25 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         }
     }
     const LaneConst LC = lane_const(T);
-    MReg mr;
-#pragma unroll
-    for (int m = 0; m < UHC_MREG; m++) {
-        const int e = LANE + UHC_WAVE * m;
-        mr.v[m] = (FAST && MODE == 0 && e < T.nM) ? A.s.qM[(size_t)env * T.nM + e] : 0.0;
-    }
+    // joint-space inertia between substeps: the PD solve of substep t+1 uses M of substep t's forward pass.  The fast
+    // kernel parks it in a per-env HBM work row (each lane re-reads exactly the entries it wrote); the committed copy
+    // qM is only replaced once the whole control step has succeeded, so a redo by the general kernel starts clean.
+    double* Mwork = FAST ? A.s.qM_work + (size_t)env * T.nM : nullptr;
+    const double* Mcommitted = A.s.qM + (size_t)env * T.nM;
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0;
     bool ran = false;
     PROF_DECL
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S, LC, mr PROF_PASS);
+        fo = k_forward<FAST>(A, mb, S, LC, Mwork PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
         for (int it = 0; it < A.c.n_substeps; it++) {
-            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, mr, LC);
+            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, (FAST && it > 0) ? Mwork : Mcommitted, LC);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
                     S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
@@ -1543,7 +1621,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
-            fo = k_forward<FAST>(A, mb, S, LC, mr PROF_PASS);
+            fo = k_forward<FAST>(A, mb, S, LC, Mwork PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && overflow) break;
@@ -1574,7 +1652,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
 #pragma unroll
             for (int m = 0; m < UHC_MREG; m++) {
                 const int e = LANE + UHC_WAVE * m;
-                if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = mr.v[m];
+                if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = Mwork[e];
             }
         }
         else for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
