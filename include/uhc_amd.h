@@ -199,7 +199,8 @@ enum UhcEnvField {
     UHC_E_PERCENT = 6,      /* [n_env] info["percent"] */
     UHC_E_CUR_T = 7,        /* int32 [n_env] */
     UHC_E_BODY_DIFF = 8,    /* [n_env] calc_body_diff() of the last step */
-    UHC_E_TARGET_BASE = 9   /* [n_env][nu] expert joint pose handed to the PD controller */
+    UHC_E_TARGET_BASE = 9,  /* [n_env][nu] expert joint pose handed to the PD controller */
+    UHC_E_CONSUMED = 10     /* int32 [n_env] 1 where the last uhc_env_auto_reset() started the queued window, 0 elsewhere */
 };
 
 int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* desc, UhcEnv** out);
@@ -213,6 +214,14 @@ int32_t uhc_env_set_bank(UhcEnv* e, const double* d_frames, int64_t n_frames, co
 /* load_expert (humanoid_im.py:182-215): env d_env_ids[i] tracks frames [fr_start, fr_start+fr_len) of clip d_clip_ids[i] */
 int32_t uhc_env_assign(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int32_t* d_clip_ids,
                        const int32_t* d_fr_start, const int32_t* d_fr_len);
+/* Episode turnover without a host round trip (the reference's sampler does `load_expert; reset` on the worker, agent_copycat.py:
+ * 526-531, right after `done`): uhc_env_set_next queues, per env, the window its NEXT episode will track (+ the reset noise,
+ * d_noise [n][nu] or NULL); uhc_env_auto_reset then does, for every env whose done flag is set, load_expert + reset_model on
+ * the device (queued window if there is one, else the current window again) and refreshes its observation row.  The done
+ * flags are left as the step wrote them; UHC_E_CONSUMED tells which envs took their queued window. */
+int32_t uhc_env_set_next(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int32_t* d_clip_ids, const int32_t* d_fr_start,
+                         const int32_t* d_fr_len, const double* d_noise);
+int32_t uhc_env_auto_reset(UhcEnv* e);
 /* MujocoEnv.reset -> reset_model (humanoid_im.py:1245-1299): state <- expert frame 0 (+ d_noise [n][nu] on the
  * joint angles, may be NULL), forward pass, observation written to the obs rows of those envs */
 int32_t uhc_env_reset(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const double* d_noise);

@@ -147,3 +147,49 @@ def test_env_inactive_and_second_clip(model, ctrl):
     after = eb.field(S.E_OBS)
     assert torch.equal(before[0], after[0]) and torch.equal(before[2], after[2]) and not torch.equal(before[1], after[1])
     assert eb.field(S.E_CUR_T).cpu().tolist() == [0, 1, 0]
+
+
+def test_auto_reset_equals_assign_plus_reset(model, ctrl):
+    """Device-side episode turnover: a finished env restarts from its queued window (+ noise) exactly as assign + reset
+    would restart it; an env without a queued window restarts its current one; running envs are untouched."""
+    import torch
+    from uhc_amd import sim as S
+    expert = _expert()
+    beta = np.linspace(-1, 1, 16)
+    n = 4
+    sb, eb = _make(model, ctrl, n, expert, beta)
+    ids = torch.arange(n, dtype=torch.int32)
+    # envs 0 and 1 track 3-frame windows (done after 2 steps), envs 2 and 3 long ones
+    eb.assign(ids, torch.zeros(n, dtype=torch.int32), torch.tensor([0, 4, 0, 8], dtype=torch.int32), torch.tensor([3, 3, 40, 30], dtype=torch.int32))
+    eb.reset(ids.cuda(), None)
+    rng = np.random.default_rng(3)
+    noise = torch.from_numpy(rng.normal(scale=0.05, size=(2, model.nu)))
+    eb.set_next(torch.tensor([0, 2], dtype=torch.int32), torch.tensor([1, 1], dtype=torch.int32), torch.tensor([6, 2], dtype=torch.int32),
+                torch.tensor([20, 25], dtype=torch.int32), noise)
+    act = torch.zeros(n, ctrl.action_dim, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        eb.step(act, None)
+    sb.sync()
+    assert eb.field(S.E_DONE).cpu().tolist() == [1, 1, 0, 0]
+    keep_obs, keep_q = eb.field(S.E_OBS).clone(), sb.field(S.F_QPOS).clone()
+    eb.auto_reset()
+    sb.sync()
+    assert eb.field(S.E_CONSUMED).cpu().tolist() == [1, 0, 0, 0] and eb.field(S.E_CUR_T).cpu().tolist() == [0, 0, 2, 2]
+    auto_obs, auto_q, auto_v = eb.field(S.E_OBS).clone(), sb.field(S.F_QPOS).clone(), sb.field(S.F_QVEL).clone()
+    assert torch.equal(auto_obs[2:], keep_obs[2:]) and torch.equal(auto_q[2:], keep_q[2:])  # running envs untouched
+    # the same restarts through the explicit path
+    eb.assign(torch.tensor([0], dtype=torch.int32), torch.tensor([1], dtype=torch.int32), torch.tensor([6], dtype=torch.int32), torch.tensor([20], dtype=torch.int32))
+    eb.reset(torch.tensor([0], dtype=torch.int32).cuda(), noise[0:1])
+    eb.reset(torch.tensor([1], dtype=torch.int32).cuda(), None)  # env 1 had nothing queued: same window again, no noise
+    sb.sync()
+    assert torch.equal(eb.field(S.E_OBS)[:2], auto_obs[:2]) and torch.equal(sb.field(S.F_QPOS)[:2], auto_q[:2]) and torch.equal(sb.field(S.F_QVEL)[:2], auto_v[:2])
+    # env 2's queued window is still waiting; it is taken when env 2 finishes
+    for _ in range(37):
+        eb.step(act, torch.tensor([0, 0, 1, 0], dtype=torch.int32, device="cuda"))
+    sb.sync()
+    assert eb.field(S.E_DONE).cpu().tolist()[2] == 1
+    eb.auto_reset()
+    sb.sync()
+    assert eb.field(S.E_CONSUMED).cpu().tolist()[2] == 1
+    q2 = sb.field(S.F_QPOS)[2].cpu().numpy()
+    np.testing.assert_allclose(q2[:7], expert["qpos"][39 - 2][:7], atol=1e-15)  # clip 1 = clip 0 reversed, window start 2

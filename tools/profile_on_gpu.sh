@@ -13,6 +13,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_I
   rocprofv3 --kernel-trace --pmc $pass -d /tmp/prof_$name -o p -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-ppo > /dev/null 2> /tmp/$name.err
   python tools/pmc_summary.py /tmp/prof_$name/p_results.db gpurun_out/${TAG}_pmc_$name.txt "$TAG: rocprofv3 --kernel-trace --pmc $pass" > /dev/null
 done
+# the PPO update (GAE + 10 epochs) on the samples of a short rollout: which kernels the learner time goes to
+rocprofv3 --kernel-trace --stats -d /tmp/prof_ppo -o kt -- python bench.py --steps 24 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_ppo_under_rocprof.json 2> /tmp/ppo.err
+python tools/rocpd_summary.py /tmp/prof_ppo/kt_results.db gpurun_out/${TAG}_ppo_kernel_stats.txt "$TAG: rocprofv3 --kernel-trace --stats -- python bench.py --steps 24 --warmup 1 --no-cpu-baseline (rollout + one PPO update)" > /dev/null
 tail -1 gpurun_out/${TAG}_bench_under_rocprof.json | cut -c1-300
 cat gpurun_out/${TAG}_kernel_stats.txt | head -8 | cut -c1-200
 cat gpurun_out/${TAG}_pmc_*.txt | grep -v "^#" | cut -c1-200

@@ -161,29 +161,43 @@ class AgentCopycat(AgentPPO):
             self._load("%s/iter_%04d.p" % (self.cfg.model_dir, iter))
 
     # ---- clip sampling hooks used by the vectorised rollout ----------------------------------------------------
-    def assign_new_clips(self, env_ids):
+    def _sample_windows(self, n):
         cfg, dl = self.cfg, self.data_loader
         if self.precision_mode:  # per-draw path of the reference (window near a recorded failure)
             keys, fs, fe = [], [], []
-            for _ in env_ids:
+            for _ in range(n):
                 dl.sample_seq(freq_dict=self.freq_dict, full_sample=False, sampling_temp=cfg.sampling_temp, sampling_freq=cfg.sampling_freq,
                               precision_mode=True)
                 keys.append(dl.curr_key)
                 fs.append(dl.fr_start)
                 fe.append(dl.fr_end)
-        else:
-            keys, fs, fe = dl.sample_windows(len(env_ids), freq_dict=self.freq_dict, sampling_temp=cfg.sampling_temp, sampling_freq=cfg.sampling_freq)
+            return keys, fs, fe
+        return dl.sample_windows(n, freq_dict=self.freq_dict, sampling_temp=cfg.sampling_temp, sampling_freq=cfg.sampling_freq)
+
+    def assign_new_clips(self, env_ids):
+        """load_expert + reset on the listed envs right now (start of a sampling pass)."""
+        keys, fs, fe = self._sample_windows(len(env_ids))
         self._env_key = getattr(self, "_env_key", {})
         for e, k, s in zip(env_ids, keys, fs):
             self._env_key[int(e)] = (k, int(s))
         self.env.assign(np.asarray(env_ids), keys, fs, fe)
         self.env.reset(np.asarray(env_ids))
 
-    def on_episode_end(self, env_ids, percents):
-        for e, p in zip(env_ids, percents):  # freq_dict[key].append([percent, fr_start]) (agent_copycat.py:559-565)
+    def queue_next_clips(self, env_ids):
+        """Sample the window each listed env starts when its current episode ends; the device does the restart itself."""
+        keys, fs, fe = self._sample_windows(len(env_ids))
+        self._env_next = getattr(self, "_env_next", {})
+        for e, k, s in zip(env_ids, keys, fs):
+            self._env_next[int(e)] = (k, int(s))
+        self.env.set_next(np.asarray(env_ids), keys, fs, fe)
+
+    def on_episode_end(self, env_ids, percents, consumed=None):
+        for n, (e, p) in enumerate(zip(env_ids, percents)):  # freq_dict[key].append([percent, fr_start]) (agent_copycat.py:559-565)
             k, s = self._env_key[int(e)]
             self.freq_dict[k].append([float(p), s])
             self.freq_dict[k] = self.freq_dict[k][-self.max_freq:]
+            if consumed is not None and consumed[n]:  # the env has moved on to its queued window
+                self._env_key[int(e)] = self._env_next[int(e)]
 
     # ---- training iteration ------------------------------------------------------------------------------
     def per_epoch_update(self, epoch):

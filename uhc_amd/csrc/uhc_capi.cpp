@@ -575,6 +575,15 @@ extern "C" int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const
     return launch(b, 0, d_action, d_target_base, d_active);
 }
 
+extern "C" hipError_t uhc_launch_set_state_masked(const DevState* s, int nq, int nv, int nu, int n_env, const int* select, const double* qpos,
+                                                  const double* qvel, int* mask, hipStream_t stream);
+// env layer: set_state + forward on the envs flagged in d_select (rows of d_qpos / d_qvel are indexed by env)
+extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, const double* d_qpos, const double* d_qvel) {
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(uhc_launch_set_state_masked(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, b->n_env, d_select, d_qpos, d_qvel, b->reset_mask, b->stream));
+    return launch(b, 1, nullptr, nullptr, b->reset_mask);
+}
+
 // ------------------------------------------------------------------ internal accessors for the env layer (uhc_env_capi.cpp)
 extern "C" int uhc_internal_set_error(const char* msg) { return fail("%s", msg); }
 extern "C" int uhc_internal_batch_info(UhcBatch* b, int* n_env, int* nq, int* nv, int* nu, int* nbody, int* action_dim, int* vf_dim,

@@ -32,4 +32,7 @@ struct EnvArgs {
     int *clip_id, *e_start, *e_len, *cur_t, *start_ind;
     double *target_base, *qpos_prev, *obs, *reward, *reward_parts, *percent, *body_diff;
     int *done, *fail, *end;
+    // queued next window per env (uhc_env_set_next / uhc_env_auto_reset)
+    int *next_clip, *next_start, *next_len, *has_next, *consumed;
+    double* next_noise;  // [n_env][nu]
 };

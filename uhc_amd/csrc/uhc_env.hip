@@ -331,3 +331,47 @@ extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids
     hipLaunchKernelGGL(uhc_env_assign_kernel, dim3((n + 63) / 64), dim3(64), 0, s, *E, env_ids, n, clip_ids, fr_start, fr_len);
     return hipGetLastError();
 }
+
+// queue of one next window per env
+__global__ void uhc_env_set_next_kernel(EnvArgs E, const int* env_ids, int n, const int* clip_ids, const int* fr_start, const int* fr_len,
+                                        const double* noise) {
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const int env = env_ids[r];
+    for (int a = threadIdx.x; a < E.nu; a += blockDim.x) E.next_noise[(size_t)env * E.nu + a] = noise ? noise[(size_t)r * E.nu + a] : 0.0;
+    if (threadIdx.x == 0) { E.next_clip[env] = clip_ids[r]; E.next_start[env] = fr_start[r]; E.next_len[env] = fr_len[r]; E.has_next[env] = 1; }
+}
+extern "C" hipError_t uhc_launch_env_set_next(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
+                                              const int* fr_len, const double* noise, hipStream_t s) {
+    hipLaunchKernelGGL(uhc_env_set_next_kernel, dim3(n), dim3(WAVE), 0, s, *E, env_ids, n, clip_ids, fr_start, fr_len, noise);
+    return hipGetLastError();
+}
+// every done env: take the queued window (or restart the current one), stage its reset state (frame 0 pose + noise, frame 1
+// velocity: see uhc_env_reset_stage_kernel) and raise select[env] for the masked set_state + forward + observation that follow
+__global__ void uhc_env_auto_stage_kernel(EnvArgs E, double* out_qpos, double* out_qvel, int* select) {
+    const int env = blockIdx.x;
+    if (env >= E.n_env) return;
+    const bool go = E.done[env] != 0;
+    const bool had = go && E.has_next[env] != 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        select[env] = go;
+        E.consumed[env] = had;
+        if (had) { E.clip_id[env] = E.next_clip[env]; E.e_start[env] = E.clip_start[E.next_clip[env]] + E.next_start[env]; E.e_len[env] = E.next_len[env]; E.has_next[env] = 0; }
+        if (go) { E.cur_t[env] = 0; E.start_ind[env] = 0; }
+    }
+    if (!go) return;
+    __syncthreads();
+    const double* fr = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE;
+    const double* frv = fr + (E.e_len[env] > 1 ? UHC_FRAME_STRIDE : 0);
+    for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
+        double v = fr[UHC_FR_QPOS + i];
+        if (had && i >= 7) v += E.next_noise[(size_t)env * E.nu + (i - 7)];
+        out_qpos[(size_t)env * E.nq + i] = v;
+    }
+    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)env * E.nv + i] = frv[UHC_FR_QVEL + i];
+}
+extern "C" hipError_t uhc_launch_env_auto_stage(const EnvArgs* E, double* out_qpos, double* out_qvel, int* select, hipStream_t s) {
+    hipLaunchKernelGGL(uhc_env_auto_stage_kernel, dim3(E->n_env), dim3(WAVE), 0, s, *E, out_qpos, out_qvel, select);
+    return hipGetLastError();
+}

@@ -12,6 +12,10 @@ extern "C" hipError_t uhc_launch_env_pre(const EnvArgs* E, const int* d_active, 
 extern "C" hipError_t uhc_launch_env_post(int mode, const EnvArgs* E, const double* d_action, const int* d_active, hipStream_t s);
 extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* env_ids, int n, const double* noise, double* out_qpos,
                                                  double* out_qvel, hipStream_t s);
+extern "C" hipError_t uhc_launch_env_set_next(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
+                                              const int* fr_len, const double* noise, hipStream_t s);
+extern "C" hipError_t uhc_launch_env_auto_stage(const EnvArgs* E, double* out_qpos, double* out_qvel, int* select, hipStream_t s);
+extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, const double* d_qpos, const double* d_qvel);
 extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
                                             const int* fr_len, hipStream_t s);
 // accessors implemented in uhc_capi.cpp
@@ -30,6 +34,7 @@ struct UhcEnv {
     EnvArgs E;
     std::vector<void*> allocs;
     double *stage_qpos = nullptr, *stage_qvel = nullptr;
+    int* select = nullptr;
     int n_clips = 0;
     int64_t n_frames = 0;
 };
@@ -81,7 +86,9 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     if (dalloc(e, N, &E.clip_id) || dalloc(e, N, &E.e_start) || dalloc(e, N, &E.e_len) || dalloc(e, N, &E.cur_t) || dalloc(e, N, &E.start_ind) ||
         dalloc(e, N * E.nu, &E.target_base) || dalloc(e, N * E.nq, &E.qpos_prev) || dalloc(e, N * E.obs_dim, &E.obs) || dalloc(e, N, &E.reward) ||
         dalloc(e, N * 5, &E.reward_parts) || dalloc(e, N, &E.percent) || dalloc(e, N, &E.body_diff) || dalloc(e, N, &E.done) || dalloc(e, N, &E.fail) ||
-        dalloc(e, N, &E.end) || dalloc(e, N * E.nq, &e->stage_qpos) || dalloc(e, N * E.nv, &e->stage_qvel)) { delete e; return 1; }
+        dalloc(e, N, &E.end) || dalloc(e, N * E.nq, &e->stage_qpos) || dalloc(e, N * E.nv, &e->stage_qvel) || dalloc(e, N, &e->select) ||
+        dalloc(e, N, &E.next_clip) || dalloc(e, N, &E.next_start) || dalloc(e, N, &E.next_len) || dalloc(e, N, &E.has_next) || dalloc(e, N, &E.consumed) ||
+        dalloc(e, N * E.nu, &E.next_noise)) { delete e; return 1; }
     *out = e;
     return 0;
 }
@@ -108,6 +115,7 @@ extern "C" int32_t uhc_env_field(UhcEnv* e, int32_t f, void** p, int64_t* n) {
         case UHC_E_CUR_T: ptr = E.cur_t; cnt = N; break;
         case UHC_E_BODY_DIFF: ptr = E.body_diff; cnt = N; break;
         case UHC_E_TARGET_BASE: ptr = E.target_base; cnt = N * E.nu; break;
+        case UHC_E_CONSUMED: ptr = E.consumed; cnt = N; break;
         default: return uhc_internal_set_error("uhc_env_field: unknown field");
     }
     if (p) *p = ptr;
@@ -141,6 +149,22 @@ extern "C" int32_t uhc_env_reset(UhcEnv* e, const int32_t* ids, int32_t n, const
     void* st; int* mask; int a; double d; double br[4];
     uhc_internal_batch_info(e->b, &a, &a, &a, &a, &a, &a, &a, &d, br, &st, &mask);
     HIP_OK(uhc_launch_env_post(1, &e->E, nullptr, mask, s));  // observation of the reset envs (mask = envs just reset)
+    return 0;
+}
+extern "C" int32_t uhc_env_set_next(UhcEnv* e, const int32_t* ids, int32_t n, const int32_t* clip_ids, const int32_t* fr_start, const int32_t* fr_len,
+                                    const double* d_noise) {
+    if (!e || !ids || !clip_ids || !fr_start || !fr_len || n < 1 || n > e->E.n_env) return uhc_internal_set_error("uhc_env_set_next: bad argument");
+    if (!e->E.bank) return uhc_internal_set_error("uhc_env_set_next: no clip bank set");
+    HIP_OK(uhc_launch_env_set_next(&e->E, ids, n, clip_ids, fr_start, fr_len, d_noise, stream_of(e)));
+    return 0;
+}
+extern "C" int32_t uhc_env_auto_reset(UhcEnv* e) {
+    if (!e) return uhc_internal_set_error("uhc_env_auto_reset: null env");
+    if (!e->E.bank) return uhc_internal_set_error("uhc_env_auto_reset: no clip bank set");
+    hipStream_t s = stream_of(e);
+    HIP_OK(uhc_launch_env_auto_stage(&e->E, e->stage_qpos, e->stage_qvel, e->select, s));
+    if (uhc_internal_set_state_masked(e->b, e->select, e->stage_qpos, e->stage_qvel)) return 1;
+    HIP_OK(uhc_launch_env_post(1, &e->E, nullptr, e->select, s));
     return 0;
 }
 extern "C" int32_t uhc_env_step(UhcEnv* e, const double* d_action, const int32_t* d_active) {

@@ -1699,6 +1699,30 @@ __global__ void uhc_set_state_kernel(DevState s, int nq, int nv, int nu, const i
     if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; mask[env] = 1; }
 }
 
+// set_state on every env whose select flag is set; row e of (qpos, qvel) belongs to env e
+__global__ void uhc_set_state_masked_kernel(DevState s, int nq, int nv, int nu, int n_env, const int* select, const double* qpos,
+                                            const double* qvel, int* mask) {
+    const int env = blockIdx.x;
+    if (env >= n_env) return;
+    const int go = select[env] != 0;
+    if (threadIdx.x == 0) mask[env] = go;
+    if (!go) return;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) s.qpos[(size_t)env * nq + i] = qpos[(size_t)env * nq + i];
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+        s.qvel[(size_t)env * nv + i] = qvel[(size_t)env * nv + i];
+        s.qacc[(size_t)env * nv + i] = 0;
+        s.qacc_ws[(size_t)env * nv + i] = 0;
+        s.applied[(size_t)env * nv + i] = 0;
+    }
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) s.ctrl[(size_t)env * nu + i] = 0;
+    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; }
+}
+extern "C" hipError_t uhc_launch_set_state_masked(const DevState* s, int nq, int nv, int nu, int n_env, const int* select, const double* qpos,
+                                                  const double* qvel, int* mask, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_set_state_masked_kernel, dim3(n_env), dim3(UHC_WAVE), 0, stream, *s, nq, nv, nu, n_env, select, qpos, qvel, mask);
+    return hipGetLastError();
+}
+
 // host-callable launchers (defined here so the kernels stay in one translation unit)
 extern "C" hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase,
                                       const int* d_active, size_t lds_bytes, hipStream_t stream) {

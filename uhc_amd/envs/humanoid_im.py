@@ -126,6 +126,20 @@ class VecHumanoidEnv:
         self.env.reset(ids, noise)
         return self.obs
 
+    def set_next(self, env_ids, keys, fr_start, fr_end):
+        """Queue the next episode's window for the listed envs (load_expert + reset_model happen on the device at `done`)."""
+        ids = torch.as_tensor(np.asarray(env_ids), dtype=torch.int32)
+        cid = torch.tensor([self._clip_index[k] for k in keys], dtype=torch.int32)
+        fs = torch.as_tensor(np.asarray(fr_start), dtype=torch.int32)
+        fl = torch.as_tensor(np.asarray(fr_end) - np.asarray(fr_start), dtype=torch.int32)
+        noise = None
+        if self.mode == "train" and self.cc_cfg.env_init_noise > 0:
+            noise = torch.from_numpy(self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof)))
+        self.env.set_next(ids, cid, fs, fl, noise)
+
+    def auto_reset(self):
+        self.env.auto_reset()
+
     def step(self, action, active=None):
         self.env.step(action, active)
         return self.obs, self.reward, self.done, {"fail": self.env.field(S.E_FAIL), "end": self.env.field(S.E_END), "percent": self.env.field(S.E_PERCENT)}

@@ -62,7 +62,11 @@ class Agent:
         """Pick a clip window for each env in env_ids (host side: data_loader.sample_seq) and reset them."""
         raise NotImplementedError
 
-    def on_episode_end(self, env_ids, percents):
+    def queue_next_clips(self, env_ids):
+        """Pick the window each env in env_ids starts after its current episode and hand it to env.set_next."""
+        raise NotImplementedError
+
+    def on_episode_end(self, env_ids, percents, consumed=None):
         pass
 
     # ---- vectorised rollout (replaces sample_worker / sample of agent.py:42-131) -------------------------
@@ -77,54 +81,86 @@ class Agent:
         R.masks = torch.ones(n_env, T, dtype=self.dtype, device=dev)
         R.exps = torch.ones(n_env, T, dtype=self.dtype, device=dev)
         R.logger = self.logger_cls()
-        R.ep_len = torch.zeros(n_env, dtype=torch.int64, device=dev)
-        R.ep_rew = torch.zeros(n_env, dtype=self.dtype, device=dev)
+        R.ep_len = torch.zeros(n_env, dtype=torch.float64, device=dev)
+        R.ep_rew = torch.zeros(n_env, dtype=torch.float64, device=dev)
         R.c_info_sum = torch.zeros(5, dtype=self.dtype, device=dev)
+        # exploration flags of the whole pass in one upload (the same stream of draws as one binomial(n_env) per step)
+        flags = np.ones((T, n_env)) if self.mean_action else env.np_random.binomial(1, 1 - self.noise_rate, size=(T, n_env))
+        R.mean_flags = torch.from_numpy(flags.astype(np.float64)).to(dev)
+        # episode turnover is asynchronous: the device restarts finished envs from a queued window (env.auto_reset); the
+        # host learns about finished episodes from a pinned snapshot one step later and refills the queues then
+        R.snap_dev = torch.empty(5, n_env, dtype=torch.float64, device=dev)
+        R.snap_host = [torch.empty(5, n_env, dtype=torch.float64).pin_memory() if dev.type == "cuda" else torch.empty(5, n_env, dtype=torch.float64) for _ in range(2)]
+        R.snap_event = [None, None]
         to_test(*self.sample_modules)
         self.assign_new_clips(np.arange(n_env))  # every sampling pass starts fresh episodes, like each reference worker
+        self.queue_next_clips(np.arange(n_env))
         obs = env.obs.to(self.dtype)
         R.state = self.running_state(obs) if self.running_state is not None else obs
 
+    def _drain_snapshot(self, slot):
+        """Host side of episode turnover for the step whose snapshot sits in `slot`: statistics, success history, new queue entries."""
+        R = self._ro
+        ev = R.snap_event[slot]
+        if ev is None:
+            return
+        if ev is not True:
+            ev.synchronize()
+        R.snap_event[slot] = None
+        host = R.snap_host[slot].numpy()
+        ids = np.nonzero(host[0])[0]
+        if len(ids):
+            R.logger.add_episodes(host[1][ids], host[2][ids])
+            self.on_episode_end(ids, host[3][ids], consumed=host[4][ids] != 0)
+            need = ids[host[4][ids] != 0]  # envs that took their queued window need a new one
+            if len(need):
+                self.queue_next_clips(need)
+
     @torch.no_grad()
     def rollout_step(self):
-        """One control step of every env: filter -> policy -> env.step -> buffers; resets finished episodes."""
+        """One control step of every env: filter -> policy -> env.step -> buffers -> device-side restart of finished episodes.
+        Nothing here waits for the GPU: the only host read is the previous step's pinned snapshot."""
         env, R = self.env, self._ro
-        n_env, dev, t, T = env.n_env, env.device, self._ro.t, self._ro.T
+        dev, t = env.device, self._ro.t
         R.states[:, t] = R.state
-        flags_np = np.ones(n_env) if self.mean_action else env.np_random.binomial(1, 1 - self.noise_rate, size=n_env)
-        mean_flag = torch.from_numpy(flags_np.astype(np.float64)).to(dev)
+        mean_flag = R.mean_flags[t]
         action = self.policy_net.select_action(self.trans_policy(R.state), mean_flag).to(torch.float64).contiguous()
         R.actions[:, t] = action
         env.step(action)
         r = env.reward.to(self.dtype)
-        done = env.done.bool()
+        done = env.done.to(torch.float64)
         if self.end_reward:
             r = r + env.env.field(5).to(self.dtype) * env.end_reward  # info["end"] * end_reward (agent.py:84-85)
         R.rewards[:, t] = r
-        R.masks[:, t] = (~done).to(self.dtype)
+        R.masks[:, t] = 1 - done
         R.exps[:, t] = 1 - mean_flag
         R.ep_len += 1
         R.ep_rew += r
         R.c_info_sum += env.reward_parts.sum(0)
-        # one host read per step (the clip sampler is host code): done flag, episode length / return, percent
-        host = torch.stack([done.to(self.dtype), R.ep_len.to(self.dtype), R.ep_rew, env.env.field(6).to(self.dtype)]).cpu().numpy()
-        ids = np.nonzero(host[0])[0]
-        if len(ids):
-            R.logger.add_episodes(host[1][ids], host[2][ids])
-            self.on_episode_end(ids, host[3][ids])
-            idt = torch.from_numpy(ids).to(dev)
-            R.ep_len[idt] = 0
-            R.ep_rew[idt] = 0
-            if t < T - 1:
-                self.assign_new_clips(ids)
+        env.auto_reset()
+        snap = R.snap_dev
+        snap[0], snap[1], snap[2], snap[3], snap[4] = done, R.ep_len, R.ep_rew, env.env.field(6), env.env.field(10).to(torch.float64)
+        slot = t & 1
+        self._drain_snapshot(slot)  # the snapshot written two steps ago (its buffer is reused now)
+        R.snap_host[slot].copy_(snap, non_blocking=True)
+        if dev.type == "cuda":
+            R.snap_event[slot] = torch.cuda.Event()
+            R.snap_event[slot].record()
+        else:
+            R.snap_event[slot] = True
+        keep = 1 - done
+        R.ep_len *= keep
+        R.ep_rew *= keep
         obs = env.obs.to(self.dtype)
         R.state = self.running_state(obs) if self.running_state is not None else obs
+        self._drain_snapshot(slot ^ 1)  # the previous step's snapshot: long since landed
         R.t += 1
 
     @torch.no_grad()
     def rollout_end(self):
         env, R = self.env, self._ro
         T, N = R.T, env.n_env * R.T
+        self._drain_snapshot((T - 1) & 1)  # the last step's episode ends
         # episodes cut by the end of the pass: bootstrap with V(s_T) folded into the last reward, then close the segment
         open_ = R.masks[:, T - 1] > 0
         if bool(open_.any()):

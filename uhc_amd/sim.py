@@ -127,8 +127,8 @@ class SimBatch:
         return ms.value, n.value
 
 
-E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE = range(10)
-_E_INT = {E_DONE, E_FAIL, E_END, E_CUR_T}
+E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE, E_CONSUMED = range(11)
+_E_INT = {E_DONE, E_FAIL, E_END, E_CUR_T, E_CONSUMED}
 FRAME_STRIDE = 584
 FR = dict(qpos=(0, 76), qvel=(76, 75), wbpos=(151, 72), wbquat=(223, 96), bquat=(319, 96), bangvel=(415, 72), ee_wpos=(487, 15), com=(502, 3), body_com=(512, 72))
 
@@ -207,6 +207,22 @@ class EnvBatch:
             nz = C.c_void_p(noise.data_ptr())
         check(self.L.uhc_env_reset(self._e, C.c_void_p(ids.data_ptr()), ids.shape[0], nz))
         self._keep = (ids, noise)
+
+    def set_next(self, env_ids, clip_ids, fr_start, fr_len, noise: Optional[torch.Tensor] = None):
+        """Queue the window (and reset noise) the listed envs start when their current episode is done (uhc_env_set_next)."""
+        a, b, c, d = (self._i32(x, self.device) for x in (env_ids, clip_ids, fr_start, fr_len))
+        nz = None
+        if noise is not None:
+            noise = noise.to(self.device, torch.float64).contiguous()
+            assert noise.shape == (a.shape[0], self.sim.model.nu)
+            nz = C.c_void_p(noise.data_ptr())
+        check(self.L.uhc_env_set_next(self._e, C.c_void_p(a.data_ptr()), a.shape[0], C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr()),
+                                      C.c_void_p(d.data_ptr()), nz))
+        self._keep_next = (a, b, c, d, noise)  # alive until the stream has consumed them (the next call replaces them a step later)
+
+    def auto_reset(self):
+        """Device-side episode turnover of every env whose done flag is set (uhc_env_auto_reset); no host round trip."""
+        check(self.L.uhc_env_auto_reset(self._e))
 
     def step(self, action: torch.Tensor, active: Optional[torch.Tensor] = None):
         assert action.dtype == torch.float64 and action.is_contiguous() and action.shape == (self.n_env, self.sim.ctrl.action_dim)
