@@ -28,6 +28,27 @@ ALGO_BYTES_PER_ENV_STEP = 8 * (76 + 75 + 75 + 105 + 69 + 76 + 75 + 75 + 75 + 100
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the fused step kernel from the committed rocprofv3 PMC passes of this same workload
+    (profiles/*_pmc_{FETCH,WRITE}_SIZE.txt, written by tools/profile_on_gpu.sh; the counters are reported in KB).  PMC
+    collection needs rocprofv3 around the process, so the live run quotes the latest committed pass (null if none)."""
+    import glob
+    import re
+    tot, src = 0.0, []
+    for kind in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.txt")))
+        if not files:
+            return None, None
+        for line in open(files[-1]):
+            if line.startswith("void uhc_step_kernel<0, true>") and f"| {kind} |" in line:
+                tot += float(line.split("|")[2]) * 1024.0
+                src.append(os.path.basename(files[-1]))
+                break
+        else:
+            return None, None
+    return tot, "+".join(src)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -161,6 +182,7 @@ def main():
     if rank == 0:
         kern_ms = kern_total_ms / max(kern_n, 1)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic() if n_env == 1024 else (None, None)
         out = {
             "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
@@ -169,9 +191,12 @@ def main():
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
                                    "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "launches": kern_n,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "note": "fused f64 step: state-only HBM traffic, bound by dependent f64 VALU/LDS latency (DESIGN.md section 5)"},
+                         "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
+                         "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
+                                 "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
+                                 "above the algorithmic bytes is the L2-resident schedule tables and the per-substep mass-matrix work row"},
             "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "pgs_iters_mean": float(iters.mean()),
                                "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},
