@@ -211,6 +211,10 @@ int32_t uhc_env_field(UhcEnv* e, int32_t field, void** d_ptr, int64_t* count);
  * d_frames [n_frames][UHC_FRAME_STRIDE], d_clip_start int32 [n_clips], d_clip_beta [n_clips][17] */
 int32_t uhc_env_set_bank(UhcEnv* e, const double* d_frames, int64_t n_frames, const int32_t* d_clip_start,
                          const double* d_clip_beta, int32_t n_clips);
+/* Per-clip body shape (the reference rebuilds the MuJoCo model from the clip's beta in load_expert -> reset_robot,
+ * humanoid_im.py:154-180,204): d_clip_model int32 [n_clips] (borrowed, NULL to switch off) names, for every clip of the
+ * bank, which of the batch's models (uhc_batch_create) its episodes run on; assign / auto_reset switch the env's model. */
+int32_t uhc_env_set_clip_models(UhcEnv* e, const int32_t* d_clip_model);
 /* load_expert (humanoid_im.py:182-215): env d_env_ids[i] tracks frames [fr_start, fr_start+fr_len) of clip d_clip_ids[i] */
 int32_t uhc_env_assign(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int32_t* d_clip_ids,
                        const int32_t* d_fr_start, const int32_t* d_fr_len);

@@ -193,3 +193,55 @@ def test_auto_reset_equals_assign_plus_reset(model, ctrl):
     assert eb.field(S.E_CONSUMED).cpu().tolist()[2] == 1
     q2 = sb.field(S.F_QPOS)[2].cpu().numpy()
     np.testing.assert_allclose(q2[:7], expert["qpos"][39 - 2][:7], atol=1e-15)  # clip 1 = clip 0 reversed, window start 2
+
+
+def test_per_clip_body_shape_switches_the_env_model(tmp_path):
+    """smpl_shape-style operation: every clip carries its own body shape (model); an env runs on the model of the clip it
+    is assigned -- at assign + reset and at a device-side restart -- and matches the oracle built on that model."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
+    from uhc_amd.envs.humanoid_im import VecHumanoidEnv
+    from uhc_amd.model.mjcf import scale_model
+    from uhc_amd.utils.config_utils.copycat_config import Config
+    cfg = Config(cfg_id="copycat_mi355x", base_dir=str(tmp_path))
+    cfg.env_init_noise = 0.0
+    base = S.load_asset_model()
+    tall = scale_model(base, 1.12)
+    env = VecHumanoidEnv(cfg, n_env=3, shape_models=[tall])
+    pk = make_synthetic_amass(2, seed=5, t_range=(40, 50))
+    keys = list(pk.keys())
+    clips = {k: dict(pose_aa=v["pose_aa"], trans=v["trans"], beta=np.zeros(16), gender=0) for k, v in pk.items()}
+    env.set_clip_bank(clips, clip_model={keys[0]: 0, keys[1]: 1})
+    env.assign(np.arange(3), [keys[0], keys[1], keys[1]], [0, 0, 5], [30, 30, 8])
+    env.reset(np.arange(3))
+    env.sim.sync()
+    feats = [env.expert_features(clips[keys[0]], 0), env.expert_features(clips[keys[1]], 1)]
+    models = [base, tall]
+    xpos = env.sim.field(S.F_XPOS).cpu().numpy()
+    os_ = []
+    for e, (ci, st) in enumerate([(0, 0), (1, 0), (1, 5)]):
+        o = OracleSim(models[ci], env.ctrl)
+        o.set_state(feats[ci]["qpos"][st], feats[ci]["qvel"][st + 1])
+        np.testing.assert_allclose(xpos[e], o.get("xpos"), atol=1e-12)
+        os_.append(o)
+    assert np.abs(xpos[1] - OracleSim(base, env.ctrl).get("xpos")[: xpos.shape[1]]).max() > 1e-3  # really another body
+    # a few control steps on the respective models
+    act = np.random.default_rng(2).normal(scale=0.05, size=(3, env.action_dim))
+    for t in range(2):
+        env.step(torch.from_numpy(act).cuda())
+        env.sim.sync()
+        gq = env.sim.field(S.F_QPOS).cpu().numpy()
+        for e, (ci, st) in enumerate([(0, 0), (1, 0), (1, 5)]):
+            os_[e].do_simulation(act[e], feats[ci]["qpos"][min(st + t + 1, st + [30, 30, 3][e] - 1)][7:])
+            np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-9)
+    # env 2's 3-frame window is over: queue a window of the OTHER clip and restart on the device
+    assert env.done.cpu().tolist() == [0, 0, 1]
+    env.set_next([2], [keys[0]], [3], [25])
+    env.auto_reset()
+    env.sim.sync()
+    o = OracleSim(base, env.ctrl)
+    o.set_state(feats[0]["qpos"][3], feats[0]["qvel"][4])
+    np.testing.assert_allclose(env.sim.field(S.F_XPOS)[2].cpu().numpy(), o.get("xpos"), atol=1e-12)
+    env.close()

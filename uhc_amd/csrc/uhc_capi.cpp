@@ -117,6 +117,7 @@ struct UhcBatch {
     int* reset_mask = nullptr;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    int n_models = 1;
     // field table
     void* field_ptr[16] = {nullptr};
     int64_t field_count[16] = {0};
@@ -306,6 +307,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     }
     TRY(upload(b, all, &A.s.model_blob));
     if (h_env_model) TRY(upload(b, std::vector<int>(h_env_model, h_env_model + n_env), &A.s.env_model));
+    else if (n_models > 1) TRY(upload(b, std::vector<int>(n_env, 0), &A.s.env_model));  // selectable later (uhc_env_set_clip_models)
+    b->n_models = n_models;
 
     // ---- controller
     DevCtrl& C = A.c;
@@ -584,6 +587,7 @@ extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, c
     return launch(b, 1, nullptr, nullptr, b->reset_mask);
 }
 
+extern "C" int* uhc_internal_env_model(UhcBatch* b, int* n_models) { *n_models = b->n_models; return const_cast<int*>(b->A.s.env_model); }
 // ------------------------------------------------------------------ internal accessors for the env layer (uhc_env_capi.cpp)
 extern "C" int uhc_internal_set_error(const char* msg) { return fail("%s", msg); }
 extern "C" int uhc_internal_batch_info(UhcBatch* b, int* n_env, int* nq, int* nv, int* nu, int* nbody, int* action_dim, int* vf_dim,

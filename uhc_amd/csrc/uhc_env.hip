@@ -325,6 +325,7 @@ __global__ void uhc_env_assign_kernel(EnvArgs E, const int* env_ids, int n, cons
     E.clip_id[env] = c;
     E.e_start[env] = E.clip_start[c] + fr_start[r];
     E.e_len[env] = fr_len[r];
+    if (E.clip_model) E.env_model[env] = E.clip_model[c];
 }
 extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
                                             const int* fr_len, hipStream_t s) {
@@ -357,7 +358,11 @@ __global__ void uhc_env_auto_stage_kernel(EnvArgs E, double* out_qpos, double* o
     if (threadIdx.x == 0) {
         select[env] = go;
         E.consumed[env] = had;
-        if (had) { E.clip_id[env] = E.next_clip[env]; E.e_start[env] = E.clip_start[E.next_clip[env]] + E.next_start[env]; E.e_len[env] = E.next_len[env]; E.has_next[env] = 0; }
+        if (had) {
+            const int c = E.next_clip[env];
+            E.clip_id[env] = c; E.e_start[env] = E.clip_start[c] + E.next_start[env]; E.e_len[env] = E.next_len[env]; E.has_next[env] = 0;
+            if (E.clip_model) E.env_model[env] = E.clip_model[c];
+        }
         if (go) { E.cur_t[env] = 0; E.start_ind[env] = 0; }
     }
     if (!go) return;

@@ -15,6 +15,7 @@ extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* en
 extern "C" hipError_t uhc_launch_env_set_next(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
                                               const int* fr_len, const double* noise, hipStream_t s);
 extern "C" hipError_t uhc_launch_env_auto_stage(const EnvArgs* E, double* out_qpos, double* out_qvel, int* select, hipStream_t s);
+extern "C" int* uhc_internal_env_model(UhcBatch* b, int* n_models);
 extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, const double* d_qpos, const double* d_qvel);
 extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
                                             const int* fr_len, hipStream_t s);
@@ -127,6 +128,15 @@ extern "C" int32_t uhc_env_set_bank(UhcEnv* e, const double* d_frames, int64_t n
     if (!e || !d_frames || !d_clip_start || !d_clip_beta || n_frames < 1 || n_clips < 1) return uhc_internal_set_error("uhc_env_set_bank: bad argument");
     e->E.bank = d_frames; e->E.clip_start = d_clip_start; e->E.clip_beta = d_clip_beta;
     e->n_clips = n_clips; e->n_frames = n_frames;
+    return 0;
+}
+extern "C" int32_t uhc_env_set_clip_models(UhcEnv* e, const int32_t* d_clip_model) {
+    if (!e) return uhc_internal_set_error("uhc_env_set_clip_models: null env");
+    int n_models = 1;
+    int* em = uhc_internal_env_model(e->b, &n_models);
+    if (d_clip_model && (!em || n_models < 2)) return uhc_internal_set_error("uhc_env_set_clip_models: the batch was created with a single model");
+    e->E.clip_model = d_clip_model;
+    e->E.env_model = em;
     return 0;
 }
 static hipStream_t stream_of(UhcEnv* e) {

@@ -26,11 +26,14 @@ class _Box:
 
 
 class VecHumanoidEnv:
-    def __init__(self, cfg, n_env, device=0, mode="train", model=None):
+    def __init__(self, cfg, n_env, device=0, mode="train", model=None, shape_models=None):
+        """shape_models: optional list of further models with the topology of `model` (body shapes, cf. the smpl_shape configs:
+        the reference rebuilds the model from each clip's beta); `set_clip_bank(..., clip_model=)` maps clips onto them."""
         self.cc_cfg = self.cfg = cfg
         self.mode = mode
         self.n_env = int(n_env)
         self.model = model if model is not None else S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh"))
+        self.models = [self.model] + list(shape_models or [])
         self.base_rot = cfg.data_specs.get("base_rot", [0.7071, 0.7071, 0.0, 0.0])
         self.rfc_rate = 1 if not cfg.rfc_decay else 0
         self.converter = SMPLConverter(self.model, self.model, smpl_model=cfg.robot_cfg.get("model", "smpl"))
@@ -39,7 +42,7 @@ class VecHumanoidEnv:
                                 residual_force_lim=cfg.residual_force_lim, rfc_rate=self.rfc_rate, action_type=cfg.action_type,
                                 pd_mul=cfg.get("pd_mul", 1), tq_mul=cfg.get("tq_mul", 1), base_rot=self.base_rot,
                                 residual_force_bodies=cfg.residual_force_bodies, residual_force_torque=cfg.residual_force_torque)
-        self.sim = S.SimBatch(self.model, self.ctrl, self.n_env, device=device)
+        self.sim = S.SimBatch(self.models, self.ctrl, self.n_env, device=device)
         self.device = self.sim.device
         thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
         if cfg.env_term_body != "body":
@@ -59,26 +62,32 @@ class VecHumanoidEnv:
         self.obs_dim = self.env.obs_dim
         self.observation_space, self.action_space = _Box(self.obs_dim), _Box(self.action_dim)
         self.humanoid = Humanoid(model=self.model)
+        self._humanoids = {0: self.humanoid}
         self.np_random = np.random.RandomState()
         self.end_reward = 0.0
         self.dt = self.model.timestep * 15
         self.clip_keys, self._clip_index, self._clip_len = [], {}, None
 
     # ---- expert clips -------------------------------------------------------------------------------------
-    def expert_features(self, sample):
-        """load_expert's feature computation (humanoid_im.py:182-215): AMASS window -> qpos -> qpos_fk."""
-        qpos = smpl_to_qpose(pose=sample["pose_aa"], mj_model=self.model, trans=np.asarray(sample["trans"]).squeeze(),
+    def expert_features(self, sample, model_index=0):
+        """load_expert's feature computation (humanoid_im.py:182-215): AMASS window -> qpos -> qpos_fk, on the clip's model."""
+        m = self.models[model_index]
+        if model_index not in self._humanoids:
+            self._humanoids[model_index] = Humanoid(model=m)
+        qpos = smpl_to_qpose(pose=sample["pose_aa"], mj_model=m, trans=np.asarray(sample["trans"]).squeeze(),
                              model=self.cc_cfg.robot_cfg.get("model", "smpl"), count_offset=self.cc_cfg.robot_cfg.get("mesh", True))
-        return self.humanoid.qpos_fk(torch.from_numpy(qpos))
+        return self._humanoids[model_index].qpos_fk(torch.from_numpy(qpos))
 
-    def set_clip_bank(self, clips: dict):
-        """clips: {key: sample dict with pose_aa/trans/beta/gender of the WHOLE clip}.  Builds the HBM bank once."""
+    def set_clip_bank(self, clips: dict, clip_model: dict = None):
+        """clips: {key: sample dict with pose_aa/trans/beta/gender of the WHOLE clip}.  Builds the HBM bank once.
+        clip_model: {key: index into [model] + shape_models}: the body shape every episode of that clip runs on."""
         frames, starts, betas, lens = [], [], [], []
         n = 0
         self.clip_keys = list(clips.keys())
-        for k in self.clip_keys:
+        cm = [int(clip_model[k]) if clip_model else 0 for k in self.clip_keys]
+        for k, mi in zip(self.clip_keys, cm):
             c = clips[k]
-            fr = S.pack_expert_frames(self.expert_features(c))
+            fr = S.pack_expert_frames(self.expert_features(c, mi))
             frames.append(fr)
             starts.append(n)
             lens.append(fr.shape[0])
@@ -91,6 +100,7 @@ class VecHumanoidEnv:
         self._clip_index = {k: i for i, k in enumerate(self.clip_keys)}
         self._clip_len = np.array(lens)
         self.env.set_bank(torch.from_numpy(np.concatenate(frames)), torch.tensor(starts, dtype=torch.int32), torch.from_numpy(np.stack(betas)))
+        self.env.set_clip_models(torch.tensor(cm, dtype=torch.int32) if clip_model else None)
 
     def set_clip_bank_from_loader(self, data_loader):
         clips = {k: dict(pose_aa=data_loader.data["pose_aa"][k], trans=data_loader.data["trans"][k], beta=data_loader.data["beta"][k],

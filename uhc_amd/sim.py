@@ -189,6 +189,17 @@ class EnvBatch:
                                       C.c_void_p(clip_beta.data_ptr()), clip_start.shape[0]))
         self._bank = (frames, clip_start, clip_beta)  # keep alive: the library borrows the pointers
 
+    def set_clip_models(self, clip_model: Optional[torch.Tensor]):
+        """Which of the batch's models the episodes of each clip run on (per-clip body shape); None switches it off."""
+        if clip_model is None:
+            check(self.L.uhc_env_set_clip_models(self._e, None))
+            self._clip_model = None
+            return
+        cm = clip_model.to(self.device, torch.int32).contiguous()
+        assert cm.shape == (self._bank[1].shape[0],)
+        check(self.L.uhc_env_set_clip_models(self._e, C.c_void_p(cm.data_ptr())))
+        self._clip_model = cm  # borrowed by the library
+
     @staticmethod
     def _i32(t, device):
         return t.to(device, torch.int32).contiguous()
