@@ -99,6 +99,38 @@ def cpu_baseline(agent, n_env_gpu):
                       f"OpenMP over envs; MuJoCo itself is not installed"}
 
 
+def cpu_ppo_baseline(agent, batch):
+    """PyTorch-CPU float64 full-batch PPO epoch (value step + policy step: forward, backward, Adam) on a bounded sample of the
+    collected batch, all host threads -- the learner half of the reference's CPU path.  Returns samples/s of a 10-epoch update."""
+    import copy
+    n = min(1024, batch.states.shape[0])
+    torch.set_num_threads(os.cpu_count() or 1)
+    pol, val = copy.deepcopy(agent.policy_net).cpu().double(), copy.deepcopy(agent.value_net).cpu().double()
+    op = torch.optim.Adam([p for p in pol.parameters() if p.requires_grad], lr=5e-5)
+    ov = torch.optim.Adam(val.parameters(), lr=3e-4)
+    x, a = batch.states[:n].detach().cpu().double(), batch.actions[:n].detach().cpu().double()
+    ret, adv = torch.randn(n, 1, dtype=torch.float64), torch.randn(n, 1, dtype=torch.float64)
+    with torch.no_grad():
+        flp = pol.get_log_prob(x, a)
+
+    def epoch():
+        vl = (val(x) - ret).pow(2).mean()
+        ov.zero_grad(); vl.backward(); ov.step()
+        ratio = torch.exp(pol.get_log_prob(x, a) - flp)
+        pl = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
+        op.zero_grad(); pl.backward(); op.step()
+
+    epoch()
+    t0, k = time.perf_counter(), 0
+    while True:
+        epoch()
+        k += 1
+        if time.perf_counter() - t0 > 5.0 or k >= 3:
+            break
+    el = (time.perf_counter() - t0) / k
+    return {"ppo_value": n / (10 * el), "ppo_unit": "samples/s (10-epoch full-batch update)", "ppo_sample": f"{k} epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +188,7 @@ def main():
     kern_total_ms, kern_n = env.sim.kernel_time()
     env.sim.set_timing(False)
     nefc = env.sim.field(S.F_NEFC).cpu().numpy()
+    ncon = env.sim.field(S.F_NCON).cpu().numpy()
     iters = env.sim.field(S.F_SOLVER_ITER).cpu().numpy()
     overflow = int(env.sim.field(S.F_EFC_OVERFLOW).sum().item())
     batch, logger = agent.rollout_end()
@@ -166,11 +199,13 @@ def main():
     # ---- one PPO update over the collected samples (outside the timed region of `value`)
     ppo = None
     if not args.no_ppo:
+        agent.time_comm = dist_on
         fence()
         t1 = time.perf_counter()
         agent.update_params(batch)
         fence()
         t_up = time.perf_counter() - t1
+        ncalls, comm_ms, comm_bytes = agent.comm_summary()
         if dist_on:
             tt = torch.tensor([t_up], device="cuda", dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -179,6 +214,10 @@ def main():
         flops = n_samples * 503e6  # ~503 MFLOP per sample per iteration (10 epochs, both nets)
         ppo = {"samples": n_samples, "update_s": t_up, "samples_per_s": n_samples / t_up, "dtype": args.ppo_dtype, "epochs": cfg.num_optim_epoch,
                "gemm_tflops": flops / t_up / 1e12, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
+        if ncalls:  # rank 0's view of the gradient exchange: one flat all-reduce per network per optimisation step
+            algbw = comm_bytes * ncalls / (comm_ms * 1e-3) / 1e9
+            ppo["allreduce"] = {"calls": ncalls, "bytes_per_call": comm_bytes, "total_ms": comm_ms, "algbw_GBs": algbw,
+                                "busbw_GBs": algbw * 2 * (world - 1) / world, "share_of_update": comm_ms * 1e-3 / t_up}
     if rank == 0:
         kern_ms = kern_total_ms / max(kern_n, 1)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
@@ -198,6 +237,9 @@ def main():
                                  "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
                                  "above the algorithmic bytes is the L2-resident schedule tables and the per-substep mass-matrix work row"},
             "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "pgs_iters_mean": float(iters.mean()),
+                               "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
+                               "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
+                               "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17])[0].tolist(),
                                "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},
         }
@@ -205,6 +247,8 @@ def main():
             out["ppo"] = ppo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(agent, n_env)
+            if ppo:
+                out["cpu_baseline"].update(cpu_ppo_baseline(agent, batch))
         print(json.dumps(out))
     if dist_on:
         td.barrier()

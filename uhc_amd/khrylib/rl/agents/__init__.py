@@ -245,7 +245,15 @@ class AgentPG(Agent):
                 off += k
         for i, (_, n) in enumerate(params_and_scale):
             buf[off + i] = float(n)
+        timed = getattr(self, "time_comm", False) and buf.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if timed:
+            e1.record()
+            self._comm_events = getattr(self, "_comm_events", [])
+            self._comm_events.append((e0, e1, buf.numel() * buf.element_size()))
         counts = buf[off:off + len(params_and_scale)]
         off = 0
         for i, (ps, _) in enumerate(params_and_scale):
@@ -255,6 +263,15 @@ class AgentPG(Agent):
                 k = p.numel()
                 p.grad.copy_((buf[off:off + k] / counts[i].clamp(min=1.0)).view_as(p.grad))
                 off += k
+
+    def comm_summary(self):
+        """(calls, total ms, bytes per call) of the gradient all-reduces timed since the last summary (time_comm = True)."""
+        ev = getattr(self, "_comm_events", [])
+        self._comm_events = []
+        if not ev:
+            return 0, 0.0, 0
+        torch.cuda.synchronize()
+        return len(ev), float(sum(a.elapsed_time(b) for a, b, _ in ev)), int(ev[0][2])
 
     def update_value(self, states, returns):
         for _ in range(self.value_opt_niter):
