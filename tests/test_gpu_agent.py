@@ -136,3 +136,25 @@ def test_release_explicit_variant(tmp_path):
     info = agent.optimize_policy(0)
     assert info["log"].num_steps == 32 * 6 and np.isfinite(info["log"].avg_c_info).all()
     agent.env.close()
+
+
+def test_split_k_linear_gradients():
+    """The full-batch learner's Linear layers take a split-K weight-gradient path on the GPU: same gradients as autograd's."""
+    import torch
+    from uhc_amd.khrylib.models.mlp import MLP
+    from uhc_amd.khrylib.rl.core import Value
+    torch.manual_seed(0)
+    net = Value(MLP(37, (64, 48), "gelu")).double().cuda()
+    x = torch.randn(4096 + 8, 37, dtype=torch.float64, device="cuda")      # not divisible by 32 -> plain path for the head
+    x2 = torch.randn(8192, 37, dtype=torch.float64, device="cuda")
+    for xx in (x, x2):
+        net.zero_grad()
+        net(xx).pow(2).mean().backward()
+        got = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad()
+        h = xx
+        for l in net.net.affine_layers:
+            h = torch.nn.functional.gelu(torch.nn.functional.linear(h, l.weight, l.bias))
+        torch.nn.functional.linear(h, net.value_head.weight, net.value_head.bias).pow(2).mean().backward()
+        for g, p in zip(got, net.parameters()):
+            assert torch.allclose(g, p.grad, rtol=1e-11, atol=1e-14)

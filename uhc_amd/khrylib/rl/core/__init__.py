@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
-from ...models.mlp import MLP
+from ...models.mlp import MLP, linear
 
 
 def estimate_advantages(rewards, masks, values, gamma, tau, seg_len=None, normalize=True, stats_reduce=None):
@@ -90,7 +90,7 @@ class PolicyGaussian(Policy):
         self.action_log_std = nn.Parameter(torch.ones(1, action_dim) * cfg.log_std, requires_grad=not cfg.fix_std)
 
     def forward(self, x):
-        mean = self.action_mean(self.net(x))
+        mean = linear(self.action_mean, self.net(x))
         return DiagGaussian(mean, torch.exp(self.action_log_std.expand_as(mean)))
 
 
@@ -105,7 +105,7 @@ class Value(nn.Module):
         self.value_head.bias.data.mul_(0.0)
 
     def forward(self, x):
-        return self.value_head(self.net(x))
+        return linear(self.value_head, self.net(x))
 
 
 class LoggerRL:
