@@ -233,6 +233,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
+                         # the bound that matters: float64 vector issue/latency.  ~20 MFLOP per env-step (factorisations,
+                         # substitutions, Delassus rows, 100 PGS sweeps, tree recursions) against the 78.6 TFLOP/s FP64 vector peak
+                         "alu_f64": {"est_flop_per_env_step": 20e6, "achieved_tflops": 20e6 * n_env / (kern_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
+                                     "frac": 20e6 * n_env / (kern_ms * 1e-3) / 78.6e12},
                          "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
                                  "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
                                  "above the algorithmic bytes is the L2-resident schedule tables and the per-substep mass-matrix work row"},

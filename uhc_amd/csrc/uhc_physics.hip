@@ -437,35 +437,39 @@ __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld,
         return k < 1 ? 0 : k;
     };
     const FacWord* pw = (const FacWord*)T.fac_prog + LANE;
-    FacWord wn[Q];
     int k = next_step(T.nv);
-#pragma unroll
-    for (int q = 0; q < Q; q++) wn[q] = pw[q * UHC_WAVE];
     double Dk = k >= 1 ? LD[pk_of(LC, k) & 0xffff] : 1.0;
-    while (k >= 1) {
+    // one elimination step on the program words `cur`, fetching the next step's words into `nxt` (two register sets used in
+    // turn: rotating one set through copies would make every step wait for the loads it has just issued)
+    auto step = [&](const FacWord (&cur)[Q], FacWord (&nxt)[Q]) __attribute__((always_inline)) {
         const int pk = pk_of(LC, k), kk = pk & 0xffff, dk = (pk >> 16) & 0xff;
         const int ns = (dk * (dk + 1) / 2 + UHC_WAVE - 1) >> 6;
-        FacWord w[Q];
-#pragma unroll
-        for (int q = 0; q < Q; q++) w[q] = wn[q];
         pw += ns * UHC_WAVE;
 #pragma unroll
-        for (int q = 0; q < Q; q++) wn[q] = pw[q * UHC_WAVE];  // the table carries 8 slots of slack
+        for (int q = 0; q < Q; q++) nxt[q] = pw[q * UHC_WAVE];  // the table carries 8 slots of slack
         const bool na = LANE < dk;
         const unsigned int norm_adr = na ? ld_adr + 8u * (unsigned)(kk + 1 + LANE) : dump_adr;
         const double fraw = lds_at(SB, na ? norm_adr : zero_adr);
         switch (ns) {
-            case 1: factor_step<1>(SB, w, Dk, fraw, norm_adr); break;
-            case 2: factor_step<2>(SB, w, Dk, fraw, norm_adr); break;
-            case 3: factor_step<3>(SB, w, Dk, fraw, norm_adr); break;
-            case 4: factor_step<4>(SB, w, Dk, fraw, norm_adr); break;
-            case 5: factor_step<5>(SB, w, Dk, fraw, norm_adr); break;
-            case 6: factor_step<6>(SB, w, Dk, fraw, norm_adr); break;
-            case 7: factor_step<7>(SB, w, Dk, fraw, norm_adr); break;
-            default: factor_step<8>(SB, w, Dk, fraw, norm_adr); break;
+            case 1: factor_step<1>(SB, cur, Dk, fraw, norm_adr); break;
+            case 2: factor_step<2>(SB, cur, Dk, fraw, norm_adr); break;
+            case 3: factor_step<3>(SB, cur, Dk, fraw, norm_adr); break;
+            case 4: factor_step<4>(SB, cur, Dk, fraw, norm_adr); break;
+            case 5: factor_step<5>(SB, cur, Dk, fraw, norm_adr); break;
+            case 6: factor_step<6>(SB, cur, Dk, fraw, norm_adr); break;
+            case 7: factor_step<7>(SB, cur, Dk, fraw, norm_adr); break;
+            default: factor_step<8>(SB, cur, Dk, fraw, norm_adr); break;
         }
         k = next_step(k);
         if (k >= 1) Dk = LD[pk_of(LC, k) & 0xffff];
+    };
+    FacWord wa[Q], wb[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) wa[q] = pw[q * UHC_WAVE];
+    while (k >= 1) {
+        step(wa, wb);
+        if (k < 1) break;
+        step(wb, wa);
     }
     wsync();
     if (LC.v0) { const double di = 1.0 / LD[LC.m0]; S[L.dinv + LANE] = di; S[L.sdinv + LANE] = sqrt(di); }
