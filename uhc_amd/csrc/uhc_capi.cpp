@@ -229,6 +229,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         }
     }
     T.body_maxdepth = *std::max_element(body_depth.begin(), body_depth.end());
+    if (nb > 64) { delete b; return fail("uhc_batch_create: %d bodies > 64 (one body per lane)", nb); }
+    for (int i = 1; i < nb; i++)
+        if (d.body_jntnum[i] > 8) { delete b; return fail("uhc_batch_create: body %d has %d joints (> 8)", i, d.body_jntnum[i]); }
     std::vector<int> dof_depth(nv, 0), dof_ndesc(nv, 0);
     for (int i = 0; i < nv; i++) dof_depth[i] = d.dof_parentid[i] < 0 ? 0 : dof_depth[d.dof_parentid[i]] + 1;
     for (int i = nv - 1; i >= 0; i--)
@@ -249,6 +252,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         int adr = d.dof_madr[i];
         for (int j = i; j >= 0; j = d.dof_parentid[j], adr++) { m_row[adr] = (short)i; m_col[adr] = (short)j; }
     }
+    std::vector<unsigned short> m_ij(T.nM + 4, 0);
+    for (int e = 0; e < T.nM; e++) m_ij[e] = (unsigned short)((m_row[e] << 8) | m_col[e]);
     std::vector<unsigned char> ncommon((size_t)nv * nv, 0);
     for (int i = 0; i < nv; i++)
         for (int j = 0; j < nv; j++) {
@@ -291,7 +296,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.dof_bodyid, nv), &T.dof_bodyid)); TRY(upload(b, ivec(d.dof_jntid, nv), &T.dof_jntid));
     TRY(upload(b, ivec(d.dof_parentid, nv), &T.dof_parentid)); TRY(upload(b, ivec(d.dof_madr, nv + 1), &T.dof_madr));
     TRY(upload(b, dof_depth, &T.dof_depth)); TRY(upload(b, dof_ndesc, &T.dof_ndesc));
-        TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col));
+        TRY(upload(b, dof_anc, &T.dof_anc)); TRY(upload(b, ncommon, &T.dof_ncommon)); TRY(upload(b, m_row, &T.m_row)); TRY(upload(b, m_col, &T.m_col)); TRY(upload(b, m_ij, &T.m_ij));
     TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
     TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
@@ -348,7 +353,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
     L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
     L.M = carve(T.nM); L.LD = carve(T.nM + 2); L.dinv = carve(nv); L.sdinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
-    L.vec = carve(nv); L.z = carve(nv); L.zero = carve(2);
+    L.vec = carve(nv); L.z = carve(nv); L.zero = carve(2); L.mij = carve((T.nM + 3) / 4 + 1);
     L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
     L.Y = carve(UHC_MAXEFC * YS);
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
@@ -365,7 +370,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         off = 0;
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
         F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.sdinv = carve(nv); F.vec = F.z;
-        F.zero = carve(2);
+        F.zero = carve(2); F.mij = carve((T.nM + 3) / 4 + 1);
         F.LD = carve(T.nM + 2); F.M = F.LD;
         F.cdof = carve(6 * nv);
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);

@@ -23,6 +23,7 @@ struct DevTopo {
     const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_madr, *dof_depth, *dof_ndesc;
     const short* dof_anc;  // [nv][maxdepth+1]: ancestor of dof i at depth q (q <= depth(i)), anc[i][depth(i)] = i
     const short *m_row, *m_col;  // [nM] sparse-M entry -> (i, j)
+    const unsigned short* m_ij;  // [nM (+pad)] the same, packed i << 8 | j (nv <= 128)
     const unsigned char* dof_ncommon;  // [nv][nv] number of common chain entries of two dofs (depth of LCA + 1, 0 if none)
     const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
     const int *mesh_adjadr, *mesh_adj;
@@ -55,6 +56,7 @@ struct DevLds {
     int xpos, xquat, xmat, xipos, ximat, rootcom, cinert, crb, cvel, cacc, cfrc;
     int xanchor, xaxis, cdof, cdofdot;
     int M, LD, dinv, sdinv, bias, smooth, vec, z, zero;
+    int mij;  // 16-bit (row << 8 | col) of every sparse-M entry, loaded once per kernel (k_crb)
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
     int total;  // doubles
 };

@@ -154,12 +154,35 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define UHC_MREG 24
 struct MReg { double v[UHC_MREG]; };
 
+// Per-lane body constants, loaded once per kernel (lane = body): the level-synchronous tree passes of every substep
+// would otherwise fetch them from global tables inside their per-level branches and wait for L2 at each of the 9 levels.
+// jt packs the joint types of the body's joints, 2 bits each (<= 8 joints per body, checked by the host).
+struct BodyConst { int p, ja, jn, depth, da, dn, nsub, root, jt; bool act; };
+__device__ __forceinline__ BodyConst body_const(const DevTopo& T) {
+    BodyConst c;
+    const int b = LANE;
+    c.act = b > 0 && b < T.nbody;
+    c.p = c.act ? T.body_parentid[b] : 0;
+    c.ja = c.act ? T.body_jntadr[b] : 0;
+    c.jn = c.act ? T.body_jntnum[b] : 0;
+    c.depth = c.act ? T.body_depth[b] : -1;
+    c.da = c.act ? T.body_dofadr[b] : 0;
+    c.dn = c.act ? T.body_dofnum[b] : 0;
+    c.nsub = c.act ? T.body_nsub[b] : 0;
+    c.root = c.act ? T.body_rootid[b] : -1;
+    c.jt = 0;
+    for (int q = 0; q < c.jn && q < 8; q++) c.jt |= T.jnt_type[c.ja + q] << (2 * q);
+    return c;
+}
+__device__ __forceinline__ int jt_of(const BodyConst& c, int q) { return (c.jt >> (2 * q)) & 3; }
+__device__ __forceinline__ int jdofs(int jt) { return jt == UHC_JNT_FREE ? 6 : jt == UHC_JNT_BALL ? 3 : 1; }
+
 // ------------------------------------------------------------------ P1 kinematics
 // Pass 1 (all bodies in parallel): pose of each body relative to its parent frame, including its own
 // joint rotations (the expensive sincos work).  Pass 2 (level-synchronous): compose with the parent.
 // Pass 3 (all joints in parallel): joint anchors/axes to the world frame.
 template <bool FAST>
-__device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S) {
+__device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S, const BodyConst& BC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
@@ -169,14 +192,15 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
         xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
         for (int k = 0; k < 9; k++) { xmat[k] = (k % 4 == 0); ximat[k] = (k % 4 == 0); }
     }
-    const bool act = b > 0 && b < T.nbody;
-    const int depth = act ? T.body_depth[b] : -1;
-    double lpos[3] = {0, 0, 0}, lquat[4] = {1, 0, 0, 0};
+    const bool act = BC.act;
+    const int depth = BC.depth;
+    double lpos[3] = {0, 0, 0}, lquat[4] = {1, 0, 0, 0}, ip[3] = {0, 0, 0}, iq[4] = {1, 0, 0, 0};
     bool is_free = false;
-    int p = 0, ja = 0, jn = 0;
+    const int p = BC.p, ja = BC.ja, jn = BC.jn;
     if (act) {
-        p = T.body_parentid[b]; ja = T.body_jntadr[b]; jn = T.body_jntnum[b];
-        is_free = jn == 1 && T.jnt_type[ja] == UHC_JNT_FREE;
+        is_free = jn == 1 && jt_of(BC, 0) == UHC_JNT_FREE;
+        for (int k = 0; k < 3; k++) ip[k] = mb[A.o.body_ipos + 3 * b + k];
+        for (int k = 0; k < 4; k++) iq[k] = mb[A.o.body_iquat + 4 * b + k];
         double R[9], t[3];
         if (is_free) {
             const double* q = S + L.qpos + T.jnt_qposadr[ja];
@@ -188,7 +212,7 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
             for (int k = 0; k < 3; k++) lpos[k] = mb[A.o.body_pos + 3 * b + k];
             for (int k = 0; k < 4; k++) lquat[k] = mb[A.o.body_quat + 4 * b + k];
             for (int j = ja; j < ja + jn; j++) {
-                const int qa = T.jnt_qposadr[j], jt = T.jnt_type[j];
+                const int qa = T.jnt_qposadr[j], jt = jt_of(BC, j - ja);
                 double qloc[4], jp[3], jx[3], ax[3];
                 for (int k = 0; k < 3; k++) { jp[k] = mb[A.o.jnt_pos + 3 * j + k]; jx[k] = mb[A.o.jnt_axis + 3 * j + k]; }
                 quat_to_mat(R, lquat);
@@ -232,9 +256,7 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
                 quat_normalize(quat);
             }
             quat_to_mat(R, quat);
-            double ip[3], iq[4], qi[4], Ri[9];
-            for (int k = 0; k < 3; k++) ip[k] = mb[A.o.body_ipos + 3 * b + k];
-            for (int k = 0; k < 4; k++) iq[k] = mb[A.o.body_iquat + 4 * b + k];
+            double qi[4], Ri[9];
             mat_vec(t, R, ip);
             quat_mul(qi, quat, iq);
             quat_to_mat(Ri, qi);
@@ -261,13 +283,13 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
 
 // ------------------------------------------------------------------ P2 comPos: tree COM, cinert (body/lane), cdof (joint/lane)
 template <bool FAST>
-__device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb, double* S) {
+__device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb, double* S, const BodyConst& BC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
-    const bool act = b > 0 && b < T.nbody;
+    const bool act = BC.act;
     const double mass = act ? mb[A.o.body_mass + b] : 0.0;
-    const int root = act ? T.body_rootid[b] : -1;
+    const int root = BC.root;
     double xi[3] = {0, 0, 0};
     if (act) for (int k = 0; k < 3; k++) xi[k] = S[L.xipos + 3 * b + k];
     // one reduction per kinematic tree (bodies whose parent is the world)
@@ -329,13 +351,13 @@ __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb,
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
 template <bool FAST>
-__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, double* Mw) {
+__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, double* Mw, const BodyConst& BC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
-    if (b > 0 && b < T.nbody) {  // bodies are in DFS order: subtree(b) = [b, b + nsub)
+    if (BC.act) {  // bodies are in DFS order: subtree(b) = [b, b + nsub)
         double acc[10];
-        const int n = T.body_nsub[b];
+        const int n = BC.nsub;
         for (int k = 0; k < 10; k++) acc[k] = S[L.cinert + 10 * (b + n - 1) + k];
         for (int c = b + n - 2; c >= b; c--)
             for (int k = 0; k < 10; k++) acc[k] += S[L.cinert + 10 * c + k];
@@ -358,7 +380,7 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
         if (!FAST && m * UHC_WAVE >= T.nM) break;
         double v = 0.0;
         if (e < T.nM) {
-            const int i = T.m_row[e], j = T.m_col[e];
+            const int ij = ((const unsigned short*)(S + L.mij))[e], i = ij >> 8, j = ij & 0xff;
             double a[6], c[6];
             for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
             v = dot6(a, c);
@@ -529,22 +551,24 @@ __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, in
 
 // ------------------------------------------------------------------ P7 velocities + bias forces
 template <bool FAST>
-__device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S) {
+__device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S, const BodyConst& BC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     if (b == 0) for (int k = 0; k < 6; k++) S[L.cvel + k] = 0;
     wsync();
-    const int depth = b < T.nbody ? T.body_depth[b] : -1;
+    const int depth = BC.depth;
     for (int level = 1; level <= T.body_maxdepth; level++) {
         if (depth == level) {
             double cvel[6], t[6], cd[6];
-            const int p = T.body_parentid[b];
+            const int p = BC.p;
             for (int k = 0; k < 6; k++) cvel[k] = S[L.cvel + 6 * p + k];
-            const int ja = T.body_jntadr[b], jn = T.body_jntnum[b];
-            for (int j = ja; j < ja + jn; j++) {
-                int da = T.jnt_dofadr[j];
-                const int jt = T.jnt_type[j];
+            const int jn = BC.jn;
+            int dnext = BC.da;
+            for (int q = 0; q < jn; q++) {
+                const int jt = jt_of(BC, q);
+                int da = dnext;
+                dnext += jdofs(jt);
                 if (jt == UHC_JNT_FREE) {
                     for (int k = 0; k < 18; k++) S[L.cdofdot + 6 * da + k] = 0;
                     for (int k = 0; k < 3; k++) {
@@ -576,19 +600,19 @@ __device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S) {
     }
 }
 template <bool FAST>
-__device__ __forceinline__ void k_rne(const KernelArgs& A, double* S) {  // qfrc_bias = RNE(qacc = 0)
+__device__ __forceinline__ void k_rne(const KernelArgs& A, double* S, const BodyConst& BC) {  // qfrc_bias = RNE(qacc = 0)
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
     if (b == 0) for (int k = 0; k < 6; k++) { S[L.cacc + k] = k < 3 ? 0.0 : -T.gravity[k - 3]; S[L.cfrc + k] = 0; }
     wsync();
-    const int depth = b < T.nbody ? T.body_depth[b] : -1;
+    const int depth = BC.depth;
     for (int level = 1; level <= T.body_maxdepth; level++) {
         if (depth == level) {
             double cacc[6], cvel[6], I[10], t[6], u[6], f[6];
-            const int p = T.body_parentid[b];
+            const int p = BC.p;
             for (int k = 0; k < 6; k++) { cacc[k] = S[L.cacc + 6 * p + k]; cvel[k] = S[L.cvel + 6 * b + k]; }
-            const int da = T.body_dofadr[b], dn = T.body_dofnum[b];
+            const int da = BC.da, dn = BC.dn;
             for (int i = da; i < da + dn; i++) {
                 const double qv = S[L.qvel + i];
                 for (int s = 0; s < 6; s++) cacc[s] += S[L.cdofdot + 6 * i + s] * qv;
@@ -603,14 +627,14 @@ __device__ __forceinline__ void k_rne(const KernelArgs& A, double* S) {  // qfrc
     }
     // subtree sums of cfrc (DFS order) gathered per dof
     double sub[6] = {0, 0, 0, 0, 0, 0};
-    if (b > 0 && b < T.nbody) {
-        const int n = T.body_nsub[b];
+    if (BC.act) {
+        const int n = BC.nsub;
         for (int k = 0; k < 6; k++) sub[k] = S[L.cfrc + 6 * (b + n - 1) + k];
         for (int c = b + n - 2; c >= b; c--)
             for (int k = 0; k < 6; k++) sub[k] += S[L.cfrc + 6 * c + k];
     }
     wsync();
-    if (b > 0 && b < T.nbody) for (int k = 0; k < 6; k++) S[L.cfrc + 6 * b + k] = sub[k];
+    if (BC.act) for (int k = 0; k < 6; k++) S[L.cfrc + 6 * b + k] = sub[k];
     wsync();
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         double a[6], c[6];
@@ -1346,15 +1370,15 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
 template <bool FAST>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, double* Mw PROF_ARGS) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, double* Mw PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     FwdOut out = {0, 0, 0, 0};
-    k_kinematics<FAST>(A, mb, S);
+    k_kinematics<FAST>(A, mb, S, BC);
     PROF(1)
-    k_com_pos<FAST>(A, mb, S);
+    k_com_pos<FAST>(A, mb, S, BC);
     PROF(2)
-    k_crb<FAST>(A, mb, S, Mw);
+    k_crb<FAST>(A, mb, S, Mw, BC);
     PROF(3)
     if (!FAST) {
         for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
@@ -1362,9 +1386,9 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     }
     k_factor<FAST>(A, S, L.LD, LC);
     PROF(4)
-    k_com_vel<FAST>(A, S);
+    k_com_vel<FAST>(A, S, BC);
     PROF(5)
-    k_rne<FAST>(A, S);
+    k_rne<FAST>(A, S, BC);
     PROF(6)
     k_smooth<FAST>(A, mb, S, LC);
     PROF(7)
@@ -1578,6 +1602,11 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
     for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
     if (MODE == 0 && !FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
+    {   // (row, col) of the sparse mass-matrix entries, two per 32-bit word
+        unsigned int* dst = (unsigned int*)(S + L.mij);
+        const unsigned int* src = (const unsigned int*)T.m_ij;
+        for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
+    }
     if (LANE == 0) { S[L.zero] = 0.0; S[L.LD + T.nM] = 0.0; S[L.LD + T.nM + 1] = 0.0; }  // slots idle lanes read / write instead of branching
     if (MODE == 0 && A.c.rfc_mode == 2) {  // explicit RFC reads the kinematics of the previous forward pass
         for (int i = LANE; i < 6 * T.nv; i += UHC_WAVE) S[L.cdof + i] = A.s.cdof[(size_t)env * 6 * T.nv + i];
@@ -1593,6 +1622,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         }
     }
     const LaneConst LC = lane_const(T);
+    const BodyConst BC = body_const(T);
     // joint-space inertia between substeps: the PD solve of substep t+1 uses M of substep t's forward pass.  The fast
     // kernel parks it in a per-env HBM work row (each lane re-reads exactly the entries it wrote); the committed copy
     // qM is only replaced once the whole control step has succeeded, so a redo by the general kernel starts clean.
@@ -1604,7 +1634,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     bool ran = false;
     PROF_DECL
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S, LC, Mwork PROF_PASS);
+        fo = k_forward<FAST>(A, mb, S, LC, BC, Mwork PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
@@ -1625,7 +1655,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
-            fo = k_forward<FAST>(A, mb, S, LC, Mwork PROF_PASS);
+            fo = k_forward<FAST>(A, mb, S, LC, BC, Mwork PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && overflow) break;
