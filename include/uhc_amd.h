@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UHC_ABI_VERSION 2
+#define UHC_ABI_VERSION 3
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -175,7 +175,8 @@ typedef struct UhcEnv UhcEnv;
 
 /* constants of HumanoidEnv (uhc/envs/humanoid_im.py) and of the reward (uhc/losses/reward_function.py:12-36) */
 typedef struct UhcEnvDesc {
-    int32_t obs_v;               /* 2: get_full_obs_v2 (humanoid_im.py:419-503); 1: get_full_obs_v1 (:323-417); 6: get_full_obs_v6 (:596-666) */
+    int32_t obs_v;               /* 2: get_full_obs_v2 (humanoid_im.py:419-503); 1: get_full_obs_v1 (:323-417); 6: get_full_obs_v6 (:596-666);
+                                  * 3: get_full_obs_v3 (:758-767) = fut_frames v2 blocks, look-ahead 0, skip, 2 skip, ... */
     int32_t has_shape;           /* append beta(16) + gender to the observation (humanoid_im.py:1390-1406) */
     int32_t env_episode_len;     /* cfg.env_episode_len */
     int32_t env_expert_trail_steps;
@@ -184,6 +185,8 @@ typedef struct UhcEnvDesc {
     double body_diff_thresh;     /* humanoid_im.py:88-89 */
     double reward_weights[10];   /* w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf */
     const double* jpos_diffw;    /* [nbody-1] SMPLConverter.get_new_diff_weight() (host) */
+    int32_t fut_frames;          /* obs_v 3: cfg.fut_frames (default 10) */
+    int32_t fut_skip;            /* obs_v 3: cfg.skip (default 10) */
 } UhcEnvDesc;
 
 /* expert frame record layout of the clip bank (doubles; see uhc_amd/csrc/uhc_device_env.h) */

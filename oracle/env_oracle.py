@@ -94,6 +94,11 @@ def full_obs_v1(qpos, qvel, xpos, xquat, xipos, expert, cur_t, start_ind=0, base
     return np.concatenate([v2[:cut], r_com.ravel(), diff_com.ravel(), v2[cut:]])
 
 
+def full_obs_v3(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, gender=None, fut_frames=10, skip=10, base_rot=BASE_ROT):
+    """humanoid_im.py:758-767: v2 observations at look-aheads 0, skip, 2 skip, ... concatenated."""
+    return np.concatenate([full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t + i, start_ind, beta, gender, base_rot) for i in range(0, fut_frames * skip, skip)])
+
+
 def get_heading_new(q):
     return math.atan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] * q[2] + q[3] * q[3]))  # math_utils.py:185-190
 

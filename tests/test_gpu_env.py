@@ -32,7 +32,7 @@ def _make(model, ctrl, n_env, expert, beta, obs_v=2, reward_v=0, has_shape=True)
     from uhc_amd import sim as S
     from uhc_amd._capi import env_desc
     sb = S.SimBatch(model, ctrl, n_env)
-    eb = S.EnvBatch(sb, env_desc(model, obs_v=obs_v, has_shape=has_shape, reward_weights=REWARD_W, reward_v=reward_v))
+    eb = S.EnvBatch(sb, env_desc(model, obs_v=obs_v, has_shape=has_shape, reward_weights=REWARD_W, reward_v=reward_v, fut_frames=3, fut_skip=4))
     frames = S.pack_expert_frames(expert)
     frames2 = np.concatenate([frames, frames[::-1].copy()])  # clip 1 = clip 0 reversed (only a second id to address)
     clip_start = torch.tensor([0, frames.shape[0]], dtype=torch.int32)
@@ -45,12 +45,14 @@ def _oracle_obs(E, obs_v, o, w, t, beta):
     xpos, xquat, xipos = o.get("xpos").reshape(-1, 3), o.get("xquat").reshape(-1, 4), o.get("xipos").reshape(-1, 3)
     if obs_v == 1:
         return E.full_obs_v1(o.get("qpos"), o.get("qvel"), xpos, xquat, xipos, w, t, 0)
+    if obs_v == 3:
+        return E.full_obs_v3(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0, fut_frames=3, skip=4)
     if obs_v == 6:
         return E.full_obs_v6(o.get("qpos"), o.get("qvel"), xpos, w, t, 0, beta, 2.0)
     return E.full_obs_v2(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)
 
 
-@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1)])
+@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1), (3, 0)])
 def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     import torch
     from oracle import env_oracle as E
@@ -81,7 +83,7 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     gobs = eb.field(S.E_OBS).cpu().numpy()
     for e in range(n):
         np.testing.assert_allclose(gobs[e], _oracle_obs(E, obs_v, os_[e], wins[e], 0, beta), atol=1e-11)
-    assert eb.obs_dim == {2: 657, 1: 784, 6: 401}[obs_v]
+    assert eb.obs_dim == {2: 657, 1: 784, 6: 401, 3: 3 * 657}[obs_v]
     # ---- steps
     cur_t = np.zeros(n, dtype=int)
     alive = np.ones(n, dtype=bool)

@@ -136,6 +136,9 @@ def test_env_oracle_obs_v1_v6_and_explicit_reward(model):
         o6 = E.full_obs_v6(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], expert, t, 0, g[p + "beta"], float(g["gender"]))
         assert o6.shape == (401,)
         np.testing.assert_allclose(o6, g[p + "obs_v6"], atol=1e-13)
+        o3 = E.full_obs_v3(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], g[p + "xquat"], expert, t, 0, g[p + "beta"], float(g["gender"]), fut_frames=3, skip=4)
+        assert o3.shape == (3 * 657,)
+        np.testing.assert_allclose(o3, g[p + "obs_v3"], atol=1e-13)
         r, parts = E.world_rfc_explicit_reward(g[p + "qpos"], g[p + "xpos"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"], expert,
                                                t, 0, model.timestep * 15, jw[1:], REWARD_W)
         assert r == pytest.approx(float(g[p + "reward_explicit"]), abs=1e-13)

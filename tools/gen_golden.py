@@ -223,6 +223,8 @@ def g4b_obs_variants(dm, feat):
         env.cc_cfg.update(obs_v=1)
         obs1 = HumanoidEnv.get_full_obs_v1(env)
         obs6 = HumanoidEnv.get_full_obs_v6(env)
+        env.cc_cfg.update(fut_frames=3, skip=4)
+        obs3 = HumanoidEnv.get_full_obs_v3(env)
         prev_q = env.data.qpos.copy()
         prev_q[7:] -= rng.normal(scale=0.02, size=69)
         save_q = env.data.qpos
@@ -235,7 +237,7 @@ def g4b_obs_variants(dm, feat):
         r, rinfo = world_rfc_explicit_reward(env, None, action, None)
         pre = f"c{c}_"
         cases.update({pre + "cur_t": cur_t, pre + "qpos": env.data.qpos, pre + "qvel": env.data.qvel, pre + "xpos": env.data.body_xpos,
-                      pre + "xquat": env.data.body_xquat, pre + "xipos": env.data.xipos, pre + "obs_v1": obs1, pre + "obs_v6": obs6,
+                      pre + "xquat": env.data.body_xquat, pre + "xipos": env.data.xipos, pre + "obs_v1": obs1, pre + "obs_v6": obs6, pre + "obs_v3": obs3,
                       pre + "prev_bquat": env.prev_bquat, pre + "action": action, pre + "reward_explicit": r, pre + "reward_explicit_info": rinfo, pre + "beta": env.expert["beta"][0]})
     cases["beta"] = env.expert["beta"][0]
     cases["gender"] = env.expert["gender"][0]

@@ -86,7 +86,8 @@ def ctrl_desc(n_substeps=15, action_type=0, meta_pd=0, rfc_mode=0, action_dim=0,
 class UhcEnvDesc(C.Structure):
     _fields_ = [("obs_v", C.c_int32), ("has_shape", C.c_int32), ("env_episode_len", C.c_int32),
                 ("env_expert_trail_steps", C.c_int32), ("ee_body", C.c_int32 * 5), ("reward_v", C.c_int32),
-                ("body_diff_thresh", C.c_double), ("reward_weights", C.c_double * 10), ("jpos_diffw", _F64P)]
+                ("body_diff_thresh", C.c_double), ("reward_weights", C.c_double * 10), ("jpos_diffw", _F64P),
+                ("fut_frames", C.c_int32), ("fut_skip", C.c_int32)]
 
 
 REWARD_KEYS = ("w_p", "w_v", "w_e", "w_c", "w_vf", "k_p", "k_v", "k_e", "k_c", "k_vf")
@@ -94,13 +95,14 @@ REWARD_DEFAULTS = (0.6, 0.1, 0.2, 0.1, 0.0, 2.0, 0.005, 20.0, 1000.0, 1.0)  # re
 
 
 def env_desc(model, *, obs_v=2, has_shape=True, env_episode_len=100000, env_expert_trail_steps=0, body_diff_thresh=0.5,
-             reward_weights=None, jpos_diffw=None, reward_v=0) -> UhcEnvDesc:
+             reward_weights=None, jpos_diffw=None, reward_v=0, fut_frames=10, fut_skip=10) -> UhcEnvDesc:
     from .smpllib.smpl_mujoco import SMPL_EE_NAMES, SMPLConverter
     d = UhcEnvDesc()
     d.obs_v, d.has_shape, d.env_episode_len, d.env_expert_trail_steps = obs_v, int(has_shape), int(env_episode_len), int(env_expert_trail_steps)
     d.ee_body = (C.c_int32 * 5)(*[model.body_names.index(n) for n in SMPL_EE_NAMES])
     d.body_diff_thresh = float(body_diff_thresh)
     d.reward_v = int(reward_v)
+    d.fut_frames, d.fut_skip = int(fut_frames), int(fut_skip)
     rw = dict(zip(REWARD_KEYS, REWARD_DEFAULTS))
     rw.update(reward_weights or {})
     d.reward_weights = (C.c_double * 10)(*[float(rw[k]) for k in REWARD_KEYS])

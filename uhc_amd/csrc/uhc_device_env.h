@@ -15,7 +15,7 @@
 #define UHC_FR_BCOM 512    // 72 (body_com, used by observation v1)
 
 struct EnvArgs {
-    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps;
+    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip;
     int ee_body[5];
     double dt, body_diff_thresh;
     double rw[10];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf

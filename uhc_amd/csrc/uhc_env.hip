@@ -171,9 +171,12 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
 
     // ------------------------------------------------------------------ observation
     // v2: get_full_obs_v2 (humanoid_im.py:419-503); v1: get_full_obs_v1 (:323-417) = v2 + body-COM blocks;
-    // v6: get_full_obs_v6 (:596-666)
-    double* obs = E.obs + (size_t)env * E.obs_dim;
-    const double* fr = bank0 + (size_t)expert_index(cur_t + 1, start_ind, len) * UHC_FRAME_STRIDE;
+    // v6: get_full_obs_v6 (:596-666); v3: get_full_obs_v3 (:758-767) = v2 at fut_frames look-aheads of `skip` frames, concatenated
+    const int nfut = E.obs_v == 3 ? E.fut_frames : 1;
+    const int blk = E.obs_dim / nfut;
+    for (int fut = 0; fut < nfut; fut++) {
+    double* obs = E.obs + (size_t)env * E.obs_dim + (size_t)fut * blk;
+    const double* fr = bank0 + (size_t)expert_index(cur_t + 1 + fut * E.fut_skip, start_ind, len) * UHC_FRAME_STRIDE;
     double rootq[4] = {s_qpos[3], s_qpos[4], s_qpos[5], s_qpos[6]}, crq[4], hq[4], hqi[4], Rr[9], Rc[9], trq[4], tq[4];
     qmul(crq, rootq, E.base_rot_inv);            // remove_base_rot (:263-264)
     for (int k = 0; k < 4; k++) tq[k] = fr[UHC_FR_QPOS + 3 + k];
@@ -281,6 +284,7 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
     if (E.has_shape) {
         const double* cb = E.clip_beta + (size_t)E.clip_id[env] * 17;
         if (LANE < 17) obs[shape_base + LANE] = cb[LANE];  // beta(16), gender
+    }
     }
     (void)s_q;
 }

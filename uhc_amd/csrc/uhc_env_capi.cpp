@@ -52,7 +52,8 @@ static int dalloc(UhcEnv* e, size_t n, T** p) {
 
 extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out) {
     if (!b || !d || !out) return uhc_internal_set_error("uhc_env_create: null argument");
-    if (d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 1, 2 or 6");
+    if (d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 3 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 1, 2, 3 or 6");
+    if (d->obs_v == 3 && (d->fut_frames < 1 || d->fut_frames > 64 || d->fut_skip < 0)) return uhc_internal_set_error("uhc_env_create: obs_v 3 needs 1 <= fut_frames <= 64, skip >= 0");
     if (d->reward_v != 0 && d->reward_v != 1) return uhc_internal_set_error("uhc_env_create: reward_v must be 0 (implicit) or 1 (explicit)");
     UhcEnv* e = new UhcEnv();
     e->b = b;
@@ -67,6 +68,9 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     E.obs_v = d->obs_v;
     E.reward_v = d->reward_v;
     E.obs_dim = (d->obs_v == 6 ? 8 + E.nv + 2 * nb + 11 * (nb - 1) : 304 + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
+    E.fut_frames = d->obs_v == 3 ? d->fut_frames : 1;
+    E.fut_skip = d->obs_v == 3 ? d->fut_skip : 0;
+    E.obs_dim *= E.fut_frames;
     E.env_episode_len = d->env_episode_len;
     E.expert_trail_steps = d->env_expert_trail_steps;
     for (int k = 0; k < 5; k++) E.ee_body[k] = d->ee_body[k];

@@ -50,7 +50,7 @@ class VecHumanoidEnv:
         reward_v = {"world_rfc_implicit": 0, "world_rfc_explicit": 1}.get(cfg.reward_id)
         if reward_v is None:
             raise NotImplementedError(f"reward_id {cfg.reward_id!r}: world_rfc_implicit and world_rfc_explicit are built (SURVEY.md 8f-4)")
-        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
+        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, fut_frames=cfg.get("fut_frames", 10), fut_skip=cfg.get("skip", 10), has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
                                                  env_episode_len=cfg.env_episode_len, env_expert_trail_steps=cfg.env_expert_trail_steps,
                                                  body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
                                                  jpos_diffw=self.converter.get_new_diff_weight()))
@@ -107,11 +107,17 @@ class VecHumanoidEnv:
                          gender=data_loader.data["gender"][k]) for k in data_loader.data_keys}
         self.set_clip_bank(clips)
 
+    def _window_len(self, fr_start, fr_end):
+        n = np.asarray(fr_end) - np.asarray(fr_start)
+        if self.cc_cfg.obs_v == 3:  # load_expert shortens the episode by 30 frames for the look-ahead observation (humanoid_im.py:214-215)
+            n = np.maximum(n - 30, 1)
+        return n
+
     def assign(self, env_ids, keys, fr_start, fr_end):
         """load_expert bookkeeping for a set of envs: env i imitates frames [fr_start, fr_end) of clip keys[i]."""
         cid = torch.tensor([self._clip_index[k] for k in keys], dtype=torch.int32)
         fs = torch.as_tensor(np.asarray(fr_start), dtype=torch.int32)
-        fl = torch.as_tensor(np.asarray(fr_end) - np.asarray(fr_start), dtype=torch.int32)
+        fl = torch.as_tensor(self._window_len(fr_start, fr_end), dtype=torch.int32)
         self.env.assign(torch.as_tensor(env_ids, dtype=torch.int32), cid, fs, fl)
 
     # ---- gym-like batched surface -----------------------------------------------------------------------
@@ -141,7 +147,7 @@ class VecHumanoidEnv:
         ids = torch.as_tensor(np.asarray(env_ids), dtype=torch.int32)
         cid = torch.tensor([self._clip_index[k] for k in keys], dtype=torch.int32)
         fs = torch.as_tensor(np.asarray(fr_start), dtype=torch.int32)
-        fl = torch.as_tensor(np.asarray(fr_end) - np.asarray(fr_start), dtype=torch.int32)
+        fl = torch.as_tensor(self._window_len(fr_start, fr_end), dtype=torch.int32)
         noise = None
         if self.mode == "train" and self.cc_cfg.env_init_noise > 0:
             noise = torch.from_numpy(self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof)))
