@@ -109,7 +109,7 @@ enum UhcField {
     UHC_F_SOLVER_ITER = 12, /* int32 [n_env] PGS sweeps used by the last solve */
     UHC_F_QFRC_APPLIED = 13, /* [n_env][nv] data.qfrc_applied of the last substep */
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
-    UHC_F_STAGE_PROF = 15    /* int64 [n_env][16] per-stage shader-cycle counters (profiling builds only) */
+    UHC_F_STAGE_PROF = 15    /* int64 [n_env][32] per-stage shader-cycle counters (profiling builds only) */
 };
 
 const char* uhc_last_error(void);

@@ -10,7 +10,9 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "uhc_amd", "csrc")
 PROF_LIB = os.path.join(CSRC, "libuhc_amd_prof.so")
 NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "smooth", "collision", "rows", "A-build",
-         "pgs-sweeps", "z+rest/pgs-general", "qacc-solve", "euler", "store"]
+         "pgs-sweeps", "z+rest/pgs-general", "qacc-solve", "euler", "store",
+         "pd: M->LD + gains", "pd: factor", "pd: solve", "kin: pass 1 (local poses)", "kin: pass 2 (levels)", "crb: subtree sums", "crb: I*cdof",
+         "rne: levels", "pd: M -> LD", "s25", "s26", "s27", "s28", "s29", "s30", "s31"]
 
 
 def build():
@@ -53,4 +55,5 @@ if __name__ == "__main__":
     tot = p.sum(1)
     print(f"n_env={n_env} steps={steps}: mean cycles per env-step = {tot.mean():.0f} (max {tot.max():.0f}); nefc mean {b.field(S.F_NEFC).float().mean().item():.1f} iters mean {b.field(S.F_SOLVER_ITER).float().mean().item():.1f}")
     for k, nm in enumerate(NAMES):
-        print(f"  {nm:22s} {p[:, k].mean():12.0f} cycles/env-step  {100 * p[:, k].mean() / tot.mean():5.1f}%")
+        if p[:, k].mean() > 0:
+            print(f"  {nm:26s} {p[:, k].mean():12.0f} cycles/env-step  {100 * p[:, k].mean() / tot.mean():5.1f}%")

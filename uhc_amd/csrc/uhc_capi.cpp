@@ -229,7 +229,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         }
     }
     T.body_maxdepth = *std::max_element(body_depth.begin(), body_depth.end());
-    if (nb > 64) { delete b; return fail("uhc_batch_create: %d bodies > 64 (one body per lane)", nb); }
+    if (nb > 32) { delete b; return fail("uhc_batch_create: %d bodies > 32 (subtree force sums use three 64-lane passes of 6 components)", nb); }
     for (int i = 1; i < nb; i++)
         if (d.body_jntnum[i] > 8) { delete b; return fail("uhc_batch_create: body %d has %d joints (> 8)", i, d.body_jntnum[i]); }
     std::vector<int> dof_depth(nv, 0), dof_ndesc(nv, 0);
@@ -462,7 +462,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E * T.nM, &S.qM_work)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 16, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));

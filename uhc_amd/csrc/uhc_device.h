@@ -71,7 +71,6 @@ struct DevCtrl {
 
 struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
-    double* qM_work;  // fast kernel: M between the substeps of one launch
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     const int* env_model;

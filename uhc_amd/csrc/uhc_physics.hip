@@ -18,7 +18,8 @@ extern __shared__ __attribute__((aligned(16))) double smem[];
 #define LANE ((int)threadIdx.x)
 // optional per-stage cycle accounting (build with -DUHC_STAGE_PROF; see tools/stage_profile.py)
 #ifdef UHC_STAGE_PROF
-#define PROF_DECL long long pt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_last_ = __builtin_readcyclecounter();
+#define UHC_NPROF 32
+#define PROF_DECL long long pt_[UHC_NPROF] = {}; long long pt_last_ = __builtin_readcyclecounter();
 #define PROF_ARGS , long long* pt_, long long& pt_last_
 #define PROF_PASS , pt_, pt_last_
 #define PROF(i) { const long long now_ = __builtin_readcyclecounter(); pt_[i] += now_ - pt_last_; pt_last_ = now_; }
@@ -151,8 +152,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // FAST variant: the tree-sparse mass matrix of the last forward pass lives in registers between substeps
 // (entry e = LANE + 64 m), because the PD controller of the NEXT substep needs it (humanoid_im.py:1019-1022)
 // and the 40 KiB LDS budget only holds its factor.
+// Explicit parking of values in the accumulation registers (AGPRs).  Only 256 of the 512 registers of a full-file
+// wave are directly addressable by VALU instructions; what the compiler cannot fit it shuttles through AGPRs (or
+// scratch) at its own discretion.  Parking long-lived data here by hand keeps the hot loops inside the VGPRs: the
+// finished Delassus row while it is being built, and the mass matrix between substeps (MPark).
+__device__ __forceinline__ void agpr_put(int& a, int v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); }
+__device__ __forceinline__ int agpr_get(int a) { int v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
 #define UHC_MREG 24
-struct MReg { double v[UHC_MREG]; };
+// the joint-space inertia of the last forward pass (entries LANE + 64 m), parked in AGPRs: the PD solve of the next substep
+// reads it back (the fast layout factorises M in place, so LDS does not keep it)
+struct MPark { int lo[UHC_MREG], hi[UHC_MREG]; };
 
 // Per-lane body constants, loaded once per kernel (lane = body): the level-synchronous tree passes of every substep
 // would otherwise fetch them from global tables inside their per-level branches and wait for L2 at each of the 9 levels.
@@ -182,7 +191,7 @@ __device__ __forceinline__ int jdofs(int jt) { return jt == UHC_JNT_FREE ? 6 : j
 // joint rotations (the expensive sincos work).  Pass 2 (level-synchronous): compose with the parent.
 // Pass 3 (all joints in parallel): joint anchors/axes to the world frame.
 template <bool FAST>
-__device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S, const BodyConst& BC) {
+__device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S, const BodyConst& BC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
@@ -240,6 +249,7 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
         }
     }
     wsync();
+    PROF(19)
     for (int level = 1; level <= T.body_maxdepth; level++) {
         if (depth == level) {
             double pos[3], quat[4], R[9], t[3];
@@ -266,6 +276,7 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
         }
         wsync();
     }
+    PROF(20)
     // joint anchors / axes: parent frame -> world
     for (int j = LANE; j < T.njnt; j += UHC_WAVE) {
         if (T.jnt_type[j] == UHC_JNT_FREE) continue;
@@ -351,19 +362,24 @@ __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb,
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
 template <bool FAST>
-__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, double* Mw, const BodyConst& BC) {
+__device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, MPark& MP, const BodyConst& BC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
-    if (BC.act) {  // bodies are in DFS order: subtree(b) = [b, b + nsub)
-        double acc[10];
-        const int n = BC.nsub;
-        for (int k = 0; k < 10; k++) acc[k] = S[L.cinert + 10 * (b + n - 1) + k];
-        for (int c = b + n - 2; c >= b; c--)
-            for (int k = 0; k < 10; k++) acc[k] += S[L.cinert + 10 * c + k];
-        for (int k = 0; k < 10; k++) S[L.crb + 10 * b + k] = acc[k];
+    // composite inertia = sum of cinert over the subtree, which is the contiguous range [b, b + nsub) in DFS order.
+    // One work item per (body, component): consecutive lanes read consecutive components, the loop length is the subtree
+    // size of the item's body (a body-per-lane loop made the root lane walk 24 x 10 dependent LDS loads alone).
+    for (int item = LANE; item < 10 * T.nbody; item += UHC_WAVE) {
+        const int bb = item / 10, k = item - 10 * bb;
+        double acc = 0.0;
+        if (bb > 0) {
+            const int n = T.body_nsub[bb];
+            for (int c = bb + n - 1; c >= bb; c--) acc += S[L.cinert + 10 * c + k];
+        }
+        S[L.crb + item] = acc;
     }
     wsync();
+    PROF(21)
     // buf[i] = crb[body(i)] * cdof[i]   (kept in the cdofdot area until k_com_vel overwrites it)
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         double I[10], v[6], r[6];
@@ -374,6 +390,7 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
         for (int k = 0; k < 6; k++) S[L.cdofdot + 6 * i + k] = r[k];
     }
     wsync();
+    PROF(22)
 #pragma unroll
     for (int m = 0; m < UHC_MREG; m++) {
         const int e = LANE + UHC_WAVE * m;
@@ -387,7 +404,7 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
             if (i == j) v += mb[A.o.dof_armature + i];
             S[L.M + e] = v;
         }
-        if (FAST && e < T.nM) Mw[e] = v;  // the fast layout factorises in place: M itself waits in HBM for the next PD solve
+        if (FAST) { agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v)); }
     }
     if (!FAST)
         for (int e = LANE + UHC_WAVE * UHC_MREG; e < T.nM; e += UHC_WAVE) {  // models larger than the register tile (general kernel only)
@@ -600,7 +617,7 @@ __device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S, const 
     }
 }
 template <bool FAST>
-__device__ __forceinline__ void k_rne(const KernelArgs& A, double* S, const BodyConst& BC) {  // qfrc_bias = RNE(qacc = 0)
+__device__ __forceinline__ void k_rne(const KernelArgs& A, double* S, const BodyConst& BC PROF_ARGS) {  // qfrc_bias = RNE(qacc = 0)
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const int b = LANE;
@@ -625,16 +642,24 @@ __device__ __forceinline__ void k_rne(const KernelArgs& A, double* S, const Body
         }
         wsync();
     }
-    // subtree sums of cfrc (DFS order) gathered per dof
-    double sub[6] = {0, 0, 0, 0, 0, 0};
-    if (BC.act) {
-        const int n = BC.nsub;
-        for (int k = 0; k < 6; k++) sub[k] = S[L.cfrc + 6 * (b + n - 1) + k];
-        for (int c = b + n - 2; c >= b; c--)
-            for (int k = 0; k < 6; k++) sub[k] += S[L.cfrc + 6 * c + k];
+    PROF(23)
+    // subtree sums of cfrc (DFS order), one work item per (body, component); the sums replace cfrc after all reads
+    double sub[3] = {0, 0, 0};
+    for (int pass = 0; pass < 3; pass++) {
+        const int item = LANE + UHC_WAVE * pass;
+        if (item < 6 * T.nbody) {
+            const int bb = item / 6, k = item - 6 * bb;
+            if (bb > 0) {
+                const int n = T.body_nsub[bb];
+                for (int c = bb + n - 1; c >= bb; c--) sub[pass] += S[L.cfrc + 6 * c + k];
+            }
+        }
     }
     wsync();
-    if (BC.act) for (int k = 0; k < 6; k++) S[L.cfrc + 6 * b + k] = sub[k];
+    for (int pass = 0; pass < 3; pass++) {
+        const int item = LANE + UHC_WAVE * pass;
+        if (item >= 6 && item < 6 * T.nbody) S[L.cfrc + item] = sub[pass];
+    }
     wsync();
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         double a[6], c[6];
@@ -1188,12 +1213,6 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     return 0;
 }
 
-// Explicit parking of values in the accumulation registers (AGPRs).  Only 256 of the 512 registers of a full-file
-// wave are directly addressable by VALU instructions; what the compiler cannot fit it shuttles through AGPRs (or
-// scratch) at its own discretion.  Parking the finished Delassus row here keeps the A build inside the VGPRs.
-__device__ __forceinline__ void agpr_put(int& a, int v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); }
-__device__ __forceinline__ int agpr_get(int a) { int v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
-
 __device__ __forceinline__ double max_neg(double a, double b) {  // max(a, -b): one VOP3 with a source modifier
     double r;
     asm("v_max_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
@@ -1370,15 +1389,15 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
 template <bool FAST>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, double* Mw PROF_ARGS) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, MPark& MP PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     FwdOut out = {0, 0, 0, 0};
-    k_kinematics<FAST>(A, mb, S, BC);
+    k_kinematics<FAST>(A, mb, S, BC PROF_PASS);
     PROF(1)
     k_com_pos<FAST>(A, mb, S, BC);
     PROF(2)
-    k_crb<FAST>(A, mb, S, Mw, BC);
+    k_crb<FAST>(A, mb, S, MP, BC PROF_PASS);
     PROF(3)
     if (!FAST) {
         for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
@@ -1388,7 +1407,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(4)
     k_com_vel<FAST>(A, S, BC);
     PROF(5)
-    k_rne<FAST>(A, S, BC);
+    k_rne<FAST>(A, S, BC PROF_PASS);
     PROF(6)
     k_smooth<FAST>(A, mb, S, LC);
     PROF(7)
@@ -1458,7 +1477,7 @@ __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVA
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
 // previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
 template <bool FAST>
-__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const double* Mr, const LaneConst& LC) {
+__device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const MPark& MP, const LaneConst& LC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const DevCtrl& C = A.c;
@@ -1473,10 +1492,11 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
 #pragma unroll
         for (int m = 0; m < UHC_MREG; m++) {
             const int e = LANE + UHC_WAVE * m;
-            if (e < T.nM) S[L.LD + e] = Mr[e];
+            if (e < T.nM) S[L.LD + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
         }
     } else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
     wsync();
+    PROF(24)
     // lane owns dofs LANE and LANE+64; actuator a drives dof 6+a (free root first)
     double kp[2] = {0, 0}, kd[2] = {0, 0}, qe[2] = {0, 0}, qv[2] = {0, 0};
     for (int h = 0; h < 2; h++) {
@@ -1499,11 +1519,14 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
         }
     }
     wsync();
+    PROF(16)
     k_factor<FAST>(A, S, L.LD, LC);
+    PROF(17)
     DofVec x;
     x.a = LANE < T.nv ? -S[L.bias + LANE] - kp[0] * qe[0] - kd[0] * qv[0] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? -S[L.bias + LANE + UHC_WAVE] - kp[1] * qe[1] - kd[1] * qv[1] : 0.0;
     k_solve<FAST>(A, S, L.LD, x, 0, LC);
+    PROF(18)
     for (int h = 0; h < 2; h++) {
         const int a = LANE + h * UHC_WAVE - 6;
         if (a >= 0 && a < nu) {
@@ -1623,25 +1646,28 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
     const LaneConst LC = lane_const(T);
     const BodyConst BC = body_const(T);
-    // joint-space inertia between substeps: the PD solve of substep t+1 uses M of substep t's forward pass.  The fast
-    // kernel parks it in a per-env HBM work row (each lane re-reads exactly the entries it wrote); the committed copy
-    // qM is only replaced once the whole control step has succeeded, so a redo by the general kernel starts clean.
-    double* Mwork = FAST ? A.s.qM_work + (size_t)env * T.nM : nullptr;
-    const double* Mcommitted = A.s.qM + (size_t)env * T.nM;
+    // joint-space inertia between substeps: the PD solve of substep t+1 uses M of substep t's forward pass
+    MPark MP;
+#pragma unroll
+    for (int m = 0; m < UHC_MREG; m++) {
+        const int e = LANE + UHC_WAVE * m;
+        const double v = (FAST && MODE == 0 && e < T.nM) ? A.s.qM[(size_t)env * T.nM + e] : 0.0;
+        agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v));
+    }
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0;
     bool ran = false;
     PROF_DECL
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S, LC, BC, Mwork PROF_PASS);
+        fo = k_forward<FAST>(A, mb, S, LC, BC, MP PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
         for (int it = 0; it < A.c.n_substeps; it++) {
-            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, (FAST && it > 0) ? Mwork : Mcommitted, LC);
+            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, MP, LC PROF_PASS);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
                     S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
@@ -1655,7 +1681,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
-            fo = k_forward<FAST>(A, mb, S, LC, BC, Mwork PROF_PASS);
+            fo = k_forward<FAST>(A, mb, S, LC, BC, MP PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && overflow) break;
@@ -1686,7 +1712,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
 #pragma unroll
             for (int m = 0; m < UHC_MREG; m++) {
                 const int e = LANE + UHC_WAVE * m;
-                if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = Mwork[e];
+                if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
             }
         }
         else for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
@@ -1705,8 +1731,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     if (A.s.prof) {
         long long mine = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) if (LANE == k) mine = pt_[k];
-        if (LANE < 16) A.s.prof[(size_t)env * 16 + LANE] += mine;
+        for (int k = 0; k < UHC_NPROF; k++) if (LANE == k) mine = pt_[k];
+        if (LANE < UHC_NPROF) A.s.prof[(size_t)env * UHC_NPROF + LANE] += mine;
     }
 #endif
     if (LANE == 0) {

@@ -76,7 +76,7 @@ class SimBatch:
         check(self.L.uhc_batch_field(self._b, f, C.byref(p), C.byref(n)))
         per = n.value // self.n_env
         if f == F_STAGE_PROF:
-            t = torch.as_tensor(_DevView(p.value, (self.n_env, 16), "<i8", self), device=self.device)
+            t = torch.as_tensor(_DevView(p.value, (self.n_env, 32), "<i8", self), device=self.device)
         elif f in _INT_FIELDS:
             t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<i4", self), device=self.device)
         else:
