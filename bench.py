@@ -57,6 +57,7 @@ def parse():
     p.add_argument("--envs", type=int, default=1024, help="environments per GPU")
     p.add_argument("--clips", type=int, default=64, help="synthetic clips per rank")
     p.add_argument("--ppo-dtype", default="float64", choices=["float64", "float32"])
+    p.add_argument("--pgs-iterations", type=int, default=None, help="sweep cap of the contact solve (default: the config's, 300 = converged)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
@@ -156,6 +157,8 @@ def main():
 
     cfg = Config(cfg_id="copycat_mi355x", base_dir=tempfile.mkdtemp(prefix="uhc_bench_"))
     cfg.n_env = args.envs
+    if args.pgs_iterations:
+        cfg.pgs_iterations = args.pgs_iterations
     cfg.no_log = True
     specs = dict(cfg.data_specs)
     specs["file_path"] = "synthetic"
@@ -228,7 +231,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
-                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "parallelism": f"env-shard x{world}"},
+                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "pgs_sweep_cap": int(env.model.iterations),
+                       "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,

@@ -220,7 +220,7 @@ def test_per_clip_body_shape_switches_the_env_model(tmp_path):
     env.reset(np.arange(3))
     env.sim.sync()
     feats = [env.expert_features(clips[keys[0]], 0), env.expert_features(clips[keys[1]], 1)]
-    models = [base, tall]
+    models = env.models  # the env's copies carry the configured PGS sweep cap
     xpos = env.sim.field(S.F_XPOS).cpu().numpy()
     os_ = []
     for e, (ci, st) in enumerate([(0, 0), (1, 0), (1, 5)]):
@@ -243,7 +243,7 @@ def test_per_clip_body_shape_switches_the_env_model(tmp_path):
     env.set_next([2], [keys[0]], [3], [25])
     env.auto_reset()
     env.sim.sync()
-    o = OracleSim(base, env.ctrl)
+    o = OracleSim(models[0], env.ctrl)
     o.set_state(feats[0]["qpos"][3], feats[0]["qvel"][4])
     np.testing.assert_allclose(env.sim.field(S.F_XPOS)[2].cpu().numpy(), o.get("xpos"), atol=1e-12)
     env.close()

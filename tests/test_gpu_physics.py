@@ -84,9 +84,14 @@ def test_free_flight_trajectory(model, ctrl, standing):
         np.testing.assert_allclose(gv[e], os_[e].get("qvel"), atol=1e-7)
 
 
-def test_contact_trajectory_200_steps(model, ctrl, standing):
-    """north_star bar: per-step qpos/qvel within 1e-4 of the CPU path over 200 env-steps, same seed."""
+@pytest.mark.parametrize("sweep_cap", [100, 300])
+def test_contact_trajectory_200_steps(model, ctrl, standing, sweep_cap):
+    """north_star bar: per-step qpos/qvel within 1e-4 of the CPU path over 200 env-steps, same seed.  With MuJoCo's default cap of
+    100 sweeps both sides run the same number of sweeps; at 300 (the package default: converged) the
+    tolerance test decides, and the two implementations may stop a sweep apart."""
+    import dataclasses
     import torch
+    model = dataclasses.replace(model, iterations=sweep_cap)
     from oracle.physics import OracleSim
     from uhc_amd import sim as S
     n = 4

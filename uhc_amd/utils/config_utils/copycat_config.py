@@ -85,6 +85,11 @@ class Config(Base_Config):
             self.jpos_diffw = np.concatenate([[1], self.b_diffw])
         self.agent_name, self.model_name = g("agent_name", "agent_copycat"), g("model_name", "super_net")
         # batched-env knobs of this build (not in the reference)
+        # sweep cap of the PGS contact solve.  The reference runs MuJoCo's Newton solver, which reaches its 1e-8 tolerance
+        # within `iterations` = 100; Gauss-Seidel needs ~150 sweeps on average (up to ~400) for the same tolerance on this
+        # model, and stopping at 100 leaves a trajectory error of ~5e-3 over 200 control steps against the converged
+        # solution (1e-7 at 300): DESIGN.md section 2
+        self.pgs_iterations = g("pgs_iterations", 300)
         self.n_env = g("n_env", 1024)
         self.ppo_dtype = g("ppo_dtype", "float64")
 
