@@ -202,6 +202,8 @@ def main():
     # ---- one PPO update over the collected samples (outside the timed region of `value`)
     ppo = None
     if not args.no_ppo:
+        agent.update_params(batch)  # untimed: the first update of a process pays rocBLAS kernel loading and allocator growth (2x)
+        agent.comm_summary()
         agent.time_comm = dist_on
         fence()
         t1 = time.perf_counter()
