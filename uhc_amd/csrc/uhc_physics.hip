@@ -1239,14 +1239,17 @@ __device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, d
     const int hot0 = LANE == 0 ? 0x3FF00000 : 0;  // high word of 1.0
     for (int it = 0; it < iterations; it++) {
         int hot = hot0;
+        // a lane's own force changes only at its own step, so the force it needs there is the one it had when the sweep
+        // began: the steps read this snapshot and the commits into f stay off the max -> readlane -> FMA chain
+        const double fs = f;
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             double delta;
             if (FRIC) {
-                const double lo = fric ? -floss - f : -f, hi = fric ? floss - f : 1e300;
+                const double lo = fric ? -floss - fs : -fs, hi = fric ? floss - fs : 1e300;
                 delta = fmin(fmax(w, lo), hi);
             } else {
-                delta = max_neg(w, f);
+                delta = max_neg(w, fs);
             }
             const double di = bcast(delta, i);
             w = fma(-di, Brow[i], w);
