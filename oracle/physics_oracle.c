@@ -11,7 +11,7 @@
  * engine_collision_convex / engine_solver / engine_forward) from its documentation; what pins it
  * here are analytic known-answer tests (tests/test_oracle_physics.py) and the reference's own
  * independent FK (uhc/smpllib/torch_smpl_humanoid.py:303-362, golden fixture).
- * The controller part IS pinned against the imported reference (tests/golden/ctrl_*.npz).
+ * The controller part IS pinned against the imported reference (tests/golden/g5_pd_rfc.npz).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
  * shared object.  The product path (uhc_amd/csrc) never links or calls it.
