@@ -1368,22 +1368,17 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     }
     row.f = f;
     PROF(11)
-    // ---- z = sum_r f_r Yhat_r (dof-per-lane pull), for qacc = qacc_smooth + L^-1 D^-1/2 z
-    for (int h = 0; h < 2; h++) {
-        const int i = LANE + h * UHC_WAVE;
-        const bool vi = i < T.nv;
-        const int di = vi ? T.dof_depth[i] : 0, nd = vi ? T.dof_ndesc[i] : -1;
-        double acc = 0;
-        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
-            constexpr int s = decltype(sc)::value;
-            if (s < nefc) {
-                const int ls = __builtin_amdgcn_readlane(row.last, s);
-                const int ys = __builtin_amdgcn_readlane(row.yoff, s);
-                const double fs = bcast(f, s);
-                if (vi && ls >= i && ls <= i + nd) acc += fs * S[L.Y + ys + di];
-            }
+    // ---- z = sum_r f_r Yhat_r for qacc = qacc_smooth + L^-1 D^-1/2 z: every row scatters its <= 31 chain entries into the
+    //      per-dof accumulators with LDS float64 atomics (rows of one body hit the same addresses; the LDS unit serialises them)
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.z + i] = 0.0;
+    wsync();
+    if (valid) {
+        const unsigned int* chain = T.chain + (size_t)row.last * UHC_YM;
+        const double* Yr = S + L.Y + row.yoff;
+        static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            if (q < row.len) __hip_atomic_fetch_add(S + L.z + (chain[q] & 0xffffu), f * Yr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         });
-        if (vi) S[L.z + i] = acc;
     }
     wsync();
     return iters;
