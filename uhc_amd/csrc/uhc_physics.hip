@@ -726,17 +726,46 @@ __device__ __forceinline__ double impedance(const double* si, double pos, double
     else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
     return dmin + y * (dmax - dmin);
 }
+// Per-lane constants of the statically filtered collision pairs (lane = pair, first 64 pairs): geom / body ids, hull vertex
+// range and contact dimension, loaded once per kernel; a wave-uniform pair index fetches them with v_readlane instead of a
+// chain of dependent global table loads every substep.
+struct PairConst { int g1, g2, b1, b2, va, vn, dim; };
+__device__ __forceinline__ PairConst pair_const(const DevTopo& T) {
+    PairConst c = {0, 0, 0, 0, 0, 0, 0};
+    if (LANE < T.npair) {
+        c.g1 = T.pair_g1[LANE]; c.g2 = T.pair_g2[LANE];
+        c.b1 = T.geom_bodyid[c.g1]; c.b2 = T.geom_bodyid[c.g2];
+        c.va = T.geom_vertadr[c.g2]; c.vn = T.geom_vertnum[c.g2];
+        c.dim = max(T.geom_condim[c.g1], T.geom_condim[c.g2]);
+    }
+    return c;
+}
+__device__ __forceinline__ PairConst pair_of(const DevTopo& T, const PairConst& mine, int pi) {  // pi wave-uniform
+    PairConst c;
+    if (pi < UHC_WAVE) {
+        c.g1 = __builtin_amdgcn_readlane(mine.g1, pi); c.g2 = __builtin_amdgcn_readlane(mine.g2, pi);
+        c.b1 = __builtin_amdgcn_readlane(mine.b1, pi); c.b2 = __builtin_amdgcn_readlane(mine.b2, pi);
+        c.va = __builtin_amdgcn_readlane(mine.va, pi); c.vn = __builtin_amdgcn_readlane(mine.vn, pi);
+        c.dim = __builtin_amdgcn_readlane(mine.dim, pi);
+    } else {
+        c.g1 = T.pair_g1[pi]; c.g2 = T.pair_g2[pi];
+        c.b1 = T.geom_bodyid[c.g1]; c.b2 = T.geom_bodyid[c.g2];
+        c.va = T.geom_vertadr[c.g2]; c.vn = T.geom_vertnum[c.g2];
+        c.dim = max(T.geom_condim[c.g1], T.geom_condim[c.g2]);
+    }
+    return c;
+}
 template <bool FAST>
-__device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, const double* w,
+__device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, const PairConst& P, const double* w,
                                 const double* n, double dist, double margin, double gap) {
+    const int g1 = P.g1, g2 = P.g2;
     const DevTopo& T = A.t;
     double* C = S + (FAST ? A.lf : A.l).con + c * UHC_CON_STRIDE;
     double fr[9];
     for (int k = 0; k < 3; k++) { C[k] = w[k] - 0.5 * dist * n[k]; fr[k] = n[k]; }
     make_frame(fr);
     for (int k = 0; k < 9; k++) C[3 + k] = fr[k];
-    const int b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
-    const int dim = max(T.geom_condim[g1], T.geom_condim[g2]);
+    const int b1 = P.b1, b2 = P.b2, dim = P.dim;
     const double inc = margin - gap;
     double solref[2], solimp[5];
     for (int k = 0; k < 2; k++) solref[k] = 0.5 * (mb[A.o.geom_solref + 2 * g1 + k] + mb[A.o.geom_solref + 2 * g2 + k]);
@@ -753,7 +782,7 @@ __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const doubl
 }
 // returns ncon (wave-uniform)
 template <bool FAST>
-__device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow) {
+__device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow, const PairConst& PC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     int ncon = 0;
@@ -761,7 +790,12 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
         const int p = p0 + LANE;
         bool keep = false;
         if (p < T.npair) {  // bounding-sphere cull, one pair per lane
-            const int g1 = T.pair_g1[p], g2 = T.pair_g2[p], b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
+            PairConst P = PC;  // the lane's own pair when p0 == 0; further blocks of 64 pairs read the tables
+            if (p0 > 0) {
+                P.g1 = T.pair_g1[p]; P.g2 = T.pair_g2[p];
+                P.b1 = T.geom_bodyid[P.g1]; P.b2 = T.geom_bodyid[P.g2];
+            }
+            const int g1 = P.g1, g2 = P.g2, b1 = P.b1, b2 = P.b2;
             double pq[4], gq[4], xq[4], R[9], t[3], gp[3], ce[3];
             for (int k = 0; k < 4; k++) { gq[k] = mb[A.o.geom_quat + 4 * g1 + k]; xq[k] = S[L.xquat + 4 * b1 + k]; }
             quat_mul(pq, xq, gq);
@@ -782,7 +816,8 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
         while (mask) {
             const int pi = p0 + __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const int g1 = T.pair_g1[pi], g2 = T.pair_g2[pi], b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
+            const PairConst P = pair_of(T, PC, pi);
+            const int g1 = P.g1, g2 = P.g2, b1 = P.b1, b2 = P.b2;
             double pq[4], gq[4], xq[4], R[9], t[3], gp[3], m1[9], m2[9], xp2[3];
             for (int k = 0; k < 4; k++) { gq[k] = mb[A.o.geom_quat + 4 * g1 + k]; xq[k] = S[L.xquat + 4 * b1 + k]; }
             quat_mul(pq, xq, gq);
@@ -794,7 +829,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             for (int k = 0; k < 3; k++) ppos[k] = S[L.xpos + 3 * b1 + k] + t[k];
             const double margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
             const double gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
-            const int va = T.geom_vertadr[g2], vn = T.geom_vertnum[g2];
+            const int va = P.va, vn = P.vn;
             // support vertex along -normal: lane-local min then wave arg-min (ties -> lowest vertex id)
             double bd = 1e300;
             int bv = 0x7fffffff;
@@ -831,7 +866,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             const unsigned long long cm = __ballot(ok);
             const int rank = __popcll(cm & ((1ull << LANE) - 1ull));
             if (ok && rank < T.plane_mesh_maxcon && ncon + rank < MAXCON_OF(FAST))
-                k_write_contact<FAST>(A, mb, S, ncon + rank, g1, g2, w, n, dist, margin, gap);
+                k_write_contact<FAST>(A, mb, S, ncon + rank, P, w, n, dist, margin, gap);
             const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
             if (want > MAXCON_OF(FAST)) *overflow = 1;
             ncon = min(MAXCON_OF(FAST), want);
@@ -1387,7 +1422,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
 template <bool FAST>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, MPark& MP PROF_ARGS) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     FwdOut out = {0, 0, 0, 0};
@@ -1409,7 +1444,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(6)
     k_smooth<FAST>(A, mb, S, LC);
     PROF(7)
-    out.ncon = k_collision<FAST>(A, mb, S, &out.overflow);
+    out.ncon = k_collision<FAST>(A, mb, S, &out.overflow, PC);
     PROF(8)
     out.nefc = k_enumerate_rows<FAST>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
@@ -1644,6 +1679,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
     const LaneConst LC = lane_const(T);
     const BodyConst BC = body_const(T);
+    const PairConst PC = pair_const(T);
     // joint-space inertia between substeps: the PD solve of substep t+1 uses M of substep t's forward pass
     MPark MP;
 #pragma unroll
@@ -1658,7 +1694,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     bool ran = false;
     PROF_DECL
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S, LC, BC, MP PROF_PASS);
+        fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
@@ -1679,7 +1715,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
-            fo = k_forward<FAST>(A, mb, S, LC, BC, MP PROF_PASS);
+            fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && overflow) break;
