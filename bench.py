@@ -58,6 +58,7 @@ def parse():
     p.add_argument("--clips", type=int, default=64, help="synthetic clips per rank")
     p.add_argument("--ppo-dtype", default="float64", choices=["float64", "float32"])
     p.add_argument("--pgs-iterations", type=int, default=None, help="sweep cap of the contact solve (default: the config's, 300 = converged)")
+    p.add_argument("--shapes", type=int, default=0, help="configs[3] (smpl_shape): K randomised body shapes, every clip runs on one of them")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
@@ -165,7 +166,16 @@ def main():
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed + rank)
     dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(args.clips, seed=1 + rank))
-    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl)
+    shape_models = clip_model = None
+    if args.shapes:  # neutral model with per-body-length scale s ~ U(0.85, 1.15) (mass ~ s^3, inertia ~ s^5), default_rng(7)
+        from uhc_amd.model.mjcf import scale_model
+        srng = np.random.default_rng(7)
+        scales = np.r_[1.0, srng.uniform(0.85, 1.15, size=args.shapes)]
+        shape_models = [scale_model(S.load_asset_model(), float(sc)) for sc in scales[1:]]
+        clip_model = {k: int(srng.integers(0, args.shapes + 1)) for k in dl.data_keys}
+        for k, mi in clip_model.items():  # the clip of a taller body carries its root higher (as AMASS clips fitted to that shape do)
+            dl.data["trans"][k] = dl.data["trans"][k] * np.array([1.0, 1.0, scales[mi]])
+    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl, shape_models=shape_models, clip_model=clip_model)
     agent.logger.handlers = [h for h in agent.logger.handlers if not isinstance(h, __import__("logging").StreamHandler) or hasattr(h, "baseFilename")]
     agent.per_epoch_update(0)
     env = agent.env
@@ -224,7 +234,7 @@ def main():
             ppo["allreduce"] = {"calls": ncalls, "bytes_per_call": comm_bytes, "total_ms": comm_ms, "algbw_GBs": algbw,
                                 "busbw_GBs": algbw * 2 * (world - 1) / world, "share_of_update": comm_ms * 1e-3 / t_up}
     if rank == 0:
-        kern_ms = kern_total_ms / max(kern_n, 1)
+        kern_ms = max(kern_total_ms / max(kern_n, 1), 1e-9)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if n_env == 1024 else (None, None)
         out = {
@@ -233,9 +243,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
-                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "pgs_sweep_cap": int(env.model.iterations),
+                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, false>" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),

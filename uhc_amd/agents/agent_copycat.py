@@ -39,8 +39,11 @@ def create_logger(filename):
 
 
 class AgentCopycat(AgentPPO):
-    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None):
+    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None, shape_models=None, clip_model=None):
+        """shape_models / clip_model: optional body shapes (models with the topology of the config's model) and the map clip key -> index
+        into [config model] + shape_models: smpl_shape-style training where every clip runs on its own body."""
         self.cfg = self.cc_cfg = cfg
+        self._shape_models, self._clip_model = shape_models, clip_model
         self.device, self.dtype, self.training = device, dtype, training
         self.max_freq = 50
         self.epoch = 0
@@ -73,8 +76,8 @@ class AgentCopycat(AgentPPO):
 
     def setup_env(self):
         dev_index = self.device.index if isinstance(self.device, torch.device) and self.device.index is not None else 0
-        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train")
-        self.env.set_clip_bank_from_loader(self.data_loader)
+        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train", shape_models=self._shape_models)
+        self.env.set_clip_bank_from_loader(self.data_loader, clip_model=self._clip_model)
 
     def setup_policy(self):
         cfg, env = self.cfg, self.env

@@ -523,20 +523,22 @@ extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n)
 }
 // fast kernel on every (active) env, then the general kernel on the envs that raised redo
 static int launch(UhcBatch* b, int mode, const double* d_action, const double* d_tbase, const int* d_active) {
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = b->timing && mode == 0;  // HIP events around the kernel that does the work of a control step
+    if (timed) {
+        if (b->ev_free.empty()) { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
+        else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
+    }
     if (b->use_fast) {
         HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env, b->stream));
-        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-        const bool timed = b->timing && mode == 0;
-        if (timed) {
-            if (b->ev_free.empty()) { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
-            else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
-            HIP_OK(hipEventRecord(ev.first, b->stream));
-        }
+        if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
         HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
     } else {
+        if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
+        if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
     }
     return 0;
 }

@@ -106,10 +106,10 @@ class VecHumanoidEnv:
         self.env.set_bank(torch.from_numpy(np.concatenate(frames)), torch.tensor(starts, dtype=torch.int32), torch.from_numpy(np.stack(betas)))
         self.env.set_clip_models(torch.tensor(cm, dtype=torch.int32) if clip_model else None)
 
-    def set_clip_bank_from_loader(self, data_loader):
+    def set_clip_bank_from_loader(self, data_loader, clip_model=None):
         clips = {k: dict(pose_aa=data_loader.data["pose_aa"][k], trans=data_loader.data["trans"][k], beta=data_loader.data["beta"][k],
                          gender=data_loader.data["gender"][k]) for k in data_loader.data_keys}
-        self.set_clip_bank(clips)
+        self.set_clip_bank(clips, clip_model=clip_model)
 
     def _window_len(self, fr_start, fr_end):
         n = np.asarray(fr_end) - np.asarray(fr_start)
