@@ -203,7 +203,9 @@ enum UhcEnvField {
     UHC_E_CUR_T = 7,        /* int32 [n_env] */
     UHC_E_BODY_DIFF = 8,    /* [n_env] calc_body_diff() of the last step */
     UHC_E_TARGET_BASE = 9,  /* [n_env][nu] expert joint pose handed to the PD controller */
-    UHC_E_CONSUMED = 10     /* int32 [n_env] 1 where the last uhc_env_auto_reset() started the queued window, 0 elsewhere */
+    UHC_E_CONSUMED = 10,    /* int32 [n_env] 1 where the last uhc_env_auto_reset() started the queued window, 0 elsewhere */
+    UHC_E_EPISODE = 11,     /* [2][n_env] running episode length and return (reward + end * end_reward), kept by step / auto_reset */
+    UHC_E_SNAPSHOT = 12     /* [5][n_env] written by uhc_env_auto_reset: done, episode length, episode return, percent, consumed */
 };
 
 int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* desc, UhcEnv** out);
@@ -229,6 +231,9 @@ int32_t uhc_env_assign(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int
 int32_t uhc_env_set_next(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int32_t* d_clip_ids, const int32_t* d_fr_start,
                          const int32_t* d_fr_len, const double* d_noise);
 int32_t uhc_env_auto_reset(UhcEnv* e);
+/* bonus added to the reward of a step that ends its clip (Agent: `if end_reward and info["end"]: reward += env.end_reward`,
+ * uhc/khrylib/rl/agents/agent.py:84-85); UHC_E_REWARD stays the plain imitation reward, the episode return includes the bonus */
+int32_t uhc_env_set_end_reward(UhcEnv* e, double end_reward);
 /* MujocoEnv.reset -> reset_model (humanoid_im.py:1245-1299): state <- expert frame 0 (+ d_noise [n][nu] on the
  * joint angles, may be NULL), forward pass, observation written to the obs rows of those envs */
 int32_t uhc_env_reset(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const double* d_noise);

@@ -35,6 +35,8 @@ struct EnvArgs {
     // queued next window per env (uhc_env_set_next / uhc_env_auto_reset)
     int *next_clip, *next_start, *next_len, *has_next, *consumed;
     double* next_noise;  // [n_env][nu]
+    double *episode, *snapshot;  // [2][n_env] length, return; [5][n_env] done, length, return, percent, consumed (auto_reset)
+    double end_reward;
     // per-clip body shape: model index of every clip, and the physics batch's per-env model selector it drives
     const int* clip_model;
     int* env_model;

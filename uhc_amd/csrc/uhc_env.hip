@@ -158,11 +158,13 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             const double rf = (E.vf_dim > 0 || E.reward_v == 1) ? exp(-W[9] * vf2) : 0.0;
             const double r = (W[0] * rp + W[1] * rv + W[2] * re + W[3] * rc + W[4] * rf) / (W[0] + W[1] + W[2] + W[3] + W[4]);
             E.reward[env] = r;
+            E.episode[env] += 1.0;
             double* rp_out = E.reward_parts + (size_t)env * 5;
             rp_out[0] = rp; rp_out[1] = rv; rp_out[2] = re; rp_out[3] = rc; rp_out[4] = rf;
             const int fail = (E.sim_fail[env] != 0) || (body_diff > E.body_diff_thresh);
             const int end = (cur_t >= E.env_episode_len) || (cur_t + start_ind >= len + E.expert_trail_steps - 1);
             E.fail[env] = fail; E.end[env] = end; E.done[env] = fail || end;
+            E.episode[E.n_env + env] += r + (end ? E.end_reward : 0.0);
             E.percent[env] = (double)cur_t / (double)(len - 1);
             E.body_diff[env] = body_diff;
             E.cur_t[env] = cur_t;
@@ -314,7 +316,7 @@ __global__ void uhc_env_reset_stage_kernel(EnvArgs E, const int* env_ids, int n,
         out_qpos[(size_t)r * E.nq + i] = v;
     }
     for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = frv[UHC_FR_QVEL + i];
-    if (threadIdx.x == 0) { E.cur_t[env] = 0; E.start_ind[env] = 0; E.done[env] = 0; E.fail[env] = 0; E.end[env] = 0; }
+    if (threadIdx.x == 0) { E.cur_t[env] = 0; E.start_ind[env] = 0; E.done[env] = 0; E.fail[env] = 0; E.end[env] = 0; E.episode[env] = 0.0; E.episode[E.n_env + env] = 0.0; }
 }
 extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* env_ids, int n, const double* noise, double* out_qpos,
                                                  double* out_qvel, hipStream_t s) {
@@ -362,6 +364,10 @@ __global__ void uhc_env_auto_stage_kernel(EnvArgs E, double* out_qpos, double* o
     if (threadIdx.x == 0) {
         select[env] = go;
         E.consumed[env] = had;
+        const size_t N = E.n_env;
+        E.snapshot[env] = go; E.snapshot[N + env] = E.episode[env]; E.snapshot[2 * N + env] = E.episode[N + env];
+        E.snapshot[3 * N + env] = E.percent[env]; E.snapshot[4 * N + env] = had;
+        if (go) { E.episode[env] = 0.0; E.episode[N + env] = 0.0; }
         if (had) {
             const int c = E.next_clip[env];
             E.clip_id[env] = c; E.e_start[env] = E.clip_start[c] + E.next_start[env]; E.e_len[env] = E.next_len[env]; E.has_next[env] = 0;

@@ -93,7 +93,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
         dalloc(e, N * 5, &E.reward_parts) || dalloc(e, N, &E.percent) || dalloc(e, N, &E.body_diff) || dalloc(e, N, &E.done) || dalloc(e, N, &E.fail) ||
         dalloc(e, N, &E.end) || dalloc(e, N * E.nq, &e->stage_qpos) || dalloc(e, N * E.nv, &e->stage_qvel) || dalloc(e, N, &e->select) ||
         dalloc(e, N, &E.next_clip) || dalloc(e, N, &E.next_start) || dalloc(e, N, &E.next_len) || dalloc(e, N, &E.has_next) || dalloc(e, N, &E.consumed) ||
-        dalloc(e, N * E.nu, &E.next_noise)) { delete e; return 1; }
+        dalloc(e, N * E.nu, &E.next_noise) || dalloc(e, 2 * N, &E.episode) || dalloc(e, 5 * N, &E.snapshot)) { delete e; return 1; }
     *out = e;
     return 0;
 }
@@ -121,6 +121,8 @@ extern "C" int32_t uhc_env_field(UhcEnv* e, int32_t f, void** p, int64_t* n) {
         case UHC_E_BODY_DIFF: ptr = E.body_diff; cnt = N; break;
         case UHC_E_TARGET_BASE: ptr = E.target_base; cnt = N * E.nu; break;
         case UHC_E_CONSUMED: ptr = E.consumed; cnt = N; break;
+        case UHC_E_EPISODE: ptr = E.episode; cnt = 2 * N; break;
+        case UHC_E_SNAPSHOT: ptr = E.snapshot; cnt = 5 * N; break;
         default: return uhc_internal_set_error("uhc_env_field: unknown field");
     }
     if (p) *p = ptr;
@@ -170,6 +172,11 @@ extern "C" int32_t uhc_env_set_next(UhcEnv* e, const int32_t* ids, int32_t n, co
     if (!e || !ids || !clip_ids || !fr_start || !fr_len || n < 1 || n > e->E.n_env) return uhc_internal_set_error("uhc_env_set_next: bad argument");
     if (!e->E.bank) return uhc_internal_set_error("uhc_env_set_next: no clip bank set");
     HIP_OK(uhc_launch_env_set_next(&e->E, ids, n, clip_ids, fr_start, fr_len, d_noise, stream_of(e)));
+    return 0;
+}
+extern "C" int32_t uhc_env_set_end_reward(UhcEnv* e, double end_reward) {
+    if (!e) return uhc_internal_set_error("uhc_env_set_end_reward: null env");
+    e->E.end_reward = end_reward;
     return 0;
 }
 extern "C" int32_t uhc_env_auto_reset(UhcEnv* e) {

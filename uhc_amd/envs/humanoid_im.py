@@ -68,7 +68,7 @@ class VecHumanoidEnv:
         self.humanoid = Humanoid(model=self.model)
         self._humanoids = {0: self.humanoid}
         self.np_random = np.random.RandomState()
-        self.end_reward = 0.0
+        self._end_reward = 0.0
         self.dt = self.model.timestep * 15
         self.clip_keys, self._clip_index, self._clip_len = [], {}, None
 
@@ -159,6 +159,15 @@ class VecHumanoidEnv:
 
     def auto_reset(self):
         self.env.auto_reset()
+
+    @property
+    def end_reward(self):
+        return self._end_reward
+
+    @end_reward.setter
+    def end_reward(self, v):  # the library adds it to the episode return of a step that ends its clip
+        self._end_reward = float(v)
+        self.env.set_end_reward(v)
 
     def step(self, action, active=None):
         self.env.step(action, active)

@@ -81,15 +81,13 @@ class Agent:
         R.masks = torch.ones(n_env, T, dtype=self.dtype, device=dev)
         R.exps = torch.ones(n_env, T, dtype=self.dtype, device=dev)
         R.logger = self.logger_cls()
-        R.ep_len = torch.zeros(n_env, dtype=torch.float64, device=dev)
-        R.ep_rew = torch.zeros(n_env, dtype=torch.float64, device=dev)
         R.c_info_sum = torch.zeros(5, dtype=self.dtype, device=dev)
         # exploration flags of the whole pass in one upload (the same stream of draws as one binomial(n_env) per step)
         flags = np.ones((T, n_env)) if self.mean_action else env.np_random.binomial(1, 1 - self.noise_rate, size=(T, n_env))
         R.mean_flags = torch.from_numpy(flags.astype(np.float64)).to(dev)
         # episode turnover is asynchronous: the device restarts finished envs from a queued window (env.auto_reset); the
         # host learns about finished episodes from a pinned snapshot one step later and refills the queues then
-        R.snap_dev = torch.empty(5, n_env, dtype=torch.float64, device=dev)
+        R.dones = torch.zeros(n_env, T, dtype=self.dtype, device=dev)
         R.snap_host = [torch.empty(5, n_env, dtype=torch.float64).pin_memory() if dev.type == "cuda" else torch.empty(5, n_env, dtype=torch.float64) for _ in range(2)]
         R.snap_event = [None, None]
         to_test(*self.sample_modules)
@@ -128,29 +126,20 @@ class Agent:
         R.actions[:, t] = action
         env.step(action)
         r = env.reward.to(self.dtype)
-        done = env.done.to(torch.float64)
         if self.end_reward:
             r = r + env.env.field(5).to(self.dtype) * env.end_reward  # info["end"] * end_reward (agent.py:84-85)
         R.rewards[:, t] = r
-        R.masks[:, t] = 1 - done
-        R.exps[:, t] = 1 - mean_flag
-        R.ep_len += 1
-        R.ep_rew += r
+        R.dones[:, t] = env.done  # masks = 1 - dones and exps = 1 - mean_flags are formed once, at the end of the pass
         R.c_info_sum += env.reward_parts.sum(0)
-        env.auto_reset()
-        snap = R.snap_dev
-        snap[0], snap[1], snap[2], snap[3], snap[4] = done, R.ep_len, R.ep_rew, env.env.field(6), env.env.field(10).to(torch.float64)
+        env.auto_reset()  # also writes the step's snapshot: done, episode length / return (kept by the library), percent, consumed
         slot = t & 1
         self._drain_snapshot(slot)  # the snapshot written two steps ago (its buffer is reused now)
-        R.snap_host[slot].copy_(snap, non_blocking=True)
+        R.snap_host[slot].copy_(env.env.field(12), non_blocking=True)
         if dev.type == "cuda":
             R.snap_event[slot] = torch.cuda.Event()
             R.snap_event[slot].record()
         else:
             R.snap_event[slot] = True
-        keep = 1 - done
-        R.ep_len *= keep
-        R.ep_rew *= keep
         obs = env.obs.to(self.dtype)
         R.state = self.running_state(obs) if self.running_state is not None else obs
         self._drain_snapshot(slot ^ 1)  # the previous step's snapshot: long since landed
@@ -161,6 +150,8 @@ class Agent:
         env, R = self.env, self._ro
         T, N = R.T, env.n_env * R.T
         self._drain_snapshot((T - 1) & 1)  # the last step's episode ends
+        R.masks = 1 - R.dones
+        R.exps = (1 - R.mean_flags).t().contiguous()
         # episodes cut by the end of the pass: bootstrap with V(s_T) folded into the last reward, then close the segment
         open_ = R.masks[:, T - 1] > 0
         if bool(open_.any()):

@@ -127,7 +127,8 @@ class SimBatch:
         return ms.value, n.value
 
 
-E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE, E_CONSUMED = range(11)
+E_OBS, E_REWARD, E_REWARD_PARTS, E_DONE, E_FAIL, E_END, E_PERCENT, E_CUR_T, E_BODY_DIFF, E_TARGET_BASE, E_CONSUMED, E_EPISODE, E_SNAPSHOT = range(13)
+_E_ROWS = {E_EPISODE: 2, E_SNAPSHOT: 5}  # fields laid out [rows][n_env]
 _E_INT = {E_DONE, E_FAIL, E_END, E_CUR_T, E_CONSUMED}
 FRAME_STRIDE = 584
 FR = dict(qpos=(0, 76), qvel=(76, 75), wbpos=(151, 72), wbquat=(223, 96), bquat=(319, 96), bangvel=(415, 72), ee_wpos=(487, 15), com=(502, 3), body_com=(512, 72))
@@ -173,6 +174,8 @@ class EnvBatch:
         per = n.value // self.n_env
         if f in _E_INT:
             t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<i4", self), device=self.device)
+        elif f in _E_ROWS:
+            t = torch.as_tensor(_DevView(p.value, (_E_ROWS[f], self.n_env), "<f8", self), device=self.device)
         elif per == 1:
             t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<f8", self), device=self.device)
         else:
@@ -234,6 +237,9 @@ class EnvBatch:
     def auto_reset(self):
         """Device-side episode turnover of every env whose done flag is set (uhc_env_auto_reset); no host round trip."""
         check(self.L.uhc_env_auto_reset(self._e))
+
+    def set_end_reward(self, v: float):
+        check(self.L.uhc_env_set_end_reward(self._e, float(v)))
 
     def step(self, action: torch.Tensor, active: Optional[torch.Tensor] = None):
         assert action.dtype == torch.float64 and action.is_contiguous() and action.shape == (self.n_env, self.sim.ctrl.action_dim)
