@@ -48,7 +48,11 @@ def estimate_advantages(rewards, masks, values, gamma, tau, seg_len=None, normal
 
 
 class DiagGaussian(Normal):
-    """distributions.py:6-25: log_prob summed over action dims, keepdim."""
+    """distributions.py:6-25: log_prob summed over action dims, keepdim.  Built without argument validation: torch's check
+    (`constraint.check(loc).all()` in a Python `if`) is a device-to-host sync on every policy call, i.e. once per rollout step."""
+
+    def __init__(self, loc, scale):
+        super().__init__(loc, scale, validate_args=False)
 
     def kl(self):
         loc1, scale1 = self.loc, self.scale
