@@ -165,6 +165,12 @@ int32_t uhc_batch_simulate(UhcBatch* b, const double* d_action, const double* d_
 int32_t uhc_batch_set_timing(UhcBatch* b, int32_t enable);
 int32_t uhc_batch_kernel_time(UhcBatch* b, double* total_ms, int32_t* launches);
 
+/* What the fast kernel does with an env that has more than 16 contacts or 64 constraint rows:
+ * 0 (default) = leave it to the general kernel (exact, costs a second pass whenever one env overflows);
+ * 1 = keep the first 16 contacts / the rows of the contacts that fit completely and carry on (MuJoCo itself drops
+ *     contacts beyond nconmax); such envs are reported in UHC_F_EFC_OVERFLOW.  Rows that do not fit the packed
+ *     row storage still go to the general kernel. */
+int32_t uhc_batch_set_overflow_mode(UhcBatch* b, int32_t truncate);
 /* mj_forward only (no control, no integration) on all envs: refreshes xpos/xquat/xipos/qM/qfrc_bias */
 int32_t uhc_batch_forward(UhcBatch* b);
 

@@ -207,6 +207,40 @@ def test_many_contacts_take_the_redo_path(model, ctrl, standing, kernel_path):
     assert max_nefc > 64 and checked > 0, f"scenario must exceed the fast kernel's capacity and stay inside the general one (max nefc={max_nefc}, checked={checked})"
 
 
+def test_truncate_mode_keeps_heavy_contact_envs_in_the_fast_kernel(model, ctrl, standing, kernel_path):
+    """Opt-in overflow mode: a lying humanoid (beyond the fast kernel's contact / row storage) keeps what fits, is flagged (in the launch where it happens), and no env
+    waits for a second pass; envs inside the capacity are bit-identical in both modes."""
+    import torch
+    from uhc_amd import sim as S
+    if kernel_path == "general":
+        pytest.skip("the mode only affects the fast kernel")
+    n = 4
+    qpos, qvel = _states(standing, model, n, 7, noise=0.02, vel=0.0)
+    c, s_ = np.cos(-np.pi / 4), np.sin(-np.pi / 4)
+    for e in range(2):  # envs 0, 1 lie face-down just above the floor; envs 2, 3 stand
+        w, x, y, z = qpos[e, 3:7]
+        qpos[e, 3:7] = [c * w - s_ * x, c * x + s_ * w, c * y - s_ * z, c * z + s_ * y]
+        qpos[e, 2] = 0.19 + 0.01 * e
+    out = {}
+    for trunc in (False, True):
+        b = _sim(model, ctrl, n)
+        b.set_overflow_mode(trunc)
+        b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+        act = torch.zeros(n, ctrl.action_dim, dtype=torch.float64, device="cuda")
+        tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+        for _ in range(5):
+            b.simulate(act, tb)
+        b.sync()
+        out[trunc] = {k: b.field(f).cpu().numpy().copy() for k, f in dict(q=S.F_QPOS, ncon=S.F_NCON, nefc=S.F_NEFC, ov=S.F_EFC_OVERFLOW, fail=S.F_FAIL).items()}
+        b.close()
+    ex, tr = out[False], out[True]
+    assert not ex["ov"].any()                                     # exact mode: the general kernel took the heavy envs, nothing dropped
+    assert tr["ncon"].max() <= 16 and tr["nefc"].max() <= 64      # truncate mode: everything stayed inside the fast kernel
+    assert tr["ov"][:2].any() and not tr["ov"][2:].any() and not tr["fail"].any() and np.isfinite(tr["q"]).all()
+    np.testing.assert_array_equal(tr["q"][2:], ex["q"][2:])                                    # envs inside the capacity: identical
+    assert np.abs(tr["q"][:2, 2] - ex["q"][:2, 2]).max() < 0.05                                # the truncated bodies still rest on the floor
+
+
 def test_per_env_models_share_one_batch(model, ctrl, standing, kernel_path):
     """smpl_shape-style batch: envs with differently scaled bodies (mass ~ s^3, inertia ~ s^5) in one launch."""
     import torch

@@ -543,6 +543,11 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
     return 0;
 }
 
+extern "C" int32_t uhc_batch_set_overflow_mode(UhcBatch* b, int32_t truncate) {
+    if (!b) return fail("uhc_batch_set_overflow_mode: null batch");
+    b->A.truncate = truncate != 0;
+    return 0;
+}
 extern "C" int32_t uhc_batch_set_timing(UhcBatch* b, int32_t enable) {
     if (!b) return fail("uhc_batch_set_timing: null batch");
     b->timing = enable != 0;

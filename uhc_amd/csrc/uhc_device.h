@@ -85,6 +85,7 @@ struct KernelArgs {
     DevLds lf;  // fast kernel: phase-aliased, 64 rows, packed Yhat
     int ycap;   // doubles available for packed Yhat rows in the fast layout
     int ld_delta;  // bytes to add to the schedule tables' LDS addresses in the general layout
+    int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     DevCtrl c;
     DevState s;
     int n_env;

@@ -868,7 +868,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             if (ok && rank < T.plane_mesh_maxcon && ncon + rank < MAXCON_OF(FAST))
                 k_write_contact<FAST>(A, mb, S, ncon + rank, P, w, n, dist, margin, gap);
             const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
-            if (want > MAXCON_OF(FAST)) *overflow = 1;
+            if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;  // 2: truncated, 1: needs the general kernel
             ncon = min(MAXCON_OF(FAST), want);
         }
     }
@@ -920,20 +920,23 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     wsync();
     // (3) contacts
     if (LANE == 0) {
-        int r = nefc;
+        int r = nefc, trunc = 0;
         for (int c = 0; c < ncon; c++) {
             const double* C = S + L.con + c * UHC_CON_STRIDE;
             if (C[12] >= C[13]) continue;
             const int dim = (int)C[21], b2 = (int)C[20];
             const int nr = dim == 1 ? 1 : 4, last = T.body_lastdof[b2];
+            if (FAST && A.truncate && r + nr > MAXEFC_OF(FAST)) { trunc = 1; break; }  // whole contacts only
             for (int e = 0; e < nr; e++, r++)
                 if (r < MAXEFC_OF(FAST)) { RM[r].type = dim == 1 ? ROW_CONTACT : ROW_PYR; RM[r].last = last; RM[r].aux = c; RM[r].edge = e; }
         }
         ((int*)(S + L.ncon_nefc))[1] = r;
+        ((int*)(S + L.ncon_nefc))[0] = trunc;
     }
     wsync();
     nefc = ((int*)(S + L.ncon_nefc))[1];
-    if (nefc > MAXEFC_OF(FAST)) { *overflow = 1; nefc = MAXEFC_OF(FAST); }
+    if (((int*)(S + L.ncon_nefc))[0]) *overflow |= 2;
+    if (nefc > MAXEFC_OF(FAST)) { *overflow |= (FAST && A.truncate) ? 2 : 1; nefc = MAXEFC_OF(FAST); }
     return nefc;
 }
 
@@ -1133,21 +1136,36 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 // (q-th dof of the chain | LDS byte address of that dof's L row << 16); positions past the chain end point at safe
 // finite data and meet Y = 0.  The finished rows are also stored to LDS (packed) for the A build of the other lanes.
 #define UHC_YM 32
-__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, double (&Y)[UHC_YM]) {
+__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int& nefc, FastRow& row, double (&Y)[UHC_YM]) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
     const char* SB = (const char*)S;
     const int r = LANE;
-    const bool valid = r < nefc;
+    bool valid = r < nefc;
     RowMisc rm = {0, 0, 0, 0};
     if (valid) rm = RM[r];
     row.type = rm.type; row.last = rm.last;
     row.len = valid ? T.dof_depth[rm.last] + 1 : 0;
-    int total;
+    int total, status = 0;
     row.yoff = wave_excl_scan(row.len, &total);
     row.R = 1; row.b = 0; row.f = 0; row.floss = 0; row.diag = 1;
-    if (total + 8 > A.ycap) return 1;
+    if (total + 8 > A.ycap) {
+        if (!A.truncate) return 1;
+        // keep the leading rows whose packed entries fit, cut back to the start of a pyramid so its edges stay together
+        const unsigned long long fit = __builtin_amdgcn_ballot_w64(valid && row.yoff + row.len + 8 <= A.ycap);
+        int nfit = ~fit == 0ull ? UHC_WAVE : __ffsll((long long)~fit) - 1;
+        if (nfit < nefc && nfit > 0) {
+            const unsigned long long starts = __builtin_amdgcn_ballot_w64(valid && !(rm.type == ROW_PYR && rm.edge != 0));
+            const unsigned long long upto = starts & (nfit >= 63 ? ~0ull : ((2ull << nfit) - 1ull));
+            nfit = upto ? 63 - __builtin_clzll(upto) : 0;
+        }
+        nefc = nfit;
+        status = 2;
+        valid = r < nefc;
+        if (!valid) { rm.type = 0; row.type = 0; row.len = 0; }
+        if (nefc == 0) return 2;
+    }
     const int len = row.len;
     int maxlen = len;  // wave maximum (uniform)
 #pragma unroll
@@ -1245,7 +1263,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
         }
     });
     wsync();
-    return 0;
+    return status;
 }
 
 __device__ __forceinline__ double max_neg(double a, double b) {  // max(a, -b): one VOP3 with a source modifier
@@ -1448,12 +1466,14 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(8)
     out.nefc = k_enumerate_rows<FAST>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
-    if (FAST && out.overflow) return out;
+    if (FAST && (out.overflow & 1)) return out;
     if (out.nefc > 0) {
         if (FAST) {
             FastRow row;
             double Yreg[UHC_YM];
-            if (k_rows_fast(A, mb, S, out.nefc, row, Yreg)) { out.overflow = 1; return out; }
+            const int st = k_rows_fast(A, mb, S, out.nefc, row, Yreg);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
+            out.overflow |= st;
+            if (st == 1) return out;
             PROF(9)
             out.iters = k_pgs_fast(A, mb, S, out.nefc, row, Yreg PROF_PASS);
             PROF(12)
@@ -1718,7 +1738,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
-            if (FAST && overflow) break;
+            if (FAST && (overflow & 1)) break;
             ran = true;
             b = 0;
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
@@ -1727,7 +1747,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             PROF(14)
         }
     }
-    if (FAST && overflow) {  // nothing committed: the general kernel redoes this env from the same inputs
+    if (FAST && (overflow & 1)) {  // nothing committed: the general kernel redoes this env from the same inputs
         if (LANE == 0) A.s.redo[env] = 1;
         return;
     }

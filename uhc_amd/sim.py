@@ -90,6 +90,11 @@ class SimBatch:
     def sync(self):
         check(self.L.uhc_batch_sync(self._b))
 
+    def set_overflow_mode(self, truncate: bool):
+        """False (default): envs beyond the fast kernel's 16 contacts / 64 rows are redone exactly by the general kernel;
+        True: they keep what fits (reported in F_EFC_OVERFLOW) and no second pass is needed."""
+        check(self.L.uhc_batch_set_overflow_mode(self._b, int(bool(truncate))))
+
     def set_rfc_scale(self, s: float):
         check(self.L.uhc_batch_set_rfc_scale(self._b, float(s)))
 
