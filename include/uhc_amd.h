@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UHC_ABI_VERSION 3
+#define UHC_ABI_VERSION 4
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -182,17 +182,22 @@ typedef struct UhcEnv UhcEnv;
 /* constants of HumanoidEnv (uhc/envs/humanoid_im.py) and of the reward (uhc/losses/reward_function.py:12-36) */
 typedef struct UhcEnvDesc {
     int32_t obs_v;               /* 2: get_full_obs_v2 (humanoid_im.py:419-503); 1: get_full_obs_v1 (:323-417); 6: get_full_obs_v6 (:596-666);
-                                  * 3: get_full_obs_v3 (:758-767) = fut_frames v2 blocks, look-ahead 0, skip, 2 skip, ... */
+                                  * 3: get_full_obs_v3 (:758-767) = fut_frames v2 blocks, look-ahead 0, skip, 2 skip, ...;
+                                  * 5: get_full_obs_v5 (:505-594); 0: get_full_obs (:290-317), shaped by obs_flags */
     int32_t has_shape;           /* append beta(16) + gender to the observation (humanoid_im.py:1390-1406) */
     int32_t env_episode_len;     /* cfg.env_episode_len */
     int32_t env_expert_trail_steps;
     int32_t ee_body[5];          /* model body ids of SMPL_EE_NAMES (smpl_parser.py:228) */
-    int32_t reward_v;            /* 0: world_rfc_implicit_reward (reward_function.py:12-88); 1: world_rfc_explicit_reward (:253-341) */
+    int32_t reward_v;            /* 0: world_rfc_implicit_reward (reward_function.py:12-88) = world_rfc_implicit_reward_quat (:92-171);
+                                  * 1: world_rfc_explicit_reward (:253-341); 2: world_rfc_implicit_v1_mul (:174-250);
+                                  * 3: world_rfc_explicit_mul_reward (:346-430); 4: world_rfc_implicit_v2 (:643-723); 5: world_rfc_implicit_v3 (:726-820) */
     double body_diff_thresh;     /* humanoid_im.py:88-89 */
-    double reward_weights[10];   /* w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf */
+    double reward_weights[16];   /* w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf | w_wp w_j k_wp k_j (reward_v 4, 5) | 0 0 */
     const double* jpos_diffw;    /* [nbody-1] SMPLConverter.get_new_diff_weight() (host) */
     int32_t fut_frames;          /* obs_v 3: cfg.fut_frames (default 10) */
     int32_t fut_skip;            /* obs_v 3: cfg.skip (default 10) */
+    int32_t obs_flags;           /* obs_v 0: bit 0 cfg.obs_heading, bit 1 cfg.root_deheading, bit 2 cfg.obs_phase, bit 3 cfg.obs_vel == "root" */
+    const double* reward_jpos_diffw; /* reward_v 4, 5: reward_weights["jpos_diffw"] [nbody-1] (host); NULL = ones */
 } UhcEnvDesc;
 
 /* expert frame record layout of the clip bank (doubles; see uhc_amd/csrc/uhc_device_env.h) */
@@ -201,7 +206,7 @@ typedef struct UhcEnvDesc {
 enum UhcEnvField {
     UHC_E_OBS = 0,          /* [n_env][obs_dim] */
     UHC_E_REWARD = 1,       /* [n_env] */
-    UHC_E_REWARD_PARTS = 2, /* [n_env][5] pose, vel, ee, com, vf */
+    UHC_E_REWARD_PARTS = 2, /* [n_env][6] pose, vel, ee, com, vf, 0 (reward_v 4, 5: pose, world pose, body com, joint pos, vel, vf) */
     UHC_E_DONE = 3,         /* int32 [n_env] */
     UHC_E_FAIL = 4,         /* int32 [n_env] info["fail"] */
     UHC_E_END = 5,          /* int32 [n_env] info["end"] */

@@ -185,3 +185,98 @@ def world_rfc_implicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur
     parts = np.array([pose_r, vel_r, ee_r, com_r, vf_r])
     ws = np.array([w["w_p"], w["w_v"], w["w_e"], w["w_c"], w["w_vf"]])
     return float((ws * parts).sum() / ws.sum()), parts
+
+
+def full_obs_v0(qpos, qvel, expert, cur_t, start_ind=0, obs_heading=False, root_deheading=True, obs_vel="full", obs_phase=True):
+    """humanoid_im.py:290-317 (get_full_obs, obs_coord='root'): [heading], qpos[2:] (root de-headed), velocities (root linear part in the
+    root frame), the expert joint angles of the CURRENT frame (get_expert_kin_pose, delta_t=0), [phase = cur_t / len]."""
+    qpos, qvel = qpos.copy(), qvel.copy()
+    qvel[:3] = transform_vec(qvel[:3], qpos[3:7], "root")
+    obs = []
+    if obs_heading:
+        obs.append(np.array([get_heading(qpos[3:7])]))
+    if root_deheading:
+        qpos[3:7] = de_heading(qpos[3:7])
+    obs.append(qpos[2:])
+    if obs_vel == "root":
+        obs.append(qvel[:6])
+    elif obs_vel == "full":
+        obs.append(qvel)
+    obs.append(expert["qpos"][expert_index(cur_t, start_ind, expert["len"])][7:])
+    if obs_phase:
+        obs.append(np.array([cur_t / expert["len"]]))
+    return np.concatenate(obs)
+
+
+def full_obs_v5(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, gender=None, base_rot=BASE_ROT):
+    """humanoid_im.py:505-594 (obs_coord='root', obs_vel='full'): the v2 blocks without the leading heading quaternion, yaw taken with
+    atan2 (get_heading_new), the root velocity rotated once and the relative root position computed from positions."""
+    qpos, qvel = qpos.copy(), qvel.copy()
+    ind = expert_index(cur_t + 1, start_ind, expert["len"])
+    target_qpos = expert["qpos"][ind].copy()
+    target_quat = expert["wbquat"][ind].reshape(-1, 4)
+    target_jpos = expert["wbpos"][ind].reshape(-1, 3)
+    crq = remove_base_rot(qpos[3:7], base_rot)
+    trq = remove_base_rot(target_qpos[3:7], base_rot)
+    yaw = get_heading_new(crq)
+    hq = np.array([math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)])
+    R = _rot_of(crq)
+    root = qpos[:3].copy()
+    qpos[3:7] = quaternion_multiply(quaternion_inverse(hq), crq)
+    diff_qpos = target_qpos.copy()
+    diff_qpos[2] -= qpos[2]
+    diff_qpos[7:] -= qpos[7:]
+    diff_qpos[3:7] = quaternion_multiply(trq, quaternion_inverse(crq))
+    obs = [target_qpos[2:], qpos[2:], diff_qpos[2:]]
+    qvel[:3] = qvel[:3] @ R
+    obs.append(qvel)
+    rel_h = get_heading_new(trq) - yaw
+    if rel_h > np.pi:
+        rel_h -= 2 * np.pi
+    if rel_h < -np.pi:
+        rel_h += 2 * np.pi
+    obs.append(np.array([rel_h]))
+    obs.append(((target_qpos[:3] - root) @ R)[:2])
+    curr_jpos = xpos[1:]
+    obs.append((R.T @ (curr_jpos - root[None]).T).ravel())
+    obs.append((R.T @ (target_jpos - curr_jpos).T).ravel())
+    cur_quat = xquat[1:].copy()
+    if cur_quat[0, 0] == 0:
+        cur_quat = target_quat.copy()
+    hq_inv = np.repeat(quaternion_inverse(hq)[None], cur_quat.shape[0], axis=0)
+    obs.append(quaternion_multiply_batch(hq_inv, cur_quat).ravel())
+    obs.append(quaternion_multiply_batch(quaternion_inverse_batch(cur_quat), target_quat).ravel())
+    if beta is not None:
+        obs += [beta, [gender]]
+    return np.concatenate(obs)
+
+
+def world_rfc_mul_reward(explicit, *args, **kw):
+    """reward_function.py:174-250 (world_rfc_implicit_v1_mul) / :346-430 (world_rfc_explicit_mul_reward): the same five terms as the
+    additive rewards, multiplied; the implicit form drops the residual-force factor when w_vf == 0."""
+    w = args[10]
+    _, parts = (world_rfc_explicit_reward if explicit else world_rfc_implicit_reward)(*args, **kw)
+    r = parts[0] * parts[1] * parts[2] * parts[3] * (parts[4] if (explicit or w["w_vf"] != 0.0) else 1.0)
+    return float(r), parts
+
+
+def world_rfc_implicit_v2_v3(v3, qpos, xpos, xquat, xipos, prev_bquat, action, expert, cur_t, start_ind, dt, w, jpos_diffw, ndof=69, vf_dim=6):
+    """reward_function.py:643-723 (v2, product) / :726-820 (v3, weighted sum, not normalised): local and world body-quaternion
+    errors, finite-difference angular velocity, per-body COM and joint position errors (all means over bodies), |vf|^2."""
+    ind = expert_index(cur_t, start_ind, expert["len"])
+    cur_bquat = get_body_quat(qpos)
+    cur_bangvel = get_angvel_fd(prev_bquat, cur_bquat, dt)
+    pose = multi_quat_norm(multi_quat_diff(cur_bquat, expert["bquat"][ind])) * jpos_diffw
+    wpose = multi_quat_norm(multi_quat_diff(xquat[1:].ravel(), expert["wbquat"][ind])) * jpos_diffw
+    vel = cur_bangvel - expert["bangvel"][ind]
+    dcom = (expert["body_com"][ind].reshape(-1, 3) - xipos[1:]) * jpos_diffw[:, None]
+    djp = (xpos[1:] - expert["wbpos"][ind].reshape(-1, 3)) * jpos_diffw[:, None]
+    vf = action[ndof:ndof + vf_dim]
+    parts = np.array([math.exp(-w["k_p"] * (pose ** 2).mean()), math.exp(-w["k_wp"] * (wpose ** 2).mean()),
+                      math.exp(-w["k_c"] * (np.linalg.norm(dcom, axis=1) ** 2).mean()), math.exp(-w["k_j"] * (np.linalg.norm(djp, axis=1) ** 2).mean()),
+                      math.exp(-w["k_v"] * (vel ** 2).mean()), math.exp(-w["k_vf"] * np.linalg.norm(vf) ** 2)])
+    if v3:
+        r = w["w_p"] * parts[0] + w["w_wp"] * parts[1] + w["w_c"] * parts[2] + w["w_j"] * parts[3] + w["w_v"] * parts[4] + w["w_vf"] * parts[5]
+    else:
+        r = parts.prod()
+    return float(r), parts

@@ -8,6 +8,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REWARD_W = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0)
+REWARD_W23 = dict(k_p=0.6, k_wp=0.3, k_v=0.004, k_j=60.0, k_c=80.0, k_vf=0.7, w_p=0.25, w_wp=0.2, w_v=0.05, w_j=0.3, w_c=0.15, w_vf=0.05,
+                  jpos_diffw=[float(x) for x in np.round(np.linspace(0.5, 1.5, 24), 3)])
 
 
 def _expert():
@@ -32,7 +34,8 @@ def _make(model, ctrl, n_env, expert, beta, obs_v=2, reward_v=0, has_shape=True)
     from uhc_amd import sim as S
     from uhc_amd._capi import env_desc
     sb = S.SimBatch(model, ctrl, n_env)
-    eb = S.EnvBatch(sb, env_desc(model, obs_v=obs_v, has_shape=has_shape, reward_weights=REWARD_W, reward_v=reward_v, fut_frames=3, fut_skip=4))
+    eb = S.EnvBatch(sb, env_desc(model, obs_v=obs_v, has_shape=has_shape, reward_weights=REWARD_W23 if reward_v >= 4 else REWARD_W, reward_v=reward_v,
+                                 fut_frames=3, fut_skip=4, obs_heading=True, root_deheading=True, obs_phase=True))
     frames = S.pack_expert_frames(expert)
     frames2 = np.concatenate([frames, frames[::-1].copy()])  # clip 1 = clip 0 reversed (only a second id to address)
     clip_start = torch.tensor([0, frames.shape[0]], dtype=torch.int32)
@@ -49,10 +52,14 @@ def _oracle_obs(E, obs_v, o, w, t, beta):
         return E.full_obs_v3(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0, fut_frames=3, skip=4)
     if obs_v == 6:
         return E.full_obs_v6(o.get("qpos"), o.get("qvel"), xpos, w, t, 0, beta, 2.0)
+    if obs_v == 5:
+        return E.full_obs_v5(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)
+    if obs_v == 0:
+        return E.full_obs_v0(o.get("qpos"), o.get("qvel"), w, t, 0, obs_heading=True, root_deheading=True, obs_phase=True)
     return E.full_obs_v2(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)
 
 
-@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1), (3, 0)])
+@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1), (3, 0), (5, 2), (0, 4), (2, 5), (2, 3)])
 def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     import torch
     from oracle import env_oracle as E
@@ -83,7 +90,7 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     gobs = eb.field(S.E_OBS).cpu().numpy()
     for e in range(n):
         np.testing.assert_allclose(gobs[e], _oracle_obs(E, obs_v, os_[e], wins[e], 0, beta), atol=1e-11)
-    assert eb.obs_dim == {2: 657, 1: 784, 6: 401, 3: 3 * 657}[obs_v]
+    assert eb.obs_dim == {2: 657, 1: 784, 6: 401, 3: 3 * 657, 5: 653, 0: 220}[obs_v]
     # ---- steps
     cur_t = np.zeros(n, dtype=int)
     alive = np.ones(n, dtype=bool)
@@ -109,7 +116,14 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
             bd = E.calc_body_diff(xpos, w["wbpos"][E.expert_index(cur_t[e], 0, w["len"])], jw)
             fail = bool(o.geti("fail")) or bd > 0.5
             end = cur_t[e] >= 100000 or cur_t[e] >= w["len"] - 1
-            if reward_v == 1:  # the explicit reward reads 24 x 9 residual entries; this controller's action carries 6 + 30 after the joints
+            if reward_v >= 4:
+                w23 = {k: v for k, v in REWARD_W23.items() if k != "jpos_diffw"}
+                r, parts = E.world_rfc_implicit_v2_v3(reward_v == 5, o.get("qpos"), xpos, xquat, xipos, prev_bquat, act[e], w, cur_t[e], 0, model.timestep * 15,
+                                                      w23, np.asarray(REWARD_W23["jpos_diffw"]))
+            elif reward_v in (2, 3):
+                a = np.r_[act[e][:75], np.zeros(300)] if reward_v == 3 else act[e]
+                r, parts = E.world_rfc_mul_reward(reward_v == 3, o.get("qpos"), xpos, xipos, prev_bquat, a, w, cur_t[e], 0, model.timestep * 15, jw[1:], REWARD_W)
+            elif reward_v == 1:  # the explicit reward reads 24 x 9 residual entries; this controller's action carries 6 + 30 after the joints
                 r, parts = E.world_rfc_explicit_reward(o.get("qpos"), xpos, xipos, prev_bquat, np.r_[act[e][:75], np.zeros(300)], w, cur_t[e], 0,
                                                        model.timestep * 15, jw[1:], REWARD_W)
             else:
@@ -118,7 +132,7 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
             assert (bool(gfail[e]), bool(gend[e]), bool(gdone[e])) == (fail, end, fail or end)
             assert gpct[e] == pytest.approx(cur_t[e] / (w["len"] - 1), abs=1e-14)
             assert grew[e] == pytest.approx(r, abs=1e-9)
-            np.testing.assert_allclose(gparts[e], parts, atol=1e-9)
+            np.testing.assert_allclose(gparts[e][:len(parts)], parts, atol=1e-9)
             np.testing.assert_allclose(gobs[e], obs, atol=1e-8)
             if fail or end:
                 alive[e] = False

@@ -239,3 +239,35 @@ def test_config_attributes_match_reference(tmp_path):
         for it, nr, ls, lr in g[f"{cid}__adaptive"]:
             cfg.update_adaptive_params(int(it))
             np.testing.assert_allclose([cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr], [nr, ls, lr], rtol=1e-15, atol=0)
+
+
+def test_env_oracle_obs_v0_v5_and_remaining_rewards(model):
+    """G4c: get_full_obs (v0), get_full_obs_v5 and the reward ids implicit_quat, v1_mul, explicit_mul, v2, v3 of the imported reference."""
+    from oracle import env_oracle as E
+    from uhc_amd.smpllib.smpl_mujoco import SMPLConverter
+    g, f = load("g4c_more_variants"), load("g3_qpos_fk")
+    expert = {k[2:]: f[k] for k in f.files if k.startswith("f_")}
+    expert["len"] = expert["qpos"].shape[0]
+    conv = SMPLConverter(model, model)
+    w = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0)
+    w23 = {str(k): float(v) for k, v in zip(g["w_v23_keys"], g["w_v23_vals"])}
+    dt = model.timestep * 15
+    for c in range(int(g["ncase"])):
+        p, t = f"c{c}_", int(g[f"c{c}_cur_t"])
+        o0 = E.full_obs_v0(g[p + "qpos"], g[p + "qvel"], expert, t, 0, obs_heading=True)
+        np.testing.assert_allclose(o0, g[p + "obs_v0"], atol=1e-13)
+        o5 = E.full_obs_v5(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], g[p + "xquat"], expert, t, 0, g[p + "beta"], float(g["gender"]))
+        assert o5.shape == g[p + "obs_v5"].shape
+        np.testing.assert_allclose(o5, g[p + "obs_v5"], atol=1e-13)
+        args = (g[p + "qpos"], g[p + "xpos"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"], expert, t, 0, dt, conv.get_new_diff_weight()[1:], w)
+        r, parts = E.world_rfc_implicit_reward(*args)  # the _quat id is the same function body
+        np.testing.assert_allclose([r, *parts], [g[p + "world_rfc_implicit_quat"], *g[p + "world_rfc_implicit_quat_info"]], atol=1e-13)
+        r, parts = E.world_rfc_mul_reward(False, *args)
+        np.testing.assert_allclose([r, *parts], [g[p + "world_rfc_implicit_v1_mul"], *g[p + "world_rfc_implicit_v1_mul_info"]], atol=1e-13)
+        args_e = args[:4] + (g[p + "action_explicit"],) + args[5:]
+        r, parts = E.world_rfc_mul_reward(True, *args_e)
+        np.testing.assert_allclose([r, *parts], [g[p + "world_rfc_explicit_mul"], *g[p + "world_rfc_explicit_mul_info"]], atol=1e-13)
+        for v3, name in ((False, "world_rfc_implicit_v2"), (True, "world_rfc_implicit_v3")):
+            r, parts = E.world_rfc_implicit_v2_v3(v3, g[p + "qpos"], g[p + "xpos"], g[p + "xquat"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"],
+                                                  expert, t, 0, dt, w23, g["w_v23_jpos_diffw"])
+            np.testing.assert_allclose([r, *parts], [g[p + name], *g[p + name + "_info"]], atol=1e-13)

@@ -245,6 +245,51 @@ def g4b_obs_variants(dm, feat):
     save("g4b_obs_variants", **cases)
 
 
+def g4c_more_variants(dm, feat):
+    """Observation v0 / v5 (v4 returns a (full, local, global) tuple that the stock agent cannot consume: not built) and the remaining reward ids (implicit_quat, v1_mul, explicit_mul, v2, v3), own rng stream."""
+    from uhc.envs.humanoid_im import HumanoidEnv
+    from uhc.losses import reward_function as RF
+    rng = np.random.default_rng(1313)
+    w_v23 = dict(k_p=0.6, k_wp=0.3, k_v=0.004, k_j=60.0, k_c=80.0, k_vf=0.7, w_p=0.25, w_wp=0.2, w_v=0.05, w_j=0.3, w_c=0.15, w_vf=0.05,
+                 jpos_diffw=[float(x) for x in np.round(np.linspace(0.5, 1.5, 24), 3)])
+    cases = {"w_v23_keys": np.array([k for k in w_v23 if k != "jpos_diffw"]), "w_v23_vals": np.array([w_v23[k] for k in w_v23 if k != "jpos_diffw"]),
+             "w_v23_jpos_diffw": np.array(w_v23["jpos_diffw"])}
+    for c, cur_t in enumerate([1, 9, 37]):
+        env = fake_env(dm, feat, rng, cur_t=cur_t)
+        env.expert["len"] = feat["qpos"].shape[0]
+        env.cc_cfg.update(obs_heading=True, root_deheading=True, obs_phase=True)
+        obs0 = HumanoidEnv.get_full_obs(env)
+        obs5 = HumanoidEnv.get_full_obs_v5(env)
+        prev_q = env.data.qpos.copy()
+        prev_q[7:] -= rng.normal(scale=0.02, size=69)
+        save_q = env.data.qpos
+        env.data.qpos = prev_q
+        env.prev_bquat = HumanoidEnv.get_body_quat(env)
+        env.data.qpos = save_q
+        action = rng.normal(scale=0.3, size=105)
+        pre = f"c{c}_"
+        cases.update({pre + "cur_t": cur_t, pre + "qpos": env.data.qpos, pre + "qvel": env.data.qvel, pre + "xpos": env.data.body_xpos,
+                      pre + "xquat": env.data.body_xquat, pre + "xipos": env.data.xipos, pre + "obs_v0": obs0, pre + "obs_v5": obs5,
+                      pre + "prev_bquat": env.prev_bquat, pre + "action": action, pre + "beta": env.expert["beta"][0]})
+        for name in ("world_rfc_implicit_quat", "world_rfc_implicit_v1_mul"):
+            r, info = RF.reward_func[name](env, None, action, None)
+            cases.update({pre + name: r, pre + name + "_info": info})
+        base_w = env.cc_cfg["reward_weights"]
+        env.cc_cfg["reward_weights"] = w_v23
+        for name in ("world_rfc_implicit_v2", "world_rfc_implicit_v3"):
+            r, info = RF.reward_func[name](env, None, action, None)
+            cases.update({pre + name: r, pre + name + "_info": info})
+        env.cc_cfg["reward_weights"] = base_w
+        env.vf_bodies = list(dm.body_names[1:])
+        env.body_vf_dim, env.vf_dim = 9, 24 * 9
+        action_e = rng.normal(scale=0.1, size=69 + 216 + 30)
+        r, info = RF.reward_func["world_rfc_explicit_mul"](env, None, action_e, None)
+        cases.update({pre + "action_explicit": action_e, pre + "world_rfc_explicit_mul": r, pre + "world_rfc_explicit_mul_info": info})
+    cases["gender"] = env.expert["gender"][0]
+    cases["ncase"] = 3
+    save("g4c_more_variants", **cases)
+
+
 # --------------------------------------------------------------------------- G5 stable PD + implicit residual force
 def g5_pd(dm, feat):
     from uhc.envs import humanoid_im
@@ -474,6 +519,7 @@ def main():
     g1_math()
     dm, qpos, feat = g2_g3_expert()
     g4_g6_obs_reward(dm, feat)
+    g4c_more_variants(dm, feat)
     g5_pd(dm, feat)
     g7_g8_learner()
     g11_metrics(dm, feat)

@@ -86,16 +86,23 @@ def ctrl_desc(n_substeps=15, action_type=0, meta_pd=0, rfc_mode=0, action_dim=0,
 class UhcEnvDesc(C.Structure):
     _fields_ = [("obs_v", C.c_int32), ("has_shape", C.c_int32), ("env_episode_len", C.c_int32),
                 ("env_expert_trail_steps", C.c_int32), ("ee_body", C.c_int32 * 5), ("reward_v", C.c_int32),
-                ("body_diff_thresh", C.c_double), ("reward_weights", C.c_double * 10), ("jpos_diffw", _F64P),
-                ("fut_frames", C.c_int32), ("fut_skip", C.c_int32)]
+                ("body_diff_thresh", C.c_double), ("reward_weights", C.c_double * 16), ("jpos_diffw", _F64P),
+                ("fut_frames", C.c_int32), ("fut_skip", C.c_int32), ("obs_flags", C.c_int32), ("reward_jpos_diffw", _F64P)]
 
 
-REWARD_KEYS = ("w_p", "w_v", "w_e", "w_c", "w_vf", "k_p", "k_v", "k_e", "k_c", "k_vf")
-REWARD_DEFAULTS = (0.6, 0.1, 0.2, 0.1, 0.0, 2.0, 0.005, 20.0, 1000.0, 1.0)  # reward_function.py:16-29
+REWARD_KEYS = ("w_p", "w_v", "w_e", "w_c", "w_vf", "k_p", "k_v", "k_e", "k_c", "k_vf", "w_wp", "w_j", "k_wp", "k_j")
+REWARD_DEFAULTS = (0.6, 0.1, 0.2, 0.1, 0.0, 2.0, 0.005, 20.0, 1000.0, 1.0, 0.0, 0.0, 0.0, 0.0)  # reward_function.py:16-29
+# world_rfc_implicit_v2 / v3 read their own defaults (reward_function.py:646-654, :729-747)
+REWARD_DEFAULTS_V23 = dict(w_p=0.4, w_wp=0.4, w_v=0.005, w_j=100.0, w_c=100.0, w_vf=1.0, k_p=0.4, k_wp=0.4, k_v=0.005, k_j=100.0, k_c=100.0, k_vf=1.0,
+                           w_e=0.0, k_e=0.0)
+REWARD_IDS = {"world_rfc_implicit": 0, "world_rfc_implicit_quat": 0, "world_rfc_explicit": 1, "world_rfc_implicit_v1_mul": 2,
+              "world_rfc_explicit_mul": 3, "world_rfc_implicit_v2": 4, "world_rfc_implicit_v3": 5}
+REWARD_PARTS = {0: 5, 1: 5, 2: 5, 3: 5, 4: 6, 5: 6}
 
 
 def env_desc(model, *, obs_v=2, has_shape=True, env_episode_len=100000, env_expert_trail_steps=0, body_diff_thresh=0.5,
-             reward_weights=None, jpos_diffw=None, reward_v=0, fut_frames=10, fut_skip=10) -> UhcEnvDesc:
+             reward_weights=None, jpos_diffw=None, reward_v=0, fut_frames=10, fut_skip=10, obs_heading=False, root_deheading=False,
+             obs_phase=True, obs_vel="full") -> UhcEnvDesc:
     from .smpllib.smpl_mujoco import SMPL_EE_NAMES, SMPLConverter
     d = UhcEnvDesc()
     d.obs_v, d.has_shape, d.env_episode_len, d.env_expert_trail_steps = obs_v, int(has_shape), int(env_episode_len), int(env_expert_trail_steps)
@@ -103,10 +110,18 @@ def env_desc(model, *, obs_v=2, has_shape=True, env_episode_len=100000, env_expe
     d.body_diff_thresh = float(body_diff_thresh)
     d.reward_v = int(reward_v)
     d.fut_frames, d.fut_skip = int(fut_frames), int(fut_skip)
-    rw = dict(zip(REWARD_KEYS, REWARD_DEFAULTS))
-    rw.update(reward_weights or {})
-    d.reward_weights = (C.c_double * 10)(*[float(rw[k]) for k in REWARD_KEYS])
+    d.obs_flags = int(bool(obs_heading)) | int(bool(root_deheading)) << 1 | int(bool(obs_phase)) << 2 | int(obs_vel == "root") << 3
+    rw = dict(REWARD_DEFAULTS_V23) if reward_v >= 4 else dict(zip(REWARD_KEYS, REWARD_DEFAULTS))
+    given = dict(reward_weights or {})
+    rjw = given.pop("jpos_diffw", None)
+    rw.update(given)
+    d.reward_weights = (C.c_double * 16)(*[float(rw[k]) for k in REWARD_KEYS], 0.0, 0.0)
     w = np.ascontiguousarray(jpos_diffw if jpos_diffw is not None else SMPLConverter(model, model).get_new_diff_weight(), dtype=np.float64)
-    d._keep = w
     d.jpos_diffw = w.ctypes.data_as(_F64P)
+    d._keep = [w]
+    if rjw is not None:
+        rjw = np.ascontiguousarray(rjw, dtype=np.float64)
+        assert rjw.shape == (model.nbody - 1,), "reward_weights['jpos_diffw'] needs one weight per body"
+        d._keep.append(rjw)
+        d.reward_jpos_diffw = rjw.ctypes.data_as(_F64P)
     return d

@@ -15,16 +15,17 @@
 #define UHC_FR_BCOM 512    // 72 (body_com, used by observation v1)
 
 struct EnvArgs {
-    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip;
+    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip, obs_flags;
     int ee_body[5];
     double dt, body_diff_thresh;
-    double rw[10];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf
+    double rw[16];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf | w_wp w_j k_wp k_j
     double base_rot_inv[4];
     // clip bank
     const double* bank;       // [n_frames][UHC_FRAME_STRIDE]
     const int* clip_start;    // [n_clips] first frame of each clip
     const double* clip_beta;  // [n_clips][17]: beta(16), gender
     const double* jpos_diffw; // [nbody-1]
+    const double* rjw;        // [nbody-1] reward_weights["jpos_diffw"] of the v2 / v3 rewards
     // simulation state (owned by the UhcBatch)
     const double *qpos, *qvel, *xpos, *xquat, *xipos;
     const int* sim_fail;

@@ -104,7 +104,9 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
         const double* fr = bank0 + (size_t)expert_index(cur_t, start_ind, len) * UHC_FRAME_STRIDE;
         const double* action = d_action + (size_t)env * E.action_dim;
         // ---- termination: mean weighted body distance (calc_body_diff, humanoid_im.py:1408-1415)
-        double dist = 0, wcount = 0, pose2 = 0, vel2 = 0;
+        double dist = 0, wcount = 0, pose2 = 0, vel2 = 0, wpose2 = 0, bcom2 = 0, jpos2 = 0;
+        const bool expl = E.reward_v == 1 || E.reward_v == 3;  // explicit residual-force flavour
+        const bool v23 = E.reward_v >= 4;                       // world_rfc_implicit_v2 / v3 (reward_function.py:643-820)
         if (LANE < nb) {
             const double w = E.jpos_diffw[LANE];
             double d[3];
@@ -117,7 +119,8 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             for (int k = 0; k < 4; k++) eq[k] = fr[UHC_FR_BQUAT + 4 * LANE + k];
             qinv(ei, eq);
             qmul(dq, cq, ei);
-            const double wq = LANE == 0 ? 1.0 : E.jpos_diffw[LANE];  // pose_diff[1:] *= body_diffw
+            const double jw = v23 ? E.rjw[LANE] : 0.0;                // v2 / v3: reward_weights["jpos_diffw"] on every term
+            const double wq = v23 ? jw : (LANE == 0 ? 1.0 : E.jpos_diffw[LANE]);  // pose_diff[1:] *= body_diffw
             const double pd = acos(fmin(fmax(dq[0], -1.0), 1.0)) * wq;  // multi_quat_norm: no abs
             pose2 = pd * pd;
             qinv(pi, pq);
@@ -131,13 +134,27 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
                 for (int k = 0; k < 3; k++) av[k] = ax[k] / an * ang / E.dt;
             }
             // explicit variant: unweighted, expert velocity zero past the clip end (reward_function.py:300-301, 308)
-            const double wv = E.reward_v == 1 ? 1.0 : w;
-            const bool past = E.reward_v == 1 && start_ind + cur_t >= len;
+            const double wv = (expl || v23) ? 1.0 : w;
+            const bool past = expl && start_ind + cur_t >= len;
             for (int k = 0; k < 3; k++) {
                 const double dv = (av[k] - (past ? 0.0 : fr[UHC_FR_BANGVEL + 3 * LANE + k])) * wv;
                 vel2 += dv * dv;
             }
+            if (v23) {
+                double cw[4], ew[4];
+                for (int k = 0; k < 4; k++) { cw[k] = xquat[4 * (LANE + 1) + k]; ew[k] = fr[UHC_FR_WBQUAT + 4 * LANE + k]; }
+                qinv(ei, ew);
+                qmul(dq, cw, ei);
+                const double wp = acos(fmin(fmax(dq[0], -1.0), 1.0)) * jw;
+                wpose2 = wp * wp;
+                for (int k = 0; k < 3; k++) {
+                    const double dc = (fr[UHC_FR_BCOM + 3 * LANE + k] - xipos[3 * (LANE + 1) + k]) * jw;
+                    const double dj = (xpos[3 * (LANE + 1) + k] - fr[UHC_FR_WBPOS + 3 * LANE + k]) * jw;
+                    bcom2 += dc * dc; jpos2 += dj * dj;
+                }
+            }
         }
+        if (v23) { wpose2 = wsum(wpose2); bcom2 = wsum(bcom2); jpos2 = wsum(jpos2); }
         const double body_diff = wsum(dist) / fmax(wsum(wcount), 1.0);
         pose2 = wsum(pose2);
         vel2 = wsum(vel2);
@@ -152,15 +169,24 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             double com2 = 0, vf2 = 0;
             for (int k = 0; k < 3; k++) { const double d = xipos[3 + k] - fr[UHC_FR_COM + k]; com2 += d * d; }
             // implicit: |vf|^2 (:74-76); explicit: force + torque entries of every body, contact points skipped (:320-327)
-            for (int k = 0; k < E.vf_dim; k++) { const double a = action[E.nu + k]; if (E.reward_v != 1 || k % 9 >= 3) vf2 += a * a; }
-            const double* W = E.rw;  // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf
-            const double rp = exp(-W[5] * pose2), rv = exp(-W[6] * vel2), re = exp(-W[7] * ee2), rc = exp(-W[8] * com2);
-            const double rf = (E.vf_dim > 0 || E.reward_v == 1) ? exp(-W[9] * vf2) : 0.0;
-            const double r = (W[0] * rp + W[1] * rv + W[2] * re + W[3] * rc + W[4] * rf) / (W[0] + W[1] + W[2] + W[3] + W[4]);
+            for (int k = 0; k < E.vf_dim; k++) { const double a = action[E.nu + k]; if (!expl || k % 9 >= 3) vf2 += a * a; }
+            const double* W = E.rw;  // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf | w_wp w_j k_wp k_j
+            double* rp_out = E.reward_parts + (size_t)env * 6;
+            double r;
+            if (v23) {  // means over bodies (over 3 nb entries for the velocity); v2 multiplies the six terms, v3 sums them with its weights
+                const double p0 = exp(-W[5] * pose2 / nb), p1 = exp(-W[12] * wpose2 / nb), p2 = exp(-W[8] * bcom2 / nb), p3 = exp(-W[13] * jpos2 / nb);
+                const double p4 = exp(-W[6] * vel2 / (3 * nb)), p5 = exp(-W[9] * vf2);
+                r = E.reward_v == 5 ? W[0] * p0 + W[10] * p1 + W[3] * p2 + W[11] * p3 + W[1] * p4 + W[4] * p5 : p0 * p1 * p2 * p3 * p4 * p5;
+                rp_out[0] = p0; rp_out[1] = p1; rp_out[2] = p2; rp_out[3] = p3; rp_out[4] = p4; rp_out[5] = p5;
+            } else {
+                const double rp = exp(-W[5] * pose2), rv = exp(-W[6] * vel2), re = exp(-W[7] * ee2), rc = exp(-W[8] * com2);
+                const double rf = (E.vf_dim > 0 || expl) ? exp(-W[9] * vf2) : 0.0;
+                if (E.reward_v >= 2) r = rp * rv * re * rc * ((expl || W[4] != 0.0) ? rf : 1.0);  // _v1_mul (:243-245) / explicit_mul (:424-426)
+                else r = (W[0] * rp + W[1] * rv + W[2] * re + W[3] * rc + W[4] * rf) / (W[0] + W[1] + W[2] + W[3] + W[4]);
+                rp_out[0] = rp; rp_out[1] = rv; rp_out[2] = re; rp_out[3] = rc; rp_out[4] = rf; rp_out[5] = 0.0;
+            }
             E.reward[env] = r;
             E.episode[env] += 1.0;
-            double* rp_out = E.reward_parts + (size_t)env * 5;
-            rp_out[0] = rp; rp_out[1] = rv; rp_out[2] = re; rp_out[3] = rc; rp_out[4] = rf;
             const int fail = (E.sim_fail[env] != 0) || (body_diff > E.body_diff_thresh);
             const int end = (cur_t >= E.env_episode_len) || (cur_t + start_ind >= len + E.expert_trail_steps - 1);
             E.fail[env] = fail; E.end[env] = end; E.done[env] = fail || end;
@@ -183,8 +209,27 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
     qmul(crq, rootq, E.base_rot_inv);            // remove_base_rot (:263-264)
     for (int k = 0; k < 4; k++) tq[k] = fr[UHC_FR_QPOS + 3 + k];
     qmul(trq, tq, E.base_rot_inv);
-    int shape_base;
-    if (E.obs_v == 6) {
+    int shape_base = 0;
+    if (E.obs_v == 0) {
+        // get_full_obs (:290-317): raw root quaternion (no base-rotation removal), expert joint angles of the CURRENT frame, phase
+        const double* fr0 = bank0 + (size_t)expert_index(cur_t, start_ind, len) * UHC_FRAME_STRIDE;
+        const int oh = E.obs_flags & 1, nvel = (E.obs_flags & 8) ? 6 : E.nv;
+        const int oq = oh, ov = oq + E.nq - 2, oe = ov + nvel, op = oe + E.nu;
+        if (LANE == 0) {
+            double v0[3], dh[4];
+            if (oh) obs[0] = heading(rootq);
+            obs[oq] = s_qpos[2];
+            if (E.obs_flags & 2) { heading_q(hq, rootq); qinv(hqi, hq); qmul(dh, hqi, rootq); } else { for (int k = 0; k < 4; k++) dh[k] = rootq[k]; }
+            for (int k = 0; k < 4; k++) obs[oq + 1 + k] = dh[k];
+            qmat(Rr, rootq);
+            const double qv[3] = {qvel[0], qvel[1], qvel[2]};
+            rotT(v0, Rr, qv);
+            for (int k = 0; k < 3; k++) obs[ov + k] = v0[k];
+            if (E.obs_flags & 4) obs[op] = (double)cur_t / (double)len;
+        }
+        for (int i = LANE; i < E.nu; i += WAVE) { obs[oq + 5 + i] = s_qpos[7 + i]; obs[oe + i] = fr0[UHC_FR_QPOS + 7 + i]; }
+        for (int i = LANE + 3; i < nvel; i += WAVE) obs[ov + i] = qvel[i];
+    } else if (E.obs_v == 6) {
         const double yaw = heading_new(crq);
         sincos(0.5 * yaw, &hq[3], &hq[0]); hq[1] = 0; hq[2] = 0;  // quaternion_about_axis(yaw, z) (math_utils.py:169-172)
         qmat(Rc, hq);
@@ -226,13 +271,17 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
         }
         shape_base = o4 + 4 * (nb - 1);
     } else {
-        heading_q(hq, crq);
+        // v5 (:505-594) = v2 without the leading heading quaternion, with the atan2 yaw, one velocity rotation and a real root offset
+        const bool v5 = E.obs_v == 5;
+        const double yaw5 = v5 ? heading_new(crq) : 0.0;
+        if (v5) { sincos(0.5 * yaw5, &hq[3], &hq[0]); hq[1] = 0; hq[2] = 0; } else heading_q(hq, crq);
         qinv(hqi, hq);
         qmat(Rr, rootq);
         qmat(Rc, crq);
+        if (v5) obs -= 4;  // every v2 offset below shifts down by the missing heading block (nothing is written below obs + 4)
         if (LANE == 0) {
             double dh[4], ci[4], dr[4], v0[3], v1[3], rel[3], rl[3];
-            for (int k = 0; k < 4; k++) obs[k] = hq[k];
+            if (!v5) for (int k = 0; k < 4; k++) obs[k] = hq[k];
             qmul(dh, hqi, crq);                      // de_heading(curr_root_quat)
             qinv(ci, crq);
             qmul(dr, trq, ci);
@@ -240,13 +289,13 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             for (int k = 0; k < 4; k++) { obs[5 + k] = tq[k]; obs[79 + k] = dh[k]; obs[153 + k] = dr[k]; }
             const double qv[3] = {qvel[0], qvel[1], qvel[2]};
             rotT(v0, Rr, qv);
-            rotT(v1, Rc, v0);                        // rotated twice, as the reference does (:425, :451)
+            if (v5) rotT(v1, Rc, qv); else rotT(v1, Rc, v0);  // v2 rotates twice, as the reference does (:425, :451)
             for (int k = 0; k < 3; k++) obs[226 + k] = v1[k];
-            double rel_h = heading(trq) - heading(crq);
+            double rel_h = v5 ? heading_new(trq) - yaw5 : heading(trq) - heading(crq);
             if (rel_h > M_PI) rel_h -= 2 * M_PI;
             if (rel_h < -M_PI) rel_h += 2 * M_PI;
             obs[301] = rel_h;
-            for (int k = 0; k < 3; k++) rel[k] = trq[k] - s_qpos[k];  // target_root_quat[:3] - qpos[:3]: bug-compatible (:466)
+            for (int k = 0; k < 3; k++) rel[k] = (v5 ? fr[UHC_FR_QPOS + k] : trq[k]) - s_qpos[k];  // v2: target_root_quat[:3] - qpos[:3], bug-compatible (:466)
             rotT(rl, Rc, rel);
             obs[302] = rl[0]; obs[303] = rl[1];
         }
@@ -282,6 +331,7 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             for (int k = 0; k < 4; k++) obs[qb + 4 * nb + 4 * b + k] = o[k];
         }
         shape_base = qb + 8 * nb;
+        if (v5) { obs += 4; shape_base -= 4; }
     }
     if (E.has_shape) {
         const double* cb = E.clip_beta + (size_t)E.clip_id[env] * 17;

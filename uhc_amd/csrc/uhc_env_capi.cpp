@@ -52,9 +52,9 @@ static int dalloc(UhcEnv* e, size_t n, T** p) {
 
 extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out) {
     if (!b || !d || !out) return uhc_internal_set_error("uhc_env_create: null argument");
-    if (d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 3 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 1, 2, 3 or 6");
+    if (d->obs_v != 0 && d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 3 && d->obs_v != 5 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 0, 1, 2, 3, 5 or 6");
     if (d->obs_v == 3 && (d->fut_frames < 1 || d->fut_frames > 64 || d->fut_skip < 0)) return uhc_internal_set_error("uhc_env_create: obs_v 3 needs 1 <= fut_frames <= 64, skip >= 0");
-    if (d->reward_v != 0 && d->reward_v != 1) return uhc_internal_set_error("uhc_env_create: reward_v must be 0 (implicit) or 1 (explicit)");
+    if (d->reward_v < 0 || d->reward_v > 5) return uhc_internal_set_error("uhc_env_create: reward_v must be 0 .. 5 (implicit, explicit, implicit_v1_mul, explicit_mul, implicit_v2, implicit_v3)");
     UhcEnv* e = new UhcEnv();
     e->b = b;
     EnvArgs& E = e->E;
@@ -67,7 +67,12 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     E.has_shape = d->has_shape;
     E.obs_v = d->obs_v;
     E.reward_v = d->reward_v;
-    E.obs_dim = (d->obs_v == 6 ? 8 + E.nv + 2 * nb + 11 * (nb - 1) : 304 + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
+    E.obs_flags = d->obs_flags;
+    if (d->obs_v == 0)  // [heading] qpos[2:] velocities expert joint angles [phase]; get_full_obs never appends the shape
+        E.obs_dim = (d->obs_flags & 1) + (E.nq - 2) + ((d->obs_flags & 8) ? 6 : E.nv) + E.nu + ((d->obs_flags >> 2) & 1);
+    else
+        E.obs_dim = (d->obs_v == 6 ? 8 + E.nv + 2 * nb + 11 * (nb - 1) : (d->obs_v == 5 ? 300 : 304) + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
+    if (d->obs_v == 0) E.has_shape = 0;
     E.fut_frames = d->obs_v == 3 ? d->fut_frames : 1;
     E.fut_skip = d->obs_v == 3 ? d->fut_skip : 0;
     E.obs_dim *= E.fut_frames;
@@ -75,11 +80,16 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     E.expert_trail_steps = d->env_expert_trail_steps;
     for (int k = 0; k < 5; k++) E.ee_body[k] = d->ee_body[k];
     E.body_diff_thresh = d->body_diff_thresh;
-    for (int k = 0; k < 10; k++) E.rw[k] = d->reward_weights[k];
-    double* w;
-    if (dalloc(e, nb, &w)) { delete e; return 1; }
+    for (int k = 0; k < 16; k++) E.rw[k] = d->reward_weights[k];
+    double *w, *rjw;
+    if (dalloc(e, nb, &w) || dalloc(e, nb, &rjw)) { delete e; return 1; }
     HIP_OK(hipMemcpy(w, d->jpos_diffw, nb * sizeof(double), hipMemcpyHostToDevice));
     E.jpos_diffw = w;
+    {
+        std::vector<double> ones(nb, 1.0);
+        HIP_OK(hipMemcpy(rjw, d->reward_jpos_diffw ? d->reward_jpos_diffw : ones.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+        E.rjw = rjw;
+    }
     void* p; int64_t cnt;
     uhc_batch_field(b, UHC_F_QPOS, &p, &cnt); E.qpos = (const double*)p;
     uhc_batch_field(b, UHC_F_QVEL, &p, &cnt); E.qvel = (const double*)p;
@@ -90,7 +100,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     const size_t N = E.n_env;
     if (dalloc(e, N, &E.clip_id) || dalloc(e, N, &E.e_start) || dalloc(e, N, &E.e_len) || dalloc(e, N, &E.cur_t) || dalloc(e, N, &E.start_ind) ||
         dalloc(e, N * E.nu, &E.target_base) || dalloc(e, N * E.nq, &E.qpos_prev) || dalloc(e, N * E.obs_dim, &E.obs) || dalloc(e, N, &E.reward) ||
-        dalloc(e, N * 5, &E.reward_parts) || dalloc(e, N, &E.percent) || dalloc(e, N, &E.body_diff) || dalloc(e, N, &E.done) || dalloc(e, N, &E.fail) ||
+        dalloc(e, N * 6, &E.reward_parts) || dalloc(e, N, &E.percent) || dalloc(e, N, &E.body_diff) || dalloc(e, N, &E.done) || dalloc(e, N, &E.fail) ||
         dalloc(e, N, &E.end) || dalloc(e, N * E.nq, &e->stage_qpos) || dalloc(e, N * E.nv, &e->stage_qvel) || dalloc(e, N, &e->select) ||
         dalloc(e, N, &E.next_clip) || dalloc(e, N, &E.next_start) || dalloc(e, N, &E.next_len) || dalloc(e, N, &E.has_next) || dalloc(e, N, &E.consumed) ||
         dalloc(e, N * E.nu, &E.next_noise) || dalloc(e, 2 * N, &E.episode) || dalloc(e, 5 * N, &E.snapshot)) { delete e; return 1; }
@@ -112,7 +122,7 @@ extern "C" int32_t uhc_env_field(UhcEnv* e, int32_t f, void** p, int64_t* n) {
     switch (f) {
         case UHC_E_OBS: ptr = E.obs; cnt = N * E.obs_dim; break;
         case UHC_E_REWARD: ptr = E.reward; cnt = N; break;
-        case UHC_E_REWARD_PARTS: ptr = E.reward_parts; cnt = N * 5; break;
+        case UHC_E_REWARD_PARTS: ptr = E.reward_parts; cnt = N * 6; break;
         case UHC_E_DONE: ptr = E.done; cnt = N; break;
         case UHC_E_FAIL: ptr = E.fail; cnt = N; break;
         case UHC_E_END: ptr = E.end; cnt = N; break;

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import sim as S
-from .._capi import env_desc
+from .._capi import REWARD_IDS, REWARD_PARTS, env_desc
 from ..smpllib.smpl_mujoco import SMPLConverter, smpl_to_qpose
 from ..smpllib.torch_smpl_humanoid import Humanoid
 
@@ -51,10 +51,16 @@ class VecHumanoidEnv:
         thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
         if cfg.env_term_body != "body":
             raise NotImplementedError("env_term_body other than 'body' is a later row (SURVEY.md 8f-4)")
-        reward_v = {"world_rfc_implicit": 0, "world_rfc_explicit": 1}.get(cfg.reward_id)
+        reward_v = REWARD_IDS.get(cfg.reward_id)
         if reward_v is None:
-            raise NotImplementedError(f"reward_id {cfg.reward_id!r}: world_rfc_implicit and world_rfc_explicit are built (SURVEY.md 8f-4)")
-        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, fut_frames=cfg.get("fut_frames", 10), fut_skip=cfg.get("skip", 10), has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
+            raise NotImplementedError(f"reward_id {cfg.reward_id!r}: built are {sorted(REWARD_IDS)} (the local_rfc_* rewards are not)")
+        if cfg.obs_v == 4:
+            raise NotImplementedError("obs_v 4 returns a (full, local, global) tuple in the reference (humanoid_im.py:769-861), which AgentCopycat cannot consume")
+        if cfg.obs_coord != "root" or (cfg.obs_v != 0 and cfg.obs_vel != "full"):
+            raise NotImplementedError("obs_coord 'root' (every reference config) and, for obs_v >= 1, obs_vel 'full' are built")
+        self.n_reward_parts = REWARD_PARTS[reward_v]
+        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, obs_heading=cfg.obs_heading, root_deheading=cfg.root_deheading,
+                                                 obs_phase=cfg.obs_phase, obs_vel=cfg.obs_vel, fut_frames=cfg.get("fut_frames", 10), fut_skip=cfg.get("skip", 10), has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
                                                  env_episode_len=cfg.env_episode_len, env_expert_trail_steps=cfg.env_expert_trail_steps,
                                                  body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
                                                  jpos_diffw=self.converter.get_new_diff_weight()))
@@ -175,7 +181,7 @@ class VecHumanoidEnv:
 
     obs = property(lambda self: self.env.field(S.E_OBS))
     reward = property(lambda self: self.env.field(S.E_REWARD))
-    reward_parts = property(lambda self: self.env.field(S.E_REWARD_PARTS))
+    reward_parts = property(lambda self: self.env.field(S.E_REWARD_PARTS)[:, :self.n_reward_parts])
     done = property(lambda self: self.env.field(S.E_DONE))
     cur_t = property(lambda self: self.env.field(S.E_CUR_T))
 

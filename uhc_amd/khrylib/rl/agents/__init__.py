@@ -81,7 +81,7 @@ class Agent:
         R.masks = torch.ones(n_env, T, dtype=self.dtype, device=dev)
         R.exps = torch.ones(n_env, T, dtype=self.dtype, device=dev)
         R.logger = self.logger_cls()
-        R.c_info_sum = torch.zeros(5, dtype=self.dtype, device=dev)
+        R.c_info_sum = torch.zeros(getattr(env, "n_reward_parts", 5), dtype=self.dtype, device=dev)
         # exploration flags of the whole pass in one upload (the same stream of draws as one binomial(n_env) per step)
         flags = np.ones((T, n_env)) if self.mean_action else env.np_random.binomial(1, 1 - self.noise_rate, size=(T, n_env))
         R.mean_flags = torch.from_numpy(flags.astype(np.float64)).to(dev)

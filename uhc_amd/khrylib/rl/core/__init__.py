@@ -119,7 +119,7 @@ class LoggerRL:
         self.num_steps = 0
         self.num_episodes = 0
         self.total_c_reward = 0.0
-        self.total_c_info = np.zeros(5)
+        self.total_c_info = 0.0  # one entry per reward term (5 or 6, by reward id)
         self.episode_c_rewards = []
         self.episode_lens = []
         self.sample_time = 0.0
@@ -137,7 +137,7 @@ class LoggerRL:
     def end_sampling(self):
         n = max(self.num_steps, 1)
         self.avg_c_reward = self.total_c_reward / n
-        self.avg_c_info = self.total_c_info / n
+        self.avg_c_info = np.atleast_1d(self.total_c_info / n)
         self.avg_episode_len = float(np.mean(self.episode_lens)) if self.episode_lens else float(self.num_steps)
         self.avg_episode_c_reward = float(np.mean(self.episode_c_rewards)) if self.episode_c_rewards else self.total_c_reward
         self.max_c_reward = max(self.episode_c_rewards) if self.episode_c_rewards else self.total_c_reward
