@@ -198,6 +198,8 @@ typedef struct UhcEnvDesc {
     int32_t fut_skip;            /* obs_v 3: cfg.skip (default 10) */
     int32_t obs_flags;           /* obs_v 0: bit 0 cfg.obs_heading, bit 1 cfg.root_deheading, bit 2 cfg.obs_phase, bit 3 cfg.obs_vel == "root" */
     const double* reward_jpos_diffw; /* reward_v 4, 5: reward_weights["jpos_diffw"] [nbody-1] (host); NULL = ones */
+    int32_t term_body;           /* cfg.env_term_body (humanoid_im.py:1223-1230): 0 "body" (mean body distance > body_diff_thresh), 1 "root" (root height
+                                  * below the window's lowest expert root height - 0.1); "Head" reads a key the reference never sets */
 } UhcEnvDesc;
 
 /* expert frame record layout of the clip bank (doubles; see uhc_amd/csrc/uhc_device_env.h) */

@@ -29,13 +29,13 @@ def _window(e, start, n, model=None):
     return w
 
 
-def _make(model, ctrl, n_env, expert, beta, obs_v=2, reward_v=0, has_shape=True):
+def _make(model, ctrl, n_env, expert, beta, obs_v=2, reward_v=0, has_shape=True, env_term_body="body"):
     import torch
     from uhc_amd import sim as S
     from uhc_amd._capi import env_desc
     sb = S.SimBatch(model, ctrl, n_env)
     eb = S.EnvBatch(sb, env_desc(model, obs_v=obs_v, has_shape=has_shape, reward_weights=REWARD_W23 if reward_v >= 4 else REWARD_W, reward_v=reward_v,
-                                 fut_frames=3, fut_skip=4, obs_heading=True, root_deheading=True, obs_phase=True))
+                                 fut_frames=3, fut_skip=4, obs_heading=True, root_deheading=True, obs_phase=True, env_term_body=env_term_body))
     frames = S.pack_expert_frames(expert)
     frames2 = np.concatenate([frames, frames[::-1].copy()])  # clip 1 = clip 0 reversed (only a second id to address)
     clip_start = torch.tensor([0, frames.shape[0]], dtype=torch.int32)
@@ -163,6 +163,40 @@ def test_env_inactive_and_second_clip(model, ctrl):
     after = eb.field(S.E_OBS)
     assert torch.equal(before[0], after[0]) and torch.equal(before[2], after[2]) and not torch.equal(before[1], after[1])
     assert eb.field(S.E_CUR_T).cpu().tolist() == [0, 1, 0]
+
+
+def test_env_term_body_root(model, ctrl):
+    """cfg.env_term_body == "root" (humanoid_im.py:1225-1226): an env fails when its root is more than 0.1 below the lowest root height of
+    its expert window -- also for a window taken through the device-side queue."""
+    import torch
+    from uhc_amd import sim as S
+    expert = dict(_expert())
+    T = expert["qpos"].shape[0]
+    expert["qpos"] = expert["qpos"].copy()
+    expert["qpos"][:, 2] += 0.3 * np.arange(T) / (T - 1)  # the expert root rises by 0.3 over the clip
+    n = 3
+    sb, eb = _make(model, ctrl, n, expert, np.zeros(16), env_term_body="root")
+    ids = torch.arange(n, dtype=torch.int32)
+    # env 0 tracks the whole clip (lowest height = frame 0), env 1 its upper half, env 2 a 2-frame window with the upper half queued behind it
+    eb.assign(ids, torch.zeros(n, dtype=torch.int32), torch.tensor([0, 20, 0], dtype=torch.int32), torch.tensor([T, T - 20, 2], dtype=torch.int32))
+    eb.set_next(torch.tensor([2], dtype=torch.int32), torch.tensor([0], dtype=torch.int32), torch.tensor([20], dtype=torch.int32), torch.tensor([T - 20], dtype=torch.int32), None)
+    eb.reset(ids.cuda(), None)
+    # all three stand at the height of frame 0, i.e. 0.154 below the lowest frame of the upper half
+    q0 = np.tile(_expert()["qpos"][0], (n, 1))
+    sb.set_state(torch.from_numpy(q0), torch.zeros(n, model.nv, dtype=torch.float64))
+    act = torch.zeros(n, ctrl.action_dim, dtype=torch.float64, device="cuda")
+    eb.step(act, None)
+    sb.sync()
+    assert eb.field(S.E_FAIL).cpu().tolist() == [0, 1, 0] and eb.field(S.E_DONE).cpu().tolist() == [0, 1, 1]  # env 2: end of its 2-frame window
+    eb.auto_reset()   # env 1 restarts its window, env 2 takes the queued upper half: both start at that window's own height
+    eb.step(act, None)
+    sb.sync()
+    assert eb.field(S.E_FAIL).cpu().tolist() == [0, 0, 0]
+    sb.set_state(torch.from_numpy(q0), torch.zeros(n, model.nv, dtype=torch.float64))
+    eb.step(act, None)
+    sb.sync()
+    assert eb.field(S.E_FAIL).cpu().tolist() == [0, 1, 1]   # the queued window's lower bound applies to env 2 now
+    sb.close()
 
 
 def test_auto_reset_equals_assign_plus_reset(model, ctrl):

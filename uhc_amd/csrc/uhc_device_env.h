@@ -15,7 +15,7 @@
 #define UHC_FR_BCOM 512    // 72 (body_com, used by observation v1)
 
 struct EnvArgs {
-    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip, obs_flags;
+    int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip, obs_flags, term_body;
     int ee_body[5];
     double dt, body_diff_thresh;
     double rw[16];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf | w_wp w_j k_wp k_j
@@ -31,7 +31,7 @@ struct EnvArgs {
     const int* sim_fail;
     // per-env episode state and outputs (owned by the UhcEnv)
     int *clip_id, *e_start, *e_len, *cur_t, *start_ind;
-    double *target_base, *qpos_prev, *obs, *reward, *reward_parts, *percent, *body_diff;
+    double *target_base, *qpos_prev, *obs, *reward, *reward_parts, *percent, *body_diff, *height_lb;
     int *done, *fail, *end;
     // queued next window per env (uhc_env_set_next / uhc_env_auto_reset)
     int *next_clip, *next_start, *next_len, *has_next, *consumed;

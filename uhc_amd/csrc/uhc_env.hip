@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             }
             E.reward[env] = r;
             E.episode[env] += 1.0;
-            const int fail = (E.sim_fail[env] != 0) || (body_diff > E.body_diff_thresh);
+            // env_term_body "body": mean body distance; "root": root height below the window's lowest expert height - 0.1 (:1225-1230)
+            const bool body_fail = E.term_body == 1 ? s_qpos[2] < E.height_lb[env] - 0.1 : body_diff > E.body_diff_thresh;
+            const int fail = (E.sim_fail[env] != 0) || body_fail;
             const int end = (cur_t >= E.env_episode_len) || (cur_t + start_ind >= len + E.expert_trail_steps - 1);
             E.fail[env] = fail; E.end[env] = end; E.done[env] = fail || end;
             E.episode[E.n_env + env] += r + (end ? E.end_reward : 0.0);
@@ -373,6 +375,13 @@ extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* en
     hipLaunchKernelGGL(uhc_env_reset_stage_kernel, dim3(n), dim3(WAVE), 0, s, *E, env_ids, n, noise, out_qpos, out_qvel);
     return hipGetLastError();
 }
+// expert["height_lb"] = min root height over the window (torch_smpl_humanoid.py:250), for env_term_body "root"
+__device__ __forceinline__ double window_height_lb(const EnvArgs& E, int env) {
+    const double* fr = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE + UHC_FR_QPOS + 2;
+    double lb = fr[0];
+    for (int t = 1; t < E.e_len[env]; t++) lb = fmin(lb, fr[(size_t)t * UHC_FRAME_STRIDE]);
+    return lb;
+}
 // load_expert bookkeeping (humanoid_im.py:182-215): env -> (clip, window start, window length)
 __global__ void uhc_env_assign_kernel(EnvArgs E, const int* env_ids, int n, const int* clip_ids, const int* fr_start, const int* fr_len) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,6 +391,7 @@ __global__ void uhc_env_assign_kernel(EnvArgs E, const int* env_ids, int n, cons
     E.e_start[env] = E.clip_start[c] + fr_start[r];
     E.e_len[env] = fr_len[r];
     if (E.clip_model) E.env_model[env] = E.clip_model[c];
+    if (E.term_body == 1) E.height_lb[env] = window_height_lb(E, env);
 }
 extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids, int n, const int* clip_ids, const int* fr_start,
                                             const int* fr_len, hipStream_t s) {
@@ -422,6 +432,7 @@ __global__ void uhc_env_auto_stage_kernel(EnvArgs E, double* out_qpos, double* o
             const int c = E.next_clip[env];
             E.clip_id[env] = c; E.e_start[env] = E.clip_start[c] + E.next_start[env]; E.e_len[env] = E.next_len[env]; E.has_next[env] = 0;
             if (E.clip_model) E.env_model[env] = E.clip_model[c];
+            if (E.term_body == 1) E.height_lb[env] = window_height_lb(E, env);
         }
         if (go) { E.cur_t[env] = 0; E.start_ind[env] = 0; }
     }

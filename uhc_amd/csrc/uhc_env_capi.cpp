@@ -54,6 +54,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     if (!b || !d || !out) return uhc_internal_set_error("uhc_env_create: null argument");
     if (d->obs_v != 0 && d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 3 && d->obs_v != 5 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 0, 1, 2, 3, 5 or 6");
     if (d->obs_v == 3 && (d->fut_frames < 1 || d->fut_frames > 64 || d->fut_skip < 0)) return uhc_internal_set_error("uhc_env_create: obs_v 3 needs 1 <= fut_frames <= 64, skip >= 0");
+    if (d->term_body != 0 && d->term_body != 1) return uhc_internal_set_error("uhc_env_create: term_body must be 0 (cfg.env_term_body 'body') or 1 ('root')");
     if (d->reward_v < 0 || d->reward_v > 5) return uhc_internal_set_error("uhc_env_create: reward_v must be 0 .. 5 (implicit, explicit, implicit_v1_mul, explicit_mul, implicit_v2, implicit_v3)");
     UhcEnv* e = new UhcEnv();
     e->b = b;
@@ -68,6 +69,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     E.obs_v = d->obs_v;
     E.reward_v = d->reward_v;
     E.obs_flags = d->obs_flags;
+    E.term_body = d->term_body;
     if (d->obs_v == 0)  // [heading] qpos[2:] velocities expert joint angles [phase]; get_full_obs never appends the shape
         E.obs_dim = (d->obs_flags & 1) + (E.nq - 2) + ((d->obs_flags & 8) ? 6 : E.nv) + E.nu + ((d->obs_flags >> 2) & 1);
     else
@@ -100,7 +102,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     const size_t N = E.n_env;
     if (dalloc(e, N, &E.clip_id) || dalloc(e, N, &E.e_start) || dalloc(e, N, &E.e_len) || dalloc(e, N, &E.cur_t) || dalloc(e, N, &E.start_ind) ||
         dalloc(e, N * E.nu, &E.target_base) || dalloc(e, N * E.nq, &E.qpos_prev) || dalloc(e, N * E.obs_dim, &E.obs) || dalloc(e, N, &E.reward) ||
-        dalloc(e, N * 6, &E.reward_parts) || dalloc(e, N, &E.percent) || dalloc(e, N, &E.body_diff) || dalloc(e, N, &E.done) || dalloc(e, N, &E.fail) ||
+        dalloc(e, N * 6, &E.reward_parts) || dalloc(e, N, &E.height_lb) || dalloc(e, N, &E.percent) || dalloc(e, N, &E.body_diff) || dalloc(e, N, &E.done) || dalloc(e, N, &E.fail) ||
         dalloc(e, N, &E.end) || dalloc(e, N * E.nq, &e->stage_qpos) || dalloc(e, N * E.nv, &e->stage_qvel) || dalloc(e, N, &e->select) ||
         dalloc(e, N, &E.next_clip) || dalloc(e, N, &E.next_start) || dalloc(e, N, &E.next_len) || dalloc(e, N, &E.has_next) || dalloc(e, N, &E.consumed) ||
         dalloc(e, N * E.nu, &E.next_noise) || dalloc(e, 2 * N, &E.episode) || dalloc(e, 5 * N, &E.snapshot)) { delete e; return 1; }

@@ -49,8 +49,8 @@ class VecHumanoidEnv:
         self.sim = S.SimBatch(self.models, self.ctrl, self.n_env, device=device)
         self.device = self.sim.device
         thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
-        if cfg.env_term_body != "body":
-            raise NotImplementedError("env_term_body other than 'body' is a later row (SURVEY.md 8f-4)")
+        if cfg.env_term_body not in ("body", "root"):
+            raise NotImplementedError("env_term_body 'body' and 'root' are built ('Head' reads expert['head_height_lb'], which the reference never sets)")
         reward_v = REWARD_IDS.get(cfg.reward_id)
         if reward_v is None:
             raise NotImplementedError(f"reward_id {cfg.reward_id!r}: built are {sorted(REWARD_IDS)} (the local_rfc_* rewards are not)")
@@ -60,7 +60,7 @@ class VecHumanoidEnv:
             raise NotImplementedError("obs_coord 'root' (every reference config) and, for obs_v >= 1, obs_vel 'full' are built")
         self.n_reward_parts = REWARD_PARTS[reward_v]
         self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, obs_heading=cfg.obs_heading, root_deheading=cfg.root_deheading,
-                                                 obs_phase=cfg.obs_phase, obs_vel=cfg.obs_vel, fut_frames=cfg.get("fut_frames", 10), fut_skip=cfg.get("skip", 10), has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
+                                                 obs_phase=cfg.obs_phase, obs_vel=cfg.obs_vel, env_term_body=cfg.env_term_body, fut_frames=cfg.get("fut_frames", 10), fut_skip=cfg.get("skip", 10), has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
                                                  env_episode_len=cfg.env_episode_len, env_expert_trail_steps=cfg.env_expert_trail_steps,
                                                  body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
                                                  jpos_diffw=self.converter.get_new_diff_weight()))
