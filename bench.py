@@ -58,6 +58,7 @@ def parse():
     p.add_argument("--clips", type=int, default=64, help="synthetic clips per rank")
     p.add_argument("--ppo-dtype", default="float64", choices=["float64", "float32"])
     p.add_argument("--pgs-iterations", type=int, default=None, help="sweep cap of the contact solve (default: the config's, 300 = converged)")
+    p.add_argument("--solver", type=int, default=None, choices=[0, 1], help="contact solver: 0 PGS sweeps, 1 exact active-set solve (default: the config's)")
     p.add_argument("--shapes", type=int, default=0, help="configs[3] (smpl_shape): K randomised body shapes, every clip runs on one of them")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
@@ -160,6 +161,8 @@ def main():
     cfg.n_env = args.envs
     if args.pgs_iterations:
         cfg.pgs_iterations = args.pgs_iterations
+    if args.solver is not None:
+        cfg.contact_solver = args.solver
     cfg.no_log = True
     specs = dict(cfg.data_specs)
     specs["file_path"] = "synthetic"

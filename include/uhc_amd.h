@@ -40,7 +40,10 @@ typedef struct UhcModelDesc {
     int32_t nq, nv, nu, nbody, njnt, ngeom, nmeshvert, nmeshadj, nexclude;
     int32_t iterations;        /* solver sweeps cap (MuJoCo opt.iterations, default 100) */
     int32_t plane_mesh_maxcon; /* max contacts a plane-mesh pair may emit */
-    int32_t _pad;
+    int32_t solver;            /* contact solve of the dual QP  min 1/2 f'Af + f'b, f >= 0:
+                                * 0 = projected Gauss-Seidel sweeps up to `iterations` / `tolerance` ([MJ-ext] mj_solPGS);
+                                * 1 = the same QP solved to its exact optimum by active-set iterations (block principal pivoting:
+                                *     factor the free block, flip every infeasible row); envs with friction-loss rows use 0 */
     double timestep, tolerance, meaninertia;
     double gravity[3];
     /* bodies [nbody] */
@@ -109,7 +112,9 @@ enum UhcField {
     UHC_F_SOLVER_ITER = 12, /* int32 [n_env] PGS sweeps used by the last solve */
     UHC_F_QFRC_APPLIED = 13, /* [n_env][nv] data.qfrc_applied of the last substep */
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
-    UHC_F_STAGE_PROF = 15    /* int64 [n_env][32] per-stage shader-cycle counters (profiling builds only) */
+    UHC_F_STAGE_PROF = 15,   /* int64 [n_env][32] per-stage shader-cycle counters (profiling builds only) */
+    UHC_F_REDO = 16          /* int32 [n_env] 1: the env's last step / forward pass exceeded the fast kernel's capacity (64 rows, 16 contacts,
+                              * packed row storage) and was computed by the general kernel -- which always runs solver 0 (sweeps) */
 };
 
 const char* uhc_last_error(void);

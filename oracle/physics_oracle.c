@@ -695,6 +695,86 @@ void orc_solve_pgs(const UhcModelDesc* m, OrcData* d) {
     for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
 }
 
+/* Exact solve of the same dual QP (UhcModelDesc.solver == 1; NOT a MuJoCo algorithm -- MuJoCo's exact solver is Newton on the
+ * primal, which reaches the same optimum): block principal pivoting (Judice & Pires 1994; Kim & Park 2011 for NNLS).
+ * F = rows allowed a positive force.  Solve A_FF f_F = -b_F, f = 0 elsewhere, y = A f + b; a row is infeasible when
+ * f < 0 (in F) or y < 0 (outside F).  Flip all infeasible rows while their number keeps falling (3 grace rounds), otherwise
+ * only the highest-index one (finite for symmetric positive definite A).  Start: F = {b < 0}.
+ * The elimination works on the whole nefc x nefc matrix with the rows outside F replaced by identity rows, in the order
+ * k = 0 .. nefc-1 and without pivoting -- the same order the device kernel uses. */
+#define ORC_AS_MAXIT 64
+static int solve_masked(int n, const double* A, const double* b, const unsigned char* F, double* W, double* f) {
+    /* Gaussian elimination on [A_FF | -b_F], rows / columns outside F skipped; back substitution */
+    double* c = W + (size_t)n * n;
+    for (int i = 0; i < n; i++) { memcpy(W + (size_t)i * n, A + (size_t)i * n, n * 8); c[i] = -b[i]; }
+    for (int k = 0; k < n; k++) {
+        if (!F[k]) continue;
+        double piv = W[(size_t)k * n + k];
+        if (!(piv > MINVAL)) return 1;
+        for (int i = k + 1; i < n; i++) {
+            if (!F[i]) continue;
+            double l = W[(size_t)i * n + k] / piv;
+            for (int j = k + 1; j < n; j++) W[(size_t)i * n + j] -= l * W[(size_t)k * n + j];
+            c[i] -= l * c[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        if (!F[k]) { f[k] = 0; continue; }
+        double a = c[k];
+        for (int j = k + 1; j < n; j++) if (F[j]) a -= W[(size_t)k * n + j] * f[j];
+        f[k] = a / W[(size_t)k * n + k];
+    }
+    return 0;
+}
+int orc_solve_active_set(const UhcModelDesc* m, OrcData* d) {
+    int nv = m->nv, n = d->nefc;
+    const double* A = d->efc_AR;
+    double* f = d->efc_force;
+    unsigned char F[ORC_MAXEFC];
+    double* W = (double*)malloc(((size_t)n * n + n) * 8);
+    double* y = (double*)malloc((size_t)n * 8);
+    for (int r = 0; r < n; r++) F[r] = d->efc_b[r] < 0;
+    int grace = 3, best = n + 1, it = 0, ok = 0;
+    for (; it < ORC_AS_MAXIT; it++) {
+        if (solve_masked(n, A, d->efc_b, F, W, f)) break;
+        int nbad = 0, last = -1;
+        for (int r = 0; r < n; r++) {
+            double a = d->efc_b[r];
+            for (int s = 0; s < n; s++) a += A[(size_t)r * n + s] * f[s];
+            y[r] = a;
+            int badr = F[r] ? f[r] < 0 : a < 0;
+            if (badr) { nbad++; last = r; }
+        }
+        if (nbad == 0) { ok = 1; it++; break; }
+        int all = 1;
+        if (nbad < best) { best = nbad; grace = 3; }
+        else if (grace > 0) grace--;
+        else all = 0;
+        for (int r = 0; r < n; r++) {
+            int badr = F[r] ? f[r] < 0 : y[r] < 0;
+            if (badr && (all || r == last)) F[r] = !F[r];
+        }
+    }
+    free(W); free(y);
+    d->solver_iter = it;
+    if (!ok) return 1;
+    for (int i = 0; i < nv; i++) {
+        double a = 0;
+        for (int r = 0; r < n; r++) a += d->efc_J[(size_t)r * nv + i] * f[r];
+        d->qfrc_constraint[i] = a;
+        d->qacc[i] = a;
+    }
+    orc_solve_sparse(m, d->qLD, d->qacc);
+    for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
+    return 0;
+}
+static void orc_solve_constraints(const UhcModelDesc* m, OrcData* d) {
+    int fric = 0;
+    for (int r = 0; r < d->nefc; r++) fric |= d->efc_type[r] == ORC_EFC_FRICTION;
+    if (m->solver == 1 && d->nefc > 0 && !fric && !orc_solve_active_set(m, d)) return;
+    orc_solve_pgs(m, d);  /* solver 0, friction-loss rows (box constraints), or no convergence within ORC_AS_MAXIT factorisations */
+}
+
 /* ------------------------------------------------------------------ mj_forward / mj_step [MJ-ext] */
 void orc_forward(const UhcModelDesc* m, OrcData* d) {
     orc_kinematics(m, d);
@@ -710,7 +790,7 @@ void orc_forward(const UhcModelDesc* m, OrcData* d) {
     orc_rne_bias(m, d);
     orc_fwd_acceleration(m, d);
     orc_project_constraint(m, d);
-    orc_solve_pgs(m, d);
+    orc_solve_constraints(m, d);
 }
 static int bad(double x) { return isnan(x) || x > MAXVAL || x < -MAXVAL; }
 void orc_euler(const UhcModelDesc* m, OrcData* d) { /* P10: mj_Euler (no joint damping -> explicit in qacc) */

@@ -84,14 +84,19 @@ def test_free_flight_trajectory(model, ctrl, standing):
         np.testing.assert_allclose(gv[e], os_[e].get("qvel"), atol=1e-7)
 
 
-@pytest.mark.parametrize("sweep_cap", [100, 300])
-def test_contact_trajectory_200_steps(model, ctrl, standing, sweep_cap):
+@pytest.mark.parametrize("sweep_cap", [100, 300, "exact"])
+def test_contact_trajectory_200_steps(model, ctrl, standing, sweep_cap, kernel_path):
     """north_star bar: per-step qpos/qvel within 1e-4 of the CPU path over 200 env-steps, same seed.  With MuJoCo's default cap of
     100 sweeps both sides run the same number of sweeps; at 300 (the package default: converged) the
     tolerance test decides, and the two implementations may stop a sweep apart."""
     import dataclasses
     import torch
-    model = dataclasses.replace(model, iterations=sweep_cap)
+    if sweep_cap == "exact":  # solver 1: the QP's exact optimum by active-set iterations on both sides (fast kernel only)
+        if kernel_path == "general":
+            pytest.skip("the general kernel always sweeps")
+        model = dataclasses.replace(model, solver=1)
+    else:
+        model = dataclasses.replace(model, iterations=sweep_cap)
     from oracle.physics import OracleSim
     from uhc_amd import sim as S
     n = 4
@@ -104,17 +109,53 @@ def test_contact_trajectory_200_steps(model, ctrl, standing, sweep_cap):
     for e in range(n):
         os_[e].set_state(qpos[e], qvel[e])
     worst_q = worst_v = 0.0
+    redone = 0
     for t in range(200):
         act = rng.normal(scale=0.05, size=(n, ctrl.action_dim))
         b.simulate(torch.from_numpy(act).cuda(), tb)
         b.sync()
         gq, gv = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy() if sweep_cap == "exact" else np.zeros(n, dtype=int)
         for e in range(n):
+            # solver 1 covers the fast kernel; a step beyond its capacity is computed by the general kernel's sweeps (UHC_F_REDO)
+            os_[e].desc.solver = 0 if (sweep_cap != "exact" or redo[e]) else 1
+            redone += int(redo[e])
             os_[e].do_simulation(act[e], qpos[e, 7:])
             worst_q = max(worst_q, np.abs(gq[e] - os_[e].get("qpos")).max())
             worst_v = max(worst_v, np.abs(gv[e] - os_[e].get("qvel")).max())
-    print(f"200-step parity: max|dqpos|={worst_q:.3e} max|dqvel|={worst_v:.3e}")
+    print(f"200-step parity: max|dqpos|={worst_q:.3e} max|dqvel|={worst_v:.3e} (env-steps through the general kernel: {redone})")
     assert worst_q < 1e-4 and worst_v < 1e-4
+
+
+def test_exact_solver_forward(model, ctrl, standing, kernel_path):
+    """solver 1 (active-set / block principal pivoting): the constrained acceleration equals the oracle's exact optimum far below
+    the sweep tolerance, within a handful of factorisations, and differs from the 100-sweep PGS answer."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    if kernel_path == "general":
+        pytest.skip("the general kernel always sweeps")
+    mx = dataclasses.replace(model, solver=1)
+    n = 32
+    qpos, qvel = _states(standing, model, n, 21)
+    b = _sim(mx, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    b.sync()
+    gacc, git, gn = b.field(S.F_QACC).cpu().numpy(), b.field(S.F_SOLVER_ITER).cpu().numpy(), b.field(S.F_NEFC).cpu().numpy()
+    moved = 0
+    for e in range(n):
+        o = OracleSim(mx, ctrl)
+        o.set_state(qpos[e], qvel[e])
+        assert gn[e] == o.geti("nefc")
+        np.testing.assert_allclose(gacc[e], o.get("qacc"), atol=1e-8, rtol=1e-9)
+        if gn[e]:
+            assert 1 <= git[e] <= 12 and abs(int(git[e]) - o.geti("solver_iter")) <= 1
+        p = OracleSim(model, ctrl)
+        p.set_state(qpos[e], qvel[e])
+        moved += np.abs(p.get("qacc") - o.get("qacc")).max() > 1e-6
+    assert moved > 0  # the tolerance-terminated sweeps stop measurably short of the optimum
+    b.close()
 
 
 def test_explicit_rfc_trajectory(model, standing):

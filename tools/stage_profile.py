@@ -12,7 +12,7 @@ PROF_LIB = os.path.join(CSRC, "libuhc_amd_prof.so")
 NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "smooth", "collision", "rows", "A-build",
          "pgs-sweeps", "z+rest/pgs-general", "qacc-solve", "euler", "store",
          "pd: M->LD + gains", "pd: factor", "pd: solve", "kin: pass 1 (local poses)", "kin: pass 2 (levels)", "crb: subtree sums", "crb: I*cdof",
-         "rne: levels", "pd: M -> LD", "s25", "s26", "s27", "s28", "s29", "s30", "s31"]
+         "rne: levels", "pd: M -> LD", "as: W load (+loop tail)", "as: elimination", "as: back substitution", "as: y = A f + b", "s29", "s30", "s31"]
 
 
 def build():
@@ -34,7 +34,8 @@ if __name__ == "__main__":
     from uhc_amd import sim as S
     n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    model = S.load_asset_model()
+    import dataclasses
+    model = dataclasses.replace(S.load_asset_model(), solver=int(os.environ.get("SOLVER", "0")), iterations=int(os.environ.get("CAP", "100")))
     ctrl = S.make_ctrl(model)
     z = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))
     rng = np.random.default_rng(1)

@@ -10,7 +10,7 @@ _I32P = C.POINTER(C.c_int32)
 _F64P = C.POINTER(C.c_double)
 
 _MODEL_INT_SCALARS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nmeshvert", "nmeshadj", "nexclude",
-                      "iterations", "plane_mesh_maxcon", "_pad"]
+                      "iterations", "plane_mesh_maxcon", "solver"]
 _MODEL_PTRS = [
     ("body_parentid", "i"), ("body_jntadr", "i"), ("body_jntnum", "i"), ("body_dofadr", "i"), ("body_dofnum", "i"),
     ("body_pos", "d"), ("body_quat", "d"), ("body_ipos", "d"), ("body_iquat", "d"),
@@ -50,8 +50,7 @@ def model_desc(model) -> UhcModelDesc:
     d = UhcModelDesc()
     keep: List[np.ndarray] = []
     for n in _MODEL_INT_SCALARS:
-        if n != "_pad":
-            setattr(d, n, int(getattr(model, n)))
+        setattr(d, n, int(getattr(model, n, 0)))
     d.timestep, d.tolerance, d.meaninertia = float(model.timestep), float(model.tolerance), float(model.meaninertia)
     d.gravity = (C.c_double * 3)(*[float(x) for x in model.gravity])
     for n, t in _MODEL_PTRS:

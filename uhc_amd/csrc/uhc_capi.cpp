@@ -119,8 +119,8 @@ struct UhcBatch {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
     int n_models = 1;
     // field table
-    void* field_ptr[16] = {nullptr};
-    int64_t field_count[16] = {0};
+    void* field_ptr[17] = {nullptr};
+    int64_t field_count[17] = {0};
 };
 
 template <class T>
@@ -207,7 +207,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const int nb = d.nbody, nv = d.nv, nj = d.njnt, ng = d.ngeom;
     T.nq = d.nq; T.nv = nv; T.nu = d.nu; T.nbody = nb; T.njnt = nj; T.ngeom = ng; T.nmeshvert = d.nmeshvert;
     T.nM = d.dof_madr[nv];
-    T.iterations = d.iterations; T.plane_mesh_maxcon = d.plane_mesh_maxcon;
+    T.iterations = d.iterations; T.plane_mesh_maxcon = d.plane_mesh_maxcon; T.solver = d.solver;
     T.timestep = d.timestep; T.tolerance = d.tolerance;
     for (int k = 0; k < 3; k++) T.gravity[k] = d.gravity[k];
     b->nM = T.nM;
@@ -479,11 +479,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         HIP_OK(hipMemcpy(S.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     void* fp[] = {S.qpos, S.qvel, S.xpos, S.xquat, S.xipos, S.qM, S.bias, S.qacc, S.ctrl, S.ncon, S.nefc, S.fail,
-                  S.solver_iter, S.applied, S.overflow, S.prof};
+                  S.solver_iter, S.applied, S.overflow, S.prof, S.redo};
     int64_t fc[] = {(int64_t)E * d.nq, (int64_t)E * nv, (int64_t)E * 3 * nb, (int64_t)E * 4 * nb, (int64_t)E * 3 * nb,
                     (int64_t)E * T.nM, (int64_t)E * nv, (int64_t)E * nv, (int64_t)E * d.nu, (int64_t)E, (int64_t)E, (int64_t)E,
-                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 32};
-    for (int k = 0; k < 16; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
+                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 32, (int64_t)E};
+    for (int k = 0; k < 17; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
     HIP_OK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     b->stream = b->own_stream;
     *out = b;
@@ -516,7 +516,7 @@ extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {
     return 0;
 }
 extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n) {
-    if (!b || f < 0 || f > 15 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
+    if (!b || f < 0 || f > 16 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
     if (p) *p = b->field_ptr[f];
     if (n) *n = b->field_count[f];
     return 0;

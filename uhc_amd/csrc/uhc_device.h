@@ -14,7 +14,7 @@
 
 // topology + options: identical for every env of a batch
 struct DevTopo {
-    int nq, nv, nu, nbody, njnt, ngeom, nM, maxdepth, nmeshvert, npair, iterations, plane_mesh_maxcon;
+    int nq, nv, nu, nbody, njnt, ngeom, nM, maxdepth, nmeshvert, npair, iterations, plane_mesh_maxcon, solver;
     double timestep, tolerance;
     double gravity[3];
     const int *body_parentid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_rootid, *body_nsub,

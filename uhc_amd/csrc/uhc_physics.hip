@@ -1318,6 +1318,97 @@ __device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, d
     return iters;
 }
 
+// Exact solve of the dual QP  min 1/2 f'Af + f'b, f >= 0  by block principal pivoting (UhcModelDesc.solver == 1; the oracle's
+// orc_solve_active_set is the same algorithm).  F = rows allowed a positive force, start F = {b < 0}.  One iteration:
+//   1. W <- A (from the AGPR-parked rows), c <- -b; Gaussian elimination over the steps k in F, lane = row: the pivot row k is
+//      broadcast entry by entry (two v_readlane each), every row i > k of F subtracts l_ik times it.  Rows outside F keep l = 0,
+//      i.e. behave as identity rows; their columns are updated but never read.  No pivoting (A_FF is positive definite).
+//   2. back substitution with the pivots' reciprocals kept by their lanes: f_k = (c_k - sum_{j>k in F} U_kj f_j) / U_kk, f = 0 outside F;
+//   3. y = A f + b; a row is infeasible if f < 0 (inside F) or y < 0 (outside); none -> optimum (KKT holds exactly);
+//   4. flip all infeasible rows while their count keeps falling (three grace rounds), else only the highest one (finite).
+// Everything is unrolled over static register indices; a step whose row is not in F, and column chunks beyond nefc, are skipped
+// by uniform branches.  Returns the number of factorisations, or -1 (pivot breakdown / no convergence: the caller runs the sweeps).
+#define UHC_AS_MAXIT 64
+__device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&Ahi)[UHC_WAVE], int nefc, double b, double& f_out PROF_ARGS) {
+    const bool valid = LANE < nefc;
+    bool inF = valid && b < 0.0;
+    int best = nefc + 1, grace = 3;
+    double f = 0.0;
+    for (int it = 1; it <= UHC_AS_MAXIT; it++) {
+        const unsigned long long Fm = __builtin_amdgcn_ballot_w64(inF);
+        double W[UHC_WAVE];
+        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            W[s] = __hiloint2double(agpr_get(Ahi[s]), agpr_get(Alo[s]));
+        });
+        PROF(25)
+        double c = -b, mypinv = 0.0;
+        bool broke = false;
+        int ln = LANE;
+        asm volatile("" : "+v"(ln));  // opaque per iteration: keeps the 64 (lane > k) masks from being hoisted into (spilled) SGPR pairs
+        // the membership tests are scalar bit tests of a mask copy that is opaque per loop: shared across the three loops the compiler
+        // turns them into 64 lane-mask booleans, spills those to VGPR lanes and reloads one per step
+        unsigned long long Fe = Fm;
+        asm volatile("" : "+s"(Fe));
+        static_for<0, UHC_WAVE>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if ((Fe >> k) & 1ull) {
+                const double pk = bcast(W[k], k);
+                broke |= !(pk > UHC_MINVAL);
+                double pinv = __builtin_amdgcn_rcp(pk);  // + two Newton steps: full precision without the division's scale / fixup sequence
+                pinv = fma(fma(-pk, pinv, 1.0), pinv, pinv);
+                pinv = fma(fma(-pk, pinv, 1.0), pinv, pinv);
+                mypinv = ln == k ? pinv : mypinv;
+                const double l = (ln > k && inF) ? W[k] * pinv : 0.0;
+                c = fma(-l, bcast(c, k), c);
+                static_for<(k + 1) / 8, UHC_WAVE / 8>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int ch = decltype(cc)::value;
+                    if (8 * ch < nefc) {
+                        static_for<(8 * ch > k + 1 ? 8 * ch : k + 1), 8 * ch + 8>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            W[j] = fma(-l, bcast(W[j], k), W[j]);  // (an LDS round trip of the pivot row instead of the readlanes is 2x slower)
+                        });
+                    }
+                });
+            }
+        });
+        if (broke) return -1;
+        PROF(26)
+        double acc = c;
+        f = 0.0;
+        unsigned long long Fb = Fm;
+        asm volatile("" : "+s"(Fb));
+        static_for<0, UHC_WAVE>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = UHC_WAVE - 1 - decltype(kc)::value;
+            if ((Fb >> k) & 1ull) {
+                const double xk = bcast(acc * mypinv, k);
+                f = ln == k ? xk : f;
+                acc = fma(-W[k], xk, acc);
+            }
+        });
+        PROF(27)
+        double y = b;
+        unsigned long long Fy = Fm;
+        asm volatile("" : "+s"(Fy));
+        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            if ((Fy >> s) & 1ull) y = fma(__hiloint2double(agpr_get(Ahi[s]), agpr_get(Alo[s])), bcast(f, s), y);
+        });
+        PROF(28)
+        const bool bad = valid && (inF ? f < 0.0 : y < 0.0);
+        const unsigned long long Bm = __builtin_amdgcn_ballot_w64(bad);
+        if (Bm == 0ull) { f_out = f; return it; }
+        const int nbad = __builtin_popcountll(Bm);
+        bool all = true;
+        if (nbad < best) { best = nbad; grace = 3; }
+        else if (grace > 0) grace--;
+        else all = false;
+        const int last = 63 - __builtin_clzll(Bm);
+        if (bad && (all || LANE == last)) inF = !inF;
+    }
+    return -1;
+}
+
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
 __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM] PROF_ARGS) {
     const DevTopo& T = A.t;
@@ -1382,6 +1473,14 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     });
     if (!valid) diag = 1.0;
     PROF(10)
+    const bool any_fric = wave_or(row.type == ROW_FRICTION ? 1 : 0) != 0;
+    int iters = -1;
+    if (T.solver == 1 && !any_fric) {
+        double fx = 0.0;
+        iters = as_solve(Alo, Ahi, nefc, valid ? row.b : 0.0, fx PROF_PASS);
+        if (iters > 0) row.f = fx;
+    }
+    if (iters < 0) {
     double Arow[UHC_WAVE];
     static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
@@ -1406,8 +1505,6 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     const double rb = valid ? row.b : 0.0;
     const double scale = 1.0 / (mb[A.o.meaninertia] * (T.nv > 1 ? T.nv : 1));
     const bool fric = row.type == ROW_FRICTION;
-    const bool any_fric = wave_or(fric ? 1 : 0) != 0;
-    int iters;
     if (any_fric) iters = pgs_sweeps<UHC_WAVE, true>(Arow, f, w, diag, rb, fric, row.floss, T.iterations, scale, T.tolerance);
     else switch ((nefc + 7) >> 3) {
         case 1: iters = pgs_sweeps<8, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
@@ -1420,6 +1517,8 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         default: iters = pgs_sweeps<64, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
     }
     row.f = f;
+    }
+    const double f = row.f;
     PROF(11)
     // ---- z = sum_r f_r Yhat_r for qacc = qacc_smooth + L^-1 D^-1/2 z: every row scatters its <= 31 chain entries into the
     //      per-dof accumulators with LDS float64 atomics (rows of one body hit the same addresses; the LDS unit serialises them)

@@ -36,7 +36,7 @@ class VecHumanoidEnv:
         self.model = model if model is not None else S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh"))
         self.models = [self.model] + list(shape_models or [])
         iters = int(getattr(cfg, "pgs_iterations", 300))
-        self.models = [dataclasses.replace(m, iterations=iters) for m in self.models]
+        self.models = [dataclasses.replace(m, iterations=iters, solver=int(getattr(cfg, "contact_solver", 0))) for m in self.models]
         self.model = self.models[0]
         self.base_rot = cfg.data_specs.get("base_rot", [0.7071, 0.7071, 0.0, 0.0])
         self.rfc_rate = 1 if not cfg.rfc_decay else 0

@@ -187,6 +187,7 @@ class Model:
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
     iterations: int = 100
+    solver: int = 0  # 0: PGS sweeps (MuJoCo's mj_solPGS), 1: exact active-set solve of the same QP (include/uhc_amd.h)
     tolerance: float = 1e-8
     meaninertia: float = 1.0
     plane_mesh_maxcon: int = 4

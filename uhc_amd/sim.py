@@ -12,8 +12,8 @@ from ._capi import UhcCtrlDesc, UhcEnvDesc, model_desc
 from ._lib import check, lib
 
 F_QPOS, F_QVEL, F_XPOS, F_XQUAT, F_XIPOS, F_QM, F_QFRC_BIAS, F_QACC, F_CTRL = range(9)
-F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF = range(9, 16)
-_INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW}
+F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF, F_REDO = range(9, 17)
+_INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW, F_REDO}
 
 
 class _DevView:

@@ -90,6 +90,8 @@ class Config(Base_Config):
         # model, and stopping at 100 leaves a trajectory error of ~5e-3 over 200 control steps against the converged
         # solution (1e-7 at 300): DESIGN.md section 2
         self.pgs_iterations = g("pgs_iterations", 300)
+        # 0: PGS sweeps; 1: the same QP solved to its exact optimum by active-set iterations (include/uhc_amd.h, UhcModelDesc.solver)
+        self.contact_solver = g("contact_solver", 0)
         self.n_env = g("n_env", 1024)
         self.ppo_dtype = g("ppo_dtype", "float64")
 
