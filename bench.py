@@ -246,7 +246,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
-                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
+                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "contact_solver": ("active-set (exact optimum of the dual QP; envs beyond the fast kernel's capacity fall back to sweeps)" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, false>" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
@@ -259,7 +259,7 @@ def main():
                          "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
                                  "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
                                  "above the algorithmic bytes is the L2-resident schedule tables and the per-substep mass-matrix work row"},
-            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "pgs_iters_mean": float(iters.mean()),
+            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int(env.sim.field(S.F_REDO).sum().item()),
                                "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
                                "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
                                "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17])[0].tolist(),

@@ -1329,6 +1329,9 @@ __device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, d
 // Everything is unrolled over static register indices; a step whose row is not in F, and column chunks beyond nefc, are skipped
 // by uniform branches.  Returns the number of factorisations, or -1 (pivot breakdown / no convergence: the caller runs the sweeps).
 #define UHC_AS_MAXIT 64
+// NC = nefc rounded up to 8: the unrolled loops stop there.  (Testing the column range at run time instead -- a uniform branch per
+// chunk of 8 columns -- costs ~70 cycles per branch with one wave per SIMD, 40% of the elimination: tools/ubench/elim.hip.)
+template <int NC>
 __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&Ahi)[UHC_WAVE], int nefc, double b, double& f_out PROF_ARGS) {
     const bool valid = LANE < nefc;
     bool inF = valid && b < 0.0;
@@ -1336,8 +1339,8 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
     double f = 0.0;
     for (int it = 1; it <= UHC_AS_MAXIT; it++) {
         const unsigned long long Fm = __builtin_amdgcn_ballot_w64(inF);
-        double W[UHC_WAVE];
-        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+        double W[NC];
+        static_for<0, NC>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             W[s] = __hiloint2double(agpr_get(Ahi[s]), agpr_get(Alo[s]));
         });
@@ -1345,12 +1348,12 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
         double c = -b, mypinv = 0.0;
         bool broke = false;
         int ln = LANE;
-        asm volatile("" : "+v"(ln));  // opaque per iteration: keeps the 64 (lane > k) masks from being hoisted into (spilled) SGPR pairs
+        asm volatile("" : "+v"(ln));  // opaque per iteration: keeps the (lane > k) masks from being hoisted into (spilled) SGPR pairs
         // the membership tests are scalar bit tests of a mask copy that is opaque per loop: shared across the three loops the compiler
-        // turns them into 64 lane-mask booleans, spills those to VGPR lanes and reloads one per step
+        // turns them into lane-mask booleans, spills those to VGPR lanes and reloads one per step
         unsigned long long Fe = Fm;
         asm volatile("" : "+s"(Fe));
-        static_for<0, UHC_WAVE>([&](auto kc) __attribute__((always_inline)) {
+        static_for<0, NC>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             if ((Fe >> k) & 1ull) {
                 const double pk = bcast(W[k], k);
@@ -1361,14 +1364,9 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
                 mypinv = ln == k ? pinv : mypinv;
                 const double l = (ln > k && inF) ? W[k] * pinv : 0.0;
                 c = fma(-l, bcast(c, k), c);
-                static_for<(k + 1) / 8, UHC_WAVE / 8>([&](auto cc) __attribute__((always_inline)) {
-                    constexpr int ch = decltype(cc)::value;
-                    if (8 * ch < nefc) {
-                        static_for<(8 * ch > k + 1 ? 8 * ch : k + 1), 8 * ch + 8>([&](auto jc) __attribute__((always_inline)) {
-                            constexpr int j = decltype(jc)::value;
-                            W[j] = fma(-l, bcast(W[j], k), W[j]);  // (an LDS round trip of the pivot row instead of the readlanes is 2x slower)
-                        });
-                    }
+                static_for<k + 1, NC>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    W[j] = fma(-l, bcast(W[j], k), W[j]);  // (an LDS round trip of the pivot row instead of the readlanes is 2x slower)
                 });
             }
         });
@@ -1378,8 +1376,8 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
         f = 0.0;
         unsigned long long Fb = Fm;
         asm volatile("" : "+s"(Fb));
-        static_for<0, UHC_WAVE>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = UHC_WAVE - 1 - decltype(kc)::value;
+        static_for<0, NC>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = NC - 1 - decltype(kc)::value;
             if ((Fb >> k) & 1ull) {
                 const double xk = bcast(acc * mypinv, k);
                 f = ln == k ? xk : f;
@@ -1390,7 +1388,7 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
         double y = b;
         unsigned long long Fy = Fm;
         asm volatile("" : "+s"(Fy));
-        static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
+        static_for<0, NC>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             if ((Fy >> s) & 1ull) y = fma(__hiloint2double(agpr_get(Ahi[s]), agpr_get(Alo[s])), bcast(f, s), y);
         });
@@ -1477,7 +1475,17 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     int iters = -1;
     if (T.solver == 1 && !any_fric) {
         double fx = 0.0;
-        iters = as_solve(Alo, Ahi, nefc, valid ? row.b : 0.0, fx PROF_PASS);
+        const double bq = valid ? row.b : 0.0;
+        switch ((nefc + 7) >> 3) {
+            case 1: iters = as_solve<8>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            case 2: iters = as_solve<16>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            case 3: iters = as_solve<24>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            case 4: iters = as_solve<32>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            case 5: iters = as_solve<40>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            case 6: iters = as_solve<48>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            case 7: iters = as_solve<56>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+            default: iters = as_solve<64>(Alo, Ahi, nefc, bq, fx PROF_PASS); break;
+        }
         if (iters > 0) row.f = fx;
     }
     if (iters < 0) {

@@ -85,13 +85,13 @@ class Config(Base_Config):
             self.jpos_diffw = np.concatenate([[1], self.b_diffw])
         self.agent_name, self.model_name = g("agent_name", "agent_copycat"), g("model_name", "super_net")
         # batched-env knobs of this build (not in the reference)
-        # sweep cap of the PGS contact solve.  The reference runs MuJoCo's Newton solver, which reaches its 1e-8 tolerance
-        # within `iterations` = 100; Gauss-Seidel needs ~150 sweeps on average (up to ~400) for the same tolerance on this
-        # model, and stopping at 100 leaves a trajectory error of ~5e-3 over 200 control steps against the converged
-        # solution (1e-7 at 300): DESIGN.md section 2
+        # contact solve of the dual QP (UhcModelDesc.solver).  1 (default): its exact optimum by active-set iterations (block principal
+        # pivoting, ~3 factorisations of the free block) -- what the reference's Newton solver converges to; envs beyond the fast
+        # kernel's capacity are solved by sweeps.  0: projected Gauss-Seidel sweeps as MuJoCo's PGS, capped at pgs_iterations:
+        # ~140 sweeps on average (up to ~400) reach the 1e-8 tolerance on this model, which still leaves the forces ~1e-4 (relative)
+        # from the optimum; stopping at MuJoCo's default 100 leaves ~5e-3 of trajectory error over 200 control steps
+        self.contact_solver = g("contact_solver", 1)
         self.pgs_iterations = g("pgs_iterations", 300)
-        # 0: PGS sweeps; 1: the same QP solved to its exact optimum by active-set iterations (include/uhc_amd.h, UhcModelDesc.solver)
-        self.contact_solver = g("contact_solver", 0)
         self.n_env = g("n_env", 1024)
         self.ppo_dtype = g("ppo_dtype", "float64")
 
