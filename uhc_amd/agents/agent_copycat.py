@@ -48,6 +48,7 @@ class AgentCopycat(AgentPPO):
         self.max_freq = 50
         self.epoch = 0
         self.precision_mode = cfg.get("precision_mode", False)
+        self.fit_single_key = ""  # scripts/fit_uhc.py: sample every window from this one clip (agent_copycat.py:102, :504-510)
         self.setup_data_loader(data_loader)
         self.setup_env()
         self.setup_policy()
@@ -148,6 +149,14 @@ class AgentCopycat(AgentPPO):
     def save_curr(self):
         pickle.dump(self._cp(), open(f"{self.cfg.model_dir}/iter_best.p", "wb"))
 
+    def save_singles(self, epoch, key):  # agent_copycat.py:203-214
+        os.makedirs(f"{self.cfg.model_dir}_singles", exist_ok=True)
+        pickle.dump(self._cp(), open(f"{self.cfg.model_dir}_singles/{key}.p", "wb"))
+
+    def load_singles(self, epoch, key):  # agent_copycat.py:238-247
+        if epoch > 0:
+            self._load(f"{self.cfg.model_dir}/iter_{(epoch + 1):04d}_{key}.p")
+
     def _load(self, path):
         self.logger.info("loading model from checkpoint: %s" % path)
         cp = CustomUnpickler(open(path, "rb")).load()
@@ -166,6 +175,14 @@ class AgentCopycat(AgentPPO):
     # ---- clip sampling hooks used by the vectorised rollout ----------------------------------------------------
     def _sample_windows(self, n):
         cfg, dl = self.cfg, self.data_loader
+        if self.fit_single_key != "":  # single-clip fitting: every window comes from one clip (agent_copycat.py:504-510)
+            keys, fs, fe = [], [], []
+            for _ in range(n):
+                dl.get_sample_from_key(self.fit_single_key, full_sample=False, freq_dict=self.freq_dict, precision_mode=self.precision_mode)
+                keys.append(dl.curr_key)
+                fs.append(dl.fr_start)
+                fe.append(dl.fr_end)
+            return keys, fs, fe
         if self.precision_mode:  # per-draw path of the reference (window near a recorded failure)
             keys, fs, fe = [], [], []
             for _ in range(n):
@@ -369,5 +386,11 @@ class CustomUnpickler(pickle.Unpickler):
         return super().find_class(module, name)
 
 
+def _eval_seq(self, take_key, loader):
+    """One clip, first frame to last, mean action (agent_copycat.py:438-494): the result dict of that clip."""
+    return self.eval_seqs([take_key], loader)[take_key]
+
+
 AgentCopycat.eval_policy = _eval_policy
 AgentCopycat.eval_seqs = _eval_seqs
+AgentCopycat.eval_seq = _eval_seq
