@@ -699,10 +699,11 @@ void orc_solve_pgs(const UhcModelDesc* m, OrcData* d) {
  * primal, which reaches the same optimum): block principal pivoting (Judice & Pires 1994; Kim & Park 2011 for NNLS).
  * F = rows allowed a positive force.  Solve A_FF f_F = -b_F, f = 0 elsewhere, y = A f + b; a row is infeasible when
  * f < 0 (in F) or y < 0 (outside F).  Flip all infeasible rows while their number keeps falling (3 grace rounds), otherwise
- * only the highest-index one (finite for symmetric positive definite A).  Start: F = {b < 0}.
+ * only the highest-index one (finite for symmetric positive definite A).  Start: F = the rows with a force after 8 sweeps.
  * The elimination works on the whole nefc x nefc matrix with the rows outside F replaced by identity rows, in the order
  * k = 0 .. nefc-1 and without pivoting -- the same order the device kernel uses. */
 #define ORC_AS_MAXIT 64
+#define ORC_AS_PRESWEEPS 8
 static int solve_masked(int n, const double* A, const double* b, const unsigned char* F, double* W, double* f) {
     /* Gaussian elimination on [A_FF | -b_F], rows / columns outside F skipped; back substitution */
     double* c = W + (size_t)n * n;
@@ -733,7 +734,16 @@ int orc_solve_active_set(const UhcModelDesc* m, OrcData* d) {
     unsigned char F[ORC_MAXEFC];
     double* W = (double*)malloc(((size_t)n * n + n) * 8);
     double* y = (double*)malloc((size_t)n * 8);
-    for (int r = 0; r < n; r++) F[r] = d->efc_b[r] < 0;
+    /* initial guess: the rows ORC_AS_PRESWEEPS plain Gauss-Seidel sweeps from f = 0 leave with a force */
+    memset(f, 0, n * 8);
+    for (int s = 0; s < ORC_AS_PRESWEEPS; s++)
+        for (int r = 0; r < n; r++) {
+            double res = d->efc_b[r];
+            for (int c = 0; c < n; c++) res += A[(size_t)r * n + c] * f[c];
+            double fn = f[r] - res / A[(size_t)r * n + r];
+            f[r] = fn < 0 ? 0 : fn;
+        }
+    for (int r = 0; r < n; r++) F[r] = f[r] > 0;
     int grace = 3, best = n + 1, it = 0, ok = 0;
     for (; it < ORC_AS_MAXIT; it++) {
         if (solve_masked(n, A, d->efc_b, F, W, f)) break;
