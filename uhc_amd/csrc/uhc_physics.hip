@@ -446,6 +446,12 @@ __device__ __forceinline__ int pk_of(const LaneConst& c, int i) {  // i wave-uni
 // the next step is fetched right after this step's stores); the program words of the next step stream in from L2
 // meanwhile.  Idle lanes read the zero slot and write the dump slot.  The LDS queue of one wave is in order, so
 // consecutive steps need no barrier.
+// 1 / x to full double precision: v_rcp_f64 + two Newton steps (~35 cycles; the IEEE division sequence with its scale / fixup costs ~77)
+__device__ __forceinline__ double rcp_newton(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
 struct FacWord { unsigned int a, o; };
 __device__ __forceinline__ double lds_at(const char* SB, unsigned int byte_off) { return *(const double*)(SB + byte_off); }
 template <int NS>
@@ -455,7 +461,7 @@ __device__ __forceinline__ void factor_step(char* SB, const FacWord (&w)[8], dou
         constexpr int q = decltype(qc)::value;
         f[q] = lds_at(SB, w[q].a & 0xffffu); r[q] = lds_at(SB, w[q].a >> 16); o[q] = lds_at(SB, w[q].o);
     });
-    const double inv = 1.0 / Dk;
+    const double inv = rcp_newton(Dk);  // on the step-to-step critical path: 1 / D_k feeds every store of the step
     static_for<0, NS>([&](auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value;
         *(double*)(SB + w[q].o) = fma(-(f[q] * inv), r[q], o[q]);
@@ -1361,9 +1367,7 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
             if ((Fe >> k) & 1ull) {
                 const double pk = bcast(W[k], k);
                 broke |= !(pk > UHC_MINVAL);
-                double pinv = __builtin_amdgcn_rcp(pk);  // + two Newton steps: full precision without the division's scale / fixup sequence
-                pinv = fma(fma(-pk, pinv, 1.0), pinv, pinv);
-                pinv = fma(fma(-pk, pinv, 1.0), pinv, pinv);
+                const double pinv = rcp_newton(pk);
                 mypinv = ln == k ? pinv : mypinv;
                 const double l = (ln > k && inF) ? W[k] * pinv : 0.0;
                 c = fma(-l, bcast(c, k), c);
