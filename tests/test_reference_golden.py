@@ -271,3 +271,31 @@ def test_env_oracle_obs_v0_v5_and_remaining_rewards(model):
             r, parts = E.world_rfc_implicit_v2_v3(v3, g[p + "qpos"], g[p + "xpos"], g[p + "xquat"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"],
                                                   expert, t, 0, dt, w23, g["w_v23_jpos_diffw"])
             np.testing.assert_allclose([r, *parts], [g[p + name], *g[p + name + "_info"]], atol=1e-13)
+
+
+def test_process_amass_db_matches_reference():
+    """G13: uhc_amd/data_process/process_amass_db.py against the reference's process_qpos_list + split rule on a synthetic AMASS
+    database (frame-rate stride, occlusion truncation / rejection, minimum length, float32 6-D rotations, 'vald' slip)."""
+    from uhc_amd.data_process.process_amass_db import process_qpos_list, split_amass
+    g = load("g13_process_amass")
+    names = [str(n) for n in g["names"]]
+    db = [(n, {"poses": g[f"db_{n}_poses"], "trans": g[f"db_{n}_trans"], "betas": g[f"db_{n}_betas"], "gender": str(g[f"db_{n}_gender"]),
+               "mocap_framerate": float(g[f"db_{n}_fr"])}) for n in names]
+    occ = {}
+    for k, issue, i0 in zip(g["occ_keys"], g["occ_issue"], g["occ_idx0"]):
+        occ[str(k)] = {"issue": str(issue)}
+        if int(i0) >= 0:
+            occ[str(k)]["idxes"] = [int(i0), int(i0) + 1]
+    res = process_qpos_list(db, occ, log=lambda *a: None)
+    assert list(res) == [str(k) for k in g["kept"]]
+    for k, v in res.items():
+        np.testing.assert_array_equal(v["pose_aa"], g[f"res_{k}_pose_aa"])
+        np.testing.assert_array_equal(v["trans"], g[f"res_{k}_trans"])
+        np.testing.assert_array_equal(v["beta"], g[f"res_{k}_beta"])
+        assert v["pose_6d"].dtype == np.float32 and v["pose_6d"].shape == g[f"res_{k}_pose_6d"].shape
+        np.testing.assert_allclose(v["pose_6d"], g[f"res_{k}_pose_6d"], atol=5e-7)
+        assert v["seq_name"] == k and v["height_fixed"] is False
+    train, test, valid = split_amass(res, log=lambda *a: None)
+    want = dict(zip([str(k) for k in g["split_keys"]], [str(v) for v in g["split_vals"]]))
+    got = {**{k: "train" for k in train}, **{k: "test" for k in test}, **{k: "valid" for k in valid}}
+    assert got == want and valid == {}   # HumanEva (a validation set) lands in train: the reference's 'vald' / 'valid' slip

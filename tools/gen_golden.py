@@ -515,6 +515,54 @@ def g10_config():
     save("g10_config", **out)
 
 
+# --------------------------------------------------------------------------- G13 AMASS database processing
+def g13_process_amass():
+    """process_qpos_list + the split rule of uhc/data_process/process_amass_db.py on a synthetic AMASS db; the SMPL height fix
+    (needs the licensed model files) is replaced by the identity on both sides."""
+    import importlib
+    mod = importlib.import_module("uhc.data_process.process_amass_db")
+    rng = np.random.default_rng(1717)
+    names = ["CMU_01_01_poses", "KIT_3_walk_poses", "SSM_synced_x_poses", "HumanEva_S1_poses", "ACCAD_sit_poses", "BMLmovi_air_poses",
+             "DanceDB_short_poses", "SFU_bad_poses", "Unknown_set_poses", "MPI_mosh_tiny_poses"]
+    db = {}
+    for i, n in enumerate(names):
+        T = [130, 240, 95, 60, 200, 150, 40, 120, 70, 25][i]
+        fr = [120.0, 100.0, 60.0, 120.0, 60.0, 59.94, 30.0, 120.0, 60.0, 120.0][i]
+        poses = rng.normal(scale=0.4, size=(T, 156))
+        poses[3, 3:6] = 1e-5  # one joint in the small-angle branch
+        db[n] = {"poses": poses, "trans": rng.normal(size=(T, 3)), "betas": rng.normal(size=16), "gender": ["male", "female", "neutral"][i % 3],
+                 "mocap_framerate": fr}
+        db[n]["poses"] = db[n]["poses"][:, :72]
+    occ = {"0-ACCAD_sit_poses": {"issue": "sitting", "idxes": [35, 36]}, "0-BMLmovi_air_poses": {"issue": "airborne", "idxes": [6]},
+           "0-SFU_bad_poses": {"issue": "stairs", "idxes": [3]}, "0-KIT_3_walk_poses": {"issue": "sitting"}}
+    mod.target_fr = 30
+    mod.amass_occlusion = occ
+    mod.fix_height_smpl_vanilla = lambda pose_aa, th_betas, th_trans, gender, seq_name: th_trans
+    mod.flags.debug = False
+    res = mod.process_qpos_list(list(db.items()))
+    out = {"names": np.array(names), "occ_keys": np.array(list(occ)), "occ_issue": np.array([occ[k]["issue"] for k in occ]),
+           "occ_idx0": np.array([occ[k].get("idxes", [-1])[0] for k in occ]), "kept": np.array(list(res))}
+    for n in names:
+        for f in ("poses", "trans", "betas"):
+            out[f"db_{n}_{f}"] = db[n][f]
+        out[f"db_{n}_gender"] = np.array(db[n]["gender"])
+        out[f"db_{n}_fr"] = db[n]["mocap_framerate"]
+    for k, v in res.items():
+        for f in ("pose_aa", "pose_6d", "trans", "beta"):
+            out[f"res_{k}_{f}"] = np.asarray(v[f])
+    # the split rule (the __main__ block, :340-361)
+    split = {}
+    for k in res:
+        start_name = k.split("-")[1]
+        for dataset_key in mod.amass_split_dict.keys():
+            if start_name.lower().startswith(dataset_key.lower()):
+                sp = mod.amass_split_dict[dataset_key]
+                split[k] = "test" if sp == "test" else ("valid" if sp == "valid" else "train")
+    out["split_keys"] = np.array(list(split))
+    out["split_vals"] = np.array(list(split.values()))
+    save("g13_process_amass", **out)
+
+
 def main():
     g1_math()
     dm, qpos, feat = g2_g3_expert()
@@ -526,6 +574,7 @@ def main():
     g9_dataset()
     g10_config()
     g12_policy_mcp()
+    g13_process_amass()
 
 
 if __name__ == "__main__":
