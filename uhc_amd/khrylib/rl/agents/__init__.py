@@ -328,7 +328,9 @@ class AgentPPO(AgentPG):
     def clip_policy_grad(self):
         if self.policy_grad_clip is not None:
             for params, max_norm in self.policy_grad_clip:
-                torch.nn.utils.clip_grad_norm_(params, max_norm)
+                params = list(params)  # the reference passes a generator: exhausted after the first call, every later call clips nothing
+                if params:
+                    torch.nn.utils.clip_grad_norm_(params, max_norm)
 
     def ppo_loss(self, states, actions, advantages, fixed_log_probs, ind):
         log_probs = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
