@@ -410,7 +410,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     // ---- static schedules for the factorisation and the triangular solves (see DevTopo).  Addresses are LDS byte
     //      addresses of the FAST layout's LD buffer (the general kernel adds its own LD offset, KernelArgs::ld_delta).
     {
-        std::vector<unsigned int> fac_prog, sol_back((size_t)std::max(nv - 1, 1) * 64, 0), sol_fwd((size_t)std::max(nv - 1, 1) * 64, 0);
+        // substitution tables: nv-1 steps, padded with no-op steps (zero-slot addresses) to a multiple of 8 plus one block of look-ahead
+        const size_t sol_steps = (size_t)((std::max(nv - 1, 1) + 7) / 8 * 8 + 8);
+        std::vector<unsigned int> fac_prog, sol_back(sol_steps * 64, 0), sol_fwd(sol_steps * 64, 0);
         const unsigned ldb = (unsigned)A.lf.LD * 8u;
         auto adr = [&](int rel) { return ldb + 8u * (unsigned)rel; };
         const int ZERO = T.nM, DUMP = T.nM + 1;
@@ -435,6 +437,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             if (i >= nv || j >= nv || j >= i || dof_depth[j] >= dof_depth[i]) return adr(ZERO);
             return dof_anc[(size_t)i * YS + dof_depth[j]] == j ? adr(d.dof_madr[i] + dof_depth[i] - dof_depth[j]) : adr(ZERO);
         };
+        for (size_t q = 0; q < sol_steps * 64; q++) sol_back[q] = sol_fwd[q] = adr(ZERO) | (adr(ZERO) << 16);
         for (int s2 = 0; s2 < nv - 1; s2++)
             for (int l = 0; l < 64; l++) {
                 const int i = nv - 1 - s2;

@@ -529,30 +529,39 @@ __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld,
 // the next block of U steps are fetched while the current block runs, the block's L entries are read up front.
 struct DofVec { double a, b; };
 __device__ __forceinline__ double dv_get(const DofVec& x, int i) { return i < UHC_WAVE ? bcast(x.a, i) : bcast(x.b, i - UHC_WAVE); }
+// dv_get without control flow: both halves are read and the words selected with scalar logic (a uniform branch costs 25-60 cycles
+// here, and this sits on the step-to-step chain of the substitutions)
+__device__ __forceinline__ double dv_get_nb(const DofVec& x, int i) {  // i wave-uniform, 0 <= i < 128
+    const int l = i & (UHC_WAVE - 1), m = -(i >> 6);
+    const int alo = __builtin_amdgcn_readlane(__double2loint(x.a), l), ahi = __builtin_amdgcn_readlane(__double2hiint(x.a), l);
+    const int blo = __builtin_amdgcn_readlane(__double2loint(x.b), l), bhi = __builtin_amdgcn_readlane(__double2hiint(x.b), l);
+    return __hiloint2double(ahi ^ ((ahi ^ bhi) & m), alo ^ ((alo ^ blo) & m));
+}
+// The tables are padded by the host to a multiple of U steps (+ one block of look-ahead) with no-op steps (zero-slot
+// addresses), so the loop body has no tests at all.
 template <bool BACK>
 __device__ __forceinline__ void solve_sweep(const unsigned int* tab, const char* SB, int n, DofVec& x) {
     constexpr int U = 8;
+    const int np = (n + U - 1) & ~(U - 1);
     unsigned int wn[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) wn[u] = tab[(size_t)(u < n ? u : n - 1) * UHC_WAVE];
-    for (int s0 = 0; s0 < n; s0 += U) {
+    for (int u = 0; u < U; u++) wn[u] = tab[(size_t)u * UHC_WAVE];
+    for (int s0 = 0; s0 < np; s0 += U) {
         double l0[U], l1[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const unsigned int ww = wn[u];
-            const int sn = s0 + U + u;
-            wn[u] = tab[(size_t)(sn < n ? sn : n - 1) * UHC_WAVE];
+            wn[u] = tab[(size_t)(s0 + U + u) * UHC_WAVE];
             l0[u] = lds_at(SB, ww & 0xffffu);
             l1[u] = lds_at(SB, ww >> 16);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the 16 LDS reads of the block ahead of its serial chain (the scheduler sinks them to their uses otherwise)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = s0 + u;
-            if (s < n) {
-                const double xs = dv_get(x, BACK ? n - s : s);
-                x.a = fma(-l0[u], xs, x.a);
-                x.b = fma(-l1[u], xs, x.b);
-            }
+            const double xs = dv_get_nb(x, BACK ? max(n - s, 0) : s);
+            x.a = fma(-l0[u], xs, x.a);
+            x.b = fma(-l1[u], xs, x.b);
         }
     }
 }
