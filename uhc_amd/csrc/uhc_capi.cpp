@@ -417,22 +417,37 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         auto adr = [&](int rel) { return ldb + 8u * (unsigned)rel; };
         const int ZERO = T.nM, DUMP = T.nM + 1;
         if (adr(DUMP) + 8 > 65536u || (unsigned)A.l.LD * 8u + 8u * (T.nM + 2) > 65536u) { delete b; return fail("uhc_batch_create: LD buffer beyond the 16-bit schedule addresses"); }
+        // factorisation program: a flat list of groups, one 16-byte record per lane and group (DevTopo::fac_prog).  A group holds two
+        // 64-lane slots of updates of ONE elimination step k,  LD[row(anc_a) + t] -= (LD[kk + a] / D_k) * LD[kk + a + t],  the address of
+        // D_k, and -- in the step's last group -- the lane's entry of row k to normalise (LD[kk + 1 + lane] /= D_k).  Steps need no
+        // boundary handling in the kernel: the LDS queue of a wave is in order.
+        int ngroups = 0;
         for (int k = nv - 1; k >= 1; k--) {
             const int dk = dof_depth[k], kk = d.dof_madr[k];
             if (!dk) continue;
-            size_t n0 = fac_prog.size();
+            std::vector<unsigned> E;  // (af | ar << 16, ao) per entry
             int anc = k;
             for (int a = 1; a <= dk; a++) {
                 anc = d.dof_parentid[anc];
-                for (int t = 0; t <= dk - a; t++) {  // LD[row(anc) + t] -= (LD[kk + a] / D_k) * LD[kk + a + t]
-                    fac_prog.push_back(adr(kk + a) | (adr(kk + a + t) << 16));
-                    fac_prog.push_back(adr(d.dof_madr[anc] + t));
-                }
+                for (int t = 0; t <= dk - a; t++) { E.push_back(adr(kk + a) | (adr(kk + a + t) << 16)); E.push_back(adr(d.dof_madr[anc] + t)); }
             }
-            while ((fac_prog.size() - n0) % 128) { fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16)); fac_prog.push_back(adr(DUMP)); }
+            while ((E.size() / 2) % 128) { E.push_back(adr(ZERO) | (adr(ZERO) << 16)); E.push_back(adr(DUMP)); }
+            const int ng = (int)(E.size() / 2 / 128);
+            for (int gi = 0; gi < ng; gi++)
+                for (int l = 0; l < 64; l++) {
+                    const size_t e0 = ((size_t)gi * 128 + l) * 2, e1 = ((size_t)gi * 128 + 64 + l) * 2;
+                    const unsigned nr = (gi == ng - 1 && l < dk) ? adr(kk + 1 + l) : adr(ZERO);
+                    fac_prog.push_back(E[e0]); fac_prog.push_back(E[e1]);
+                    fac_prog.push_back(E[e0 + 1] | (E[e1 + 1] << 16));
+                    fac_prog.push_back(adr(kk) | (nr << 16));
+                }
+            ngroups += ng;
         }
-        T.fac_nslot = (int)(fac_prog.size() / 128);
-        for (int q = 0; q < 8 * 64; q++) { fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16)); fac_prog.push_back(adr(DUMP)); }  // look-ahead slack
+        T.fac_nslot = ngroups;
+        for (int q = 0; q < 2 * 64; q++) {  // two groups of look-ahead slack
+            fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16)); fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16));
+            fac_prog.push_back(adr(DUMP) | (adr(DUMP) << 16)); fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16));
+        }
         auto entry = [&](int i, int j) -> unsigned {  // address of L[i][j] if j is a proper ancestor of i, else the zero slot
             if (i >= nv || j >= nv || j >= i || dof_depth[j] >= dof_depth[i]) return adr(ZERO);
             return dof_anc[(size_t)i * YS + dof_depth[j]] == j ? adr(d.dof_madr[i] + dof_depth[i] - dof_depth[j]) : adr(ZERO);

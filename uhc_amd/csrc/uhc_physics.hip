@@ -437,84 +437,44 @@ __device__ __forceinline__ int pk_of(const LaneConst& c, int i) {  // i wave-uni
     return i < UHC_WAVE ? __builtin_amdgcn_readlane(c.pk0, i) : __builtin_amdgcn_readlane(c.pk1, i - UHC_WAVE);
 }
 
-// In-place L^T D L of the tree-sparse matrix in the LD buffer (same elimination order as MuJoCo's mj_factorM [MJ-ext]);
-// also dinv[i] = 1/D[i].  The updates of elimination step k,  LD[row(anc_a) + t] -= (LD[kk+a] / D_k) * LD[kk+a+t]  for
-// every ancestor a and offset t, depend on the tree only, so the host lays them out once as a dense program of
-// 64-lane slots (DevTopo::fac_prog): per slot a lane gets three ready LDS byte addresses in one 64-bit word -- no
-// per-step predicates, address arithmetic or partially filled passes.  A step issues the loads of all its NS (<= 8)
-// slots before the first store, so their LDS latencies overlap with each other and with the division 1 / D_k (D_k of
-// the next step is fetched right after this step's stores); the program words of the next step stream in from L2
-// meanwhile.  Idle lanes read the zero slot and write the dump slot.  The LDS queue of one wave is in order, so
-// consecutive steps need no barrier.
 // 1 / x to full double precision: v_rcp_f64 + two Newton steps (~35 cycles; the IEEE division sequence with its scale / fixup costs ~77)
 __device__ __forceinline__ double rcp_newton(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
 }
+// In-place L^T D L of the tree-sparse matrix in the LD buffer (same elimination order as MuJoCo's mj_factorM [MJ-ext]);
+// also dinv[i] = 1/D[i].  The updates of elimination step k,  LD[row(anc_a) + t] -= (LD[kk+a] / D_k) * LD[kk+a+t]  for
+// every ancestor a and offset t, depend on the tree only, so the host lays them out once as a flat program of groups
+// (DevTopo::fac_prog): per group a lane gets one 16-byte record with the ready LDS byte addresses of two updates of one step,
+// of that step's D_k and -- in the step's last group -- of its entry of row k to normalise.  The loop body is the same for every
+// group: no step bookkeeping, predicates, address arithmetic or branches (a wave-uniform branch costs 25-60 cycles with one wave
+// per SIMD; the earlier per-step version spent most of its ~1100 cycles per step on them).  Idle lanes read the zero slot and
+// write the dump slot.  The LDS queue of one wave is in order, so consecutive groups and steps need no barrier; the record of
+// the next group streams in from L2 meanwhile.
 struct FacWord { unsigned int a, o; };
 __device__ __forceinline__ double lds_at(const char* SB, unsigned int byte_off) { return *(const double*)(SB + byte_off); }
-template <int NS>
-__device__ __forceinline__ void factor_step(char* SB, const FacWord (&w)[8], double Dk, double fraw, unsigned int norm_adr) {
-    double f[NS], r[NS], o[NS];
-    static_for<0, NS>([&](auto qc) __attribute__((always_inline)) {
-        constexpr int q = decltype(qc)::value;
-        f[q] = lds_at(SB, w[q].a & 0xffffu); r[q] = lds_at(SB, w[q].a >> 16); o[q] = lds_at(SB, w[q].o);
-    });
-    const double inv = rcp_newton(Dk);  // on the step-to-step critical path: 1 / D_k feeds every store of the step
-    static_for<0, NS>([&](auto qc) __attribute__((always_inline)) {
-        constexpr int q = decltype(qc)::value;
-        *(double*)(SB + w[q].o) = fma(-(f[q] * inv), r[q], o[q]);
-    });
-    *(double*)(SB + norm_adr) = fraw * inv;
-}
 template <bool FAST>
 __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     double* LD = S + ld;
     char* SB = (char*)S + (FAST ? 0 : A.ld_delta);  // schedule addresses are byte offsets in the fast layout
-    constexpr int Q = 8;
-    const unsigned int zero_adr = (unsigned)(A.lf.LD + T.nM) * 8u, dump_adr = zero_adr + 8u, ld_adr = (unsigned)A.lf.LD * 8u;
-    auto depth_of = [&](int k) __attribute__((always_inline)) { return (pk_of(LC, k) >> 16) & 0xff; };
-    auto next_step = [&](int k) __attribute__((always_inline)) {  // next k' < k that has ancestors (0 = none)
-        do k--; while (k >= 1 && depth_of(k) == 0);
-        return k < 1 ? 0 : k;
-    };
-    const FacWord* pw = (const FacWord*)T.fac_prog + LANE;
-    int k = next_step(T.nv);
-    double Dk = k >= 1 ? LD[pk_of(LC, k) & 0xffff] : 1.0;
-    // one elimination step on the program words `cur`, fetching the next step's words into `nxt` (two register sets used in
-    // turn: rotating one set through copies would make every step wait for the loads it has just issued)
-    auto step = [&](const FacWord (&cur)[Q], FacWord (&nxt)[Q]) __attribute__((always_inline)) {
-        const int pk = pk_of(LC, k), kk = pk & 0xffff, dk = (pk >> 16) & 0xff;
-        const int ns = (dk * (dk + 1) / 2 + UHC_WAVE - 1) >> 6;
-        pw += ns * UHC_WAVE;
-#pragma unroll
-        for (int q = 0; q < Q; q++) nxt[q] = pw[q * UHC_WAVE];  // the table carries 8 slots of slack
-        const bool na = LANE < dk;
-        const unsigned int norm_adr = na ? ld_adr + 8u * (unsigned)(kk + 1 + LANE) : dump_adr;
-        const double fraw = lds_at(SB, na ? norm_adr : zero_adr);
-        switch (ns) {
-            case 1: factor_step<1>(SB, cur, Dk, fraw, norm_adr); break;
-            case 2: factor_step<2>(SB, cur, Dk, fraw, norm_adr); break;
-            case 3: factor_step<3>(SB, cur, Dk, fraw, norm_adr); break;
-            case 4: factor_step<4>(SB, cur, Dk, fraw, norm_adr); break;
-            case 5: factor_step<5>(SB, cur, Dk, fraw, norm_adr); break;
-            case 6: factor_step<6>(SB, cur, Dk, fraw, norm_adr); break;
-            case 7: factor_step<7>(SB, cur, Dk, fraw, norm_adr); break;
-            default: factor_step<8>(SB, cur, Dk, fraw, norm_adr); break;
-        }
-        k = next_step(k);
-        if (k >= 1) Dk = LD[pk_of(LC, k) & 0xffff];
-    };
-    FacWord wa[Q], wb[Q];
-#pragma unroll
-    for (int q = 0; q < Q; q++) wa[q] = pw[q * UHC_WAVE];
-    while (k >= 1) {
-        step(wa, wb);
-        if (k < 1) break;
-        step(wb, wa);
+    const unsigned int zero_adr = (unsigned)(A.lf.LD + T.nM) * 8u, dump_adr = zero_adr + 8u;
+    const uint4* pg = (const uint4*)T.fac_prog + LANE;
+    uint4 cur = pg[0];
+    for (int g = 0; g < T.fac_nslot; g++) {
+        const uint4 nxt = pg[(size_t)(g + 1) * UHC_WAVE];  // the table carries two groups of slack
+        const unsigned int nr = cur.w >> 16;
+        const double Dk = lds_at(SB, cur.w & 0xffffu);
+        const double f0 = lds_at(SB, cur.x & 0xffffu), r0 = lds_at(SB, cur.x >> 16), o0 = lds_at(SB, cur.z & 0xffffu);
+        const double f1 = lds_at(SB, cur.y & 0xffffu), r1 = lds_at(SB, cur.y >> 16), o1 = lds_at(SB, cur.z >> 16);
+        const double fraw = lds_at(SB, nr);
+        const double inv = rcp_newton(Dk);  // on the group-to-group critical path: 1 / D_k feeds every store
+        *(double*)(SB + (cur.z & 0xffffu)) = fma(-(f0 * inv), r0, o0);
+        *(double*)(SB + (cur.z >> 16)) = fma(-(f1 * inv), r1, o1);
+        *(double*)(SB + (nr == zero_adr ? dump_adr : nr)) = fraw * inv;
+        cur = nxt;
     }
     wsync();
     if (LC.v0) { const double di = 1.0 / LD[LC.m0]; S[L.dinv + LANE] = di; S[L.sdinv + LANE] = sqrt(di); }
