@@ -516,12 +516,22 @@ __device__ __forceinline__ void solve_sweep(const unsigned int* tab, const char*
             l1[u] = lds_at(SB, ww >> 16);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the 16 LDS reads of the block ahead of its serial chain (the scheduler sinks them to their uses otherwise)
+        // one test per block: when all eight pivots are dofs < 64 (8 of the humanoid's 10 blocks) the broadcast reads x.a only
+        if (BACK ? n - s0 < UHC_WAVE : s0 + U <= UHC_WAVE) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = s0 + u;
-            const double xs = dv_get_nb(x, BACK ? max(n - s, 0) : s);
-            x.a = fma(-l0[u], xs, x.a);
-            x.b = fma(-l1[u], xs, x.b);
+            for (int u = 0; u < U; u++) {
+                const double xs = bcast(x.a, BACK ? max(n - s0 - u, 0) : s0 + u);
+                x.a = fma(-l0[u], xs, x.a);
+                x.b = fma(-l1[u], xs, x.b);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u;
+                const double xs = dv_get_nb(x, BACK ? max(n - s, 0) : s);
+                x.a = fma(-l0[u], xs, x.a);
+                x.b = fma(-l1[u], xs, x.b);
+            }
         }
     }
 }
@@ -1429,6 +1439,8 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
             }
             // chunks of 8 chain positions, skipped uniformly beyond row s's length; inside a chunk no tests are needed:
             // Ym is zero past the common prefix (<= lens) and every row's registers are zero past its own length
+            // (all loads of a row up front in two halves of 16 with two accumulators: A-build -8 %, but the rest of the kernel +1.5 %
+            //  from the changed register allocation: not kept)
             static_for<0, UHC_YM / 8>([&](auto cc) __attribute__((always_inline)) {
                 constexpr int c = decltype(cc)::value;
                 if (8 * c < lens) {
