@@ -297,3 +297,48 @@ def test_per_clip_body_shape_switches_the_env_model(tmp_path):
     o.set_state(feats[0]["qpos"][3], feats[0]["qvel"][4])
     np.testing.assert_allclose(env.sim.field(S.F_XPOS)[2].cpu().numpy(), o.get("xpos"), atol=1e-12)
     env.close()
+
+
+@pytest.mark.parametrize("solver", [1, 0])
+def test_deferred_reset_forward_matches_explicit_reset(model, ctrl, solver):
+    """uhc_env_auto_reset only refreshes the kinematics of a restarted env and leaves the rest of sim.forward() to the head of the
+    env's next step kernel: the steps that follow are bit-identical to those after an explicit assign + reset (full forward pass
+    at once), for envs restarted from a queued window and for envs restarting their own window."""
+    import dataclasses
+    import torch
+    from uhc_amd import sim as S
+    model = dataclasses.replace(model, solver=solver)
+    expert = _expert()
+    beta = np.linspace(-1, 1, 16)
+    n = 4
+    rng = np.random.default_rng(8)
+    noise = torch.from_numpy(rng.normal(scale=0.05, size=(2, model.nu)))
+    acts = [torch.from_numpy(rng.normal(scale=0.1, size=(n, ctrl.action_dim))).cuda() for _ in range(5)]
+    ids = torch.arange(n, dtype=torch.int32)
+    out = []
+    for path in ("auto", "explicit"):
+        sb, eb = _make(model, ctrl, n, expert, beta)
+        eb.assign(ids, torch.zeros(n, dtype=torch.int32), torch.tensor([0, 4, 0, 8], dtype=torch.int32), torch.tensor([3, 3, 40, 30], dtype=torch.int32))
+        eb.reset(ids.cuda(), None)
+        if path == "auto":
+            eb.set_next(torch.tensor([0], dtype=torch.int32), torch.tensor([1], dtype=torch.int32), torch.tensor([6], dtype=torch.int32), torch.tensor([20], dtype=torch.int32), noise[0:1])
+        for t in range(2):
+            eb.step(acts[t], None)
+        sb.sync()
+        assert eb.field(S.E_DONE).cpu().tolist() == [1, 1, 0, 0]
+        if path == "auto":
+            eb.auto_reset()
+        else:
+            eb.assign(torch.tensor([0], dtype=torch.int32), torch.tensor([1], dtype=torch.int32), torch.tensor([6], dtype=torch.int32), torch.tensor([20], dtype=torch.int32))
+            eb.reset(torch.tensor([0], dtype=torch.int32).cuda(), noise[0:1])
+            eb.reset(torch.tensor([1], dtype=torch.int32).cuda(), None)
+        rec = [eb.field(S.E_OBS).clone()]
+        for t in range(2, 5):
+            eb.step(acts[t], None)
+            rec += [eb.field(S.E_OBS).clone(), sb.field(S.F_QPOS).clone(), sb.field(S.F_QVEL).clone(), eb.field(S.E_REWARD).clone()]
+        sb.sync()
+        rec += [sb.field(S.F_QM).clone(), sb.field(S.F_QFRC_BIAS).clone()]
+        out.append(rec)
+        sb.close()
+    for a, b in zip(*out):
+        assert torch.equal(a, b)

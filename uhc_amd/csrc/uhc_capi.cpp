@@ -480,7 +480,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
@@ -614,7 +614,10 @@ extern "C" hipError_t uhc_launch_set_state_masked(const DevState* s, int nq, int
 extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, const double* d_qpos, const double* d_qvel) {
     HIP_OK(hipSetDevice(b->device));
     HIP_OK(uhc_launch_set_state_masked(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, b->n_env, d_select, d_qpos, d_qvel, b->reset_mask, b->stream));
-    return launch(b, 1, nullptr, nullptr, b->reset_mask);
+    // only the kinematics now (the reset observation reads body poses); the dynamics part of sim.forward() runs at the head of the
+    // env's next step kernel (DevState::fresh), which saves a forward-pass-long launch per control step
+    HIP_OK(uhc_launch_step(2, b->use_fast ? 1 : 0, &b->A, nullptr, nullptr, b->reset_mask, b->use_fast ? b->lds_bytes_fast : b->lds_bytes, b->stream));
+    return 0;
 }
 
 extern "C" int* uhc_internal_env_model(UhcBatch* b, int* n_models) { *n_models = b->n_models; return const_cast<int*>(b->A.s.env_model); }

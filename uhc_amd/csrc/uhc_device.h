@@ -73,6 +73,7 @@ struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
+    int* fresh;  // 1: the env was restarted on the device (set_state done, kinematics refreshed); its mj_forward runs at the head of its next step
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)
     const double* model_blob;

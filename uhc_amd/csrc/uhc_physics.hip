@@ -1793,6 +1793,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     double* S = smem;
     const double* mb = A.s.model_blob + (size_t)(A.s.env_model ? A.s.env_model[env] : 0) * A.o.stride;
     int fail = MODE == 0 ? A.s.fail[env] : 0;
+    const bool fresh = MODE == 0 && A.s.fresh[env] != 0;  // restarted by uhc_env_auto_reset: sim.forward() of the reset is still due
     // ---- load state (coalesced: consecutive lanes, consecutive doubles)
     for (int i = LANE; i < T.nq; i += UHC_WAVE) S[L.qpos + i] = A.s.qpos[(size_t)env * T.nq + i];
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
@@ -1838,6 +1839,15 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     int overflow = 0;
     bool ran = false;
     PROF_DECL
+    if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
+        k_kinematics<FAST>(A, mb, S, BC PROF_PASS);
+        for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
+            A.s.xpos[(size_t)env * 3 * T.nbody + i] = S[L.xpos + i];
+            A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
+        }
+        for (int i = LANE; i < 4 * T.nbody; i += UHC_WAVE) A.s.xquat[(size_t)env * 4 * T.nbody + i] = S[L.xquat + i];
+        return;
+    }
     if (MODE == 1) {
         fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
         overflow |= fo.overflow;
@@ -1845,7 +1855,11 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
-        for (int it = 0; it < A.c.n_substeps; it++) {
+        // a freshly restarted env first runs the forward pass of its reset (it = -1: no control, no integration), through the
+        // same inlined k_forward as the substeps
+        for (int it = fresh ? -1 : 0; it < A.c.n_substeps; it++) {
+            int b = 0;
+            if (it >= 0) {
             if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, MP, LC PROF_PASS);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
@@ -1855,16 +1869,22 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             if (A.c.rfc_mode == 1) k_rfc_implicit<FAST>(A, S, action);
             else if (A.c.rfc_mode == 2) k_rfc_explicit<FAST>(A, S, action);
             // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
-            int b = 0;
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
+            }
             PROF(0)
             fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && (overflow & 1)) break;
             ran = true;
+            if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
+                wsync();
+                for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.qacc + i] = A.s.qacc_ws[(size_t)env * T.nv + i];
+                wsync();
+                continue;
+            }
             b = 0;
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
             if (wave_or(b)) { fail = 1; break; }
@@ -1918,6 +1938,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         if (ran) { A.s.ncon[env] = fo.ncon; A.s.nefc[env] = fo.nefc; A.s.solver_iter[env] = fo.iters; }
         A.s.fail[env] = fail;
         if (overflow) A.s.overflow[env] = 1;
+        A.s.fresh[env] = 0;
     }
 }
 
@@ -1935,7 +1956,7 @@ __global__ void uhc_set_state_kernel(DevState s, int nq, int nv, int nu, const i
         s.applied[(size_t)env * nv + i] = 0;
     }
     for (int i = threadIdx.x; i < nu; i += blockDim.x) s.ctrl[(size_t)env * nu + i] = 0;
-    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; mask[env] = 1; }
+    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; s.fresh[env] = 0; mask[env] = 1; }
 }
 
 // set_state on every env whose select flag is set; row e of (qpos, qvel) belongs to env e
@@ -1954,7 +1975,7 @@ __global__ void uhc_set_state_masked_kernel(DevState s, int nq, int nv, int nu, 
         s.applied[(size_t)env * nv + i] = 0;
     }
     for (int i = threadIdx.x; i < nu; i += blockDim.x) s.ctrl[(size_t)env * nu + i] = 0;
-    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; }
+    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; s.fresh[env] = 1; }  // the forward pass of this reset runs at the head of the env's next step
 }
 extern "C" hipError_t uhc_launch_set_state_masked(const DevState* s, int nq, int nv, int nu, int n_env, const int* select, const double* qpos,
                                                   const double* qvel, int* mask, hipStream_t stream) {
@@ -1968,6 +1989,8 @@ extern "C" hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, c
     dim3 grid(A->n_env), block(UHC_WAVE);
     if (mode == 0 && fast) hipLaunchKernelGGL((uhc_step_kernel<0, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
     else if (mode == 0) hipLaunchKernelGGL((uhc_step_kernel<0, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    else if (mode == 2 && fast) hipLaunchKernelGGL((uhc_step_kernel<2, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    else if (mode == 2) hipLaunchKernelGGL((uhc_step_kernel<2, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
     else if (fast) hipLaunchKernelGGL((uhc_step_kernel<1, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
     else hipLaunchKernelGGL((uhc_step_kernel<1, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
@@ -1976,6 +1999,8 @@ extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast)
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)uhc_step_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast);
 }
