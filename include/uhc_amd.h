@@ -245,7 +245,10 @@ int32_t uhc_env_assign(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int
  * 526-531, right after `done`): uhc_env_set_next queues, per env, the window its NEXT episode will track (+ the reset noise,
  * d_noise [n][nu] or NULL); uhc_env_auto_reset then does, for every env whose done flag is set, load_expert + reset_model on
  * the device (queued window if there is one, else the current window again) and refreshes its observation row.  The done
- * flags are left as the step wrote them; UHC_E_CONSUMED tells which envs took their queued window. */
+ * flags are left as the step wrote them; UHC_E_CONSUMED tells which envs took their queued window.  Of the reset's sim.forward()
+ * only the kinematics run here (UHC_F_XPOS / XQUAT / XIPOS, the observation); its dynamics half (qM, qfrc_bias, qacc of the reset
+ * state) runs at the head of the env's next uhc_env_step, so UHC_F_QM / QFRC_BIAS / QACC / NCON / NEFC of a restarted env are those
+ * of its previous episode until then.  The steps that follow are bit-identical to those after uhc_env_assign + uhc_env_reset. */
 int32_t uhc_env_set_next(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const int32_t* d_clip_ids, const int32_t* d_fr_start,
                          const int32_t* d_fr_len, const double* d_noise);
 int32_t uhc_env_auto_reset(UhcEnv* e);
