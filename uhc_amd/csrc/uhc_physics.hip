@@ -1939,6 +1939,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         A.s.fail[env] = fail;
         if (overflow) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
+        if (!FAST) A.s.redo[env] = 1;  // UHC_F_REDO = "computed by the general kernel", also when the batch runs it alone
     }
 }
 
