@@ -203,3 +203,28 @@ def test_two_rank_gloo_update_equals_single_process(tmp_path):
     for net in ("pol", "val"):
         for k in a[net]:
             np.testing.assert_allclose(a[net][k].numpy(), b[net][k].numpy(), atol=1e-10, err_msg=f"{net}.{k}")
+
+
+def test_process_amass_raw_collects_action_files(tmp_path):
+    """uhc_amd/data_process/process_amass_raw.py (reference :83-131): <data set>/<subject>/<action>.npz -> "<data set>_<subject>_<action>",
+    shape.npz and other files skipped, arrays unchanged (checked identical to the imported reference on the same tree when written)."""
+    from uhc_amd.data_process.process_amass_raw import ALL_SEQUENCES, read_data
+    rng = np.random.default_rng(0)
+    want = {}
+    for ds, subs in (("CMU", {"01": ["01_01_poses.npz", "shape.npz", "notes.txt"], "02": ["02_03_poses.npz"]}), ("KIT", {"3": ["walk_poses.npz", "shape.npz"]})):
+        for sub, files in subs.items():
+            os.makedirs(tmp_path / ds / sub)
+            for f in files:
+                if f.endswith(".npz"):
+                    arrs = dict(poses=rng.normal(size=(5, 156)), trans=rng.normal(size=(5, 3)), betas=rng.normal(size=16), mocap_framerate=np.float64(120.0))
+                    np.savez(tmp_path / ds / sub / f, **arrs)
+                    if f != "shape.npz":
+                        want[f"{ds}_{sub}_{f[:-4]}"] = arrs
+                else:
+                    (tmp_path / ds / sub / f).write_text("x")
+    db = read_data(str(tmp_path), ["CMU", "KIT"], log=lambda *a: None)
+    assert sorted(db) == sorted(want) == ["CMU_01_01_01_poses", "CMU_02_02_03_poses", "KIT_3_walk_poses"]
+    for k, arrs in want.items():
+        for f, v in arrs.items():
+            np.testing.assert_array_equal(db[k][f], v)
+    assert len(ALL_SEQUENCES) == 19 and "DanceDB" in ALL_SEQUENCES
