@@ -417,7 +417,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         auto adr = [&](int rel) { return ldb + 8u * (unsigned)rel; };
         const int ZERO = T.nM, DUMP = T.nM + 1;
         if (adr(DUMP) + 8 > 65536u || (unsigned)A.l.LD * 8u + 8u * (T.nM + 2) > 65536u) { delete b; return fail("uhc_batch_create: LD buffer beyond the 16-bit schedule addresses"); }
-        // factorisation program: a flat list of groups, one 16-byte record per lane and group (DevTopo::fac_prog).  A group holds two
+        // factorisation program: a flat list of groups, one 24-byte record per lane and group (DevTopo::fac_prog).  A group holds three
         // 64-lane slots of updates of ONE elimination step k,  LD[row(anc_a) + t] -= (LD[kk + a] / D_k) * LD[kk + a + t],  the address of
         // D_k, and -- in the step's last group -- the lane's entry of row k to normalise (LD[kk + 1 + lane] /= D_k).  Steps need no
         // boundary handling in the kernel: the LDS queue of a wave is in order.
@@ -431,22 +431,25 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
                 anc = d.dof_parentid[anc];
                 for (int t = 0; t <= dk - a; t++) { E.push_back(adr(kk + a) | (adr(kk + a + t) << 16)); E.push_back(adr(d.dof_madr[anc] + t)); }
             }
-            while ((E.size() / 2) % 128) { E.push_back(adr(ZERO) | (adr(ZERO) << 16)); E.push_back(adr(DUMP)); }
-            const int ng = (int)(E.size() / 2 / 128);
+            constexpr int G = 3;  // update slots per group (uhc_physics.hip k_factor): 99 groups for the SMPL tree (129 with 2, 88 with 4 but 36 % more padded slots)
+            while ((E.size() / 2) % (64 * G)) { E.push_back(adr(ZERO) | (adr(ZERO) << 16)); E.push_back(adr(DUMP)); }
+            const int ng = (int)(E.size() / 2 / (64 * G));
             for (int gi = 0; gi < ng; gi++)
                 for (int l = 0; l < 64; l++) {
-                    const size_t e0 = ((size_t)gi * 128 + l) * 2, e1 = ((size_t)gi * 128 + 64 + l) * 2;
+                    size_t e[G];
+                    for (int q = 0; q < G; q++) e[q] = ((size_t)gi * 64 * G + 64 * q + l) * 2;
                     const unsigned nr = (gi == ng - 1 && l < dk) ? adr(kk + 1 + l) : adr(ZERO);
-                    fac_prog.push_back(E[e0]); fac_prog.push_back(E[e1]);
-                    fac_prog.push_back(E[e0 + 1] | (E[e1 + 1] << 16));
-                    fac_prog.push_back(adr(kk) | (nr << 16));
+                    for (int q = 0; q < G; q++) fac_prog.push_back(E[e[q]]);
+                    fac_prog.push_back(E[e[0] + 1] | (E[e[1] + 1] << 16));
+                    fac_prog.push_back(E[e[2] + 1] | (nr << 16));
+                    fac_prog.push_back(adr(kk));
                 }
             ngroups += ng;
         }
         T.fac_nslot = ngroups;
         for (int q = 0; q < 2 * 64; q++) {  // two groups of look-ahead slack
-            fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16)); fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16));
-            fac_prog.push_back(adr(DUMP) | (adr(DUMP) << 16)); fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16));
+            for (int w = 0; w < 3; w++) fac_prog.push_back(adr(ZERO) | (adr(ZERO) << 16));
+            fac_prog.push_back(adr(DUMP) | (adr(DUMP) << 16)); fac_prog.push_back(adr(DUMP) | (adr(ZERO) << 16)); fac_prog.push_back(adr(ZERO));
         }
         auto entry = [&](int i, int j) -> unsigned {  // address of L[i][j] if j is a proper ancestor of i, else the zero slot
             if (i >= nv || j >= nv || j >= i || dof_depth[j] >= dof_depth[i]) return adr(ZERO);

@@ -32,7 +32,7 @@ struct DevTopo {
     int body_maxdepth;
     // static schedules of the tree-sparse factorisation / substitutions (uhc_capi.cpp).  Entries are LDS byte addresses
     // inside the LD buffer, whose slots nM (always 0.0) and nM+1 (write-only dump) serve idle lanes.
-    const unsigned int* fac_prog;  // [fac_nslot (+2)][64][4] groups of two update slots of one step: {af0 | ar0 << 16, af1 | ar1 << 16, ao0 | ao1 << 16, D_k | norm << 16}:  LD[ao] -= (LD[af] / D_k) * LD[ar]
+    const unsigned int* fac_prog;  // [fac_nslot (+2)][64][6] groups of three update slots of one step: {af_q | ar_q << 16 (q = 0..2), ao0 | ao1 << 16, ao2 | norm << 16, D_k}:  LD[ao] -= (LD[af] / D_k) * LD[ar]
     const unsigned int* sol_back;  // [nv-1][64] step s <-> i = nv-1-s : address of L[i][j] for j = lane (low 16) and lane+64 (high 16)
     const unsigned int* sol_fwd;   // [nv-1][64] step s <-> j = s      : address of L[i][j] for i = lane (low 16) and lane+64 (high 16)
     const unsigned int* chain;     // [nv][32] position q on the chain of dof i: (q-th dof from the root | LDS byte address of its L row << 16)

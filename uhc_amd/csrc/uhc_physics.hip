@@ -446,7 +446,7 @@ __device__ __forceinline__ double rcp_newton(double x) {
 // In-place L^T D L of the tree-sparse matrix in the LD buffer (same elimination order as MuJoCo's mj_factorM [MJ-ext]);
 // also dinv[i] = 1/D[i].  The updates of elimination step k,  LD[row(anc_a) + t] -= (LD[kk+a] / D_k) * LD[kk+a+t]  for
 // every ancestor a and offset t, depend on the tree only, so the host lays them out once as a flat program of groups
-// (DevTopo::fac_prog): per group a lane gets one 16-byte record with the ready LDS byte addresses of two updates of one step,
+// (DevTopo::fac_prog): per group a lane gets one 24-byte record with the ready LDS byte addresses of three updates of one step,
 // of that step's D_k and -- in the step's last group -- of its entry of row k to normalise.  The loop body is the same for every
 // group: no step bookkeeping, predicates, address arithmetic or branches (a wave-uniform branch costs 25-60 cycles with one wave
 // per SIMD; the earlier per-step version spent most of its ~1100 cycles per step on them).  Idle lanes read the zero slot and
@@ -461,18 +461,21 @@ __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld,
     double* LD = S + ld;
     char* SB = (char*)S + (FAST ? 0 : A.ld_delta);  // schedule addresses are byte offsets in the fast layout
     const unsigned int zero_adr = (unsigned)(A.lf.LD + T.nM) * 8u, dump_adr = zero_adr + 8u;
-    const uint4* pg = (const uint4*)T.fac_prog + LANE;
-    uint4 cur = pg[0];
+    struct FacRec { unsigned int fr[3], o01, o2n, dk; };
+    const FacRec* pg = (const FacRec*)T.fac_prog + LANE;
+    FacRec cur = pg[0];
     for (int g = 0; g < T.fac_nslot; g++) {
-        const uint4 nxt = pg[(size_t)(g + 1) * UHC_WAVE];  // the table carries two groups of slack
-        const unsigned int nr = cur.w >> 16;
-        const double Dk = lds_at(SB, cur.w & 0xffffu);
-        const double f0 = lds_at(SB, cur.x & 0xffffu), r0 = lds_at(SB, cur.x >> 16), o0 = lds_at(SB, cur.z & 0xffffu);
-        const double f1 = lds_at(SB, cur.y & 0xffffu), r1 = lds_at(SB, cur.y >> 16), o1 = lds_at(SB, cur.z >> 16);
+        const FacRec nxt = pg[(size_t)(g + 1) * UHC_WAVE];  // the table carries two groups of slack
+        const unsigned int nr = cur.o2n >> 16;
+        const unsigned int oa[3] = {cur.o01 & 0xffffu, cur.o01 >> 16, cur.o2n & 0xffffu};
+        const double Dk = lds_at(SB, cur.dk);
+        double f[3], r[3], o[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { f[q] = lds_at(SB, cur.fr[q] & 0xffffu); r[q] = lds_at(SB, cur.fr[q] >> 16); o[q] = lds_at(SB, oa[q]); }
         const double fraw = lds_at(SB, nr);
         const double inv = rcp_newton(Dk);  // on the group-to-group critical path: 1 / D_k feeds every store
-        *(double*)(SB + (cur.z & 0xffffu)) = fma(-(f0 * inv), r0, o0);
-        *(double*)(SB + (cur.z >> 16)) = fma(-(f1 * inv), r1, o1);
+#pragma unroll
+        for (int q = 0; q < 3; q++) *(double*)(SB + oa[q]) = fma(-(f[q] * inv), r[q], o[q]);
         *(double*)(SB + (nr == zero_adr ? dump_adr : nr)) = fraw * inv;
         cur = nxt;
     }
