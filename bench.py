@@ -2,7 +2,7 @@
 
 A "step" is one control step of EVERY environment of the batch, exactly as a training rollout performs it:
 observation filter -> policy MLP forward (sampling) -> PD-target gather -> fused physics kernel (15 substeps of
-stable-PD, residual force, forward dynamics, PGS contact solve, Euler) -> termination, imitation reward and next
+stable-PD, residual force, forward dynamics, contact solve, Euler) -> termination, imitation reward and next
 observation -> rollout-buffer writes -> reset of finished episodes (new clip window, set_state, forward).
 Workload = BASELINE.json configs[1]: copycat config, 1024 batched envs per GPU, synthetic clips.
 value = env-steps/s summed over all ranks (weak scaling: envs shard across ranks, no data-path collective).
@@ -36,7 +36,8 @@ def pmc_traffic():
     import re
     tot, src = 0.0, []
     for kind in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.txt")))
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.txt")),
+                       key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r01_v12 after r01_v9
         if not files:
             return None, None
         for line in open(files[-1]):
