@@ -433,9 +433,6 @@ __device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
     c.pk1 = c.m1 | (c.d1 << 16) | ((c.v1 ? c.n1 : 0) << 24);
     return c;
 }
-__device__ __forceinline__ int pk_of(const LaneConst& c, int i) {  // i wave-uniform
-    return i < UHC_WAVE ? __builtin_amdgcn_readlane(c.pk0, i) : __builtin_amdgcn_readlane(c.pk1, i - UHC_WAVE);
-}
 
 // 1 / x to full double precision: v_rcp_f64 + two Newton steps (~35 cycles; the IEEE division sequence with its scale / fixup costs ~77)
 __device__ __forceinline__ double rcp_newton(double x) {
@@ -452,7 +449,6 @@ __device__ __forceinline__ double rcp_newton(double x) {
 // per SIMD; the earlier per-step version spent most of its ~1100 cycles per step on them).  Idle lanes read the zero slot and
 // write the dump slot.  The LDS queue of one wave is in order, so consecutive groups and steps need no barrier; the record of
 // the next group streams in from L2 meanwhile.
-struct FacWord { unsigned int a, o; };
 __device__ __forceinline__ double lds_at(const char* SB, unsigned int byte_off) { return *(const double*)(SB + byte_off); }
 template <bool FAST>
 __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld, const LaneConst& LC) {
@@ -491,7 +487,6 @@ __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld,
 // host tables sol_back / sol_fwd hold its LDS address (or the zero slot) for both of the lane's dofs; the words of
 // the next block of U steps are fetched while the current block runs, the block's L entries are read up front.
 struct DofVec { double a, b; };
-__device__ __forceinline__ double dv_get(const DofVec& x, int i) { return i < UHC_WAVE ? bcast(x.a, i) : bcast(x.b, i - UHC_WAVE); }
 // dv_get without control flow: both halves are read and the words selected with scalar logic (a uniform branch costs 25-60 cycles
 // here, and this sits on the step-to-step chain of the substitutions)
 __device__ __forceinline__ double dv_get_nb(const DofVec& x, int i) {  // i wave-uniform, 0 <= i < 128
