@@ -253,3 +253,42 @@ def test_meta_pd_gains_follow_the_residual_block(model, standing):
         o.set_state(qpos, rng.normal(size=75) * 0)
         tq.append(o.pd_torque(np.r_[joint, rng.normal(size=nvf), meta], standing["qpos"][7:], 7).copy())
     np.testing.assert_array_equal(tq[0], tq[1])
+
+
+def test_active_set_solver_satisfies_kkt_exactly_and_is_path_independent(model, standing):
+    """Oracle solver 1 (block principal pivoting on the dual QP): the result satisfies the KKT conditions of
+    min 1/2 f'Af + f'b, f >= 0 to rounding (f >= 0, y = Af + b >= 0, f.y = 0) -- which tolerance-terminated sweeps do not --,
+    agrees with Gauss-Seidel run far beyond its tolerance, and needs only a few factorisation rounds."""
+    import dataclasses
+    from oracle.physics import OracleSim
+    from uhc_amd.sim import make_ctrl
+    rng = np.random.default_rng(12)
+    exact = dataclasses.replace(model, solver=1)
+    sweeps = dataclasses.replace(model, solver=0, iterations=100)
+    long_sweeps = dataclasses.replace(model, solver=0, iterations=40000, tolerance=1e-18)
+    ctrl = make_ctrl(model)
+    checked = 0
+    for trial in range(6):
+        qpos = standing["qpos"].copy()
+        qpos[7:] += rng.normal(scale=0.1, size=69)
+        qvel = rng.normal(scale=0.5, size=75)
+        se, sp, sl = OracleSim(exact, ctrl), OracleSim(sweeps, ctrl), OracleSim(long_sweeps, ctrl)
+        for s in (se, sp, sl):
+            s.set_state(qpos, qvel)
+        n = se.geti("nefc")
+        if n == 0:
+            continue
+        A, b = se.get("efc_AR").reshape(n, n), se.get("efc_b")
+        f = se.get("efc_force")
+        y = A @ f + b
+        scale = np.abs(b).max()
+        assert (f >= 0).all() and y.min() > -1e-10 * scale and np.abs(f * y).max() < 1e-10 * scale * max(f.max(), 1.0)
+        assert 1 <= se.geti("solver_iter") <= 10
+        # sweeps at MuJoCo's defaults stop short of the optimum; sweeps run to exhaustion reach it
+        fp, fl = sp.get("efc_force"), sl.get("efc_force")
+        assert np.abs(fl - f).max() < 1e-7 * (1 + np.abs(f).max())
+        yp = A @ fp + b
+        assert np.abs(fp * yp).max() > 1e-9 * scale or np.abs(fp - f).max() > 1e-7
+        np.testing.assert_allclose(sl.get("qacc"), se.get("qacc"), atol=1e-6)
+        checked += 1
+    assert checked >= 4
