@@ -1,7 +1,7 @@
 """Build-container-only helper: import the (pure-Python) reference from /root/reference with stub
 modules standing in for the third-party packages this image lacks (mujoco_py, gym, smplx, ...).
-Used ONLY by tools/gen_golden.py to produce input/output vectors; nothing under tests/, bench.py or
-the package imports this."""
+Used by tools/gen_golden.py to produce input/output vectors and by tests/test_reference_live.py (skipped wherever
+/root/reference is absent); bench.py, the GPU tests and the package never import this."""
 import importlib.abc
 import importlib.machinery
 import os
