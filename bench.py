@@ -254,12 +254,12 @@ def main():
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
                          # the bound that matters: float64 vector issue/latency.  ~20 MFLOP per env-step (factorisations,
-                         # substitutions, Delassus rows, 100 PGS sweeps, tree recursions) against the 78.6 TFLOP/s FP64 vector peak
+                         # substitutions, Delassus rows, contact solve, tree recursions) against the 78.6 TFLOP/s FP64 vector peak
                          "alu_f64": {"est_flop_per_env_step": 20e6, "achieved_tflops": 20e6 * n_env / (kern_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
                                      "frac": 20e6 * n_env / (kern_ms * 1e-3) / 78.6e12},
                          "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
                                  "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
-                                 "above the algorithmic bytes is the L2-resident schedule tables and the per-substep mass-matrix work row"},
+                                 "above the algorithmic bytes is L2 misses of the schedule tables / kernel code and register spills to scratch"},
             "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int(env.sim.field(S.F_REDO).sum().item()),
                                "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
                                "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
