@@ -135,8 +135,34 @@ def cpu_ppo_baseline(agent, batch):
     return {"ppo_value": n / (10 * el), "ppo_unit": "samples/s (10-epoch full-batch update)", "ppo_sample": f"{k} epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the env, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Under
+    `python -m torch.distributed.run` WORLD_SIZE is already set and this is skipped."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,10 +235,13 @@ def main():
     iters = env.sim.field(S.F_SOLVER_ITER).cpu().numpy()
     overflow = int(env.sim.field(S.F_EFC_OVERFLOW).sum().item())
     batch, logger = agent.rollout_end()
+    per_rank = [n_env * args.steps / elapsed]
     if dist_on:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        td.all_gather(allt, tt)
+        per_rank = [n_env * args.steps / float(x.item()) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)  # the job is as fast as its slowest rank
     # ---- one PPO update over the collected samples (outside the timed region of `value`)
     ppo = None
     if not args.no_ppo:
@@ -243,7 +272,7 @@ def main():
         traffic, traffic_src = pmc_traffic() if n_env == 1024 else (None, None)
         out = {
             "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "n_gpus": world, "per_rank_env_steps_per_s": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "

@@ -426,6 +426,209 @@ static void collide_plane_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2
         }
     }
 }
+/* ---- convex-convex narrow phase: Minkowski Portal Refinement.
+ * [MJ-ext] MuJoCo 2.1.0 sends mesh-mesh (and every other pair without an analytic routine) through mjc_Convex, i.e. libccd's
+ * ccdMPRPenetration (libccd src/mpr.c, double precision build: CCD_EPS = DBL_EPSILON) with its own support / centre callbacks:
+ *   centre  = geom_xpos (for a mesh: the hull's centre of mass),
+ *   support = the hull vertex with the largest dot product with the direction (first maximum wins) + dir * margin / 2,
+ *   tolerance = opt.mpr_tolerance (1e-6), iteration cap = opt.mpr_iterations (50),
+ * and turns (depth, dir, pos) into ONE contact: dist = margin - depth, normal = dir (from geom 1 to geom 2), pos = the mid point of
+ * the two witness points.  Restated from libccd's published algorithm (G. Snethen, "XenoCollide", Game Programming Gems 7); the
+ * structure (discoverPortal / refinePortal / findPenetr / findPos, the zero and equality tests) follows libccd so that the same
+ * portal is found, but nothing here is pinned against MuJoCo. */
+#define CCD_EPS 2.220446049250313e-16
+#define MPR_TOLERANCE 1e-6
+#define MPR_MAXIT 50
+typedef struct { double v[3], v1[3], v2[3]; } CcdSup; /* a point of the Minkowski difference and its two witnesses */
+typedef struct { const UhcModelDesc* m; const OrcData* d; int g1, g2; double margin; } CcdPair;
+static int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
+static int ccd_eq(double a, double b) {
+    double ab = fabs(a - b);
+    if (ab < CCD_EPS) return 1;
+    a = fabs(a); b = fabs(b);
+    return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
+}
+static void v3sub(double r[3], const double a[3], const double b[3]) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static void v3norm(double a[3]) { double n = sqrt(dot3(a, a)); a[0] /= n; a[1] /= n; a[2] /= n; }
+static void mesh_support(const UhcModelDesc* m, const OrcData* d, int g, const double dir[3], double margin, double out[3]) {
+    int b = m->geom_bodyid[g], va = m->geom_vertadr[g], vn = m->geom_vertnum[g], best = va;
+    const double* R = d->xmat + 9 * b;
+    double loc[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
+                     R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]}; /* R^T dir */
+    double bd = -1e300;
+    for (int v = va; v < va + vn; v++) {
+        double s = dot3(loc, m->mesh_vert + 3 * v);
+        if (s > bd) { bd = s; best = v; }
+    }
+    mat_vec(out, R, m->mesh_vert + 3 * best);
+    for (int k = 0; k < 3; k++) out[k] += d->xpos[3 * b + k] + dir[k] * 0.5 * margin;
+}
+static void geom_centre(const UhcModelDesc* m, const OrcData* d, int g, double out[3]) {
+    int b = m->geom_bodyid[g];
+    mat_vec(out, d->xmat + 9 * b, m->geom_center + 3 * g);
+    for (int k = 0; k < 3; k++) out[k] += d->xpos[3 * b + k];
+}
+static void ccd_support(const CcdPair* P, const double dir[3], CcdSup* s) {
+    double nd[3] = {-dir[0], -dir[1], -dir[2]};
+    mesh_support(P->m, P->d, P->g1, dir, P->margin, s->v1);
+    mesh_support(P->m, P->d, P->g2, nd, P->margin, s->v2);
+    v3sub(s->v, s->v1, s->v2);
+}
+static void portal_dir(const CcdSup p[4], double dir[3]) {
+    double a[3], b[3];
+    v3sub(a, p[2].v, p[1].v); v3sub(b, p[3].v, p[1].v);
+    cross3(dir, a, b);
+    v3norm(dir);
+}
+static int portal_reach_tolerance(const CcdSup p[4], const CcdSup* v4, const double dir[3]) {
+    double dv1 = dot3(p[1].v, dir), dv2 = dot3(p[2].v, dir), dv3 = dot3(p[3].v, dir), dv4 = dot3(v4->v, dir);
+    double d1 = dv4 - dv1, d2 = dv4 - dv2, d3 = dv4 - dv3;
+    d1 = fmin(d1, d2); d1 = fmin(d1, d3);
+    return ccd_eq(d1, MPR_TOLERANCE) || d1 < MPR_TOLERANCE;
+}
+static void expand_portal(CcdSup p[4], const CcdSup* v4) {
+    double v4v0[3];
+    cross3(v4v0, v4->v, p[0].v);
+    if (dot3(p[1].v, v4v0) > 0) {
+        if (dot3(p[2].v, v4v0) > 0) p[1] = *v4; else p[3] = *v4;
+    } else {
+        if (dot3(p[3].v, v4v0) > 0) p[2] = *v4; else p[1] = *v4;
+    }
+}
+static double point_seg_dist2(const double x0[3], const double b[3], double w[3]) { /* from the origin */
+    double dd[3], t;
+    v3sub(dd, b, x0);
+    t = -dot3(x0, dd) / dot3(dd, dd);
+    if (t < 0 || ccd_zero(t)) memcpy(w, x0, 24);
+    else if (t > 1 || ccd_eq(t, 1)) memcpy(w, b, 24);
+    else for (int k = 0; k < 3; k++) w[k] = dd[k] * t + x0[k];
+    return dot3(w, w);
+}
+static double point_tri_dist2(const double x0[3], const double B[3], const double C[3], double w[3]) { /* from the origin */
+    double d1[3], d2[3], v, ww, p, q, r, s, t, dist, dist2, w2[3];
+    v3sub(d1, B, x0); v3sub(d2, C, x0);
+    v = dot3(d1, d1); ww = dot3(d2, d2); p = dot3(x0, d1); q = dot3(x0, d2); r = dot3(d1, d2);
+    s = (q * r - ww * p) / (ww * v - r * r);
+    t = (-s * r - q) / ww;
+    if ((ccd_zero(s) || s > 0) && (ccd_eq(s, 1) || s < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + s, 1) || t + s < 1)) {
+        for (int k = 0; k < 3; k++) w[k] = x0[k] + d1[k] * s + d2[k] * t;
+        return dot3(w, w);
+    }
+    dist = point_seg_dist2(x0, B, w);
+    dist2 = point_seg_dist2(x0, C, w2);
+    if (dist2 < dist) { dist = dist2; memcpy(w, w2, 24); }
+    dist2 = point_seg_dist2(B, C, w2);
+    if (dist2 < dist) { dist = dist2; memcpy(w, w2, 24); }
+    return dist;
+}
+static void find_pos(const CcdSup p[4], double pos[3]) {
+    double dir[3], b[4], vec[3], sum, inv, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+    portal_dir(p, dir);
+    cross3(vec, p[1].v, p[2].v); b[0] = dot3(vec, p[3].v);
+    cross3(vec, p[3].v, p[2].v); b[1] = dot3(vec, p[0].v);
+    cross3(vec, p[0].v, p[1].v); b[2] = dot3(vec, p[3].v);
+    cross3(vec, p[2].v, p[1].v); b[3] = dot3(vec, p[0].v);
+    sum = b[0] + b[1] + b[2] + b[3];
+    if (ccd_zero(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(vec, p[2].v, p[3].v); b[1] = dot3(vec, dir);
+        cross3(vec, p[3].v, p[1].v); b[2] = dot3(vec, dir);
+        cross3(vec, p[1].v, p[2].v); b[3] = dot3(vec, dir);
+        sum = b[1] + b[2] + b[3];
+    }
+    inv = 1.0 / sum;
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++) { p1[k] += p[i].v1[k] * b[i]; p2[k] += p[i].v2[k] * b[i]; }
+    for (int k = 0; k < 3; k++) pos[k] = (p1[k] * inv + p2[k] * inv) * 0.5;
+}
+/* 0: penetration found (depth, dir, pos);  -1: the (inflated) hulls are apart */
+static int mpr_penetration(const CcdPair* P, double* depth, double dir[3], double pos[3]) {
+    CcdSup p[4], v4;
+    double va[3], vb[3], dt;
+    int size;
+    /* ---- discoverPortal */
+    geom_centre(P->m, P->d, P->g1, p[0].v1); geom_centre(P->m, P->d, P->g2, p[0].v2);
+    v3sub(p[0].v, p[0].v1, p[0].v2);
+    if (ccd_eq(p[0].v[0], 0) && ccd_eq(p[0].v[1], 0) && ccd_eq(p[0].v[2], 0)) p[0].v[0] += CCD_EPS * 10;
+    for (int k = 0; k < 3; k++) dir[k] = -p[0].v[k];
+    v3norm(dir);
+    ccd_support(P, dir, &p[1]);
+    dt = dot3(p[1].v, dir);
+    if (ccd_zero(dt) || dt < 0) return -1;
+    cross3(dir, p[0].v, p[1].v);
+    if (ccd_zero(dot3(dir, dir))) {
+        if (ccd_eq(p[1].v[0], 0) && ccd_eq(p[1].v[1], 0) && ccd_eq(p[1].v[2], 0)) { /* origin on v1: touching contact */
+            *depth = 0; dir[0] = dir[1] = dir[2] = 0;
+        } else { /* origin on the segment v0-v1 */
+            *depth = sqrt(dot3(p[1].v, p[1].v));
+            memcpy(dir, p[1].v, 24); v3norm(dir);
+        }
+        for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p[1].v1[k] + p[1].v2[k]);
+        return 0;
+    }
+    v3norm(dir);
+    ccd_support(P, dir, &p[2]);
+    dt = dot3(p[2].v, dir);
+    if (ccd_zero(dt) || dt < 0) return -1;
+    v3sub(va, p[1].v, p[0].v); v3sub(vb, p[2].v, p[0].v);
+    cross3(dir, va, vb); v3norm(dir);
+    if (dot3(dir, p[0].v) > 0) { CcdSup t = p[1]; p[1] = p[2]; p[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+    size = 3;
+    while (size < 4) {
+        int cont = 0;
+        ccd_support(P, dir, &v4);
+        dt = dot3(v4.v, dir);
+        if (ccd_zero(dt) || dt < 0) return -1;
+        cross3(va, p[1].v, v4.v);
+        dt = dot3(va, p[0].v);
+        if (dt < 0 && !ccd_zero(dt)) { p[2] = v4; cont = 1; }
+        if (!cont) {
+            cross3(va, v4.v, p[2].v);
+            dt = dot3(va, p[0].v);
+            if (dt < 0 && !ccd_zero(dt)) { p[1] = v4; cont = 1; }
+        }
+        if (cont) {
+            v3sub(va, p[1].v, p[0].v); v3sub(vb, p[2].v, p[0].v);
+            cross3(dir, va, vb); v3norm(dir);
+        } else { p[3] = v4; size = 4; }
+    }
+    /* ---- refinePortal */
+    for (;;) {
+        portal_dir(p, dir);
+        dt = dot3(dir, p[1].v);
+        if (ccd_zero(dt) || dt > 0) break; /* the portal encapsulates the origin */
+        ccd_support(P, dir, &v4);
+        dt = dot3(v4.v, dir);
+        if (!(ccd_zero(dt) || dt > 0) || portal_reach_tolerance(p, &v4, dir)) return -1;
+        expand_portal(p, &v4);
+    }
+    /* ---- findPenetr */
+    for (unsigned long it = 0;; it++) {
+        portal_dir(p, dir);
+        ccd_support(P, dir, &v4);
+        if (portal_reach_tolerance(p, &v4, dir) || it > MPR_MAXIT) {
+            double pd[3];
+            *depth = sqrt(point_tri_dist2(p[1].v, p[2].v, p[3].v, pd));
+            if (ccd_zero(pd[0]) && ccd_zero(pd[1]) && ccd_zero(pd[2])) memcpy(pd, dir, 24);
+            v3norm(pd);
+            memcpy(dir, pd, 24);
+            find_pos(p, pos);
+            return 0;
+        }
+        expand_portal(p, &v4);
+    }
+}
+static void collide_mesh_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2, double margin, double gap) {
+    double c1[3], c2[3], dc[3], depth, dir[3], pos[3];
+    geom_centre(m, d, g1, c1); geom_centre(m, d, g2, c2);
+    v3sub(dc, c1, c2);
+    double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+    if (dot3(dc, dc) > bound * bound) return; /* [MJ-ext] mj_collideGeoms bounding-sphere filter */
+    CcdPair P = {m, d, g1, g2, margin};
+    if (mpr_penetration(&P, &depth, dir, pos)) return;
+    if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return; /* normal undefined (mjc_MPRIteration) */
+    add_contact(m, d, g1, g2, pos, dir, margin - depth, margin - gap);
+}
 void orc_collision(const UhcModelDesc* m, OrcData* d) {
     d->ncon = 0;
     for (int g1 = 0; g1 < m->ngeom; g1++)
@@ -438,7 +641,7 @@ void orc_collision(const UhcModelDesc* m, OrcData* d) {
             int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
             if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g1, g2, margin, gap);
             else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g2, g1, margin, gap);
-            /* mesh-mesh (self-collision of generated models) is a later row: SURVEY.md 8a P4 */
+            else if (t1 == UHC_GEOM_MESH && t2 == UHC_GEOM_MESH) collide_mesh_mesh(m, d, g1, g2, margin, gap);
         }
 }
 
@@ -803,9 +1006,30 @@ void orc_forward(const UhcModelDesc* m, OrcData* d) {
     orc_solve_constraints(m, d);
 }
 static int bad(double x) { return isnan(x) || x > MAXVAL || x < -MAXVAL; }
-void orc_euler(const UhcModelDesc* m, OrcData* d) { /* P10: mj_Euler (no joint damping -> explicit in qacc) */
+void orc_euler(const UhcModelDesc* m, OrcData* d) {
+    /* P10: [MJ-ext] mj_Euler.  Without joint damping the velocity update uses qacc as is.  With any dof_damping > 0 the damping
+     * force is integrated implicitly: (M + h diag(B)) a = qfrc_smooth + qfrc_constraint (qfrc_smooth already holds the explicit
+     * -B v of mj_passive), v += h a.  d->qacc itself -- what the next step's warm start and the acceleration check see -- stays
+     * the explicit one.  The reference reaches this branch whenever a config sets joint damping (humanoid_im.py:221-224,
+     * config/copycat_ball/copycat_ball_1.yml:104-113). */
     double h = m->timestep;
-    for (int i = 0; i < m->nv; i++) d->qvel[i] += h * d->qacc[i];
+    int damped = 0;
+    for (int i = 0; i < m->nv; i++) damped |= m->dof_damping[i] > 0;
+    if (!damped) {
+        for (int i = 0; i < m->nv; i++) d->qvel[i] += h * d->qacc[i];
+    } else {
+        double* MhB = (double*)malloc((size_t)d->nM * 8);
+        double* a = (double*)malloc((size_t)m->nv * 8);
+        memcpy(MhB, d->qM, (size_t)d->nM * 8);
+        for (int i = 0; i < m->nv; i++) {
+            MhB[m->dof_madr[i]] += h * m->dof_damping[i];
+            a[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+        }
+        orc_factor_sparse(m, MhB);
+        orc_solve_sparse(m, MhB, a);
+        for (int i = 0; i < m->nv; i++) d->qvel[i] += h * a[i];
+        free(MhB); free(a);
+    }
     for (int j = 0; j < m->njnt; j++) {
         int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
         switch (m->jnt_type[j]) {

@@ -16,9 +16,9 @@ sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
 import numpy as np
 import torch
 
-from uhc_amd.agents import agent_dict
-from uhc_amd.utils.config_utils.copycat_config import Config
-from uhc_amd.utils.flags import flags
+from uhc.agents import agent_dict  # the reference's import paths (scripts/train_uhc.py:30-32), served by uhc/__init__.py -> uhc_amd
+from uhc.utils.config_utils.copycat_config import Config
+from uhc.utils.flags import flags
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
@@ -35,6 +35,8 @@ if __name__ == "__main__":
     parser.add_argument("--full_eval", action="store_true", default=False)
     parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic clips instead of data_specs.file_path")
     parser.add_argument("--num_epoch", type=int, default=None)
+    parser.add_argument("--n_env", type=int, default=None, help="batched environments per GPU (default: the config's; 1 = the reference's single-env plumbing case)")
+    parser.add_argument("--min_batch_size", type=int, default=None, help="samples per iteration (default: the config's)")
     args = parser.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -44,11 +46,13 @@ if __name__ == "__main__":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     cfg = Config(cfg_id=args.cfg, create_dirs=not (args.render or args.epoch > 0))
-    num_epoch = args.num_epoch
-    delattr(args, "num_epoch")
+    over = {k: getattr(args, k) for k in ("num_epoch", "n_env", "min_batch_size")}
+    for k in over:
+        delattr(args, k)
     cfg.update(args)
-    if num_epoch is not None:
-        cfg.num_epoch = num_epoch
+    for k, v in over.items():
+        if v is not None:
+            setattr(cfg, k, v)
     flags.debug = args.debug
     if not cfg.no_log:
         try:

@@ -16,6 +16,19 @@ def box_triangles(hx, hy, hz, center=(0, 0, 0)):
     return np.array(tris)
 
 
+def prism_triangles(r, h):
+    """Upright prism over an equilateral triangle (circumradius r, half height h): its three bottom corners are mutual hull
+    neighbours, so it rests level on exactly three contacts."""
+    a = np.array([[r * np.cos(t), r * np.sin(t)] for t in (np.pi / 2, np.pi / 2 + 2 * np.pi / 3, np.pi / 2 + 4 * np.pi / 3)])
+    lo = [np.r_[p, -h] for p in a]
+    hi = [np.r_[p, h] for p in a]
+    tris = [[lo[0], lo[2], lo[1]], [hi[0], hi[1], hi[2]]]
+    for i in range(3):
+        j = (i + 1) % 3
+        tris += [[lo[i], lo[j], hi[j]], [lo[i], hi[j], hi[i]]]
+    return np.array(tris)
+
+
 PENDULUM_XML = """
 <mujoco>
   <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
@@ -58,3 +71,57 @@ def pendulum_model(length=0.5, half=0.05):
 def box_model(half=0.1):
     from uhc_amd.model.mjcf import compile_mjcf
     return compile_mjcf(BOX_ON_PLANE_XML, meshes={"box": box_triangles(half, half, half)})
+
+
+def hull_triangles(verts):
+    """Outward-oriented triangles of the convex hull of a vertex set (the compiled Model keeps hull vertices, not faces)."""
+    from scipy.spatial import ConvexHull
+    h = ConvexHull(verts)
+    tris = verts[h.simplices].copy()
+    n = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+    flip = np.einsum("ij,ij->i", n, h.equations[:, :3]) < 0
+    tris[flip] = tris[flip][:, ::-1]
+    return tris
+
+
+def weld_statue(model, qpos, *, friction=None, extra_geom_attr=""):
+    """The articulated humanoid frozen in the pose `qpos` as ONE free rigid body carrying all of its hulls (a statue): what is left
+    of the model when every hinge is welded.  Used by the behavioural contact tests: a statue whose centre of mass projects well
+    inside its support polygon has to keep standing, whatever the controller would do."""
+    from uhc_amd.model.mjcf import compile_mjcf, kinematics_np, quat_to_mat
+    xpos, xquat, _, _ = kinematics_np(model, np.asarray(qpos, dtype=np.float64))
+    Rr, pr = quat_to_mat(xquat[1]), xpos[1]
+    meshes, geoms = {}, []
+    for g in range(model.ngeom):
+        if model.geom_type[g] != 7:
+            continue
+        b = model.geom_bodyid[g]
+        v = model.mesh_vert[model.geom_vertadr[g]:model.geom_vertadr[g] + model.geom_vertnum[g]]
+        w = v @ quat_to_mat(xquat[b]).T + xpos[b]          # world
+        meshes[f"h{g}"] = hull_triangles((w - pr) @ Rr)      # root-body frame
+        geoms.append(f'<geom type="mesh" mesh="h{g}" {extra_geom_attr}/>')
+    fr = "" if friction is None else f'friction="{friction} 0.005 0.0001"'
+    xml = f"""
+<mujoco>
+  <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
+  <option timestep="{model.timestep}"/>
+  <default><geom contype="0" conaffinity="1" condim="1" margin="0.001"/></default>
+  <asset>{''.join(f'<mesh name="{k}" file="unused.stl"/>' for k in meshes)}</asset>
+  <worldbody>
+    <geom name="floor" type="plane" size="10 10 0.1" pos="0 0 0" contype="1" conaffinity="1" condim="3" {fr}/>
+    <body name="statue" pos="{pr[0]} {pr[1]} {pr[2]}" quat="{xquat[1][0]} {xquat[1][1]} {xquat[1][2]} {xquat[1][3]}">
+      <joint name="root" type="free"/>
+      {''.join(geoms)}
+    </body>
+  </worldbody>
+</mujoco>
+"""
+    return compile_mjcf(xml, meshes=meshes)
+
+
+def passive_ctrl(model, n_substeps=1):
+    """Controller description of an unactuated / torque-driven model for SimBatch: action = raw torques (none when nu == 0)."""
+    from uhc_amd._capi import ctrl_desc
+    nu = max(int(model.nu), 1)
+    return ctrl_desc(n_substeps=n_substeps, action_type=1, meta_pd=0, rfc_mode=0, action_dim=nu, jkp=np.zeros(nu), jkd=np.zeros(nu),
+                     torque_lim=np.full(nu, 1e9), a_scale=np.full(nu, 0.01))

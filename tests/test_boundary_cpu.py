@@ -1,0 +1,29 @@
+"""CPU: the reference's import surface resolves (the `uhc` alias package), with the reference's registry keys and call signatures."""
+import inspect
+
+
+def test_reference_import_paths_resolve_to_this_build():
+    import uhc_amd.agents
+    import uhc_amd.agents.agent_copycat as real
+    from uhc.agents import agent_dict                     # scripts/train_uhc.py:32
+    from uhc.agents.agent_copycat import AgentCopycat     # scripts/train_uhc.py:90
+    from uhc.data_loaders.dataset_amass_single import DatasetAMASSSingle
+    from uhc.envs import env_dict
+    from uhc.khrylib.rl.core import PolicyGaussian, Value, estimate_advantages  # noqa: F401
+    from uhc.khrylib.utils.zfilter import ZFilter  # noqa: F401
+    from uhc.smpllib.smpl_mujoco import SMPLConverter, smpl_to_qpose  # noqa: F401
+    from uhc.utils.config_utils.copycat_config import Config  # scripts/train_uhc.py:31
+    from uhc.utils.flags import flags  # noqa: F401
+    assert agent_dict is uhc_amd.agents.agent_dict and AgentCopycat is real.AgentCopycat
+    assert set(agent_dict) == {"agent_copycat"} and set(env_dict) == {"humanoid_im"}
+    # constructor / method signatures the reference's callers rely on (agent_copycat.py:55, humanoid_im.py:49, dataset_amass_single.py)
+    assert list(inspect.signature(AgentCopycat.__init__).parameters)[:6] == ["self", "cfg", "dtype", "device", "training", "checkpoint_epoch"]
+    assert list(inspect.signature(env_dict["humanoid_im"].__init__).parameters)[:6] == ["self", "cfg", "init_expert", "data_specs", "mode", "no_root"]
+    assert list(inspect.signature(DatasetAMASSSingle.sample_seq).parameters)[:6] == ["self", "full_sample", "freq_dict", "sampling_temp", "sampling_freq", "precision_mode"]
+    for name in ("reset", "step", "load_expert", "set_mode", "seed", "get_expert_attr", "get_expert_index", "get_wbody_pos", "get_world_vf", "fail_safe",
+                 "get_ee_pos", "get_body_quat", "get_com", "get_humanoid_qpos"):
+        assert callable(getattr(env_dict["humanoid_im"], name)), name
+    assert Config.__module__ == "uhc_amd.utils.config_utils.copycat_config"
+    import pytest
+    with pytest.raises(ModuleNotFoundError):
+        import uhc.no_such_module  # noqa: F401

@@ -38,7 +38,8 @@ def test_agent_iteration_and_checkpoint_roundtrip(tmp_path):
     assert log.num_steps == 64 * 8 and 0.0 < log.avg_c_reward <= 1.0 and np.isfinite(log.avg_c_info).all()
     # reset observation + 8 steps per env, + one reset observation per evaluated clip (eval runs after the checkpoint is
     # written and filters its first observation with update=True, agent_copycat.py:445-446)
-    assert agent.running_state.rs.n == 64 * 9 + 6
+    # ... + the last observation of every episode that finished inside the pass (agent.py:77-79 filters it too)
+    assert agent.running_state.rs.n == 64 * 9 + 6 + log.num_episodes
     changed = [k for k, v in agent.policy_net.state_dict().items() if not torch.equal(v, before[k])]
     assert "action_mean.weight" in changed and "action_log_std" not in changed  # fix_std
     # standing clips + noise actions: nothing blows up
@@ -191,3 +192,92 @@ def test_fit_uhc_single_clip_loop(tmp_path):
     assert sorted(os.listdir(f"{cfg.model_dir}_singles")) == sorted(f"{k}.p" for k in keys)
     assert fit_uhc.fit(agent, 0, 3, log=lines.append) == {}  # everything is done: nothing left to fit
     agent.env.close()
+
+
+def test_episodes_continue_across_sampling_passes(tmp_path):
+    """An episode cut by the end of a sampling pass goes on in the next pass (the reference runs every episode to fail / end): the
+    env's frame counter keeps counting, long windows get finished and recorded, and the logged reward is the plain imitation reward."""
+    import torch
+    from uhc_amd.agents import agent_dict
+    from uhc_amd import sim as S
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path, n_env=16, batch=16 * 5)
+    cfg.save_n_epochs = 1000
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
+    agent.per_epoch_update(0)
+    agent.noise_rate = 0.0
+    agent.rollout_begin(5)
+    for _ in range(5):
+        agent.rollout_step()
+    t1 = agent.env.cur_t.cpu().numpy().copy()
+    plain = float(agent._ro.c_reward_sum.item()) / (16 * 5)
+    agent.value_net.value_head.bias.data.fill_(3.0)  # make the bootstrap visible: V(s_T) ~ 3
+    batch, log = agent.rollout_end()
+    assert float(batch.rewards.mean().item()) > plain + 0.1  # the bootstrap went into the samples ...
+    still = np.nonzero(batch.masks.reshape(16, 5)[:, :4].cpu().numpy().min(1) > 0)[0]  # envs whose first episode was still running
+    assert len(still) > 0 and (t1[still] == 5).all()
+    # the logged reward is the mean imitation reward: the gamma * V bootstrap folded into the last sample is not in it
+    assert log.avg_c_reward == pytest.approx(plain, rel=1e-12) and 0.0 < plain <= 1.0  # ... but not into the logged reward
+    n_before = agent.running_state.rs.n
+    agent.rollout_begin(5)  # second pass: continues
+    assert (agent.env.cur_t.cpu().numpy()[still] == 5).all()
+    assert agent.running_state.rs.n == n_before  # the observations the envs stopped at are not counted twice
+    agent.rollout_step()
+    t2 = agent.env.cur_t.cpu().numpy()
+    done = agent.env.done.cpu().numpy().astype(bool)
+    assert ((t2[still] == 6) | done[still] | (t2[still] == 0)).all() and (t2[still] == 6).any()
+    for _ in range(4):
+        agent.rollout_step()
+    agent.rollout_end()
+    agent.rollout_begin(3, fresh=True)  # an explicit restart assigns and resets every env
+    assert (agent.env.cur_t.cpu().numpy() == 0).all()
+    agent.env.close()
+
+
+def test_train_script_single_env_plumbing(tmp_path):
+    """BASELINE configs[0]: scripts/train_uhc.py end to end with ONE environment (the reference's shape: 1 env, python loop), through
+    the reference's import paths (`uhc.agents`, `uhc.utils.config_utils`)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_uhc.py"), "--cfg", "copycat_mi355x", "--synthetic", "4", "--num_epoch", "2",
+                          "--n_env", "1", "--min_batch_size", "64", "--no_log"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "training done!" in out.stdout
+    assert out.stderr.count("Ep: ") + out.stdout.count("Ep: ") >= 2
+
+
+def test_facade_accessors_match_device_fields(tmp_path):
+    """get_ee_pos / get_body_quat / get_com / fail_safe / prev_bquat of the single-env facade (humanoid_im.py:902-965) against the
+    device state they are read from."""
+    import torch
+    from uhc_amd.envs import env_dict
+    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
+    from uhc_amd.smpllib.smpl_mujoco import SMPL_EE_NAMES
+    from uhc_amd.utils.transformation import quaternion_from_euler
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path, n_env=1)
+    data = make_synthetic_amass(1, seed=9, t_range=(40, 50))
+    key = list(data.keys())[0]
+    clip = dict(data[key], seq_name=key)
+    env = env_dict["humanoid_im"](cfg, init_expert=clip, data_specs=cfg.data_specs, mode="test")
+    env.reset()
+    b0 = env.prev_bquat.copy()
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        env.step(rng.normal(scale=0.1, size=env.action_dim))
+    d = env.data
+    assert env.prev_bquat.shape == (96,) and not np.allclose(env.prev_bquat, b0)
+    bq = env.get_body_quat()
+    np.testing.assert_allclose(bq[:4], d.qpos[3:7])
+    np.testing.assert_allclose(bq[4:8], quaternion_from_euler(d.qpos[7], d.qpos[8], d.qpos[9], "rzyx"))
+    ee = env.get_ee_pos(None).reshape(5, 3)
+    for k, n in enumerate(SMPL_EE_NAMES):
+        np.testing.assert_allclose(ee[k], d.body_xpos[env.model.body_names.index(n)])
+    assert np.linalg.norm(env.get_ee_pos("root").reshape(5, 3), axis=1).max() < 1.5
+    np.testing.assert_allclose(env.get_com(), d.xipos[env.model.body_names.index("Pelvis")])
+    env.fail_safe()
+    t = env.cur_t
+    np.testing.assert_allclose(env.data.qpos, env.expert["qpos"][min(t, env.expert["len"] - 1)], atol=1e-12)
+    env.vec.close()

@@ -31,3 +31,19 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "env-steps/s" and "sample" in c
     assert d["ppo"]["samples"] == 64 * 6 and d["ppo"]["samples_per_s"] > 0
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two RCCL ranks itself (here both on GPU 0) and reports the whole job."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--steps", "4", "--warmup", "2", "--envs", "64",
+                          "--clips", "8"], cwd=ROOT, capture_output=True, text=True, timeout=1200,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_env_steps_per_s"]) == 2
+    assert d["value"] == pytest.approx(2 * 64 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
+    assert d["value"] <= sum(d["per_rank_env_steps_per_s"]) * (1 + 1e-9)
+    assert d["ppo"]["samples"] == 2 * 64 * 6 and d["ppo"]["allreduce"]["calls"] == 20 and d["ppo"]["allreduce"]["busbw_GBs"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only

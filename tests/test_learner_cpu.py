@@ -109,6 +109,27 @@ def test_zfilter_sequential_and_batched():
     np.testing.assert_allclose(z1.rs.var, [1.0, 4.0, 9.0])  # n == 1: var = mean^2 (zfilter.py:34-35)
 
 
+def test_zfilter_weighted_batch_push_equals_row_pushes():
+    """push_batch(weights=done) counts exactly the flagged rows (the last observation of a finished episode), with no host-side count."""
+    import torch
+    from uhc_amd.khrylib.utils.zfilter import ZFilter
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(40, 5)) * 3 + 1
+    w = rng.integers(0, 2, size=40)
+    a, b = ZFilter((5,), clip=5), ZFilter((5,), clip=5)
+    a(torch.from_numpy(x[:10]))
+    for r in x[:10]:
+        b(r)
+    a.rs.push_batch(torch.from_numpy(x[10:]), weights=torch.from_numpy(w[10:]))
+    a.rs.push_batch(torch.from_numpy(x[10:]), weights=torch.zeros(30))  # nothing flagged: a no-op
+    for r, wi in zip(x[10:], w[10:]):
+        if wi:
+            b(r)
+    assert a.rs.n == b.rs.n == 10 + int(w[10:].sum())
+    np.testing.assert_allclose(a.rs.mean, b.rs.mean, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a.rs.var, b.rs.var, rtol=1e-10)
+
+
 def test_dataset_sampling_interface():
     import random
     from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle

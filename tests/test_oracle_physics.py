@@ -292,3 +292,159 @@ def test_active_set_solver_satisfies_kkt_exactly_and_is_path_independent(model, 
         np.testing.assert_allclose(sl.get("qacc"), se.get("qacc"), atol=1e-6)
         checked += 1
     assert checked >= 4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Behavioural known-answer tests of the contact model and the integrator.  MuJoCo itself is absent, so these do
+# not pin the restatement to MuJoCo's numbers; they make it falsifiable: a mis-stated friction cone, reference acceleration,
+# regulariser or contact placement fails them.  tests/test_gpu_physics.py runs the same scenarios on the HIP path.
+# ---------------------------------------------------------------------------------------------------------------
+def scenario_tilted_gravity_box(tan_theta, hx=0.1, hz=0.02):
+    """Flat box (tumbles only beyond tan(theta) = hx / hz = 5) resting on the plane, gravity tilted by theta about y -- the same as
+    tilting the plane: returns (model, qpos0)."""
+    from uhc_amd.model.mjcf import compile_mjcf
+    from tests.helpers import BOX_ON_PLANE_XML, box_triangles
+    m = compile_mjcf(BOX_ON_PLANE_XML, meshes={"box": box_triangles(hx, hx, hz)})
+    th = np.arctan(tan_theta)
+    m.gravity = 9.81 * np.array([np.sin(th), 0.0, -np.cos(th)])
+    m.solver = 1
+    return m, np.array([0, 0, hz - 0.0003, 1, 0, 0, 0.0])
+
+
+@pytest.mark.parametrize("tan_theta,slides", [(0.8, False), (0.95, False), (1.1, True), (1.5, True)])
+def test_friction_cone_slip_threshold(tan_theta, slides):
+    """Coulomb threshold of the pyramidal cone along a pyramid axis: with mu = 1 (MuJoCo's default sliding friction) a box holds on
+    a slope of tan(theta) < mu and slides with a = g (sin(theta) - mu cos(theta)) beyond it.  The soft constraint lets a held box
+    creep (regularised friction), which bounds the 'holds' side from below."""
+    from oracle.physics import OracleSim
+    m, q0 = scenario_tilted_gravity_box(tan_theta)
+    s = OracleSim(m)
+    s.set_state(q0, np.zeros(6))
+    n = 500
+    for _ in range(n):
+        s.step()
+    t = n * m.timestep
+    x = s.get("qpos")[0]
+    th = np.arctan(tan_theta)
+    assert s.geti("fail") == 0 and abs(s.get("qpos")[2] - 0.02) < 1e-2  # still on the plane (a sliding box chatters on its corners)
+    if slides:
+        a = 9.81 * (np.sin(th) - 1.0 * np.cos(th))
+        assert x == pytest.approx(0.5 * a * t * t, rel=0.12)
+    else:
+        assert abs(x) < 0.02 * 0.5 * 9.81 * np.sin(th) * t * t  # < 2 % of the frictionless slide
+
+
+def scenario_pushed_box(force_frac, hx=0.05, hz=0.2):
+    """Tall box (half extents hx, hx, hz) on the plane, pushed horizontally at its centre: tips iff F hz > m g hx."""
+    from uhc_amd.model.mjcf import compile_mjcf
+    from tests.helpers import BOX_ON_PLANE_XML, box_triangles
+    m = compile_mjcf(BOX_ON_PLANE_XML, meshes={"box": box_triangles(hx, hx, hz)})
+    m.solver = 1
+    f = force_frac * m.body_mass[1] * 9.81 * hx / hz
+    return m, np.array([0, 0, hz - 0.0003, 1, 0, 0, 0.0]), np.array([f, 0, 0, 0, 0, 0.0])
+
+
+@pytest.mark.parametrize("force_frac,tips", [(0.8, False), (1.2, True)])
+def test_tipping_threshold_of_a_pushed_box(force_frac, tips):
+    """Torque balance of a multi-point support: the normal forces can shift to the leading edge and no further, so a horizontal push
+    at the centre of mass tips the box iff F h > m g a (friction mu = 1 > a / h keeps it from sliding first)."""
+    from oracle.physics import OracleSim
+    m, q0, push = scenario_pushed_box(force_frac)
+    s = OracleSim(m)
+    s.set_state(q0, np.zeros(6))
+    for _ in range(100):  # settle
+        s.step()
+    s.set("qfrc_applied", push)
+    for _ in range(400):
+        s.step()
+    w = s.get("qpos")[3]
+    tilt = 2 * np.arccos(min(1.0, abs(w)))
+    assert (tilt > 0.5) if tips else (tilt < 0.02)
+
+
+def test_resting_penetration_matches_the_solref_solimp_equilibrium():
+    """At rest (v = 0, J qacc = 0) every active pyramid edge carries f = (1 / R_py) k imp(r) (margin - r) with R_py = 2 mu^2 R_0,
+    R_0 = (1 - imp) / imp (1 + mu^2) (invweight_body + invweight_world) [MJ-ext mj_makeImpedance], k = 1 / (dmax^2 tc^2 dr^2); the edge forces add up to
+    the weight.  Solve that scalar equation for the penetration independently and compare with where the box actually rests."""
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import compile_mjcf
+    from tests.helpers import BOX_ON_PLANE_XML, prism_triangles
+    m = compile_mjcf(BOX_ON_PLANE_XML, meshes={"box": prism_triangles(0.1, 0.05)})  # rests level on its three bottom corners
+    m.solver = 1
+    s = OracleSim(m)
+    s.set_state(np.array([0, 0, 0.0499, 1, 0, 0, 0.0]), np.zeros(6))
+    for _ in range(1500):
+        s.step()
+    s.forward()
+    assert abs(s.get("qvel")).max() < 1e-6 and s.geti("ncon") == 3
+    f = s.get("efc_force")
+    dist = s.get("con_dist")
+    ncon = s.geti("ncon")
+    active = f.reshape(ncon, 4).sum(1) > 0
+    assert f.sum() == pytest.approx(m.body_mass[1] * 9.81, rel=1e-6)  # every edge Jacobian has a unit normal component
+    mu, margin, tc, dr = 1.0, 0.001, 0.02, 1.0
+    dmin, dmax, width, mid, power = 0.9, 0.95, 0.001, 0.5, 2.0
+    k = 1.0 / (dmax * dmax * tc * tc * dr * dr)
+    tran = m.body_invweight0[1, 0] + m.body_invweight0[0, 0]
+
+    def imp(r):
+        x = abs(r - margin) / width
+        if x >= 1:
+            return dmax
+        y = (x / mid) ** power * mid if x <= mid else 1 - ((1 - x) / (1 - mid)) ** power * (1 - mid)
+        return dmin + y * (dmax - dmin)
+
+    def edge_force(r):
+        i = imp(r)
+        R0 = (1 - i) / i * (tran + mu * mu * tran)
+        return k * i * (margin - r) / (2 * mu * mu * R0)
+
+    # the box rests level on its active corners: all share one distance r; 4 edges each
+    r_act = dist[active]
+    assert np.ptp(r_act) < 1e-6
+    n_edges = 4 * int(active.sum())
+    lo, hi = -0.01, margin
+    for _ in range(200):  # bisection on the monotone force law
+        mid_r = 0.5 * (lo + hi)
+        if n_edges * edge_force(mid_r) > m.body_mass[1] * 9.81:
+            lo = mid_r
+        else:
+            hi = mid_r
+    assert r_act.mean() == pytest.approx(0.5 * (lo + hi), abs=1e-7)
+
+
+def test_flat_box_contacts_are_its_bottom_hull_vertices():
+    """Plane vs convex mesh: the contacts of a box lying flat are bottom corners of the hull (support vertex + hull-graph neighbours
+    inside the margin), placed half-way between vertex and plane, with the plane's normal."""
+    from oracle.physics import OracleSim
+    m = box_model(0.1)
+    s = OracleSim(m)
+    s.set_state(np.array([0.3, -0.2, 0.1004, 1, 0, 0, 0.0]), np.zeros(6))
+    ncon = s.geti("ncon")
+    assert ncon in (3, 4)  # 4 when the triangulated bottom face's diagonal starts at the support corner
+    pos = s.get("con_pos").reshape(ncon, 3)
+    frame = s.get("con_frame").reshape(ncon, 9)
+    corners = {(round(0.3 + sx * 0.1, 6), round(-0.2 + sy * 0.1, 6)) for sx in (-1, 1) for sy in (-1, 1)}
+    assert {(round(p[0], 6), round(p[1], 6)) for p in pos} <= corners and len({tuple(p.round(6)) for p in pos}) == ncon
+    np.testing.assert_allclose(pos[:, 2], 0.5 * 0.0004, atol=1e-12)
+    np.testing.assert_allclose(s.get("con_dist"), 0.0004, atol=1e-12)
+    np.testing.assert_allclose(frame[:, :3], np.tile([0, 0, 1.0], (ncon, 1)), atol=1e-15)
+
+
+def test_implicit_joint_damping_is_backward_euler_in_the_velocity():
+    """[MJ-ext] mj_Euler with dof_damping > 0 solves (M + h B) a = f: a spinning damped hinge without gravity then decays by exactly
+    I / (I + h b) per step (backward Euler), while the reported qacc stays the explicit -b w / I."""
+    from oracle.physics import OracleSim
+    m = pendulum_model(length=0.5, half=0.05)
+    m.gravity = np.zeros(3)
+    b = 0.7
+    m.dof_damping = np.array([b])
+    s = OracleSim(m)
+    I = 1.0 / m.dof_invweight0[0]
+    w0, h, n = 3.0, m.timestep, 400
+    s.set_state(np.array([0.1]), np.array([w0]))
+    assert s.get("qacc")[0] == pytest.approx(-b * w0 / I, rel=1e-12)
+    for _ in range(n):
+        s.step()
+    assert s.get("qvel")[0] == pytest.approx(w0 * (I / (I + h * b)) ** n, rel=1e-11)
+    assert s.get("qvel")[0] != pytest.approx(w0 * (1 - h * b / I) ** n, rel=1e-6)  # not the explicit update

@@ -15,7 +15,7 @@ import torch
 from ..data_loaders.dataset_amass_single import DatasetAMASSSingle
 from ..envs.humanoid_im import VecHumanoidEnv
 from ..khrylib.models.mlp import MLP
-from ..khrylib.rl.agents import AgentPPO
+from ..khrylib.rl.agents import AgentPPO, _dist_on
 from ..khrylib.rl.core import PolicyGaussian, Value
 from ..khrylib.utils.torch import get_eta_str, lambda_rule, set_optimizer_lr, to_device
 from ..khrylib.utils.zfilter import ZFilter
@@ -60,6 +60,7 @@ class AgentCopycat(AgentPPO):
         if checkpoint_epoch > 0:
             self.load_checkpoint(checkpoint_epoch)
             self.epoch = checkpoint_epoch
+            self._loaded_shared_filter = True
         super().__init__(env=self.env, dtype=dtype, device=device, running_state=self.running_state, custom_reward=self.expert_reward,
                          mean_action=bool(getattr(cfg, "render", False)) and not getattr(cfg, "show_noise", False), render=False,
                          num_threads=getattr(cfg, "num_threads", 1), data_loader=self.data_loader, policy_net=self.policy_net,
@@ -67,6 +68,8 @@ class AgentCopycat(AgentPPO):
                          opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
                          policy_grad_clip=[(self.policy_net.parameters(), 40)], end_reward=cfg.end_reward, use_mini_batch=False,
                          mini_batch_size=0)
+        if getattr(self, "_loaded_shared_filter", False):
+            self.mark_running_state_shared()  # every rank loaded the same filter statistics: they are not new samples
 
     # ---- setup ------------------------------------------------------------------------------------------
     def setup_data_loader(self, data_loader=None):
@@ -125,12 +128,22 @@ class AgentCopycat(AgentPPO):
                     self.freq_dict = fd
             except Exception:
                 pass
-        self.logger = create_logger(os.path.join(cfg.log_dir, "log.txt"))
+        import torch.distributed as dist
+        rank = dist.get_rank() if _dist_on() else 0
+        self.logger = create_logger(os.path.join(cfg.log_dir, "log.txt" if rank == 0 else f"log_rank{rank}.txt"))
 
     def seed(self, seed):
-        torch.manual_seed(seed)
-        np.random.seed(seed)
-        self.env.seed(seed)
+        """Data-parallel ranks share the weights (initialised before this call from the script's global seed, and broadcast from
+        rank 0 below) but must draw different clip windows, exploration flags and action noise: their sampling streams are seeded
+        with seed + rank (rank 0 alone reproduces the single-process run)."""
+        import torch.distributed as dist
+        self.rank = dist.get_rank() if _dist_on() else 0
+        if _dist_on():
+            for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
+                dist.broadcast(p.data, 0)
+        torch.manual_seed(seed + self.rank)
+        np.random.seed(seed + self.rank)
+        self.env.seed(seed + self.rank)
 
     # ---- checkpoints: file names, dict keys and CPU float64 state_dict layout as agent_copycat.py:190-276 ----
     def _cp(self):
@@ -139,6 +152,8 @@ class AgentCopycat(AgentPPO):
 
     def save_checkpoint(self, epoch):
         cfg = self.cfg
+        if getattr(self, "rank", 0) != 0:  # one writer: the weights are identical on every rank, the filter is merged (sync_running_state)
+            return
         pickle.dump(self._cp(), open("%s/iter_%04d.p" % (cfg.model_dir, epoch + 1), "wb"))
         try:
             import joblib
@@ -147,9 +162,13 @@ class AgentCopycat(AgentPPO):
             pass
 
     def save_curr(self):
+        if getattr(self, "rank", 0) != 0:
+            return
         pickle.dump(self._cp(), open(f"{self.cfg.model_dir}/iter_best.p", "wb"))
 
     def save_singles(self, epoch, key):  # agent_copycat.py:203-214
+        if getattr(self, "rank", 0) != 0:
+            return
         os.makedirs(f"{self.cfg.model_dir}_singles", exist_ok=True)
         pickle.dump(self._cp(), open(f"{self.cfg.model_dir}_singles/{key}.p", "wb"))
 
@@ -245,10 +264,11 @@ class AgentCopycat(AgentPPO):
             torch.cuda.synchronize()
         t2 = time.time()
         info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
-        if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0:
+        if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0 and getattr(self, "rank", 0) == 0:
             self.save_checkpoint(epoch)
-            info["log_eval"] = self.eval_policy(epoch)
-        self.log_train(info)
+            info["log_eval"] = self.eval_policy(epoch)  # rank 0 evaluates; the others meet it again at the next collective
+        if getattr(self, "rank", 0) == 0:
+            self.log_train(info)
         return info
 
     def log_train(self, info):

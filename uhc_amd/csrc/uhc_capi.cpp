@@ -211,6 +211,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     T.timestep = d.timestep; T.tolerance = d.tolerance;
     for (int k = 0; k < 3; k++) T.gravity[k] = d.gravity[k];
     b->nM = T.nM;
+    T.has_damping = 0;
+    for (int k = 0; k < n_models; k++)
+        for (int i = 0; i < nv; i++) T.has_damping |= models[k]->d.dof_damping[i] > 0;
 
     // ---- derived topology tables
     std::vector<int> body_depth(nb, 0), body_rootid(nb, 0), body_nsub(nb, 1), body_lastdof(nb, -1);

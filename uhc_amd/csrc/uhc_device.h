@@ -38,6 +38,7 @@ struct DevTopo {
     const unsigned int* chain;     // [nv][32] position q on the chain of dof i: (q-th dof from the root | LDS byte address of its L row << 16)
     int fac_nslot;                 // number of groups
     int act_one_per_dof;           // every dof is driven by at most one actuator (lane-parallel accumulation)
+    int has_damping;               // some model of the batch has dof_damping > 0: mj_Euler integrates the damping implicitly
 };
 
 // offsets (in doubles) of the numeric arrays inside one model blob

@@ -1618,12 +1618,13 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
 }
 
 // ------------------------------------------------------------------ P10 semi-implicit Euler
+// acc: LDS offset of the acceleration the velocity update uses (qacc, or the implicitly damped one left by k_damped_accel)
 template <bool FAST>
-__device__ __forceinline__ void k_euler(const KernelArgs& A, double* S) {
+__device__ __forceinline__ void k_euler(const KernelArgs& A, double* S, int acc) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const double h = T.timestep;
-    for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.qvel + i] += h * S[L.qacc + i];
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.qvel + i] += h * S[acc + i];
     wsync();
     for (int j = LANE; j < T.njnt; j += UHC_WAVE) {
         int qa = T.jnt_qposadr[j], da = T.jnt_dofadr[j];
@@ -1648,6 +1649,34 @@ __device__ __forceinline__ void k_euler(const KernelArgs& A, double* S) {
     wsync();
 }
 __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVAL || x < -UHC_MAXVAL; }
+
+// [MJ-ext] mj_Euler with joint damping: (M + h diag(B)) a = qfrc_smooth + qfrc_constraint = M qacc, i.e.
+// a = qacc - (M + h B)^-1 (h B qacc) -- the right-hand side is diagonal, so neither force vector has to be kept.  M comes from
+// the parked copy of this forward pass (FAST) or S.M; the factor overwrites LD (rebuilt by the next forward pass / PD solve).
+// Result in S[L.smooth] (qacc_smooth is dead after k_forward); S[L.qacc] keeps the explicit acceleration (warm start, checks).
+template <bool FAST>
+__device__ __forceinline__ void k_damped_accel(const KernelArgs& A, const double* mb, double* S, const MPark& MP, const LaneConst& LC) {
+    const DevTopo& T = A.t;
+    const DevLds& L = FAST ? A.lf : A.l;
+    const double h = T.timestep;
+    if (FAST) {
+#pragma unroll
+        for (int m = 0; m < UHC_MREG; m++) {
+            const int e = LANE + UHC_WAVE * m;
+            if (e < T.nM) S[L.LD + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
+        }
+    } else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    wsync();
+    DofVec x = {0.0, 0.0};
+    if (LC.v0) { const double hb = h * mb[A.o.dof_damping + LANE]; S[L.LD + LC.m0] += hb; x.a = hb * S[L.qacc + LANE]; }
+    if (LC.v1) { const double hb = h * mb[A.o.dof_damping + LANE + UHC_WAVE]; S[L.LD + LC.m1] += hb; x.b = hb * S[L.qacc + LANE + UHC_WAVE]; }
+    wsync();
+    k_factor<FAST>(A, S, L.LD, LC);
+    k_solve<FAST>(A, S, L.LD, x, 0, LC);
+    if (LC.v0) S[L.smooth + LANE] = S[L.qacc + LANE] - x.a;
+    if (LC.v1) S[L.smooth + LANE + UHC_WAVE] = S[L.qacc + LANE + UHC_WAVE] - x.b;
+    wsync();
+}
 
 // ------------------------------------------------------------------ E3/E4 stable PD, E5 implicit residual force
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
@@ -1886,7 +1915,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             b = 0;
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
             if (wave_or(b)) { fail = 1; break; }
-            k_euler<FAST>(A, S);
+            if (T.has_damping) { k_damped_accel<FAST>(A, mb, S, MP, LC); k_euler<FAST>(A, S, L.smooth); }
+            else k_euler<FAST>(A, S, L.qacc);
             PROF(14)
         }
     }

@@ -253,9 +253,12 @@ class HumanoidEnv:
         self.vec.assign([0], [expert_data["seq_name"]], [0], [self.expert["len"]])
 
     def reset(self):
-        return self.vec.reset()[0].cpu().numpy()
+        obs = self.vec.reset()[0].cpu().numpy()
+        self.prev_bquat = self.get_body_quat()  # humanoid_im.py:1269 (reset_model -> get_body_quat)
+        return obs
 
     def step(self, a):
+        self.prev_bquat = self.get_body_quat()  # humanoid_im.py:1195-1196: the reward's finite difference reads the pre-step quaternions
         act = torch.as_tensor(np.asarray(a, dtype=np.float64).reshape(1, -1), device=self.vec.device)
         self.vec.step(act)
         info = {"fail": bool(self.vec.env.field(S.E_FAIL)[0].item()), "end": bool(self.vec.env.field(S.E_END)[0].item()),
@@ -281,3 +284,61 @@ class HumanoidEnv:
 
     def get_world_vf(self):
         return None
+
+    # ---- accessors the reference's reward functions and eval loop call (humanoid_im.py:902-965) --------------------------------
+    def get_expert_qpos(self, delta_t=0):
+        return self.get_expert_attr("qpos", self.get_expert_index(self.cur_t + delta_t))
+
+    def get_expert_qvel(self, delta_t=0):
+        return self.get_expert_attr("qvel", self.get_expert_index(self.cur_t + delta_t))
+
+    def fail_safe(self):
+        """Teleport to the expert state of the current frame and refresh the kinematics (humanoid_im.py:902-905)."""
+        q = torch.as_tensor(self.get_expert_qpos()[None], dtype=torch.float64)
+        v = torch.as_tensor(self.get_expert_qvel()[None], dtype=torch.float64)
+        self.vec.sim.set_state(q, v, torch.zeros(1, dtype=torch.int32))
+
+    def get_head_idx(self):
+        return self.model._body_name2id["Head"] - 1
+
+    def get_ee_pos(self, transform):
+        """World (transform None) or root / heading relative positions of SMPL_EE_NAMES (humanoid_im.py:910-923)."""
+        from ..smpllib.smpl_mujoco import SMPL_EE_NAMES
+        from ..utils.math_utils import transform_vec
+        d = self.data
+        root_pos, root_q = d.qpos[:3], d.qpos[3:7].copy()
+        out = []
+        for name in SMPL_EE_NAMES:
+            v = d.get_body_xpos(name)
+            if transform is not None:
+                v = transform_vec(v - root_pos, root_q, transform)
+            out.append(v)
+        return np.concatenate(out)
+
+    def get_body_quat(self):
+        """Root quaternion + one quaternion per body from its hinge triple, quaternion_from_euler(z, y, x, 'rzyx') (humanoid_im.py:925-947)."""
+        from ..utils.transformation import quaternion_from_euler
+        qpos = self.get_humanoid_qpos()
+        out = [qpos[3:7]]
+        for b in range(2, self.model.nbody):
+            a = 7 + 3 * (b - 2)
+            out.append(quaternion_from_euler(qpos[a], qpos[a + 1], qpos[a + 2], "rzyx"))
+        return np.concatenate(out)
+
+    def get_wbody_quat(self, selectList=None):
+        d = self.data
+        if selectList is None:
+            return d.body_xquat[1:].copy().ravel()
+        return np.concatenate([d.body_xquat[self.model._body_name2id[b]] for b in selectList])
+
+    def get_com(self):
+        return self.data.get_body_xipos("Pelvis")
+
+    def get_body_com(self, selectList=None):
+        d = self.data
+        if selectList is None:
+            return d.xipos[1:].copy().ravel()
+        return np.concatenate([d.get_body_xipos(b) for b in selectList])
+
+    def calc_body_diff(self):
+        return float(self.vec.env.field(S.E_BODY_DIFF)[0].item())

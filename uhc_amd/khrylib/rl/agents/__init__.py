@@ -71,7 +71,9 @@ class Agent:
 
     # ---- vectorised rollout (replaces sample_worker / sample of agent.py:42-131) -------------------------
     @torch.no_grad()
-    def rollout_begin(self, T):
+    def rollout_begin(self, T, fresh=None):
+        """fresh: True = assign + reset every env (new episodes), False = continue the episodes left open by the previous pass,
+        None = fresh on the first pass only."""
         env = self.env
         n_env, dev = env.n_env, env.device
         R = self._ro = types.SimpleNamespace(T=T, t=0)
@@ -91,10 +93,25 @@ class Agent:
         R.snap_host = [torch.empty(5, n_env, dtype=torch.float64).pin_memory() if dev.type == "cuda" else torch.empty(5, n_env, dtype=torch.float64) for _ in range(2)]
         R.snap_event = [None, None]
         to_test(*self.sample_modules)
-        self.assign_new_clips(np.arange(n_env))  # every sampling pass starts fresh episodes, like each reference worker
-        self.queue_next_clips(np.arange(n_env))
-        obs = env.obs.to(self.dtype)
-        R.state = self.running_state(obs) if self.running_state is not None else obs
+        R.c_reward_sum = torch.zeros((), dtype=self.dtype, device=dev)
+        if fresh is None:
+            fresh = not getattr(self, "_episodes_live", False)
+        if fresh:
+            # first pass (or an explicit restart): every env starts a new episode.  Later passes CONTINUE the running episodes: the
+            # reference's workers run every episode to `fail` or `end` (agent.py:60-100), so an episode cut by the end of a pass is
+            # bootstrapped with V(s_T) in rollout_end and simply goes on here -- its state, running length / return, clip window and
+            # queued successor all live on (device and agent bookkeeping), so env_episode_len, t_max and the success history of long
+            # windows behave as in the reference.
+            self.assign_new_clips(np.arange(n_env))
+            self.queue_next_clips(np.arange(n_env))
+            obs = env.obs.to(self.dtype)
+            R.state = self.running_state(obs) if self.running_state is not None else obs
+            self._episodes_live = True
+        else:
+            # the observations the envs stopped at were already counted by the filter at the end of the previous pass; only
+            # re-normalise them with the current statistics (the filter may have been merged across ranks since)
+            obs = env.obs.to(self.dtype)
+            R.state = self.running_state(obs, update=False) if self.running_state is not None else obs
 
     def _drain_snapshot(self, slot):
         """Host side of episode turnover for the step whose snapshot sits in `slot`: statistics, success history, new queue entries."""
@@ -126,6 +143,9 @@ class Agent:
         R.actions[:, t] = action
         env.step(action)
         r = env.reward.to(self.dtype)
+        R.c_reward_sum += r.sum()  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
+        if self.running_state is not None:  # the reference also filters the last observation of an episode (agent.py:77-79); the
+            self.running_state.rs.push_batch(env.obs.to(self.dtype), weights=env.done)  # restart below overwrites those rows
         if self.end_reward:
             r = r + env.env.field(5).to(self.dtype) * env.end_reward  # info["end"] * end_reward (agent.py:84-85)
         R.rewards[:, t] = r
@@ -159,7 +179,7 @@ class Agent:
             R.rewards[open_, T - 1] += self.gamma * v_next
             R.masks[open_, T - 1] = 0
         self.sync_running_state()
-        R.logger.add_steps(N, float(R.rewards.sum().item()), R.c_info_sum.cpu().numpy())
+        R.logger.add_steps(N, float(R.c_reward_sum.item()), R.c_info_sum.cpu().numpy())
         R.logger.end_sampling()
         return RolloutBatch(R.states.reshape(N, -1), R.actions.reshape(N, -1), R.rewards.reshape(N, 1), R.masks.reshape(N, 1), R.exps.reshape(N), T), R.logger
 
@@ -172,12 +192,10 @@ class Agent:
         dev = self.env.device if self.env is not None else torch.device("cpu")
         mine = torch.cat([torch.tensor([float(rs.n)], dtype=torch.float64), torch.from_numpy(np.asarray(rs.mean, dtype=np.float64).ravel()),
                           torch.from_numpy(np.asarray(rs._S, dtype=np.float64).ravel())]).to(dev)
-        if rs._stale:
-            mine = torch.cat([torch.tensor([float(rs.n)], dtype=torch.float64, device=dev), rs._dev[1].to(dev).ravel(), rs._dev[2].to(dev).ravel()])
         allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(allv, mine)
         d = (mine.numel() - 1) // 2
-        base = getattr(self, "_rs_synced", None)  # statistics every rank already shares (from the previous merge)
+        base = getattr(self, "_rs_synced", None)  # statistics every rank already shares (previous merge, or a loaded checkpoint)
         n0, M0, S0 = (0.0, np.zeros(d), np.zeros(d)) if base is None else base
         n, M, Sq = n0, M0.copy(), S0.copy()
         for v in allv:  # add each rank's NEW samples: (rank stats) minus (shared base), merged pairwise
@@ -194,9 +212,15 @@ class Agent:
             Sq = Sq + Sb + delta * delta * (n * nb / tot)
             M = M + delta * (nb / tot)
             n = tot
-        rs._dev, rs._stale = None, False
-        rs._n, rs._M[...], rs._S[...] = int(round(n)), M.reshape(rs._M.shape), Sq.reshape(rs._S.shape)
+        self.running_state.set_mean_std(M.reshape(rs._M.shape), Sq.reshape(rs._S.shape), int(round(n)))
         self._rs_synced = (float(rs._n), M.copy(), Sq.copy())
+
+    def mark_running_state_shared(self):
+        """The filter statistics are the same on every rank right now (loaded from one checkpoint): later merges add only what each
+        rank observes from here on."""
+        if self.running_state is not None:
+            rs = self.running_state.rs
+            self._rs_synced = (float(rs.n), np.asarray(rs.mean, dtype=np.float64).ravel().copy(), np.asarray(rs._S, dtype=np.float64).ravel().copy())
 
     def sample(self, min_batch_size):
         t0 = time.time()

@@ -28,38 +28,48 @@ class RunningStat:
             self._M[...] = old + (x - old) / self._n
             self._S[...] = self._S + (x - old) * (x - self._M)
 
-    def push_batch(self, xb: torch.Tensor):
-        """Merge B rows at once: (n, M, S) <- merge((n, M, S), (B, mean_b, S_b)).  The statistics stay on the
+    def _to_device(self, device):
+        if self._dev is None or self._dev[1].device != device:
+            self._sync()
+            self._dev = [torch.tensor(float(self._n), dtype=torch.float64, device=device), torch.as_tensor(self._M, dtype=torch.float64, device=device),
+                         torch.as_tensor(self._S, dtype=torch.float64, device=device)]
+
+    def push_batch(self, xb: torch.Tensor, weights: torch.Tensor = None):
+        """Merge B rows at once: (n, M, S) <- merge((n, M, S), (B, mean_b, S_b)).  `weights` (0/1 per row, a device tensor) selects the
+        rows that count, without the host having to know how many there are.  The statistics -- the count included -- stay on the
         device of `xb` (no host sync per rollout step); the numpy views are refreshed lazily."""
-        B = xb.shape[0]
-        if B == 0:
+        if xb.shape[0] == 0:
             return
-        if self._dev is None or self._dev[1].device != xb.device:
-            self._dev = [float(self._n), torch.as_tensor(self._M, dtype=torch.float64, device=xb.device),
-                         torch.as_tensor(self._S, dtype=torch.float64, device=xb.device)]
+        self._to_device(xb.device)
         x = xb.double()
-        mb = x.mean(0)
-        Sb = ((x - mb) ** 2).sum(0)
         n, M, Sd = self._dev
+        if weights is None:
+            B = torch.tensor(float(xb.shape[0]), dtype=torch.float64, device=xb.device)
+            mb = x.mean(0)
+            Sb = ((x - mb) ** 2).sum(0)
+        else:
+            w = (weights != 0).double()
+            B = w.sum()
+            mb = (w[:, None] * x).sum(0) / B.clamp(min=1.0)
+            Sb = (w[:, None] * (x - mb) ** 2).sum(0)
         tot = n + B
+        ts = tot.clamp(min=1.0)
         delta = mb - M
-        self._dev = [tot, M + delta * (B / tot), Sd + Sb + delta * delta * (n * B / tot)]
-        self._n = int(tot)
+        self._dev = [tot, M + delta * (B / ts), Sd + Sb + delta * delta * (n * B / ts)]
         self._stale = True
 
     def _sync(self):
         if self._stale:
+            self._n = int(round(float(self._dev[0].item())))
             self._M[...] = self._dev[1].cpu().numpy()
             self._S[...] = self._dev[2].cpu().numpy()
             self._stale = False
 
     def device_mean_std(self, like: torch.Tensor):
         """(mean, std) as tensors on like.device without a host round trip."""
-        if self._dev is None or self._dev[1].device != like.device:
-            self._dev = [float(self._n), torch.as_tensor(self._M, dtype=torch.float64, device=like.device),
-                         torch.as_tensor(self._S, dtype=torch.float64, device=like.device)]
+        self._to_device(like.device)
         n, M, Sd = self._dev
-        var = Sd / (n - 1) if n > 1 else M * M
+        var = torch.where(n > 1, Sd / (n - 1).clamp(min=1.0), M * M)
         return M.to(like.dtype), torch.sqrt(var).to(like.dtype)
 
     def merge(self, nb, mb, Sb):
@@ -80,7 +90,11 @@ class RunningStat:
         self.__dict__.update(st)
         self._dev, self._stale = None, False
 
-    n = property(lambda self: self._n)
+    @property
+    def n(self):
+        self._sync()
+        return self._n
+
     @property
     def mean(self):
         self._sync()

@@ -112,7 +112,9 @@ class SimBatch:
 
     def simulate(self, action: torch.Tensor, target_base: torch.Tensor, active: Optional[torch.Tensor] = None):
         assert action.dtype == torch.float64 and action.is_contiguous() and action.shape == (self.n_env, self.ctrl.action_dim)
-        assert target_base.dtype == torch.float64 and target_base.is_contiguous() and target_base.shape == (self.n_env, self.model.nu)
+        if self.model.nu == 0:  # unactuated model: the library still wants non-null buffers
+            target_base = action
+        assert target_base.dtype == torch.float64 and target_base.is_contiguous() and (self.model.nu == 0 or target_base.shape == (self.n_env, self.model.nu))
         a = None
         if active is not None:
             assert active.dtype == torch.int32 and active.is_contiguous()
