@@ -630,19 +630,24 @@ static void collide_mesh_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2,
     add_contact(m, d, g1, g2, pos, dir, margin - depth, margin - gap);
 }
 void orc_collision(const UhcModelDesc* m, OrcData* d) {
+    /* Contact order: plane pairs first, convex-convex pairs after them, each in (g1 < g2) order.  [MJ-ext] MuJoCo orders contacts by
+     * body pair and then geom pair; with the floor as geom 0 of the world body (every model of the reference) that is the same order.
+     * The device kernel uses this two-pass order, so both sides enumerate constraint rows identically. */
     d->ncon = 0;
-    for (int g1 = 0; g1 < m->ngeom; g1++)
-        for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
-            int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
-            if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
-            if (bodies_filtered(m, b1, b2)) continue;
-            double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
-            double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
-            int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-            if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g1, g2, margin, gap);
-            else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g2, g1, margin, gap);
-            else if (t1 == UHC_GEOM_MESH && t2 == UHC_GEOM_MESH) collide_mesh_mesh(m, d, g1, g2, margin, gap);
-        }
+    for (int pass = 0; pass < 2; pass++)
+        for (int g1 = 0; g1 < m->ngeom; g1++)
+            for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+                int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+                if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
+                if (bodies_filtered(m, b1, b2)) continue;
+                double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+                double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+                int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+                if (pass == 0) {
+                    if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g1, g2, margin, gap);
+                    else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g2, g1, margin, gap);
+                } else if (t1 == UHC_GEOM_MESH && t2 == UHC_GEOM_MESH) collide_mesh_mesh(m, d, g1, g2, margin, gap);
+            }
 }
 
 /* ------------------------------------------------------------------ P5: mj_makeConstraint [MJ-ext] */

@@ -125,3 +125,30 @@ def passive_ctrl(model, n_substeps=1):
     nu = max(int(model.nu), 1)
     return ctrl_desc(n_substeps=n_substeps, action_type=1, meta_pd=0, rfc_mode=0, action_dim=nu, jkp=np.zeros(nu), jkd=np.zeros(nu),
                      torque_lim=np.full(nu, 1e9), a_scale=np.full(nu, 0.01))
+
+
+TWO_BOX_XML = """
+<mujoco>
+  <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
+  <option timestep="0.002"/>
+  <default><geom contype="1" conaffinity="1" condim="1" margin="0.001"/></default>
+  <asset><mesh name="a" file="unused.stl"/><mesh name="b" file="unused.stl"/></asset>
+  <worldbody>
+    <geom name="floor" type="plane" size="10 10 0.1" pos="0 0 0" condim="3"/>
+    <body name="A" pos="0 0 0.1">
+      <joint name="ra" type="free"/>
+      <geom type="mesh" mesh="a"/>
+    </body>
+    <body name="B" pos="0 0 0.3">
+      <joint name="rb" type="free"/>
+      <geom type="mesh" mesh="b"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def two_box_model(ha=0.1, hb=0.06):
+    """Two free boxes (meshes) above the plane: box-box contacts go through the convex-convex (MPR) narrow phase, two kinematic trees."""
+    from uhc_amd.model.mjcf import compile_mjcf
+    return compile_mjcf(TWO_BOX_XML, meshes={"a": box_triangles(ha, ha, ha), "b": box_triangles(hb, hb, hb)})

@@ -1,0 +1,143 @@
+"""GPU parity for the convex-convex narrow phase (MPR, one pair per lane) and for contact rows between two moving bodies (dense rows):
+free boxes (two kinematic trees) and the humanoid with body-body collisions on, as the reference's generated models have them
+(uhc/smpllib/smpl_parser.py:327-328, uhc/smpllib/smpl_robot.py:1177-1198).  HIP path through the C-ABI vs the CPU oracle."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import passive_ctrl, two_box_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["fast", "general"], autouse=True)
+def kernel_path(request):
+    old = os.environ.get("UHC_FORCE_GENERAL")
+    os.environ["UHC_FORCE_GENERAL"] = "1" if request.param == "general" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("UHC_FORCE_GENERAL", None)
+    else:
+        os.environ["UHC_FORCE_GENERAL"] = old
+
+
+def _box_poses(n, seed):
+    """n poses of the two boxes high above the floor: box B near a face / edge / corner of box A, random orientations."""
+    from scipy.spatial.transform import Rotation as sR
+    rng = np.random.default_rng(seed)
+    q = np.zeros((n, 14))
+    for e in range(n):
+        qa = sR.from_rotvec(rng.normal(size=3) * 0.5)
+        qb = sR.from_rotvec(rng.normal(size=3) * 0.9)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        q[e, :3] = [0, 0, 2.0]
+        q[e, 3:7] = np.roll(qa.as_quat(), 1)
+        q[e, 7:10] = q[e, :3] + d * rng.uniform(0.12, 0.2)
+        q[e, 10:14] = np.roll(qb.as_quat(), 1)
+    return q
+
+
+def test_mpr_contacts_match_oracle(kernel_path):
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    m = dataclasses.replace(two_box_model(0.1, 0.06), solver=1)
+    n = 64
+    q = _box_poses(n, 3)
+    v = np.random.default_rng(4).normal(scale=0.3, size=(n, 12))
+    b = S.SimBatch(m, passive_ctrl(m), n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    ncon, nefc, qacc = (b.field(f).cpu().numpy() for f in (S.F_NCON, S.F_NEFC, S.F_QACC))
+    hits = 0
+    for e in range(n):
+        o = OracleSim(m)
+        o.desc.solver = 0 if kernel_path == "general" else 1
+        o.set_state(q[e], v[e])
+        assert ncon[e] == o.geti("ncon") and nefc[e] == o.geti("nefc"), e
+        np.testing.assert_allclose(qacc[e], o.get("qacc"), atol=1e-6, rtol=1e-6)
+        hits += o.geti("ncon")
+    assert 10 < hits < n  # the sample has touching and separated pairs
+
+
+def test_stacked_boxes_trajectory_matches_oracle(kernel_path):
+    """Two trees, floor contacts (chain rows) + a box-box contact (dense row) in one solve, 120 steps."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    m = dataclasses.replace(two_box_model(0.1, 0.06), solver=1)
+    q0 = np.array([[0, 0, 0.0998, 1, 0, 0, 0, 0.01, -0.02, 0.2 + 0.0598, 1, 0, 0, 0.0],
+                   [0, 0, 0.0998, 1, 0, 0, 0, 0.05, 0.03, 0.2 + 0.07, 0.9689, 0.2474, 0, 0.0]])
+    b = S.SimBatch(m, passive_ctrl(m), 2)
+    b.set_state(torch.from_numpy(q0), torch.zeros(2, 12, dtype=torch.float64))
+    act = torch.zeros(2, 1, dtype=torch.float64, device="cuda")
+    os_ = [OracleSim(m) for _ in range(2)]
+    for e in range(2):
+        os_[e].desc.solver = 0 if kernel_path == "general" else 1
+        os_[e].set_state(q0[e], np.zeros(12))
+    worst = 0.0
+    for t in range(120):
+        b.simulate(act, act)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        for e in range(2):
+            os_[e].step()
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    assert worst < 1e-6, worst
+    assert int(b.field(S.F_FAIL).sum().item()) == 0 and gq[0, 9] > 0.24  # still stacked
+
+
+def _humanoid_states(standing, n, seed, lift):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(standing["qpos"], (n, 1))
+    qpos[:, 7:] += rng.normal(scale=0.08, size=(n, 69))
+    qpos[:, 2] += lift
+    return qpos, rng.normal(scale=0.3, size=(n, 75))
+
+
+@pytest.mark.parametrize("lift", [1.0, 0.0])
+def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, lift):
+    """Body-body contacts of the humanoid: forward fields and a 20-control-step trajectory.  lift = 1: airborne, only self-contacts
+    (the fast kernel's dense-row path); lift = 0: standing, floor + self contacts (> 64 rows: redone by the general kernel)."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import self_collision_variant
+    from uhc_amd.sim import make_ctrl
+    sc = dataclasses.replace(self_collision_variant(model), solver=1)
+    ctrl = make_ctrl(sc)
+    n = 6
+    qpos, qvel = _humanoid_states(standing, n, 31, lift)
+    b = S.SimBatch(sc, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    b.sync()
+    os_ = [OracleSim(sc, ctrl) for _ in range(n)]
+    ncon, nefc, qacc, redo = (b.field(f).cpu().numpy() for f in (S.F_NCON, S.F_NEFC, S.F_QACC, S.F_REDO))
+    nself = 0
+    for e in range(n):
+        os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+        os_[e].set_state(qpos[e], qvel[e])
+        assert ncon[e] == os_[e].geti("ncon") and nefc[e] == os_[e].geti("nefc"), (e, ncon[e], os_[e].geti("ncon"))
+        np.testing.assert_allclose(qacc[e], os_[e].get("qacc"), atol=1e-5, rtol=1e-6)
+        nself += os_[e].geti("ncon")
+    assert nself > 0
+    if lift > 0 and kernel_path == "fast":
+        assert redo.sum() == 0  # few rows: the fast kernel's dense path did the work
+    rng = np.random.default_rng(32)
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    worst = 0.0
+    for t in range(20):
+        act = rng.normal(scale=0.05, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].do_simulation(act[e], qpos[e, 7:])
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    assert worst < 1e-5, worst
+    assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0

@@ -448,3 +448,102 @@ def test_implicit_joint_damping_is_backward_euler_in_the_velocity():
         s.step()
     assert s.get("qvel")[0] == pytest.approx(w0 * (I / (I + h * b)) ** n, rel=1e-11)
     assert s.get("qvel")[0] != pytest.approx(w0 * (1 - h * b / I) ** n, rel=1e-6)  # not the explicit update
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Convex-convex narrow phase (MPR) and contacts between two moving bodies
+# ---------------------------------------------------------------------------------------------------------------
+def test_mpr_depth_normal_and_position_of_overlapping_boxes():
+    """Two axis-aligned cubes overlapping by d along x: penetration depth d (+ margin through the inflated supports), normal +x from
+    geom 1 to geom 2, contact point in the middle of the overlap slab."""
+    from oracle.physics import OracleSim
+    from tests.helpers import two_box_model
+    m = two_box_model(0.1, 0.06)
+    s = OracleSim(m)
+    d = 0.004
+    # A at the origin height 1 (far from the floor), B shifted along +x so that the faces overlap by d, offset in y/z inside A's face
+    q = np.array([0, 0, 1.0, 1, 0, 0, 0, 0.1 + 0.06 - d, 0.013, 1.0 + 0.021, 1, 0, 0, 0.0])
+    s.set_state(q, np.zeros(12))
+    assert s.geti("ncon") == 1
+    np.testing.assert_allclose(s.get("con_dist"), [-d], atol=2e-6)       # dist = margin - depth(inflated) = -d, to the MPR tolerance
+    np.testing.assert_allclose(s.get("con_frame")[:3], [1, 0, 0], atol=1e-6)
+    pos = s.get("con_pos")
+    # libccd places the point by the barycentric coordinates of the origin in the final portal TETRAHEDRON, whose apex is the pair of
+    # hull centres: the point sits a fraction depth / |centre distance| behind the overlap slab's middle (0.098), towards the centres
+    assert 0.1 - d / 2 - 0.001 < pos[0] <= 0.1 - d / 2 + 1e-6 and abs(pos[1] - 0.013) < 0.06 and abs(pos[2] - 1.021) < 0.06
+    # separated by more than the margin: no contact; inside the margin: a contact with positive distance
+    q[7] = 0.16 + 0.002
+    s.set_state(q, np.zeros(12))
+    assert s.geti("ncon") == 0
+    q[7] = 0.16 + 0.0004
+    s.set_state(q, np.zeros(12))
+    assert s.geti("ncon") == 1 and s.get("con_dist")[0] == pytest.approx(0.0004, abs=2e-6)
+
+
+def test_mpr_is_rotation_and_translation_covariant():
+    from oracle.physics import OracleSim
+    from tests.helpers import two_box_model
+    from scipy.spatial.transform import Rotation as sR
+    m = two_box_model(0.1, 0.06)
+    s = OracleSim(m)
+    rng = np.random.default_rng(5)
+    qa = sR.from_rotvec(rng.normal(size=3) * 0.4)
+    qb = sR.from_rotvec(rng.normal(size=3) * 0.7)
+    pa, pb = np.array([0.0, 0, 2.0]), np.array([0.12, 0.05, 2.03])
+
+    def run(Rw, tw):
+        A, B = Rw * qa, Rw * qb
+        xa, xb = Rw.apply(pa) + tw, Rw.apply(pb) + tw
+        q = np.r_[xa, np.roll(A.as_quat(), 1), xb, np.roll(B.as_quat(), 1)]
+        s.set_state(q, np.zeros(12))
+        assert s.geti("ncon") == 1
+        return s.get("con_dist")[0], s.get("con_frame")[:3].copy(), s.get("con_pos").copy()
+
+    d0, n0, p0 = run(sR.identity(), np.zeros(3))
+    assert d0 < 0
+    Rw, tw = sR.from_rotvec([0.3, -1.1, 0.5]), np.array([0.4, -0.2, 3.0])
+    d1, n1, p1 = run(Rw, tw)
+    assert d1 == pytest.approx(d0, abs=1e-6)
+    np.testing.assert_allclose(n1, Rw.apply(n0), atol=1e-5)
+    np.testing.assert_allclose(p1, Rw.apply(p0) + tw, atol=1e-5)
+
+
+def test_box_stacked_on_box_rests_and_carries_its_weight():
+    """Two trees, a two-body contact row: the small box rests on the big one, the floor carries both weights, the box-box contact
+    carries the upper weight (Newton's third law through J_b2 - J_b1)."""
+    from oracle.physics import OracleSim
+    from tests.helpers import two_box_model
+    m = two_box_model(0.1, 0.06)
+    m.solver = 1
+    s = OracleSim(m)
+    s.set_state(np.array([0, 0, 0.0998, 1, 0, 0, 0, 0.01, -0.02, 0.2 + 0.0598, 1, 0, 0, 0.0]), np.zeros(12))
+    fc = np.zeros(12)
+    for t in range(1500):
+        s.step()
+        if t >= 1000:
+            fc += s.get("qfrc_constraint") / 500
+    # MPR yields ONE contact point per hull pair, so the upper box keeps rocking gently on it (as mesh-on-mesh does in MuJoCo 2.1)
+    assert s.geti("fail") == 0 and abs(s.get("qvel")).max() < 0.5
+    q = s.get("qpos")
+    # (the single contact sits at a corner of the face and hops between corners: the box settles ~8 mm deep instead of < 1 mm)
+    assert q[2] == pytest.approx(0.1, abs=2e-3) and 0.245 < q[9] < 0.262 and np.hypot(q[7] - 0.01, q[8] + 0.02) < 0.02
+    wa, wb = m.body_mass[1] * 9.81, m.body_mass[2] * 9.81
+    assert fc[8] == pytest.approx(wb, rel=3e-2)          # the upper box: held up by its weight (time average)
+    assert fc[2] == pytest.approx(wa, rel=3e-2)          # the lower box: floor (wa + wb) minus the load from above (wb)
+
+
+def test_self_collision_variant_generates_body_body_contacts(model, standing):
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import self_collision_variant
+    sc = self_collision_variant(model)
+    assert sc.nexclude == 2 and (sc.geom_contype[1:] == 1).all()
+    a, b = OracleSim(model), OracleSim(sc)
+    a.set_state(standing["qpos"], np.zeros(75))
+    b.set_state(standing["qpos"], np.zeros(75))
+    n0, n1 = a.geti("ncon"), b.geti("ncon")
+    assert n1 > n0  # the static asset's arm hulls touch the torso in the standing pose
+    # every new contact separates two hulls: normal force along the normal does no work on the common ancestors' dofs
+    J = b.get("efc_J").reshape(b.geti("nefc"), 75)
+    nl = b.geti("nefc") - (4 * n0 + (n1 - n0))
+    two = J[nl + 4 * n0:]
+    assert two.shape[0] == n1 - n0 and np.abs(two[:, :6]).max() < 1e-12  # internal forces: no net wrench on the root

@@ -266,7 +266,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             ncommon[(size_t)i * nv + j] = (unsigned char)q;
         }
     // statically filtered collision pairs (plane, mesh)
-    std::vector<int> pg1, pg2;
+    std::vector<int> pg1, pg2, cg1, cg2;
     int skipped_pairs = 0;
     for (int g1 = 0; g1 < ng; g1++)
         for (int g2 = g1 + 1; g2 < ng; g2++) {
@@ -281,12 +281,17 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             }
             if (ex) continue;
             int t1 = d.geom_type[g1], t2 = d.geom_type[g2];
+            if (body_lastdof[b1] < 0 && body_lastdof[b2] < 0) continue;  // two static bodies never collide ([MJ-ext] same weld id)
             if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH && b1 == 0) { pg1.push_back(g1); pg2.push_back(g2); }
             else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH && b2 == 0) { pg1.push_back(g2); pg2.push_back(g1); }
+            else if (t1 == UHC_GEOM_MESH && t2 == UHC_GEOM_MESH) { cg1.push_back(g1); cg2.push_back(g2); }
             else skipped_pairs++;
         }
-    (void)skipped_pairs;  // mesh-mesh pairs: not generated yet (SURVEY 8a P4 "later")
+    if (skipped_pairs) { delete b; return fail("uhc_batch_create: %d collision pairs of unsupported geom types (built: plane-mesh, mesh-mesh)", skipped_pairs); }
     T.npair = (int)pg1.size();
+    T.ncpair = (int)cg1.size();
+    std::vector<int> dof_rootid(nv, 0);
+    for (int i = 0; i < nv; i++) dof_rootid[i] = body_rootid[d.dof_bodyid[i]];
 
     auto ivec = [](const int32_t* p, size_t n) { return std::vector<int>(p, p + n); };
     TRY(upload(b, ivec(d.body_parentid, nb), &T.body_parentid)); TRY(upload(b, ivec(d.body_jntadr, nb), &T.body_jntadr));
@@ -305,6 +310,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
     TRY(upload(b, ivec(d.mesh_adjadr, d.nmeshvert + 1), &T.mesh_adjadr)); TRY(upload(b, ivec(d.mesh_adj, d.nmeshadj), &T.mesh_adj));
     TRY(upload(b, pg1, &T.pair_g1)); TRY(upload(b, pg2, &T.pair_g2));
+    TRY(upload(b, cg1, &T.cpair_g1)); TRY(upload(b, cg2, &T.cpair_g2)); TRY(upload(b, dof_rootid, &T.dof_rootid));
     TRY(upload(b, ivec(d.actuator_dofid, d.nu), &T.actuator_dofid));
 
     // ---- numeric blobs, one per model
@@ -362,7 +368,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
     L.rowDa = carve(UHC_MAXEFC);
     L.rowMisc = carve(UHC_MAXEFC * 2);  // 4 ints per row
-    L.ncon_nefc = carve(2);
+    L.ncon_nefc = carve(2 + UHC_MAXTWO / 2);  // ints: truncated flag, nefc, number of two-body rows, spare, then their row ids
+    A.nvp = (nv + 1) & ~1;
+    A.ndense_g = T.ncpair > 0 ? UHC_MAXTWO : 0;
+    L.dense = carve(A.ndense_g * A.nvp);
+    L.dcol = carve(A.ndense_g * 4);  // general kernel: (vel, jas, jaw, diag) of every dense row
     L.total = off;
     b->lds_bytes = (size_t)off * sizeof(double);
     if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }
@@ -395,9 +405,14 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         off = base;
         F.con = carve(UHC_FAST_MAXCON * UHC_CON_STRIDE);
         F.rowMisc = carve(UHC_WAVE * 2);
-        F.ncon_nefc = carve(2);
+        F.ncon_nefc = carve(2 + UHC_MAXTWO / 2);
+        // models with body-body contacts (self-collision, objects) keep up to UHC_FAST_MAXTWO dense rows + their Delassus columns; they
+        // get a third of the CU's LDS (3 workgroups per CU) instead of a quarter -- the stock floor-only model keeps its 40 KiB layout
+        A.ndense_f = T.ncpair > 0 ? UHC_FAST_MAXTWO : 0;
+        F.dense = carve(A.ndense_f * A.nvp);
+        F.dcol = carve(A.ndense_f * UHC_WAVE);
         F.Y = off;
-        const int budget = 40 * 1024 / 8;
+        const int budget = T.ncpair > 0 ? (160 * 1024 / 3) / 8 : 40 * 1024 / 8;
         int ycap = budget - off;
         const int need1 = end1 - off;  // phase 1 may need more than the constraint data
         if (ycap < need1) ycap = need1;

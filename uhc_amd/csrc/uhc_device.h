@@ -8,6 +8,8 @@
 #define UHC_MAXEFC 128   // constraint rows per env (2 per lane)
 #define UHC_MAXCON 40    // contacts per env (general kernel)
 #define UHC_FAST_MAXCON 16  // contacts per env (fast kernel)
+#define UHC_MAXTWO 32       // constraint rows between two moving bodies per env (general kernel); they are kept as dense dof vectors
+#define UHC_FAST_MAXTWO 12  // the same for the fast kernel
 #define UHC_CON_STRIDE 24
 #define UHC_MINVAL 1e-15
 #define UHC_MAXVAL 1e10
@@ -28,6 +30,9 @@ struct DevTopo {
     const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
     const int *mesh_adjadr, *mesh_adj;
     const int *pair_g1, *pair_g2;  // statically filtered candidate geom pairs (g1 = plane, g2 = mesh)
+    const int *cpair_g1, *cpair_g2;  // statically filtered convex-convex candidate pairs (mesh, mesh), g1 < g2, in (g1, g2) order
+    int ncpair;
+    const int* dof_rootid;  // [nv] body id of the kinematic-tree root the dof belongs to (its cdof are taken about that tree's COM)
     const int* actuator_dofid;
     int body_maxdepth;
     // static schedules of the tree-sparse factorisation / substitutions (uhc_capi.cpp).  Entries are LDS byte addresses
@@ -59,6 +64,8 @@ struct DevLds {
     int M, LD, dinv, sdinv, bias, smooth, vec, z, zero;
     int mij;  // 16-bit (row << 8 | col) of every sparse-M entry, loaded once per kernel (k_crb)
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
+    int dense;  // [ndense][nvp] dense Yhat rows of the constraints that touch two moving bodies (self-collision, objects)
+    int dcol;   // fast kernel: [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back)
     int total;  // doubles
 };
 
@@ -88,6 +95,8 @@ struct KernelArgs {
     int ycap;   // doubles available for packed Yhat rows in the fast layout
     int ld_delta;  // bytes to add to the schedule tables' LDS addresses in the general layout
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
+    int ndense_f, ndense_g;  // dense-row slots of the fast / general layout (0: the model has no two-body contacts)
+    int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     DevCtrl c;
     DevState s;
     int n_env;

@@ -12,6 +12,7 @@
 #include <type_traits>
 #include "../../include/uhc_amd.h"
 #include "uhc_device.h"
+#include "uhc_mpr.h"
 
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
@@ -421,7 +422,7 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
 // Per-lane topology constants, loaded once per kernel: the lane owns dofs LANE and LANE+64.
 // pk packs (madr | depth << 16 | ndesc << 24) so that a wave-uniform dof index i can fetch its row
 // address / depth / descendant count with one v_readlane instead of a table load.
-struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1; bool v0, v1; };
+struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1, r0, r1; bool v0, v1; };  // r0, r1: tree-root body of the lane's dofs
 __device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
     LaneConst c;
     const int i0 = LANE, i1 = LANE + UHC_WAVE;
@@ -429,6 +430,7 @@ __device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
     c.d0 = c.v0 ? T.dof_depth[i0] : 0; c.d1 = c.v1 ? T.dof_depth[i1] : 0;
     c.n0 = c.v0 ? T.dof_ndesc[i0] : -1; c.n1 = c.v1 ? T.dof_ndesc[i1] : -1;
     c.m0 = c.v0 ? T.dof_madr[i0] : 0; c.m1 = c.v1 ? T.dof_madr[i1] : 0;
+    c.r0 = c.v0 ? T.dof_rootid[i0] : 0; c.r1 = c.v1 ? T.dof_rootid[i1] : 0;
     c.pk0 = c.m0 | (c.d0 << 16) | ((c.v0 ? c.n0 : 0) << 24);
     c.pk1 = c.m1 | (c.d1 << 16) | ((c.v1 ? c.n1 : 0) << 24);
     return c;
@@ -739,16 +741,14 @@ __device__ __forceinline__ PairConst pair_of(const DevTopo& T, const PairConst& 
     return c;
 }
 template <bool FAST>
-__device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, const PairConst& P, const double* w,
-                                const double* n, double dist, double margin, double gap) {
-    const int g1 = P.g1, g2 = P.g2;
+__device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, int b1, int b2, int dim,
+                                                const double* pos, const double* n, double dist, double margin, double gap) {
     const DevTopo& T = A.t;
     double* C = S + (FAST ? A.lf : A.l).con + c * UHC_CON_STRIDE;
     double fr[9];
-    for (int k = 0; k < 3; k++) { C[k] = w[k] - 0.5 * dist * n[k]; fr[k] = n[k]; }
+    for (int k = 0; k < 3; k++) { C[k] = pos[k]; fr[k] = n[k]; }
     make_frame(fr);
     for (int k = 0; k < 9; k++) C[3 + k] = fr[k];
-    const int b1 = P.b1, b2 = P.b2, dim = P.dim;
     const double inc = margin - gap;
     double solref[2], solimp[5];
     for (int k = 0; k < 2; k++) solref[k] = 0.5 * (mb[A.o.geom_solref + 2 * g1 + k] + mb[A.o.geom_solref + 2 * g2 + k]);
@@ -848,12 +848,54 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             }
             const unsigned long long cm = __ballot(ok);
             const int rank = __popcll(cm & ((1ull << LANE) - 1ull));
-            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < MAXCON_OF(FAST))
-                k_write_contact<FAST>(A, mb, S, ncon + rank, P, w, n, dist, margin, gap);
+            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < MAXCON_OF(FAST)) {
+                const double cp[3] = {w[0] - 0.5 * dist * n[0], w[1] - 0.5 * dist * n[1], w[2] - 0.5 * dist * n[2]};
+                k_write_contact<FAST>(A, mb, S, ncon + rank, P.g1, P.g2, P.b1, P.b2, P.dim, cp, n, dist, margin, gap);
+            }
             const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
             if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;  // 2: truncated, 1: needs the general kernel
             ncon = min(MAXCON_OF(FAST), want);
         }
+    }
+    // ---- convex-convex pairs (hull vs hull): one candidate pair per lane through bounding-sphere cull and MPR (uhc_mpr.h); the hits
+    //      become contacts in pair order.  Contact = (pos, normal from geom 1 to geom 2, dist = margin - depth) [MJ-ext mjc_Convex].
+    for (int p0 = 0; p0 < T.ncpair; p0 += UHC_WAVE) {
+        const int p = p0 + LANE;
+        bool hit = false;
+        int g1 = 0, g2 = 0, b1 = 0, b2 = 0;
+        double depth = 0, margin = 0, gap = 0;
+        V3 dir = v3(0, 0, 0), pos = v3(0, 0, 0);
+        if (p < T.ncpair) {
+            g1 = T.cpair_g1[p]; g2 = T.cpair_g2[p];
+            b1 = T.geom_bodyid[g1]; b2 = T.geom_bodyid[g2];
+            CcdHull H1, H2;
+            for (int k = 0; k < 9; k++) { H1.R[k] = S[L.xmat + 9 * b1 + k]; H2.R[k] = S[L.xmat + 9 * b2 + k]; }
+            H1.p = v3(S[L.xpos + 3 * b1], S[L.xpos + 3 * b1 + 1], S[L.xpos + 3 * b1 + 2]);
+            H2.p = v3(S[L.xpos + 3 * b2], S[L.xpos + 3 * b2 + 1], S[L.xpos + 3 * b2 + 2]);
+            H1.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g1]; H1.vn = T.geom_vertnum[g1];
+            H2.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g2]; H2.vn = T.geom_vertnum[g2];
+            double ce1[3], ce2[3], t1[3], t2[3];
+            for (int k = 0; k < 3; k++) { ce1[k] = mb[A.o.geom_center + 3 * g1 + k]; ce2[k] = mb[A.o.geom_center + 3 * g2 + k]; }
+            mat_vec(t1, H1.R, ce1); mat_vec(t2, H2.R, ce2);
+            const V3 c1 = v3(t1[0] + H1.p.x, t1[1] + H1.p.y, t1[2] + H1.p.z), c2 = v3(t2[0] + H2.p.x, t2[1] + H2.p.y, t2[2] + H2.p.z);
+            margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+            gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
+            const double bound = mb[A.o.geom_rbound + g1] + mb[A.o.geom_rbound + g2] + margin;
+            const V3 dc = c1 - c2;
+            if (!(vdot(dc, dc) > bound * bound)) {
+                hit = mpr_penetration(H1, H2, c1, c2, margin, depth, dir, pos);
+                hit = hit && !(dir.x == 0 && dir.y == 0 && dir.z == 0);
+            }
+        }
+        const unsigned long long hm = __ballot(hit);
+        const int rank = __popcll(hm & ((1ull << LANE) - 1ull));
+        if (hit && ncon + rank < MAXCON_OF(FAST)) {
+            const double cp[3] = {pos.x, pos.y, pos.z}, nn[3] = {dir.x, dir.y, dir.z};
+            k_write_contact<FAST>(A, mb, S, ncon + rank, g1, g2, b1, b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - depth, margin, gap);
+        }
+        const int want = ncon + (int)__popcll(hm);
+        if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;
+        ncon = min(MAXCON_OF(FAST), want);
     }
     wsync();
     return ncon;
@@ -865,6 +907,9 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
 #define ROW_LIMIT 2
 #define ROW_CONTACT 3
 #define ROW_PYR 4
+#define ROW_TWO 0x10   // contact between two moving bodies: the row is kept as a dense dof vector (slot = type >> 8), not along one chain
+#define ROW_NEG 0x20   // single-chain contact row whose moving body is geom 1's (geom 2's is static): Jacobian sign -1
+#define RTYPE(t) ((t) & 0xf)
 struct RowMisc { int type, last, aux, edge; };  // aux: contact id | dof ; edge: pyramid edge | sign
 
 template <bool FAST>
@@ -903,46 +948,115 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     wsync();
     // (3) contacts
     if (LANE == 0) {
-        int r = nefc, trunc = 0;
+        int r = nefc, trunc = 0, ntwo = 0, twofull = 0;
+        int* NI = (int*)(S + L.ncon_nefc);
+        const int maxtwo = FAST ? A.ndense_f : A.ndense_g;
         for (int c = 0; c < ncon; c++) {
             const double* C = S + L.con + c * UHC_CON_STRIDE;
             if (C[12] >= C[13]) continue;
-            const int dim = (int)C[21], b2 = (int)C[20];
-            const int nr = dim == 1 ? 1 : 4, last = T.body_lastdof[b2];
+            const int dim = (int)C[21], b1 = (int)C[19], b2 = (int)C[20];
+            const int nr = dim == 1 ? 1 : 4, l1 = T.body_lastdof[b1], l2 = T.body_lastdof[b2];
+            const bool two = l1 >= 0 && l2 >= 0;
             if (FAST && A.truncate && r + nr > MAXEFC_OF(FAST)) { trunc = 1; break; }  // whole contacts only
+            if (two && ntwo + nr > maxtwo) { twofull = 1; if (FAST && !A.truncate) break; continue; }  // no dense slot left
             for (int e = 0; e < nr; e++, r++)
-                if (r < MAXEFC_OF(FAST)) { RM[r].type = dim == 1 ? ROW_CONTACT : ROW_PYR; RM[r].last = last; RM[r].aux = c; RM[r].edge = e; }
+                if (r < MAXEFC_OF(FAST)) {
+                    int ty = dim == 1 ? ROW_CONTACT : ROW_PYR;
+                    if (two) { ty |= ROW_TWO | (ntwo << 8); NI[4 + ntwo] = r; ntwo++; }
+                    else if (l2 < 0) ty |= ROW_NEG;
+                    RM[r].type = ty; RM[r].last = two ? -1 : (l2 >= 0 ? l2 : l1); RM[r].aux = c; RM[r].edge = e;
+                }
         }
-        ((int*)(S + L.ncon_nefc))[1] = r;
-        ((int*)(S + L.ncon_nefc))[0] = trunc;
+        NI[1] = r; NI[0] = trunc; NI[2] = ntwo; NI[3] = twofull;
     }
     wsync();
     nefc = ((int*)(S + L.ncon_nefc))[1];
     if (((int*)(S + L.ncon_nefc))[0]) *overflow |= 2;
+    if (((int*)(S + L.ncon_nefc))[3]) *overflow |= (FAST && !A.truncate) ? 1 : 2;  // fast: the general kernel has more dense slots; else rows were dropped
     if (nefc > MAXEFC_OF(FAST)) { *overflow |= (FAST && A.truncate) ? 2 : 1; nefc = MAXEFC_OF(FAST); }
     return nefc;
+}
+
+// A contact between two moving bodies (hull vs hull of one humanoid, object vs body) has J = J_b2(p) - J_b1(p): non-zero on the union
+// of two dof chains (up to 45 dofs for two arms; two disjoint trees for an object), which the chain-packed rows cannot hold.  Such rows
+// are kept DENSE: Yhat = D^-1/2 L^-T J^T as an nv-vector in LDS (slot `slot`), built wave-cooperatively with lane = dof: the Jacobian
+// entry of dof i is +-dv . (cdof_lin + cdof_ang x (p - c0(i))) if i lies on the chain of body 2 / body 1 (both: the contributions
+// cancel exactly, as in the oracle's jp2 - jp1), the back substitution is the register-resident sweep of k_solve.  Returns the row's
+// J.qvel, J.qacc_smooth, J.qacc_warmstart and |Yhat|^2 (wave-uniform).
+struct DenseOut { double vel, jas, jaw, yy; };
+template <bool FAST>
+__device__ __forceinline__ DenseOut k_dense_row(const KernelArgs& A, double* S, int r, int slot, const LaneConst& LC) {
+    const DevTopo& T = A.t;
+    const DevLds& L = FAST ? A.lf : A.l;
+    const RowMisc rm = ((const RowMisc*)(S + L.rowMisc))[r];
+    const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
+    const int l1 = T.body_lastdof[(int)C[19]], l2 = T.body_lastdof[(int)C[20]];
+    double dv[3];
+    if (RTYPE(rm.type) == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+    else {
+        const double sgn = (rm.edge & 1) ? -1.0 : 1.0, mu = C[14];
+        const int td = 1 + rm.edge / 2;
+        for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
+    }
+    DofVec x = {0.0, 0.0};
+    double qv[2] = {0, 0}, qs[2] = {0, 0}, qw[2] = {0, 0};
+    for (int h = 0; h < 2; h++) {
+        const int i = LANE + h * UHC_WAVE, nd = h ? LC.n1 : LC.n0, root = h ? LC.r1 : LC.r0;
+        if (!(h ? LC.v1 : LC.v0)) continue;
+        const int sg = (int)(i <= l2 && l2 <= i + nd) - (int)(i <= l1 && l1 <= i + nd);
+        double j = 0.0;
+        if (sg != 0) {
+            double cd[6], off[3], cr[3];
+            for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
+            for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
+            cross3(cr, cd, off);
+            j = (double)sg * (dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]));
+        }
+        if (h) x.b = j; else x.a = j;
+        qv[h] = S[L.qvel + i]; qs[h] = S[L.smooth + i]; qw[h] = S[L.qacc + i];
+    }
+    DenseOut o;
+    o.vel = wave_sum(x.a * qv[0] + x.b * qv[1]);
+    o.jas = wave_sum(x.a * qs[0] + x.b * qs[1]);
+    o.jaw = wave_sum(x.a * qw[0] + x.b * qw[1]);
+    if (T.nv >= 2) solve_sweep<true>(T.sol_back + LANE, (const char*)S + (FAST ? 0 : A.ld_delta), T.nv - 1, x);  // x <- L^-T x
+    double* D = S + L.dense + slot * A.nvp;
+    double y0 = 0.0, y1 = 0.0;
+    if (LC.v0) { y0 = x.a * S[L.sdinv + LANE]; D[LANE] = y0; }
+    if (LC.v1) { y1 = x.b * S[L.sdinv + LANE + UHC_WAVE]; D[LANE + UHC_WAVE] = y1; }
+    o.yy = wave_sum(y0 * y0 + y1 * y1);
+    return o;
 }
 
 // Per row (lane r and r+64): J over the dof chain of the row, reference acceleration, R, warm-start
 // force, and Yhat = D^-1/2 L^-T J^T stored chain-sparse (index = depth of the dof).
 template <bool FAST>
-__device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nefc) {
+__device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
     const int YS = T.maxdepth + 1;
+    const int* NI = (const int*)(S + L.ncon_nefc);
+    const int ntwo = (FAST ? A.ndense_f : A.ndense_g) > 0 ? NI[2] : 0;
+    for (int k = 0; k < ntwo; k++) {  // dense rows first (wave-cooperative); their scalars wait in dcol for the lane that owns the row
+        const DenseOut o = k_dense_row<FAST>(A, S, NI[4 + k], k, LC);
+        if (LANE == 0) { S[L.dcol + 4 * k] = o.vel; S[L.dcol + 4 * k + 1] = o.jas; S[L.dcol + 4 * k + 2] = o.jaw; S[L.dcol + 4 * k + 3] = o.yy; }
+    }
+    wsync();
     for (int r = LANE; r < nefc; r += UHC_WAVE) {
         const RowMisc rm = RM[r];
-        const int last = rm.last, len = T.dof_depth[last] + 1;
-        const short* anc = T.dof_anc + last * YS;
+        const int rt = RTYPE(rm.type);
+        const bool two = (rm.type & ROW_TWO) != 0;
+        const int last = rm.last, len = two ? 0 : T.dof_depth[last] + 1;
+        const short* anc = T.dof_anc + (two ? 0 : last) * YS;
         double* Y = S + L.Y + r * YS;
         double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
-        if (rm.type == ROW_FRICTION || rm.type == ROW_LIMIT) {
+        if (rt == ROW_FRICTION || rt == ROW_LIMIT) {
             const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
             const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
             K = 1.0 / (dmax * dmax * timeconst * timeconst);
             B = 2.0 / (dmax * timeconst);
-            if (rm.type == ROW_LIMIT) {
+            if (rt == ROW_LIMIT) {
                 const int j = rm.aux;
                 const double v = S[L.qpos + T.jnt_qposadr[j]];
                 margin = mb[A.o.jnt_margin + j];
@@ -958,16 +1072,17 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
             imp = impedance(dsolimp, pos, margin);
         } else {
             const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
-            const int b2 = (int)C[20];
-            const int root = T.body_rootid[b2];
+            const int bb = (rm.type & ROW_NEG) ? (int)C[19] : (int)C[20];  // the moving body of a single-chain row
+            const double jsg = (rm.type & ROW_NEG) ? -1.0 : 1.0;
+            const int root = T.body_rootid[bb];
             double off[3], dv[3];
             const double mu = C[14];
             for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
-            if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+            if (rt == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = jsg * C[3 + k];
             else {
                 const double sgn = (rm.edge & 1) ? -1.0 : 1.0;
                 const int td = 1 + rm.edge / 2;
-                for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
+                for (int k = 0; k < 3; k++) dv[k] = jsg * (C[3 + k] + sgn * mu * C[3 + 3 * td + k]);
             }
             for (int q = 0; q < len; q++) {
                 const int i = anc[q];
@@ -977,8 +1092,8 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
                 Y[q] = dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]);
             }
             pos = C[12]; margin = C[13]; K = C[15]; B = C[16]; imp = C[17];
-            diagApprox = rm.type == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
-            if (rm.type == ROW_PYR) {
+            diagApprox = rt == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
+            if (rt == ROW_PYR) {
                 // all edges of a pyramid share R = 2 mu^2 R(first edge); first edge uses friction[0] = mu
                 const double R0 = fmax(UHC_MINVAL, (1 - imp) * (C[18] + mu * mu * C[18]) / imp);
                 diagApprox = -2 * mu * mu * R0;  // negative => final R given directly
@@ -992,11 +1107,13 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
             jas += j * S[L.smooth + i];
             jaw += j * S[L.qacc + i];
         }
+        double yy = 0;
+        if (two) { const double* o = S + L.dcol + 4 * (rm.type >> 8); vel = o[0]; jas = o[1]; jaw = o[2]; yy = o[3]; }
         const double R = diagApprox < 0 ? -diagApprox : fmax(UHC_MINVAL, (1 - imp) * diagApprox / imp);
         const double aref = -B * vel - K * imp * (pos - margin);
         const double jar = jaw - aref, D = 1.0 / R;
         double f;
-        if (rm.type == ROW_FRICTION) f = clampd(-D * jar, -floss, floss);
+        if (rt == ROW_FRICTION) f = clampd(-D * jar, -floss, floss);
         else f = jar < 0 ? -D * jar : 0.0;
         // Y <- L^-T Y restricted to the chain, then scale by sqrt(1/D_i)
         for (int q = len - 1; q >= 1; q--) {
@@ -1005,7 +1122,7 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
             const int mi = T.dof_madr[i];
             for (int q2 = q - 1; q2 >= 0; q2--) Y[q2] -= S[L.LD + mi + (q - q2)] * xi;
         }
-        double da = R;
+        double da = R + yy;
         for (int q = 0; q < len; q++) {
             const double y = Y[q] * S[L.sdinv + anc[q]];
             Y[q] = y;
@@ -1029,7 +1146,9 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
     const int YS = T.maxdepth + 1;
     double* z = S + L.z;
-    // z from the warm-start forces: dof-per-lane pull over all rows
+    const int* NI = (const int*)(S + L.ncon_nefc);
+    const int ntwo = (FAST ? A.ndense_f : A.ndense_g) > 0 ? NI[2] : 0;
+    // z from the warm-start forces: dof-per-lane pull over all rows (dense rows carry last = -1 and are added from their slots)
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         const int di = T.dof_depth[i], nd = T.dof_ndesc[i];
         double acc = 0;
@@ -1037,17 +1156,24 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
             const int last = RM[r].last;
             if (last >= i && last <= i + nd) acc += S[L.rowF + r] * S[L.Y + r * YS + di];
         }
+        for (int k = 0; k < ntwo; k++) acc += S[L.rowF + NI[4 + k]] * S[L.dense + k * A.nvp + i];
         z[i] = acc;
     }
     wsync();
     // dual cost of the warm start; fall back to zero forces if it is not an improvement
     double cost = 0;
     for (int r = LANE; r < nefc; r += UHC_WAVE) {
-        const int last = RM[r].last, len = T.dof_depth[last] + 1;
-        const short* anc = T.dof_anc + last * YS;
+        const RowMisc rm = RM[r];
         const double f = S[L.rowF + r];
         double af = S[L.rowR + r] * f;
-        for (int q = 0; q < len; q++) af += S[L.Y + r * YS + q] * z[anc[q]];
+        if (rm.type & ROW_TWO) {
+            const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
+            for (int i = 0; i < T.nv; i++) af += D[i] * z[i];
+        } else {
+            const int last = rm.last, len = T.dof_depth[last] + 1;
+            const short* anc = T.dof_anc + last * YS;
+            for (int q = 0; q < len; q++) af += S[L.Y + r * YS + q] * z[anc[q]];
+        }
         cost += f * (0.5 * af + S[L.rowB + r]);
     }
     cost = wave_sum(cost);
@@ -1062,10 +1188,15 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
         double improvement = 0;
         for (int r = 0; r < nefc; r++) {
             const RowMisc rm = RM[r];
-            const int len = T.dof_depth[rm.last] + 1;
+            const bool two = (rm.type & ROW_TWO) != 0;
+            const int len = two ? 0 : T.dof_depth[rm.last] + 1;
             int dof = 0;
-            double y = 0, part = 0;
-            if (LANE < len) {
+            double y = 0, part = 0, y1 = 0;
+            if (two) {  // dense row: lane = dof (two per lane)
+                const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
+                if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
+                if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
+            } else if (LANE < len) {
                 dof = T.dof_anc[rm.last * YS + LANE];
                 y = S[L.Y + r * YS + LANE];
                 part = y * z[dof];
@@ -1073,14 +1204,17 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
             const double old = S[L.rowF + r], Rr = S[L.rowR + r], Arr = S[L.rowDa + r];
             const double res = wave_sum(part) + Rr * old + S[L.rowB + r];
             double f = old - res / Arr;
-            if (rm.type == ROW_FRICTION) { const double fl = S[L.rowAref + r]; f = clampd(f, -fl, fl); }
+            if (RTYPE(rm.type) == ROW_FRICTION) { const double fl = S[L.rowAref + r]; f = clampd(f, -fl, fl); }
             else f = f < 0 ? 0.0 : f;
             double delta = f - old;
             double change = 0.5 * delta * delta * Arr + delta * res;
             if (change > 1e-10) { f = old; delta = 0; change = 0; }
             improvement -= change;
             if (delta != 0) {
-                if (LANE < len) z[dof] += delta * y;
+                if (two) {
+                    if (LANE < T.nv) z[LANE] += delta * y;
+                    if (LANE + UHC_WAVE < T.nv) z[LANE + UHC_WAVE] += delta * y1;
+                } else if (LANE < len) z[dof] += delta * y;
                 if (LANE == 0) S[L.rowF + r] = f;
             }
             wsync();
@@ -1097,7 +1231,7 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
 // packed), and row r of the Delassus matrix A = Yhat Yhat^T + diag(R) in 64 VGPR pairs.  A PGS row
 // update is then: lane i computes its own step, one broadcast of delta, one FMA per lane on the
 // residual vector -- no reduction and no LDS traffic inside the sweep.
-struct FastRow { int type, last, len, yoff; double R, b, f, floss, diag; };
+struct FastRow { int type, last, len, yoff, two /* dense slot or -1 */; double R, b, f, floss, diag; };
 
 
 __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
@@ -1119,7 +1253,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 // (q-th dof of the chain | LDS byte address of that dof's L row << 16); positions past the chain end point at safe
 // finite data and meet Y = 0.  The finished rows are also stored to LDS (packed) for the A build of the other lanes.
 #define UHC_YM 32
-__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int& nefc, FastRow& row, double (&Y)[UHC_YM]) {
+__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int& nefc, FastRow& row, double (&Y)[UHC_YM], const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
@@ -1128,8 +1262,13 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     bool valid = r < nefc;
     RowMisc rm = {0, 0, 0, 0};
     if (valid) rm = RM[r];
-    row.type = rm.type; row.last = rm.last;
-    row.len = valid ? T.dof_depth[rm.last] + 1 : 0;
+    const bool two = (rm.type & ROW_TWO) != 0;  // dense row (two moving bodies): no chain, built wave-cooperatively below
+    const bool jneg = (rm.type & ROW_NEG) != 0;
+    row.two = two ? (rm.type >> 8) : -1;
+    rm.type = RTYPE(rm.type);
+    if (two) rm.last = 0;
+    row.type = rm.type; row.last = two ? -1 : rm.last;
+    row.len = (valid && !two) ? T.dof_depth[rm.last] + 1 : 0;
     int total, status = 0;
     row.yoff = wave_excl_scan(row.len, &total);
     row.R = 1; row.b = 0; row.f = 0; row.floss = 0; row.diag = 1;
@@ -1181,15 +1320,16 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
         imp = impedance(dsolimp, pos, margin);
     } else if (is_con) {
         const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
-        const int b2 = (int)C[20];
-        const int root = T.body_rootid[b2];
+        const int bb = jneg ? (int)C[19] : (int)C[20];  // the moving body of a single-chain row
+        const double jsg = jneg ? -1.0 : 1.0;
+        const int root = T.body_rootid[bb];
         const double mu = C[14];
         for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
-        if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+        if (rm.type == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = jsg * C[3 + k];
         else {
             const double sgn = (rm.edge & 1) ? -1.0 : 1.0;
             const int td = 1 + rm.edge / 2;
-            for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
+            for (int k = 0; k < 3; k++) dv[k] = jsg * (C[3 + k] + sgn * mu * C[3 + 3 * td + k]);
         }
         pos = C[12]; margin = C[13]; K = C[15]; B = C[16]; imp = C[17];
         diagApprox = rm.type == ROW_CONTACT ? C[18] : C[18] + mu * mu * C[18];
@@ -1201,6 +1341,16 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     }
     // ---- J along the chain, and J.qvel, J.qacc_smooth, J.qacc_warmstart
     double vel = 0, jas = 0, jaw = 0;
+    if (A.ndense_f > 0) {  // dense rows: wave-cooperative (lane = dof), their scalars go to the lane that owns the row
+        const int* NI = (const int*)(S + L.ncon_nefc);
+        const int ntwo = NI[2];
+        for (int k = 0; k < ntwo; k++) {
+            const int rr = __builtin_amdgcn_readfirstlane(NI[4 + k]);
+            if (rr >= nefc) break;  // dropped by the truncation above
+            const DenseOut o = k_dense_row<true>(A, S, rr, k, LC);
+            if (LANE == rr) { vel = o.vel; jas = o.jas; jaw = o.jaw; }
+        }
+    }
     // chain positions in groups of four: one uniform test per group (a branch costs 25-60 cycles here) and the LDS reads of four
     // positions in flight together; positions past a row's own length yield y = 0, chain slots past the chain hold dof 0
     static_for<0, UHC_YM / 4>([&](auto gc) __attribute__((always_inline)) {
@@ -1398,10 +1548,40 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
 }
 
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
-__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM] PROF_ARGS) {
+__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM], const LaneConst& LC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const bool valid = LANE < nefc;
+    const int* NI = (const int*)(S + L.ncon_nefc);
+    int ntwo = 0;  // dense rows among the first nefc rows (wave-uniform)
+    if (A.ndense_f > 0) {
+        const int nt = NI[2];
+        for (int k = 0; k < nt; k++) ntwo += NI[4 + k] < nefc;
+        ntwo = __builtin_amdgcn_readfirstlane(ntwo);
+    }
+    // ---- Delassus columns of the dense rows: A[l][c] = Yhat_l . Yhat_c for every lane l, kept in LDS (dcol[slot][lane]): lane l reads its
+    //      entry when column c comes up below, and -- A being symmetric -- the lane that owns dense row c reads its whole ROW from there.
+    if (ntwo > 0) {
+        unsigned int cdq[UHC_YM];
+        const unsigned int* chain = T.chain + (size_t)(row.last >= 0 ? row.last : 0) * UHC_YM;
+        static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { constexpr int q = decltype(qc)::value; cdq[q] = chain[q] & 0xffffu; });
+        for (int k = 0; k < ntwo; k++) {
+            const double* Dk = S + L.dense + k * A.nvp;
+            double acc = 0.0;
+            static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                acc = fma(Y[q], Dk[cdq[q]], acc);  // Y is zero past the row's own chain (and for dense rows)
+            });
+            if (row.two >= 0) {
+                const double* Dm = S + L.dense + row.two * A.nvp;
+                double a2 = 0.0;
+                for (int i = 0; i < T.nv; i++) a2 = fma(Dm[i], Dk[i], a2);
+                acc = a2;
+            }
+            S[L.dcol + k * UHC_WAVE + LANE] = valid ? acc : 0.0;
+        }
+        wsync();
+    }
     // ---- A[r][s] = sum over the common part of the two dof chains, entirely in registers: row s is broadcast from lane
     //      the packed LDS rows (same address in all lanes), the own row is pre-masked to the common chain prefix.  Rows of one body are
     //      adjacent and share that prefix length, so the masked copy is rebuilt only when the body changes.
@@ -1413,7 +1593,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
             nraw[s] = 0;
             if (s < nefc) {
                 const int ls = __builtin_amdgcn_readlane(row.last, s);
-                nraw[s] = valid ? (int)A.t.dof_ncommon[row.last * T.nv + ls] : 0;
+                nraw[s] = (valid && row.last >= 0 && ls >= 0) ? (int)A.t.dof_ncommon[row.last * T.nv + ls] : 0;
             }
         });
         static_for<0, UHC_WAVE / 4>([&](auto jc) __attribute__((always_inline)) {
@@ -1426,12 +1606,17 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     double diag = 1.0;
     int prev = -1;
     static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { Ym[decltype(qc)::value] = 0.0; });
+    auto build_A = [&](auto dense_c) __attribute__((always_inline)) {
+    constexpr bool DENSE = decltype(dense_c)::value;
     static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         double acc = 0.0;
         if (s < nefc) {
             const int ls = __builtin_amdgcn_readlane(row.last, s);
             const int lens = __builtin_amdgcn_readlane(row.len, s);
+            const int two_s = DENSE ? __builtin_amdgcn_readlane(row.two, s) : -1;
+            if (DENSE && two_s >= 0) acc = S[L.dcol + two_s * UHC_WAVE + LANE];
+            else {
             const double* Ys = S + L.Y + __builtin_amdgcn_readlane(row.yoff, s);  // row s in LDS: one broadcast read per entry
             if (ls != prev) {
                 prev = ls;
@@ -1456,11 +1641,16 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
                     });
                 }
             });
+            if (DENSE && row.two >= 0) acc = S[L.dcol + row.two * UHC_WAVE + s];  // the dense row's own lane: its row of A by symmetry
+            }
+            if (DENSE && !valid) acc = 0.0;
             if (s == LANE) { acc += row.R; diag = acc; }
         }
         agpr_put(Alo[s], __double2loint(acc));
         agpr_put(Ahi[s], __double2hiint(acc));
     });
+    };
+    if (ntwo > 0) build_A(std::true_type{}); else build_A(std::false_type{});
     if (!valid) diag = 1.0;
     PROF(10)
     const bool any_fric = wave_or(row.type == ROW_FRICTION ? 1 : 0) != 0;
@@ -1548,7 +1738,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     //      per-dof accumulators with LDS float64 atomics (rows of one body hit the same addresses; the LDS unit serialises them)
     for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.z + i] = 0.0;
     wsync();
-    if (valid) {
+    if (valid && row.last >= 0) {
         const unsigned int* chain = T.chain + (size_t)row.last * UHC_YM;
         const double* Yr = S + L.Y + row.yoff;
         static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
@@ -1557,6 +1747,15 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         });
     }
     wsync();
+    if (ntwo > 0) {  // dense rows: lane = dof
+        for (int k = 0; k < ntwo; k++) {
+            const double fk = bcast(f, __builtin_amdgcn_readfirstlane(NI[4 + k]));
+            const double* Dk = S + L.dense + k * A.nvp;
+            if (LC.v0) S[L.z + LANE] += fk * Dk[LANE];
+            if (LC.v1) S[L.z + LANE + UHC_WAVE] += fk * Dk[LANE + UHC_WAVE];
+        }
+        wsync();
+    }
     return iters;
 }
 
@@ -1594,14 +1793,14 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
         if (FAST) {
             FastRow row;
             double Yreg[UHC_YM];
-            const int st = k_rows_fast(A, mb, S, out.nefc, row, Yreg);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
+            const int st = k_rows_fast(A, mb, S, out.nefc, row, Yreg, LC);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
             out.overflow |= st;
             if (st == 1) return out;
             PROF(9)
-            out.iters = k_pgs_fast(A, mb, S, out.nefc, row, Yreg PROF_PASS);
+            out.iters = k_pgs_fast(A, mb, S, out.nefc, row, Yreg, LC PROF_PASS);
             PROF(12)
         } else {
-            k_rows<FAST>(A, mb, S, out.nefc);
+            k_rows<FAST>(A, mb, S, out.nefc, LC);
             PROF(9)
             out.iters = k_pgs<FAST>(A, mb, S, out.nefc);
             PROF(11)

@@ -82,7 +82,7 @@ class DatasetAMASSSingle:
         if freq_dict is None or len(freq_dict.keys()) != len(self.data_keys):
             self.curr_key = random.choice(self.sample_keys)[0]
         else:
-            succ = np.array([ewma(np.array(freq_dict[k])[:, 0] == 1) if len(freq_dict[k]) > 0 else 0 for k in freq_dict.keys()])
+            succ = np.array([ewma(np.array(freq_dict[k])[:, 0] == 1) if len(freq_dict[k]) > 0 else 0 for k in freq_dict.keys()], dtype=np.float64)  # (one-entry histories are numpy bools)
             p = np.exp(-succ / sampling_temp)
             p = p / p.sum()
             self.curr_key = np.random.choice(self.data_keys, p=p) if np.random.binomial(1, sampling_freq) else np.random.choice(self.data_keys)
@@ -125,7 +125,7 @@ class DatasetAMASSSingle:
         if freq_dict is None or len(freq_dict.keys()) != len(self.data_keys):
             keys = [random.choice(self.sample_keys)[0] for _ in range(n)]
         else:
-            succ = np.array([ewma(np.array(freq_dict[k])[:, 0] == 1) if len(freq_dict[k]) > 0 else 0 for k in freq_dict.keys()])
+            succ = np.array([ewma(np.array(freq_dict[k])[:, 0] == 1) if len(freq_dict[k]) > 0 else 0 for k in freq_dict.keys()], dtype=np.float64)  # (one-entry histories are numpy bools)
             p = np.exp(-succ / sampling_temp)
             p = p / p.sum()
             weighted = np.random.binomial(1, sampling_freq, size=n).astype(bool)

@@ -878,3 +878,21 @@ def scale_model(m: Model, s: float) -> Model:
     o.qpos_spring = o.qpos0.copy()
     set_const(o)
     return o
+
+
+def self_collision_variant(m: Model) -> Model:
+    """The model with body-body collisions switched on, as the reference's GENERATED models have them (every body geom contype = 1,
+    conaffinity = 1: uhc/smpllib/smpl_parser.py:327-328; Chest excluded against both shoulders: uhc/smpllib/smpl_robot.py:1177-1198).
+    The shipped static asset is floor-only (contype 0); this is the same humanoid as the generator would emit it."""
+    o = m.copy()
+    o.geom_contype = m.geom_contype.copy()
+    o.geom_contype[np.asarray(m.geom_bodyid) > 0] = 1
+    ex = [list(p) for p in np.asarray(m.exclude_pair).reshape(-1, 2).tolist()]
+    for a, b in (("Chest", "L_Shoulder"), ("Chest", "R_Shoulder")):
+        if a in m.body_names and b in m.body_names:
+            pair = [m.body_names.index(a), m.body_names.index(b)]
+            if pair not in ex and pair[::-1] not in ex:
+                ex.append(pair)
+    o.exclude_pair = np.array(ex, dtype=np.int32).reshape(-1, 2)
+    o.nexclude = len(ex)
+    return o
