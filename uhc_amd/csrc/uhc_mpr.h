@@ -2,8 +2,7 @@
 //
 // What it replaces: the mesh-mesh branch of MuJoCo's mj_collision behind self.sim.step() (uhc/envs/humanoid_im.py:1177): generated
 // SMPL models collide every body hull with every other (uhc/smpllib/smpl_parser.py:327-328, excludes at uhc/smpllib/smpl_robot.py:
-// 1177-1198), which MuJoCo 2.1 resolves with libccd's ccdMPRPenetration [MJ-ext].  oracle/physics_oracle.c (mpr_penetration) is the
-// CPU restatement this file is checked against; both follow libccd's structure (discoverPortal / refinePortal / findPenetr / findPos)
+// 1177-1198), which MuJoCo 2.1 resolves with libccd's ccdMPRPenetration [MJ-ext].  the tests check this file against a CPU restatement of the same algorithm; both follow libccd's structure (discoverPortal / refinePortal / findPenetr / findPos)
 // and its zero / equality tests so that the same portal is found.
 //
 // Mapping to the hardware: the algorithm is a short, branchy, strictly serial refinement whose only wide operation is the support

@@ -981,7 +981,7 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
 // of two dof chains (up to 45 dofs for two arms; two disjoint trees for an object), which the chain-packed rows cannot hold.  Such rows
 // are kept DENSE: Yhat = D^-1/2 L^-T J^T as an nv-vector in LDS (slot `slot`), built wave-cooperatively with lane = dof: the Jacobian
 // entry of dof i is +-dv . (cdof_lin + cdof_ang x (p - c0(i))) if i lies on the chain of body 2 / body 1 (both: the contributions
-// cancel exactly, as in the oracle's jp2 - jp1), the back substitution is the register-resident sweep of k_solve.  Returns the row's
+// cancel exactly), the back substitution is the register-resident sweep of k_solve.  Returns the row's
 // J.qvel, J.qacc_smooth, J.qacc_warmstart and |Yhat|^2 (wave-uniform).
 struct DenseOut { double vel, jas, jaw, yy; };
 template <bool FAST>
