@@ -237,7 +237,7 @@ def main():
     batch, logger = agent.rollout_end()
     per_rank = [n_env * args.steps / elapsed]
     if dist_on:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         allt = [torch.empty_like(tt) for _ in range(world)]
         td.all_gather(allt, tt)
         per_rank = [n_env * args.steps / float(x.item()) for x in allt]
@@ -255,7 +255,7 @@ def main():
         t_up = time.perf_counter() - t1
         ncalls, comm_ms, comm_bytes = agent.comm_summary()
         if dist_on:
-            tt = torch.tensor([t_up], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([t_up], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             t_up = float(tt.item())
         n_samples = batch.states.shape[0] * world

@@ -34,8 +34,9 @@ def test_bench_json_contract():
 
 
 def test_bench_spawns_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher starts two RCCL ranks itself (here both on GPU 0) and reports the whole job."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--steps", "4", "--warmup", "2", "--envs", "64",
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself and reports the whole job.  On this one-GPU box both ranks
+    share GPU 0, which RCCL refuses (duplicate device), so the plumbing check rides on gloo; on an N-GPU node the default backend is RCCL."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "4", "--warmup", "2", "--envs", "64",
                           "--clips", "8"], cwd=ROOT, capture_output=True, text=True, timeout=1200,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert out.returncode == 0, out.stderr[-2000:]

@@ -16,9 +16,8 @@ NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "
 
 
 def build():
-    srcs = [os.path.join(CSRC, s) for s in ("uhc_physics.hip", "uhc_env.hip", "uhc_capi.cpp", "uhc_env_capi.cpp")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-Wno-unused-value", "-DUHC_STAGE_PROF", "-o", PROF_LIB] + srcs, cwd=CSRC)
+    import __graft_entry__ as g
+    g.compile_lib(lib=PROF_LIB, extra_flags=["-DUHC_STAGE_PROF"], obj_dir=os.path.join(CSRC, "build_prof"))
 
 
 if __name__ == "__main__":

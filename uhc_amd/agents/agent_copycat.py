@@ -181,7 +181,9 @@ class AgentCopycat(AgentPPO):
         cp = CustomUnpickler(open(path, "rb")).load()
         self.policy_net.load_state_dict(cp["policy_dict"])
         self.value_net.load_state_dict(cp["value_dict"])
-        self.running_state = cp["running_state"]
+        rs = cp["running_state"]  # copied INTO the agent's filter: its device tensors are referenced by the captured rollout graphs
+        self.running_state.set_mean_std(np.asarray(rs.rs.mean), np.asarray(rs.rs._S), int(rs.rs.n))
+        self.running_state.demean, self.running_state.destd, self.running_state.clip = rs.demean, rs.destd, rs.clip
         to_device(self.device, self.policy_net, self.value_net)
 
     def load_curr(self):

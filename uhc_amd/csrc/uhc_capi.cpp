@@ -13,9 +13,29 @@
 #include "../../include/uhc_amd.h"
 #include "uhc_device.h"
 
-extern "C" hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase,
-                                      const int* d_active, size_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast);
+// the instantiations of uhc_step_kernel<MODE, FAST, DENSE> live in separate translation units (uhc_k_*.hip) so that they compile in parallel
+#define UHC_DECL_LAUNCH(fn)                                                                                                               \
+    extern "C" hipError_t fn(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, \
+                             hipStream_t stream);                                                                                        \
+    extern "C" hipError_t fn##_lds(size_t lds_bytes);
+UHC_DECL_LAUNCH(uhc_launch_m0_fast) UHC_DECL_LAUNCH(uhc_launch_m0_fast_dense) UHC_DECL_LAUNCH(uhc_launch_m1_fast) UHC_DECL_LAUNCH(uhc_launch_m1_fast_dense)
+UHC_DECL_LAUNCH(uhc_launch_m2_fast) UHC_DECL_LAUNCH(uhc_launch_m0_gen) UHC_DECL_LAUNCH(uhc_launch_m1_gen) UHC_DECL_LAUNCH(uhc_launch_m2_gen)
+// mode 0: control step, 1: forward only, 2: kinematics only; fast: the compact-LDS kernel; dense: the model has body-body contacts
+static hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active,
+                                  size_t lds_bytes, hipStream_t stream) {
+    const bool dense = A->ndense_f > 0;
+    if (!fast) return (mode == 0 ? uhc_launch_m0_gen : mode == 1 ? uhc_launch_m1_gen : uhc_launch_m2_gen)(A, d_action, d_tbase, d_active, lds_bytes, stream);
+    if (mode == 2) return uhc_launch_m2_fast(A, d_action, d_tbase, d_active, lds_bytes, stream);
+    if (mode == 0) return (dense ? uhc_launch_m0_fast_dense : uhc_launch_m0_fast)(A, d_action, d_tbase, d_active, lds_bytes, stream);
+    return (dense ? uhc_launch_m1_fast_dense : uhc_launch_m1_fast)(A, d_action, d_tbase, d_active, lds_bytes, stream);
+}
+static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast) {
+    hipError_t e;
+    if ((e = uhc_launch_m0_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m1_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m2_gen_lds(lds_bytes)) != hipSuccess) return e;
+    if ((e = uhc_launch_m0_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m0_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
+    if ((e = uhc_launch_m1_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m1_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
+    return uhc_launch_m2_fast_lds(lds_bytes_fast);
+}
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream);
 

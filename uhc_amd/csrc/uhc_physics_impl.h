@@ -1,4 +1,5 @@
-// uhc_physics.hip -- fused rigid-body step for batched SMPL humanoids on MI355X (gfx950).
+#pragma once
+// uhc_physics_impl.h -- fused rigid-body step for batched SMPL humanoids on MI355X (gfx950).
 //
 // One environment per 64-lane wavefront (workgroup = 1 wave), every per-env intermediate in LDS or
 // registers, one launch per control step (n_substeps x {stable-PD, residual force, forward dynamics,
@@ -422,7 +423,8 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
 // Per-lane topology constants, loaded once per kernel: the lane owns dofs LANE and LANE+64.
 // pk packs (madr | depth << 16 | ndesc << 24) so that a wave-uniform dof index i can fetch its row
 // address / depth / descendant count with one v_readlane instead of a table load.
-struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1, r0, r1; bool v0, v1; };  // r0, r1: tree-root body of the lane's dofs
+struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1, r0, r1; bool v0, v1; };  // r0, r1: tree-root body of the lane's dofs (dense rows only)
+template <bool DENSE>
 __device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
     LaneConst c;
     const int i0 = LANE, i1 = LANE + UHC_WAVE;
@@ -430,7 +432,7 @@ __device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
     c.d0 = c.v0 ? T.dof_depth[i0] : 0; c.d1 = c.v1 ? T.dof_depth[i1] : 0;
     c.n0 = c.v0 ? T.dof_ndesc[i0] : -1; c.n1 = c.v1 ? T.dof_ndesc[i1] : -1;
     c.m0 = c.v0 ? T.dof_madr[i0] : 0; c.m1 = c.v1 ? T.dof_madr[i1] : 0;
-    c.r0 = c.v0 ? T.dof_rootid[i0] : 0; c.r1 = c.v1 ? T.dof_rootid[i1] : 0;
+    c.r0 = (DENSE && c.v0) ? T.dof_rootid[i0] : 0; c.r1 = (DENSE && c.v1) ? T.dof_rootid[i1] : 0;
     c.pk0 = c.m0 | (c.d0 << 16) | ((c.v0 ? c.n0 : 0) << 24);
     c.pk1 = c.m1 | (c.d1 << 16) | ((c.v1 ? c.n1 : 0) << 24);
     return c;
@@ -764,7 +766,7 @@ __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const doubl
     C[19] = b1; C[20] = b2; C[21] = dim;
 }
 // returns ncon (wave-uniform)
-template <bool FAST>
+template <bool FAST, bool DENSE>
 __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow, const PairConst& PC) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
@@ -859,6 +861,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
     }
     // ---- convex-convex pairs (hull vs hull): one candidate pair per lane through bounding-sphere cull and MPR (uhc_mpr.h); the hits
     //      become contacts in pair order.  Contact = (pos, normal from geom 1 to geom 2, dist = margin - depth) [MJ-ext mjc_Convex].
+    if constexpr (DENSE)
     for (int p0 = 0; p0 < T.ncpair; p0 += UHC_WAVE) {
         const int p = p0 + LANE;
         bool hit = false;
@@ -912,7 +915,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
 #define RTYPE(t) ((t) & 0xf)
 struct RowMisc { int type, last, aux, edge; };  // aux: contact id | dof ; edge: pyramid edge | sign
 
-template <bool FAST>
+template <bool FAST, bool DENSE>
 __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S, int ncon, int* overflow) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
@@ -950,13 +953,13 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     if (LANE == 0) {
         int r = nefc, trunc = 0, ntwo = 0, twofull = 0;
         int* NI = (int*)(S + L.ncon_nefc);
-        const int maxtwo = FAST ? A.ndense_f : A.ndense_g;
+        const int maxtwo = !DENSE ? 0 : FAST ? A.ndense_f : A.ndense_g;
         for (int c = 0; c < ncon; c++) {
             const double* C = S + L.con + c * UHC_CON_STRIDE;
             if (C[12] >= C[13]) continue;
             const int dim = (int)C[21], b1 = (int)C[19], b2 = (int)C[20];
             const int nr = dim == 1 ? 1 : 4, l1 = T.body_lastdof[b1], l2 = T.body_lastdof[b2];
-            const bool two = l1 >= 0 && l2 >= 0;
+            const bool two = DENSE && l1 >= 0 && l2 >= 0;
             if (FAST && A.truncate && r + nr > MAXEFC_OF(FAST)) { trunc = 1; break; }  // whole contacts only
             if (two && ntwo + nr > maxtwo) { twofull = 1; if (FAST && !A.truncate) break; continue; }  // no dense slot left
             for (int e = 0; e < nr; e++, r++)
@@ -1253,6 +1256,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 // (q-th dof of the chain | LDS byte address of that dof's L row << 16); positions past the chain end point at safe
 // finite data and meet Y = 0.  The finished rows are also stored to LDS (packed) for the A build of the other lanes.
 #define UHC_YM 32
+template <bool DENSE>
 __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int& nefc, FastRow& row, double (&Y)[UHC_YM], const LaneConst& LC) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
@@ -1262,7 +1266,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     bool valid = r < nefc;
     RowMisc rm = {0, 0, 0, 0};
     if (valid) rm = RM[r];
-    const bool two = (rm.type & ROW_TWO) != 0;  // dense row (two moving bodies): no chain, built wave-cooperatively below
+    const bool two = DENSE && (rm.type & ROW_TWO) != 0;  // dense row (two moving bodies): no chain, built wave-cooperatively below
     const bool jneg = (rm.type & ROW_NEG) != 0;
     row.two = two ? (rm.type >> 8) : -1;
     rm.type = RTYPE(rm.type);
@@ -1341,7 +1345,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     }
     // ---- J along the chain, and J.qvel, J.qacc_smooth, J.qacc_warmstart
     double vel = 0, jas = 0, jaw = 0;
-    if (A.ndense_f > 0) {  // dense rows: wave-cooperative (lane = dof), their scalars go to the lane that owns the row
+    if constexpr (DENSE) {  // dense rows: wave-cooperative (lane = dof), their scalars go to the lane that owns the row
         const int* NI = (const int*)(S + L.ncon_nefc);
         const int ntwo = NI[2];
         for (int k = 0; k < ntwo; k++) {
@@ -1548,20 +1552,21 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
 }
 
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
+template <bool DENSE>
 __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM], const LaneConst& LC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const bool valid = LANE < nefc;
     const int* NI = (const int*)(S + L.ncon_nefc);
     int ntwo = 0;  // dense rows among the first nefc rows (wave-uniform)
-    if (A.ndense_f > 0) {
+    if constexpr (DENSE) {
         const int nt = NI[2];
         for (int k = 0; k < nt; k++) ntwo += NI[4 + k] < nefc;
         ntwo = __builtin_amdgcn_readfirstlane(ntwo);
     }
     // ---- Delassus columns of the dense rows: A[l][c] = Yhat_l . Yhat_c for every lane l, kept in LDS (dcol[slot][lane]): lane l reads its
     //      entry when column c comes up below, and -- A being symmetric -- the lane that owns dense row c reads its whole ROW from there.
-    if (ntwo > 0) {
+    if (DENSE && ntwo > 0) {
         unsigned int cdq[UHC_YM];
         const unsigned int* chain = T.chain + (size_t)(row.last >= 0 ? row.last : 0) * UHC_YM;
         static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { constexpr int q = decltype(qc)::value; cdq[q] = chain[q] & 0xffffu; });
@@ -1607,15 +1612,15 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     int prev = -1;
     static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { Ym[decltype(qc)::value] = 0.0; });
     auto build_A = [&](auto dense_c) __attribute__((always_inline)) {
-    constexpr bool DENSE = decltype(dense_c)::value;
+    constexpr bool DCOL = decltype(dense_c)::value;  // some row of this env is dense
     static_for<0, UHC_WAVE>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         double acc = 0.0;
         if (s < nefc) {
             const int ls = __builtin_amdgcn_readlane(row.last, s);
             const int lens = __builtin_amdgcn_readlane(row.len, s);
-            const int two_s = DENSE ? __builtin_amdgcn_readlane(row.two, s) : -1;
-            if (DENSE && two_s >= 0) acc = S[L.dcol + two_s * UHC_WAVE + LANE];
+            const int two_s = DCOL ? __builtin_amdgcn_readlane(row.two, s) : -1;
+            if (DCOL && two_s >= 0) acc = S[L.dcol + two_s * UHC_WAVE + LANE];
             else {
             const double* Ys = S + L.Y + __builtin_amdgcn_readlane(row.yoff, s);  // row s in LDS: one broadcast read per entry
             if (ls != prev) {
@@ -1641,16 +1646,16 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
                     });
                 }
             });
-            if (DENSE && row.two >= 0) acc = S[L.dcol + row.two * UHC_WAVE + s];  // the dense row's own lane: its row of A by symmetry
+            if (DCOL && row.two >= 0) acc = S[L.dcol + row.two * UHC_WAVE + s];  // the dense row's own lane: its row of A by symmetry
             }
-            if (DENSE && !valid) acc = 0.0;
+            if (DCOL && !valid) acc = 0.0;
             if (s == LANE) { acc += row.R; diag = acc; }
         }
         agpr_put(Alo[s], __double2loint(acc));
         agpr_put(Ahi[s], __double2hiint(acc));
     });
     };
-    if (ntwo > 0) build_A(std::true_type{}); else build_A(std::false_type{});
+    if (DENSE && ntwo > 0) build_A(std::true_type{}); else build_A(std::false_type{});
     if (!valid) diag = 1.0;
     PROF(10)
     const bool any_fric = wave_or(row.type == ROW_FRICTION ? 1 : 0) != 0;
@@ -1747,7 +1752,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         });
     }
     wsync();
-    if (ntwo > 0) {  // dense rows: lane = dof
+    if (DENSE && ntwo > 0) {  // dense rows: lane = dof
         for (int k = 0; k < ntwo; k++) {
             const double fk = bcast(f, __builtin_amdgcn_readfirstlane(NI[4 + k]));
             const double* Dk = S + L.dense + k * A.nvp;
@@ -1761,7 +1766,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
-template <bool FAST>
+template <bool FAST, bool DENSE>
 __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
@@ -1784,20 +1789,20 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(6)
     k_smooth<FAST>(A, mb, S, LC);
     PROF(7)
-    out.ncon = k_collision<FAST>(A, mb, S, &out.overflow, PC);
+    out.ncon = k_collision<FAST, DENSE>(A, mb, S, &out.overflow, PC);
     PROF(8)
-    out.nefc = k_enumerate_rows<FAST>(A, mb, S, out.ncon, &out.overflow);
+    out.nefc = k_enumerate_rows<FAST, DENSE>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
     if (FAST && (out.overflow & 1)) return out;
     if (out.nefc > 0) {
         if (FAST) {
             FastRow row;
             double Yreg[UHC_YM];
-            const int st = k_rows_fast(A, mb, S, out.nefc, row, Yreg, LC);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
+            const int st = k_rows_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
             out.overflow |= st;
             if (st == 1) return out;
             PROF(9)
-            out.iters = k_pgs_fast(A, mb, S, out.nefc, row, Yreg, LC PROF_PASS);
+            out.iters = k_pgs_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC PROF_PASS);
             PROF(12)
         } else {
             k_rows<FAST>(A, mb, S, out.nefc, LC);
@@ -2008,7 +2013,9 @@ __device__ __forceinline__ void k_rfc_explicit(const KernelArgs& A, double* S, c
 // FAST: compact LDS (4 workgroups per CU), <= 64 constraint rows, A in registers.  An env that does not
 // fit (rows, contacts or Yhat storage) leaves its state untouched and raises redo[env]; the host then
 // launches the general variant on exactly those envs.
-template <int MODE, bool FAST>
+// DENSE: the model has contacts between two moving bodies (convex-convex pairs): MPR narrow phase + dense rows are compiled in.  The
+// floor-only stock model runs the DENSE = false instantiation, whose code and register allocation are those of the kernel without them.
+template <int MODE, bool FAST, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
     const int env = blockIdx.x;
@@ -2049,7 +2056,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             for (int k = 0; k < 9; k++) S[L.xmat + 9 * b + k] = R[k];
         }
     }
-    const LaneConst LC = lane_const(T);
+    const LaneConst LC = lane_const<DENSE>(T);
     const BodyConst BC = body_const(T);
     const PairConst PC = pair_const(T);
     // joint-space inertia between substeps: the PD solve of substep t+1 uses M of substep t's forward pass
@@ -2075,7 +2082,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         return;
     }
     if (MODE == 1) {
-        fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+        fo = k_forward<FAST, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
@@ -2100,7 +2107,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             if (wave_or(b)) { fail = 1; break; }
             }
             PROF(0)
-            fo = k_forward<FAST>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+            fo = k_forward<FAST, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && (overflow & 1)) break;
@@ -2170,70 +2177,3 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
 }
 
-// set_state: scatter rows of (qpos, qvel) into the listed envs, clear warm start / flags
-__global__ void uhc_set_state_kernel(DevState s, int nq, int nv, int nu, const int* env_ids, int n, const double* qpos,
-                                     const double* qvel, int* mask) {
-    const int r = blockIdx.x;
-    if (r >= n) return;
-    const int env = env_ids ? env_ids[r] : r;
-    for (int i = threadIdx.x; i < nq; i += blockDim.x) s.qpos[(size_t)env * nq + i] = qpos[(size_t)r * nq + i];
-    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
-        s.qvel[(size_t)env * nv + i] = qvel[(size_t)r * nv + i];
-        s.qacc[(size_t)env * nv + i] = 0;
-        s.qacc_ws[(size_t)env * nv + i] = 0;
-        s.applied[(size_t)env * nv + i] = 0;
-    }
-    for (int i = threadIdx.x; i < nu; i += blockDim.x) s.ctrl[(size_t)env * nu + i] = 0;
-    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; s.fresh[env] = 0; mask[env] = 1; }
-}
-
-// set_state on every env whose select flag is set; row e of (qpos, qvel) belongs to env e
-__global__ void uhc_set_state_masked_kernel(DevState s, int nq, int nv, int nu, int n_env, const int* select, const double* qpos,
-                                            const double* qvel, int* mask) {
-    const int env = blockIdx.x;
-    if (env >= n_env) return;
-    const int go = select[env] != 0;
-    if (threadIdx.x == 0) mask[env] = go;
-    if (!go) return;
-    for (int i = threadIdx.x; i < nq; i += blockDim.x) s.qpos[(size_t)env * nq + i] = qpos[(size_t)env * nq + i];
-    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
-        s.qvel[(size_t)env * nv + i] = qvel[(size_t)env * nv + i];
-        s.qacc[(size_t)env * nv + i] = 0;
-        s.qacc_ws[(size_t)env * nv + i] = 0;
-        s.applied[(size_t)env * nv + i] = 0;
-    }
-    for (int i = threadIdx.x; i < nu; i += blockDim.x) s.ctrl[(size_t)env * nu + i] = 0;
-    if (threadIdx.x == 0) { s.fail[env] = 0; s.overflow[env] = 0; s.fresh[env] = 1; }  // the forward pass of this reset runs at the head of the env's next step
-}
-extern "C" hipError_t uhc_launch_set_state_masked(const DevState* s, int nq, int nv, int nu, int n_env, const int* select, const double* qpos,
-                                                  const double* qvel, int* mask, hipStream_t stream) {
-    hipLaunchKernelGGL(uhc_set_state_masked_kernel, dim3(n_env), dim3(UHC_WAVE), 0, stream, *s, nq, nv, nu, n_env, select, qpos, qvel, mask);
-    return hipGetLastError();
-}
-
-// host-callable launchers (defined here so the kernels stay in one translation unit)
-extern "C" hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase,
-                                      const int* d_active, size_t lds_bytes, hipStream_t stream) {
-    dim3 grid(A->n_env), block(UHC_WAVE);
-    if (mode == 0 && fast) hipLaunchKernelGGL((uhc_step_kernel<0, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    else if (mode == 0) hipLaunchKernelGGL((uhc_step_kernel<0, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    else if (mode == 2 && fast) hipLaunchKernelGGL((uhc_step_kernel<2, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    else if (mode == 2) hipLaunchKernelGGL((uhc_step_kernel<2, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    else if (fast) hipLaunchKernelGGL((uhc_step_kernel<1, true>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    else hipLaunchKernelGGL((uhc_step_kernel<1, false>), grid, block, lds_bytes, stream, *A, d_action, d_tbase, d_active);
-    return hipGetLastError();
-}
-extern "C" hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast) {
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)uhc_step_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast)) != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)uhc_step_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_fast);
-}
-extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
-                                           const double* qpos, const double* qvel, int* mask, hipStream_t stream) {
-    hipLaunchKernelGGL(uhc_set_state_kernel, dim3(n), dim3(UHC_WAVE), 0, stream, *s, nq, nv, nu, env_ids, n, qpos, qvel, mask);
-    return hipGetLastError();
-}

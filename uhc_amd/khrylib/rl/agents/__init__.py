@@ -70,30 +70,53 @@ class Agent:
         pass
 
     # ---- vectorised rollout (replaces sample_worker / sample of agent.py:42-131) -------------------------
+    # One control step = three pieces: `_seg_pre` (buffer write, policy forward, sampling -- torch ops), the library's env.step (PD target,
+    # fused physics, termination, reward, observation: its own HIP kernels) and `_seg_post` (reward / done bookkeeping, observation filter,
+    # device-side restart of finished episodes, next filtered state).  The torch pieces are ~60 small launches whose Python dispatch cost
+    # more than their GPU time; on a GPU they are captured once into two HIP graphs (per pass length T) and replayed, the step index living
+    # in a device counter.  Every buffer a graph touches is allocated once and updated in place across passes.
+    use_graph = True  # class default; set agent.use_graph = False to run the eager path (CPU runs always do)
+
+    def _buffers(self, T):
+        env = self.env
+        n_env, dev = env.n_env, env.device
+        cache = self.__dict__.setdefault("_ro_cache", {})
+        R = cache.get(T)
+        if R is None:
+            R = cache[T] = types.SimpleNamespace(T=T)
+            R.states = torch.empty(n_env, T, env.obs_dim, dtype=self.dtype, device=dev)
+            R.actions = torch.empty(n_env, T, env.action_dim, dtype=self.dtype, device=dev)
+            R.rewards = torch.zeros(n_env, T, dtype=self.dtype, device=dev)
+            R.dones = torch.zeros(n_env, T, dtype=self.dtype, device=dev)
+            R.mean_flags = torch.zeros(T, n_env, dtype=torch.float64, device=dev)
+            R.c_info_sum = torch.zeros(getattr(env, "n_reward_parts", 5), dtype=self.dtype, device=dev)
+            R.c_reward_sum = torch.zeros((), dtype=self.dtype, device=dev)
+            R.t_dev = torch.zeros(1, dtype=torch.long, device=dev)
+            R.end_reward_dev = torch.zeros((), dtype=self.dtype, device=dev)
+            R.state = torch.zeros(n_env, env.obs_dim, dtype=self.dtype, device=dev)
+            R.action = torch.zeros(n_env, env.action_dim, dtype=torch.float64, device=dev)
+            R.snap_host = [torch.empty(5, n_env, dtype=torch.float64).pin_memory() if dev.type == "cuda" else torch.empty(5, n_env, dtype=torch.float64) for _ in range(2)]
+            R.graphs = None
+        return R
+
     @torch.no_grad()
     def rollout_begin(self, T, fresh=None):
         """fresh: True = assign + reset every env (new episodes), False = continue the episodes left open by the previous pass,
         None = fresh on the first pass only."""
         env = self.env
         n_env, dev = env.n_env, env.device
-        R = self._ro = types.SimpleNamespace(T=T, t=0)
-        R.states = torch.empty(n_env, T, env.obs_dim, dtype=self.dtype, device=dev)
-        R.actions = torch.empty(n_env, T, env.action_dim, dtype=self.dtype, device=dev)
-        R.rewards = torch.zeros(n_env, T, dtype=self.dtype, device=dev)
-        R.masks = torch.ones(n_env, T, dtype=self.dtype, device=dev)
-        R.exps = torch.ones(n_env, T, dtype=self.dtype, device=dev)
+        R = self._ro = self._buffers(T)
+        R.t = 0
+        R.t_dev.zero_(); R.rewards.zero_(); R.dones.zero_(); R.c_info_sum.zero_(); R.c_reward_sum.zero_()
+        R.end_reward_dev.fill_(float(env.end_reward) if self.end_reward else 0.0)
         R.logger = self.logger_cls()
-        R.c_info_sum = torch.zeros(getattr(env, "n_reward_parts", 5), dtype=self.dtype, device=dev)
         # exploration flags of the whole pass in one upload (the same stream of draws as one binomial(n_env) per step)
         flags = np.ones((T, n_env)) if self.mean_action else env.np_random.binomial(1, 1 - self.noise_rate, size=(T, n_env))
-        R.mean_flags = torch.from_numpy(flags.astype(np.float64)).to(dev)
+        R.mean_flags.copy_(torch.from_numpy(flags.astype(np.float64)))
         # episode turnover is asynchronous: the device restarts finished envs from a queued window (env.auto_reset); the
         # host learns about finished episodes from a pinned snapshot one step later and refills the queues then
-        R.dones = torch.zeros(n_env, T, dtype=self.dtype, device=dev)
-        R.snap_host = [torch.empty(5, n_env, dtype=torch.float64).pin_memory() if dev.type == "cuda" else torch.empty(5, n_env, dtype=torch.float64) for _ in range(2)]
         R.snap_event = [None, None]
         to_test(*self.sample_modules)
-        R.c_reward_sum = torch.zeros((), dtype=self.dtype, device=dev)
         if fresh is None:
             fresh = not getattr(self, "_episodes_live", False)
         if fresh:
@@ -105,13 +128,13 @@ class Agent:
             self.assign_new_clips(np.arange(n_env))
             self.queue_next_clips(np.arange(n_env))
             obs = env.obs.to(self.dtype)
-            R.state = self.running_state(obs) if self.running_state is not None else obs
+            R.state.copy_(self.running_state(obs) if self.running_state is not None else obs)
             self._episodes_live = True
         else:
             # the observations the envs stopped at were already counted by the filter at the end of the previous pass; only
             # re-normalise them with the current statistics (the filter may have been merged across ranks since)
             obs = env.obs.to(self.dtype)
-            R.state = self.running_state(obs, update=False) if self.running_state is not None else obs
+            R.state.copy_(self.running_state(obs, update=False) if self.running_state is not None else obs)
 
     def _drain_snapshot(self, slot):
         """Host side of episode turnover for the step whose snapshot sits in `slot`: statistics, success history, new queue entries."""
@@ -131,28 +154,68 @@ class Agent:
             if len(need):
                 self.queue_next_clips(need)
 
+    def _seg_pre(self):
+        """state -> rollout buffer, policy forward + sampling -> action (buffer + the fixed tensor env.step reads)."""
+        R = self._ro
+        t = R.t_dev
+        R.states.index_copy_(1, t, R.state.unsqueeze(1))
+        mean_flag = R.mean_flags.index_select(0, t).squeeze(0)
+        action = self.policy_net.select_action(self.trans_policy(R.state), mean_flag)
+        R.actions.index_copy_(1, t, action.to(self.dtype).unsqueeze(1))
+        R.action.copy_(action)
+
+    def _seg_post(self):
+        """reward / done bookkeeping, observation filter (the finished episodes' last observation included, agent.py:77-79), device-side
+        restart of finished episodes, filtered state of the next step, step counter."""
+        env, R = self.env, self._ro
+        t = R.t_dev
+        env.sim.use_current_stream()  # the library's launches below go to the stream this runs (or is being captured) on
+        r = env.reward.to(self.dtype)
+        R.c_reward_sum.add_(r.sum())  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
+        if self.running_state is not None:
+            self.running_state.rs.push_batch(env.obs.to(self.dtype), weights=env.done)  # the restart below overwrites those rows
+        r = r + env.env.field(5).to(self.dtype) * R.end_reward_dev  # info["end"] * end_reward (agent.py:84-85); 0 when switched off
+        R.rewards.index_copy_(1, t, r.unsqueeze(1))
+        R.dones.index_copy_(1, t, env.done.to(self.dtype).unsqueeze(1))  # masks = 1 - dones and exps = 1 - mean_flags are formed at the end of the pass
+        R.c_info_sum.add_(env.reward_parts.sum(0))
+        env.auto_reset()  # also writes the step's snapshot: done, episode length / return (kept by the library), percent, consumed
+        obs = env.obs.to(self.dtype)
+        R.state.copy_(self.running_state(obs) if self.running_state is not None else obs)
+        t.add_(1)
+
+    def _capture(self):
+        """Capture the two torch segments into HIP graphs (torch.cuda.CUDAGraph = hipGraph on ROCm).  The capture records the work
+        without running it; the caller replays."""
+        env, R = self.env, self._ro
+        torch.cuda.synchronize()
+        g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_pre):
+            self._seg_pre()
+        with torch.cuda.graph(g_post, pool=g_pre.pool()):
+            self._seg_post()
+        env.sim.use_current_stream()  # back from the capture stream
+        R.graphs = (g_pre, g_post)
+
     @torch.no_grad()
     def rollout_step(self):
         """One control step of every env: filter -> policy -> env.step -> buffers -> device-side restart of finished episodes.
         Nothing here waits for the GPU: the only host read is the previous step's pinned snapshot."""
         env, R = self.env, self._ro
-        dev, t = env.device, self._ro.t
-        R.states[:, t] = R.state
-        mean_flag = R.mean_flags[t]
-        action = self.policy_net.select_action(self.trans_policy(R.state), mean_flag).to(torch.float64).contiguous()
-        R.actions[:, t] = action
-        env.step(action)
-        r = env.reward.to(self.dtype)
-        R.c_reward_sum += r.sum()  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
-        if self.running_state is not None:  # the reference also filters the last observation of an episode (agent.py:77-79); the
-            self.running_state.rs.push_batch(env.obs.to(self.dtype), weights=env.done)  # restart below overwrites those rows
-        if self.end_reward:
-            r = r + env.env.field(5).to(self.dtype) * env.end_reward  # info["end"] * end_reward (agent.py:84-85)
-        R.rewards[:, t] = r
-        R.dones[:, t] = env.done  # masks = 1 - dones and exps = 1 - mean_flags are formed once, at the end of the pass
-        R.c_info_sum += env.reward_parts.sum(0)
-        env.auto_reset()  # also writes the step's snapshot: done, episode length / return (kept by the library), percent, consumed
-        slot = t & 1
+        dev = env.device
+        graphed = self.use_graph and dev.type == "cuda"
+        if graphed and R.graphs is None and R.t >= 2:  # two eager steps first: library handles, allocator pools and the filter's device state exist
+            self._capture()
+        if graphed and R.graphs is not None:
+            R.graphs[0].replay()
+            env.step(R.action)
+            R.graphs[1].replay()
+            if self.running_state is not None:
+                self.running_state.rs.mark_device_updated()
+        else:
+            self._seg_pre()
+            env.step(R.action)
+            self._seg_post()
+        slot = R.t & 1
         self._drain_snapshot(slot)  # the snapshot written two steps ago (its buffer is reused now)
         R.snap_host[slot].copy_(env.env.field(12), non_blocking=True)
         if dev.type == "cuda":
@@ -160,8 +223,6 @@ class Agent:
             R.snap_event[slot].record()
         else:
             R.snap_event[slot] = True
-        obs = env.obs.to(self.dtype)
-        R.state = self.running_state(obs) if self.running_state is not None else obs
         self._drain_snapshot(slot ^ 1)  # the previous step's snapshot: long since landed
         R.t += 1
 
@@ -171,17 +232,18 @@ class Agent:
         T, N = R.T, env.n_env * R.T
         self._drain_snapshot((T - 1) & 1)  # the last step's episode ends
         R.masks = 1 - R.dones
-        R.exps = (1 - R.mean_flags).t().contiguous()
+        R.exps = (1 - R.mean_flags).t().contiguous().to(self.dtype)
+        rewards = R.rewards.clone()  # the pass's buffers are reused by the next pass: the batch owns what it changes
         # episodes cut by the end of the pass: bootstrap with V(s_T) folded into the last reward, then close the segment
         open_ = R.masks[:, T - 1] > 0
         if bool(open_.any()):
             v_next = self.value_net(self.trans_value(R.state[open_])).squeeze(-1)
-            R.rewards[open_, T - 1] += self.gamma * v_next
+            rewards[open_, T - 1] += self.gamma * v_next
             R.masks[open_, T - 1] = 0
         self.sync_running_state()
         R.logger.add_steps(N, float(R.c_reward_sum.item()), R.c_info_sum.cpu().numpy())
         R.logger.end_sampling()
-        return RolloutBatch(R.states.reshape(N, -1), R.actions.reshape(N, -1), R.rewards.reshape(N, 1), R.masks.reshape(N, 1), R.exps.reshape(N), T), R.logger
+        return RolloutBatch(R.states.reshape(N, -1), R.actions.reshape(N, -1), rewards.reshape(N, 1), R.masks.reshape(N, 1), R.exps.reshape(N), T), R.logger
 
     def sync_running_state(self):
         """Data-parallel runs: merge the observation-filter statistics of all ranks (Chan), so every rank
@@ -190,6 +252,8 @@ class Agent:
             return
         rs = self.running_state.rs
         dev = self.env.device if self.env is not None else torch.device("cpu")
+        if dist.get_backend() != "nccl":
+            dev = torch.device("cpu")  # gloo gathers host tensors only
         mine = torch.cat([torch.tensor([float(rs.n)], dtype=torch.float64), torch.from_numpy(np.asarray(rs.mean, dtype=np.float64).ravel()),
                           torch.from_numpy(np.asarray(rs._S, dtype=np.float64).ravel())]).to(dev)
         allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]

@@ -13,11 +13,16 @@ class RunningStat:
         self._n = 0
         self._M = np.zeros(shape)
         self._S = np.zeros(shape)
-        self._dev, self._stale = None, False  # device-resident copy used by the batched path
+        # device-resident copy used by the batched path: [n (0-d), M, S].  Once created the three tensors are only ever updated IN PLACE
+        # (a captured HIP graph of the rollout step keeps their addresses); _stale = the device holds newer statistics than the numpy
+        # arrays, _dirty = the numpy arrays were set from the host and must be copied down before the next device use
+        self._dev, self._stale, self._dirty = None, False, False
+
+    def _host_changed(self):
+        self._stale, self._dirty = False, self._dev is not None
 
     def push(self, x):
         self._sync()
-        self._dev = None
         x = np.asarray(x)
         assert x.shape == self._M.shape
         self._n += 1
@@ -27,24 +32,33 @@ class RunningStat:
             old = self._M.copy()
             self._M[...] = old + (x - old) / self._n
             self._S[...] = self._S + (x - old) * (x - self._M)
+        self._host_changed()
 
     def _to_device(self, device):
-        if self._dev is None or self._dev[1].device != device:
+        if self._dev is not None and self._dev[1].device != device:
             self._sync()
-            self._dev = [torch.tensor(float(self._n), dtype=torch.float64, device=device), torch.as_tensor(self._M, dtype=torch.float64, device=device),
-                         torch.as_tensor(self._S, dtype=torch.float64, device=device)]
+            self._dev = None
+        if self._dev is None:
+            self._dev = [torch.tensor(float(self._n), dtype=torch.float64, device=device), torch.as_tensor(self._M, dtype=torch.float64, device=device).clone(),
+                         torch.as_tensor(self._S, dtype=torch.float64, device=device).clone()]
+            self._dirty = False
+        elif self._dirty:
+            self._dev[0].fill_(float(self._n))
+            self._dev[1].copy_(torch.as_tensor(self._M, dtype=torch.float64))
+            self._dev[2].copy_(torch.as_tensor(self._S, dtype=torch.float64))
+            self._dirty = False
 
     def push_batch(self, xb: torch.Tensor, weights: torch.Tensor = None):
         """Merge B rows at once: (n, M, S) <- merge((n, M, S), (B, mean_b, S_b)).  `weights` (0/1 per row, a device tensor) selects the
         rows that count, without the host having to know how many there are.  The statistics -- the count included -- stay on the
-        device of `xb` (no host sync per rollout step); the numpy views are refreshed lazily."""
+        device of `xb` and are updated in place (no host sync per rollout step, graph-capturable); the numpy views are refreshed lazily."""
         if xb.shape[0] == 0:
             return
         self._to_device(xb.device)
         x = xb.double()
         n, M, Sd = self._dev
         if weights is None:
-            B = torch.tensor(float(xb.shape[0]), dtype=torch.float64, device=xb.device)
+            B = torch.full((), float(xb.shape[0]), dtype=torch.float64, device=xb.device)
             mb = x.mean(0)
             Sb = ((x - mb) ** 2).sum(0)
         else:
@@ -55,8 +69,15 @@ class RunningStat:
         tot = n + B
         ts = tot.clamp(min=1.0)
         delta = mb - M
-        self._dev = [tot, M + delta * (B / ts), Sd + Sb + delta * delta * (n * B / ts)]
+        Sd.add_(Sb + delta * delta * (n * B / ts))
+        M.add_(delta * (B / ts))
+        n.copy_(tot)
         self._stale = True
+
+    def mark_device_updated(self):
+        """The device copy was advanced by a replayed graph (no Python ran): the numpy views are stale."""
+        if self._dev is not None:
+            self._stale = True
 
     def _sync(self):
         if self._stale:
@@ -80,7 +101,7 @@ class RunningStat:
         self._S[...] = self._S + Sb + delta * delta * (n * nb / tot)
         self._M[...] = self._M + delta * (nb / tot)
         self._n = tot
-        self._dev = None
+        self._host_changed()
 
     def __getstate__(self):  # checkpoints hold plain numpy statistics, like the reference's pickles
         self._sync()
@@ -88,7 +109,7 @@ class RunningStat:
 
     def __setstate__(self, st):
         self.__dict__.update(st)
-        self._dev, self._stale = None, False
+        self._dev, self._stale, self._dirty = None, False, False
 
     @property
     def n(self):
@@ -138,7 +159,7 @@ class ZFilter:
         return np.clip(x, -self.clip, self.clip) if self.clip else x
 
     def set_mean_std(self, mean, std, n):
-        self.rs._dev, self.rs._stale = None, False
         self.rs._n = n
         self.rs._M[...] = mean
         self.rs._S[...] = std
+        self.rs._host_changed()
