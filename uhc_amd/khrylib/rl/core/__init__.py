@@ -66,6 +66,14 @@ class DiagGaussian(Normal):
     def mean_sample(self):
         return self.loc
 
+    def sample(self, sample_shape=torch.Size()):
+        """loc + scale * N(0, 1): what Normal.sample draws (torch.normal(loc, scale) is randn * scale + loc on the same Philox stream),
+        without torch.normal's host-side `std >= 0` check -- a device-to-host sync per call, and illegal while the rollout step is being
+        captured into a HIP graph."""
+        with torch.no_grad():
+            shape = self._extended_shape(sample_shape)
+            return self.loc.expand(shape) + self.scale.expand(shape) * torch.randn(shape, dtype=self.loc.dtype, device=self.loc.device)
+
 
 class Policy(nn.Module):
     def select_action(self, x, mean_action=False):

@@ -896,3 +896,182 @@ def self_collision_variant(m: Model) -> Model:
     o.exclude_pair = np.array(ex, dtype=np.int32).reshape(-1, 2)
     o.nexclude = len(ex)
     return o
+
+
+def _rebuild_dof_tables(m: Model) -> None:
+    """jnt_qposadr / jnt_dofadr / body_dofadr / body_dofnum / dof_* topology from (body tree, joints in body order, joint types)."""
+    qn = {JNT_FREE: 7, JNT_BALL: 4, JNT_SLIDE: 1, JNT_HINGE: 1}
+    vn = {JNT_FREE: 6, JNT_BALL: 3, JNT_SLIDE: 1, JNT_HINGE: 1}
+    m.nq = int(sum(qn[int(t)] for t in m.jnt_type))
+    m.nv = int(sum(vn[int(t)] for t in m.jnt_type))
+    m.jnt_qposadr = np.zeros(m.njnt, dtype=np.int32)
+    m.jnt_dofadr = np.zeros(m.njnt, dtype=np.int32)
+    m.body_dofadr = np.full(m.nbody, -1, dtype=np.int32)
+    m.body_dofnum = np.zeros(m.nbody, dtype=np.int32)
+    m.dof_bodyid = np.zeros(m.nv, dtype=np.int32)
+    m.dof_jntid = np.zeros(m.nv, dtype=np.int32)
+    m.dof_parentid = np.full(m.nv, -1, dtype=np.int32)
+    last = np.full(m.nbody, -1, dtype=np.int32)
+    qa = da = 0
+    for b in range(m.nbody):
+        ja, jn = int(m.body_jntadr[b]), int(m.body_jntnum[b])
+        prev, anc = -1, int(m.body_parentid[b])
+        while b > 0:
+            if last[anc] >= 0:
+                prev = int(last[anc])
+                break
+            if anc == 0:
+                break
+            anc = int(m.body_parentid[anc])
+        if jn:
+            m.body_dofadr[b] = da
+        for j in range(ja, ja + jn):
+            t = int(m.jnt_type[j])
+            m.jnt_qposadr[j], m.jnt_dofadr[j] = qa, da
+            for _ in range(vn[t]):
+                m.dof_bodyid[da], m.dof_jntid[da], m.dof_parentid[da] = b, j, prev
+                prev = da
+                da += 1
+            qa += qn[t]
+        if jn:
+            m.body_dofnum[b] = da - m.body_dofadr[b]
+            last[b] = da - 1
+    m.dof_madr = np.zeros(m.nv + 1, dtype=np.int32)
+    for i in range(m.nv):
+        depth, k = 0, i
+        while k >= 0:
+            depth += 1
+            k = int(m.dof_parentid[k])
+        m.dof_madr[i + 1] = m.dof_madr[i] + depth
+
+
+def ball_variant(m: Model, armature: float = 0.01, damping: float = 0.0) -> Model:
+    """The humanoid with every (z, y, x) hinge triple replaced by ONE ball joint and three torque motors whose gear vectors are the
+    old hinge axes -- the model `robot.ball: True` generates (uhc/khrylib/mocap/skeleton_mesh_v2.py:183-193 motors with gear = axis,
+    :243-267 one `type="ball"` joint per bone; config/copycat_ball/copycat_ball_1.yml:99).  nq = 7 + 4 (nbody - 2), nv unchanged."""
+    o = m.copy()
+    jt, jb, jpos, names = [], [], [], []
+    gear, act_j = [], []
+    o.body_jntadr = np.full(m.nbody, -1, dtype=np.int32)
+    o.body_jntnum = np.zeros(m.nbody, dtype=np.int32)
+    for b in range(m.nbody):
+        ja, jn = int(m.body_jntadr[b]), int(m.body_jntnum[b])
+        if jn == 0:
+            continue
+        o.body_jntadr[b], o.body_jntnum[b] = len(jt), 1
+        if jn == 1 and m.jnt_type[ja] == JNT_FREE:
+            jt.append(JNT_FREE); jb.append(b); jpos.append(np.zeros(3)); names.append(m.joint_names[ja])
+            continue
+        assert jn == 3 and all(m.jnt_type[ja + k] == JNT_HINGE for k in range(3)), "ball_variant expects hinge triples"
+        assert np.allclose(m.jnt_pos[ja], m.jnt_pos[ja + 1]) and np.allclose(m.jnt_pos[ja], m.jnt_pos[ja + 2])
+        jt.append(JNT_BALL); jb.append(b); jpos.append(m.jnt_pos[ja].copy()); names.append(m.body_names[b])
+        for k in range(3):
+            act_j.append(len(jt) - 1)
+            gear.append(m.jnt_axis[ja + k].copy())
+    o.njnt = len(jt)
+    o.joint_names = names
+    o.jnt_type = np.array(jt, dtype=np.int32)
+    o.jnt_bodyid = np.array(jb, dtype=np.int32)
+    o.jnt_pos = np.array(jpos)
+    o.jnt_axis = np.tile(np.array([0.0, 0, 1]), (o.njnt, 1))
+    o.jnt_limited = np.zeros(o.njnt, dtype=np.int32)  # the generated ball joints carry no range
+    o.jnt_range = np.zeros((o.njnt, 2))
+    o.jnt_stiffness = np.zeros(o.njnt)
+    o.jnt_margin = np.zeros(o.njnt)
+    _rebuild_dof_tables(o)
+    o.qpos0 = np.zeros(o.nq)
+    for j in range(o.njnt):
+        a = o.jnt_qposadr[j]
+        if o.jnt_type[j] == JNT_FREE:
+            o.qpos0[a:a + 7] = m.qpos0[m.jnt_qposadr[m.body_jntadr[o.jnt_bodyid[j]]]:][:7]
+        else:
+            o.qpos0[a] = 1.0
+    o.qpos_spring = o.qpos0.copy()
+    o.dof_armature = np.array([0.0 if o.jnt_type[o.dof_jntid[i]] == JNT_FREE else armature for i in range(o.nv)])
+    o.dof_damping = np.array([0.0 if o.jnt_type[o.dof_jntid[i]] == JNT_FREE else damping for i in range(o.nv)])
+    o.dof_frictionloss = np.zeros(o.nv)
+    o.nu = len(gear)
+    o.actuator_dofid = np.array([o.jnt_dofadr[j] for j in act_j], dtype=np.int32)
+    o.actuator_gear = np.array(gear, dtype=np.float64).reshape(-1, 3)
+    o.actuator_names = list(m.actuator_names)
+    o.actuator_ctrlrange = np.zeros((o.nu, 2))
+    set_const(o)
+    return o
+
+
+def hinge_to_ball_qpos(m_hinge: Model, m_ball: Model, qpos: np.ndarray) -> np.ndarray:
+    """qpos of the hinge model -> the same pose of its ball variant (quaternion of R_z(a0) R_y(a1) R_x(a2) per body)."""
+    out = m_ball.qpos0.copy()
+    out[:7] = qpos[:7]
+    for j in range(1, m_ball.njnt):
+        if m_ball.jnt_type[j] != JNT_BALL:
+            continue
+        b = m_ball.jnt_bodyid[j]
+        ja = m_hinge.body_jntadr[b]
+        q = np.array([1.0, 0, 0, 0])
+        for k in range(3):
+            q = quat_mul(q, _axis_angle_quat(m_hinge.jnt_axis[ja + k], qpos[m_hinge.jnt_qposadr[ja + k]] - m_hinge.qpos0[m_hinge.jnt_qposadr[ja + k]]))
+        a = m_ball.jnt_qposadr[j]
+        out[a:a + 4] = q
+    return out
+
+
+def add_free_bodies(m: Model, hulls: List[np.ndarray], poses: np.ndarray, density: float = 1000.0, names: Optional[List[str]] = None,
+                    contype: int = 1, conaffinity: int = 1, condim: int = 1) -> Model:
+    """Append free-floating convex bodies (objects) to a model: one body, one free joint and one mesh geom each (the reference appends
+    objects the same way: a body with a `free` joint and a mesh geom, contype = conaffinity = 1, uhc/smpllib/smpl_robot.py:1205-1224).
+    hulls: list of (ntri, 3, 3) triangle soups in the object frame; poses: (K, 7) pos + quat of each object in qpos0."""
+    o = m.copy()
+    K = len(hulls)
+    names = names or [f"obj{k}" for k in range(K)]
+    g0 = m.ngeom - 1 if m.ngeom > 1 else 0  # geom whose contact parameters the objects copy (a body geom)
+    for k, tris in enumerate(hulls):
+        verts, faces = weld(np.asarray(tris, dtype=np.float64))
+        vol, com, I = polyhedron_mass_properties(verts, faces)
+        evals, evecs = np.linalg.eigh(density * I)
+        order = np.argsort(-evals)
+        evals, evecs = evals[order], evecs[:, order]
+        if np.linalg.det(evecs) < 0:
+            evecs[:, 2] = -evecs[:, 2]
+        adr, idx = hull_adjacency(len(verts), faces)
+        b, j, g = o.nbody, o.njnt, o.ngeom
+        o.body_names = o.body_names + [names[k]]
+        o.joint_names = o.joint_names + [names[k]]
+        o.geom_names = o.geom_names + [names[k]]
+        ap = lambda a, v: np.concatenate([a, np.asarray(v, dtype=a.dtype).reshape((1,) + a.shape[1:])])
+        o.body_parentid = ap(o.body_parentid, 0); o.body_jntadr = ap(o.body_jntadr, j); o.body_jntnum = ap(o.body_jntnum, 1)
+        o.body_dofadr = ap(o.body_dofadr, 0); o.body_dofnum = ap(o.body_dofnum, 6)
+        o.body_pos = ap(o.body_pos, poses[k, :3]); o.body_quat = ap(o.body_quat, poses[k, 3:7] / np.linalg.norm(poses[k, 3:7]))
+        o.body_ipos = ap(o.body_ipos, com); o.body_iquat = ap(o.body_iquat, mat_to_quat(evecs))
+        o.body_mass = ap(o.body_mass, density * vol); o.body_inertia = ap(o.body_inertia, evals)
+        o.body_invweight0 = ap(o.body_invweight0, [0.0, 0.0])
+        o.jnt_type = ap(o.jnt_type, JNT_FREE); o.jnt_bodyid = ap(o.jnt_bodyid, b); o.jnt_qposadr = ap(o.jnt_qposadr, 0); o.jnt_dofadr = ap(o.jnt_dofadr, 0)
+        o.jnt_pos = ap(o.jnt_pos, np.zeros(3)); o.jnt_axis = ap(o.jnt_axis, [0, 0, 1.0]); o.jnt_limited = ap(o.jnt_limited, 0)
+        o.jnt_range = ap(o.jnt_range, [0.0, 0.0]); o.jnt_stiffness = ap(o.jnt_stiffness, 0.0); o.jnt_margin = ap(o.jnt_margin, 0.0)
+        o.geom_type = ap(o.geom_type, GEOM_MESH); o.geom_bodyid = ap(o.geom_bodyid, b); o.geom_contype = ap(o.geom_contype, contype)
+        o.geom_conaffinity = ap(o.geom_conaffinity, conaffinity); o.geom_condim = ap(o.geom_condim, condim)
+        o.geom_pos = ap(o.geom_pos, np.zeros(3)); o.geom_quat = ap(o.geom_quat, [1.0, 0, 0, 0]); o.geom_size = ap(o.geom_size, np.zeros(3))
+        for name in ("geom_friction", "geom_margin", "geom_gap", "geom_solref", "geom_solimp"):
+            a = getattr(o, name)
+            setattr(o, name, ap(a, a[g0]))
+        o.geom_rbound = ap(o.geom_rbound, np.linalg.norm(verts - com, axis=1).max()); o.geom_center = ap(o.geom_center, com)
+        o.geom_vertadr = ap(o.geom_vertadr, o.nmeshvert); o.geom_vertnum = ap(o.geom_vertnum, len(verts))
+        o.mesh_adjadr = np.concatenate([o.mesh_adjadr[:-1], adr[:-1] + o.nmeshadj, [o.nmeshadj + len(idx)]]).astype(np.int32)
+        o.mesh_adj = np.concatenate([o.mesh_adj, idx + o.nmeshvert]).astype(np.int32)
+        o.mesh_vert = np.concatenate([o.mesh_vert, verts])
+        o.nmeshvert += len(verts); o.nmeshadj += len(idx)
+        o.nbody += 1; o.njnt += 1; o.ngeom += 1
+    nq_old = m.nq
+    _rebuild_dof_tables(o)
+    q0 = np.zeros(o.nq)
+    q0[:nq_old] = m.qpos0
+    for k in range(K):
+        a = o.jnt_qposadr[m.njnt + k]
+        q0[a:a + 3] = poses[k, :3]
+        q0[a + 3:a + 7] = poses[k, 3:7] / np.linalg.norm(poses[k, 3:7])
+    o.qpos0, o.qpos_spring = q0, q0.copy()
+    z6 = np.zeros(6 * K)
+    o.dof_armature = np.concatenate([m.dof_armature, z6]); o.dof_damping = np.concatenate([m.dof_damping, z6])
+    o.dof_frictionloss = np.concatenate([m.dof_frictionloss, z6])
+    set_const(o)
+    return o
