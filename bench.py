@@ -41,7 +41,7 @@ def pmc_traffic():
         if not files:
             return None, None
         for line in open(files[-1]):
-            if line.startswith("void uhc_step_kernel<0, true>") and f"| {kind} |" in line:
+            if line.startswith("void uhc_step_kernel<0, true") and f"| {kind} |" in line:
                 tot += float(line.split("|")[2]) * 1024.0
                 src.append(os.path.basename(files[-1]))
                 break
@@ -278,7 +278,7 @@ def main():
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
                                    "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "contact_solver": ("active-set (exact optimum of the dual QP; envs beyond the fast kernel's capacity fall back to sweeps)" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, false>" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, false, true>" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, true, false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UHC_ABI_VERSION 4
+#define UHC_ABI_VERSION 5
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -67,7 +67,9 @@ typedef struct UhcModelDesc {
     const int32_t *mesh_adjadr;    /* [nmeshvert+1] CSR */
     const int32_t *mesh_adj;       /* [nmeshadj] global vertex ids */
     const int32_t *exclude_pair;   /* [nexclude][2] body ids */
-    /* actuators [nu]: motors on scalar joints */
+    /* actuators [nu]: motors on joints ([MJ-ext] joint transmission).  actuator_dofid = first dof of the joint; actuator_gear [nu][3]:
+     * gear[0] scales the control on a hinge / slide dof, on a ball joint the generalised force on its three dofs is gear[0..2] * ctrl
+     * (a torque vector in the child body's frame: uhc/khrylib/mocap/skeleton_mesh_v2.py:183-193 writes one such motor per bone axis) */
     const int32_t *actuator_dofid;
     const double *actuator_gear;
 } UhcModelDesc;

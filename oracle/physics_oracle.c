@@ -819,7 +819,10 @@ void orc_rne_bias(const UhcModelDesc* m, OrcData* d) { /* mj_rne(flg_acc=0) */
 void orc_fwd_acceleration(const UhcModelDesc* m, OrcData* d) {
     int nv = m->nv;
     memset(d->qfrc_actuator, 0, nv * 8);
-    for (int a = 0; a < m->nu; a++) d->qfrc_actuator[m->actuator_dofid[a]] += m->actuator_gear[a] * d->ctrl[a];
+    for (int a = 0; a < m->nu; a++) { /* [MJ-ext] joint transmission: gear[0] on a scalar joint, gear[0..2] on the three dofs of a ball joint */
+        int da = m->actuator_dofid[a], nd = m->jnt_type[m->dof_jntid[da]] == UHC_JNT_BALL ? 3 : 1;
+        for (int k = 0; k < nd; k++) d->qfrc_actuator[da + k] += m->actuator_gear[3 * a + k] * d->ctrl[a];
+    }
     for (int i = 0; i < nv; i++) {
         d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_applied[i] + d->qfrc_actuator[i];
         d->qacc_smooth[i] = d->qfrc_smooth[i];

@@ -253,14 +253,12 @@ def test_facade_accessors_match_device_fields(tmp_path):
     device state they are read from."""
     import torch
     from uhc_amd.envs import env_dict
-    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
     from uhc_amd.smpllib.smpl_mujoco import SMPL_EE_NAMES
     from uhc_amd.utils.transformation import quaternion_from_euler
     torch.set_default_dtype(torch.float64)
     cfg = _cfg(tmp_path, n_env=1)
-    data = make_synthetic_amass(1, seed=9, t_range=(40, 50))
-    key = list(data.keys())[0]
-    clip = dict(data[key], seq_name=key)
+    np.random.seed(2)
+    clip = _loader(cfg).sample_seq()  # the loader's sample dict (gender as a number, beta padded): what load_expert receives
     env = env_dict["humanoid_im"](cfg, init_expert=clip, data_specs=cfg.data_specs, mode="test")
     env.reset()
     b0 = env.prev_bquat.copy()

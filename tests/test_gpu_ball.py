@@ -1,0 +1,122 @@
+"""GPU parity for the ball-joint humanoid (robot.ball: True, config/copycat_ball/copycat_ball_1.yml:99: one ball joint + three
+gear-vector motors per bone, action_type torque) and for free objects around it (BASELINE configs[4] stand-in):
+nq = 99 (+7 per object), two-tree contacts, self-collision on.  HIP path through the C-ABI vs the CPU oracle."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["fast", "general"], autouse=True)
+def kernel_path(request):
+    old = os.environ.get("UHC_FORCE_GENERAL")
+    os.environ["UHC_FORCE_GENERAL"] = "1" if request.param == "general" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("UHC_FORCE_GENERAL", None)
+    else:
+        os.environ["UHC_FORCE_GENERAL"] = old
+
+
+def _ball_setup(model, objects=0, self_collision=False):
+    from tests.helpers import box_triangles
+    from uhc_amd.model.mjcf import add_free_bodies, ball_variant, self_collision_variant
+    from uhc_amd.sim import make_ctrl
+    ball = ball_variant(model)
+    if self_collision:
+        ball = self_collision_variant(ball)
+    if objects:
+        rng = np.random.default_rng(11)
+        ang = rng.uniform(0, 2 * np.pi, size=objects)
+        poses = np.stack([np.r_[-0.15 + 0.7 * np.cos(a), -0.05 + 0.7 * np.sin(a), 0.16 + 0.4 * k, 1, 0, 0, 0] for k, a in enumerate(ang)])
+        ball = add_free_bodies(ball, [box_triangles(0.15, 0.15, 0.15)] * objects, poses, density=5.0 / 0.027)
+    ball = dataclasses.replace(ball, solver=1)
+    hinge_ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)  # copycat_ball_1.yml: torque, tq_mul 4, no RFC
+    return ball, hinge_ctrl
+
+
+def _states(model, ball, standing, n, seed, lift):
+    from uhc_amd.model.mjcf import hinge_to_ball_qpos, ball_variant
+    rng = np.random.default_rng(seed)
+    base = ball_variant(model)
+    q = np.tile(ball.qpos0, (n, 1))
+    for e in range(n):
+        qh = standing["qpos"].copy()
+        qh[7:] += rng.normal(scale=0.1, size=69)
+        qh[2] += lift
+        q[e, :99] = hinge_to_ball_qpos(model, base, qh)
+    v = np.zeros((n, ball.nv))
+    v[:, :75] = rng.normal(scale=0.3, size=(n, 75))
+    return q, v
+
+
+@pytest.mark.parametrize("lift", [3.0, 0.0])
+def test_ball_humanoid_trajectory_matches_oracle(model, standing, kernel_path, lift):
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    ball, ctrl = _ball_setup(model)
+    n = 4
+    q, v = _states(model, ball, standing, n, 41, lift)
+    b = S.SimBatch(ball, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    os_ = [OracleSim(ball, ctrl) for _ in range(n)]
+    for e in range(n):
+        os_[e].desc.solver = 0 if kernel_path == "general" else 1
+        os_[e].set_state(q[e], v[e])
+        np.testing.assert_allclose(b.field(S.F_QM)[e].cpu().numpy(), os_[e].get("qM"), atol=1e-10)
+        np.testing.assert_allclose(b.field(S.F_QACC)[e].cpu().numpy(), os_[e].get("qacc"), atol=1e-5, rtol=1e-6)
+    rng = np.random.default_rng(42)
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for t in range(15):
+        act = rng.normal(scale=0.3, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].do_simulation(act[e], np.zeros(69))
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    assert worst < 1e-6, worst
+    assert np.abs(np.linalg.norm(gq[:, 7:11], axis=1) - 1).max() < 1e-12  # ball quaternions stay normalised
+
+
+def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_path):
+    """configs[4] stand-in: ball joints, self-collision, 3 free boxes (5 kg, 0.3 m) next to the humanoid: nq 120, nv 93, three trees."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    ball, ctrl = _ball_setup(model, objects=3, self_collision=True)
+    assert (ball.nq, ball.nv, ball.nbody) == (99 + 21, 75 + 18, 28)
+    n = 3
+    q, v = _states(model, ball, standing, n, 43, 0.0)
+    b = S.SimBatch(ball, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    os_ = [OracleSim(ball, ctrl) for _ in range(n)]
+    redo = b.field(S.F_REDO).cpu().numpy()
+    for e in range(n):
+        os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+        os_[e].set_state(q[e], v[e])
+        assert int(b.field(S.F_NCON)[e].item()) == os_[e].geti("ncon") and int(b.field(S.F_NEFC)[e].item()) == os_[e].geti("nefc")
+    rng = np.random.default_rng(44)
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for t in range(12):
+        act = rng.normal(scale=0.3, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].do_simulation(act[e], np.zeros(69))
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    assert worst < 1e-5, worst
+    assert int(b.field(S.F_FAIL).sum().item()) == 0

@@ -547,3 +547,89 @@ def test_self_collision_variant_generates_body_body_contacts(model, standing):
     nl = b.geti("nefc") - (4 * n0 + (n1 - n0))
     two = J[nl + 4 * n0:]
     assert two.shape[0] == n1 - n0 and np.abs(two[:, :6]).max() < 1e-12  # internal forces: no net wrench on the root
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ball joints (robot.ball: True -- config/copycat_ball/copycat_ball_1.yml:99) and free objects
+# ---------------------------------------------------------------------------------------------------------------
+def test_ball_variant_equals_hinge_model_where_the_coordinates_coincide(model, standing):
+    """At zero joint angles the hinge rates (z, y, x) of a body ARE its body-frame angular velocity (x, y, z reversed), so the ball
+    model's mass matrix and bias forces must equal the hinge model's under that permutation -- kinematics, cdof, CRB and RNE of ball
+    joints against the (pinned-by-FK, KAT-tested) hinge path.  Away from zero the poses still agree through the quaternion map."""
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import ball_variant, hinge_to_ball_qpos
+    ball = ball_variant(model)
+    assert (ball.nq, ball.nv, ball.nu, ball.njnt) == (99, 75, 69, 24) and ball.dof_madr[-1] == model.dof_madr[-1]
+    q = model.qpos0.copy()
+    q[2] = 5.0
+    q[3:7] = standing["qpos"][3:7]
+    perm = np.r_[np.arange(6), [6 + 3 * b + (2 - k) for b in range(23) for k in range(3)]]  # ball dof (b, x/y/z) <- hinge dof (b, z/y/x)
+    h, s = OracleSim(model), OracleSim(ball)
+    h.set_state(q, np.zeros(75))
+    s.set_state(hinge_to_ball_qpos(model, ball, q), np.zeros(75))
+    np.testing.assert_allclose(s.full_m(), h.full_m()[np.ix_(perm, perm)], atol=1e-12)
+    np.testing.assert_allclose(s.get("qfrc_bias"), h.get("qfrc_bias")[perm], atol=1e-10)
+    np.testing.assert_allclose(s.get("xpos"), h.get("xpos"), atol=1e-14)
+    # a bent pose: same body poses through the quaternion map, M still symmetric positive definite with the total mass on the root
+    qb = standing["qpos"].copy()
+    qb[2] = 5.0
+    h.set_state(qb, np.zeros(75))
+    s.set_state(hinge_to_ball_qpos(model, ball, qb), np.zeros(75))
+    np.testing.assert_allclose(s.get("xpos"), h.get("xpos"), atol=1e-12)
+    np.testing.assert_allclose(s.get("xquat"), h.get("xquat"), atol=1e-12)
+    M = s.full_m()
+    assert np.linalg.eigvalsh(M).min() > 0.009 and M[0, 0] == pytest.approx(model.body_mass.sum(), rel=1e-12)
+    # free fall: the centre of mass accelerates with g whatever the joint type
+    com_acc = (M @ s.get("qacc"))[:3] / model.body_mass.sum()
+    np.testing.assert_allclose(com_acc, [0, 0, -9.81], atol=1e-9)
+
+
+def test_ball_motor_gear_is_a_torque_vector_in_the_child_frame(model, standing):
+    """[MJ-ext] joint transmission on a ball joint: qfrc_actuator[dofs] = gear * ctrl; with gear = the old hinge axis, driving motor k of a
+    body at the zero pose produces the acceleration the hinge model gets from the same torque on hinge k."""
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import ball_variant, hinge_to_ball_qpos
+    ball = ball_variant(model)
+    q = model.qpos0.copy()
+    q[2] = 5.0
+    h, s = OracleSim(model), OracleSim(ball)
+    ctrl = np.zeros(69)
+    ctrl[[4, 30, 61]] = [20.0, -15.0, 7.0]
+    perm = np.r_[np.arange(6), [6 + 3 * b + (2 - k) for b in range(23) for k in range(3)]]
+    for sim, qq in ((h, q), (s, hinge_to_ball_qpos(model, ball, q))):
+        sim.set_state(qq, np.zeros(75))
+        sim.set("ctrl", ctrl)
+        sim.forward()
+    np.testing.assert_allclose(s.get("qfrc_actuator"), h.get("qfrc_actuator")[perm], atol=1e-14)
+    np.testing.assert_allclose(s.get("qacc"), h.get("qacc")[perm], atol=1e-8)
+
+
+def test_ball_joint_free_flight_conserves_angular_momentum(model, standing):
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import ball_variant, hinge_to_ball_qpos
+    errs = []
+    for div in (1, 2):
+        ball = ball_variant(model)
+        ball.gravity = np.zeros(3)
+        ball.timestep = model.timestep / div
+        s = OracleSim(ball)
+        rng = np.random.default_rng(8)
+        qb = standing["qpos"].copy()
+        qb[2] = 5.0
+        s.set_state(hinge_to_ball_qpos(model, ball_variant(model), qb), rng.normal(scale=1.0, size=75))
+
+        def ang_mom():
+            s.forward()
+            # spatial momentum of the whole tree about its COM = sum_b cinert_b * cvel_b (angular part); both are expressed at the tree COM
+            ci, cv = s.get("cinert").reshape(-1, 10), s.get("cvel").reshape(-1, 6)
+            L = np.zeros(3)
+            for b in range(1, ball.nbody):
+                I = np.array([[ci[b, 0], ci[b, 3], ci[b, 4]], [ci[b, 3], ci[b, 1], ci[b, 5]], [ci[b, 4], ci[b, 5], ci[b, 2]]])
+                L += I @ cv[b, :3] + np.cross(ci[b, 6:9], cv[b, 3:])
+            return L
+
+        L0 = ang_mom()
+        for _ in range(40 * div):
+            s.step()
+        errs.append(np.abs(ang_mom() - L0).max() / np.abs(L0).max())
+    assert errs[0] < 2e-2 and errs[0] / errs[1] == pytest.approx(2.0, rel=0.25)  # first-order integrator: the drift halves with the step

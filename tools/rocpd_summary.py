@@ -14,7 +14,7 @@ def main(db, out, note=""):
         short = name if len(name) < 110 else name[:107] + "..."
         m = meta.get(name, ("?",) * 6)
         lines.append(f"{short} | {calls} | {total / 1e3:.1f} | {avg / 1e3:.2f} | {pct:.3f} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {m[5]}")
-    open(out, "w").write("\n".join(lines[:20]) + "\n")
+    open(out, "w").write("\n".join(lines[:70]) + "\n")
     print("\n".join(lines[:8]))
 
 

@@ -55,6 +55,8 @@ def model_desc(model) -> UhcModelDesc:
     d.gravity = (C.c_double * 3)(*[float(x) for x in model.gravity])
     for n, t in _MODEL_PTRS:
         arr = np.ascontiguousarray(getattr(model, n), dtype=np.int32 if t == "i" else np.float64)
+        if n == "actuator_gear" and arr.ndim == 1:  # scalar gears of hinge models -> [nu][3]
+            arr = np.ascontiguousarray(np.stack([arr, np.zeros_like(arr), np.zeros_like(arr)], axis=1))
         if arr.size == 0:
             arr = np.zeros(1, dtype=arr.dtype)
         keep.append(arr)

@@ -113,7 +113,7 @@ extern "C" int32_t uhc_model_create(const UhcModelDesc* in, UhcModel** out) {
     take(m->mesh_vert, d.mesh_vert, 3 * (size_t)d.nmeshvert);
     take(m->mesh_adjadr, d.mesh_adjadr, (size_t)d.nmeshvert + 1); take(m->mesh_adj, d.mesh_adj, d.nmeshadj);
     take(m->exclude_pair, d.exclude_pair, 2 * (size_t)d.nexclude);
-    take(m->actuator_dofid, d.actuator_dofid, d.nu); take(m->actuator_gear, d.actuator_gear, d.nu);
+    take(m->actuator_dofid, d.actuator_dofid, d.nu); take(m->actuator_gear, d.actuator_gear, 3 * (size_t)d.nu);
     // structural checks the kernels rely on
     for (size_t b = 1; b < nb; b++)
         if (d.body_parentid[b] >= (int)b) { delete m; return fail("uhc_model_create: bodies must be in depth-first order"); }
@@ -196,7 +196,7 @@ static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>&
     o.geom_solimp = put(d.geom_solimp, 5 * d.ngeom); o.geom_rbound = put(d.geom_rbound, d.ngeom);
     o.geom_center = put(d.geom_center, 3 * d.ngeom);
     o.mesh_vert = put(d.mesh_vert, 3 * (size_t)d.nmeshvert);
-    o.actuator_gear = put(d.actuator_gear, d.nu);
+    o.actuator_gear = put(d.actuator_gear, 3 * (size_t)d.nu);
     o.meaninertia = put(&d.meaninertia, 1);
     while (blob.size() % 2) blob.push_back(0.0);
     o.stride = (int)blob.size();
@@ -508,9 +508,19 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             }
         TRY(upload(b, chain, &T.chain));
         if (nv > 128) { delete b; return fail("uhc_batch_create: nv %d > 128 unsupported", nv); }
-        std::vector<int> cnt(nv, 0);
-        T.act_one_per_dof = 1;
-        for (int a = 0; a < d.nu; a++) if (++cnt[d.actuator_dofid[a]] > 1) T.act_one_per_dof = 0;
+        // actuation is gathered per dof (lane = dof): up to UHC_DOF_MAXACT motors drive the joint of a dof (three on a ball joint, one per gear axis)
+        std::vector<int> dof_act((size_t)nv * UHC_DOF_MAXACT, -1);
+        for (int a = 0; a < d.nu; a++) {
+            const int j = d.dof_jntid[d.actuator_dofid[a]], nd = d.jnt_type[j] == UHC_JNT_BALL ? 3 : d.jnt_type[j] == UHC_JNT_FREE ? 6 : 1;
+            if (nd == 6) { delete b; return fail("uhc_batch_create: motors on free joints are not supported"); }
+            for (int k = 0; k < nd; k++) {
+                int q = 0;
+                while (q < UHC_DOF_MAXACT && dof_act[(size_t)(d.jnt_dofadr[j] + k) * UHC_DOF_MAXACT + q] >= 0) q++;
+                if (q == UHC_DOF_MAXACT) { delete b; return fail("uhc_batch_create: more than %d motors on one joint", UHC_DOF_MAXACT); }
+                dof_act[(size_t)(d.jnt_dofadr[j] + k) * UHC_DOF_MAXACT + q] = a;
+            }
+        }
+        TRY(upload(b, dof_act, &T.dof_act));
         TRY(upload(b, fac_prog, &T.fac_prog)); TRY(upload(b, sol_back, &T.sol_back)); TRY(upload(b, sol_fwd, &T.sol_fwd));
         A.ld_delta = (A.l.LD - A.lf.LD) * 8;
     }

@@ -10,6 +10,7 @@
 #define UHC_FAST_MAXCON 16  // contacts per env (fast kernel)
 #define UHC_MAXTWO 32       // constraint rows between two moving bodies per env (general kernel); they are kept as dense dof vectors
 #define UHC_FAST_MAXTWO 12  // the same for the fast kernel
+#define UHC_DOF_MAXACT 4
 #define UHC_CON_STRIDE 24
 #define UHC_MINVAL 1e-15
 #define UHC_MAXVAL 1e10
@@ -42,7 +43,7 @@ struct DevTopo {
     const unsigned int* sol_fwd;   // [nv-1][64] step s <-> j = s      : address of L[i][j] for i = lane (low 16) and lane+64 (high 16)
     const unsigned int* chain;     // [nv][32] position q on the chain of dof i: (q-th dof from the root | LDS byte address of its L row << 16)
     int fac_nslot;                 // number of groups
-    int act_one_per_dof;           // every dof is driven by at most one actuator (lane-parallel accumulation)
+    const int* dof_act;            // [nv][UHC_DOF_MAXACT] motors acting on the joint of each dof (-1 = none)
     int has_damping;               // some model of the batch has dof_damping > 0: mj_Euler integrates the damping implicitly
 };
 

@@ -671,13 +671,15 @@ __device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, 
             const int qa = T.jnt_qposadr[j];
             f -= k * (S[L.qpos + qa] - mb[A.o.qpos_spring + qa]);
         }
+        // actuation: the motors of the dof's joint, gear component = the dof's index inside the joint (0 on scalar joints)
+        const int comp = i - T.jnt_dofadr[j];
+#pragma unroll
+        for (int q = 0; q < UHC_DOF_MAXACT; q++) {
+            const int a = T.dof_act[i * UHC_DOF_MAXACT + q];
+            if (a >= 0) f += mb[A.o.actuator_gear + 3 * a + comp] * S[L.ctrl + a];
+        }
         S[L.smooth + i] = f;
     }
-    wsync();
-    if (T.act_one_per_dof) {
-        for (int a = LANE; a < T.nu; a += UHC_WAVE) S[L.smooth + T.actuator_dofid[a]] += mb[A.o.actuator_gear + a] * S[L.ctrl + a];
-    } else if (LANE == 0)
-        for (int a = 0; a < T.nu; a++) S[L.smooth + T.actuator_dofid[a]] += mb[A.o.actuator_gear + a] * S[L.ctrl + a];
     wsync();
     DofVec x;
     x.a = LANE < T.nv ? S[L.smooth + LANE] : 0.0;

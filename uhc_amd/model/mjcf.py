@@ -839,15 +839,16 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
                 continue
             jn = e.attrib["joint"]
             j = m.joint_names.index(jn)
-            if m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
-                raise ValueError("only scalar-joint motors are supported")
+            if m.jnt_type[j] == JNT_FREE:
+                raise ValueError("motors on free joints are not supported")
             dofid.append(m.jnt_dofadr[j])
-            gear.append(float(_floats(dfl.get("motor", e, "gear", "1"))[0]))
+            g = _floats(dfl.get("motor", e, "gear", "1"))
+            gear.append(np.r_[g, np.zeros(3)][:3])  # [MJ-ext] gear[0] on scalar joints, gear[0..2] = torque vector on ball joints
             names.append(e.attrib.get("name", jn))
             crange.append(_floats(dfl.get("motor", e, "ctrlrange"), 2, [0, 0]))
     m.nu = len(dofid)
     m.actuator_dofid = np.array(dofid, dtype=np.int32)
-    m.actuator_gear = np.array(gear, dtype=np.float64)
+    m.actuator_gear = np.array(gear, dtype=np.float64).reshape(-1, 3)
     m.actuator_names = names
     m.actuator_ctrlrange = np.array(crange, dtype=np.float64).reshape(-1, 2)
 
