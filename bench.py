@@ -50,6 +50,45 @@ def pmc_traffic():
     return tot, "+".join(src)
 
 
+def _latest(pattern):
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    return files[-1] if files else None
+
+
+def contact_solve_share():
+    """Share of the fused kernel's cycles spent in the contact solve proper (active-set factorisations + pre-sweeps, or the PGS sweeps),
+    from the latest committed stage profile (tools/stage_profile.py, an instrumented build: cannot run inside the timed region)."""
+    f = _latest("*_stage_profile.txt")
+    if not f:
+        return None, None
+    share = 0.0
+    for line in open(f):
+        name = line.strip().split("  ")[0]
+        if name.startswith("as:") or name.startswith("pgs-sweeps"):
+            share += float(line.strip().split()[-1].rstrip("%")) / 100.0
+    return (share or None), os.path.basename(f)
+
+
+def valu_f64_counters():
+    """float64 VALU instructions per launch of the fused kernel from the latest committed PMC pass (profiles/*_pmc_VALU_F64.txt):
+    flop = (ADD + MUL + TRANS + 2 FMA) wave-instructions x 64 lanes (an upper bound on useful flops: inactive lanes count too)."""
+    f = _latest("*_pmc_VALU_F64.txt")
+    if not f:
+        return None
+    c = {}
+    for line in open(f):
+        if line.startswith("void uhc_step_kernel<0, true") and "|" in line:
+            parts = [x.strip() for x in line.split("|")]
+            c[parts[1]] = float(parts[2])
+    need = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64")
+    if not all(k in c for k in need):
+        return None
+    flop = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
+    return {"flop_per_launch": flop, "counters": {k: v for k, v in c.items() if "F64" in k or k == "SQ_INSTS_VALU"}, "source": os.path.basename(f)}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -60,7 +99,12 @@ def parse():
     p.add_argument("--ppo-dtype", default="float64", choices=["float64", "float32"])
     p.add_argument("--pgs-iterations", type=int, default=None, help="sweep cap of the contact solve (default: the config's, 300 = converged)")
     p.add_argument("--solver", type=int, default=None, choices=[0, 1], help="contact solver: 0 PGS sweeps, 1 exact active-set solve (default: the config's)")
-    p.add_argument("--shapes", type=int, default=0, help="configs[3] (smpl_shape): K randomised body shapes, every clip runs on one of them")
+    p.add_argument("--shapes", type=int, default=0, help="configs[3] (smpl_shape): K body shapes with per-body length scales ~ U(0.85, 1.15), default_rng(7); "
+                   "every clip gets its own (clips >= K + 1 are generated), so --shapes 1023 gives 1024 distinct model blobs")
+    p.add_argument("--workload", default="copycat", choices=["copycat", "ball_objects"],
+                   help="copycat = configs[1] (the metric's config); ball_objects = configs[4] stand-in: ball-joint humanoid, self-collision, free boxes, torque actions (physics only)")
+    p.add_argument("--objects", type=int, default=4, help="ball_objects: free boxes per env")
+    p.add_argument("--no-pgs-probe", action="store_true", help="skip the short PGS (solver 0) kernel timings after the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
@@ -69,46 +113,59 @@ def parse():
 
 
 def cpu_baseline(agent, n_env_gpu):
-    """The CPU oracle (own restatement of the MuJoCo step + PD; kind 'port') on the host cores, bounded sample of
-    the same workload: physics control steps from the clips' first frames with init-policy action noise."""
+    """The CPU oracle (own restatement of the MuJoCo step + PD; kind 'port') on the host cores, bounded sample of the same workload:
+    physics control steps from the clips' first frames with init-policy action noise -- at ONE thread and at all host cores."""
     import ctypes as C
     from oracle.physics import OracleSim, lib
     env = agent.env
     cores = os.cpu_count() or 1
-    n = min(n_env_gpu, 4 * cores)
     frames = env.env._bank[0].cpu().numpy()
     starts = env.env._bank[1].cpu().numpy()
-    rng = np.random.default_rng(0)
-    sims, tb = [], []
-    for e in range(n):
-        f0 = frames[starts[e % len(starts)]]
-        s = OracleSim(env.model, env.ctrl)
-        s.set_state(f0[0:76], frames[starts[e % len(starts)] + 1][76:151])
-        sims.append(s)
-        tb.append(frames[starts[e % len(starts)] + 1][7:76])
     L = lib()
-    ptrs = (C.c_void_p * n)(*[s.d for s in sims])
-    tb = np.ascontiguousarray(np.stack(tb))
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        a = np.ascontiguousarray(rng.normal(scale=np.exp(-2.3), size=(n, env.action_dim)))
-        L.orc_batch_do_simulation(C.byref(sims[0].desc), C.byref(env.ctrl), ptrs, n, a.ctypes.data_as(C.POINTER(C.c_double)),
-                                  tb.ctypes.data_as(C.POINTER(C.c_double)))
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or steps >= 15:
-            break
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} physics control steps (15 substeps, PD + RFC) of the same clips, oracle/physics_oracle.c with "
-                      f"OpenMP over envs; MuJoCo itself is not installed"}
+    L.orc_set_threads.argtypes = [C.c_int]
+
+    def run(n, threads, budget_s, max_steps):
+        rng = np.random.default_rng(0)
+        sims, tb = [], []
+        for e in range(n):
+            f0 = frames[starts[e % len(starts)]]
+            s = OracleSim(env.model, env.ctrl)
+            s.set_state(f0[0:76], frames[starts[e % len(starts)] + 1][76:151])
+            sims.append(s)
+            tb.append(frames[starts[e % len(starts)] + 1][7:76])
+        ptrs = (C.c_void_p * n)(*[s.d for s in sims])
+        tb = np.ascontiguousarray(np.stack(tb))
+        L.orc_set_threads(threads)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            a = np.ascontiguousarray(rng.normal(scale=np.exp(-2.3), size=(n, env.action_dim)))
+            L.orc_batch_do_simulation(C.byref(sims[0].desc), C.byref(env.ctrl), ptrs, n, a.ctypes.data_as(C.POINTER(C.c_double)),
+                                      tb.ctypes.data_as(C.POINTER(C.c_double)))
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or steps >= max_steps:
+                break
+        return n * steps / el, n, steps
+
+    v1, n1, s1 = run(8, 1, 5.0, 15)
+    n = min(n_env_gpu, 4 * cores)
+    vall, na, sa = run(n, cores, 10.0, 15)
+    return {"value": vall, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1_thread": v1,
+            "sample": f"{na} envs x {sa} physics control steps (15 substeps, PD + RFC) of the same clips on {cores} OpenMP threads, and {n1} envs x {s1} on one thread; "
+                      f"oracle/physics_oracle.c; MuJoCo itself is not installed"}
 
 
 def cpu_ppo_baseline(agent, batch):
-    """PyTorch-CPU float64 full-batch PPO epoch (value step + policy step: forward, backward, Adam) on a bounded sample of the
-    collected batch, all host threads -- the learner half of the reference's CPU path.  Returns samples/s of a 10-epoch update."""
+    """PyTorch-CPU float64 full-batch PPO epochs (value step + policy step: forward, backward, Adam) on a bounded sample of the collected
+    batch -- the learner half of the reference's CPU path -- with one torch thread per physical core.  samples/s of a 10-epoch update."""
     import copy
-    n = min(1024, batch.states.shape[0])
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        phys = os.cpu_count() or 1
+    n = min(4096, batch.states.shape[0])
+    torch.set_num_threads(phys)
     pol, val = copy.deepcopy(agent.policy_net).cpu().double(), copy.deepcopy(agent.value_net).cpu().double()
     op = torch.optim.Adam([p for p in pol.parameters() if p.requires_grad], lr=5e-5)
     ov = torch.optim.Adam(val.parameters(), lr=3e-4)
@@ -124,15 +181,16 @@ def cpu_ppo_baseline(agent, batch):
         pl = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
         op.zero_grad(); pl.backward(); op.step()
 
-    epoch()
-    t0, k = time.perf_counter(), 0
-    while True:
+    epoch()  # warm-up (thread pool, allocator)
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < 3 or (time.perf_counter() - t_all < 8.0 and len(ts) < 10):
+        t0 = time.perf_counter()
         epoch()
-        k += 1
-        if time.perf_counter() - t0 > 5.0 or k >= 3:
-            break
-    el = (time.perf_counter() - t0) / k
-    return {"ppo_value": n / (10 * el), "ppo_unit": "samples/s (10-epoch full-batch update)", "ppo_sample": f"{k} epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads"}
+        ts.append(time.perf_counter() - t0)
+    el = float(np.median(ts))
+    return {"ppo_value": n / (10 * el), "ppo_unit": "samples/s (10-epoch full-batch update)",
+            "ppo_sample": f"median of {len(ts)} full epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads (physical cores)"}
 
 
 def spawn_ranks(args):
@@ -159,8 +217,89 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
+def bench_ball_objects(args):
+    """BASELINE configs[4] stand-in (the real config needs licensed SMPL / GRAB files and the reference's ball-joint env
+    path does not run as shipped): ball-joint humanoid (one ball joint + three gear-vector motors per bone, nq 99, action_type torque,
+    tq_mul 4: config/copycat_ball/copycat_ball_1.yml), body-body collisions on, K free boxes (0.3 m, 5 kg, contype 1) dropped around every
+    humanoid, default_rng(11); random torque actions, every env re-posed every 30 control steps.  Physics only (uhc_batch_simulate):
+    the quaternion observation / reward of that config are not built.  One JSON line, value = env-steps/s of this GPU."""
+    import dataclasses
+    from tests.helpers import box_triangles
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, ball_variant, hinge_to_ball_qpos, self_collision_variant
+    torch.cuda.set_device(0)
+    base = S.load_asset_model()
+    rng = np.random.default_rng(11)
+    K = args.objects
+    ang = rng.uniform(0, 2 * np.pi, size=K)
+    poses = np.stack([np.r_[-0.15 + 0.75 * np.cos(a), -0.05 + 0.75 * np.sin(a), 0.3 + 0.45 * k, 1, 0, 0, 0] for k, a in enumerate(ang)]) if K else np.zeros((0, 7))
+    hb = ball_variant(base)
+    m = self_collision_variant(hb)
+    if K:
+        m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
+    m = dataclasses.replace(m, solver=1 if args.solver is None else args.solver, iterations=args.pgs_iterations or 300)
+    ctrl = S.make_ctrl(base, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n_env = args.envs
+    stand = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))["qpos"]
+    q0 = np.tile(m.qpos0, (n_env, 1))
+    for e in range(n_env):
+        qh = stand.copy()
+        qh[7:] += rng.normal(scale=0.1, size=69)
+        q0[e, :99] = hinge_to_ball_qpos(base, hb, qh)
+    v0 = np.zeros((n_env, m.nv))
+    v0[:, :75] = rng.normal(scale=0.2, size=(n_env, 75))
+    sim = S.SimBatch(m, ctrl, n_env)
+    q0d, v0d = torch.from_numpy(q0).cuda(), torch.from_numpy(v0).cuda()
+    tb = torch.zeros(n_env, 69, dtype=torch.float64, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    acts = 0.3 * torch.randn(16, n_env, ctrl.action_dim, dtype=torch.float64, device="cuda", generator=gen)
+    hist_nefc, hist_ncon, redo_tot, steps_done = [], [], 0, 0
+
+    def run(k, timed):
+        nonlocal redo_tot, steps_done
+        for i in range(k):
+            if steps_done % 30 == 0:
+                sim.set_state(q0d, v0d)
+            sim.simulate(acts[steps_done % 16], tb)
+            steps_done += 1
+            if timed:
+                redo_tot += sim.field(S.F_REDO)  # device-side accumulation, no sync
+                if i % 5 == 4:
+                    hist_nefc.append(sim.field(S.F_NEFC).clone()); hist_ncon.append(sim.field(S.F_NCON).clone())
+
+    redo_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    run(args.warmup, False)
+    torch.cuda.synchronize()
+    sim.set_timing(True)
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms, k = sim.kernel_time()
+    nefc = torch.cat(hist_nefc).cpu().numpy() if hist_nefc else np.zeros(1)
+    ncon = torch.cat(hist_ncon).cpu().numpy() if hist_ncon else np.zeros(1)
+    out = {"metric": "env-steps/sec (ball-joint SMPL humanoid + free objects, 15 substeps/step, physics only)", "value": n_env * args.steps / el, "unit": "env-steps/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"configs[4] stand-in: ball-joint humanoid (nq {m.nq}, nv {m.nv}), self-collision on, {K} free 5 kg boxes, torque actions, {n_env} envs, "
+                                  "re-posed every 30 control steps; physics only", "envs_per_gpu": n_env, "objects": K,
+                      "contact_solver": "active-set in the fast kernel, sweeps in the general kernel" if int(m.solver) == 1 else "pgs sweeps", "pgs_sweep_cap": int(m.iterations)},
+           "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true, true>", "kernel_ms": ms / max(k, 1), "launches": k,
+                        "achieved": 8 * (2 * m.nq + 3 * m.nv + ctrl.action_dim + 7 * m.nbody) * n_env / (ms / max(k, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "note": "fast-kernel launches only (HIP events); envs beyond its capacity (64 rows / 16 contacts / 12 body-body rows) are redone by the general "
+                                "kernel in a second launch, which ms_per_step includes"},
+           "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()), "ncon_max": int(ncon.max()),
+                              "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129])[0].tolist(),
+                              "general_kernel_share_of_env_steps": float(redo_tot.double().sum().item()) / (n_env * args.steps),
+                              "efc_overflow_envs": int(sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(sim.field(S.F_FAIL).sum().item())}}
+    out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload == "ball_objects":
+        return bench_ball_objects(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -195,16 +334,30 @@ def main():
     specs["file_path"] = "synthetic"
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed + rank)
-    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(args.clips, seed=1 + rank))
+    n_clips = max(args.clips, args.shapes + 1) if args.shapes else args.clips
+    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(n_clips, seed=1 + rank))
     shape_models = clip_model = None
-    if args.shapes:  # neutral model with per-body-length scale s ~ U(0.85, 1.15) (mass ~ s^3, inertia ~ s^5), default_rng(7)
-        from uhc_amd.model.mjcf import scale_model
+    if args.shapes:  # per-body length scale s_b ~ U(0.85, 1.15) (mass ~ s^3, inertia ~ s^5), default_rng(7); one shape per clip
+        from uhc_amd.model.mjcf import kinematics_np, quat_to_mat, scale_model_per_body
+        base = S.load_asset_model()
         srng = np.random.default_rng(7)
-        scales = np.r_[1.0, srng.uniform(0.85, 1.15, size=args.shapes)]
-        shape_models = [scale_model(S.load_asset_model(), float(sc)) for sc in scales[1:]]
-        clip_model = {k: int(srng.integers(0, args.shapes + 1)) for k in dl.data_keys}
-        for k, mi in clip_model.items():  # the clip of a taller body carries its root higher (as AMASS clips fitted to that shape do)
-            dl.data["trans"][k] = dl.data["trans"][k] * np.array([1.0, 1.0, scales[mi]])
+        stand = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))["qpos"]
+
+        def lowest(m):  # lowest hull vertex of the standing pose: the clip of a longer-legged body carries its root higher
+            xp, xq, _, _ = kinematics_np(m, stand)
+            return min((m.mesh_vert[m.geom_vertadr[g]:m.geom_vertadr[g] + m.geom_vertnum[g]] @ quat_to_mat(xq[m.geom_bodyid[g]]).T + xp[m.geom_bodyid[g]])[:, 2].min()
+                       for g in range(m.ngeom) if m.geom_type[g] == 7)
+
+        z0 = lowest(base)
+        shape_models, lift = [], [0.0]
+        for _ in range(args.shapes):
+            sm = scale_model_per_body(base, np.r_[1.0, srng.uniform(0.85, 1.15, size=base.nbody - 1)])
+            shape_models.append(sm)
+            lift.append(z0 - lowest(sm))
+        keys = list(dl.data_keys)
+        clip_model = {k: (i % (args.shapes + 1)) for i, k in enumerate(keys)}
+        for k, mi in clip_model.items():
+            dl.data["trans"][k] = dl.data["trans"][k] + np.array([0.0, 0.0, lift[mi]])
     agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl, shape_models=shape_models, clip_model=clip_model)
     agent.logger.handlers = [h for h in agent.logger.handlers if not isinstance(h, __import__("logging").StreamHandler) or hasattr(h, "baseFilename")]
     agent.per_epoch_update(0)
@@ -266,10 +419,48 @@ def main():
             algbw = comm_bytes * ncalls / (comm_ms * 1e-3) / 1e9
             ppo["allreduce"] = {"calls": ncalls, "bytes_per_call": comm_bytes, "total_ms": comm_ms, "algbw_GBs": algbw,
                                 "busbw_GBs": algbw * 2 * (world - 1) / world, "share_of_update": comm_ms * 1e-3 / t_up}
+    # ---- the same rollout with MuJoCo-style PGS sweeps (solver 0), kernel time only: what north_star's "PGS contact solve" costs
+    pgs = None
+    if world == 1 and not args.no_pgs_probe:
+        pgs = {}
+        orig = (int(env.model.solver), int(env.model.iterations))
+        for cap in (100, 300):
+            env.sim.set_solver(0, cap)
+            agent.rollout_begin(12)
+            for _ in range(4):
+                agent.rollout_step()
+            torch.cuda.synchronize()
+            env.sim.kernel_time()
+            env.sim.set_timing(True)
+            for _ in range(8):
+                agent.rollout_step()
+            torch.cuda.synchronize()
+            ms, k = env.sim.kernel_time()
+            env.sim.set_timing(False)
+            sweeps = float(env.sim.field(S.F_SOLVER_ITER).double().mean().item())
+            agent.rollout_end()
+            pgs[f"sweep_cap_{cap}"] = {"kernel_ms": ms / max(k, 1), "kernel_only_env_steps_per_s": n_env / (ms / max(k, 1) * 1e-3), "mean_sweeps_last_substep": sweeps, "launches": k}
+        env.sim.set_solver(*orig)
     if rank == 0:
         kern_ms = max(kern_total_ms / max(kern_n, 1), 1e-9)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if n_env == 1024 else (None, None)
+        # the bound that matters: float64 vector issue / latency.  Flops from the PMC instruction counters of the same workload when a
+        # committed pass exists (profiles/*_pmc_VALU_F64.txt, 1024 envs), else the SURVEY 8d estimate of ~20 MFLOP per env-step
+        vc = valu_f64_counters() if n_env == 1024 else None
+        flop_launch = vc["flop_per_launch"] if vc else 20e6 * n_env
+        alu = {"flop_per_env_step": flop_launch / n_env, "source": (vc["source"] + ": 64 x (ADD + MUL + TRANS + 2 FMA) f64 wave-instructions") if vc else "estimate (SURVEY 8d)",
+               "achieved_tflops": flop_launch / (kern_ms * 1e-3) / 1e12, "peak_tflops": 78.6, "frac": flop_launch / (kern_ms * 1e-3) / 78.6e12}
+        if vc:
+            alu["counters_per_launch"] = vc["counters"]
+        # SURVEY 8d's stand-alone contact-solve accounting: A (nefc^2) + b, R, f in + f out = 8 (nefc^2 + 4 nefc) bytes per solve, 15 solves per
+        # launch; the time is the kernel's contact-solve share (stage profile).  The solve keeps A in registers: it is nowhere near HBM-bound.
+        share, share_src = contact_solve_share()
+        cs_bytes = float((8.0 * (nefc.astype(np.float64) ** 2 + 4.0 * nefc)).sum()) * 15
+        csolve = {"algorithmic_bytes_per_launch": cs_bytes, "share_of_kernel": share, "share_source": share_src,
+                  "achieved_GBs": (cs_bytes / (kern_ms * 1e-3 * share) / 1e9) if share else None,
+                  "frac_of_hbm_peak": (cs_bytes / (kern_ms * 1e-3 * share) / 1e9 / HBM_PEAK_GBS) if share else None,
+                  "formula": "sum over envs of 8 (nefc^2 + 4 nefc) x 15 substeps, nefc of the last substep"}
         out = {
             "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "per_rank_env_steps_per_s": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
@@ -282,10 +473,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
-                         # the bound that matters: float64 vector issue/latency.  ~20 MFLOP per env-step (factorisations,
-                         # substitutions, Delassus rows, contact solve, tree recursions) against the 78.6 TFLOP/s FP64 vector peak
-                         "alu_f64": {"est_flop_per_env_step": 20e6, "achieved_tflops": 20e6 * n_env / (kern_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
-                                     "frac": 20e6 * n_env / (kern_ms * 1e-3) / 78.6e12},
+                         "alu_f64": alu,
+                         "contact_solve": csolve,
                          "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
                                  "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
                                  "above the algorithmic bytes is L2 misses of the schedule tables / kernel code and register spills to scratch"},
@@ -296,6 +485,8 @@ def main():
                                "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},
         }
+        if pgs:
+            out["pgs"] = pgs
         if ppo:
             out["ppo"] = ppo
         if world == 1 and not args.no_cpu_baseline:

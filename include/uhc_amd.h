@@ -144,6 +144,10 @@ int32_t uhc_batch_sync(UhcBatch* b);
 /* change rfc_scale between iterations (rfc_decay: uhc/agents/agent_copycat.py:283-290) */
 int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
 
+/* switch the contact solver of the dual QP between launches: solver 0 / 1 and the sweep cap, as in UhcModelDesc (MuJoCo's opt.solver /
+ * opt.iterations are run-time options too); iterations <= 0 keeps the current cap */
+int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t iterations);
+
 /* device pointer + element count of a state field (valid until uhc_batch_free) */
 int32_t uhc_batch_field(UhcBatch* b, int32_t field, void** d_ptr, int64_t* count);
 

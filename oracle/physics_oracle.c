@@ -1246,6 +1246,14 @@ void orc_set(const UhcModelDesc* m, OrcData* d, const char* name, const double* 
 }
 
 /* ------------------------------------------------------------------ batch driver for the CPU baseline */
+void orc_set_threads(int n) { /* OpenMP threads of the batch driver (the CPU baseline is reported at 1 thread and at all host cores) */
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
 void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData** ds, int n_env,
                              const double* actions, const double* target_base) {
 #pragma omp parallel for schedule(dynamic, 1)

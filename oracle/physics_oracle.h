@@ -51,6 +51,7 @@ void orc_rfc_implicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, c
 void orc_rfc_explicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action);
 void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
                        const double* target_base);
+void orc_set_threads(int n);
 void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData** ds, int n_env,
                              const double* actions, const double* target_base);
 int orc_get(const UhcModelDesc* m, const OrcData* d, const char* name, double* out, int max);

@@ -74,7 +74,7 @@ def test_ball_humanoid_trajectory_matches_oracle(model, standing, kernel_path, l
     tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
     worst = 0.0
     for t in range(15):
-        act = rng.normal(scale=0.3, size=(n, ctrl.action_dim))
+        act = rng.normal(scale=0.003, size=(n, ctrl.action_dim))  # x a_scale x 100: torques of a few N m (the hands weigh 0.4 kg)
         b.simulate(torch.from_numpy(act).cuda(), tb)
         b.sync()
         gq = b.field(S.F_QPOS).cpu().numpy()
@@ -109,7 +109,7 @@ def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_p
     tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
     worst = 0.0
     for t in range(12):
-        act = rng.normal(scale=0.3, size=(n, ctrl.action_dim))
+        act = rng.normal(scale=0.003, size=(n, ctrl.action_dim))  # x a_scale x 100: torques of a few N m (the hands weigh 0.4 kg)
         b.simulate(torch.from_numpy(act).cuda(), tb)
         b.sync()
         gq = b.field(S.F_QPOS).cpu().numpy()

@@ -584,6 +584,12 @@ extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {
     b->A.c.rfc_scale = s;
     return 0;
 }
+extern "C" int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t iterations) {
+    if (!b || (solver != 0 && solver != 1)) return fail("uhc_batch_set_solver: solver must be 0 (sweeps) or 1 (active set)");
+    b->A.t.solver = solver;
+    if (iterations > 0) b->A.t.iterations = iterations;
+    return 0;
+}
 extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n) {
     if (!b || f < 0 || f > 16 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
     if (p) *p = b->field_ptr[f];

@@ -6,7 +6,7 @@
 
 #define UHC_WAVE 64
 #define UHC_MAXEFC 128   // constraint rows per env (2 per lane)
-#define UHC_MAXCON 40    // contacts per env (general kernel)
+#define UHC_MAXCON 64    // contacts per env (general kernel)
 #define UHC_FAST_MAXCON 16  // contacts per env (fast kernel)
 #define UHC_MAXTWO 32       // constraint rows between two moving bodies per env (general kernel); they are kept as dense dof vectors
 #define UHC_FAST_MAXTWO 12  // the same for the fast kernel

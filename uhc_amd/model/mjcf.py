@@ -1076,3 +1076,34 @@ def add_free_bodies(m: Model, hulls: List[np.ndarray], poses: np.ndarray, densit
     o.dof_frictionloss = np.concatenate([m.dof_frictionloss, z6])
     set_const(o)
     return o
+
+
+def scale_model_per_body(m: Model, scales) -> Model:
+    """Body-shape variation as SURVEY.md 8d config 4 prescribes: every body b gets its own length scale s_b (bone offsets of its
+    children and its hull scale with s_b, mass with s_b^3, inertia with s_b^5 at constant density); the constants derived at qpos0
+    are recomputed.  Same topology as `m`, so such models share one batch (one model blob per env)."""
+    s = np.asarray(scales, dtype=np.float64)
+    assert s.shape == (m.nbody,)
+    o = m.copy()
+    par = np.asarray(m.body_parentid)
+    ps = np.where(par > 0, s[par], 1.0)  # a body's offset from its parent lives in the parent's frame: the parent's bone length
+    o.body_pos = m.body_pos * ps[:, None]
+    o.body_ipos = m.body_ipos * s[:, None]
+    jb = np.asarray(m.jnt_bodyid)
+    o.jnt_pos = m.jnt_pos * s[jb][:, None]
+    gb = np.asarray(m.geom_bodyid)
+    o.geom_pos = m.geom_pos * s[gb][:, None]
+    o.geom_center = m.geom_center * s[gb][:, None]
+    o.geom_rbound = m.geom_rbound * s[gb]
+    mv = m.mesh_vert.copy()
+    for g in range(m.ngeom):
+        if m.geom_type[g] == GEOM_MESH:
+            a, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
+            mv[a:a + n] *= s[gb[g]]
+    o.mesh_vert = mv
+    o.body_mass = m.body_mass * s ** 3
+    o.body_inertia = m.body_inertia * (s ** 5)[:, None]
+    o.qpos0 = m.qpos0.copy()
+    o.qpos_spring = o.qpos0.copy()
+    set_const(o)
+    return o

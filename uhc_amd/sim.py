@@ -95,6 +95,10 @@ class SimBatch:
         True: they keep what fits (reported in F_EFC_OVERFLOW) and no second pass is needed."""
         check(self.L.uhc_batch_set_overflow_mode(self._b, int(bool(truncate))))
 
+    def set_solver(self, solver: int, iterations: int = 0):
+        """Contact solver of the following launches: 0 = PGS sweeps (cap `iterations`), 1 = exact active-set solve."""
+        check(self.L.uhc_batch_set_solver(self._b, int(solver), int(iterations)))
+
     def set_rfc_scale(self, s: float):
         check(self.L.uhc_batch_set_rfc_scale(self._b, float(s)))
 
