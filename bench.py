@@ -233,7 +233,7 @@ def bench_ball_objects(args):
     K = args.objects
     ang = rng.uniform(0, 2 * np.pi, size=K)
     poses = np.stack([np.r_[-0.15 + 0.75 * np.cos(a), -0.05 + 0.75 * np.sin(a), 0.3 + 0.45 * k, 1, 0, 0, 0] for k, a in enumerate(ang)]) if K else np.zeros((0, 7))
-    hb = ball_variant(base)
+    hb = ball_variant(base, damping=5.0)  # joint damping inside copycat_ball_1.yml's [0, 10] range: mj_Euler's implicit-damping branch
     m = self_collision_variant(hb)
     if K:
         m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
@@ -252,7 +252,7 @@ def bench_ball_objects(args):
     q0d, v0d = torch.from_numpy(q0).cuda(), torch.from_numpy(v0).cuda()
     tb = torch.zeros(n_env, 69, dtype=torch.float64, device="cuda")
     gen = torch.Generator(device="cuda").manual_seed(11)
-    acts = 0.3 * torch.randn(16, n_env, ctrl.action_dim, dtype=torch.float64, device="cuda", generator=gen)
+    acts = 0.1 * torch.randn(16, n_env, ctrl.action_dim, dtype=torch.float64, device="cuda", generator=gen)  # init-policy noise (log_std -2.3): torques ~ N(0, 10 N m)
     hist_nefc, hist_ncon, redo_tot, steps_done = [], [], 0, 0
 
     def run(k, timed):

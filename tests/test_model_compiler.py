@@ -83,3 +83,50 @@ def test_asset_matches_fresh_compile_of_reference_xml():
     for name in ("body_pos", "body_mass", "body_inertia", "body_ipos", "mesh_vert", "dof_invweight0", "body_invweight0", "jnt_range"):
         np.testing.assert_allclose(getattr(a, name), getattr(b, name), rtol=0, atol=1e-12, err_msg=name)
     assert a.body_names == b.body_names and a.actuator_names == b.actuator_names
+
+
+def test_shape_to_model_generator_round_trip(model):
+    """uhc_amd/smpllib/smpl_robot.py (the reference's Robot.load_from_skeleton pipeline): fed with the neutral asset's own hull vertices as
+    'SMPL vertices' (one-hot skin weights, joints = body origins), the generator must give the asset back -- same tree and names, same bone
+    offsets, the same masses up to the vertices the 50-vertex budget removes -- with body-body collisions and the two excludes switched on."""
+    import numpy as np
+    from uhc_amd.model.mjcf import kinematics_np, quat_to_mat
+    from uhc_amd.smpllib.smpl_mujoco import SMPL_BONE_ORDER_NAMES
+    from uhc_amd.smpllib.smpl_robot import Robot, SMPLBody, decimate_hull
+    xpos, xquat, _, _ = kinematics_np(model, model.qpos0)
+    verts, owner = [], []
+    for g in range(model.ngeom):
+        if model.geom_type[g] != 7:
+            continue
+        b = model.geom_bodyid[g]
+        v = model.mesh_vert[model.geom_vertadr[g]:model.geom_vertadr[g] + model.geom_vertnum[g]] @ quat_to_mat(xquat[b]).T + xpos[b]
+        verts.append(v)
+        owner += [SMPL_BONE_ORDER_NAMES.index(model.body_names[b])] * len(v)
+    verts = np.concatenate(verts)
+    W = np.zeros((len(verts), 24))
+    W[np.arange(len(verts)), owner] = 1
+    joints = np.stack([xpos[model.body_names.index(n)] for n in SMPL_BONE_ORDER_NAMES])
+    for ball in (False, True):
+        r = Robot({"mesh": True, "ball": ball}, body_provider=lambda b, g: (verts, joints, W))
+        r.load_from_skeleton(np.zeros(16), gender=[0])
+        assert b"<mujoco" in r.export_xml_string()
+        g = r.get_model()
+        assert g.body_names == model.body_names and g.nbody == 25 and g.nv == 75 and g.nu == 69 and g.nq == (99 if ball else 76)
+        np.testing.assert_allclose(g.body_pos, model.body_pos, atol=1e-4)  # the XML carries 4 decimals, like the reference's writer
+        np.testing.assert_allclose(g.body_mass, model.body_mass, rtol=0.02)
+        assert (g.geom_contype[1:] == 1).all() and g.nexclude == 2 and g.geom_vertnum.max() <= 50
+        assert g.actuator_names == model.actuator_names
+        if not ball:  # rel_joint_lm knee range (smpl_robot.py:1087-1092)
+            j = g.joint_names.index("L_Knee_x")
+            np.testing.assert_allclose(g.jnt_range[j], [-np.pi / 16, np.pi], atol=1e-4)
+    # the vertex budget: a dense ellipsoid comes down to 50 hull vertices and keeps most of its volume
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(0)
+    P = rng.normal(size=(800, 3))
+    P = P / np.linalg.norm(P, axis=1)[:, None] * [0.1, 0.05, 0.2]
+    D = decimate_hull(P, 50)
+    assert len(D) == 50 and ConvexHull(D).volume > 0.85 * ConvexHull(P).volume
+    # the SMPL forward pass itself needs the licensed model files
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        SMPLBody("/nonexistent")(np.zeros(10), 0)
