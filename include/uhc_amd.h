@@ -115,8 +115,9 @@ enum UhcField {
     UHC_F_QFRC_APPLIED = 13, /* [n_env][nv] data.qfrc_applied of the last substep */
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
     UHC_F_STAGE_PROF = 15,   /* int64 [n_env][32] per-stage shader-cycle counters (profiling builds only) */
-    UHC_F_REDO = 16          /* int32 [n_env] 1: the env's last step / forward pass exceeded the fast kernel's capacity (64 rows, 16 contacts,
-                              * packed row storage) and was computed by the general kernel -- which always runs solver 0 (sweeps) */
+    UHC_F_REDO = 16          /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast kernel's capacity (64 rows, 16 contacts, packed
+                              * row storage, 12 body-body rows) and was computed by the general kernel (128 rows, 64 contacts, 32 body-body rows), which
+                              * solves the QP exactly too (working sets of <= 64 rows); bit 1: that solve fell back to solver 0 (sweeps to tolerance) */
 };
 
 const char* uhc_last_error(void);

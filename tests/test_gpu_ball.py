@@ -66,7 +66,7 @@ def test_ball_humanoid_trajectory_matches_oracle(model, standing, kernel_path, l
     b.sync()
     os_ = [OracleSim(ball, ctrl) for _ in range(n)]
     for e in range(n):
-        os_[e].desc.solver = 0 if kernel_path == "general" else 1
+        os_[e].desc.solver = 0 if (int(b.field(S.F_REDO)[e].item()) & 2) else 1
         os_[e].set_state(q[e], v[e])
         np.testing.assert_allclose(b.field(S.F_QM)[e].cpu().numpy(), os_[e].get("qM"), atol=1e-10)
         np.testing.assert_allclose(b.field(S.F_QACC)[e].cpu().numpy(), os_[e].get("qacc"), atol=1e-5, rtol=1e-6)
@@ -80,7 +80,7 @@ def test_ball_humanoid_trajectory_matches_oracle(model, standing, kernel_path, l
         gq = b.field(S.F_QPOS).cpu().numpy()
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].desc.solver = 0 if (redo[e] & 2) else 1  # UHC_F_REDO bit 1: the general kernel fell back to sweeps
             os_[e].do_simulation(act[e], np.zeros(69))
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-6, worst
@@ -102,7 +102,7 @@ def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_p
     os_ = [OracleSim(ball, ctrl) for _ in range(n)]
     redo = b.field(S.F_REDO).cpu().numpy()
     for e in range(n):
-        os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+        os_[e].desc.solver = 0 if (redo[e] & 2) else 1
         os_[e].set_state(q[e], v[e])
         assert int(b.field(S.F_NCON)[e].item()) == os_[e].geti("ncon") and int(b.field(S.F_NEFC)[e].item()) == os_[e].geti("nefc")
     rng = np.random.default_rng(44)
@@ -115,7 +115,7 @@ def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_p
         gq = b.field(S.F_QPOS).cpu().numpy()
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].desc.solver = 0 if (redo[e] & 2) else 1
             os_[e].do_simulation(act[e], np.zeros(69))
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-5, worst

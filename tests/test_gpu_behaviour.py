@@ -70,8 +70,8 @@ def test_friction_cone_slip_threshold_gpu(kernel_path):
             assert q[e, 0] == pytest.approx(0.5 * 9.81 * (np.sin(th) - np.cos(th)) * t * t, rel=0.12)
         else:
             assert abs(q[e, 0]) < 0.02 * 0.5 * 9.81 * np.sin(th) * t * t
-        # and the oracle's trajectory (same solver per kernel path: the general kernel always sweeps)
-        o = _oracle(ms[e], q0s[e], np.zeros(6), n, solver=0 if kernel_path == "general" else 1)
+        # and the oracle's trajectory (both kernels solve the QP exactly: active set in registers / by working sets)
+        o = _oracle(ms[e], q0s[e], np.zeros(6), n, solver=1)
         np.testing.assert_allclose(q[e], o.get("qpos"), atol=5e-5 if kernel_path == "general" else 1e-7)
 
 
@@ -95,7 +95,7 @@ def test_resting_equilibrium_and_flat_contacts_gpu(kernel_path):
     m.solver = 1
     q0 = np.array([0, 0, 0.0499, 1, 0, 0, 0.0])
     b = _run([m], [q0], [np.zeros(6)], 1500)
-    o = _oracle(m, q0, np.zeros(6), 1500, solver=0 if kernel_path == "general" else 1)
+    o = _oracle(m, q0, np.zeros(6), 1500, solver=1)
     np.testing.assert_allclose(b.field(S.F_QPOS).cpu().numpy()[0], o.get("qpos"), atol=1e-6)
     assert int(b.field(S.F_NCON)[0].item()) == 3 and abs(b.field(S.F_QVEL).cpu().numpy()).max() < 1e-5
     mb = box_model(0.1)
@@ -152,7 +152,7 @@ def test_implicit_joint_damping_gpu(kernel_path):
         hb.sync()
         redo = hb.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].desc.solver = 0 if (redo[e] & 2) else 1
             os_[e].do_simulation(act[e], qpos[e, 7:])
     gq = hb.field(S.F_QPOS).cpu().numpy()
     for e in range(n):

@@ -55,7 +55,7 @@ def test_mpr_contacts_match_oracle(kernel_path):
     hits = 0
     for e in range(n):
         o = OracleSim(m)
-        o.desc.solver = 0 if kernel_path == "general" else 1
+        o.desc.solver = 0 if (int(b.field(S.F_REDO)[e].item()) & 2) else 1
         o.set_state(q[e], v[e])
         assert ncon[e] == o.geti("ncon") and nefc[e] == o.geti("nefc"), e
         np.testing.assert_allclose(qacc[e], o.get("qacc"), atol=1e-6, rtol=1e-6)
@@ -76,7 +76,7 @@ def test_stacked_boxes_trajectory_matches_oracle(kernel_path):
     act = torch.zeros(2, 1, dtype=torch.float64, device="cuda")
     os_ = [OracleSim(m) for _ in range(2)]
     for e in range(2):
-        os_[e].desc.solver = 0 if kernel_path == "general" else 1
+        os_[e].desc.solver = 1
         os_[e].set_state(q0[e], np.zeros(12))
     worst = 0.0
     for t in range(120):
@@ -118,14 +118,14 @@ def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, li
     ncon, nefc, qacc, redo = (b.field(f).cpu().numpy() for f in (S.F_NCON, S.F_NEFC, S.F_QACC, S.F_REDO))
     nself = 0
     for e in range(n):
-        os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+        os_[e].desc.solver = 0 if (redo[e] & 2) else 1
         os_[e].set_state(qpos[e], qvel[e])
         assert ncon[e] == os_[e].geti("ncon") and nefc[e] == os_[e].geti("nefc"), (e, ncon[e], os_[e].geti("ncon"))
         np.testing.assert_allclose(qacc[e], os_[e].get("qacc"), atol=1e-5, rtol=1e-6)
         nself += os_[e].geti("ncon")
     assert nself > 0
     if lift > 0 and kernel_path == "fast":
-        assert redo.sum() <= 1  # few rows: the fast kernel's dense path did the work (an env with > 12 body-body rows goes to the general kernel)
+        assert (redo != 0).sum() <= 1  # few rows: the fast kernel's dense path did the work (an env with > 12 body-body rows goes to the general kernel)
     rng = np.random.default_rng(32)
     tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
     worst = 0.0
@@ -136,7 +136,7 @@ def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, li
         gq = b.field(S.F_QPOS).cpu().numpy()
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (kernel_path == "general" or redo[e]) else 1
+            os_[e].desc.solver = 0 if (redo[e] & 2) else 1
             os_[e].do_simulation(act[e], qpos[e, 7:])
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-5, worst

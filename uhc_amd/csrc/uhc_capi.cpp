@@ -388,11 +388,12 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
     L.rowDa = carve(UHC_MAXEFC);
     L.rowMisc = carve(UHC_MAXEFC * 2);  // 4 ints per row
-    L.ncon_nefc = carve(2 + UHC_MAXTWO / 2);  // ints: truncated flag, nefc, number of two-body rows, spare, then their row ids
+    L.ncon_nefc = carve(2 + UHC_MAXTWO);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids, slot -> lane of the working set
     A.nvp = (nv + 1) & ~1;
     A.ndense_g = T.ncpair > 0 ? UHC_MAXTWO : 0;
     L.dense = carve(A.ndense_g * A.nvp);
-    L.dcol = carve(A.ndense_g * 4);  // general kernel: (vel, jas, jaw, diag) of every dense row
+    L.dcol = carve(A.ndense_g * UHC_WAVE);  // Delassus columns of the dense rows within the working set (as in the fast layout)
+    L.dsc = carve(A.ndense_g * 4);          // (vel, jas, jaw, |Yhat|^2) of every dense row
     L.total = off;
     b->lds_bytes = (size_t)off * sizeof(double);
     if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }

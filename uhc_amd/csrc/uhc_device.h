@@ -66,7 +66,8 @@ struct DevLds {
     int mij;  // 16-bit (row << 8 | col) of every sparse-M entry, loaded once per kernel (k_crb)
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
     int dense;  // [ndense][nvp] dense Yhat rows of the constraints that touch two moving bodies (self-collision, objects)
-    int dcol;   // fast kernel: [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back)
+    int dcol;   // [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back)
+    int dsc;    // general kernel: [ndense][4] J.qvel, J.qacc_smooth, J.qacc_warmstart, |Yhat|^2 of every dense row
     int total;  // doubles
 };
 

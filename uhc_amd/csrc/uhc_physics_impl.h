@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
     const int ntwo = (FAST ? A.ndense_f : A.ndense_g) > 0 ? NI[2] : 0;
     for (int k = 0; k < ntwo; k++) {  // dense rows first (wave-cooperative); their scalars wait in dcol for the lane that owns the row
         const DenseOut o = k_dense_row<FAST>(A, S, NI[4 + k], k, LC);
-        if (LANE == 0) { S[L.dcol + 4 * k] = o.vel; S[L.dcol + 4 * k + 1] = o.jas; S[L.dcol + 4 * k + 2] = o.jaw; S[L.dcol + 4 * k + 3] = o.yy; }
+        if (LANE == 0) { S[L.dsc + 4 * k] = o.vel; S[L.dsc + 4 * k + 1] = o.jas; S[L.dsc + 4 * k + 2] = o.jaw; S[L.dsc + 4 * k + 3] = o.yy; }
     }
     wsync();
     for (int r = LANE; r < nefc; r += UHC_WAVE) {
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
             jaw += j * S[L.qacc + i];
         }
         double yy = 0;
-        if (two) { const double* o = S + L.dcol + 4 * (rm.type >> 8); vel = o[0]; jas = o[1]; jaw = o[2]; yy = o[3]; }
+        if (two) { const double* o = S + L.dsc + 4 * (rm.type >> 8); vel = o[0]; jas = o[1]; jaw = o[2]; yy = o[3]; }
         const double R = diagApprox < 0 ? -diagApprox : fmax(UHC_MINVAL, (1 - imp) * diagApprox / imp);
         const double aref = -B * vel - K * imp * (pos - margin);
         const double jar = jaw - aref, D = 1.0 / R;
@@ -1554,16 +1554,17 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
 }
 
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
-template <bool DENSE>
-__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM], const LaneConst& LC PROF_ARGS) {
+// FASTL: which LDS layout the rows live in (the general kernel solves working sets of <= 64 of its rows with the same code).
+// SL[0 .. nslot): lane that holds the dense row of slot k (an entry outside [0, nefc) = that row is not part of this solve).
+template <bool FASTL, bool DENSE>
+__device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM], const LaneConst& LC,
+                                          const int* SL, int nslot PROF_ARGS) {
     const DevTopo& T = A.t;
-    const DevLds& L = A.lf;
+    const DevLds& L = FASTL ? A.lf : A.l;
     const bool valid = LANE < nefc;
-    const int* NI = (const int*)(S + L.ncon_nefc);
-    int ntwo = 0;  // dense rows among the first nefc rows (wave-uniform)
+    int ntwo = 0;  // dense rows taking part (wave-uniform)
     if constexpr (DENSE) {
-        const int nt = NI[2];
-        for (int k = 0; k < nt; k++) ntwo += NI[4 + k] < nefc;
+        for (int k = 0; k < nslot; k++) ntwo += (unsigned)SL[k] < (unsigned)nefc;
         ntwo = __builtin_amdgcn_readfirstlane(ntwo);
     }
     // ---- Delassus columns of the dense rows: A[l][c] = Yhat_l . Yhat_c for every lane l, kept in LDS (dcol[slot][lane]): lane l reads its
@@ -1572,7 +1573,8 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         unsigned int cdq[UHC_YM];
         const unsigned int* chain = T.chain + (size_t)(row.last >= 0 ? row.last : 0) * UHC_YM;
         static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) { constexpr int q = decltype(qc)::value; cdq[q] = chain[q] & 0xffffu; });
-        for (int k = 0; k < ntwo; k++) {
+        for (int k = 0; k < nslot; k++) {
+            if ((unsigned)__builtin_amdgcn_readfirstlane(SL[k]) >= (unsigned)nefc) continue;
             const double* Dk = S + L.dense + k * A.nvp;
             double acc = 0.0;
             static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
@@ -1755,8 +1757,10 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
     }
     wsync();
     if (DENSE && ntwo > 0) {  // dense rows: lane = dof
-        for (int k = 0; k < ntwo; k++) {
-            const double fk = bcast(f, __builtin_amdgcn_readfirstlane(NI[4 + k]));
+        for (int k = 0; k < nslot; k++) {
+            const int ln = __builtin_amdgcn_readfirstlane(SL[k]);
+            if ((unsigned)ln >= (unsigned)nefc) continue;
+            const double fk = bcast(f, ln);
             const double* Dk = S + L.dense + k * A.nvp;
             if (LC.v0) S[L.z + LANE] += fk * Dk[LANE];
             if (LC.v1) S[L.z + LANE + UHC_WAVE] += fk * Dk[LANE + UHC_WAVE];
@@ -1764,6 +1768,138 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         wsync();
     }
     return iters;
+}
+
+// ------------------------------------------------------------------ general kernel: exact solve by working sets
+// Up to 128 rows do not fit the register-resident Delassus matrix (lane = row), but the rows that carry a force at the optimum are
+// rarely more than 64.  Solve the QP restricted to a working set C of <= 64 rows exactly (compacted into the lanes, same code as the
+// fast kernel: A_CC in registers, block principal pivoting), evaluate y = A f + b on the rows outside C (matrix-free: Yhat_r . z + b_r),
+// add the violated ones (y < 0), drop the rows of C that ended without a force, repeat.  Every new working set contains the support of
+// the current f, so the dual cost falls strictly from one round to the next: no cycling.  C starts as the rows that 8 Gauss-Seidel
+// sweeps from f = 0 leave with a force.  Returns the number of factorisations, or -1 (friction-loss rows, more than 64 candidates, no
+// convergence in UHC_WS_MAXIT rounds): the caller then runs the sweeps.
+#define UHC_WS_MAXIT 12
+template <bool DENSE>
+__device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC PROF_ARGS) {
+    const DevTopo& T = A.t;
+    const DevLds& L = A.l;
+    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
+    const int YS = T.maxdepth + 1;
+    int* NI = (int*)(S + L.ncon_nefc);
+    const int nslot = (DENSE && A.ndense_g > 0) ? NI[2] : 0;
+    int* SLg = NI + 4 + UHC_MAXTWO;           // slot -> lane of the current working set
+    int* list = (int*)(S + L.rowAref);        // working-set row ids (rowAref only holds friction-loss bounds, unused here)
+    double* z = S + L.z;
+    const int r0 = LANE, r1 = LANE + UHC_WAVE;
+    const bool v0 = r0 < nefc, v1 = r1 < nefc;
+    if (wave_or((v0 && RTYPE(RM[r0].type) == ROW_FRICTION) || (v1 && RTYPE(RM[r1].type) == ROW_FRICTION))) return -1;
+    // ---- 8 Gauss-Seidel sweeps from f = 0 (matrix-free, as k_pgs but without warm start / cost bookkeeping)
+    if (v0) S[L.rowF + r0] = 0.0;
+    if (v1) S[L.rowF + r1] = 0.0;
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
+    wsync();
+    for (int it = 0; it < UHC_AS_PRESWEEPS; it++)
+        for (int r = 0; r < nefc; r++) {
+            const RowMisc rm = RM[r];
+            const bool two = (rm.type & ROW_TWO) != 0;
+            const int len = two ? 0 : T.dof_depth[rm.last] + 1;
+            int dof = 0;
+            double y = 0, part = 0, y1 = 0;
+            if (two) {
+                const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
+                if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
+                if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
+            } else if (LANE < len) {
+                dof = T.dof_anc[rm.last * YS + LANE];
+                y = S[L.Y + r * YS + LANE];
+                part = y * z[dof];
+            }
+            const double old = S[L.rowF + r];
+            const double res = wave_sum(part) + S[L.rowR + r] * old + S[L.rowB + r];
+            double f = old - res / S[L.rowDa + r];
+            f = f < 0 ? 0.0 : f;
+            const double delta = f - old;
+            if (delta != 0) {
+                if (two) {
+                    if (LANE < T.nv) z[LANE] += delta * y;
+                    if (LANE + UHC_WAVE < T.nv) z[LANE + UHC_WAVE] += delta * y1;
+                } else if (LANE < len) z[dof] += delta * y;
+                if (LANE == 0) S[L.rowF + r] = f;
+            }
+            wsync();
+        }
+    bool c0 = v0 && S[L.rowF + r0] > 0.0, c1 = v1 && S[L.rowF + r1] > 0.0;
+    int iters = 0;
+    for (int outer = 0; outer < UHC_WS_MAXIT; outer++) {
+        // ---- compact the working set into the lanes (row order kept)
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1), below = (1ull << LANE) - 1ull;
+        const int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
+        if (nC > UHC_WAVE) return -1;
+        if (nC == 0) {  // no candidate: f = 0 is optimal iff b >= 0 everywhere
+            c0 = v0 && S[L.rowB + r0] < 0.0; c1 = v1 && S[L.rowB + r1] < 0.0;
+            if (!wave_or(c0 || c1)) {
+                if (v0) S[L.rowF + r0] = 0.0;
+                if (v1) S[L.rowF + r1] = 0.0;
+                for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
+                wsync();
+                return iters;
+            }
+            continue;
+        }
+        if (c0) list[__builtin_popcountll(m0 & below)] = r0;
+        if (c1) list[n0 + __builtin_popcountll(m1 & below)] = r1;
+        if (LANE < nslot) SLg[LANE] = -1;
+        wsync();
+        const bool valid = LANE < nC;
+        const int r = valid ? list[LANE] : 0;
+        FastRow row;
+        RowMisc rm = {0, 0, 0, 0};
+        if (valid) rm = RM[r];
+        const bool two = valid && (rm.type & ROW_TWO) != 0;
+        row.two = two ? (rm.type >> 8) : -1;
+        row.type = valid ? RTYPE(rm.type) : 0;
+        row.last = (valid && !two) ? rm.last : (valid ? -1 : 0);
+        row.len = (valid && !two) ? T.dof_depth[rm.last] + 1 : 0;
+        row.yoff = r * YS;
+        row.R = valid ? S[L.rowR + r] : 1.0; row.b = valid ? S[L.rowB + r] : 0.0; row.f = 0.0; row.floss = 0.0; row.diag = 1.0;
+        if (two) SLg[row.two] = LANE;
+        double Y[UHC_YM];
+        static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            Y[q] = q < row.len ? S[L.Y + r * YS + q] : 0.0;
+        });
+        wsync();
+        const int it = k_pgs_fast<false, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum f Yhat
+        iters += it > 0 ? it : 1;
+        // ---- forces back to the rows, y on the rows outside C
+        if (v0) S[L.rowF + r0] = 0.0;
+        if (v1) S[L.rowF + r1] = 0.0;
+        wsync();
+        if (valid) S[L.rowF + r] = row.f;
+        wsync();
+        bool viol[2] = {false, false}, keep[2] = {false, false};
+        for (int h = 0; h < 2; h++) {
+            const int rr = h ? r1 : r0;
+            if (!(h ? v1 : v0)) continue;
+            const bool inC = h ? c1 : c0;
+            if (inC) { keep[h] = S[L.rowF + rr] > 0.0; continue; }
+            const RowMisc q = RM[rr];
+            double y = S[L.rowB + rr];
+            if (q.type & ROW_TWO) {
+                const double* D = S + L.dense + (q.type >> 8) * A.nvp;
+                for (int i = 0; i < T.nv; i++) y = fma(D[i], z[i], y);
+            } else {
+                const int len = T.dof_depth[q.last] + 1;
+                const short* anc = T.dof_anc + q.last * YS;
+                for (int k = 0; k < len; k++) y = fma(S[L.Y + rr * YS + k], z[anc[k]], y);
+            }
+            viol[h] = y < 0.0;
+        }
+        if (!wave_or(viol[0] || viol[1])) return iters;  // KKT holds on every row: optimum
+        c0 = keep[0] || viol[0]; c1 = keep[1] || viol[1];
+        wsync();
+    }
+    return -1;
 }
 
 // ------------------------------------------------------------------ mj_forward
@@ -1804,12 +1940,16 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             out.overflow |= st;
             if (st == 1) return out;
             PROF(9)
-            out.iters = k_pgs_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC PROF_PASS);
+            const int* NI = (const int*)(S + L.ncon_nefc);
+            out.iters = k_pgs_fast<true, DENSE>(A, mb, S, out.nefc, row, Yreg, LC, NI + 4, DENSE ? NI[2] : 0 PROF_PASS);
             PROF(12)
         } else {
             k_rows<FAST>(A, mb, S, out.nefc, LC);
             PROF(9)
-            out.iters = k_pgs<FAST>(A, mb, S, out.nefc);
+            int it = -1;
+            if (T.solver == 1) it = k_as_general<DENSE>(A, mb, S, out.nefc, LC PROF_PASS);
+            if (it < 0) { it = k_pgs<FAST>(A, mb, S, out.nefc); out.overflow |= 4; }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1
+            out.iters = it;
             PROF(11)
         }
         // qacc = qacc_smooth + L^-1 D^-1/2 z
@@ -2173,9 +2313,9 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     if (LANE == 0) {
         if (ran) { A.s.ncon[env] = fo.ncon; A.s.nefc[env] = fo.nefc; A.s.solver_iter[env] = fo.iters; }
         A.s.fail[env] = fail;
-        if (overflow) A.s.overflow[env] = 1;
+        if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
-        if (!FAST) A.s.redo[env] = 1;  // UHC_F_REDO = "computed by the general kernel", also when the batch runs it alone
+        if (!FAST) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0);  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
     }
 }
 
