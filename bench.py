@@ -212,7 +212,7 @@ def spawn_ranks(args):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = p.wait() or rc
-    sys.stdout.write(out)
+    sys.stdout.write("".join(l + "\n" for l in out.splitlines() if l.startswith("{")))  # the JSON line only (gloo chats on stdout)
     sys.stdout.flush()
     sys.exit(rc)
 
@@ -256,18 +256,20 @@ def bench_ball_objects(args):
     hist_nefc, hist_ncon, redo_tot, steps_done = [], [], 0, 0
 
     def run(k, timed):
-        nonlocal redo_tot, steps_done
+        nonlocal redo_tot, sweep_tot, steps_done
         for i in range(k):
             if steps_done % 30 == 0:
                 sim.set_state(q0d, v0d)
             sim.simulate(acts[steps_done % 16], tb)
             steps_done += 1
             if timed:
-                redo_tot += sim.field(S.F_REDO)  # device-side accumulation, no sync
+                redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync
+                sweep_tot += ((sim.field(S.F_REDO) & 2) != 0).int()
                 if i % 5 == 4:
                     hist_nefc.append(sim.field(S.F_NEFC).clone()); hist_ncon.append(sim.field(S.F_NCON).clone())
 
     redo_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    sweep_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     run(args.warmup, False)
     torch.cuda.synchronize()
     sim.set_timing(True)
@@ -291,6 +293,7 @@ def bench_ball_objects(args):
            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()), "ncon_max": int(ncon.max()),
                               "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129])[0].tolist(),
                               "general_kernel_share_of_env_steps": float(redo_tot.double().sum().item()) / (n_env * args.steps),
+                              "sweeps_fallback_share_of_env_steps": float(sweep_tot.double().sum().item()) / (n_env * args.steps),
                               "efc_overflow_envs": int(sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(sim.field(S.F_FAIL).sum().item())}}
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     print(json.dumps(out))

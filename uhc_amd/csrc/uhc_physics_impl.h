@@ -1828,78 +1828,125 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
             }
             wsync();
         }
-    bool c0 = v0 && S[L.rowF + r0] > 0.0, c1 = v1 && S[L.rowF + r1] > 0.0;
-    int iters = 0;
-    for (int outer = 0; outer < UHC_WS_MAXIT; outer++) {
-        // ---- compact the working set into the lanes (row order kept)
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1), below = (1ull << LANE) - 1ull;
-        const int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
-        if (nC > UHC_WAVE) return -1;
-        if (nC == 0) {  // no candidate: f = 0 is optimal iff b >= 0 everywhere
-            c0 = v0 && S[L.rowB + r0] < 0.0; c1 = v1 && S[L.rowB + r1] < 0.0;
-            if (!wave_or(c0 || c1)) {
-                if (v0) S[L.rowF + r0] = 0.0;
-                if (v1) S[L.rowF + r1] = 0.0;
-                for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
-                wsync();
-                return iters;
-            }
-            continue;
+    // ---- islands: kinematic trees that share no contact row have independent QPs (A is block diagonal), so each island gets its own
+    //      working set of <= 64 rows: a humanoid and four boxes resting beside it are five small solves, not one of 130 rows.
+    //      Tree label = root body id; a dense row (two bodies) merges the labels of its two trees (lane 0, a handful of rows).
+    int* label = list + UHC_WAVE;  // [nbody] island label of every tree root
+    if (LANE < T.nbody) label[LANE] = LANE;
+    wsync();
+    if (LANE == 0)
+        for (int k = 0; k < nslot; k++) {
+            const RowMisc rm = RM[NI[4 + k]];
+            const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
+            int a = T.body_rootid[(int)C[19]], b = T.body_rootid[(int)C[20]];
+            while (label[a] != a) a = label[a];
+            while (label[b] != b) b = label[b];
+            if (a != b) label[max(a, b)] = min(a, b);
         }
-        if (c0) list[__builtin_popcountll(m0 & below)] = r0;
-        if (c1) list[n0 + __builtin_popcountll(m1 & below)] = r1;
-        if (LANE < nslot) SLg[LANE] = -1;
-        wsync();
-        const bool valid = LANE < nC;
-        const int r = valid ? list[LANE] : 0;
-        FastRow row;
-        RowMisc rm = {0, 0, 0, 0};
-        if (valid) rm = RM[r];
-        const bool two = valid && (rm.type & ROW_TWO) != 0;
-        row.two = two ? (rm.type >> 8) : -1;
-        row.type = valid ? RTYPE(rm.type) : 0;
-        row.last = (valid && !two) ? rm.last : (valid ? -1 : 0);
-        row.len = (valid && !two) ? T.dof_depth[rm.last] + 1 : 0;
-        row.yoff = r * YS;
-        row.R = valid ? S[L.rowR + r] : 1.0; row.b = valid ? S[L.rowB + r] : 0.0; row.f = 0.0; row.floss = 0.0; row.diag = 1.0;
-        if (two) SLg[row.two] = LANE;
-        double Y[UHC_YM];
-        static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value;
-            Y[q] = q < row.len ? S[L.Y + r * YS + q] : 0.0;
-        });
-        wsync();
-        const int it = k_pgs_fast<false, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum f Yhat
-        iters += it > 0 ? it : 1;
-        // ---- forces back to the rows, y on the rows outside C
-        if (v0) S[L.rowF + r0] = 0.0;
-        if (v1) S[L.rowF + r1] = 0.0;
-        wsync();
-        if (valid) S[L.rowF + r] = row.f;
-        wsync();
-        bool viol[2] = {false, false}, keep[2] = {false, false};
-        for (int h = 0; h < 2; h++) {
-            const int rr = h ? r1 : r0;
-            if (!(h ? v1 : v0)) continue;
-            const bool inC = h ? c1 : c0;
-            if (inC) { keep[h] = S[L.rowF + rr] > 0.0; continue; }
-            const RowMisc q = RM[rr];
-            double y = S[L.rowB + rr];
-            if (q.type & ROW_TWO) {
-                const double* D = S + L.dense + (q.type >> 8) * A.nvp;
-                for (int i = 0; i < T.nv; i++) y = fma(D[i], z[i], y);
-            } else {
-                const int len = T.dof_depth[q.last] + 1;
-                const short* anc = T.dof_anc + q.last * YS;
-                for (int k = 0; k < len; k++) y = fma(S[L.Y + rr * YS + k], z[anc[k]], y);
-            }
-            viol[h] = y < 0.0;
-        }
-        if (!wave_or(viol[0] || viol[1])) return iters;  // KKT holds on every row: optimum
-        c0 = keep[0] || viol[0]; c1 = keep[1] || viol[1];
-        wsync();
+    wsync();
+    int isl[2] = {-1, -1};
+    for (int h = 0; h < 2; h++) {
+        const int rr = h ? r1 : r0;
+        if (!(h ? v1 : v0)) continue;
+        const RowMisc rm = RM[rr];
+        int a;
+        if (rm.type & ROW_TWO) a = T.body_rootid[(int)S[L.con + rm.aux * UHC_CON_STRIDE + 20]];
+        else a = T.dof_rootid[rm.last];
+        while (label[a] != a) a = label[a];
+        isl[h] = a;
     }
-    return -1;
+    double* ztot = S + L.vec;
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] = 0.0;
+    const bool f0pos = v0 && S[L.rowF + r0] > 0.0, f1pos = v1 && S[L.rowF + r1] > 0.0;
+    int iters = 0;
+    unsigned long long todo = 0ull;  // island labels present (nbody <= 64)
+    for (int h = 0; h < 2; h++) {
+#pragma unroll 1
+        for (int b = 1; b < T.nbody; b++) todo |= __builtin_amdgcn_ballot_w64(isl[h] == b) ? (1ull << b) : 0ull;
+    }
+    while (todo) {
+        const int I = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const bool in0 = isl[0] == I, in1 = isl[1] == I;
+        bool c0 = in0 && f0pos, c1 = in1 && f1pos, done = false;
+        for (int outer = 0; outer < UHC_WS_MAXIT && !done; outer++) {
+            // ---- compact the island's working set into the lanes (row order kept)
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1), below = (1ull << LANE) - 1ull;
+            const int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
+            if (nC > UHC_WAVE) return -1;
+            if (nC == 0) {  // no candidate: f = 0 is optimal on this island iff b >= 0 on its rows
+                c0 = in0 && S[L.rowB + r0] < 0.0; c1 = in1 && S[L.rowB + r1] < 0.0;
+                if (!wave_or(c0 || c1)) {
+                    if (in0) S[L.rowF + r0] = 0.0;
+                    if (in1) S[L.rowF + r1] = 0.0;
+                    wsync();
+                    done = true;
+                }
+                continue;
+            }
+            if (c0) list[__builtin_popcountll(m0 & below)] = r0;
+            if (c1) list[n0 + __builtin_popcountll(m1 & below)] = r1;
+            if (LANE < nslot) SLg[LANE] = -1;
+            wsync();
+            const bool valid = LANE < nC;
+            const int r = valid ? list[LANE] : 0;
+            FastRow row;
+            RowMisc rm = {0, 0, 0, 0};
+            if (valid) rm = RM[r];
+            const bool two = valid && (rm.type & ROW_TWO) != 0;
+            row.two = two ? (rm.type >> 8) : -1;
+            row.type = valid ? RTYPE(rm.type) : 0;
+            row.last = (valid && !two) ? rm.last : (valid ? -1 : 0);
+            row.len = (valid && !two) ? T.dof_depth[rm.last] + 1 : 0;
+            row.yoff = r * YS;
+            row.R = valid ? S[L.rowR + r] : 1.0; row.b = valid ? S[L.rowB + r] : 0.0; row.f = 0.0; row.floss = 0.0; row.diag = 1.0;
+            if (two) SLg[row.two] = LANE;
+            double Y[UHC_YM];
+            static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                Y[q] = q < row.len ? S[L.Y + r * YS + q] : 0.0;
+            });
+            wsync();
+            const int it = k_pgs_fast<false, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum_C f Yhat
+            iters += it > 0 ? it : 1;
+            // ---- forces back to the island's rows, y on its rows outside C
+            if (in0) S[L.rowF + r0] = 0.0;
+            if (in1) S[L.rowF + r1] = 0.0;
+            wsync();
+            if (valid) S[L.rowF + r] = row.f;
+            wsync();
+            bool viol[2] = {false, false}, keep[2] = {false, false};
+            for (int h = 0; h < 2; h++) {
+                const int rr = h ? r1 : r0;
+                if (!(h ? in1 : in0)) continue;
+                const bool inC = h ? c1 : c0;
+                if (inC) { keep[h] = S[L.rowF + rr] > 0.0; continue; }
+                const RowMisc q = RM[rr];
+                double y = S[L.rowB + rr];
+                if (q.type & ROW_TWO) {
+                    const double* D = S + L.dense + (q.type >> 8) * A.nvp;
+                    for (int i = 0; i < T.nv; i++) y = fma(D[i], z[i], y);
+                } else {
+                    const int len = T.dof_depth[q.last] + 1;
+                    const short* anc = T.dof_anc + q.last * YS;
+                    for (int k = 0; k < len; k++) y = fma(S[L.Y + rr * YS + k], z[anc[k]], y);
+                }
+                viol[h] = y < 0.0;
+            }
+            if (!wave_or(viol[0] || viol[1])) {  // KKT holds on every row of the island: its optimum
+                for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] += z[i];
+                wsync();
+                done = true;
+            } else {
+                c0 = keep[0] || viol[0]; c1 = keep[1] || viol[1];
+                wsync();
+            }
+        }
+        if (!done) return -1;
+    }
+    for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = ztot[i];
+    wsync();
+    return iters;
 }
 
 // ------------------------------------------------------------------ mj_forward
