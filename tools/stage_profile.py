@@ -35,24 +35,51 @@ if __name__ == "__main__":
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     import dataclasses
     model = dataclasses.replace(S.load_asset_model(), solver=int(os.environ.get("SOLVER", "0")), iterations=int(os.environ.get("CAP", "100")))
-    ctrl = S.make_ctrl(model)
     z = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))
     rng = np.random.default_rng(1)
-    qpos = np.tile(z["qpos"], (n_env, 1))
-    qpos[:, 7:] += rng.normal(scale=0.05, size=(n_env, model.nu))
-    qvel = rng.normal(scale=0.1, size=(n_env, model.nv))
-    actions = rng.normal(scale=np.exp(-2.3), size=(8, n_env, ctrl.action_dim))
+    scene = os.environ.get("MODEL", "copycat")  # copycat | selfcol (body-body collisions on) | ball_objects (bench.py --workload ball_objects)
+    if scene == "ball_objects":
+        from tests.helpers import box_triangles
+        from uhc_amd.model.mjcf import add_free_bodies, ball_variant, hinge_to_ball_qpos, self_collision_variant
+        base = model
+        K = int(os.environ.get("OBJECTS", "4"))
+        ang = np.random.default_rng(11).uniform(0, 2 * np.pi, size=K)
+        poses = np.stack([np.r_[-0.15 + 0.75 * np.cos(a), -0.05 + 0.75 * np.sin(a), 0.3 + 0.45 * k, 1, 0, 0, 0] for k, a in enumerate(ang)]) if K else np.zeros((0, 7))
+        hb = ball_variant(base, damping=5.0)
+        model = self_collision_variant(hb)
+        if K:
+            model = add_free_bodies(model, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
+        model = dataclasses.replace(model, solver=base.solver, iterations=base.iterations)
+        ctrl = S.make_ctrl(base, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+        qpos = np.tile(model.qpos0, (n_env, 1))
+        for e in range(n_env):
+            qh = z["qpos"].copy()
+            qh[7:] += rng.normal(scale=0.1, size=69)
+            qpos[e, :99] = hinge_to_ball_qpos(base, hb, qh)
+        qvel = np.zeros((n_env, model.nv))
+        qvel[:, :75] = rng.normal(scale=0.2, size=(n_env, 75))
+        actions = 0.1 * rng.normal(size=(8, n_env, ctrl.action_dim))
+    else:
+        if scene == "selfcol":
+            from uhc_amd.model.mjcf import self_collision_variant
+            model = dataclasses.replace(self_collision_variant(model), solver=model.solver, iterations=model.iterations)
+        ctrl = S.make_ctrl(model)
+        qpos = np.tile(z["qpos"], (n_env, 1))
+        qpos[:, 7:] += rng.normal(scale=0.05, size=(n_env, model.nu))
+        qvel = rng.normal(scale=0.1, size=(n_env, model.nv))
+        actions = rng.normal(scale=np.exp(-2.3), size=(8, n_env, ctrl.action_dim))
     b = S.SimBatch(model, ctrl, n_env)
     b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
     b.sync()
     b.field(S.F_STAGE_PROF).zero_()
     a = torch.from_numpy(actions).cuda()
-    tb = torch.from_numpy(np.ascontiguousarray(qpos[:, 7:])).cuda()
+    tb = torch.from_numpy(np.ascontiguousarray(qpos[:, 7:7 + 69])).cuda()
     for t in range(steps):
         b.simulate(a[t % 8], tb)
     b.sync()
     p = b.field(S.F_STAGE_PROF).cpu().numpy().astype(np.float64) / steps
     tot = p.sum(1)
+    print(f"scene={scene} general_share={(b.field(S.F_REDO) != 0).float().mean().item():.2f} ", end="")
     print(f"n_env={n_env} steps={steps}: mean cycles per env-step = {tot.mean():.0f} (max {tot.max():.0f}); nefc mean {b.field(S.F_NEFC).float().mean().item():.1f} iters mean {b.field(S.F_SOLVER_ITER).float().mean().item():.1f}")
     for k, nm in enumerate(NAMES):
         if p[:, k].mean() > 0:

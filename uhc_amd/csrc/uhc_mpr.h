@@ -51,10 +51,21 @@ __device__ __forceinline__ V3 hull_support(const CcdHull& H, const V3& dir, doub
     const double ly = H.R[1] * dir.x + H.R[4] * dir.y + H.R[7] * dir.z;
     const double lz = H.R[2] * dir.x + H.R[5] * dir.y + H.R[8] * dir.z;
     double bd = -1e300, bx = 0, by = 0, bz = 0;
-    for (int v = 0; v < H.vn; v++) {
-        const double x = H.vert[3 * v], y = H.vert[3 * v + 1], z = H.vert[3 * v + 2];
-        const double s = lx * x + ly * y + lz * z;
-        if (s > bd) { bd = s; bx = x; by = y; bz = z; }
+    // four vertices per trip: their twelve loads are issued together (the vertices sit in L2 / L1, a load costs hundreds of cycles and a
+    // one-vertex loop would pay that per vertex); the tail repeats the last vertex, which a strict `>` never selects again
+    const int last = H.vn - 1;
+    for (int v = 0; v < H.vn; v += 4) {
+        double c[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 3 * min(v + k, last);
+            c[k][0] = H.vert[i]; c[k][1] = H.vert[i + 1]; c[k][2] = H.vert[i + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double s = lx * c[k][0] + ly * c[k][1] + lz * c[k][2];
+            if (s > bd) { bd = s; bx = c[k][0]; by = c[k][1]; bz = c[k][2]; }
+        }
     }
     const double hm = 0.5 * margin;
     return v3((H.R[0] * bx + H.R[1] * by + H.R[2] * bz) + (H.p.x + dir.x * hm), (H.R[3] * bx + H.R[4] * by + H.R[5] * bz) + (H.p.y + dir.y * hm),

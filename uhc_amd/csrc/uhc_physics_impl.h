@@ -863,44 +863,69 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
     }
     // ---- convex-convex pairs (hull vs hull): one candidate pair per lane through bounding-sphere cull and MPR (uhc_mpr.h); the hits
     //      become contacts in pair order.  Contact = (pos, normal from geom 1 to geom 2, dist = margin - depth) [MJ-ext mjc_Convex].
-    if constexpr (DENSE)
-    for (int p0 = 0; p0 < T.ncpair; p0 += UHC_WAVE) {
-        const int p = p0 + LANE;
-        bool hit = false;
-        int g1 = 0, g2 = 0, b1 = 0, b2 = 0;
-        double depth = 0, margin = 0, gap = 0;
-        V3 dir = v3(0, 0, 0), pos = v3(0, 0, 0);
-        if (p < T.ncpair) {
-            g1 = T.cpair_g1[p]; g2 = T.cpair_g2[p];
-            b1 = T.geom_bodyid[g1]; b2 = T.geom_bodyid[g2];
-            CcdHull H1, H2;
-            for (int k = 0; k < 9; k++) { H1.R[k] = S[L.xmat + 9 * b1 + k]; H2.R[k] = S[L.xmat + 9 * b2 + k]; }
-            H1.p = v3(S[L.xpos + 3 * b1], S[L.xpos + 3 * b1 + 1], S[L.xpos + 3 * b1 + 2]);
-            H2.p = v3(S[L.xpos + 3 * b2], S[L.xpos + 3 * b2 + 1], S[L.xpos + 3 * b2 + 2]);
-            H1.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g1]; H1.vn = T.geom_vertnum[g1];
-            H2.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g2]; H2.vn = T.geom_vertnum[g2];
-            double ce1[3], ce2[3], t1[3], t2[3];
-            for (int k = 0; k < 3; k++) { ce1[k] = mb[A.o.geom_center + 3 * g1 + k]; ce2[k] = mb[A.o.geom_center + 3 * g2 + k]; }
-            mat_vec(t1, H1.R, ce1); mat_vec(t2, H2.R, ce2);
-            const V3 c1 = v3(t1[0] + H1.p.x, t1[1] + H1.p.y, t1[2] + H1.p.z), c2 = v3(t2[0] + H2.p.x, t2[1] + H2.p.y, t2[2] + H2.p.z);
-            margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
-            gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
-            const double bound = mb[A.o.geom_rbound + g1] + mb[A.o.geom_rbound + g2] + margin;
-            const V3 dc = c1 - c2;
-            if (!(vdot(dc, dc) > bound * bound)) {
+    if constexpr (DENSE) {
+        // phase 1: bounding-sphere cull of every pair, survivors compacted (in pair order) into a list -- phase 2 then needs one
+        // MPR pass for the 10-40 candidates of a typical pose instead of one per block of 64 pairs
+        int* cand = (int*)(S + L.rowMisc);  // free until the rows are enumerated
+        constexpr int CAND_CAP = 256;
+        int ncand = 0;
+        for (int p0 = 0; p0 < T.ncpair; p0 += UHC_WAVE) {
+            const int p = p0 + LANE;
+            bool c = false;
+            if (p < T.ncpair) {
+                const int g1 = T.cpair_g1[p], g2 = T.cpair_g2[p], b1 = T.geom_bodyid[g1], b2 = T.geom_bodyid[g2];
+                double ce1[3], ce2[3], t1[3], t2[3], R1[9], R2[9];
+                for (int k = 0; k < 9; k++) { R1[k] = S[L.xmat + 9 * b1 + k]; R2[k] = S[L.xmat + 9 * b2 + k]; }
+                for (int k = 0; k < 3; k++) { ce1[k] = mb[A.o.geom_center + 3 * g1 + k]; ce2[k] = mb[A.o.geom_center + 3 * g2 + k]; }
+                mat_vec(t1, R1, ce1); mat_vec(t2, R2, ce2);
+                double d2 = 0;
+                for (int k = 0; k < 3; k++) { const double d = (t1[k] + S[L.xpos + 3 * b1 + k]) - (t2[k] + S[L.xpos + 3 * b2 + k]); d2 += d * d; }
+                const double bound = mb[A.o.geom_rbound + g1] + mb[A.o.geom_rbound + g2] + fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                c = !(d2 > bound * bound);
+            }
+            const unsigned long long cm = __ballot(c);
+            const int rank = ncand + __popcll(cm & ((1ull << LANE) - 1ull));
+            if (c && rank < CAND_CAP) cand[rank] = p;
+            ncand += (int)__popcll(cm);
+        }
+        if (ncand > CAND_CAP) { *overflow |= FAST ? 1 : 2; ncand = CAND_CAP; }
+        wsync();
+        // phase 2: MPR, one candidate pair per lane
+        for (int c0 = 0; c0 < ncand; c0 += UHC_WAVE) {
+            const int ci = c0 + LANE;
+            bool hit = false;
+            int g1 = 0, g2 = 0, b1 = 0, b2 = 0;
+            double depth = 0, margin = 0, gap = 0;
+            V3 dir = v3(0, 0, 0), pos = v3(0, 0, 0);
+            if (ci < ncand) {
+                const int p = cand[ci];
+                g1 = T.cpair_g1[p]; g2 = T.cpair_g2[p];
+                b1 = T.geom_bodyid[g1]; b2 = T.geom_bodyid[g2];
+                CcdHull H1, H2;
+                for (int k = 0; k < 9; k++) { H1.R[k] = S[L.xmat + 9 * b1 + k]; H2.R[k] = S[L.xmat + 9 * b2 + k]; }
+                H1.p = v3(S[L.xpos + 3 * b1], S[L.xpos + 3 * b1 + 1], S[L.xpos + 3 * b1 + 2]);
+                H2.p = v3(S[L.xpos + 3 * b2], S[L.xpos + 3 * b2 + 1], S[L.xpos + 3 * b2 + 2]);
+                H1.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g1]; H1.vn = T.geom_vertnum[g1];
+                H2.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g2]; H2.vn = T.geom_vertnum[g2];
+                double ce1[3], ce2[3], t1[3], t2[3];
+                for (int k = 0; k < 3; k++) { ce1[k] = mb[A.o.geom_center + 3 * g1 + k]; ce2[k] = mb[A.o.geom_center + 3 * g2 + k]; }
+                mat_vec(t1, H1.R, ce1); mat_vec(t2, H2.R, ce2);
+                const V3 c1 = v3(t1[0] + H1.p.x, t1[1] + H1.p.y, t1[2] + H1.p.z), c2 = v3(t2[0] + H2.p.x, t2[1] + H2.p.y, t2[2] + H2.p.z);
+                margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
                 hit = mpr_penetration(H1, H2, c1, c2, margin, depth, dir, pos);
                 hit = hit && !(dir.x == 0 && dir.y == 0 && dir.z == 0);
             }
+            const unsigned long long hm = __ballot(hit);
+            const int rank = __popcll(hm & ((1ull << LANE) - 1ull));
+            if (hit && ncon + rank < MAXCON_OF(FAST)) {
+                const double cp[3] = {pos.x, pos.y, pos.z}, nn[3] = {dir.x, dir.y, dir.z};
+                k_write_contact<FAST>(A, mb, S, ncon + rank, g1, g2, b1, b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - depth, margin, gap);
+            }
+            const int want = ncon + (int)__popcll(hm);
+            if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;
+            ncon = min(MAXCON_OF(FAST), want);
         }
-        const unsigned long long hm = __ballot(hit);
-        const int rank = __popcll(hm & ((1ull << LANE) - 1ull));
-        if (hit && ncon + rank < MAXCON_OF(FAST)) {
-            const double cp[3] = {pos.x, pos.y, pos.z}, nn[3] = {dir.x, dir.y, dir.z};
-            k_write_contact<FAST>(A, mb, S, ncon + rank, g1, g2, b1, b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - depth, margin, gap);
-        }
-        const int want = ncon + (int)__popcll(hm);
-        if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;
-        ncon = min(MAXCON_OF(FAST), want);
     }
     wsync();
     return ncon;
