@@ -16,7 +16,7 @@ SYMBOLS = [
     "uhc_last_error", "uhc_abi_version", "uhc_model_create", "uhc_model_free", "uhc_model_nM",
     "uhc_batch_create", "uhc_batch_free", "uhc_batch_set_stream", "uhc_batch_sync", "uhc_batch_set_rfc_scale",
     "uhc_batch_field", "uhc_batch_set_state", "uhc_batch_simulate", "uhc_batch_forward", "uhc_batch_set_timing",
-    "uhc_batch_kernel_time", "uhc_batch_set_overflow_mode", "uhc_batch_set_solver",
+    "uhc_batch_kernel_time", "uhc_batch_set_overflow_mode", "uhc_batch_set_solver", "uhc_batch_set_kernel_path",
     "uhc_env_create", "uhc_env_free", "uhc_env_obs_dim", "uhc_env_field", "uhc_env_set_bank", "uhc_env_assign",
     "uhc_env_reset", "uhc_env_step", "uhc_env_set_next", "uhc_env_auto_reset", "uhc_env_set_clip_models", "uhc_env_set_end_reward",
 ]
@@ -58,6 +58,7 @@ def lib():
     L.uhc_batch_set_timing.argtypes = [P, C.c_int32]
     L.uhc_batch_set_overflow_mode.argtypes = [P, C.c_int32]
     L.uhc_batch_set_solver.argtypes = [P, C.c_int32, C.c_int32]
+    L.uhc_batch_set_kernel_path.argtypes = [P, C.c_int32]
     L.uhc_batch_kernel_time.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.uhc_env_create.argtypes = [P, C.POINTER(UhcEnvDesc), C.POINTER(P)]
     L.uhc_env_free.argtypes = [P]

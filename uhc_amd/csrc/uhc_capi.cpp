@@ -132,6 +132,7 @@ struct UhcBatch {
     KernelArgs A;
     size_t lds_bytes = 0, lds_bytes_fast = 0;
     bool use_fast = true;
+    bool general_only = false;
     std::vector<void*> allocs;
     int nM = 0;
     int* reset_mask = nullptr;
@@ -394,6 +395,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.dense = carve(A.ndense_g * A.nvp);
     L.dcol = carve(A.ndense_g * UHC_WAVE);  // Delassus columns of the dense rows within the working set (as in the fast layout)
     L.dsc = carve(A.ndense_g * 4);          // (vel, jas, jaw, |Yhat|^2) of every dense row
+    // MPR walks hull vertices once per support call and lane: staged in LDS they cost an LDS read instead of an L2 round trip.  The rows'
+    // storage (Y .. rowDa, contiguous) is not written before the collision pass is over: the vertices borrow it every substep.
+    A.vstage_g = (T.ncpair > 0 && 3 * d.nmeshvert <= UHC_MAXEFC * YS + 5 * UHC_MAXEFC) ? L.Y : -1;
     L.total = off;
     b->lds_bytes = (size_t)off * sizeof(double);
     if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }
@@ -439,6 +443,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         if (ycap < need1) ycap = need1;
         if (ycap < 8 * YS) ycap = 8 * YS;
         A.ycap = ycap;
+        A.vstage_f = (T.ncpair > 0 && 3 * d.nmeshvert <= A.ndense_f * A.nvp + A.ndense_f * UHC_WAVE + ycap) ? F.dense : -1;  // dense, dcol, Y are contiguous
         off += ycap;
         F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.Y;  // unused by the fast kernel
         F.total = off;
@@ -585,6 +590,11 @@ extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {
     b->A.c.rfc_scale = s;
     return 0;
 }
+extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t general_only) {
+    if (!b) return fail("uhc_batch_set_kernel_path: null batch");
+    b->general_only = general_only != 0;
+    return 0;
+}
 extern "C" int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t iterations) {
     if (!b || (solver != 0 && solver != 1)) return fail("uhc_batch_set_solver: solver must be 0 (sweeps) or 1 (active set)");
     b->A.t.solver = solver;
@@ -605,7 +615,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (b->ev_free.empty()) { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
         else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
     }
-    if (b->use_fast) {
+    if (b->use_fast && !b->general_only) {
         HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env, b->stream));
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
@@ -674,7 +684,8 @@ extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, c
     HIP_OK(uhc_launch_set_state_masked(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, b->n_env, d_select, d_qpos, d_qvel, b->reset_mask, b->stream));
     // only the kinematics now (the reset observation reads body poses); the dynamics part of sim.forward() runs at the head of the
     // env's next step kernel (DevState::fresh), which saves a forward-pass-long launch per control step
-    HIP_OK(uhc_launch_step(2, b->use_fast ? 1 : 0, &b->A, nullptr, nullptr, b->reset_mask, b->use_fast ? b->lds_bytes_fast : b->lds_bytes, b->stream));
+    const bool kf = b->use_fast && !b->general_only;
+    HIP_OK(uhc_launch_step(2, kf ? 1 : 0, &b->A, nullptr, nullptr, b->reset_mask, kf ? b->lds_bytes_fast : b->lds_bytes, b->stream));
     return 0;
 }
 

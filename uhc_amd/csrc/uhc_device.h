@@ -99,6 +99,8 @@ struct KernelArgs {
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int ndense_f, ndense_g;  // dense-row slots of the fast / general layout (0: the model has no two-body contacts)
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
+    int vstage_f, vstage_g;  // LDS offset (doubles) where the hull vertices are staged for the MPR pass of every substep, or -1: they do not fit the
+                             // region that is free at collision time (the not-yet-written constraint rows) and MPR reads them from L2
     DevCtrl c;
     DevState s;
     int n_env;

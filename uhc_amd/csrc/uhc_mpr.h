@@ -43,10 +43,11 @@ __device__ __forceinline__ CcdSup sup_sel(bool c, const CcdSup& a, const CcdSup&
 }
 
 // one convex hull posed in the world: rotation (row major), position, vertex range of the model blob
-struct CcdHull { double R[9]; V3 p; const double* vert; int vn; };
+struct CcdHull { double R[9]; V3 p; int voff, vn; };  // voff: offset (doubles) of the hull's first vertex in the vertex array
 
 // hull vertex with the largest projection on `dir` (first maximum wins), in the world, pushed out by margin / 2 along dir
-__device__ __forceinline__ V3 hull_support(const CcdHull& H, const V3& dir, double margin) {
+__device__ __forceinline__ V3 hull_support(const double* __restrict__ VB, const CcdHull& H, const V3& dir, double margin) {
+    const double* vert = VB + H.voff;
     const double lx = H.R[0] * dir.x + H.R[3] * dir.y + H.R[6] * dir.z;  // R^T dir
     const double ly = H.R[1] * dir.x + H.R[4] * dir.y + H.R[7] * dir.z;
     const double lz = H.R[2] * dir.x + H.R[5] * dir.y + H.R[8] * dir.z;
@@ -59,7 +60,7 @@ __device__ __forceinline__ V3 hull_support(const CcdHull& H, const V3& dir, doub
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = 3 * min(v + k, last);
-            c[k][0] = H.vert[i]; c[k][1] = H.vert[i + 1]; c[k][2] = H.vert[i + 2];
+            c[k][0] = vert[i]; c[k][1] = vert[i + 1]; c[k][2] = vert[i + 2];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -71,10 +72,10 @@ __device__ __forceinline__ V3 hull_support(const CcdHull& H, const V3& dir, doub
     return v3((H.R[0] * bx + H.R[1] * by + H.R[2] * bz) + (H.p.x + dir.x * hm), (H.R[3] * bx + H.R[4] * by + H.R[5] * bz) + (H.p.y + dir.y * hm),
               (H.R[6] * bx + H.R[7] * by + H.R[8] * bz) + (H.p.z + dir.z * hm));
 }
-__device__ __forceinline__ CcdSup ccd_support(const CcdHull& H1, const CcdHull& H2, const V3& dir, double margin) {
+__device__ __forceinline__ CcdSup ccd_support(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& dir, double margin) {
     CcdSup s;
-    s.v1 = hull_support(H1, dir, margin);
-    s.v2 = hull_support(H2, neg(dir), margin);
+    s.v1 = hull_support(VB, H1, dir, margin);
+    s.v2 = hull_support(VB, H2, neg(dir), margin);
     s.v = s.v1 - s.v2;
     return s;
 }
@@ -143,7 +144,7 @@ __device__ __forceinline__ V3 find_pos(const CcdSup& p0, const CcdSup& p1, const
 
 // true: the hulls (each inflated by margin / 2) penetrate; depth, dir (from hull 1 to hull 2, zero if undefined) and pos are set.
 // c1, c2: the hulls' centres (MuJoCo: geom_xpos = the mesh's centre of mass).
-__device__ __forceinline__ bool mpr_penetration(const CcdHull& H1, const CcdHull& H2, const V3& c1, const V3& c2, double margin, double& depth,
+__device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& c1, const V3& c2, double margin, double& depth,
                                                 V3& dir, V3& pos) {
     CcdSup p0, p1, p2, p3, v4;
     double dt;
@@ -151,7 +152,7 @@ __device__ __forceinline__ bool mpr_penetration(const CcdHull& H1, const CcdHull
     p0.v1 = c1; p0.v2 = c2; p0.v = c1 - c2;
     if (ccd_eq(p0.v.x, 0) && ccd_eq(p0.v.y, 0) && ccd_eq(p0.v.z, 0)) p0.v.x += UHC_CCD_EPS * 10;
     dir = vnorm(neg(p0.v));
-    p1 = ccd_support(H1, H2, dir, margin);
+    p1 = ccd_support(VB, H1, H2, dir, margin);
     dt = vdot(p1.v, dir);
     if (ccd_zero(dt) || dt < 0) return false;
     dir = vcross(p0.v, p1.v);
@@ -162,13 +163,13 @@ __device__ __forceinline__ bool mpr_penetration(const CcdHull& H1, const CcdHull
         return true;
     }
     dir = vnorm(dir);
-    p2 = ccd_support(H1, H2, dir, margin);
+    p2 = ccd_support(VB, H1, H2, dir, margin);
     dt = vdot(p2.v, dir);
     if (ccd_zero(dt) || dt < 0) return false;
     dir = vnorm(vcross(p1.v - p0.v, p2.v - p0.v));
     if (vdot(dir, p0.v) > 0) { const CcdSup t = p1; p1 = p2; p2 = t; dir = neg(dir); }
     for (;;) {
-        v4 = ccd_support(H1, H2, dir, margin);
+        v4 = ccd_support(VB, H1, H2, dir, margin);
         dt = vdot(v4.v, dir);
         if (ccd_zero(dt) || dt < 0) return false;
         bool cont = false;
@@ -186,7 +187,7 @@ __device__ __forceinline__ bool mpr_penetration(const CcdHull& H1, const CcdHull
         dir = portal_dir(p1, p2, p3);
         dt = vdot(dir, p1.v);
         if (ccd_zero(dt) || dt > 0) break;  // the portal encapsulates the origin
-        v4 = ccd_support(H1, H2, dir, margin);
+        v4 = ccd_support(VB, H1, H2, dir, margin);
         dt = vdot(v4.v, dir);
         if (!(ccd_zero(dt) || dt > 0) || portal_reach_tolerance(p1, p2, p3, v4, dir)) return false;
         expand_portal(p0, p1, p2, p3, v4);
@@ -194,7 +195,7 @@ __device__ __forceinline__ bool mpr_penetration(const CcdHull& H1, const CcdHull
     // ---- findPenetr
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
-        v4 = ccd_support(H1, H2, dir, margin);
+        v4 = ccd_support(VB, H1, H2, dir, margin);
         if (portal_reach_tolerance(p1, p2, p3, v4, dir) || it > UHC_MPR_MAXIT) {
             V3 pd;
             depth = sqrt(point_tri_dist2(p1.v, p2.v, p3.v, pd));

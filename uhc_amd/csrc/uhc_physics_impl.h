@@ -889,6 +889,10 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             ncand += (int)__popcll(cm);
         }
         if (ncand > CAND_CAP) { *overflow |= FAST ? 1 : 2; ncand = CAND_CAP; }
+        // the hull vertices (body frame, model constants) into the LDS region the constraint rows will use after this pass
+        const int vstage = FAST ? A.vstage_f : A.vstage_g;
+        if (vstage >= 0 && ncand > 0)
+            for (int i = LANE; i < 3 * T.nmeshvert; i += UHC_WAVE) S[vstage + i] = mb[A.o.mesh_vert + i];
         wsync();
         // phase 2: MPR, one candidate pair per lane
         for (int c0 = 0; c0 < ncand; c0 += UHC_WAVE) {
@@ -905,15 +909,17 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 for (int k = 0; k < 9; k++) { H1.R[k] = S[L.xmat + 9 * b1 + k]; H2.R[k] = S[L.xmat + 9 * b2 + k]; }
                 H1.p = v3(S[L.xpos + 3 * b1], S[L.xpos + 3 * b1 + 1], S[L.xpos + 3 * b1 + 2]);
                 H2.p = v3(S[L.xpos + 3 * b2], S[L.xpos + 3 * b2 + 1], S[L.xpos + 3 * b2 + 2]);
-                H1.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g1]; H1.vn = T.geom_vertnum[g1];
-                H2.vert = mb + A.o.mesh_vert + 3 * T.geom_vertadr[g2]; H2.vn = T.geom_vertnum[g2];
+                H1.voff = 3 * T.geom_vertadr[g1]; H1.vn = T.geom_vertnum[g1];
+                H2.voff = 3 * T.geom_vertadr[g2]; H2.vn = T.geom_vertnum[g2];
                 double ce1[3], ce2[3], t1[3], t2[3];
                 for (int k = 0; k < 3; k++) { ce1[k] = mb[A.o.geom_center + 3 * g1 + k]; ce2[k] = mb[A.o.geom_center + 3 * g2 + k]; }
                 mat_vec(t1, H1.R, ce1); mat_vec(t2, H2.R, ce2);
                 const V3 c1 = v3(t1[0] + H1.p.x, t1[1] + H1.p.y, t1[2] + H1.p.z), c2 = v3(t2[0] + H2.p.x, t2[1] + H2.p.y, t2[2] + H2.p.z);
                 margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
                 gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
-                hit = mpr_penetration(H1, H2, c1, c2, margin, depth, dir, pos);
+                // two copies of the refinement so that each knows its address space at compile time (ds_read vs global_load)
+                if (vstage >= 0) hit = mpr_penetration(S + vstage, H1, H2, c1, c2, margin, depth, dir, pos);
+                else hit = mpr_penetration(mb + A.o.mesh_vert, H1, H2, c1, c2, margin, depth, dir, pos);
                 hit = hit && !(dir.x == 0 && dir.y == 0 && dir.z == 0);
             }
             const unsigned long long hm = __ballot(hit);
@@ -1889,17 +1895,32 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
 #pragma unroll 1
         for (int b = 1; b < T.nbody; b++) todo |= __builtin_amdgcn_ballot_w64(isl[h] == b) ? (1ull << b) : 0ull;
     }
+    bool nomerge = false;
     while (todo) {
-        const int I = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const bool in0 = isl[0] == I, in1 = isl[1] == I;
-        bool c0 = in0 && f0pos, c1 = in1 && f1pos, done = false;
+        // ---- next group: islands are independent, but every solve pays the fixed cost of a register-resident build, so small islands
+        //      share one (A is block diagonal across them by itself: rows of different trees have no common dofs).  Islands are packed
+        //      while their candidates fit 48 of the 64 lanes (room for violated rows to join); a group that overflows is split again.
+        unsigned long long G = 0ull, rest = todo;
+        int gcount = 0;
+        while (rest) {
+            const int I = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[0] == I && f0pos)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[1] == I && f1pos));
+            if (G == 0ull || (!nomerge && gcount + c <= 48)) { G |= 1ull << I; gcount += c; }
+        }
+        todo &= ~G;
+        const bool in0 = isl[0] >= 0 && ((G >> isl[0]) & 1ull), in1 = isl[1] >= 0 && ((G >> isl[1]) & 1ull);
+        bool c0 = in0 && f0pos, c1 = in1 && f1pos, done = false, split = false;
         for (int outer = 0; outer < UHC_WS_MAXIT && !done; outer++) {
-            // ---- compact the island's working set into the lanes (row order kept)
+            // ---- compact the group's working set into the lanes (row order kept)
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1), below = (1ull << LANE) - 1ull;
             const int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
-            if (nC > UHC_WAVE) return -1;
-            if (nC == 0) {  // no candidate: f = 0 is optimal on this island iff b >= 0 on its rows
+            if (nC > UHC_WAVE) {
+                if (__builtin_popcountll(G) == 1) return -1;
+                split = true;  // too many candidates for one solve: take the group's islands one at a time
+                break;
+            }
+            if (nC == 0) {  // no candidate: f = 0 is optimal on this group iff b >= 0 on its rows
                 c0 = in0 && S[L.rowB + r0] < 0.0; c1 = in1 && S[L.rowB + r1] < 0.0;
                 if (!wave_or(c0 || c1)) {
                     if (in0) S[L.rowF + r0] = 0.0;
@@ -1967,6 +1988,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
                 wsync();
             }
         }
+        if (split) { todo |= G; nomerge = true; continue; }
         if (!done) return -1;
     }
     for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = ztot[i];
