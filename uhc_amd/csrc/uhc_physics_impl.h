@@ -1612,13 +1612,22 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
                 constexpr int q = decltype(qc)::value;
                 acc = fma(Y[q], Dk[cdq[q]], acc);  // Y is zero past the row's own chain (and for dense rows)
             });
-            if (row.two >= 0) {
-                const double* Dm = S + L.dense + row.two * A.nvp;
-                double a2 = 0.0;
-                for (int i = 0; i < T.nv; i++) a2 = fma(Dm[i], Dk[i], a2);
-                acc = a2;
+            S[L.dcol + k * UHC_WAVE + LANE] = valid ? acc : 0.0;  // (dense lanes: 0 for now)
+        }
+        wsync();
+        // dense x dense entries: one wave reduction per pair of slots (lane = dof), written to both lanes' columns
+        for (int k = 0; k < nslot; k++) {
+            const int lk = __builtin_amdgcn_readfirstlane(SL[k]);
+            if ((unsigned)lk >= (unsigned)nefc) continue;
+            const double* Dk = S + L.dense + k * A.nvp;
+            const double dk0 = LC.v0 ? Dk[LANE] : 0.0, dk1 = LC.v1 ? Dk[LANE + UHC_WAVE] : 0.0;
+            for (int m = 0; m <= k; m++) {
+                const int lm = __builtin_amdgcn_readfirstlane(SL[m]);
+                if ((unsigned)lm >= (unsigned)nefc) continue;
+                const double* Dm = S + L.dense + m * A.nvp;
+                const double v = wave_sum(dk0 * (LC.v0 ? Dm[LANE] : 0.0) + dk1 * (LC.v1 ? Dm[LANE + UHC_WAVE] : 0.0));
+                if (LANE == 0) { S[L.dcol + k * UHC_WAVE + lm] = v; S[L.dcol + m * UHC_WAVE + lk] = v; }
             }
-            S[L.dcol + k * UHC_WAVE + LANE] = valid ? acc : 0.0;
         }
         wsync();
     }
@@ -1806,8 +1815,8 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // rarely more than 64.  Solve the QP restricted to a working set C of <= 64 rows exactly (compacted into the lanes, same code as the
 // fast kernel: A_CC in registers, block principal pivoting), evaluate y = A f + b on the rows outside C (matrix-free: Yhat_r . z + b_r),
 // add the violated ones (y < 0), drop the rows of C that ended without a force, repeat.  Every new working set contains the support of
-// the current f, so the dual cost falls strictly from one round to the next: no cycling.  C starts as the rows that 8 Gauss-Seidel
-// sweeps from f = 0 leave with a force.  Returns the number of factorisations, or -1 (friction-loss rows, more than 64 candidates, no
+// the current f, so the dual cost falls strictly from one round to the next: no cycling.  C starts as the rows with a positive
+// warm-start force.  Returns the number of factorisations, or -1 (friction-loss rows, more than 64 candidates, no
 // convergence in UHC_WS_MAXIT rounds): the caller then runs the sweeps.
 #define UHC_WS_MAXIT 12
 template <bool DENSE>
@@ -1824,41 +1833,11 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
     const int r0 = LANE, r1 = LANE + UHC_WAVE;
     const bool v0 = r0 < nefc, v1 = r1 < nefc;
     if (wave_or((v0 && RTYPE(RM[r0].type) == ROW_FRICTION) || (v1 && RTYPE(RM[r1].type) == ROW_FRICTION))) return -1;
-    // ---- 8 Gauss-Seidel sweeps from f = 0 (matrix-free, as k_pgs but without warm start / cost bookkeeping)
-    if (v0) S[L.rowF + r0] = 0.0;
-    if (v1) S[L.rowF + r1] = 0.0;
+    // ---- first candidates: the rows whose warm-start force (k_rows: the force the previous substep's acceleration implies) is positive.
+    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free (the 8 matrix-free
+    //      Gauss-Seidel sweeps a cold start would need cost as much as three register-resident solves).  Any start gives the same optimum.
     for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
     wsync();
-    for (int it = 0; it < UHC_AS_PRESWEEPS; it++)
-        for (int r = 0; r < nefc; r++) {
-            const RowMisc rm = RM[r];
-            const bool two = (rm.type & ROW_TWO) != 0;
-            const int len = two ? 0 : T.dof_depth[rm.last] + 1;
-            int dof = 0;
-            double y = 0, part = 0, y1 = 0;
-            if (two) {
-                const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
-                if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
-                if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
-            } else if (LANE < len) {
-                dof = T.dof_anc[rm.last * YS + LANE];
-                y = S[L.Y + r * YS + LANE];
-                part = y * z[dof];
-            }
-            const double old = S[L.rowF + r];
-            const double res = wave_sum(part) + S[L.rowR + r] * old + S[L.rowB + r];
-            double f = old - res / S[L.rowDa + r];
-            f = f < 0 ? 0.0 : f;
-            const double delta = f - old;
-            if (delta != 0) {
-                if (two) {
-                    if (LANE < T.nv) z[LANE] += delta * y;
-                    if (LANE + UHC_WAVE < T.nv) z[LANE + UHC_WAVE] += delta * y1;
-                } else if (LANE < len) z[dof] += delta * y;
-                if (LANE == 0) S[L.rowF + r] = f;
-            }
-            wsync();
-        }
     // ---- islands: kinematic trees that share no contact row have independent QPs (A is block diagonal), so each island gets its own
     //      working set of <= 64 rows: a humanoid and four boxes resting beside it are five small solves, not one of 130 rows.
     //      Tree label = root body id; a dense row (two bodies) merges the labels of its two trees (lane 0, a handful of rows).
@@ -1953,6 +1932,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
                 Y[q] = q < row.len ? S[L.Y + r * YS + q] : 0.0;
             });
             wsync();
+            PROF(30)
             const int it = k_pgs_fast<false, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum_C f Yhat
             iters += it > 0 ? it : 1;
             // ---- forces back to the island's rows, y on its rows outside C
@@ -1979,6 +1959,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
                 }
                 viol[h] = y < 0.0;
             }
+            PROF(31)
             if (!wave_or(viol[0] || viol[1])) {  // KKT holds on every row of the island: its optimum
                 for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] += z[i];
                 wsync();
