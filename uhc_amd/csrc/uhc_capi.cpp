@@ -388,6 +388,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.Y = carve(UHC_MAXEFC * YS);
     L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
     L.rowDa = carve(UHC_MAXEFC);
+    L.rowW = carve(UHC_MAXEFC);
     L.rowMisc = carve(UHC_MAXEFC * 2);  // 4 ints per row
     L.ncon_nefc = carve(2 + UHC_MAXTWO);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids, slot -> lane of the working set
     A.nvp = (nv + 1) & ~1;

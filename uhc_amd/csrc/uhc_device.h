@@ -65,6 +65,7 @@ struct DevLds {
     int M, LD, dinv, sdinv, bias, smooth, vec, z, zero;
     int mij;  // 16-bit (row << 8 | col) of every sparse-M entry, loaded once per kernel (k_crb)
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
+    int rowW;   // general kernel: the warm-start forces, kept for the sweeps fallback of the working-set solve
     int dense;  // [ndense][nvp] dense Yhat rows of the constraints that touch two moving bodies (self-collision, objects)
     int dcol;   // [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back)
     int dsc;    // general kernel: [ndense][4] J.qvel, J.qacc_smooth, J.qacc_warmstart, |Yhat|^2 of every dense row

@@ -1833,9 +1833,9 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
     const int r0 = LANE, r1 = LANE + UHC_WAVE;
     const bool v0 = r0 < nefc, v1 = r1 < nefc;
     if (wave_or((v0 && RTYPE(RM[r0].type) == ROW_FRICTION) || (v1 && RTYPE(RM[r1].type) == ROW_FRICTION))) return -1;
-    // ---- first candidates: the rows whose warm-start force (k_rows: the force the previous substep's acceleration implies) is positive.
-    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free (the 8 matrix-free
-    //      Gauss-Seidel sweeps a cold start would need cost as much as three register-resident solves).  Any start gives the same optimum.
+    // the warm-start forces survive for the sweeps fallback (which must start where the reference's PGS starts)
+    if (v0) S[L.rowW + r0] = S[L.rowF + r0];
+    if (v1) S[L.rowW + r1] = S[L.rowF + r1];
     for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
     wsync();
     // ---- islands: kinematic trees that share no contact row have independent QPs (A is block diagonal), so each island gets its own
@@ -1865,9 +1865,59 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
         while (label[a] != a) a = label[a];
         isl[h] = a;
     }
+    // ---- first candidates: the rows whose warm-start force (k_rows: the force the previous substep's acceleration implies) is positive.
+    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free.  The warm start can also
+    //      mark far more rows than end up active; when an island's candidates would not leave room in the 64 lanes, fall back to the
+    //      candidates of a cold start: the rows that 8 matrix-free Gauss-Seidel sweeps from f = 0 leave with a force (as costly as three
+    //      register-resident solves, so only then).  Any start gives the same optimum.
+    bool f0pos = v0 && S[L.rowF + r0] > 0.0, f1pos = v1 && S[L.rowF + r1] > 0.0;
+    {
+        int worst = 0;
+        for (int b = 1; b < T.nbody; b++) {
+            const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[0] == b && f0pos)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[1] == b && f1pos));
+            worst = max(worst, c);
+        }
+        if (worst > 48) {
+            if (v0) S[L.rowF + r0] = 0.0;
+            if (v1) S[L.rowF + r1] = 0.0;
+            wsync();
+        for (int it = 0; it < UHC_AS_PRESWEEPS; it++)
+            for (int r = 0; r < nefc; r++) {
+                const RowMisc rm = RM[r];
+                const bool two = (rm.type & ROW_TWO) != 0;
+                const int len = two ? 0 : T.dof_depth[rm.last] + 1;
+                int dof = 0;
+                double y = 0, part = 0, y1 = 0;
+                if (two) {
+                    const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
+                    if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
+                    if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
+                } else if (LANE < len) {
+                    dof = T.dof_anc[rm.last * YS + LANE];
+                    y = S[L.Y + r * YS + LANE];
+                    part = y * z[dof];
+                }
+                const double old = S[L.rowF + r];
+                const double res = wave_sum(part) + S[L.rowR + r] * old + S[L.rowB + r];
+                double f = old - res / S[L.rowDa + r];
+                f = f < 0 ? 0.0 : f;
+                const double delta = f - old;
+                if (delta != 0) {
+                    if (two) {
+                        if (LANE < T.nv) z[LANE] += delta * y;
+                        if (LANE + UHC_WAVE < T.nv) z[LANE + UHC_WAVE] += delta * y1;
+                    } else if (LANE < len) z[dof] += delta * y;
+                    if (LANE == 0) S[L.rowF + r] = f;
+                }
+                wsync();
+            }
+            f0pos = v0 && S[L.rowF + r0] > 0.0; f1pos = v1 && S[L.rowF + r1] > 0.0;
+            for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
+            wsync();
+        }
+    }
     double* ztot = S + L.vec;
     for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] = 0.0;
-    const bool f0pos = v0 && S[L.rowF + r0] > 0.0, f1pos = v1 && S[L.rowF + r1] > 0.0;
     int iters = 0;
     unsigned long long todo = 0ull;  // island labels present (nbody <= 64)
     for (int h = 0; h < 2; h++) {
@@ -2023,7 +2073,14 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             PROF(9)
             int it = -1;
             if (T.solver == 1) it = k_as_general<DENSE>(A, mb, S, out.nefc, LC PROF_PASS);
-            if (it < 0) { it = k_pgs<FAST>(A, mb, S, out.nefc); out.overflow |= 4; }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1
+            if (it < 0) {
+                if (T.solver == 1) {  // the working sets gave up: sweep from the warm start, as the reference's PGS does
+                    for (int r = LANE; r < out.nefc; r += UHC_WAVE) S[L.rowF + r] = S[L.rowW + r];
+                    wsync();
+                }
+                it = k_pgs<FAST>(A, mb, S, out.nefc);
+                out.overflow |= 4;
+            }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1
             out.iters = it;
             PROF(11)
         }
