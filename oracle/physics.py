@@ -31,6 +31,7 @@ def lib():
             getattr(L, fn).restype = None
         L.orc_set_state.argtypes = [C.POINTER(UhcModelDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_do_simulation.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_do_simulation_mixed.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint]
         L.orc_pd_torque.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         L.orc_rfc_implicit.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double)]
         L.orc_rfc_explicit.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(UhcCtrlDesc), P, C.POINTER(C.c_double)]
@@ -80,10 +81,12 @@ class OracleSim:
     def step(self):
         self.call("step")
 
-    def do_simulation(self, action, target_base):
+    def do_simulation(self, action, target_base, redo=0):
+        """redo: the device path's UHC_F_REDO word of the same step; its bits 8+ name the substeps the device solved by sweeps after its
+        exact solve gave up, and the checker takes solver 0 in exactly those."""
         action = np.ascontiguousarray(action, dtype=np.float64)
         target_base = np.ascontiguousarray(target_base, dtype=np.float64)
-        self.L.orc_do_simulation(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action), _dp(target_base))
+        self.L.orc_do_simulation_mixed(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action), _dp(target_base), (int(redo) >> 8) & 0x7fffff)
 
     def pd_torque(self, action, target_base, it):
         action = np.ascontiguousarray(action, dtype=np.float64)

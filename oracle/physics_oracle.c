@@ -1185,9 +1185,14 @@ void orc_rfc_explicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, c
  * M and C used by the PD solve are the ones left in `d` by the previous forward pass
  * (humanoid_im.py:1019-1022 reads data.qM / data.qfrc_bias before sim.step()).
  */
-void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
-                       const double* target_base) {
+void orc_do_simulation_mixed(const UhcModelDesc* m0, const UhcCtrlDesc* c, OrcData* d, const double* action,
+                             const double* target_base, unsigned sweep_mask) {
+    /* sweep_mask bit k: substep k is solved by the sweeps (solver 0) whatever the model says.  The device path reports the substeps in
+     * which its exact solve gave up and swept (UHC_F_REDO bits 8+); the checker follows it substep by substep. */
+    UhcModelDesc mm = *m0;
+    const UhcModelDesc* m = &mm;
     for (int it = 0; it < c->n_substeps && !d->fail; it++) {
+        mm.solver = (it < 32 && ((sweep_mask >> it) & 1u)) ? 0 : m0->solver;
         if (c->action_type == 0) orc_pd_torque(m, c, d, action, target_base, it);
         else
             for (int a = 0; a < m->nu; a++) /* :1160-1161 */
@@ -1196,6 +1201,10 @@ void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, 
         else if (c->rfc_mode == 2) orc_rfc_explicit(m, c, d, action);
         orc_step(m, d);
     }
+}
+void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
+                       const double* target_base) {
+    orc_do_simulation_mixed(m, c, d, action, target_base, 0u);
 }
 
 /* ------------------------------------------------------------------ field access for tests */

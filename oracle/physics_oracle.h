@@ -51,6 +51,9 @@ void orc_rfc_implicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, c
 void orc_rfc_explicit(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action);
 void orc_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
                        const double* target_base);
+/* the same with solver 0 forced in the substeps whose bit is set (follows the device path's per-substep fallback, UHC_F_REDO bits 8+) */
+void orc_do_simulation_mixed(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData* d, const double* action,
+                             const double* target_base, unsigned sweep_mask);
 void orc_set_threads(int n);
 void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcData** ds, int n_env,
                              const double* actions, const double* target_base);

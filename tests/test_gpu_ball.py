@@ -70,6 +70,8 @@ def test_ball_humanoid_trajectory_matches_oracle(model, standing, kernel_path, l
         os_[e].set_state(q[e], v[e])
         np.testing.assert_allclose(b.field(S.F_QM)[e].cpu().numpy(), os_[e].get("qM"), atol=1e-10)
         np.testing.assert_allclose(b.field(S.F_QACC)[e].cpu().numpy(), os_[e].get("qacc"), atol=1e-5, rtol=1e-6)
+    for o in os_:
+        o.desc.solver = 1  # (the forward pass of set_state may have been compared under solver 0, see above)
     rng = np.random.default_rng(42)
     tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
     worst = 0.0
@@ -80,8 +82,7 @@ def test_ball_humanoid_trajectory_matches_oracle(model, standing, kernel_path, l
         gq = b.field(S.F_QPOS).cpu().numpy()
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (redo[e] & 2) else 1  # UHC_F_REDO bit 1: the general kernel fell back to sweeps
-            os_[e].do_simulation(act[e], np.zeros(69))
+            os_[e].do_simulation(act[e], np.zeros(69), redo=redo[e])  # UHC_F_REDO bits 8+: the substeps the general kernel solved by sweeps
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-6, worst
     assert np.abs(np.linalg.norm(gq[:, 7:11], axis=1) - 1).max() < 1e-12  # ball quaternions stay normalised
@@ -105,6 +106,8 @@ def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_p
         os_[e].desc.solver = 0 if (redo[e] & 2) else 1
         os_[e].set_state(q[e], v[e])
         assert int(b.field(S.F_NCON)[e].item()) == os_[e].geti("ncon") and int(b.field(S.F_NEFC)[e].item()) == os_[e].geti("nefc")
+    for o in os_:
+        o.desc.solver = 1  # (the forward pass of set_state may have been compared under solver 0, see above)
     rng = np.random.default_rng(44)
     tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
     worst = 0.0
@@ -115,8 +118,7 @@ def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_p
         gq = b.field(S.F_QPOS).cpu().numpy()
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (redo[e] & 2) else 1
-            os_[e].do_simulation(act[e], np.zeros(69))
+            os_[e].do_simulation(act[e], np.zeros(69), redo=redo[e])  # UHC_F_REDO bits 8+: the substeps the general kernel solved by sweeps
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-5, worst
     assert int(b.field(S.F_FAIL).sum().item()) == 0

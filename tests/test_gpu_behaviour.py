@@ -152,8 +152,7 @@ def test_implicit_joint_damping_gpu(kernel_path):
         hb.sync()
         redo = hb.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (redo[e] & 2) else 1
-            os_[e].do_simulation(act[e], qpos[e, 7:])
+            os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])  # UHC_F_REDO bits 8+: the substeps the general kernel solved by sweeps
     gq = hb.field(S.F_QPOS).cpu().numpy()
     for e in range(n):
         np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-6)

@@ -285,8 +285,7 @@ def test_per_clip_body_shape_switches_the_env_model(tmp_path):
         gq = env.sim.field(S.F_QPOS).cpu().numpy()
         redo = env.sim.field(S.F_REDO).cpu().numpy()
         for e, (ci, st) in enumerate([(0, 0), (1, 0), (1, 5)]):
-            os_[e].desc.solver = 0 if (redo[e] & 2) else models[ci].solver  # UHC_F_REDO bit 1: the general kernel's working-set solve fell back to sweeps
-            os_[e].do_simulation(act[e], feats[ci]["qpos"][min(st + t + 1, st + [30, 30, 3][e] - 1)][7:])
+            os_[e].do_simulation(act[e], feats[ci]["qpos"][min(st + t + 1, st + [30, 30, 3][e] - 1)][7:], redo=redo[e])  # UHC_F_REDO bits 8+: the substeps the general kernel solved by sweeps
             np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-9)
     # env 2's 3-frame window is over: queue a window of the OTHER clip and restart on the device
     assert env.done.cpu().tolist() == [0, 0, 1]

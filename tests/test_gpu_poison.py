@@ -1,0 +1,23 @@
+"""Uninitialised-LDS check: the parity tests once more against the debug build whose kernels fill their LDS with NaNs before they start
+(tools/poison_build.py, -DUHC_POISON_LDS).  A kernel that reads LDS it has not written -- e.g. the tail of a chunked row load that meets
+a zero multiplier -- passes or fails by what the previous workgroup on that CU left behind; with the poison it fails every time."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POISON_LIB = os.path.join(ROOT, "uhc_amd", "csrc", "libuhc_amd_poison.so")
+
+
+@pytest.mark.skipif(not os.path.exists(POISON_LIB), reason="debug library not built (python tools/poison_build.py)")
+def test_parity_holds_with_poisoned_lds():
+    if os.environ.get("UHC_LIB"):
+        pytest.skip("already running against an alternative library")
+    env = dict(os.environ, UHC_LIB=POISON_LIB)
+    sel = ["tests/test_gpu_physics.py", "tests/test_gpu_selfcollision.py", "tests/test_gpu_ball.py", "tests/test_gpu_behaviour.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "--tb=short", "-m", "gpu"] + sel, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:]

@@ -126,6 +126,8 @@ def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, li
     assert nself > 0
     if lift > 0 and kernel_path == "fast":
         assert (redo != 0).sum() <= 1  # few rows: the fast kernel's dense path did the work (an env with > 12 body-body rows goes to the general kernel)
+    for o in os_:
+        o.desc.solver = 1  # (the forward pass of set_state may have been compared under solver 0, see above)
     rng = np.random.default_rng(32)
     tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
     worst = 0.0
@@ -136,8 +138,7 @@ def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, li
         gq = b.field(S.F_QPOS).cpu().numpy()
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
-            os_[e].desc.solver = 0 if (redo[e] & 2) else 1
-            os_[e].do_simulation(act[e], qpos[e, 7:])
+            os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])  # UHC_F_REDO bits 8+: the substeps the general kernel solved by sweeps
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-5, worst
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0

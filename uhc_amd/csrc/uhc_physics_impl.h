@@ -1164,12 +1164,16 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
             Y[q] = y;
             da += y * y;
         }
+        // the register-resident solves of the working sets (k_as_general) read rows in chunks of 8 entries, past the row's own length
+        // and into the next slot: everything there must be finite (it meets a zero multiplier), so the slot is zero-filled
+        for (int q = len; q < YS; q++) Y[q] = 0.0;
         S[L.rowR + r] = R;
         S[L.rowAref + r] = floss;        // (aref itself is folded into b; the slot keeps the friction-loss bound)
         S[L.rowB + r] = jas - aref;
         S[L.rowF + r] = f;
         S[L.rowDa + r] = da;             // diagonal of A + R
     }
+    if (!FAST && nefc < UHC_MAXEFC && LANE < YS) S[L.Y + nefc * YS + LANE] = 0.0;  // (the slot after the last row as well)
     wsync();
 }
 
@@ -1780,6 +1784,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         default: iters = pgs_sweeps<64, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
     }
     row.f = f;
+    if (!FASTL && T.solver == 1 && !any_fric) return -1;  // a working set of the general kernel that is not solved exactly is of no use to it
     }
     const double f = row.f;
     PROF(11)
@@ -1817,7 +1822,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // add the violated ones (y < 0), drop the rows of C that ended without a force, repeat.  Every new working set contains the support of
 // the current f, so the dual cost falls strictly from one round to the next: no cycling.  C starts as the rows with a positive
 // warm-start force.  Returns the number of factorisations, or -1 (friction-loss rows, more than 64 candidates, no
-// convergence in UHC_WS_MAXIT rounds): the caller then runs the sweeps.
+// convergence in UHC_WS_MAXIT rounds, a working set the pivoting cannot solve: -1 .. -4): the caller then runs the sweeps.
 #define UHC_WS_MAXIT 12
 template <bool DENSE>
 __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC PROF_ARGS) {
@@ -1945,7 +1950,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1), below = (1ull << LANE) - 1ull;
             const int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
             if (nC > UHC_WAVE) {
-                if (__builtin_popcountll(G) == 1) return -1;
+                if (__builtin_popcountll(G) == 1) return -2;
                 split = true;  // too many candidates for one solve: take the group's islands one at a time
                 break;
             }
@@ -1984,6 +1989,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
             wsync();
             PROF(30)
             const int it = k_pgs_fast<false, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum_C f Yhat
+            if (it < 0) return -4;  // pivot breakdown / no convergence of the pivoting on this working set
             iters += it > 0 ? it : 1;
             // ---- forces back to the island's rows, y on its rows outside C
             if (in0) S[L.rowF + r0] = 0.0;
@@ -2020,7 +2026,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
             }
         }
         if (split) { todo |= G; nomerge = true; continue; }
-        if (!done) return -1;
+        if (!done) return -3;
     }
     for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = ztot[i];
     wsync();
@@ -2078,9 +2084,9 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
                     for (int r = LANE; r < out.nefc; r += UHC_WAVE) S[L.rowF + r] = S[L.rowW + r];
                     wsync();
                 }
+                out.overflow |= 4 | (T.solver == 1 ? (4 << (-it)) : 0);
                 it = k_pgs<FAST>(A, mb, S, out.nefc);
-                out.overflow |= 4;
-            }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1
+            }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1; 8 / 16 / 32 / 64: why the working sets gave up (bits 2-5)
             out.iters = it;
             PROF(11)
         }
@@ -2298,6 +2304,10 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     const DevTopo& T = A.t;
     const DevLds& L = FAST ? A.lf : A.l;
     double* S = smem;
+#ifdef UHC_POISON_LDS  // debug builds (tools/poison_build.py): any read of LDS the kernel did not write first meets a NaN / a huge int
+    for (int i = LANE; i < L.total; i += UHC_WAVE) S[i] = __longlong_as_double(0x7ff8dead7fffbeefll);
+    wsync();
+#endif
     const double* mb = A.s.model_blob + (size_t)(A.s.env_model ? A.s.env_model[env] : 0) * A.o.stride;
     int fail = MODE == 0 ? A.s.fail[env] : 0;
     const bool fresh = MODE == 0 && A.s.fresh[env] != 0;  // restarted by uhc_env_auto_reset: sim.forward() of the reset is still due
@@ -2343,7 +2353,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
     wsync();
     FwdOut fo = {0, 0, 0, 0};
-    int overflow = 0;
+    int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
     bool ran = false;
     PROF_DECL
     if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
@@ -2385,6 +2395,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             PROF(13)
             overflow |= fo.overflow;
             if (FAST && (overflow & 1)) break;
+            if (!FAST && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
             ran = true;
             if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
                 wsync();
@@ -2447,7 +2458,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         A.s.fail[env] = fail;
         if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
-        if (!FAST) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0);  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
+        if (!FAST) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | swept;  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
     }
 }
 
