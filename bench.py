@@ -267,11 +267,17 @@ def bench_ball_objects(args):
             if timed:
                 redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync
                 sweep_tot += ((sim.field(S.F_REDO) & 2) != 0).int()
+                r = sim.field(S.F_REDO)
+                for j in range(4):  # bits 2-5: why the working sets gave up (friction rows / > 64 candidates in one island / no convergence / unsolved set)
+                    why_tot[j] += ((r >> (2 + j)) & 1).sum()
+                sub_tot[0] += sum(((r >> (8 + j)) & 1).sum() for j in range(15))  # bits 8+: the substeps solved by sweeps
                 if i % 5 == 4:
                     hist_nefc.append(sim.field(S.F_NEFC).clone()); hist_ncon.append(sim.field(S.F_NCON).clone())
 
     redo_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     sweep_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    why_tot = torch.zeros(4, dtype=torch.int64, device="cuda")
+    sub_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
     run(args.warmup, False)
     torch.cuda.synchronize()
     sim.set_timing(True)
@@ -296,6 +302,8 @@ def bench_ball_objects(args):
                               "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129])[0].tolist(),
                               "general_kernel_share_of_env_steps": float(redo_tot.double().sum().item()) / (n_env * args.steps),
                               "sweeps_fallback_share_of_env_steps": float(sweep_tot.double().sum().item()) / (n_env * args.steps),
+                              "sweeps_fallback_share_of_substeps": float(sub_tot.item()) / (n_env * args.steps * 15),
+                              "sweeps_fallback_reasons_env_steps": dict(zip(["friction_rows", "island_needs_over_64_rows", "no_convergence", "unsolved_working_set"], why_tot.cpu().tolist())),
                               "efc_overflow_envs": int(sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(sim.field(S.F_FAIL).sum().item())}}
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     print(json.dumps(out))
@@ -489,7 +497,9 @@ def main():
                                "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
                                "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
                                "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17])[0].tolist(),
-                               "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
+                               "sweeps_fallback_share_of_substeps": float(sub_tot.item()) / (n_env * args.steps * 15),
+                              "sweeps_fallback_reasons_env_steps": dict(zip(["friction_rows", "island_needs_over_64_rows", "no_convergence", "unsolved_working_set"], why_tot.cpu().tolist())),
+                              "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},
         }
         if pgs:

@@ -118,7 +118,7 @@ enum UhcField {
     UHC_F_REDO = 16          /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast kernel's capacity (64 rows, 16 contacts, packed
                               * row storage, 12 body-body rows) and was computed by the general kernel (128 rows, 64 contacts, 32 body-body rows), which
                               * solves the QP exactly too (working sets of <= 64 rows); bit 1: in at least one substep that solve fell back to solver 0
-                              * (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one island with more than 64 candidate rows /
+                              * (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one island with 64 rows that carry a force and more that want in /
                               * no convergence of the working sets / a working set the pivoting could not solve); bit 8 + k: substep k (< 23)
                               * of the step was one of those (a checker that follows the same path needs to know which) */
 };

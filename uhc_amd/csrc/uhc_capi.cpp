@@ -398,7 +398,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     L.dsc = carve(A.ndense_g * 4);          // (vel, jas, jaw, |Yhat|^2) of every dense row
     // MPR walks hull vertices once per support call and lane: staged in LDS they cost an LDS read instead of an L2 round trip.  The rows'
     // storage (Y .. rowDa, contiguous) is not written before the collision pass is over: the vertices borrow it every substep.
-    A.vstage_g = (T.ncpair > 0 && 3 * d.nmeshvert <= UHC_MAXEFC * YS + 5 * UHC_MAXEFC) ? L.Y : -1;
+    { const char* dbg = getenv("UHC_DEBUG"); A.dbg = dbg ? atoi(dbg) : 0; }
+    A.vstage_g = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= UHC_MAXEFC * YS + 5 * UHC_MAXEFC) ? L.Y : -1;
     L.total = off;
     b->lds_bytes = (size_t)off * sizeof(double);
     if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }
@@ -444,7 +445,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         if (ycap < need1) ycap = need1;
         if (ycap < 8 * YS) ycap = 8 * YS;
         A.ycap = ycap;
-        A.vstage_f = (T.ncpair > 0 && 3 * d.nmeshvert <= A.ndense_f * A.nvp + A.ndense_f * UHC_WAVE + ycap) ? F.dense : -1;  // dense, dcol, Y are contiguous
+        A.vstage_f = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= A.ndense_f * A.nvp + A.ndense_f * UHC_WAVE + ycap) ? F.dense : -1;  // dense, dcol, Y are contiguous
         off += ycap;
         F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.Y;  // unused by the fast kernel
         F.total = off;

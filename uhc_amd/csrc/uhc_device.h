@@ -98,6 +98,7 @@ struct KernelArgs {
     int ycap;   // doubles available for packed Yhat rows in the fast layout
     int ld_delta;  // bytes to add to the schedule tables' LDS addresses in the general layout
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
+    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS
     int ndense_f, ndense_g;  // dense-row slots of the fast / general layout (0: the model has no two-body contacts)
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     int vstage_f, vstage_g;  // LDS offset (doubles) where the hull vertices are staged for the MPR pass of every substep, or -1: they do not fit the

@@ -1821,9 +1821,9 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // fast kernel: A_CC in registers, block principal pivoting), evaluate y = A f + b on the rows outside C (matrix-free: Yhat_r . z + b_r),
 // add the violated ones (y < 0), drop the rows of C that ended without a force, repeat.  Every new working set contains the support of
 // the current f, so the dual cost falls strictly from one round to the next: no cycling.  C starts as the rows with a positive
-// warm-start force.  Returns the number of factorisations, or -1 (friction-loss rows, more than 64 candidates, no
+// warm-start force.  Returns the number of factorisations, or a negative reason (friction-loss rows, 64 rows with a force and more violated, no
 // convergence in UHC_WS_MAXIT rounds, a working set the pivoting cannot solve: -1 .. -4): the caller then runs the sweeps.
-#define UHC_WS_MAXIT 12
+#define UHC_WS_MAXIT 16
 template <bool DENSE>
 __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC PROF_ARGS) {
     const DevTopo& T = A.t;
@@ -1871,56 +1871,10 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
         isl[h] = a;
     }
     // ---- first candidates: the rows whose warm-start force (k_rows: the force the previous substep's acceleration implies) is positive.
-    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free.  The warm start can also
-    //      mark far more rows than end up active; when an island's candidates would not leave room in the 64 lanes, fall back to the
-    //      candidates of a cold start: the rows that 8 matrix-free Gauss-Seidel sweeps from f = 0 leave with a force (as costly as three
-    //      register-resident solves, so only then).  Any start gives the same optimum.
-    bool f0pos = v0 && S[L.rowF + r0] > 0.0, f1pos = v1 && S[L.rowF + r1] > 0.0;
-    {
-        int worst = 0;
-        for (int b = 1; b < T.nbody; b++) {
-            const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[0] == b && f0pos)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[1] == b && f1pos));
-            worst = max(worst, c);
-        }
-        if (worst > 48) {
-            if (v0) S[L.rowF + r0] = 0.0;
-            if (v1) S[L.rowF + r1] = 0.0;
-            wsync();
-        for (int it = 0; it < UHC_AS_PRESWEEPS; it++)
-            for (int r = 0; r < nefc; r++) {
-                const RowMisc rm = RM[r];
-                const bool two = (rm.type & ROW_TWO) != 0;
-                const int len = two ? 0 : T.dof_depth[rm.last] + 1;
-                int dof = 0;
-                double y = 0, part = 0, y1 = 0;
-                if (two) {
-                    const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
-                    if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
-                    if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
-                } else if (LANE < len) {
-                    dof = T.dof_anc[rm.last * YS + LANE];
-                    y = S[L.Y + r * YS + LANE];
-                    part = y * z[dof];
-                }
-                const double old = S[L.rowF + r];
-                const double res = wave_sum(part) + S[L.rowR + r] * old + S[L.rowB + r];
-                double f = old - res / S[L.rowDa + r];
-                f = f < 0 ? 0.0 : f;
-                const double delta = f - old;
-                if (delta != 0) {
-                    if (two) {
-                        if (LANE < T.nv) z[LANE] += delta * y;
-                        if (LANE + UHC_WAVE < T.nv) z[LANE + UHC_WAVE] += delta * y1;
-                    } else if (LANE < len) z[dof] += delta * y;
-                    if (LANE == 0) S[L.rowF + r] = f;
-                }
-                wsync();
-            }
-            f0pos = v0 && S[L.rowF + r0] > 0.0; f1pos = v1 && S[L.rowF + r1] > 0.0;
-            for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
-            wsync();
-        }
-    }
+    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free.  (A cold start -- the rows
+    //      that 8 matrix-free Gauss-Seidel sweeps from f = 0 leave with a force -- costs as much as three register-resident solves and
+    //      was slower on every workload measured, also when the warm start marks more rows than lanes: those are capped below.)
+    const bool f0pos = v0 && S[L.rowF + r0] > 0.0, f1pos = v1 && S[L.rowF + r1] > 0.0;
     double* ztot = S + L.vec;
     for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] = 0.0;
     int iters = 0;
@@ -1929,7 +1883,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
 #pragma unroll 1
         for (int b = 1; b < T.nbody; b++) todo |= __builtin_amdgcn_ballot_w64(isl[h] == b) ? (1ull << b) : 0ull;
     }
-    bool nomerge = false;
+    bool nomerge = (A.dbg & 1) != 0;
     while (todo) {
         // ---- next group: islands are independent, but every solve pays the fixed cost of a register-resident build, so small islands
         //      share one (A is block diagonal across them by itself: rows of different trees have no common dofs).  Islands are packed
@@ -1945,14 +1899,26 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
         todo &= ~G;
         const bool in0 = isl[0] >= 0 && ((G >> isl[0]) & 1ull), in1 = isl[1] >= 0 && ((G >> isl[1]) & 1ull);
         bool c0 = in0 && f0pos, c1 = in1 && f1pos, done = false, split = false;
+        bool p0 = false, p1 = false;  // rows of the working set that carry a force after the last solve: they must stay
         for (int outer = 0; outer < UHC_WS_MAXIT && !done; outer++) {
             // ---- compact the group's working set into the lanes (row order kept)
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1), below = (1ull << LANE) - 1ull;
-            const int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
+            const unsigned long long below = (1ull << LANE) - 1ull;
+            unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1);
+            int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
             if (nC > UHC_WAVE) {
-                if (__builtin_popcountll(G) == 1) return -2;
-                split = true;  // too many candidates for one solve: take the group's islands one at a time
-                break;
+                if (__builtin_popcountll(G) > 1) {
+                    split = true;  // too many candidates for one solve: take the group's islands one at a time
+                    break;
+                }
+                // one island, more candidates than lanes: the rows with a force stay, the others join in row order while there is room
+                // (the rest wait for a later round: any violated row that joins lowers the dual cost, so this still terminates)
+                const unsigned long long q0 = __builtin_amdgcn_ballot_w64(c0 && !p0), q1 = __builtin_amdgcn_ballot_w64(c1 && !p1);
+                const int room = UHC_WAVE - (nC - __builtin_popcountll(q0) - __builtin_popcountll(q1));
+                if (room <= 0) return -2;  // 64 rows carry a force and more want in: beyond one register-resident solve
+                c0 = c0 && (p0 || __builtin_popcountll(q0 & below) < room);
+                c1 = c1 && (p1 || __builtin_popcountll(q0) + __builtin_popcountll(q1 & below) < room);
+                m0 = __builtin_amdgcn_ballot_w64(c0); m1 = __builtin_amdgcn_ballot_w64(c1);
+                n0 = __builtin_popcountll(m0); nC = n0 + __builtin_popcountll(m1);
             }
             if (nC == 0) {  // no candidate: f = 0 is optimal on this group iff b >= 0 on its rows
                 c0 = in0 && S[L.rowB + r0] < 0.0; c1 = in1 && S[L.rowB + r1] < 0.0;
@@ -2022,6 +1988,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
                 done = true;
             } else {
                 c0 = keep[0] || viol[0]; c1 = keep[1] || viol[1];
+                p0 = keep[0]; p1 = keep[1];
                 wsync();
             }
         }
