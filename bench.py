@@ -293,7 +293,7 @@ def bench_ball_objects(args):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"configs[4] stand-in: ball-joint humanoid (nq {m.nq}, nv {m.nv}), self-collision on, {K} free 5 kg boxes, torque actions, {n_env} envs, "
                                   "re-posed every 30 control steps; physics only", "envs_per_gpu": n_env, "objects": K, "kernel_path": "general only" if args.general_only else "fast, then general on the envs beyond its capacity",
-                      "contact_solver": "active-set in the fast kernel, sweeps in the general kernel" if int(m.solver) == 1 else "pgs sweeps", "pgs_sweep_cap": int(m.iterations)},
+                      "contact_solver": "exact: active set in the fast kernel, working sets in the general kernel" if int(m.solver) == 1 else "pgs sweeps", "pgs_sweep_cap": int(m.iterations)},
            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true, true>", "kernel_ms": ms / max(k, 1), "launches": k,
                         "achieved": 8 * (2 * m.nq + 3 * m.nv + ctrl.action_dim + 7 * m.nbody) * n_env / (ms / max(k, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "note": "fast-kernel launches only (HIP events); envs beyond its capacity (64 rows / 16 contacts / 12 body-body rows) are redone by the general "
@@ -482,7 +482,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
-                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "contact_solver": ("active-set (exact optimum of the dual QP; envs beyond the fast kernel's capacity fall back to sweeps)" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
+                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "contact_solver": ("exact optimum of the dual QP: active set in registers (fast kernel), working sets of <= 64 rows in the general kernel for envs beyond its capacity" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, false, true>" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, true, false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
@@ -497,8 +497,6 @@ def main():
                                "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
                                "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
                                "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17])[0].tolist(),
-                               "sweeps_fallback_share_of_substeps": float(sub_tot.item()) / (n_env * args.steps * 15),
-                              "sweeps_fallback_reasons_env_steps": dict(zip(["friction_rows", "island_needs_over_64_rows", "no_convergence", "unsolved_working_set"], why_tot.cpu().tolist())),
                               "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},
         }
