@@ -389,13 +389,13 @@ def main():
         agent.rollout_step()
     fence()
     env.sim.set_timing(True)
-    redo_acc = torch.zeros(n_env, dtype=torch.int32, device=env.device)  # env-steps the general kernel had to redo, over the whole timed region
+    redo0 = agent._ro.redo_counts.clone()  # env-steps the general kernel had to redo: counted on the device by the step's own bookkeeping launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.rollout_step()
-        redo_acc += (env.sim.field(S.F_REDO) != 0).int()
     fence()
     elapsed = time.perf_counter() - t0
+    redo_d = (agent._ro.redo_counts - redo0).cpu().tolist()
     kern_total_ms, kern_n = env.sim.kernel_time()
     env.sim.set_timing(False)
     nefc = env.sim.field(S.F_NEFC).cpu().numpy()
@@ -493,7 +493,7 @@ def main():
                          "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
                                  "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
                                  "above the algorithmic bytes is L2 misses of the schedule tables / kernel code and register spills to scratch"},
-            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int((env.sim.field(S.F_REDO) != 0).sum().item()), "general_kernel_env_steps_timed_region": int(redo_acc.sum().item()),
+            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int((env.sim.field(S.F_REDO) != 0).sum().item()), "general_kernel_env_steps_timed_region": int(redo_d[0]), "sweeps_fallback_env_steps_timed_region": int(redo_d[1]),
                                "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
                                "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
                                "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17])[0].tolist(),

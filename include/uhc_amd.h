@@ -277,6 +277,35 @@ int32_t uhc_env_reset(UhcEnv* e, const int32_t* d_env_ids, int32_t n, const doub
  * cur_t += 1, termination, reward, next observation */
 int32_t uhc_env_step(UhcEnv* e, const double* d_action, const int32_t* d_active);
 
+/* ------------------------------------------------------------------ rollout bookkeeping (one control step of the sampling loop)
+ * The reference's sample_worker (uhc/khrylib/rl/agents/agent.py:60-100) does, per env step on the host: running_state(state),
+ * select_action, memory.push, reward / mask bookkeeping.  Batched on the device these are launch-latency bound (~80 framework launches
+ * per step); the entries below do them in a handful.  Free functions: all pointers are device pointers, `stream` is a hipStream_t
+ * (NULL = the default stream), every reduction has a fixed order (bit-reproducible).  Layouts: states [n_env][T][obs_dim], actions
+ * [n_env][T][act_dim], rewards / dones [n_env][T], mean_flags [T][n_env] (1.0 = take the mean action), d_t = the pass's step counter. */
+
+/* memory.push(state, action, ...) + PolicyGaussian.select_action's sampling (policy_gaussian.py:22-31, distributions.py:6-25):
+ * states[:, t] = state; action = mean where mean_flags[t] != 0 else mean + exp(log_std) * noise; actions[:, t] = action = d_action */
+int32_t uhc_rollout_act(void* stream, int32_t n_env, int32_t T, const int64_t* d_t, int32_t obs_dim, int32_t act_dim, const double* d_state,
+                        const double* d_mean, const double* d_log_std, const double* d_noise, const double* d_mean_flags, double* d_states,
+                        double* d_actions, double* d_action);
+/* agent.py:80-92: rewards[:, t] = reward + end * end_reward, dones[:, t] = done, c_reward_sum += sum(reward),
+ * c_info_sum[k] += sum(parts[:, k]) (LoggerRL.step, logger_rl.py:29-33); n_parts <= 8.  d_redo (may be NULL): UHC_F_REDO of the step;
+ * d_redo_counts[0] += envs the general kernel computed, [1] += envs whose exact contact solve fell back to sweeps (diagnostics) */
+int32_t uhc_rollout_record(void* stream, int32_t n_env, int32_t T, const int64_t* d_t, const double* d_reward, const int32_t* d_done,
+                           const int32_t* d_end, const double* d_end_reward, const double* d_parts, int32_t parts_stride, int32_t n_parts,
+                           double* d_rewards, double* d_dones, double* d_c_reward_sum, double* d_c_info_sum, const int32_t* d_redo,
+                           int64_t* d_redo_counts);
+/* RunningStat.push for a batch (zfilter.py:17-27; Chan et al. merge, mathematically the rows pushed one by one): (n, mean, S) <-
+ * merged with the rows of d_x [n_rows][dim] whose d_weights entry is non-zero (NULL = all rows).  d_scratch: uhc_filter_scratch_doubles */
+int64_t uhc_filter_scratch_doubles(int32_t n_rows, int32_t dim);
+int32_t uhc_filter_push(void* stream, const double* d_x, int32_t n_rows, int32_t dim, const int32_t* d_weights, double* d_n, double* d_mean,
+                        double* d_S, double* d_scratch);
+/* ZFilter.__call__ (zfilter.py:55-64): out = clip((x - mean) / (std + 1e-8), +-clip); std = sqrt(S / (n - 1)) (n <= 1: |mean|);
+ * clip == 0: no clipping.  d_t_inc (may be NULL): incremented by one -- the step counter, this being the last launch of a step */
+int32_t uhc_filter_apply(void* stream, const double* d_x, int32_t n_rows, int32_t dim, const double* d_n, const double* d_mean, const double* d_S,
+                         int32_t demean, int32_t destd, double clip, double* d_out, int64_t* d_t_inc);
+
 #ifdef __cplusplus
 }
 #endif

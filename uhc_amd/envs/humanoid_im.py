@@ -154,14 +154,14 @@ class VecHumanoidEnv:
 
     def set_next(self, env_ids, keys, fr_start, fr_end):
         """Queue the next episode's window for the listed envs (load_expert + reset_model happen on the device at `done`)."""
-        ids = torch.as_tensor(np.asarray(env_ids), dtype=torch.int32)
-        cid = torch.tensor([self._clip_index[k] for k in keys], dtype=torch.int32)
-        fs = torch.as_tensor(np.asarray(fr_start), dtype=torch.int32)
-        fl = torch.as_tensor(self._window_len(fr_start, fr_end), dtype=torch.int32)
+        ids = np.asarray(env_ids, dtype=np.int32)
+        cid = np.fromiter((self._clip_index[k] for k in keys), dtype=np.int32, count=len(ids))
+        fs = np.asarray(fr_start, dtype=np.int32)
+        fl = np.asarray(self._window_len(fr_start, fr_end), dtype=np.int32)
         noise = None
         if self.mode == "train" and self.cc_cfg.env_init_noise > 0:
-            noise = torch.from_numpy(self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof)))
-        self.env.set_next(ids, cid, fs, fl, noise)
+            noise = self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof))
+        self.env.set_next_host(ids, cid, fs, fl, noise)  # one asynchronous copy: the sampling loop must not wait for the GPU here
 
     def auto_reset(self):
         self.env.auto_reset()

@@ -20,7 +20,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..core import LoggerRL, estimate_advantages
+from uhc_amd import rollout_ops
+
+from ..core import LoggerRL, PolicyGaussian, estimate_advantages, linear
 from ...utils.torch import to_test, to_train
 
 
@@ -92,6 +94,7 @@ class Agent:
             R.c_info_sum = torch.zeros(getattr(env, "n_reward_parts", 5), dtype=self.dtype, device=dev)
             R.c_reward_sum = torch.zeros((), dtype=self.dtype, device=dev)
             R.t_dev = torch.zeros(1, dtype=torch.long, device=dev)
+            R.redo_counts = torch.zeros(2, dtype=torch.long, device=dev)  # env-steps through the general kernel / its sweeps fallback, this pass
             R.end_reward_dev = torch.zeros((), dtype=self.dtype, device=dev)
             R.state = torch.zeros(n_env, env.obs_dim, dtype=self.dtype, device=dev)
             R.action = torch.zeros(n_env, env.action_dim, dtype=torch.float64, device=dev)
@@ -107,7 +110,7 @@ class Agent:
         n_env, dev = env.n_env, env.device
         R = self._ro = self._buffers(T)
         R.t = 0
-        R.t_dev.zero_(); R.rewards.zero_(); R.dones.zero_(); R.c_info_sum.zero_(); R.c_reward_sum.zero_()
+        R.t_dev.zero_(); R.redo_counts.zero_(); R.rewards.zero_(); R.dones.zero_(); R.c_info_sum.zero_(); R.c_reward_sum.zero_()
         R.end_reward_dev.fill_(float(env.end_reward) if self.end_reward else 0.0)
         R.logger = self.logger_cls()
         # exploration flags of the whole pass in one upload (the same stream of draws as one binomial(n_env) per step)
@@ -158,6 +161,13 @@ class Agent:
         """state -> rollout buffer, policy forward + sampling -> action (buffer + the fixed tensor env.step reads)."""
         R = self._ro
         t = R.t_dev
+        pol = self.policy_net
+        if isinstance(pol, PolicyGaussian) and rollout_ops.usable(R.state, R.states, R.actions, R.action, pol.action_log_std.data):
+            # device float64: the trunk's GEMMs stay with the framework, everything around them is one launch of the library
+            mean = linear(pol.action_mean, pol.net(self.trans_policy(R.state)))
+            noise = torch.randn(mean.shape, dtype=mean.dtype, device=mean.device)  # the draw DiagGaussian.sample makes (same Philox stream)
+            rollout_ops.act(t, R.state, mean.contiguous(), pol.action_log_std.data, noise, R.mean_flags, R.states, R.actions, R.action)
+            return
         R.states.index_copy_(1, t, R.state.unsqueeze(1))
         mean_flag = R.mean_flags.index_select(0, t).squeeze(0)
         action = self.policy_net.select_action(self.trans_policy(R.state), mean_flag)
@@ -170,6 +180,22 @@ class Agent:
         env, R = self.env, self._ro
         t = R.t_dev
         env.sim.use_current_stream()  # the library's launches below go to the stream this runs (or is being captured) on
+        if rollout_ops.usable(env.reward, env.obs, R.rewards, R.dones, R.state, R.c_info_sum) and env.done.dtype == torch.int32:
+            # device float64: six launches of the library (+ the restart's) instead of ~50 framework ones
+            rollout_ops.record(t, env.reward, env.done, env.env.field(5), R.end_reward_dev, env.env.field(2), int(R.c_info_sum.numel()), R.rewards, R.dones,
+                               R.c_reward_sum, R.c_info_sum, env.sim.field(16), R.redo_counts)
+            if self.running_state is not None:
+                self.running_state.rs.push_batch(env.obs, weights=env.done)  # the finished episodes' last observations (agent.py:77-79)
+            env.auto_reset()
+            if self.running_state is not None:
+                self.running_state(env.obs, out=R.state, step_counter=t)
+            else:
+                R.state.copy_(env.obs)
+                t.add_(1)
+            return
+        redo = env.sim.field(16)  # UHC_F_REDO: which envs the general kernel computed / solved by sweeps in this step (diagnostics)
+        R.redo_counts[0] += (redo != 0).sum()
+        R.redo_counts[1] += ((redo & 2) != 0).sum()
         r = env.reward.to(self.dtype)
         R.c_reward_sum.add_(r.sum())  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
         if self.running_state is not None:
@@ -223,7 +249,13 @@ class Agent:
             R.snap_event[slot].record()
         else:
             R.snap_event[slot] = True
-        self._drain_snapshot(slot ^ 1)  # the previous step's snapshot: long since landed
+        # the previous step's snapshot landed before that step returned: its host work (episode statistics, sampling the next windows,
+        # ~0.8 ms at 1 024 envs) runs while the GPU computes this step
+        self._drain_snapshot(slot ^ 1)
+        # ... and the host then waits for this step, so the GPU queue never holds more than one control step.  Letting the host run a
+        # step ahead measured slower and erratic (4.1 - 8 ms per step against a steady 4.15): see DESIGN.md section 6.
+        if dev.type == "cuda":
+            R.snap_event[slot].synchronize()
         R.t += 1
 
     @torch.no_grad()

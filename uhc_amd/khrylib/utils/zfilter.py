@@ -7,6 +7,8 @@ a single numpy vector (reference behaviour) or a (B, dim) torch tensor (batched 
 import numpy as np
 import torch
 
+from uhc_amd import rollout_ops
+
 
 class RunningStat:
     def __init__(self, shape):
@@ -17,6 +19,7 @@ class RunningStat:
         # (a captured HIP graph of the rollout step keeps their addresses); _stale = the device holds newer statistics than the numpy
         # arrays, _dirty = the numpy arrays were set from the host and must be copied down before the next device use
         self._dev, self._stale, self._dirty = None, False, False
+        self._scratch = {}  # rows per batch -> partial-sum buffer of the library's push (kept: a captured graph holds its address)
 
     def _host_changed(self):
         self._stale, self._dirty = False, self._dev is not None
@@ -55,8 +58,17 @@ class RunningStat:
         if xb.shape[0] == 0:
             return
         self._to_device(xb.device)
-        x = xb.double()
         n, M, Sd = self._dev
+        if xb.dim() == 2 and M.dim() == 1 and rollout_ops.usable(xb) and (weights is None or (weights.dtype == torch.int32 and weights.is_contiguous())):
+            # device float64: two launches of the library (uhc_filter_push: per-row-block partials, fixed-order Chan merges)
+            key = xb.shape[0]
+            scratch = self._scratch.get(key)
+            if scratch is None or scratch.device != xb.device:
+                scratch = self._scratch[key] = rollout_ops.filter_scratch(xb.shape[0], xb.shape[1], xb.device)
+            rollout_ops.filter_push(xb, weights, n, M, Sd, scratch)
+            self._stale = True
+            return
+        x = xb.double()
         if weights is None:
             B = torch.full((), float(xb.shape[0]), dtype=torch.float64, device=xb.device)
             mb = x.mean(0)
@@ -110,6 +122,7 @@ class RunningStat:
     def __setstate__(self, st):
         self.__dict__.update(st)
         self._dev, self._stale, self._dirty = None, False, False
+        self._scratch = {}
 
     @property
     def n(self):
@@ -140,16 +153,25 @@ class ZFilter:
         self.demean, self.destd, self.clip = demean, destd, clip
         self.rs = RunningStat(shape)
 
-    def __call__(self, x, update=True):
+    def __call__(self, x, update=True, out=None, step_counter=None):
+        """out / step_counter (batched device path): write the result into `out` and add one to the int64 device scalar `step_counter`
+        (the rollout's step index; with the library's kernel both ride on the normalisation launch)."""
         if torch.is_tensor(x):
             if update:
                 self.rs.push_batch(x)
-            mean, std = self.rs.device_mean_std(x)
-            if self.demean:
-                x = x - mean
-            if self.destd:
-                x = x / (std + 1e-8)
-            return torch.clamp(x, -self.clip, self.clip) if self.clip else x
+            if x.dim() == 2 and self.rs._M.ndim == 1 and rollout_ops.usable(x) and (out is None or rollout_ops.usable(out)):
+                self.rs._to_device(x.device)
+                n, M, Sd = self.rs._dev
+                y = torch.empty_like(x) if out is None else out
+                rollout_ops.filter_apply(x, n, M, Sd, self.demean, self.destd, self.clip, y, step_counter)
+                return y
+            y = self._call_torch(x)
+            if out is not None:
+                out.copy_(y)
+                y = out
+            if step_counter is not None:
+                step_counter.add_(1)
+            return y
         if update:
             self.rs.push(x)
         if self.demean:
@@ -157,6 +179,14 @@ class ZFilter:
         if self.destd:
             x = x / (self.rs.std + 1e-8)
         return np.clip(x, -self.clip, self.clip) if self.clip else x
+
+    def _call_torch(self, x):
+        mean, std = self.rs.device_mean_std(x)
+        if self.demean:
+            x = x - mean
+        if self.destd:
+            x = x / (std + 1e-8)
+        return torch.clamp(x, -self.clip, self.clip) if self.clip else x
 
     def set_mean_std(self, mean, std, n):
         self.rs._n = n

@@ -3,6 +3,7 @@ memory and streams; every computation happens inside libuhc_amd.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -248,6 +249,29 @@ class EnvBatch:
         check(self.L.uhc_env_set_next(self._e, C.c_void_p(a.data_ptr()), a.shape[0], C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr()),
                                       C.c_void_p(d.data_ptr()), nz))
         self._keep_next = (a, b, c, d, noise)  # alive until the stream has consumed them (the next call replaces them a step later)
+
+    def set_next_host(self, env_ids, clip_ids, fr_start, fr_len, noise=None):
+        """set_next from host (numpy) arrays: the five arrays are packed into one buffer and go down in ONE copy (a copy from pageable
+        memory waits for everything queued before it; five of them per control step cost ~0.1 ms of idle GPU).  Measured alternatives,
+        both dropped: an asynchronous copy from a pinned ring, and the kernel reading the pinned buffer over PCIe itself -- with either
+        the host runs ahead of the GPU and the step time became erratic (4.1 .. 8 ms against a steady 4.1)."""
+        import numpy as np
+        k, nu = int(len(env_ids)), self.sim.model.nu
+        if k == 0:
+            return
+        nbytes = 16 * k + (8 * k * nu if noise is not None else 0)
+        hb = np.empty(nbytes, dtype=np.uint8)
+        ints = hb[:16 * k].view(np.int32).reshape(4, k)
+        ints[0], ints[1], ints[2], ints[3] = env_ids, clip_ids, fr_start, fr_len
+        if noise is not None:
+            hb[16 * k:].view(np.float64).reshape(k, nu)[...] = noise
+        dev = self.__dict__.get("_next_dev")
+        if dev is None or dev.numel() < nbytes:
+            dev = self._next_dev = torch.empty(max(nbytes, 16 * self.n_env + 8 * self.n_env * nu), dtype=torch.uint8, device=self.device)
+        dev[:nbytes].copy_(torch.from_numpy(hb))
+        base = dev.data_ptr()
+        check(self.L.uhc_env_set_next(self._e, C.c_void_p(base), k, C.c_void_p(base + 4 * k), C.c_void_p(base + 8 * k), C.c_void_p(base + 12 * k),
+                                      C.c_void_p(base + 16 * k) if noise is not None else None))
 
     def auto_reset(self):
         """Device-side episode turnover of every env whose done flag is set (uhc_env_auto_reset); no host round trip."""
