@@ -24,7 +24,7 @@ for graph, fused in combos:
         agent = AgentCopycat(cfg, torch.float64, torch.device("cuda", 0), data_loader=dl)
         agent.use_graph = graph
         agent.per_epoch_update(0)
-        T = 60
+        T = 100  # 10 warm-up + 40 timed steps + 2 x 20 stand-alone graph replays
         agent.rollout_begin(T)
         for _ in range(10):
             agent.rollout_step()

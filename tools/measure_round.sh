@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): the round's measurement pass.  Everything lands under gpurun_out/ with the given tag; the
 # summaries worth keeping are then copied into profiles/ by hand.
 set -u
-TAG=${1:-r02_v2}
+TAG=${1:-r02_v3}
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v amdgpu | tail -15) > gpurun_out/${TAG}_pytest_gpu.txt 2>&1

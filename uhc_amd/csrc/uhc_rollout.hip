@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) uhc_rollout_act_kernel(int n_env, int T, 
     if (idx >= (long long)n_env * W) return;
     const int env = (int)(idx / W), j = (int)(idx % W);
     const long long t = t_dev[0];
+    if (t < 0 || t >= T) return;  // more steps than the pass was sized for: nothing is written
     if (j < obs_dim) {
         states[((size_t)env * T + t) * obs_dim + j] = state[(size_t)env * obs_dim + j];
         return;
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(1024) uhc_rollout_record_kernel(int n_env, int
     __shared__ double red[1024];
     const int tid = threadIdx.x;
     const long long t = t_dev[0];
+    if (t < 0 || t >= T) return;  // (uniform: every thread reads the same counter)
     const double er = end_reward[0];
     double acc[11];  // reward, up to 8 reward terms, two env counts (exact in float64)
     const int nacc = n_parts + 3;

@@ -225,8 +225,10 @@ class Agent:
     @torch.no_grad()
     def rollout_step(self):
         """One control step of every env: filter -> policy -> env.step -> buffers -> device-side restart of finished episodes.
-        Nothing here waits for the GPU: the only host read is the previous step's pinned snapshot."""
+        The host reads the previous step's pinned snapshot while the GPU computes this one, then waits for this step (see below)."""
         env, R = self.env, self._ro
+        if R.t >= R.T:
+            raise RuntimeError(f"rollout_step: the pass was begun for {R.T} steps")
         dev = env.device
         graphed = self.use_graph and dev.type == "cuda"
         if graphed and R.graphs is None and R.t >= 2:  # two eager steps first: library handles, allocator pools and the filter's device state exist
