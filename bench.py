@@ -104,7 +104,8 @@ def parse():
     p.add_argument("--workload", default="copycat", choices=["copycat", "ball_objects"],
                    help="copycat = configs[1] (the metric's config); ball_objects = configs[4] stand-in: ball-joint humanoid, self-collision, free boxes, torque actions (physics only)")
     p.add_argument("--objects", type=int, default=4, help="ball_objects: free boxes per env")
-    p.add_argument("--general-only", action="store_true", help="ball_objects: skip the fast kernel (uhc_batch_set_kernel_path)")
+    p.add_argument("--general-only", action="store_true", help="ball_objects: skip the fast kernel (uhc_batch_set_kernel_path 1)")
+    p.add_argument("--fixed-path", action="store_true", help="ball_objects: fast kernel then general kernel on every step (uhc_batch_set_kernel_path 0) instead of the adaptive default")
     p.add_argument("--no-pgs-probe", action="store_true", help="skip the short PGS (solver 0) kernel timings after the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
@@ -250,7 +251,7 @@ def bench_ball_objects(args):
     v0 = np.zeros((n_env, m.nv))
     v0[:, :75] = rng.normal(scale=0.2, size=(n_env, 75))
     sim = S.SimBatch(m, ctrl, n_env)
-    sim.set_kernel_path(args.general_only)
+    sim.set_kernel_path(1 if args.general_only else (0 if args.fixed_path else 2))
     q0d, v0d = torch.from_numpy(q0).cuda(), torch.from_numpy(v0).cuda()
     tb = torch.zeros(n_env, 69, dtype=torch.float64, device="cuda")
     gen = torch.Generator(device="cuda").manual_seed(11)
@@ -292,7 +293,7 @@ def bench_ball_objects(args):
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"configs[4] stand-in: ball-joint humanoid (nq {m.nq}, nv {m.nv}), self-collision on, {K} free 5 kg boxes, torque actions, {n_env} envs, "
-                                  "re-posed every 30 control steps; physics only", "envs_per_gpu": n_env, "objects": K, "kernel_path": "general only" if args.general_only else "fast, then general on the envs beyond its capacity",
+                                  "re-posed every 30 control steps; physics only", "envs_per_gpu": n_env, "objects": K, "kernel_path": "general only" if args.general_only else ("fast, then general on the envs beyond its capacity" if args.fixed_path else "adaptive (uhc_batch_set_kernel_path 2)"),
                       "contact_solver": "exact: active set in the fast kernel, working sets in the general kernel" if int(m.solver) == 1 else "pgs sweeps", "pgs_sweep_cap": int(m.iterations)},
            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true, true>", "kernel_ms": ms / max(k, 1), "launches": k,
                         "achieved": 8 * (2 * m.nq + 3 * m.nv + ctrl.action_dim + 7 * m.nbody) * n_env / (ms / max(k, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

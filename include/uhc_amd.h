@@ -150,8 +150,11 @@ int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
 
 /* Which kernel computes a step: 0 (default) = the fast kernel on every env, then the general kernel on the envs beyond its capacity
  * (UHC_F_REDO); 1 = the general kernel alone -- for scenes where most envs exceed 64 rows (objects, self-collision on the ground) the
- * first pass is wasted work.  Timing (uhc_batch_set_timing) brackets the kernel that runs first. */
-int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t general_only);
+ * first pass is wasted work; 2 = adaptive: the library switches between the two from the kernels' own counts (to the general kernel alone
+ * when > 60 % of the env-steps of an 8-step window were handed on, back when > 70 % of what it computed would have fitted the fast
+ * kernel), read with a fixed lag, so the same sequence of calls switches at the same step.  Timing (uhc_batch_set_timing) brackets the
+ * kernel that runs first. */
+int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode);
 
 /* switch the contact solver of the dual QP between launches: solver 0 / 1 and the sweep cap, as in UhcModelDesc (MuJoCo's opt.solver /
  * opt.iterations are run-time options too); iterations <= 0 keeps the current cap */

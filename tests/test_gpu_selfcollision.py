@@ -142,3 +142,56 @@ def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, li
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-5, worst
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0
+
+
+def test_adaptive_kernel_path_switches_with_the_scene(model, standing):
+    """uhc_batch_set_kernel_path(2): seven self-colliding humanoids standing on the floor (> 64 rows each) and one in the air.  While the
+    fast kernel runs first, the airborne env is its own (UHC_F_REDO 0); after the decision window the library skips the fast kernel and
+    the airborne env too is computed by the general one (UHC_F_REDO 1); with everybody in the air it goes back.  The states follow the
+    oracle through both switches.  (Every step restarts from the same states, so the scene stays what it is.)"""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import self_collision_variant
+    from uhc_amd.sim import make_ctrl
+    if os.environ.get("UHC_FORCE_GENERAL") == "1":
+        pytest.skip("the batch has no fast kernel to switch from")
+    sc = dataclasses.replace(self_collision_variant(model), solver=1)
+    ctrl = make_ctrl(sc)
+    n = 8
+    rng = np.random.default_rng(61)
+    qpos = np.tile(standing["qpos"], (n, 1))
+    qpos[:, 7:] += rng.normal(scale=0.002, size=(n, 69))
+    qpos[7, 2] += 50.0
+    qvel = rng.normal(scale=0.01, size=(n, 75))
+    b = S.SimBatch(sc, ctrl, n)
+    b.set_kernel_path(2)
+    os_ = [OracleSim(sc, ctrl) for _ in range(n)]
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    act = np.zeros((n, ctrl.action_dim))
+    a = torch.from_numpy(act).cuda()
+
+    def steps(q, k):
+        worst, hist = 0.0, []
+        for _ in range(k):
+            b.set_state(torch.from_numpy(q), torch.from_numpy(qvel))
+            b.simulate(a, tb)
+            b.sync()
+            redo, gq = b.field(S.F_REDO).cpu().numpy().copy(), b.field(S.F_QPOS).cpu().numpy()
+            hist.append(redo)
+            for e in range(n):
+                os_[e].set_state(q[e], qvel[e])
+                os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])
+                worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+        return worst, np.array(hist)
+
+    w1, h1 = steps(qpos, 20)
+    assert (h1[0, :7] != 0).sum() >= 6 and h1[0, 7] == 0  # the standing envs are beyond the fast kernel, the airborne one is not
+    assert h1[-1, 7] != 0 and (h1[-1] != 0).all()  # ... and now the general kernel computes all of them
+    first = int(np.argmax(h1[:, 7] != 0))
+    assert 12 <= first <= 17, first  # decided at step 16 from the window that ended at step 11 (fixed lag: reproducible)
+    lifted = qpos.copy()
+    lifted[:, 2] += 50.0
+    w2, h2 = steps(lifted, 20)
+    assert (h2[0] != 0).all() and (h2[-1] == 0).all()  # airborne: back on the fast kernel
+    assert max(w1, w2) < 1e-9, (w1, w2)

@@ -133,6 +133,14 @@ struct UhcBatch {
     size_t lds_bytes = 0, lds_bytes_fast = 0;
     bool use_fast = true;
     bool general_only = false;
+    // uhc_batch_set_kernel_path(2): the library picks the path from the kernels' own counts (DevState::path_stats), read with a fixed
+    // lag of 4 control steps every 8 steps -- the same sequence of calls always switches at the same step
+    int path_mode = 0;
+    bool auto_general = false;
+    unsigned long long* h_stats = nullptr;  // pinned [8][3]
+    hipEvent_t st_ev[8] = {};
+    long long st_step = 0;
+    unsigned long long st_prev[3] = {0, 0, 0};
     std::vector<void*> allocs;
     int nM = 0;
     int* reset_mask = nullptr;
@@ -539,6 +547,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     const size_t E = n_env;
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
+    TRY(dalloc(b, 4, &S.path_stats));
     TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
@@ -574,6 +583,8 @@ extern "C" void uhc_batch_free(UhcBatch* b) {
     for (void* p : b->allocs) hipFree(p);
     for (auto& ev : b->ev_used) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& ev : b->ev_free) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (hipEvent_t e : b->st_ev) if (e) hipEventDestroy(e);
+    if (b->h_stats) hipHostFree(b->h_stats);
     if (b->own_stream) hipStreamDestroy(b->own_stream);
     delete b;
 }
@@ -592,9 +603,34 @@ extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {
     b->A.c.rfc_scale = s;
     return 0;
 }
-extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t general_only) {
+extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode) {
     if (!b) return fail("uhc_batch_set_kernel_path: null batch");
-    b->general_only = general_only != 0;
+    if (mode < 0 || mode > 2) return fail("uhc_batch_set_kernel_path: mode %d (0 fast then general, 1 general only, 2 adaptive)", mode);
+    b->general_only = mode == 1;
+    b->path_mode = mode;
+    b->auto_general = false;
+    if (mode == 2 && !b->h_stats) {
+        HIP_OK(hipSetDevice(b->device));
+        HIP_OK(hipHostMalloc((void**)&b->h_stats, sizeof(unsigned long long) * 8 * 3, hipHostMallocDefault));
+        for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&b->st_ev[k], hipEventDisableTiming));
+    }
+    b->st_step = 0;
+    return 0;
+}
+// adaptive path: snapshot the counters after this control step; every 8 steps decide from the snapshot taken 4 steps ago
+static int path_update(UhcBatch* b) {
+    const int slot = (int)(b->st_step % 8);
+    HIP_OK(hipMemcpyAsync(b->h_stats + 3 * slot, b->A.s.path_stats, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, b->stream));
+    HIP_OK(hipEventRecord(b->st_ev[slot], b->stream));
+    b->st_step++;
+    if (b->st_step % 8 != 0 || b->st_step < 8) return 0;
+    const int old = (int)((b->st_step - 5) % 8);  // the snapshot written after step st_step - 5 (0-based): long since landed
+    HIP_OK(hipEventSynchronize(b->st_ev[old]));
+    unsigned long long cur[3], d[3];
+    for (int k = 0; k < 3; k++) { cur[k] = b->h_stats[3 * old + k]; d[k] = cur[k] - b->st_prev[k]; b->st_prev[k] = cur[k]; }
+    const double env_steps = 8.0 * b->n_env;  // (the first window is 4 steps long: it only makes the thresholds harder to reach)
+    if (!b->auto_general) { if ((double)d[0] > 0.6 * env_steps) b->auto_general = true; }
+    else if (d[2] > 0 && (double)d[1] > 0.7 * (double)d[2]) b->auto_general = false;
     return 0;
 }
 extern "C" int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t iterations) {
@@ -617,7 +653,8 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (b->ev_free.empty()) { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
         else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
     }
-    if (b->use_fast && !b->general_only) {
+    const bool general = b->general_only || (b->path_mode == 2 && b->auto_general);
+    if (b->use_fast && !general) {
         HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env, b->stream));
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
@@ -628,6 +665,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
     }
+    if (mode == 0 && b->path_mode == 2 && b->use_fast) return path_update(b);
     return 0;
 }
 
@@ -686,7 +724,7 @@ extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, c
     HIP_OK(uhc_launch_set_state_masked(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, b->n_env, d_select, d_qpos, d_qvel, b->reset_mask, b->stream));
     // only the kinematics now (the reset observation reads body poses); the dynamics part of sim.forward() runs at the head of the
     // env's next step kernel (DevState::fresh), which saves a forward-pass-long launch per control step
-    const bool kf = b->use_fast && !b->general_only;
+    const bool kf = b->use_fast && !(b->general_only || (b->path_mode == 2 && b->auto_general));
     HIP_OK(uhc_launch_step(2, kf ? 1 : 0, &b->A, nullptr, nullptr, b->reset_mask, kf ? b->lds_bytes_fast : b->lds_bytes, b->stream));
     return 0;
 }

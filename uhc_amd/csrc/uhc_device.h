@@ -87,6 +87,8 @@ struct DevState {  // HBM, env-major
     int* fresh;  // 1: the env was restarted on the device (set_state done, kinematics refreshed); its mj_forward runs at the head of its next step
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)
+    unsigned long long* path_stats;  // running counts of control steps (MODE 0): [0] envs the fast kernel handed on, [1] envs the general kernel
+                                     // computed that would have fitted the fast one, [2] envs the general kernel computed (uhc_batch_set_kernel_path 2)
     const double* model_blob;
 };
 

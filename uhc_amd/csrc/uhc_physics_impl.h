@@ -1713,6 +1713,8 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         const double bq = valid ? row.b : 0.0;
         // initial guess of the free set: the rows UHC_AS_PRESWEEPS Gauss-Seidel sweeps from f = 0 leave with a force (cuts the
         // factorisation rounds from ~3.2 to ~2.1, from ~4.2 to ~2.6 on the 48+ row solves that set the launch time)
+        // (starting from the warm-start forces' support instead was measured: 2.14 factorisations instead of 2.01 and costlier
+        //  rounds, 3.60 -> 3.88 ms per launch)
         bool f0;
         {
             double Br[UHC_WAVE];
@@ -2321,7 +2323,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
-    bool ran = false;
+    bool ran = false, fits = true;  // fits (general kernel): every substep of this step was within the fast kernel's capacity
     PROF_DECL
     if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
         k_kinematics<FAST>(A, mb, S, BC PROF_PASS);
@@ -2363,6 +2365,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             overflow |= fo.overflow;
             if (FAST && (overflow & 1)) break;
             if (!FAST && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
+            if (!FAST) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= UHC_FAST_MAXCON &&
+                              (!(DENSE && A.ndense_g > 0) || ((const int*)(S + L.ncon_nefc))[2] <= UHC_FAST_MAXTWO);
             ran = true;
             if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
                 wsync();
@@ -2379,7 +2383,10 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         }
     }
     if (FAST && (overflow & 1)) {  // nothing committed: the general kernel redoes this env from the same inputs
-        if (LANE == 0) A.s.redo[env] = 1;
+        if (LANE == 0) {
+            A.s.redo[env] = 1;
+            if (MODE == 0) atomicAdd(A.s.path_stats, 1ull);
+        }
         return;
     }
     // ---- store state
@@ -2425,7 +2432,11 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         A.s.fail[env] = fail;
         if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
-        if (!FAST) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | swept;  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
+        if (!FAST) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | swept;
+        if (!FAST && MODE == 0) {
+            atomicAdd(A.s.path_stats + 2, 1ull);
+            if (fits) atomicAdd(A.s.path_stats + 1, 1ull);
+        }  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
     }
 }
 

@@ -96,9 +96,10 @@ class SimBatch:
         True: they keep what fits (reported in F_EFC_OVERFLOW) and no second pass is needed."""
         check(self.L.uhc_batch_set_overflow_mode(self._b, int(bool(truncate))))
 
-    def set_kernel_path(self, general_only: bool):
-        """True: every env goes straight to the general kernel (scenes where most envs exceed the fast kernel's 64 rows)."""
-        check(self.L.uhc_batch_set_kernel_path(self._b, int(bool(general_only))))
+    def set_kernel_path(self, mode):
+        """0 / False: fast kernel, then the general kernel on the envs beyond its capacity; 1 / True: the general kernel alone (scenes where
+        most envs exceed the fast kernel's 64 rows); 2: adaptive -- the library switches between the two from the kernels' own counts."""
+        check(self.L.uhc_batch_set_kernel_path(self._b, int(mode)))
 
     def set_solver(self, solver: int, iterations: int = 0):
         """Contact solver of the following launches: 0 = PGS sweeps (cap `iterations`), 1 = exact active-set solve."""
