@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UHC_ABI_VERSION 5
+#define UHC_ABI_VERSION 6
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };

@@ -16,6 +16,11 @@ POISON_LIB = os.path.join(ROOT, "uhc_amd", "csrc", "libuhc_amd_poison.so")
 def test_parity_holds_with_poisoned_lds():
     if os.environ.get("UHC_LIB"):
         pytest.skip("already running against an alternative library")
+    import ctypes
+    from uhc_amd import _lib
+    dbg = ctypes.CDLL(POISON_LIB)
+    if any(not hasattr(dbg, sym) for sym in _lib.SYMBOLS) or dbg.uhc_abi_version() != _lib.lib().uhc_abi_version():
+        pytest.skip("debug library is older than the sources (python tools/poison_build.py)")
     env = dict(os.environ, UHC_LIB=POISON_LIB)
     sel = ["tests/test_gpu_physics.py", "tests/test_gpu_selfcollision.py", "tests/test_gpu_ball.py", "tests/test_gpu_behaviour.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "--tb=short", "-m", "gpu"] + sel, cwd=ROOT, env=env,
