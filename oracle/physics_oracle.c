@@ -910,11 +910,11 @@ void orc_solve_pgs(const UhcModelDesc* m, OrcData* d) {
  * primal, which reaches the same optimum): block principal pivoting (Judice & Pires 1994; Kim & Park 2011 for NNLS).
  * F = rows allowed a positive force.  Solve A_FF f_F = -b_F, f = 0 elsewhere, y = A f + b; a row is infeasible when
  * f < 0 (in F) or y < 0 (outside F).  Flip all infeasible rows while their number keeps falling (3 grace rounds), otherwise
- * only the highest-index one (finite for symmetric positive definite A).  Start: F = the rows with a force after 8 sweeps.
+ * only the highest-index one (finite for symmetric positive definite A).  Start: F = the rows with a force after ORC_AS_PRESWEEPS sweeps.
  * The elimination works on the whole nefc x nefc matrix with the rows outside F replaced by identity rows, in the order
  * k = 0 .. nefc-1 and without pivoting -- the same order the device kernel uses. */
 #define ORC_AS_MAXIT 64
-#define ORC_AS_PRESWEEPS 8
+#define ORC_AS_PRESWEEPS 16
 static int solve_masked(int n, const double* A, const double* b, const unsigned char* F, double* W, double* f) {
     /* Gaussian elimination on [A_FF | -b_F], rows / columns outside F skipped; back substitution */
     double* c = W + (size_t)n * n;

@@ -1500,7 +1500,7 @@ __device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, d
 }
 
 // Exact solve of the dual QP  min 1/2 f'Af + f'b, f >= 0  by block principal pivoting (UhcModelDesc.solver == 1; the oracle's
-// orc_solve_active_set is the same algorithm).  F = rows allowed a positive force, start F = the rows that 8 Gauss-Seidel
+// orc_solve_active_set is the same algorithm).  F = rows allowed a positive force, start F = the rows that UHC_AS_PRESWEEPS Gauss-Seidel
 // sweeps from f = 0 leave with a force (k_pgs_fast).  One iteration:
 //   1. W <- A (from the AGPR-parked rows), c <- -b; Gaussian elimination over the steps k in F, lane = row: the pivot row k is
 //      broadcast entry by entry (two v_readlane each), every row i > k of F subtracts l_ik times it.  Rows outside F keep l = 0,
@@ -1511,7 +1511,8 @@ __device__ __forceinline__ int pgs_sweeps(double (&Brow)[UHC_WAVE], double& f, d
 // Everything is unrolled over static register indices; a step whose row is not in F, and column chunks beyond nefc, are skipped
 // by uniform branches.  Returns the number of factorisations, or -1 (pivot breakdown / no convergence: the caller runs the sweeps).
 #define UHC_AS_MAXIT 64
-#define UHC_AS_PRESWEEPS 8
+#define UHC_AS_PRESWEEPS 16  // measured on the bench workload: 2 / 4 / 6 / 8 / 12 / 16 / 20 / 24 / 32 sweeps -> 3.80 / 3.69 / 3.64 / 3.62 / 3.58 / 3.55 / 3.56 / 3.57 / 3.59 ms per launch
+                             // (2.57 ... 1.39 factorisations per solve: a sweep is cheaper than the factorisation rounds it saves, up to a point)
 // NC = nefc rounded up to 8: the unrolled loops stop there.  (Testing the column range at run time instead -- a uniform branch per
 // chunk of 8 columns -- costs ~70 cycles per branch with one wave per SIMD, 40% of the elimination: tools/ubench/elim.hip.)
 template <int NC>
@@ -1712,7 +1713,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         double fx = 0.0;
         const double bq = valid ? row.b : 0.0;
         // initial guess of the free set: the rows UHC_AS_PRESWEEPS Gauss-Seidel sweeps from f = 0 leave with a force (cuts the
-        // factorisation rounds from ~3.2 to ~2.1, from ~4.2 to ~2.6 on the 48+ row solves that set the launch time)
+        // factorisation rounds from ~3.2 to ~1.7)
         // (starting from the warm-start forces' support instead was measured: 2.14 factorisations instead of 2.01 and costlier
         //  rounds, 3.60 -> 3.88 ms per launch)
         bool f0;
