@@ -84,3 +84,10 @@ if __name__ == "__main__":
     for k, nm in enumerate(NAMES):
         if p[:, k].mean() > 0:
             print(f"  {nm:26s} {p[:, k].mean():12.0f} cycles/env-step  {100 * p[:, k].mean() / tot.mean():5.1f}%")
+    # a launch lasts as long as its slowest env: the same breakdown for the slowest 1 % of the envs (top-level stages only)
+    top = p[:, :16].sum(1)
+    slow = np.argsort(top)[-max(n_env // 100, 1):]
+    print(f"slowest 1% of the envs: {top[slow].mean():.0f} cycles/env-step in the top-level stages (all envs: {top.mean():.0f}); nefc of their last step: {b.field(S.F_NEFC)[torch.from_numpy(slow).cuda()].tolist()}")
+    for k, nm in enumerate(NAMES):
+        if p[:, k].mean() > 0:
+            print(f"  {nm:26s} {p[slow, k].mean():12.0f} cycles/env-step  x{p[slow, k].mean() / max(p[:, k].mean(), 1):.2f} of the mean")
