@@ -130,6 +130,21 @@ def test_zfilter_weighted_batch_push_equals_row_pushes():
     np.testing.assert_allclose(a.rs.var, b.rs.var, rtol=1e-10)
 
 
+def test_zfilter_out_and_step_counter_host_path():
+    """ZFilter(x, out=, step_counter=) -- the rollout's last op of a step -- on host tensors (the framework path): same numbers as the
+    plain call, written in place, counter advanced by one."""
+    import torch
+    from uhc_amd.khrylib.utils.zfilter import ZFilter
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.normal(size=(12, 7)) * 2 - 1)
+    a, b = ZFilter((7,), clip=5), ZFilter((7,), clip=5)
+    want = a(x)
+    out, t = torch.zeros_like(x), torch.zeros(1, dtype=torch.long)
+    got = b(x, out=out, step_counter=t)
+    assert got is out and torch.equal(out, want) and int(t) == 1 and a.rs.n == b.rs.n == 12
+    assert torch.equal(b(x, update=False, out=out, step_counter=t), a(x, update=False)) and int(t) == 2 and b.rs.n == 12
+
+
 def test_dataset_sampling_interface():
     import random
     from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle
