@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from uhc_amd import rollout_ops
+from uhc_amd import sim as _S  # field ids of the library's views
 
 from ..core import LoggerRL, PolicyGaussian, estimate_advantages, linear
 from ...utils.torch import to_test, to_train
@@ -182,8 +183,8 @@ class Agent:
         env.sim.use_current_stream()  # the library's launches below go to the stream this runs (or is being captured) on
         if rollout_ops.usable(env.reward, env.obs, R.rewards, R.dones, R.state, R.c_info_sum) and env.done.dtype == torch.int32:
             # device float64: six launches of the library (+ the restart's) instead of ~50 framework ones
-            rollout_ops.record(t, env.reward, env.done, env.env.field(5), R.end_reward_dev, env.env.field(2), int(R.c_info_sum.numel()), R.rewards, R.dones,
-                               R.c_reward_sum, R.c_info_sum, env.sim.field(16), R.redo_counts)
+            rollout_ops.record(t, env.reward, env.done, env.env.field(_S.E_END), R.end_reward_dev, env.env.field(_S.E_REWARD_PARTS), int(R.c_info_sum.numel()), R.rewards, R.dones,
+                               R.c_reward_sum, R.c_info_sum, env.sim.field(_S.F_REDO), R.redo_counts)
             if self.running_state is not None:
                 self.running_state.rs.push_batch(env.obs, weights=env.done)  # the finished episodes' last observations (agent.py:77-79)
             env.auto_reset()
@@ -193,14 +194,14 @@ class Agent:
                 R.state.copy_(env.obs)
                 t.add_(1)
             return
-        redo = env.sim.field(16)  # UHC_F_REDO: which envs the general kernel computed / solved by sweeps in this step (diagnostics)
+        redo = env.sim.field(_S.F_REDO)  # UHC_F_REDO: which envs the general kernel computed / solved by sweeps in this step (diagnostics)
         R.redo_counts[0] += (redo != 0).sum()
         R.redo_counts[1] += ((redo & 2) != 0).sum()
         r = env.reward.to(self.dtype)
         R.c_reward_sum.add_(r.sum())  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
         if self.running_state is not None:
             self.running_state.rs.push_batch(env.obs.to(self.dtype), weights=env.done)  # the restart below overwrites those rows
-        r = r + env.env.field(5).to(self.dtype) * R.end_reward_dev  # info["end"] * end_reward (agent.py:84-85); 0 when switched off
+        r = r + env.env.field(_S.E_END).to(self.dtype) * R.end_reward_dev  # info["end"] * end_reward (agent.py:84-85); 0 when switched off
         R.rewards.index_copy_(1, t, r.unsqueeze(1))
         R.dones.index_copy_(1, t, env.done.to(self.dtype).unsqueeze(1))  # masks = 1 - dones and exps = 1 - mean_flags are formed at the end of the pass
         R.c_info_sum.add_(env.reward_parts.sum(0))
@@ -245,7 +246,7 @@ class Agent:
             self._seg_post()
         slot = R.t & 1
         self._drain_snapshot(slot)  # the snapshot written two steps ago (its buffer is reused now)
-        R.snap_host[slot].copy_(env.env.field(12), non_blocking=True)
+        R.snap_host[slot].copy_(env.env.field(_S.E_SNAPSHOT), non_blocking=True)
         if dev.type == "cuda":
             R.snap_event[slot] = torch.cuda.Event()
             R.snap_event[slot].record()
