@@ -508,6 +508,36 @@ def test_mpr_is_rotation_and_translation_covariant():
     np.testing.assert_allclose(p1, Rw.apply(p0) + tw, atol=1e-5)
 
 
+def test_mpr_on_round_hulls_finds_the_overlap_along_the_centre_line():
+    """Two 52-vertex polyhedral 'spheres' (Fibonacci points + the two poles of the centre line) overlapping by d: the penetration
+    direction is the centre line (to the faceting, a few degrees), the depth is d (the poles are exact support points along it), the
+    contact point lies on the centre line inside the lens -- for three directions in space."""
+    from oracle.physics import OracleSim
+    from tests.helpers import TWO_BOX_XML, hull_triangles
+    from uhc_amd.model.mjcf import compile_mjcf
+
+    def ball(r, u, n=50):
+        k = np.arange(n) + 0.5
+        phi, th = np.arccos(1 - 2 * k / n), np.pi * (1 + 5 ** 0.5) * k
+        p = np.c_[np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)]
+        p = p[np.abs(p @ u) < 0.995]  # make room for the exact poles
+        return r * np.r_[p, [u], [-u]]
+
+    ra, rb, d = 0.1, 0.07, 0.012
+    for u in (np.array([1.0, 0, 0]), np.array([0.0, 0.6, 0.8]), np.array([2.0, -1.0, 2.0]) / 3.0):
+        m = compile_mjcf(TWO_BOX_XML, meshes={"a": hull_triangles(ball(ra, u)), "b": hull_triangles(ball(rb, u))})
+        s = OracleSim(m)
+        ca = np.array([0.0, 0.0, 2.0])
+        cb = ca + (ra + rb - d) * u
+        s.set_state(np.r_[ca, 1, 0, 0, 0, cb, 1, 0, 0, 0], np.zeros(12))
+        assert s.geti("ncon") == 1
+        nrm, pos, dist = s.get("con_frame")[:3], s.get("con_pos"), s.get("con_dist")[0]
+        assert nrm @ u > np.cos(np.deg2rad(8.0)), (u, nrm)            # from geom 1 to geom 2, along the centre line
+        assert -d - 1e-5 <= dist <= -0.8 * d, (u, dist)               # never deeper than the true overlap; the facets may hide a little of it
+        t = (pos - ca) @ u
+        assert ra - d - 1e-3 <= t <= ra + 1e-3 and np.linalg.norm(pos - ca - t * u) < 0.03, (u, pos)
+
+
 def test_box_stacked_on_box_rests_and_carries_its_weight():
     """Two trees, a two-body contact row: the small box rests on the big one, the floor carries both weights, the box-box contact
     carries the upper weight (Newton's third law through J_b2 - J_b1)."""
