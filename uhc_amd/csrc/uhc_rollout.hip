@@ -162,10 +162,7 @@ __global__ void __launch_bounds__(1024) uhc_filter_merge_kernel(int dim, int R, 
         ntot = n;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (dim <= 0) return;
-        n_run[0] = ntot;
-    }
+    if (threadIdx.x == 0) n_run[0] = ntot;  // thread 0 owns column 0 (dim >= 1), so its ntot is the merged count
 }
 
 // ------------------------------------------------------------------ observation filter: normalise
