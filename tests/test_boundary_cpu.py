@@ -27,3 +27,28 @@ def test_reference_import_paths_resolve_to_this_build():
     import pytest
     with pytest.raises(ModuleNotFoundError):
         import uhc.no_such_module  # noqa: F401
+
+
+def test_bench_defaults_are_the_drivers_contract():
+    """`python bench.py` with no flags: one GPU, a step count that finishes in minutes, the metric's configuration (1 024 envs, exact
+    contact solve, float64 learner); the flags the driver passes exist."""
+    import importlib.util
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_cli", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.gpus == 1 and a.steps == 50 and a.warmup == 10 and a.envs == 1024 and a.workload == "copycat" and a.ppo_dtype == "float64"
+    assert a.solver is None and not a.general_only and not a.fixed_path and a.shapes == 0
+    sys.argv = ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    try:
+        b = bench.parse()
+    finally:
+        sys.argv = argv
+    assert (b.gpus, b.steps, b.warmup) == (8, 20, 5)
