@@ -18,6 +18,8 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("OMP_PROC_BIND", "close")  # cpu_baseline leg: pin the oracle's OpenMP threads (set before any OpenMP runtime loads)
+os.environ.setdefault("OMP_PLACES", "cores")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -120,7 +122,8 @@ def cpu_baseline(agent, n_env_gpu):
     import ctypes as C
     from oracle.physics import OracleSim, lib
     env = agent.env
-    cores = os.cpu_count() or 1
+    # the threads this process may actually run on (a cgroup / affinity-limited lease sees fewer than os.cpu_count() reports)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     frames = env.env._bank[0].cpu().numpy()
     starts = env.env._bank[1].cpu().numpy()
     L = lib()
@@ -152,9 +155,13 @@ def cpu_baseline(agent, n_env_gpu):
     v1, n1, s1 = run(8, 1, 5.0, 15)
     n = min(n_env_gpu, 4 * cores)
     vall, na, sa = run(n, cores, 10.0, 15)
-    return {"value": vall, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1_thread": v1,
-            "sample": f"{na} envs x {sa} physics control steps (15 substeps, PD + RFC) of the same clips on {cores} OpenMP threads, and {n1} envs x {s1} on one thread; "
-                      f"oracle/physics_oracle.c; MuJoCo itself is not installed"}
+    eff = vall / (cores * v1) if v1 > 0 else None
+    note = "" if eff is None or eff >= 0.5 else (f"; the all-thread run reaches only {eff:.2f} of {cores} x the one-thread rate: the lease's host threads are shared / SMT siblings, "
+                                                 "so `value` understates a dedicated host")
+    return {"value": vall, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1_thread": v1, "scaling_efficiency": eff,
+            "os_cpu_count": os.cpu_count(), "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
+            "sample": f"{na} envs x {sa} physics control steps (15 substeps, PD + RFC) of the same clips on {cores} OpenMP threads (sched_getaffinity), and {n1} envs x {s1} on one thread; "
+                      f"oracle/physics_oracle.c; MuJoCo itself is not installed" + note}
 
 
 def cpu_ppo_baseline(agent, batch):
@@ -226,7 +233,7 @@ def bench_ball_objects(args):
     humanoid, default_rng(11); random torque actions, every env re-posed every 30 control steps.  Physics only (uhc_batch_simulate):
     the quaternion observation / reward of that config are not built.  One JSON line, value = env-steps/s of this GPU."""
     import dataclasses
-    from tests.helpers import box_triangles
+    from uhc_amd.model.shapes import box_triangles
     from uhc_amd import sim as S
     from uhc_amd.model.mjcf import add_free_bodies, ball_variant, hinge_to_ball_qpos, self_collision_variant
     torch.cuda.set_device(0)
@@ -430,7 +437,8 @@ def main():
         n_samples = batch.states.shape[0] * world
         flops = n_samples * 503e6  # ~503 MFLOP per sample per iteration (10 epochs, both nets)
         ppo = {"samples": n_samples, "update_s": t_up, "samples_per_s": n_samples / t_up, "dtype": args.ppo_dtype, "epochs": cfg.num_optim_epoch,
-               "gemm_tflops": flops / t_up / 1e12, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
+               "gemm_tflops": flops / t_up / 1e12, "mfma_util": flops / t_up / 1e12 / (78.6 if args.ppo_dtype == "float64" else 157.3),
+               "mfma_peak_tflops": 78.6 if args.ppo_dtype == "float64" else 157.3, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
         if ncalls:  # rank 0's view of the gradient exchange: one flat all-reduce per network per optimisation step
             algbw = comm_bytes * ncalls / (comm_ms * 1e-3) / 1e9
             ppo["allreduce"] = {"calls": ncalls, "bytes_per_call": comm_bytes, "total_ms": comm_ms, "algbw_GBs": algbw,

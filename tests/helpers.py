@@ -1,32 +1,7 @@
 """Shared builders for tests (synthetic MJCF models written for this repo)."""
 import numpy as np
 
-BOX_TRIS = None
-
-
-def box_triangles(hx, hy, hz, center=(0, 0, 0)):
-    c = np.array(center, dtype=np.float64)
-    v = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64) + c
-    # vertex index = 4*ix + 2*iy + iz
-    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
-    tris = []
-    for a, b, cc, d in quads:
-        tris.append([v[a], v[b], v[cc]])
-        tris.append([v[a], v[cc], v[d]])
-    return np.array(tris)
-
-
-def prism_triangles(r, h):
-    """Upright prism over an equilateral triangle (circumradius r, half height h): its three bottom corners are mutual hull
-    neighbours, so it rests level on exactly three contacts."""
-    a = np.array([[r * np.cos(t), r * np.sin(t)] for t in (np.pi / 2, np.pi / 2 + 2 * np.pi / 3, np.pi / 2 + 4 * np.pi / 3)])
-    lo = [np.r_[p, -h] for p in a]
-    hi = [np.r_[p, h] for p in a]
-    tris = [[lo[0], lo[2], lo[1]], [hi[0], hi[1], hi[2]]]
-    for i in range(3):
-        j = (i + 1) % 3
-        tris += [[lo[i], lo[j], hi[j]], [lo[i], hi[j], hi[i]]]
-    return np.array(tris)
+from uhc_amd.model.shapes import box_triangles, hull_triangles, prism_triangles  # noqa: F401  (re-exported for the tests)
 
 
 PENDULUM_XML = """
@@ -71,17 +46,6 @@ def pendulum_model(length=0.5, half=0.05):
 def box_model(half=0.1):
     from uhc_amd.model.mjcf import compile_mjcf
     return compile_mjcf(BOX_ON_PLANE_XML, meshes={"box": box_triangles(half, half, half)})
-
-
-def hull_triangles(verts):
-    """Outward-oriented triangles of the convex hull of a vertex set (the compiled Model keeps hull vertices, not faces)."""
-    from scipy.spatial import ConvexHull
-    h = ConvexHull(verts)
-    tris = verts[h.simplices].copy()
-    n = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
-    flip = np.einsum("ij,ij->i", n, h.equations[:, :3]) < 0
-    tris[flip] = tris[flip][:, ::-1]
-    return tris
 
 
 def weld_statue(model, qpos, *, friction=None, extra_geom_attr=""):

@@ -309,3 +309,47 @@ def test_per_env_models_share_one_batch(model, ctrl, standing, kernel_path):
         np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-9)
         np.testing.assert_allclose(gm[e], os_[e].get("qM"), atol=1e-9)
     assert abs(gm[1, 0] / gm[0, 0] - 0.9 ** 3) < 1e-9  # total mass on the root translation scales with s^3
+
+
+def test_per_body_scaled_models_share_one_batch(model, ctrl, standing, kernel_path):
+    """configs[3] as `bench.py --shapes` builds it (scale_model_per_body: every body its own length scale, s ~ U(0.85, 1.15),
+    default_rng(7)): four differently proportioned humanoids + the stock one in one launch, GPU vs oracle over 10 control steps."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import kinematics_np, quat_to_mat, scale_model_per_body
+    rng = np.random.default_rng(7)
+    models = [model] + [scale_model_per_body(model, np.r_[1.0, rng.uniform(0.85, 1.15, size=model.nbody - 1)]) for _ in range(4)]
+
+    def lowest(m, q):
+        xp, xq, _, _ = kinematics_np(m, q)
+        return min((m.mesh_vert[m.geom_vertadr[g]:m.geom_vertadr[g] + m.geom_vertnum[g]] @ quat_to_mat(xq[m.geom_bodyid[g]]).T + xp[m.geom_bodyid[g]])[:, 2].min()
+                   for g in range(m.ngeom) if m.geom_type[g] == 7)
+
+    env_model = [0, 1, 2, 3, 4, 2, 4, 1]
+    n = len(env_model)
+    qpos, qvel = _states(standing, model, n, 11, noise=0.03, vel=0.1)
+    for e in range(n):  # a longer-legged body carries its root higher: keep the feet where the stock model has them
+        qpos[e, 2] += lowest(model, qpos[e]) - lowest(models[env_model[e]], qpos[e])
+    act = np.random.default_rng(12).normal(scale=0.1, size=(n, ctrl.action_dim))
+    b = S.SimBatch(models, ctrl, n, env_model=env_model)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(models[env_model[e]], ctrl) for e in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    ncon = 0
+    for t in range(10):
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])
+            ncon += os_[e].geti("ncon")
+    gq, gv, gm = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy(), b.field(S.F_QM).cpu().numpy()
+    assert ncon > 0  # the feet are on the ground: the per-model hull vertices and invweight0 constants are exercised, not only the tree
+    for e in range(n):
+        np.testing.assert_allclose(gq[e], os_[e].get("qpos"), atol=1e-9)
+        np.testing.assert_allclose(gv[e], os_[e].get("qvel"), atol=1e-7)
+        np.testing.assert_allclose(gm[e], os_[e].get("qM"), atol=1e-9)
+    assert np.abs(gm[1] - gm[0]).max() > 1e-3  # different bodies indeed

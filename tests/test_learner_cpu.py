@@ -264,3 +264,42 @@ def test_process_amass_raw_collects_action_files(tmp_path):
         for f, v in arrs.items():
             np.testing.assert_array_equal(db[k][f], v)
     assert len(ALL_SEQUENCES) == 19 and "DanceDB" in ALL_SEQUENCES
+
+
+# ---- data-parallel bookkeeping: the clip-success history and the end-reward mean are the same on every rank -----------
+def _freq_ranks(rank, world, port, out_dir):
+    import pickle
+    import types
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from uhc_amd.agents.agent_copycat import AgentCopycat
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ag = types.SimpleNamespace(freq_dict={"a": [[1.0, 0]], "b": []}, max_freq=4, device=torch.device("cpu"))  # shared history: one row of "a"
+    for name in ("_freq_add", "sync_freq_dict", "_global_mean"):
+        setattr(ag, name, types.MethodType(getattr(AgentCopycat, name), ag))
+    ag._freq_add("a", [[0.5 + rank, 10 * rank]])          # each rank's own rollout results
+    if rank == 0:
+        ag._freq_add("b", [[True, 0]] * 3)                 # rank 0's evaluation entries
+    ag.sync_freq_dict()
+    first = {k: list(v) for k, v in ag.freq_dict.items()}
+    ag._freq_add("a", [[0.25, 7 + rank]])
+    ag.sync_freq_dict()                                    # a second merge must not duplicate what is already common
+    mean = ag._global_mean(1.0 + rank, 10 * (rank + 1))    # weights 10, 20 -> (10 + 40) / 30
+    pickle.dump((first, ag.freq_dict, mean), open(os.path.join(out_dir, f"r{rank}.p"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_freq_dict_merge_and_reward_mean(tmp_path):
+    """only rank 0 evaluates and every rank appended its own rollout results, so the sampling distributions
+    drifted apart.  After sync_freq_dict every rank holds the same history: common base + every rank's new rows in rank order,
+    truncated to max_freq as the reference truncates (agent_copycat.py:598-604)."""
+    import pickle
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_freq_ranks, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (pickle.load(open(tmp_path / f"r{r}.p", "rb")) for r in (0, 1))
+    assert r0[0] == r1[0] and r0[1] == r1[1]
+    assert r0[0]["a"] == [[1.0, 0], [0.5, 0], [1.5, 10]] and r0[0]["b"] == [[True, 0]] * 3
+    assert r0[1]["a"] == [[0.5, 0], [1.5, 10], [0.25, 7], [0.25, 8]]  # last max_freq = 4 rows
+    assert r0[2] == pytest.approx(50.0 / 30.0) and r1[2] == pytest.approx(50.0 / 30.0)

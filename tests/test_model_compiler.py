@@ -130,3 +130,78 @@ def test_shape_to_model_generator_round_trip(model):
     import pytest
     with pytest.raises(FileNotFoundError):
         SMPLBody("/nonexistent")(np.zeros(10), 0)
+
+
+def test_export_mjcf_round_trips_through_the_compiler(model):
+    """export_mjcf (local coordinates, inline hull vertices; the form handed to a real MuJoCo in tests/test_mujoco_live.py) compiled
+    again gives the same model: exactly with the inertial numbers written out, to the hull-vs-STL difference when mass properties are
+    left to the reader (`density=`: the shipped STL hulls are convex only to ~1e-5 m)."""
+    from uhc_amd.model.mjcf import ball_variant, compile_mjcf, export_mjcf, self_collision_variant
+    for m in (self_collision_variant(model), ball_variant(model, damping=5.0)):
+        r = compile_mjcf(export_mjcf(m))
+        assert (r.nq, r.nv, r.nu, r.nbody, r.njnt, r.ngeom, r.nexclude) == (m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.nexclude)
+        for k in ("body_parentid", "dof_parentid", "dof_madr", "jnt_type", "geom_contype", "geom_conaffinity", "geom_condim", "actuator_dofid"):
+            np.testing.assert_array_equal(getattr(r, k), getattr(m, k), err_msg=k)
+        for k in ("body_pos", "body_quat", "body_mass", "body_inertia", "body_ipos", "jnt_pos", "jnt_axis", "jnt_range", "dof_armature", "dof_damping",
+                  "dof_invweight0", "body_invweight0", "qpos0", "geom_margin", "geom_solref", "geom_solimp", "geom_friction"):
+            np.testing.assert_allclose(getattr(r, k), getattr(m, k), atol=1e-12, err_msg=k)
+        np.testing.assert_allclose(np.asarray(r.actuator_gear).reshape(m.nu, -1)[:, :1 if m.actuator_gear.ndim == 1 else 3],
+                                   np.asarray(m.actuator_gear).reshape(m.nu, -1), atol=0)
+        assert np.array_equal(np.sort(r.exclude_pair, axis=1), np.sort(m.exclude_pair, axis=1))
+    d = compile_mjcf(export_mjcf(model, density=1000.0))
+    np.testing.assert_allclose(d.body_mass, model.body_mass, rtol=2e-3)
+    np.testing.assert_allclose(d.body_ipos, model.body_ipos, atol=1e-4)
+
+
+def _recompile_scaled(model, s):
+    """The per-body-scaled humanoid compiled FROM SCRATCH: hull of body b scaled by s_b about the body origin, bone offsets to its children
+    by s_b, densities unchanged -- through the MJCF exporter and the compiler, i.e. mass properties re-integrated from the scaled meshes
+    and the qpos0 constants recomputed, instead of the s^3 / s^5 shortcut of scale_model_per_body."""
+    m = model.copy()
+    par = np.asarray(model.body_parentid)
+    m.body_pos = model.body_pos * np.where(par > 0, s[par], 1.0)[:, None]
+    m.jnt_pos = model.jnt_pos * s[np.asarray(model.jnt_bodyid)][:, None]
+    mv = model.mesh_vert.copy()
+    for g in range(model.ngeom):
+        if model.geom_type[g] == mjcf.GEOM_MESH:
+            a, n = int(model.geom_vertadr[g]), int(model.geom_vertnum[g])
+            mv[a:a + n] *= s[model.geom_bodyid[g]]
+    m.mesh_vert = mv
+    return mjcf.compile_mjcf(mjcf.export_mjcf(m, density=1000.0))
+
+
+def test_scale_model_per_body_equals_a_recompile_of_the_scaled_meshes(model):
+    """configs[3] (`bench.py --shapes`, smpl_shape): scale_model_per_body's closed-form scaling (mass ~ s^3, inertia ~ s^5, offsets ~ s,
+    qpos0 constants recomputed) against a fresh compile of the scaled hulls.  The reference rebuilds the MuJoCo model from the new meshes
+    for every shape (uhc/envs/humanoid_im.py:154-190); the two must agree up to the hull-vs-STL difference of the baseline itself."""
+    from uhc_amd.model.mjcf import scale_model_per_body
+    rng = np.random.default_rng(7)
+    base = mjcf.compile_mjcf(mjcf.export_mjcf(model, density=1000.0))  # same route, unit scales: isolates the hull-vs-STL difference
+    for _ in range(3):
+        s = np.r_[1.0, rng.uniform(0.85, 1.15, size=model.nbody - 1)]
+        a, b = scale_model_per_body(base, s), _recompile_scaled(model, s)
+        np.testing.assert_allclose(a.body_pos, b.body_pos, atol=1e-12)
+        np.testing.assert_allclose(a.body_mass, b.body_mass, rtol=1e-9)
+        np.testing.assert_allclose(a.body_ipos, b.body_ipos, atol=1e-10)
+        np.testing.assert_allclose(a.body_inertia, b.body_inertia, rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(a.geom_rbound, b.geom_rbound, rtol=1e-9)
+        np.testing.assert_allclose(a.dof_invweight0, b.dof_invweight0, rtol=1e-7)
+        np.testing.assert_allclose(a.body_invweight0, b.body_invweight0, rtol=1e-7)
+        assert a.meaninertia == pytest.approx(b.meaninertia, rel=1e-9)
+        # principal frames agree as rotations (quaternion sign and the order of near-equal moments aside): compare the inertia tensors
+        for bd in range(1, model.nbody):
+            Ra, Rb = mjcf.quat_to_mat(a.body_iquat[bd]), mjcf.quat_to_mat(b.body_iquat[bd])
+            np.testing.assert_allclose(Ra @ np.diag(a.body_inertia[bd]) @ Ra.T, Rb @ np.diag(b.body_inertia[bd]) @ Rb.T, atol=1e-9)
+        # hull vertices: same sets (the recompile reorders them through qhull)
+        for g in range(model.ngeom):
+            if model.geom_type[g] == mjcf.GEOM_MESH:
+                va = a.mesh_vert[a.geom_vertadr[g]:a.geom_vertadr[g] + a.geom_vertnum[g]]
+                vb = b.mesh_vert[b.geom_vertadr[g]:b.geom_vertadr[g] + b.geom_vertnum[g]]
+                assert len(va) == len(vb)
+                np.testing.assert_allclose(va[np.lexsort(va.T)], vb[np.lexsort(vb.T)], atol=1e-12)
+    # and the mass-weighted identities the docstring promises, on the shipped asset itself
+    s = np.r_[1.0, rng.uniform(0.85, 1.15, size=model.nbody - 1)]
+    o = scale_model_per_body(model, s)
+    np.testing.assert_allclose(o.body_mass, model.body_mass * s ** 3, rtol=1e-14)
+    np.testing.assert_allclose(o.body_inertia, model.body_inertia * (s ** 5)[:, None], rtol=1e-14)
+    assert o.nq == model.nq and np.array_equal(o.dof_madr, model.dof_madr)

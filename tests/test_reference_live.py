@@ -30,11 +30,15 @@ def test_config_equals_reference_on_every_shipped_config():
     import yaml
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import ref_import
-    ref_import.install()
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
-    from uhc.utils.config_utils.copycat_config import Config as RefConfig
+    import uhc  # noqa: F401  -- this build's alias package on purpose: the comparison must survive it being imported first
+    with ref_import.reference_modules():
+        from uhc.utils.config_utils.copycat_config import Config as RefConfig
+        ref_import.assert_is_reference(RefConfig)
     from uhc_amd.utils.config_utils.copycat_config import Config as MyConfig
+    assert RefConfig is not MyConfig
+    assert os.path.realpath(RefConfig.__init__.__code__.co_filename).startswith(os.path.realpath(REF) + os.sep)
+    assert os.sep + "uhc_amd" + os.sep in os.path.realpath(MyConfig.__init__.__code__.co_filename)
+    assert sys.modules["uhc"] is uhc  # the alias is back for whoever runs after this test
     files = sorted(glob.glob(os.path.join(REF, "config", "**", "*.yml"), recursive=True))
     assert len(files) > 100
     compared = 0

@@ -19,6 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ref_import  # noqa: E402
 
 ref_import.install()
+import uhc as _ref_uhc  # noqa: E402
+
+ref_import.assert_is_reference(_ref_uhc)  # this repository also has a package called `uhc` (an alias of uhc_amd): never generate vectors from it
 import torch  # noqa: E402
 
 torch.set_default_dtype(torch.float64)  # scripts/train_uhc.py:80-81

@@ -2,6 +2,7 @@
 modules standing in for the third-party packages this image lacks (mujoco_py, gym, smplx, ...).
 Used by tools/gen_golden.py to produce input/output vectors and by tests/test_reference_live.py (skipped wherever
 /root/reference is absent); bench.py, the GPU tests and the package never import this."""
+import importlib
 import importlib.abc
 import importlib.machinery
 import os
@@ -81,3 +82,51 @@ def install():
     if REF not in sys.path:
         sys.path.insert(0, REF)
     os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+
+def assert_is_reference(obj):
+    """Fail unless `obj` (module, class or function) was loaded from a file under REF.  This repository ships an alias package that is
+    also called `uhc` (uhc/__init__.py -> uhc_amd); once it is in sys.modules a plain `from uhc... import X` silently yields this
+    build's own X and a "comparison with the reference" compares the build with itself."""
+    import inspect
+    mod = obj if isinstance(obj, types.ModuleType) else sys.modules[obj.__module__]
+    f = os.path.realpath(getattr(mod, "__file__", None) or inspect.getsourcefile(obj) or "")
+    root = os.path.realpath(REF) + os.sep
+    if not f.startswith(root):
+        raise AssertionError(f"{getattr(obj, '__name__', obj)!r} comes from {f!r}, not from the reference under {root!r}")
+    return obj
+
+
+class reference_modules:
+    """Context manager: inside it `import uhc...` resolves to the REFERENCE package, whatever was imported before.  Every `uhc` /
+    `uhc.*` entry of sys.modules (this build's alias modules, if a test imported them earlier) is set aside, the alias finder is
+    taken off sys.meta_path and REF goes to the front of sys.path; on exit the reference's modules are removed from sys.modules again
+    and the previous state is restored, so later tests that use the alias are not handed reference code either.  Objects imported
+    inside the block stay valid (they keep their modules alive)."""
+
+    def __enter__(self):
+        install()
+        self._saved = {k: v for k, v in sys.modules.items() if k == "uhc" or k.startswith("uhc.")}
+        for k in self._saved:
+            del sys.modules[k]
+        self._finders = [f for f in sys.meta_path if type(f).__name__ == "_AliasFinder"]
+        for f in self._finders:
+            sys.meta_path.remove(f)
+        self._path = list(sys.path)
+        sys.path[:] = [REF] + [p for p in sys.path if os.path.realpath(p or ".") != os.path.realpath(os.path.join(os.path.dirname(__file__), ".."))
+                               and p != REF]
+        importlib.invalidate_caches()
+        import uhc
+        assert_is_reference(uhc)
+        return self
+
+    def __exit__(self, *exc):
+        for k in [k for k in sys.modules if k == "uhc" or k.startswith("uhc.")]:
+            del sys.modules[k]
+        sys.modules.update(self._saved)
+        sys.path[:] = self._path
+        for f in self._finders:
+            if f not in sys.meta_path:
+                sys.meta_path.insert(0, f)
+        importlib.invalidate_caches()
+        return False

@@ -11,6 +11,7 @@ import time
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from ..data_loaders.dataset_amass_single import DatasetAMASSSingle
 from ..envs.humanoid_im import VecHumanoidEnv
@@ -182,9 +183,14 @@ class AgentCopycat(AgentPPO):
         self.policy_net.load_state_dict(cp["policy_dict"])
         self.value_net.load_state_dict(cp["value_dict"])
         rs = cp["running_state"]  # copied INTO the agent's filter: its device tensors are referenced by the captured rollout graphs
-        self.running_state.set_mean_std(np.asarray(rs.rs.mean), np.asarray(rs.rs._S), int(rs.rs.n))
-        self.running_state.demean, self.running_state.destd, self.running_state.clip = rs.demean, rs.destd, rs.clip
+        if rs is not None and self.running_state is not None:  # (the reference accepts checkpoints without a filter: the current one stays)
+            self.running_state.set_mean_std(np.asarray(rs.rs.mean), np.asarray(rs.rs._S), int(rs.rs.n))
+            self.running_state.demean, self.running_state.destd, self.running_state.clip = rs.demean, rs.destd, rs.clip
         to_device(self.device, self.policy_net, self.value_net)
+        # every rank has just loaded the same statistics: they are the shared base of the next merge, not new samples of this rank
+        # (only once the Agent base exists -- __init__ loads before it and marks the base itself)
+        if hasattr(self, "mark_running_state_shared") and hasattr(self, "env") and getattr(self, "_ro_cache", None) is not None:
+            self.mark_running_state_shared()
 
     def load_curr(self):
         self._load(f"{self.cfg.model_dir}/iter_best.p")
@@ -235,8 +241,7 @@ class AgentCopycat(AgentPPO):
     def on_episode_end(self, env_ids, percents, consumed=None):
         for n, (e, p) in enumerate(zip(env_ids, percents)):  # freq_dict[key].append([percent, fr_start]) (agent_copycat.py:559-565)
             k, s = self._env_key[int(e)]
-            self.freq_dict[k].append([float(p), s])
-            self.freq_dict[k] = self.freq_dict[k][-self.max_freq:]
+            self._freq_add(k, [[float(p), s]])
             if consumed is not None and consumed[n]:  # the env has moved on to its queued window
                 self._env_key[int(e)] = self._env_next[int(e)]
 
@@ -259,19 +264,53 @@ class AgentCopycat(AgentPPO):
         self.per_epoch_update(epoch)
         batch, log = self.sample(cfg.min_batch_size)
         if cfg.end_reward:
-            self.env.end_reward = log.avg_c_reward * cfg.gamma / (1 - cfg.gamma)
+            # one value on every rank (the sample-weighted mean over the ranks' logs), or the ranks' reward shaping drifts apart
+            self.env.end_reward = self._global_mean(log.avg_c_reward, log.num_steps) * cfg.gamma / (1 - cfg.gamma)
         t1 = time.time()
         self.update_params(batch)
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         t2 = time.time()
         info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
-        if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0 and getattr(self, "rank", 0) == 0:
-            self.save_checkpoint(epoch)
-            info["log_eval"] = self.eval_policy(epoch)  # rank 0 evaluates; the others meet it again at the next collective
+        if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0:
+            if getattr(self, "rank", 0) == 0:
+                self.save_checkpoint(epoch)
+                info["log_eval"] = self.eval_policy(epoch)  # rank 0 evaluates (the process group is created with a long timeout for this)
+        self.sync_freq_dict()  # every iteration, as the reference merges its workers' histories after every sample(); eval-driven entries included
         if getattr(self, "rank", 0) == 0:
             self.log_train(info)
         return info
+
+    def _global_mean(self, value, weight):
+        if not _dist_on():
+            return float(value)
+        dev = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([float(value) * float(weight), float(weight)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        return float(t[0].item() / max(t[1].item(), 1e-300))
+
+    def _freq_add(self, key, rows):
+        """freq_dict[key] += rows, remembered as this rank's contribution since the last merge (sync_freq_dict)."""
+        self.freq_dict[key] = (self.freq_dict[key] + rows)[-self.max_freq:]
+        new = self.__dict__.setdefault("_freq_new", {})
+        new[key] = (new.get(key, []) + rows)[-self.max_freq:]
+
+    def sync_freq_dict(self):
+        """Data-parallel runs: merge the per-clip success history of all ranks, as the reference merges its workers' (agent_copycat.py:
+        598-604: concatenate per key, keep the last `max_freq`), rank 0's evaluation entries included -- every rank then draws its next
+        windows from the same distribution.  Each rank contributes what it appended since the last merge; the history before that is
+        already common."""
+        if not _dist_on():
+            return
+        new = self.__dict__.setdefault("_freq_new", {})
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, new)
+        for k in self.freq_dict:
+            mine = len(new.get(k, []))
+            base = self.freq_dict[k][:len(self.freq_dict[k]) - mine] if mine else self.freq_dict[k]
+            add = [row for p in parts for row in p.get(k, [])]  # rank order: the same list on every rank
+            self.freq_dict[k] = (base + add)[-self.max_freq:]
+        self._freq_new = {}
 
     def log_train(self, info):
         log, cfg = info["log"], self.cfg
@@ -291,7 +330,7 @@ def _eval_policy(self, epoch=0, dump=False):
         cov = self.eval_seqs(loader.data_keys, loader)
         for k, res in cov.items():
             if k in self.freq_dict:
-                self.freq_dict[k] += [[res["succ"][0], 0]] * (1 if res["succ"][0] else 3)
+                self._freq_add(k, [[res["succ"][0], 0]] * (1 if res["succ"][0] else 3))
         m = defaultdict(list)
         for res in cov.values():
             for k, v in res.items():

@@ -526,7 +526,11 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
             name = me.attrib.get("name") or os.path.splitext(os.path.basename(f))[0]
             if name in mesh_tris:
                 continue
-            tri = load_binary_stl(os.path.join(asset_dir, f))
+            if f is None:  # inline vertices (what export_mjcf writes): the mesh is their convex hull [MJ-ext]
+                from .shapes import hull_triangles
+                tri = hull_triangles(_floats(me.attrib["vertex"]).reshape(-1, 3))
+            else:
+                tri = load_binary_stl(os.path.join(asset_dir, f))
             if "scale" in me.attrib:
                 tri = tri * _floats(me.attrib["scale"], 3)
             mesh_tris[name] = tri
@@ -581,6 +585,9 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
                 if e.tag == "freejoint":
                     e.attrib["type"] = "free"
                 bodies[parent_id]["joints"].append(parse_joint(e, parent_id))
+            elif e.tag == "inertial":
+                bodies[parent_id]["inertial"] = dict(pos=_floats(e.attrib.get("pos"), 3, [0, 0, 0]), quat=_floats(e.attrib.get("quat"), 4, [1, 0, 0, 0]),
+                                                     mass=float(e.attrib["mass"]), diag=_floats(e.attrib.get("diaginertia"), 3, [0, 0, 0]))
             elif e.tag == "body":
                 bid = len(bodies)
                 b = dict(name=e.attrib.get("name", f"body{bid}"), parent=parent_id,
@@ -802,8 +809,17 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
     m.mesh_adj = np.concatenate(adj_idx).astype(np.int32) if all_verts else np.zeros(0, dtype=np.int32)
     m.nmeshadj = abase
 
+    ifg = comp.get("inertiafromgeom", "auto")
     for bid in range(1, m.nbody):
         a = acc[bid]
+        ine = bodies[bid].get("inertial")
+        if ine is not None and ifg in ("false", "auto"):  # [MJ-ext] explicit <inertial> wins unless inertiafromgeom="true"
+            if global_coord:
+                Rb = quat_to_mat(bodies[bid]["wquat"])
+                ine = dict(ine, pos=Rb.T @ (ine["pos"] - bodies[bid]["wpos"]), quat=quat_mul(quat_conj(bodies[bid]["wquat"]), ine["quat"]))
+            m.body_mass[bid], m.body_ipos[bid] = ine["mass"], ine["pos"]
+            m.body_iquat[bid], m.body_inertia[bid] = ine["quat"] / np.linalg.norm(ine["quat"]), ine["diag"]
+            continue
         if a["mass"] <= 0:
             raise ValueError(f"body '{bodies[bid]['name']}' has no mass (inertiafromgeom needs a geom)")
         com = a["mc"] / a["mass"]
@@ -1107,3 +1123,83 @@ def scale_model_per_body(m: Model, scales) -> Model:
     o.qpos_spring = o.qpos0.copy()
     set_const(o)
     return o
+
+
+def export_mjcf(m: Model, density: Optional[float] = None) -> str:
+    """The compiled model written back as MJCF in LOCAL coordinates (the reference's assets use `coordinate="global"`, which MuJoCo
+    dropped after 2.x; this is the build's global -> local rewrite in file form).  Meshes are inlined as `vertex=` lists (body frame);
+    MuJoCo takes their convex hull itself.  With `density` the bodies' inertial properties are left to the reader of the file
+    (inertiafromgeom: what the reference's models do, density 1000); without, they are written out as `<inertial>` elements.
+    Used to hand a model to a real MuJoCo where one is installed (tests/test_oracle_physics.py: the `import mujoco` comparison) and
+    as the on-disk form of per-shape models."""
+    f = lambda a: " ".join(repr(float(x)) for x in np.asarray(a).ravel())
+    out = ['<mujoco model="uhc_amd_export">', '  <compiler angle="radian" inertiafromgeom="%s"/>' % ("true" if density is not None else "false"),
+           f'  <option timestep="{m.timestep!r}" gravity="{f(m.gravity)}" iterations="{int(m.iterations)}" tolerance="{m.tolerance!r}"/>',
+           '  <size njmax="2500" nconmax="500"/>', "  <asset>"]
+    for g in range(m.ngeom):
+        if m.geom_type[g] == GEOM_MESH:
+            a, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
+            out.append(f'    <mesh name="mesh{g}" vertex="{f(m.mesh_vert[a:a + n])}"/>')
+    out += ["  </asset>", "  <worldbody>"]
+    children: List[List[int]] = [[] for _ in range(m.nbody)]
+    for b in range(1, m.nbody):
+        children[int(m.body_parentid[b])].append(b)
+    gtype = {GEOM_PLANE: "plane", GEOM_SPHERE: "sphere", GEOM_BOX: "box", GEOM_MESH: "mesh"}
+
+    def geoms_of(b, ind):
+        for g in range(m.ngeom):
+            if int(m.geom_bodyid[g]) != b:
+                continue
+            t = int(m.geom_type[g])
+            s = (f'{ind}<geom name="{m.geom_names[g] or "geom%d" % g}" type="{gtype[t]}" contype="{int(m.geom_contype[g])}" '
+                 f'conaffinity="{int(m.geom_conaffinity[g])}" condim="{int(m.geom_condim[g])}" friction="{f(m.geom_friction[g])}" '
+                 f'margin="{float(m.geom_margin[g])!r}" gap="{float(m.geom_gap[g])!r}" solref="{f(m.geom_solref[g])}" solimp="{f(m.geom_solimp[g])}"')
+            if t == GEOM_MESH:
+                s += f' mesh="mesh{g}"'
+            else:
+                s += f' pos="{f(m.geom_pos[g])}" quat="{f(m.geom_quat[g])}" size="{f(m.geom_size[g])}"'
+            if density is not None and b > 0:
+                s += f' density="{float(density)!r}"'
+            out.append(s + "/>")
+
+    def emit(b, ind):
+        out.append(f'{ind}<body name="{m.body_names[b]}" pos="{f(m.body_pos[b])}" quat="{f(m.body_quat[b])}">')
+        if density is None:
+            out.append(f'{ind}  <inertial pos="{f(m.body_ipos[b])}" quat="{f(m.body_iquat[b])}" mass="{float(m.body_mass[b])!r}" '
+                       f'diaginertia="{f(m.body_inertia[b])}"/>')
+        ja, jn = int(m.body_jntadr[b]), int(m.body_jntnum[b])
+        for j in range(ja, ja + max(jn, 0)):
+            t, d = int(m.jnt_type[j]), int(m.jnt_dofadr[j])
+            name = m.joint_names[j] or f"joint{j}"
+            if t == JNT_FREE:
+                out.append(f'{ind}  <joint name="{name}" type="free" armature="{float(m.dof_armature[d])!r}" damping="{float(m.dof_damping[d])!r}"/>')
+                continue
+            kind = {JNT_BALL: "ball", JNT_SLIDE: "slide", JNT_HINGE: "hinge"}[t]
+            out.append(f'{ind}  <joint name="{name}" type="{kind}" pos="{f(m.jnt_pos[j])}" axis="{f(m.jnt_axis[j])}" '
+                       f'limited="{"true" if m.jnt_limited[j] else "false"}" range="{f(m.jnt_range[j])}" armature="{float(m.dof_armature[d])!r}" '
+                       f'damping="{float(m.dof_damping[d])!r}" frictionloss="{float(m.dof_frictionloss[d])!r}" stiffness="{float(m.jnt_stiffness[j])!r}" '
+                       f'margin="{float(m.jnt_margin[j])!r}"/>')
+        geoms_of(b, ind + "  ")
+        for c in children[b]:
+            emit(c, ind + "  ")
+        out.append(f"{ind}</body>")
+
+    geoms_of(0, "    ")
+    for c in children[0]:
+        emit(c, "    ")
+    out.append("  </worldbody>")
+    if m.nexclude:
+        out.append("  <contact>")
+        for a, b in np.asarray(m.exclude_pair).reshape(-1, 2):
+            out.append(f'    <exclude body1="{m.body_names[int(a)]}" body2="{m.body_names[int(b)]}"/>')
+        out.append("  </contact>")
+    if m.nu:
+        out.append("  <actuator>")
+        for a in range(m.nu):
+            j = int(m.dof_jntid[int(m.actuator_dofid[a])])
+            gear = np.atleast_1d(np.asarray(m.actuator_gear[a], dtype=np.float64))
+            gs = f(gear) + " 0 0 0" if m.jnt_type[j] == JNT_BALL else repr(float(gear[0]))
+            out.append(f'    <motor name="{m.actuator_names[a] or "motor%d" % a}" joint="{m.joint_names[j] or "joint%d" % j}" gear="{gs}"/>')
+        out.append("  </actuator>")
+    out.append("</mujoco>")
+    return "\n".join(out) + "\n"
