@@ -195,3 +195,61 @@ def test_adaptive_kernel_path_switches_with_the_scene(model, standing):
     w2, h2 = steps(lifted, 20)
     assert (h2[0] != 0).all() and (h2[-1] == 0).all()  # airborne: back on the fast kernel
     assert max(w1, w2) < 1e-9, (w1, w2)
+
+
+def test_lying_humanoid_among_boxes_exceeds_128_rows(model, standing):
+    """The reference's models ask MuJoCo for njmax 2500 / nconmax 500 (uhc/khrylib/mocap/skeleton_mesh.py:46).  A self-colliding
+    humanoid lying face down among four boxes has 100-150 constraint rows: beyond the general tier (128 rows / 64 contacts), so the env is
+    handed to the large tier (256 rows, UHC_F_REDO bit 6) instead of losing constraints.  GPU vs oracle over 12 control steps, and
+    nothing is dropped (UHC_F_EFC_OVERFLOW stays clear)."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    m = self_collision_variant(model)
+    poses = np.array([[0.6, 0.3, 0.16, 1, 0, 0, 0], [-0.6, 0.2, 0.16, 1, 0, 0, 0], [0.1, 0.9, 0.16, 1, 0, 0, 0], [0.0, -0.7, 0.16, 1, 0, 0, 0]], dtype=np.float64)
+    m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * 4, poses, density=5.0 / 0.027)
+    m = dataclasses.replace(m, solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n = 3
+    rng = np.random.default_rng(3)
+    q = np.tile(m.qpos0, (n, 1))
+    for e in range(n):
+        qh = standing["qpos"].copy()
+        qh[7:] += rng.normal(scale=0.05 * e, size=69)
+        a = np.pi / 2 + 0.1 * e
+        qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])  # tipped forward: face down
+        qh[2] = 0.25
+        q[e, :76] = qh
+    v = np.zeros((n, m.nv))
+    b = S.SimBatch(m, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    os_ = [OracleSim(m, ctrl) for _ in range(n)]
+    redo = b.field(S.F_REDO).cpu().numpy()
+    for e in range(n):
+        os_[e].desc.solver = 0 if (redo[e] & 2) else 1
+        os_[e].set_state(q[e], v[e])
+        os_[e].desc.solver = 1
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    worst, big_steps, max_nefc = 0.0, 0, 0
+    for t in range(12):
+        act = rng.normal(scale=0.003, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        nefc = b.field(S.F_NEFC).cpu().numpy()
+        for e in range(n):
+            os_[e].do_simulation(act[e], np.zeros(69), redo=redo[e])
+            assert nefc[e] == os_[e].geti("nefc"), (t, e, nefc[e], os_[e].geti("nefc"))
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+            big_steps += int((redo[e] & 0x40) != 0)
+            max_nefc = max(max_nefc, os_[e].geti("max_nefc"))
+    print(f"lying humanoid + 4 boxes: max nefc {max_nefc}, env-steps in the large tier {big_steps} / {12 * n}, worst |dqpos| {worst:.2e}")
+    assert max_nefc > 128 and big_steps > 0
+    assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
+    assert worst < 1e-5, worst

@@ -20,17 +20,21 @@
     extern "C" hipError_t fn##_lds(size_t lds_bytes);
 UHC_DECL_LAUNCH(uhc_launch_m0_fast) UHC_DECL_LAUNCH(uhc_launch_m0_fast_dense) UHC_DECL_LAUNCH(uhc_launch_m1_fast) UHC_DECL_LAUNCH(uhc_launch_m1_fast_dense)
 UHC_DECL_LAUNCH(uhc_launch_m2_fast) UHC_DECL_LAUNCH(uhc_launch_m0_gen) UHC_DECL_LAUNCH(uhc_launch_m1_gen) UHC_DECL_LAUNCH(uhc_launch_m2_gen)
-// mode 0: control step, 1: forward only, 2: kinematics only; fast: the compact-LDS kernel; dense: the model has body-body contacts
-static hipError_t uhc_launch_step(int mode, int fast, const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active,
+UHC_DECL_LAUNCH(uhc_launch_m0_big) UHC_DECL_LAUNCH(uhc_launch_m1_big)
+// mode 0: control step, 1: forward only, 2: kinematics only; tier 1: the fast kernel, 2: general, 3: large; dense: the model has body-body contacts
+static hipError_t uhc_launch_step(int mode, int tier, const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active,
                                   size_t lds_bytes, hipStream_t stream) {
-    const bool dense = A->ndense_f > 0;
+    const bool dense = A->cf.ndense > 0;
+    const bool fast = tier == 1;
+    if (tier == 3) return (mode == 0 ? uhc_launch_m0_big : uhc_launch_m1_big)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (!fast) return (mode == 0 ? uhc_launch_m0_gen : mode == 1 ? uhc_launch_m1_gen : uhc_launch_m2_gen)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (mode == 2) return uhc_launch_m2_fast(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (mode == 0) return (dense ? uhc_launch_m0_fast_dense : uhc_launch_m0_fast)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     return (dense ? uhc_launch_m1_fast_dense : uhc_launch_m1_fast)(A, d_action, d_tbase, d_active, lds_bytes, stream);
 }
-static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast) {
+static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, size_t lds_bytes_big) {
     hipError_t e;
+    if (lds_bytes_big && ((e = uhc_launch_m0_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m1_big_lds(lds_bytes_big)) != hipSuccess)) return e;
     if ((e = uhc_launch_m0_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m1_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m2_gen_lds(lds_bytes)) != hipSuccess) return e;
     if ((e = uhc_launch_m0_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m0_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
     if ((e = uhc_launch_m1_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m1_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
@@ -130,7 +134,7 @@ struct UhcBatch {
     int n_env = 0, device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     KernelArgs A;
-    size_t lds_bytes = 0, lds_bytes_fast = 0;
+    size_t lds_bytes = 0, lds_bytes_fast = 0, lds_bytes_big = 0;
     bool use_fast = true;
     bool general_only = false;
     // uhc_batch_set_kernel_path(2): the library picks the path from the kernels' own counts (DevState::path_stats), read with a fixed
@@ -381,47 +385,25 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, dvec(ctrl->jkp), &C.jkp)); TRY(upload(b, dvec(ctrl->jkd), &C.jkd));
     TRY(upload(b, dvec(ctrl->torque_lim), &C.torque_lim)); TRY(upload(b, dvec(ctrl->a_scale), &C.a_scale));
 
-    // ---- LDS carve (doubles; every offset even => 16-byte aligned)
-    DevLds& L = A.l;
+    // ---- LDS carve (doubles; every offset even => 16-byte aligned).  Every tier's layout has a persistent part (state, the factor of M,
+    //      body poses, cdof) and ONE region shared by the dynamics temporaries (first half of a forward pass) and the constraint data
+    //      (second half).  M itself is parked in registers between substeps (MPark), so no tier keeps a second copy in LDS.
     int off = 0;
     auto carve = [&](int n) { int o = off; off += (n + 1) & ~1; return o; };
-    L.qpos = carve(d.nq); L.qvel = carve(nv); L.qacc = carve(nv); L.ctrl = carve(d.nu); L.applied = carve(nv);
-    L.xpos = carve(3 * nb); L.xquat = carve(4 * nb); L.xmat = carve(9 * nb); L.xipos = carve(3 * nb); L.ximat = carve(9 * nb);
-    L.rootcom = carve(3 * nb); L.cinert = carve(10 * nb); L.crb = carve(10 * nb); L.cvel = carve(6 * nb);
-    L.cacc = carve(6 * nb); L.cfrc = carve(6 * nb);
-    L.xanchor = carve(3 * nj); L.xaxis = carve(3 * nj); L.cdof = carve(6 * nv); L.cdofdot = carve(6 * nv);
-    L.M = carve(T.nM); L.LD = carve(T.nM + 2); L.dinv = carve(nv); L.sdinv = carve(nv); L.bias = carve(nv); L.smooth = carve(nv);
-    L.vec = carve(nv); L.z = carve(nv); L.zero = carve(2); L.mij = carve((T.nM + 3) / 4 + 1);
-    L.con = carve(UHC_MAXCON * UHC_CON_STRIDE);
-    L.Y = carve(UHC_MAXEFC * YS);
-    L.rowR = carve(UHC_MAXEFC); L.rowAref = carve(UHC_MAXEFC); L.rowB = carve(UHC_MAXEFC); L.rowF = carve(UHC_MAXEFC);
-    L.rowDa = carve(UHC_MAXEFC);
-    L.rowW = carve(UHC_MAXEFC);
-    L.rowMisc = carve(UHC_MAXEFC * 2);  // 4 ints per row
-    L.ncon_nefc = carve(2 + UHC_MAXTWO);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids, slot -> lane of the working set
+    if (T.nM > 64 * 24) { delete b; return fail("uhc_batch_create: nM %d > 1536 (the register tile that carries M between substeps)", T.nM); }
     A.nvp = (nv + 1) & ~1;
-    A.ndense_g = T.ncpair > 0 ? UHC_MAXTWO : 0;
-    L.dense = carve(A.ndense_g * A.nvp);
-    L.dcol = carve(A.ndense_g * UHC_WAVE);  // Delassus columns of the dense rows within the working set (as in the fast layout)
-    L.dsc = carve(A.ndense_g * 4);          // (vel, jas, jaw, |Yhat|^2) of every dense row
-    // MPR walks hull vertices once per support call and lane: staged in LDS they cost an LDS read instead of an L2 round trip.  The rows'
-    // storage (Y .. rowDa, contiguous) is not written before the collision pass is over: the vertices borrow it every substep.
     { const char* dbg = getenv("UHC_DEBUG"); A.dbg = dbg ? atoi(dbg) : 0; }
-    A.vstage_g = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= UHC_MAXEFC * YS + 5 * UHC_MAXEFC) ? L.Y : -1;
-    L.total = off;
-    b->lds_bytes = (size_t)off * sizeof(double);
-    if (b->lds_bytes > 160 * 1024) { delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", b->lds_bytes); }
-    // ---- fast layout: persistent part + one region shared by the dynamics temporaries (phase 1) and the
-    //      constraint data (phase 2); target 40 KiB per workgroup => 4 workgroups (one per SIMD) per CU
-    {
-        DevLds& F = A.lf;
+    int end1 = 0;
+    auto common = [&](DevLds& F, bool fast) {  // persistent part + phase 1; returns the offset where phase 2 starts
         off = 0;
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
-        F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.sdinv = carve(nv); F.vec = F.z;
-        F.zero = carve(2); F.mij = carve((T.nM + 3) / 4 + 1);
+        F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.sdinv = carve(nv);
+        F.zero = carve(2);
+        F.mij = fast ? carve((T.nM + 3) / 4 + 1) : 0;  // the larger tiers read the (row, col) table from L2 and keep the LDS for rows
         F.LD = carve(T.nM + 2); F.M = F.LD;
         F.cdof = carve(6 * nv);
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);
+        F.vec = fast ? F.z : carve(nv);  // the working sets accumulate z over islands in vec
         const int base = off;
         // phase 1
         F.cinert = carve(10 * nb);
@@ -435,31 +417,85 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         const int endB = off;
         off = r3;
         F.cvel = carve(6 * nb); F.cacc = carve(6 * nb); F.cfrc = carve(6 * nb);         // k_com_vel .. k_rne
-        const int end1 = std::max(std::max(endA, endB), off);
-        // phase 2
+        end1 = std::max(std::max(endA, endB), off);
         off = base;
+        return base;
+    };
+    // ---- fast tier: target 40 KiB per workgroup => 4 workgroups (one per SIMD) per CU
+    {
+        DevLds& F = A.lf;
+        common(F, true);
         F.con = carve(UHC_FAST_MAXCON * UHC_CON_STRIDE);
         F.rowMisc = carve(UHC_WAVE * 2);
         F.ncon_nefc = carve(2 + UHC_MAXTWO / 2);
         // models with body-body contacts (self-collision, objects) keep up to UHC_FAST_MAXTWO dense rows + their Delassus columns; they
         // get a third of the CU's LDS (3 workgroups per CU) instead of a quarter -- the stock floor-only model keeps its 40 KiB layout
-        A.ndense_f = T.ncpair > 0 ? UHC_FAST_MAXTWO : 0;
-        F.dense = carve(A.ndense_f * A.nvp);
-        F.dcol = carve(A.ndense_f * UHC_WAVE);
+        A.cf.maxefc = UHC_FAST_MAXEFC; A.cf.maxcon = UHC_FAST_MAXCON; A.cf.ld_delta = 0;
+        A.cf.ndense = T.ncpair > 0 ? UHC_FAST_MAXTWO : 0;
+        F.dense = carve(A.cf.ndense * A.nvp);
+        F.dcol = carve(A.cf.ndense * UHC_WAVE);
         F.Y = off;
         const int budget = T.ncpair > 0 ? (160 * 1024 / 3) / 8 : 40 * 1024 / 8;
         int ycap = budget - off;
         const int need1 = end1 - off;  // phase 1 may need more than the constraint data
         if (ycap < need1) ycap = need1;
         if (ycap < 8 * YS) ycap = 8 * YS;
-        A.ycap = ycap;
-        A.vstage_f = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= A.ndense_f * A.nvp + A.ndense_f * UHC_WAVE + ycap) ? F.dense : -1;  // dense, dcol, Y are contiguous
+        A.cf.ycap = ycap;
+        A.cf.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= A.cf.ndense * A.nvp + A.cf.ndense * UHC_WAVE + ycap) ? F.dense : -1;  // dense, dcol, Y are contiguous
         off += ycap;
-        F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.Y;  // unused by the fast kernel
+        F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.rowW = F.rowY = F.dsc = F.Y;  // unused by the fast kernel
         F.total = off;
         b->lds_bytes_fast = (size_t)off * sizeof(double);
         const char* env = getenv("UHC_FORCE_GENERAL");
-        b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024 && T.nM <= 64 * 24 /* UHC_MREG register tile */;
+        b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024;
+    }
+    // ---- general / large tiers: rows two (four) per lane, Yhat packed row after row.  The general tier is sized for TWO workgroups per CU
+    //      (<= 79 KiB): its Yhat storage is what that budget leaves, and an env whose packed rows (or contacts, rows, dense rows) do not
+    //      fit goes on to the large tier, which owns a whole CU's LDS and holds maxefc rows of full length.
+    auto rows_layout = [&](DevLds& F, TierCap& cp, int maxefc, int maxcon, int maxtwo, int budget_doubles, bool full_y) -> bool {
+        common(F, false);
+        cp.maxefc = maxefc; cp.maxcon = maxcon; cp.ndense = T.ncpair > 0 ? maxtwo : 0;
+        cp.ld_delta = (F.LD - A.lf.LD) * 8;
+        F.con = carve(std::max(maxcon * UHC_CON_STRIDE, cp.ndense * UHC_WAVE));
+        F.dcol = F.con;  // the dense rows' Delassus columns are built when nothing reads the contacts any more (k_as_general)
+        F.rowMisc = carve(maxefc * 2);  // 4 ints per row; the collision pass keeps its candidate-pair list here (256 ints)
+        F.ncon_nefc = carve(2 + UHC_MAXTWO);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids, slot -> lane of the working set
+        F.rowY = carve(maxefc / 2);
+        F.rowR = carve(maxefc); F.rowAref = carve(maxefc); F.rowB = carve(maxefc); F.rowF = carve(maxefc); F.rowDa = carve(maxefc); F.rowW = carve(maxefc);
+        // MPR walks hull vertices once per support call and lane: staged in LDS they cost an LDS read instead of an L2 round trip.  The
+        // dense rows, their scalars and Yhat (contiguous) are not written before the collision pass is over: the vertices borrow them.
+        F.dense = carve(cp.ndense * A.nvp);
+        F.dsc = carve(cp.ndense * 4);  // (vel, jas, jaw, |Yhat|^2) of every dense row
+        F.Y = off;
+        const int full = maxefc * YS + 8;
+        int ycap = full_y ? full : std::min(budget_doubles - off, full);
+        if (!full_y && ycap < 64 * 18) return false;  // too little left for rows: not worth a tier of its own
+        if (ycap < end1 - off) ycap = end1 - off;     // (the region also holds the dynamics temporaries of phase 1)
+        cp.ycap = ycap & ~1;
+        cp.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= cp.ndense * A.nvp + cp.ndense * 4 + cp.ycap) ? F.dense : -1;
+        off += cp.ycap;
+        F.total = off;
+        return off <= budget_doubles;
+    };
+    {
+        const char* tv = getenv("UHC_TIERS");
+        A.last_tier = (tv && tv[0] == '2') ? 2 : 3;
+        if (A.last_tier == 3) {  // the large tier: as many rows (<= 256) as a CU's 160 KiB hold at full length
+            bool ok = false;
+            for (int me = UHC_BIG_MAXEFC; me > UHC_GEN_MAXEFC && !ok; me -= 32) {
+                ok = rows_layout(A.lh, A.ch, me, me / 2, UHC_BIG_MAXTWO, 160 * 1024 / 8, true);
+            }
+            if (ok) b->lds_bytes_big = (size_t)A.lh.total * sizeof(double);
+            else A.last_tier = 2;
+        }
+        const int two_per_cu = 79 * 1024 / 8;
+        bool ok = A.last_tier == 3 && rows_layout(A.l, A.cg, UHC_GEN_MAXEFC, UHC_GEN_MAXCON, UHC_GEN_MAXTWO, two_per_cu, false);
+        if (!ok) {  // the last tier must hold every row at full length: a whole CU's LDS if need be (32 dense slots as before)
+            if (!rows_layout(A.l, A.cg, UHC_GEN_MAXEFC, UHC_GEN_MAXCON, A.last_tier == 2 ? UHC_MAXTWO : UHC_GEN_MAXTWO, 160 * 1024 / 8, true)) {
+                delete b; return fail("uhc_batch_create: model needs %zu B of LDS per env (> 160 KiB)", (size_t)A.l.total * 8);
+            }
+        }
+        b->lds_bytes = (size_t)A.l.total * sizeof(double);
     }
     // ---- static schedules for the factorisation and the triangular solves (see DevTopo).  Addresses are LDS byte
     //      addresses of the FAST layout's LD buffer (the general kernel adds its own LD offset, KernelArgs::ld_delta).
@@ -538,9 +574,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         }
         TRY(upload(b, dof_act, &T.dof_act));
         TRY(upload(b, fac_prog, &T.fac_prog)); TRY(upload(b, sol_back, &T.sol_back)); TRY(upload(b, sol_fwd, &T.sol_fwd));
-        A.ld_delta = (A.l.LD - A.lf.LD) * 8;
     }
-    HIP_OK(uhc_set_lds_limit(b->lds_bytes, b->lds_bytes_fast));
+    HIP_OK(uhc_set_lds_limit(b->lds_bytes, b->lds_bytes_fast, b->lds_bytes_big));
 
     // ---- state
     DevState& S = A.s;
@@ -548,7 +583,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
     TRY(dalloc(b, 4, &S.path_stats));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, E, &S.redo)); TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 2 * E, &S.redo)); S.redo2 = S.redo + E; TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
@@ -654,17 +689,20 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
     }
     const bool general = b->general_only || (b->path_mode == 2 && b->auto_general);
+    const bool big = b->A.last_tier == 3;
+    // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
+    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * (big ? 2 : 1), b->stream));  // redo and redo2 are one allocation
     if (b->use_fast && !general) {
-        HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env, b->stream));
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
-        HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
+        HIP_OK(uhc_launch_step(mode, 2, &b->A, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
     } else {
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
-        HIP_OK(uhc_launch_step(mode, 0, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
+        HIP_OK(uhc_launch_step(mode, 2, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
     }
+    if (big) HIP_OK(uhc_launch_step(mode, 3, &b->A, d_action, d_tbase, b->A.s.redo2, b->lds_bytes_big, b->stream));
     if (mode == 0 && b->path_mode == 2 && b->use_fast) return path_update(b);
     return 0;
 }
@@ -725,7 +763,7 @@ extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, c
     // only the kinematics now (the reset observation reads body poses); the dynamics part of sim.forward() runs at the head of the
     // env's next step kernel (DevState::fresh), which saves a forward-pass-long launch per control step
     const bool kf = b->use_fast && !(b->general_only || (b->path_mode == 2 && b->auto_general));
-    HIP_OK(uhc_launch_step(2, kf ? 1 : 0, &b->A, nullptr, nullptr, b->reset_mask, kf ? b->lds_bytes_fast : b->lds_bytes, b->stream));
+    HIP_OK(uhc_launch_step(2, kf ? 1 : 2, &b->A, nullptr, nullptr, b->reset_mask, kf ? b->lds_bytes_fast : b->lds_bytes, b->stream));
     return 0;
 }
 

@@ -5,11 +5,19 @@
 #include <stdint.h>
 
 #define UHC_WAVE 64
-#define UHC_MAXEFC 128   // constraint rows per env (2 per lane)
-#define UHC_MAXCON 64    // contacts per env (general kernel)
-#define UHC_FAST_MAXCON 16  // contacts per env (fast kernel)
-#define UHC_MAXTWO 32       // constraint rows between two moving bodies per env (general kernel); they are kept as dense dof vectors
-#define UHC_FAST_MAXTWO 12  // the same for the fast kernel
+// capacities per env of the three kernel tiers (fast / general / large): constraint rows, contacts, rows between two moving bodies (kept
+// as dense dof vectors).  The reference's models ask MuJoCo for njmax 2500 / nconmax 500 (uhc/khrylib/mocap/skeleton_mesh.py:46); what
+// exceeds the last tier is dropped and flagged (UHC_F_EFC_OVERFLOW).
+#define UHC_FAST_MAXEFC 64   // one row per lane, Delassus matrix in registers
+#define UHC_FAST_MAXCON 16
+#define UHC_FAST_MAXTWO 12
+#define UHC_GEN_MAXEFC 128   // two rows per lane, working sets of <= 64 rows
+#define UHC_GEN_MAXCON 64
+#define UHC_GEN_MAXTWO 16
+#define UHC_BIG_MAXEFC 256   // four rows per lane
+#define UHC_BIG_MAXCON 128
+#define UHC_BIG_MAXTWO 32
+#define UHC_MAXTWO 32        // dense-row slots of the largest tier (sizes the slot tables of every layout)
 #define UHC_DOF_MAXACT 4
 #define UHC_CON_STRIDE 24
 #define UHC_MINVAL 1e-15
@@ -65,9 +73,11 @@ struct DevLds {
     int M, LD, dinv, sdinv, bias, smooth, vec, z, zero;
     int mij;  // 16-bit (row << 8 | col) of every sparse-M entry, loaded once per kernel (k_crb)
     int con, Y, rowR, rowAref, rowB, rowF, rowDa, rowMisc /* ints: type,last,len,yoff */, ncon_nefc;
-    int rowW;   // general kernel: the warm-start forces, kept for the sweeps fallback of the working-set solve
+    int rowW;   // general / large tiers: the warm-start forces, kept for the sweeps fallback of the working-set solve
+    int rowY;   // general / large tiers: ints [maxefc] offset of every row's packed Yhat entries inside Y
     int dense;  // [ndense][nvp] dense Yhat rows of the constraints that touch two moving bodies (self-collision, objects)
-    int dcol;   // [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back)
+    int dcol;   // [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back); in the general /
+                // large layouts it shares the contacts' storage, which nothing reads once the rows are built
     int dsc;    // general kernel: [ndense][4] J.qvel, J.qacc_smooth, J.qacc_warmstart, |Yhat|^2 of every dense row
     int total;  // doubles
 };
@@ -84,6 +94,7 @@ struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
+    int* redo2;  // envs the general tier handed on to the large tier this step
     int* fresh;  // 1: the env was restarted on the device (set_state done, kinematics refreshed); its mj_forward runs at the head of its next step
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)
@@ -92,19 +103,28 @@ struct DevState {  // HBM, env-major
     const double* model_blob;
 };
 
+// capacities of one tier's LDS layout
+struct TierCap {
+    int maxefc, maxcon;
+    int ndense;    // dense-row slots (0: the model has no two-body contacts)
+    int ycap;      // doubles available for the packed Yhat rows
+    int vstage;    // LDS offset (doubles) where the hull vertices are staged for the MPR pass of every substep, or -1: they do not fit the
+                   // region that is free at collision time (the not-yet-written constraint rows) and MPR reads them from L2
+    int ld_delta;  // bytes to add to the schedule tables' LDS addresses (they are built for the fast layout's LD buffer)
+};
 struct KernelArgs {
     DevTopo t;
     DevNumOff o;
-    DevLds l;   // general kernel: every buffer separate, 128 rows
-    DevLds lf;  // fast kernel: phase-aliased, 64 rows, packed Yhat
-    int ycap;   // doubles available for packed Yhat rows in the fast layout
-    int ld_delta;  // bytes to add to the schedule tables' LDS addresses in the general layout
+    // all three layouts are phase-aliased: a persistent part (state, factor, body poses, cdof) + one region shared by the dynamics
+    // temporaries (first half of a forward pass) and the constraint data (second half); M itself is parked in registers
+    DevLds lf;  // fast tier: 40 KiB (53 with dense-row slots): 4 (3) workgroups per CU
+    DevLds l;   // general tier: <= 79 KiB: 2 workgroups per CU
+    DevLds lh;  // large tier: <= 160 KiB
+    TierCap cf, cg, ch;
+    int last_tier;  // 2 or 3: the tier that drops what exceeds it instead of handing the env on
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS
-    int ndense_f, ndense_g;  // dense-row slots of the fast / general layout (0: the model has no two-body contacts)
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
-    int vstage_f, vstage_g;  // LDS offset (doubles) where the hull vertices are staged for the MPR pass of every substep, or -1: they do not fit the
-                             // region that is free at collision time (the not-yet-written constraint rows) and MPR reads them from L2
     DevCtrl c;
     DevState s;
     int n_env;

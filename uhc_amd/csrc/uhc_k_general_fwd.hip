@@ -2,15 +2,15 @@
 #include "uhc_physics_impl.h"
 
 extern "C" hipError_t uhc_launch_m1_gen(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((uhc_step_kernel<1, false, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    hipLaunchKernelGGL((uhc_step_kernel<1, 2, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
 }
-extern "C" hipError_t uhc_launch_m1_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }
+extern "C" hipError_t uhc_launch_m1_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }
 extern "C" hipError_t uhc_launch_m2_gen(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((uhc_step_kernel<2, false, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    hipLaunchKernelGGL((uhc_step_kernel<2, 2, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
 }
-extern "C" hipError_t uhc_launch_m2_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }
+extern "C" hipError_t uhc_launch_m2_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }
 
 // set_state: scatter rows of (qpos, qvel) into the listed envs, clear warm start / flags
 __global__ void uhc_set_state_kernel(DevState s, int nq, int nv, int nu, const int* env_ids, int n, const double* qpos,

@@ -31,8 +31,17 @@ extern __shared__ __attribute__((aligned(16))) double smem[];
 #define PROF_PASS
 #define PROF(i)
 #endif
-#define MAXCON_OF(FAST) ((FAST) ? UHC_FAST_MAXCON : UHC_MAXCON)
-#define MAXEFC_OF(FAST) ((FAST) ? UHC_WAVE : UHC_MAXEFC)
+// Three tiers of one kernel: TIER 1 = fast (compact LDS, <= 64 rows, Delassus matrix in registers), TIER 2 = general (<= 128 rows, working
+// sets, two workgroups per CU), TIER 3 = large (<= 256 rows, a whole CU's LDS).  A tier that cannot hold an env leaves it untouched and
+// hands it to the next one; only the last tier of a batch (KernelArgs::last_tier) drops what exceeds it and flags the env.
+template <int TIER> __device__ __forceinline__ const DevLds& lds_of(const KernelArgs& A) {
+    if constexpr (TIER == 1) return A.lf; else if constexpr (TIER == 2) return A.l; else return A.lh;
+}
+template <int TIER> __device__ __forceinline__ const TierCap& cap_of(const KernelArgs& A) {
+    if constexpr (TIER == 1) return A.cf; else if constexpr (TIER == 2) return A.cg; else return A.ch;
+}
+// does this tier hand an env it cannot hold to the next one (true), or drop the excess and flag it (false)?
+template <int TIER> __device__ __forceinline__ bool hands_on(const KernelArgs& A) { return TIER == 1 ? !A.truncate : TIER < A.last_tier; }
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
 // ------------------------------------------------------------------ lane helpers
@@ -192,10 +201,10 @@ __device__ __forceinline__ int jdofs(int jt) { return jt == UHC_JNT_FREE ? 6 : j
 // Pass 1 (all bodies in parallel): pose of each body relative to its parent frame, including its own
 // joint rotations (the expensive sincos work).  Pass 2 (level-synchronous): compose with the parent.
 // Pass 3 (all joints in parallel): joint anchors/axes to the world frame.
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* mb, double* S, const BodyConst& BC PROF_ARGS) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const int b = LANE;
     double *xpos = S + L.xpos, *xquat = S + L.xquat, *xmat = S + L.xmat, *xipos = S + L.xipos, *ximat = S + L.ximat;
     if (b == 0) {
@@ -295,10 +304,10 @@ __device__ __forceinline__ void k_kinematics(const KernelArgs& A, const double* 
 }
 
 // ------------------------------------------------------------------ P2 comPos: tree COM, cinert (body/lane), cdof (joint/lane)
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb, double* S, const BodyConst& BC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const int b = LANE;
     const bool act = BC.act;
     const double mass = act ? mb[A.o.body_mass + b] : 0.0;
@@ -363,10 +372,10 @@ __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb,
 }
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, MPark& MP, const BodyConst& BC PROF_ARGS) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const int b = LANE;
     // composite inertia = sum of cinert over the subtree, which is the contiguous range [b, b + nsub) in DFS order.
     // One work item per (body, component): consecutive lanes read consecutive components, the loop length is the subtree
@@ -396,27 +405,17 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
 #pragma unroll
     for (int m = 0; m < UHC_MREG; m++) {
         const int e = LANE + UHC_WAVE * m;
-        if (!FAST && m * UHC_WAVE >= T.nM) break;
         double v = 0.0;
         if (e < T.nM) {
-            const int ij = ((const unsigned short*)(S + L.mij))[e], i = ij >> 8, j = ij & 0xff;
+            const int ij = TIER == 1 ? ((const unsigned short*)(S + L.mij))[e] : T.m_ij[e], i = ij >> 8, j = ij & 0xff;  // (the larger tiers keep their LDS for rows)
             double a[6], c[6];
             for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
             v = dot6(a, c);
             if (i == j) v += mb[A.o.dof_armature + i];
             S[L.M + e] = v;
         }
-        if (FAST) { agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v)); }
+        agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v));
     }
-    if (!FAST)
-        for (int e = LANE + UHC_WAVE * UHC_MREG; e < T.nM; e += UHC_WAVE) {  // models larger than the register tile (general kernel only)
-            const int i = T.m_row[e], j = T.m_col[e];
-            double a[6], c[6];
-            for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
-            double v = dot6(a, c);
-            if (i == j) v += mb[A.o.dof_armature + i];
-            S[L.M + e] = v;
-        }
     wsync();
 }
 
@@ -454,12 +453,12 @@ __device__ __forceinline__ double rcp_newton(double x) {
 // write the dump slot.  The LDS queue of one wave is in order, so consecutive groups and steps need no barrier; the record of
 // the next group streams in from L2 meanwhile.
 __device__ __forceinline__ double lds_at(const char* SB, unsigned int byte_off) { return *(const double*)(SB + byte_off); }
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_factor(const KernelArgs& A, double* S, int ld, const LaneConst& LC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     double* LD = S + ld;
-    char* SB = (char*)S + (FAST ? 0 : A.ld_delta);  // schedule addresses are byte offsets in the fast layout
+    char* SB = (char*)S + cap_of<TIER>(A).ld_delta;  // schedule addresses are byte offsets in the fast layout
     const unsigned int zero_adr = (unsigned)(A.lf.LD + T.nM) * 8u, dump_adr = zero_adr + 8u;
     struct FacRec { unsigned int fr[3], o01, o2n, dk; };
     const FacRec* pg = (const FacRec*)T.fac_prog + LANE;
@@ -537,11 +536,11 @@ __device__ __forceinline__ void solve_sweep(const unsigned int* tab, const char*
         }
     }
 }
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half, const LaneConst& LC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
-    const char* SB = (const char*)S + (FAST ? 0 : A.ld_delta);
+    const DevLds& L = lds_of<TIER>(A);
+    const char* SB = (const char*)S + cap_of<TIER>(A).ld_delta;
     if (T.nv < 2) { if (!half && LC.v0) x.a *= S[L.dinv + LANE]; return; }
     if (!half) {
         // x <- L^-T x : for i descending, every ancestor j of i:  x[j] -= L[i][j] x[i]
@@ -554,10 +553,10 @@ __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, in
 }
 
 // ------------------------------------------------------------------ P7 velocities + bias forces
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S, const BodyConst& BC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const int b = LANE;
     if (b == 0) for (int k = 0; k < 6; k++) S[L.cvel + k] = 0;
     wsync();
@@ -603,10 +602,10 @@ __device__ __forceinline__ void k_com_vel(const KernelArgs& A, double* S, const 
         wsync();
     }
 }
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_rne(const KernelArgs& A, double* S, const BodyConst& BC PROF_ARGS) {  // qfrc_bias = RNE(qacc = 0)
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const int b = LANE;
     if (b == 0) for (int k = 0; k < 6; k++) { S[L.cacc + k] = k < 3 ? 0.0 : -T.gravity[k - 3]; S[L.cfrc + k] = 0; }
     wsync();
@@ -658,10 +657,10 @@ __device__ __forceinline__ void k_rne(const KernelArgs& A, double* S, const Body
 }
 
 // ------------------------------------------------------------------ P8 smooth forces / acceleration
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     // qfrc_smooth = passive - bias + applied + actuator  -> S.smooth
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         double f = -mb[A.o.dof_damping + i] * S[L.qvel + i] - S[L.bias + i] + S[L.applied + i];
@@ -684,7 +683,7 @@ __device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, 
     DofVec x;
     x.a = LANE < T.nv ? S[L.smooth + LANE] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? S[L.smooth + LANE + UHC_WAVE] : 0.0;
-    k_solve<FAST>(A, S, L.LD, x, 0, LC);
+    k_solve<TIER>(A, S, L.LD, x, 0, LC);
     if (LANE < T.nv) S[L.smooth + LANE] = x.a;  // now qacc_smooth
     if (LANE + UHC_WAVE < T.nv) S[L.smooth + LANE + UHC_WAVE] = x.b;
     wsync();
@@ -744,11 +743,11 @@ __device__ __forceinline__ PairConst pair_of(const DevTopo& T, const PairConst& 
     }
     return c;
 }
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, int b1, int b2, int dim,
                                                 const double* pos, const double* n, double dist, double margin, double gap) {
     const DevTopo& T = A.t;
-    double* C = S + (FAST ? A.lf : A.l).con + c * UHC_CON_STRIDE;
+    double* C = S + lds_of<TIER>(A).con + c * UHC_CON_STRIDE;
     double fr[9];
     for (int k = 0; k < 3; k++) { C[k] = pos[k]; fr[k] = n[k]; }
     make_frame(fr);
@@ -768,10 +767,10 @@ __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const doubl
     C[19] = b1; C[20] = b2; C[21] = dim;
 }
 // returns ncon (wave-uniform)
-template <bool FAST, bool DENSE>
+template <int TIER, bool DENSE>
 __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow, const PairConst& PC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     int ncon = 0;
     for (int p0 = 0; p0 < T.npair; p0 += UHC_WAVE) {
         const int p = p0 + LANE;
@@ -852,13 +851,13 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             }
             const unsigned long long cm = __ballot(ok);
             const int rank = __popcll(cm & ((1ull << LANE) - 1ull));
-            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < MAXCON_OF(FAST)) {
+            if (ok && rank < T.plane_mesh_maxcon && ncon + rank < cap_of<TIER>(A).maxcon) {
                 const double cp[3] = {w[0] - 0.5 * dist * n[0], w[1] - 0.5 * dist * n[1], w[2] - 0.5 * dist * n[2]};
-                k_write_contact<FAST>(A, mb, S, ncon + rank, P.g1, P.g2, P.b1, P.b2, P.dim, cp, n, dist, margin, gap);
+                k_write_contact<TIER>(A, mb, S, ncon + rank, P.g1, P.g2, P.b1, P.b2, P.dim, cp, n, dist, margin, gap);
             }
             const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
-            if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;  // 2: truncated, 1: needs the general kernel
-            ncon = min(MAXCON_OF(FAST), want);
+            if (want > cap_of<TIER>(A).maxcon) *overflow |= hands_on<TIER>(A) ? 1 : 2;  // 1: needs the next tier, 2: dropped
+            ncon = min(cap_of<TIER>(A).maxcon, want);
         }
     }
     // ---- convex-convex pairs (hull vs hull): one candidate pair per lane through bounding-sphere cull and MPR (uhc_mpr.h); the hits
@@ -888,9 +887,9 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             if (c && rank < CAND_CAP) cand[rank] = p;
             ncand += (int)__popcll(cm);
         }
-        if (ncand > CAND_CAP) { *overflow |= FAST ? 1 : 2; ncand = CAND_CAP; }
+        if (ncand > CAND_CAP) { *overflow |= hands_on<TIER>(A) ? 1 : 2; ncand = CAND_CAP; }
         // the hull vertices (body frame, model constants) into the LDS region the constraint rows will use after this pass
-        const int vstage = FAST ? A.vstage_f : A.vstage_g;
+        const int vstage = cap_of<TIER>(A).vstage;
         if (vstage >= 0 && ncand > 0)
             for (int i = LANE; i < 3 * T.nmeshvert; i += UHC_WAVE) S[vstage + i] = mb[A.o.mesh_vert + i];
         wsync();
@@ -924,13 +923,13 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             }
             const unsigned long long hm = __ballot(hit);
             const int rank = __popcll(hm & ((1ull << LANE) - 1ull));
-            if (hit && ncon + rank < MAXCON_OF(FAST)) {
+            if (hit && ncon + rank < cap_of<TIER>(A).maxcon) {
                 const double cp[3] = {pos.x, pos.y, pos.z}, nn[3] = {dir.x, dir.y, dir.z};
-                k_write_contact<FAST>(A, mb, S, ncon + rank, g1, g2, b1, b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - depth, margin, gap);
+                k_write_contact<TIER>(A, mb, S, ncon + rank, g1, g2, b1, b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - depth, margin, gap);
             }
             const int want = ncon + (int)__popcll(hm);
-            if (want > MAXCON_OF(FAST)) *overflow |= (FAST && A.truncate) ? 2 : 1;
-            ncon = min(MAXCON_OF(FAST), want);
+            if (want > cap_of<TIER>(A).maxcon) *overflow |= hands_on<TIER>(A) ? 1 : 2;
+            ncon = min(cap_of<TIER>(A).maxcon, want);
         }
     }
     wsync();
@@ -948,10 +947,10 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
 #define RTYPE(t) ((t) & 0xf)
 struct RowMisc { int type, last, aux, edge; };  // aux: contact id | dof ; edge: pyramid edge | sign
 
-template <bool FAST, bool DENSE>
+template <int TIER, bool DENSE>
 __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const double* mb, double* S, int ncon, int* overflow) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     RowMisc* RM = (RowMisc*)(S + L.rowMisc);
     int nefc = 0;
     // (1) friction loss
@@ -960,7 +959,7 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
         const bool has = i < T.nv && mb[A.o.dof_frictionloss + i] > 0;
         const unsigned long long m = __ballot(has);
         const int r = nefc + __popcll(m & ((1ull << LANE) - 1ull));
-        if (has && r < MAXEFC_OF(FAST)) { RM[r].type = ROW_FRICTION; RM[r].last = i; RM[r].aux = i; RM[r].edge = 1; }
+        if (has && r < cap_of<TIER>(A).maxefc) { RM[r].type = ROW_FRICTION; RM[r].last = i; RM[r].aux = i; RM[r].edge = 1; }
         nefc += __popcll(m);
     }
     // (2) joint limits: lower side then upper side of each joint, joints in order
@@ -977,8 +976,8 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
         }
         const unsigned long long ml = __ballot(lo), mh = __ballot(hi), below = (1ull << LANE) - 1ull;
         int r = nefc + __popcll(ml & below) + __popcll(mh & below);
-        if (lo) { if (r < MAXEFC_OF(FAST)) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = -1; } r++; }
-        if (hi) { if (r < MAXEFC_OF(FAST)) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = 1; } }
+        if (lo) { if (r < cap_of<TIER>(A).maxefc) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = -1; } r++; }
+        if (hi) { if (r < cap_of<TIER>(A).maxefc) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = 1; } }
         nefc += __popcll(ml) + __popcll(mh);
     }
     wsync();
@@ -986,17 +985,17 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     if (LANE == 0) {
         int r = nefc, trunc = 0, ntwo = 0, twofull = 0;
         int* NI = (int*)(S + L.ncon_nefc);
-        const int maxtwo = !DENSE ? 0 : FAST ? A.ndense_f : A.ndense_g;
+        const int maxtwo = !DENSE ? 0 : cap_of<TIER>(A).ndense;
         for (int c = 0; c < ncon; c++) {
             const double* C = S + L.con + c * UHC_CON_STRIDE;
             if (C[12] >= C[13]) continue;
             const int dim = (int)C[21], b1 = (int)C[19], b2 = (int)C[20];
             const int nr = dim == 1 ? 1 : 4, l1 = T.body_lastdof[b1], l2 = T.body_lastdof[b2];
             const bool two = DENSE && l1 >= 0 && l2 >= 0;
-            if (FAST && A.truncate && r + nr > MAXEFC_OF(FAST)) { trunc = 1; break; }  // whole contacts only
-            if (two && ntwo + nr > maxtwo) { twofull = 1; if (FAST && !A.truncate) break; continue; }  // no dense slot left
+            if (TIER == 1 && A.truncate && r + nr > cap_of<TIER>(A).maxefc) { trunc = 1; break; }  // whole contacts only
+            if (two && ntwo + nr > maxtwo) { twofull = 1; if (hands_on<TIER>(A)) break; continue; }  // no dense slot left
             for (int e = 0; e < nr; e++, r++)
-                if (r < MAXEFC_OF(FAST)) {
+                if (r < cap_of<TIER>(A).maxefc) {
                     int ty = dim == 1 ? ROW_CONTACT : ROW_PYR;
                     if (two) { ty |= ROW_TWO | (ntwo << 8); NI[4 + ntwo] = r; ntwo++; }
                     else if (l2 < 0) ty |= ROW_NEG;
@@ -1008,8 +1007,8 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     wsync();
     nefc = ((int*)(S + L.ncon_nefc))[1];
     if (((int*)(S + L.ncon_nefc))[0]) *overflow |= 2;
-    if (((int*)(S + L.ncon_nefc))[3]) *overflow |= (FAST && !A.truncate) ? 1 : 2;  // fast: the general kernel has more dense slots; else rows were dropped
-    if (nefc > MAXEFC_OF(FAST)) { *overflow |= (FAST && A.truncate) ? 2 : 1; nefc = MAXEFC_OF(FAST); }
+    if (((int*)(S + L.ncon_nefc))[3]) *overflow |= hands_on<TIER>(A) ? 1 : 2;  // the next tier has more dense slots; the last one dropped the rows
+    if (nefc > cap_of<TIER>(A).maxefc) { *overflow |= hands_on<TIER>(A) ? 1 : 2; nefc = cap_of<TIER>(A).maxefc; }
     return nefc;
 }
 
@@ -1020,10 +1019,10 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
 // cancel exactly), the back substitution is the register-resident sweep of k_solve.  Returns the row's
 // J.qvel, J.qacc_smooth, J.qacc_warmstart and |Yhat|^2 (wave-uniform).
 struct DenseOut { double vel, jas, jaw, yy; };
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ DenseOut k_dense_row(const KernelArgs& A, double* S, int r, int slot, const LaneConst& LC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const RowMisc rm = ((const RowMisc*)(S + L.rowMisc))[r];
     const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
     const int l1 = T.body_lastdof[(int)C[19]], l2 = T.body_lastdof[(int)C[20]];
@@ -1055,7 +1054,7 @@ __device__ __forceinline__ DenseOut k_dense_row(const KernelArgs& A, double* S, 
     o.vel = wave_sum(x.a * qv[0] + x.b * qv[1]);
     o.jas = wave_sum(x.a * qs[0] + x.b * qs[1]);
     o.jaw = wave_sum(x.a * qw[0] + x.b * qw[1]);
-    if (T.nv >= 2) solve_sweep<true>(T.sol_back + LANE, (const char*)S + (FAST ? 0 : A.ld_delta), T.nv - 1, x);  // x <- L^-T x
+    if (T.nv >= 2) solve_sweep<true>(T.sol_back + LANE, (const char*)S + cap_of<TIER>(A).ld_delta, T.nv - 1, x);  // x <- L^-T x
     double* D = S + L.dense + slot * A.nvp;
     double y0 = 0.0, y1 = 0.0;
     if (LC.v0) { y0 = x.a * S[L.sdinv + LANE]; D[LANE] = y0; }
@@ -1064,18 +1063,43 @@ __device__ __forceinline__ DenseOut k_dense_row(const KernelArgs& A, double* S, 
     return o;
 }
 
+__device__ __forceinline__ int wave_excl_scan(int v, int* total) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < UHC_WAVE; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (LANE >= o) x += y;
+    }
+    *total = __builtin_amdgcn_readlane(x, UHC_WAVE - 1);
+    return x - v;
+}
+
 // Per row (lane r and r+64): J over the dof chain of the row, reference acceleration, R, warm-start
 // force, and Yhat = D^-1/2 L^-T J^T stored chain-sparse (index = depth of the dof).
-template <bool FAST>
-__device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC) {
+// Returns 0, or 1 when the packed rows do not fit this tier's Yhat storage (-> the env goes to the next tier; the last tier's storage holds
+// maxefc full-length rows, so it cannot happen there).
+template <int TIER>
+__device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
-    const int YS = T.maxdepth + 1;
     const int* NI = (const int*)(S + L.ncon_nefc);
-    const int ntwo = (FAST ? A.ndense_f : A.ndense_g) > 0 ? NI[2] : 0;
+    // packed storage: row r starts at RY[r] and is as long as its dof chain (0 for dense rows); offsets by a scan in row order
+    int* RY = (int*)(S + L.rowY);
+    int ytot = 0;
+    for (int r0 = 0; r0 < nefc; r0 += UHC_WAVE) {
+        const int r = r0 + LANE;
+        int len = 0;
+        if (r < nefc) { const RowMisc rm = RM[r]; len = (rm.type & ROW_TWO) ? 0 : T.dof_depth[rm.last] + 1; }
+        int tot;
+        const int off = wave_excl_scan(len, &tot);
+        if (r < nefc) RY[r] = ytot + off;
+        ytot += tot;
+    }
+    if (ytot + 8 > cap_of<TIER>(A).ycap) return 1;
+    const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
     for (int k = 0; k < ntwo; k++) {  // dense rows first (wave-cooperative); their scalars wait in dcol for the lane that owns the row
-        const DenseOut o = k_dense_row<FAST>(A, S, NI[4 + k], k, LC);
+        const DenseOut o = k_dense_row<TIER>(A, S, NI[4 + k], k, LC);
         if (LANE == 0) { S[L.dsc + 4 * k] = o.vel; S[L.dsc + 4 * k + 1] = o.jas; S[L.dsc + 4 * k + 2] = o.jaw; S[L.dsc + 4 * k + 3] = o.yy; }
     }
     wsync();
@@ -1084,8 +1108,8 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
         const int rt = RTYPE(rm.type);
         const bool two = (rm.type & ROW_TWO) != 0;
         const int last = rm.last, len = two ? 0 : T.dof_depth[last] + 1;
-        const short* anc = T.dof_anc + (two ? 0 : last) * YS;
-        double* Y = S + L.Y + r * YS;
+        const short* anc = T.dof_anc + (two ? 0 : last) * (T.maxdepth + 1);
+        double* Y = S + L.Y + RY[r];
         double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
         if (rt == ROW_FRICTION || rt == ROW_LIMIT) {
             const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
@@ -1164,37 +1188,38 @@ __device__ __forceinline__ void k_rows(const KernelArgs& A, const double* mb, do
             Y[q] = y;
             da += y * y;
         }
-        // the register-resident solves of the working sets (k_as_general) read rows in chunks of 8 entries, past the row's own length
-        // and into the next slot: everything there must be finite (it meets a zero multiplier), so the slot is zero-filled
-        for (int q = len; q < YS; q++) Y[q] = 0.0;
         S[L.rowR + r] = R;
         S[L.rowAref + r] = floss;        // (aref itself is folded into b; the slot keeps the friction-loss bound)
         S[L.rowB + r] = jas - aref;
         S[L.rowF + r] = f;
         S[L.rowDa + r] = da;             // diagonal of A + R
     }
-    if (!FAST && nefc < UHC_MAXEFC && LANE < YS) S[L.Y + nefc * YS + LANE] = 0.0;  // (the slot after the last row as well)
+    // the register-resident solves of the working sets (k_as_general) read rows in chunks of 8 entries, past the row's own length and into
+    // the next row: everything there must be finite (it meets a zero multiplier) -- the rows are, and so is the slack after the last one
+    if (LANE < 8) S[L.Y + ytot + LANE] = 0.0;
     wsync();
+    return 0;
 }
 
 // ------------------------------------------------------------------ P9 projected Gauss-Seidel on the dual (matrix-free)
 // z = sum_r f_r Yhat_r  (nv vector in LDS);  (A f)_r = Yhat_r . z[chain_r].
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
     const int YS = T.maxdepth + 1;
+    const int* RY = (const int*)(S + L.rowY);
     double* z = S + L.z;
     const int* NI = (const int*)(S + L.ncon_nefc);
-    const int ntwo = (FAST ? A.ndense_f : A.ndense_g) > 0 ? NI[2] : 0;
+    const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
     // z from the warm-start forces: dof-per-lane pull over all rows (dense rows carry last = -1 and are added from their slots)
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         const int di = T.dof_depth[i], nd = T.dof_ndesc[i];
         double acc = 0;
         for (int r = 0; r < nefc; r++) {
             const int last = RM[r].last;
-            if (last >= i && last <= i + nd) acc += S[L.rowF + r] * S[L.Y + r * YS + di];
+            if (last >= i && last <= i + nd) acc += S[L.rowF + r] * S[L.Y + RY[r] + di];
         }
         for (int k = 0; k < ntwo; k++) acc += S[L.rowF + NI[4 + k]] * S[L.dense + k * A.nvp + i];
         z[i] = acc;
@@ -1212,7 +1237,7 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
         } else {
             const int last = rm.last, len = T.dof_depth[last] + 1;
             const short* anc = T.dof_anc + last * YS;
-            for (int q = 0; q < len; q++) af += S[L.Y + r * YS + q] * z[anc[q]];
+            for (int q = 0; q < len; q++) af += S[L.Y + RY[r] + q] * z[anc[q]];
         }
         cost += f * (0.5 * af + S[L.rowB + r]);
     }
@@ -1238,7 +1263,7 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
                 if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
             } else if (LANE < len) {
                 dof = T.dof_anc[rm.last * YS + LANE];
-                y = S[L.Y + r * YS + LANE];
+                y = S[L.Y + RY[r] + LANE];
                 part = y * z[dof];
             }
             const double old = S[L.rowF + r], Rr = S[L.rowR + r], Arr = S[L.rowDa + r];
@@ -1274,17 +1299,6 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
 struct FastRow { int type, last, len, yoff, two /* dense slot or -1 */; double R, b, f, floss, diag; };
 
 
-__device__ __forceinline__ int wave_excl_scan(int v, int* total) {
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < UHC_WAVE; o <<= 1) {
-        const int y = __shfl_up(x, o);
-        if (LANE >= o) x += y;
-    }
-    *total = __builtin_amdgcn_readlane(x, UHC_WAVE - 1);
-    return x - v;
-}
-
 // returns 0 on success, 1 if the packed Yhat rows do not fit (-> the env is redone by the general kernel)
 // The row's Yhat = D^-1/2 L^-T J^T entries along its dof chain are built in REGISTERS (Y[q], q = position on the chain,
 // compile-time indices): Jacobian, the three J.v products, the back substitution and the D^-1/2 scaling never round-trip
@@ -1313,10 +1327,10 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     int total, status = 0;
     row.yoff = wave_excl_scan(row.len, &total);
     row.R = 1; row.b = 0; row.f = 0; row.floss = 0; row.diag = 1;
-    if (total + 8 > A.ycap) {
+    if (total + 8 > A.cf.ycap) {
         if (!A.truncate) return 1;
         // keep the leading rows whose packed entries fit, cut back to the start of a pyramid so its edges stay together
-        const unsigned long long fit = __builtin_amdgcn_ballot_w64(valid && row.yoff + row.len + 8 <= A.ycap);
+        const unsigned long long fit = __builtin_amdgcn_ballot_w64(valid && row.yoff + row.len + 8 <= A.cf.ycap);
         int nfit = ~fit == 0ull ? UHC_WAVE : __ffsll((long long)~fit) - 1;
         if (nfit < nefc && nfit > 0) {
             const unsigned long long starts = __builtin_amdgcn_ballot_w64(valid && !(rm.type == ROW_PYR && rm.edge != 0));
@@ -1388,7 +1402,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
         for (int k = 0; k < ntwo; k++) {
             const int rr = __builtin_amdgcn_readfirstlane(NI[4 + k]);
             if (rr >= nefc) break;  // dropped by the truncation above
-            const DenseOut o = k_dense_row<true>(A, S, rr, k, LC);
+            const DenseOut o = k_dense_row<1>(A, S, rr, k, LC);
             if (LANE == rr) { vel = o.vel; jas = o.jas; jaw = o.jaw; }
         }
     }
@@ -1590,13 +1604,13 @@ __device__ __forceinline__ int as_solve(const int (&Alo)[UHC_WAVE], const int (&
 }
 
 // PGS with A in registers; returns the sweep count.  On exit S[L.z] = sum_r f_r Yhat_r.
-// FASTL: which LDS layout the rows live in (the general kernel solves working sets of <= 64 of its rows with the same code).
+// LT: the tier whose LDS layout the rows live in (the general / large tiers solve working sets of <= 64 of their rows with the same code).
 // SL[0 .. nslot): lane that holds the dense row of slot k (an entry outside [0, nefc) = that row is not part of this solve).
-template <bool FASTL, bool DENSE>
+template <int LT, bool DENSE>
 __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb, double* S, int nefc, FastRow& row, const double (&Y)[UHC_YM], const LaneConst& LC,
                                           const int* SL, int nslot PROF_ARGS) {
     const DevTopo& T = A.t;
-    const DevLds& L = FASTL ? A.lf : A.l;
+    const DevLds& L = lds_of<LT>(A);
     const bool valid = LANE < nefc;
     int ntwo = 0;  // dense rows taking part (wave-uniform)
     if constexpr (DENSE) {
@@ -1787,7 +1801,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
         default: iters = pgs_sweeps<64, false>(Arow, f, w, diag, rb, false, 0.0, T.iterations, scale, T.tolerance); break;
     }
     row.f = f;
-    if (!FASTL && T.solver == 1 && !any_fric) return -1;  // a working set of the general kernel that is not solved exactly is of no use to it
+    if (LT != 1 && T.solver == 1 && !any_fric) return -1;  // a working set of the general kernel that is not solved exactly is of no use to it
     }
     const double f = row.f;
     PROF(11)
@@ -1827,23 +1841,34 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // warm-start force.  Returns the number of factorisations, or a negative reason (friction-loss rows, 64 rows with a force and more violated, no
 // convergence in UHC_WS_MAXIT rounds, a working set the pivoting cannot solve: -1 .. -4): the caller then runs the sweeps.
 #define UHC_WS_MAXIT 16
-template <bool DENSE>
+// NRL = rows per lane: 2 in the general tier (<= 128 rows), 4 in the large tier (<= 256 rows); row r lives in lane r % 64, slot r / 64.
+template <int TIER, bool DENSE>
 __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC PROF_ARGS) {
+    constexpr int NRL = TIER == 3 ? 4 : 2;
     const DevTopo& T = A.t;
-    const DevLds& L = A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
+    const int* RY = (const int*)(S + L.rowY);
     const int YS = T.maxdepth + 1;
     int* NI = (int*)(S + L.ncon_nefc);
-    const int nslot = (DENSE && A.ndense_g > 0) ? NI[2] : 0;
+    const int nslot = (DENSE && cap_of<TIER>(A).ndense > 0) ? NI[2] : 0;
     int* SLg = NI + 4 + UHC_MAXTWO;           // slot -> lane of the current working set
     int* list = (int*)(S + L.rowAref);        // working-set row ids (rowAref only holds friction-loss bounds, unused here)
     double* z = S + L.z;
-    const int r0 = LANE, r1 = LANE + UHC_WAVE;
-    const bool v0 = r0 < nefc, v1 = r1 < nefc;
-    if (wave_or((v0 && RTYPE(RM[r0].type) == ROW_FRICTION) || (v1 && RTYPE(RM[r1].type) == ROW_FRICTION))) return -1;
+    const unsigned long long below = (1ull << LANE) - 1ull;
+    int rr[NRL];
+    bool vv[NRL];
+    bool fric = false;
+#pragma unroll
+    for (int h = 0; h < NRL; h++) {
+        rr[h] = LANE + h * UHC_WAVE;
+        vv[h] = rr[h] < nefc;
+        fric = fric || (vv[h] && RTYPE(RM[rr[h]].type) == ROW_FRICTION);
+    }
+    if (wave_or(fric)) return -1;
     // the warm-start forces survive for the sweeps fallback (which must start where the reference's PGS starts)
-    if (v0) S[L.rowW + r0] = S[L.rowF + r0];
-    if (v1) S[L.rowW + r1] = S[L.rowF + r1];
+#pragma unroll
+    for (int h = 0; h < NRL; h++) if (vv[h]) S[L.rowW + rr[h]] = S[L.rowF + rr[h]];
     for (int i = LANE; i < T.nv; i += UHC_WAVE) z[i] = 0.0;
     wsync();
     // ---- islands: kinematic trees that share no contact row have independent QPs (A is block diagonal), so each island gets its own
@@ -1862,27 +1887,31 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
             if (a != b) label[max(a, b)] = min(a, b);
         }
     wsync();
-    int isl[2] = {-1, -1};
-    for (int h = 0; h < 2; h++) {
-        const int rr = h ? r1 : r0;
-        if (!(h ? v1 : v0)) continue;
-        const RowMisc rm = RM[rr];
+    int isl[NRL];
+    bool fpos[NRL];
+    // ---- first candidates: the rows whose warm-start force (k_rows: the force the previous substep's acceleration implies) is positive.
+    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free.  (A cold start -- the rows
+    //      that 8 matrix-free Gauss-Seidel sweeps from f = 0 leave with a force -- costs as much as three register-resident solves and
+    //      was slower on every workload measured, also when the warm start marks more rows than lanes: those are capped below.)
+#pragma unroll
+    for (int h = 0; h < NRL; h++) {
+        isl[h] = -1;
+        fpos[h] = vv[h] && S[L.rowF + rr[h]] > 0.0;
+        if (!vv[h]) continue;
+        const RowMisc rm = RM[rr[h]];
         int a;
         if (rm.type & ROW_TWO) a = T.body_rootid[(int)S[L.con + rm.aux * UHC_CON_STRIDE + 20]];
         else a = T.dof_rootid[rm.last];
         while (label[a] != a) a = label[a];
         isl[h] = a;
     }
-    // ---- first candidates: the rows whose warm-start force (k_rows: the force the previous substep's acceleration implies) is positive.
-    //      Contacts persist from substep to substep, so this is nearly the final active set, and it is free.  (A cold start -- the rows
-    //      that 8 matrix-free Gauss-Seidel sweeps from f = 0 leave with a force -- costs as much as three register-resident solves and
-    //      was slower on every workload measured, also when the warm start marks more rows than lanes: those are capped below.)
-    const bool f0pos = v0 && S[L.rowF + r0] > 0.0, f1pos = v1 && S[L.rowF + r1] > 0.0;
+    wsync();  // (the dense rows' Delassus columns may live where the contacts were: nothing reads the contacts from here on)
     double* ztot = S + L.vec;
     for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] = 0.0;
     int iters = 0;
     unsigned long long todo = 0ull;  // island labels present (nbody <= 64)
-    for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int h = 0; h < NRL; h++) {
 #pragma unroll 1
         for (int b = 1; b < T.nbody; b++) todo |= __builtin_amdgcn_ballot_w64(isl[h] == b) ? (1ull << b) : 0ull;
     }
@@ -1896,18 +1925,22 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
         while (rest) {
             const int I = __ffsll((long long)rest) - 1;
             rest &= rest - 1;
-            const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[0] == I && f0pos)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[1] == I && f1pos));
+            int c = 0;
+#pragma unroll
+            for (int h = 0; h < NRL; h++) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(isl[h] == I && fpos[h]));
             if (G == 0ull || (!nomerge && gcount + c <= 48)) { G |= 1ull << I; gcount += c; }
         }
         todo &= ~G;
-        const bool in0 = isl[0] >= 0 && ((G >> isl[0]) & 1ull), in1 = isl[1] >= 0 && ((G >> isl[1]) & 1ull);
-        bool c0 = in0 && f0pos, c1 = in1 && f1pos, done = false, split = false;
-        bool p0 = false, p1 = false;  // rows of the working set that carry a force after the last solve: they must stay
+        bool in[NRL], c[NRL], p[NRL];  // in the group; candidate of the working set; carried a force after the last solve (must stay)
+#pragma unroll
+        for (int h = 0; h < NRL; h++) { in[h] = isl[h] >= 0 && ((G >> isl[h]) & 1ull); c[h] = in[h] && fpos[h]; p[h] = false; }
+        bool done = false, split = false;
         for (int outer = 0; outer < UHC_WS_MAXIT && !done; outer++) {
             // ---- compact the group's working set into the lanes (row order kept)
-            const unsigned long long below = (1ull << LANE) - 1ull;
-            unsigned long long m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1);
-            int n0 = __builtin_popcountll(m0), nC = n0 + __builtin_popcountll(m1);
+            unsigned long long m[NRL];
+            int nC = 0;
+#pragma unroll
+            for (int h = 0; h < NRL; h++) { m[h] = __builtin_amdgcn_ballot_w64(c[h]); nC += __builtin_popcountll(m[h]); }
             if (nC > UHC_WAVE) {
                 if (__builtin_popcountll(G) > 1) {
                     split = true;  // too many candidates for one solve: take the group's islands one at a time
@@ -1915,26 +1948,42 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
                 }
                 // one island, more candidates than lanes: the rows with a force stay, the others join in row order while there is room
                 // (the rest wait for a later round: any violated row that joins lowers the dual cost, so this still terminates)
-                const unsigned long long q0 = __builtin_amdgcn_ballot_w64(c0 && !p0), q1 = __builtin_amdgcn_ballot_w64(c1 && !p1);
-                const int room = UHC_WAVE - (nC - __builtin_popcountll(q0) - __builtin_popcountll(q1));
+                unsigned long long q[NRL];
+                int nq = 0;
+#pragma unroll
+                for (int h = 0; h < NRL; h++) { q[h] = __builtin_amdgcn_ballot_w64(c[h] && !p[h]); nq += __builtin_popcountll(q[h]); }
+                const int room = UHC_WAVE - (nC - nq);
                 if (room <= 0) return -2;  // 64 rows carry a force and more want in: beyond one register-resident solve
-                c0 = c0 && (p0 || __builtin_popcountll(q0 & below) < room);
-                c1 = c1 && (p1 || __builtin_popcountll(q0) + __builtin_popcountll(q1 & below) < room);
-                m0 = __builtin_amdgcn_ballot_w64(c0); m1 = __builtin_amdgcn_ballot_w64(c1);
-                n0 = __builtin_popcountll(m0); nC = n0 + __builtin_popcountll(m1);
+                int before = 0;
+                nC = 0;
+#pragma unroll
+                for (int h = 0; h < NRL; h++) {
+                    c[h] = c[h] && (p[h] || before + __builtin_popcountll(q[h] & below) < room);
+                    before += __builtin_popcountll(q[h]);
+                    m[h] = __builtin_amdgcn_ballot_w64(c[h]);
+                    nC += __builtin_popcountll(m[h]);
+                }
             }
             if (nC == 0) {  // no candidate: f = 0 is optimal on this group iff b >= 0 on its rows
-                c0 = in0 && S[L.rowB + r0] < 0.0; c1 = in1 && S[L.rowB + r1] < 0.0;
-                if (!wave_or(c0 || c1)) {
-                    if (in0) S[L.rowF + r0] = 0.0;
-                    if (in1) S[L.rowF + r1] = 0.0;
+                bool any = false;
+#pragma unroll
+                for (int h = 0; h < NRL; h++) { c[h] = in[h] && S[L.rowB + rr[h]] < 0.0; any = any || c[h]; }
+                if (!wave_or(any)) {
+#pragma unroll
+                    for (int h = 0; h < NRL; h++) if (in[h]) S[L.rowF + rr[h]] = 0.0;
                     wsync();
                     done = true;
                 }
                 continue;
             }
-            if (c0) list[__builtin_popcountll(m0 & below)] = r0;
-            if (c1) list[n0 + __builtin_popcountll(m1 & below)] = r1;
+            {
+                int off = 0;
+#pragma unroll
+                for (int h = 0; h < NRL; h++) {
+                    if (c[h]) list[off + __builtin_popcountll(m[h] & below)] = rr[h];
+                    off += __builtin_popcountll(m[h]);
+                }
+            }
             if (LANE < nslot) SLg[LANE] = -1;
             wsync();
             const bool valid = LANE < nC;
@@ -1947,51 +1996,53 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
             row.type = valid ? RTYPE(rm.type) : 0;
             row.last = (valid && !two) ? rm.last : (valid ? -1 : 0);
             row.len = (valid && !two) ? T.dof_depth[rm.last] + 1 : 0;
-            row.yoff = r * YS;
+            row.yoff = valid ? RY[r] : 0;
             row.R = valid ? S[L.rowR + r] : 1.0; row.b = valid ? S[L.rowB + r] : 0.0; row.f = 0.0; row.floss = 0.0; row.diag = 1.0;
             if (two) SLg[row.two] = LANE;
             double Y[UHC_YM];
             static_for<0, UHC_YM>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                Y[q] = q < row.len ? S[L.Y + r * YS + q] : 0.0;
+                Y[q] = q < row.len ? S[L.Y + row.yoff + q] : 0.0;
             });
             wsync();
             PROF(30)
-            const int it = k_pgs_fast<false, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum_C f Yhat
+            const int it = k_pgs_fast<TIER, DENSE>(A, mb, S, nC, row, Y, LC, SLg, nslot PROF_PASS);  // exact on C (or its sweeps to tolerance); z = sum_C f Yhat
             if (it < 0) return -4;  // pivot breakdown / no convergence of the pivoting on this working set
             iters += it > 0 ? it : 1;
             // ---- forces back to the island's rows, y on its rows outside C
-            if (in0) S[L.rowF + r0] = 0.0;
-            if (in1) S[L.rowF + r1] = 0.0;
+#pragma unroll
+            for (int h = 0; h < NRL; h++) if (in[h]) S[L.rowF + rr[h]] = 0.0;
             wsync();
             if (valid) S[L.rowF + r] = row.f;
             wsync();
-            bool viol[2] = {false, false}, keep[2] = {false, false};
-            for (int h = 0; h < 2; h++) {
-                const int rr = h ? r1 : r0;
-                if (!(h ? in1 : in0)) continue;
-                const bool inC = h ? c1 : c0;
-                if (inC) { keep[h] = S[L.rowF + rr] > 0.0; continue; }
-                const RowMisc q = RM[rr];
-                double y = S[L.rowB + rr];
+            bool viol[NRL], keep[NRL], anyv = false;
+#pragma unroll
+            for (int h = 0; h < NRL; h++) {
+                viol[h] = keep[h] = false;
+                if (!in[h]) continue;
+                if (c[h]) { keep[h] = S[L.rowF + rr[h]] > 0.0; continue; }
+                const RowMisc q = RM[rr[h]];
+                double y = S[L.rowB + rr[h]];
                 if (q.type & ROW_TWO) {
                     const double* D = S + L.dense + (q.type >> 8) * A.nvp;
                     for (int i = 0; i < T.nv; i++) y = fma(D[i], z[i], y);
                 } else {
                     const int len = T.dof_depth[q.last] + 1;
                     const short* anc = T.dof_anc + q.last * YS;
-                    for (int k = 0; k < len; k++) y = fma(S[L.Y + rr * YS + k], z[anc[k]], y);
+                    const double* Yr = S + L.Y + RY[rr[h]];
+                    for (int k = 0; k < len; k++) y = fma(Yr[k], z[anc[k]], y);
                 }
                 viol[h] = y < 0.0;
+                anyv = anyv || viol[h];
             }
             PROF(31)
-            if (!wave_or(viol[0] || viol[1])) {  // KKT holds on every row of the island: its optimum
+            if (!wave_or(anyv)) {  // KKT holds on every row of the island: its optimum
                 for (int i = LANE; i < T.nv; i += UHC_WAVE) ztot[i] += z[i];
                 wsync();
                 done = true;
             } else {
-                c0 = keep[0] || viol[0]; c1 = keep[1] || viol[1];
-                p0 = keep[0]; p1 = keep[1];
+#pragma unroll
+                for (int h = 0; h < NRL; h++) { c[h] = keep[h] || viol[h]; p[h] = keep[h]; }
                 wsync();
             }
         }
@@ -2004,37 +2055,33 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
 }
 
 // ------------------------------------------------------------------ mj_forward
-struct FwdOut { int ncon, nefc, iters, overflow; };  // FAST: overflow => redo with the general kernel
-template <bool FAST, bool DENSE>
+struct FwdOut { int ncon, nefc, iters, overflow; };  // overflow bit 0: the env does not fit this tier => redone by the next one
+template <int TIER, bool DENSE>
 __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP PROF_ARGS) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     FwdOut out = {0, 0, 0, 0};
-    k_kinematics<FAST>(A, mb, S, BC PROF_PASS);
+    k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
     PROF(1)
-    k_com_pos<FAST>(A, mb, S, BC);
+    k_com_pos<TIER>(A, mb, S, BC);
     PROF(2)
-    k_crb<FAST>(A, mb, S, MP, BC PROF_PASS);
+    k_crb<TIER>(A, mb, S, MP, BC PROF_PASS);
     PROF(3)
-    if (!FAST) {
-        for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
-        wsync();
-    }
-    k_factor<FAST>(A, S, L.LD, LC);
+    k_factor<TIER>(A, S, L.LD, LC);
     PROF(4)
-    k_com_vel<FAST>(A, S, BC);
+    k_com_vel<TIER>(A, S, BC);
     PROF(5)
-    k_rne<FAST>(A, S, BC PROF_PASS);
+    k_rne<TIER>(A, S, BC PROF_PASS);
     PROF(6)
-    k_smooth<FAST>(A, mb, S, LC);
+    k_smooth<TIER>(A, mb, S, LC);
     PROF(7)
-    out.ncon = k_collision<FAST, DENSE>(A, mb, S, &out.overflow, PC);
+    out.ncon = k_collision<TIER, DENSE>(A, mb, S, &out.overflow, PC);
     PROF(8)
-    out.nefc = k_enumerate_rows<FAST, DENSE>(A, mb, S, out.ncon, &out.overflow);
+    out.nefc = k_enumerate_rows<TIER, DENSE>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
-    if (FAST && (out.overflow & 1)) return out;
+    if (out.overflow & 1) return out;  // (bit 0 is only raised by a tier that hands the env on)
     if (out.nefc > 0) {
-        if (FAST) {
+        if constexpr (TIER == 1) {
             FastRow row;
             double Yreg[UHC_YM];
             const int st = k_rows_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
@@ -2042,20 +2089,20 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             if (st == 1) return out;
             PROF(9)
             const int* NI = (const int*)(S + L.ncon_nefc);
-            out.iters = k_pgs_fast<true, DENSE>(A, mb, S, out.nefc, row, Yreg, LC, NI + 4, DENSE ? NI[2] : 0 PROF_PASS);
+            out.iters = k_pgs_fast<1, DENSE>(A, mb, S, out.nefc, row, Yreg, LC, NI + 4, DENSE ? NI[2] : 0 PROF_PASS);
             PROF(12)
         } else {
-            k_rows<FAST>(A, mb, S, out.nefc, LC);
+            if (k_rows<TIER>(A, mb, S, out.nefc, LC)) { out.overflow |= 1; return out; }  // the packed rows need the next tier's storage
             PROF(9)
             int it = -1;
-            if (T.solver == 1) it = k_as_general<DENSE>(A, mb, S, out.nefc, LC PROF_PASS);
+            if (T.solver == 1) it = k_as_general<TIER, DENSE>(A, mb, S, out.nefc, LC PROF_PASS);
             if (it < 0) {
                 if (T.solver == 1) {  // the working sets gave up: sweep from the warm start, as the reference's PGS does
                     for (int r = LANE; r < out.nefc; r += UHC_WAVE) S[L.rowF + r] = S[L.rowW + r];
                     wsync();
                 }
                 out.overflow |= 4 | (T.solver == 1 ? (4 << (-it)) : 0);
-                it = k_pgs<FAST>(A, mb, S, out.nefc);
+                it = k_pgs<TIER>(A, mb, S, out.nefc);
             }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1; 8 / 16 / 32 / 64: why the working sets gave up (bits 2-5)
             out.iters = it;
             PROF(11)
@@ -2063,7 +2110,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
         // qacc = qacc_smooth + L^-1 D^-1/2 z
         if (LANE < T.nv) x.a = S[L.z + LANE] * S[L.sdinv + LANE];
         if (LANE + UHC_WAVE < T.nv) x.b = S[L.z + LANE + UHC_WAVE] * S[L.sdinv + LANE + UHC_WAVE];
-        k_solve<FAST>(A, S, L.LD, x, 1, LC);
+        k_solve<TIER>(A, S, L.LD, x, 1, LC);
     }
     if (LANE < T.nv) S[L.qacc + LANE] = S[L.smooth + LANE] + x.a;
     if (LANE + UHC_WAVE < T.nv) S[L.qacc + LANE + UHC_WAVE] = S[L.smooth + LANE + UHC_WAVE] + x.b;
@@ -2073,10 +2120,10 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
 
 // ------------------------------------------------------------------ P10 semi-implicit Euler
 // acc: LDS offset of the acceleration the velocity update uses (qacc, or the implicitly damped one left by k_damped_accel)
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_euler(const KernelArgs& A, double* S, int acc) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const double h = T.timestep;
     for (int i = LANE; i < T.nv; i += UHC_WAVE) S[L.qvel + i] += h * S[acc + i];
     wsync();
@@ -2108,25 +2155,23 @@ __device__ __forceinline__ bool bad(double x) { return isnan(x) || x > UHC_MAXVA
 // a = qacc - (M + h B)^-1 (h B qacc) -- the right-hand side is diagonal, so neither force vector has to be kept.  M comes from
 // the parked copy of this forward pass (FAST) or S.M; the factor overwrites LD (rebuilt by the next forward pass / PD solve).
 // Result in S[L.smooth] (qacc_smooth is dead after k_forward); S[L.qacc] keeps the explicit acceleration (warm start, checks).
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_damped_accel(const KernelArgs& A, const double* mb, double* S, const MPark& MP, const LaneConst& LC) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const double h = T.timestep;
-    if (FAST) {
 #pragma unroll
-        for (int m = 0; m < UHC_MREG; m++) {
-            const int e = LANE + UHC_WAVE * m;
-            if (e < T.nM) S[L.LD + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
-        }
-    } else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    for (int m = 0; m < UHC_MREG; m++) {
+        const int e = LANE + UHC_WAVE * m;
+        if (e < T.nM) S[L.LD + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
+    }
     wsync();
     DofVec x = {0.0, 0.0};
     if (LC.v0) { const double hb = h * mb[A.o.dof_damping + LANE]; S[L.LD + LC.m0] += hb; x.a = hb * S[L.qacc + LANE]; }
     if (LC.v1) { const double hb = h * mb[A.o.dof_damping + LANE + UHC_WAVE]; S[L.LD + LC.m1] += hb; x.b = hb * S[L.qacc + LANE + UHC_WAVE]; }
     wsync();
-    k_factor<FAST>(A, S, L.LD, LC);
-    k_solve<FAST>(A, S, L.LD, x, 0, LC);
+    k_factor<TIER>(A, S, L.LD, LC);
+    k_solve<TIER>(A, S, L.LD, x, 0, LC);
     if (LC.v0) S[L.smooth + LANE] = S[L.qacc + LANE] - x.a;
     if (LC.v1) S[L.smooth + LANE + UHC_WAVE] = S[L.qacc + LANE + UHC_WAVE] - x.b;
     wsync();
@@ -2135,10 +2180,10 @@ __device__ __forceinline__ void k_damped_accel(const KernelArgs& A, const double
 // ------------------------------------------------------------------ E3/E4 stable PD, E5 implicit residual force
 // compute_torque + compute_desired_accel (humanoid_im.py:1014-1076): uses the M and bias left by the
 // previous forward pass (S.M, S.bias); factorises M + diag(kd) dt into S.LD (overwritten later by P3).
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, const double* action, const double* tbase, int it, const MPark& MP, const LaneConst& LC PROF_ARGS) {
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const DevCtrl& C = A.c;
     const double dt = T.timestep;
     const int nu = T.nu, vf = C.rfc_mode == 1 ? 6 : C.rfc_mode == 2 ? C.n_vf_body * C.body_vf_dim : 0;
@@ -2147,13 +2192,11 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
         skp = clampd(action[nu + vf + it] + 1, 0, 10);
         skd = clampd(action[nu + vf + it + C.n_substeps] + 1, 0, 10);
     }
-    if (FAST) {
 #pragma unroll
-        for (int m = 0; m < UHC_MREG; m++) {
-            const int e = LANE + UHC_WAVE * m;
-            if (e < T.nM) S[L.LD + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
-        }
-    } else for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.LD + e] = S[L.M + e];
+    for (int m = 0; m < UHC_MREG; m++) {
+        const int e = LANE + UHC_WAVE * m;
+        if (e < T.nM) S[L.LD + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
+    }
     wsync();
     PROF(24)
     // lane owns dofs LANE and LANE+64; actuator a drives dof 6+a (free root first)
@@ -2179,12 +2222,12 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
     }
     wsync();
     PROF(16)
-    k_factor<FAST>(A, S, L.LD, LC);
+    k_factor<TIER>(A, S, L.LD, LC);
     PROF(17)
     DofVec x;
     x.a = LANE < T.nv ? -S[L.bias + LANE] - kp[0] * qe[0] - kd[0] * qv[0] : 0.0;
     x.b = LANE + UHC_WAVE < T.nv ? -S[L.bias + LANE + UHC_WAVE] - kp[1] * qe[1] - kd[1] * qv[1] : 0.0;
-    k_solve<FAST>(A, S, L.LD, x, 0, LC);
+    k_solve<TIER>(A, S, L.LD, x, 0, LC);
     PROF(18)
     for (int h = 0; h < 2; h++) {
         const int a = LANE + h * UHC_WAVE - 6;
@@ -2196,9 +2239,9 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
     }
     wsync();
 }
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_rfc_implicit(const KernelArgs& A, double* S, const double* action) {
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const DevCtrl& C = A.c;
     if (LANE == 0) {
         double vf[6], q[4], rq[4], hq[4], R[9], r[3];
@@ -2219,9 +2262,9 @@ __device__ __forceinline__ void k_rfc_implicit(const KernelArgs& A, double* S, c
 // the body frame; qfrc_applied = sum_b J_b(point)^T [f; tau].  With cdof about the root's subtree COM c0 this is
 // qfrc_i = cdof_i . W_sub(body(i)), W_b = [tau + (p - c0) x f ; f] summed over the subtree of the dof's body.
 // Uses the kinematics left by the previous forward pass (xpos, xmat, cdof, subtree COM), as the reference does.
-template <bool FAST>
+template <int TIER>
 __device__ __forceinline__ void k_rfc_explicit(const KernelArgs& A, double* S, const double* action) {
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     const DevTopo& T = A.t;
     const DevCtrl& C = A.c;
     double* W = S + L.cfrc;  // free between substeps
@@ -2265,14 +2308,14 @@ __device__ __forceinline__ void k_rfc_explicit(const KernelArgs& A, double* S, c
 // launches the general variant on exactly those envs.
 // DENSE: the model has contacts between two moving bodies (convex-convex pairs): MPR narrow phase + dense rows are compiled in.  The
 // floor-only stock model runs the DENSE = false instantiation, whose code and register allocation are those of the kernel without them.
-template <int MODE, bool FAST, bool DENSE>
+template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
     const int env = blockIdx.x;
     if (env >= A.n_env) return;
     if (d_active && !d_active[env]) return;
     const DevTopo& T = A.t;
-    const DevLds& L = FAST ? A.lf : A.l;
+    const DevLds& L = lds_of<TIER>(A);
     double* S = smem;
 #ifdef UHC_POISON_LDS  // debug builds (tools/poison_build.py): any read of LDS the kernel did not write first meets a NaN / a huge int
     for (int i = LANE; i < L.total; i += UHC_WAVE) S[i] = __longlong_as_double(0x7ff8dead7fffbeefll);
@@ -2290,8 +2333,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         if (MODE == 0) S[L.bias + i] = A.s.bias[(size_t)env * T.nv + i];
     }
     for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
-    if (MODE == 0 && !FAST) for (int e = LANE; e < T.nM; e += UHC_WAVE) S[L.M + e] = A.s.qM[(size_t)env * T.nM + e];
-    {   // (row, col) of the sparse mass-matrix entries, two per 32-bit word
+    if (TIER == 1) {   // (row, col) of the sparse mass-matrix entries, two per 32-bit word
         unsigned int* dst = (unsigned int*)(S + L.mij);
         const unsigned int* src = (const unsigned int*)T.m_ij;
         for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
@@ -2318,7 +2360,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
 #pragma unroll
     for (int m = 0; m < UHC_MREG; m++) {
         const int e = LANE + UHC_WAVE * m;
-        const double v = (FAST && MODE == 0 && e < T.nM) ? A.s.qM[(size_t)env * T.nM + e] : 0.0;
+        const double v = (MODE == 0 && e < T.nM) ? A.s.qM[(size_t)env * T.nM + e] : 0.0;
         agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v));
     }
     wsync();
@@ -2327,7 +2369,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     bool ran = false, fits = true;  // fits (general kernel): every substep of this step was within the fast kernel's capacity
     PROF_DECL
     if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
-        k_kinematics<FAST>(A, mb, S, BC PROF_PASS);
+        k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
         for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
             A.s.xpos[(size_t)env * 3 * T.nbody + i] = S[L.xpos + i];
             A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
@@ -2336,7 +2378,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         return;
     }
     if (MODE == 1) {
-        fo = k_forward<FAST, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+        fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
         overflow |= fo.overflow;
         ran = true;
     } else if (!fail) {
@@ -2347,27 +2389,27 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         for (int it = fresh ? -1 : 0; it < A.c.n_substeps; it++) {
             int b = 0;
             if (it >= 0) {
-            if (A.c.action_type == 0) k_pd_torque<FAST>(A, S, action, tbase, it, MP, LC PROF_PASS);
+            if (A.c.action_type == 0) k_pd_torque<TIER>(A, S, action, tbase, it, MP, LC PROF_PASS);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
                     S[L.ctrl + a] = clampd(action[a] * A.c.a_scale[a] * 100, -A.c.torque_lim[a], A.c.torque_lim[a]);
                 wsync();
             }
-            if (A.c.rfc_mode == 1) k_rfc_implicit<FAST>(A, S, action);
-            else if (A.c.rfc_mode == 2) k_rfc_explicit<FAST>(A, S, action);
+            if (A.c.rfc_mode == 1) k_rfc_implicit<TIER>(A, S, action);
+            else if (A.c.rfc_mode == 2) k_rfc_explicit<TIER>(A, S, action);
             // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             }
             PROF(0)
-            fo = k_forward<FAST, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+            fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
-            if (FAST && (overflow & 1)) break;
-            if (!FAST && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
-            if (!FAST) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= UHC_FAST_MAXCON &&
-                              (!(DENSE && A.ndense_g > 0) || ((const int*)(S + L.ncon_nefc))[2] <= UHC_FAST_MAXTWO);
+            if (overflow & 1) break;
+            if (TIER != 1 && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
+            if (TIER != 1) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= UHC_FAST_MAXCON &&
+                              (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= UHC_FAST_MAXTWO);
             ran = true;
             if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
                 wsync();
@@ -2378,15 +2420,15 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             b = 0;
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qacc + i]);
             if (wave_or(b)) { fail = 1; break; }
-            if (T.has_damping) { k_damped_accel<FAST>(A, mb, S, MP, LC); k_euler<FAST>(A, S, L.smooth); }
-            else k_euler<FAST>(A, S, L.qacc);
+            if (T.has_damping) { k_damped_accel<TIER>(A, mb, S, MP, LC); k_euler<TIER>(A, S, L.smooth); }
+            else k_euler<TIER>(A, S, L.qacc);
             PROF(14)
         }
     }
-    if (FAST && (overflow & 1)) {  // nothing committed: the general kernel redoes this env from the same inputs
+    if (overflow & 1) {  // nothing committed: the next tier redoes this env from the same inputs
         if (LANE == 0) {
-            A.s.redo[env] = 1;
-            if (MODE == 0) atomicAdd(A.s.path_stats, 1ull);
+            if (TIER == 1) A.s.redo[env] = 1; else A.s.redo2[env] = 1;
+            if (TIER == 1 && MODE == 0) atomicAdd(A.s.path_stats, 1ull);
         }
         return;
     }
@@ -2401,14 +2443,11 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     for (int i = LANE; i < T.nu; i += UHC_WAVE) A.s.ctrl[(size_t)env * T.nu + i] = S[L.ctrl + i];
     if (ran) {
         for (int i = LANE; i < T.nv; i += UHC_WAVE) A.s.bias[(size_t)env * T.nv + i] = S[L.bias + i];
-        if (FAST) {
 #pragma unroll
-            for (int m = 0; m < UHC_MREG; m++) {
-                const int e = LANE + UHC_WAVE * m;
-                if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
-            }
+        for (int m = 0; m < UHC_MREG; m++) {
+            const int e = LANE + UHC_WAVE * m;
+            if (e < T.nM) A.s.qM[(size_t)env * T.nM + e] = __hiloint2double(agpr_get(MP.hi[m]), agpr_get(MP.lo[m]));
         }
-        else for (int e = LANE; e < T.nM; e += UHC_WAVE) A.s.qM[(size_t)env * T.nM + e] = S[L.M + e];
         for (int i = LANE; i < 3 * T.nbody; i += UHC_WAVE) {
             A.s.xpos[(size_t)env * 3 * T.nbody + i] = S[L.xpos + i];
             A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
@@ -2433,8 +2472,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         A.s.fail[env] = fail;
         if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
-        if (!FAST) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | swept;
-        if (!FAST && MODE == 0) {
+        if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | swept;
+        if (TIER != 1 && MODE == 0) {
             atomicAdd(A.s.path_stats + 2, 1ull);
             if (fits) atomicAdd(A.s.path_stats + 1, 1ull);
         }  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
