@@ -109,6 +109,7 @@ def parse():
     p.add_argument("--general-only", action="store_true", help="ball_objects: skip the fast kernel (uhc_batch_set_kernel_path 1)")
     p.add_argument("--fixed-path", action="store_true", help="ball_objects: fast kernel then general kernel on every step (uhc_batch_set_kernel_path 0) instead of the adaptive default")
     p.add_argument("--no-pgs-probe", action="store_true", help="skip the short PGS (solver 0) kernel timings after the timed region")
+    p.add_argument("--no-probes", action="store_true", help="skip the self_collision / shapes / ball_objects sub-lines after the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
@@ -202,6 +203,97 @@ def cpu_ppo_baseline(agent, batch):
             "ppo_sample": f"median of {len(ts)} full epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads (physical cores)"}
 
 
+def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None):
+    """AgentCopycat on synthetic clips for the copycat rollout: `shapes` body shapes (configs[3]), `robot_cfg` overriding the config's
+    robot block (None: config/uhc_amd/copycat_mi355x.yml = the floor-only static asset; {} keys of a reference config = the generated
+    model class: body-body collisions on, rel_joint_lm ranges)."""
+    import tempfile
+    from uhc_amd import sim as S
+    from uhc_amd.agents.agent_copycat import AgentCopycat
+    from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle
+    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
+    from uhc_amd.utils.config_utils.copycat_config import Config
+
+    cfg = Config(cfg_id="copycat_mi355x", base_dir=tempfile.mkdtemp(prefix="uhc_bench_"))
+    cfg.n_env = args.envs
+    if robot_cfg is not None:
+        cfg.robot_cfg = dict(robot_cfg)
+    if args.pgs_iterations:
+        cfg.pgs_iterations = args.pgs_iterations
+    if args.solver is not None:
+        cfg.contact_solver = args.solver
+    cfg.no_log = True
+    specs = dict(cfg.data_specs)
+    specs["file_path"] = "synthetic"
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed + rank)
+    n_clips = max(args.clips, shapes + 1) if shapes else args.clips
+    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(n_clips, seed=1 + rank))
+    shape_models = clip_model = None
+    if shapes:  # SURVEY 8d config 4: per-body length scale s_b ~ U(0.85, 1.15) (mass ~ s^3, inertia ~ s^5), default_rng(7); one shape per clip
+        from uhc_amd.model.mjcf import kinematics_np, quat_to_mat, scale_model_per_body
+        base = S.load_asset_model()
+        srng = np.random.default_rng(7)
+        stand = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))["qpos"]
+
+        def lowest(m):  # lowest hull vertex of the standing pose: the clip of a longer-legged body carries its root higher
+            xp, xq, _, _ = kinematics_np(m, stand)
+            return min((m.mesh_vert[m.geom_vertadr[g]:m.geom_vertadr[g] + m.geom_vertnum[g]] @ quat_to_mat(xq[m.geom_bodyid[g]]).T + xp[m.geom_bodyid[g]])[:, 2].min()
+                       for g in range(m.ngeom) if m.geom_type[g] == 7)
+
+        z0 = lowest(base)
+        shape_models, lift = [], [0.0]
+        for _ in range(shapes):
+            sm = scale_model_per_body(base, np.r_[1.0, srng.uniform(0.85, 1.15, size=base.nbody - 1)])
+            shape_models.append(sm)
+            lift.append(z0 - lowest(sm))
+        keys = list(dl.data_keys)
+        clip_model = {k: (i % (shapes + 1)) for i, k in enumerate(keys)}
+        for k, mi in clip_model.items():
+            dl.data["trans"][k] = dl.data["trans"][k] + np.array([0.0, 0.0, lift[mi]])
+    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl, shape_models=shape_models, clip_model=clip_model)
+    agent.logger.handlers = [h for h in agent.logger.handlers if not isinstance(h, __import__("logging").StreamHandler) or hasattr(h, "baseFilename")]
+    return agent
+
+
+def rollout_probe(args, local, dtype, name, warmup=6, steps=14, **kw):
+    """A short rollout of a VARIANT of the metric's workload after the timed region (like the `pgs` lines): same step, same envs per
+    GPU, own agent.  Returns the sub-line: env-steps/s, kernel time, which tier computed the env-steps, row statistics."""
+    from uhc_amd import sim as S
+    agent = build_agent(args, 0, local, dtype, **kw)
+    agent.per_epoch_update(0)
+    env = agent.env
+    n_env = env.n_env
+    agent.rollout_begin(warmup + steps)
+    for _ in range(warmup):
+        agent.rollout_step()
+    torch.cuda.synchronize()
+    env.sim.set_timing(True)
+    redo0 = agent._ro.redo_counts.clone()
+    big = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.rollout_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    redo_d = (agent._ro.redo_counts - redo0).cpu().tolist()
+    ms, k = env.sim.kernel_time()
+    env.sim.set_timing(False)
+    nefc, ncon = env.sim.field(S.F_NEFC).cpu().numpy(), env.sim.field(S.F_NCON).cpu().numpy()
+    _, logger = agent.rollout_end()
+    out = {"env_steps_per_s": n_env * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup, "first_tier_kernel_ms": ms / max(k, 1),
+           "general_tier_share_of_env_steps": redo_d[0] / (n_env * steps), "sweeps_fallback_share_of_env_steps": redo_d[1] / (n_env * steps),
+           "large_tier_envs_last_step": int(((env.sim.field(S.F_REDO) & 0x40) != 0).sum().item()),
+           "nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()),
+           "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 257])[0].tolist(),
+           "efc_overflow_envs": int(env.sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(env.sim.field(S.F_FAIL).sum().item()),
+           "avg_episode_len": logger.avg_episode_len, "avg_reward": logger.avg_c_reward, "workload": name}
+    env.close()
+    del agent
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in the env, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Under
@@ -266,7 +358,7 @@ def bench_ball_objects(args):
     hist_nefc, hist_ncon, redo_tot, steps_done = [], [], 0, 0
 
     def run(k, timed):
-        nonlocal redo_tot, sweep_tot, steps_done
+        nonlocal redo_tot, sweep_tot, big_tot, steps_done
         for i in range(k):
             if steps_done % 30 == 0:
                 sim.set_state(q0d, v0d)
@@ -274,6 +366,7 @@ def bench_ball_objects(args):
             steps_done += 1
             if timed:
                 redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync
+                big_tot += ((sim.field(S.F_REDO) & 0x40) != 0).int()  # computed by the large tier (> 128 rows / 64 contacts / 16 body-body rows)
                 sweep_tot += ((sim.field(S.F_REDO) & 2) != 0).int()
                 r = sim.field(S.F_REDO)
                 for j in range(4):  # bits 2-5: why the working sets gave up (friction rows / > 64 candidates in one island / no convergence / unsolved set)
@@ -284,6 +377,7 @@ def bench_ball_objects(args):
 
     redo_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     sweep_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    big_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     why_tot = torch.zeros(4, dtype=torch.int64, device="cuda")
     sub_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
     run(args.warmup, False)
@@ -295,6 +389,7 @@ def bench_ball_objects(args):
     el = time.perf_counter() - t0
     ms, k = sim.kernel_time()
     nefc = torch.cat(hist_nefc).cpu().numpy() if hist_nefc else np.zeros(1)
+    redo_share = float(redo_tot.double().sum().item()) / (n_env * args.steps)
     ncon = torch.cat(hist_ncon).cpu().numpy() if hist_ncon else np.zeros(1)
     out = {"metric": "env-steps/sec (ball-joint SMPL humanoid + free objects, 15 substeps/step, physics only)", "value": n_env * args.steps / el, "unit": "env-steps/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -302,25 +397,29 @@ def bench_ball_objects(args):
            "config": {"workload": f"configs[4] stand-in: ball-joint humanoid (nq {m.nq}, nv {m.nv}), self-collision on, {K} free 5 kg boxes, torque actions, {n_env} envs, "
                                   "re-posed every 30 control steps; physics only", "envs_per_gpu": n_env, "objects": K, "kernel_path": "general only" if args.general_only else ("fast, then general on the envs beyond its capacity" if args.fixed_path else "adaptive (uhc_batch_set_kernel_path 2)"),
                       "contact_solver": "exact: active set in the fast kernel, working sets in the general kernel" if int(m.solver) == 1 else "pgs sweeps", "pgs_sweep_cap": int(m.iterations)},
-           "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, true, true>", "kernel_ms": ms / max(k, 1), "launches": k,
+           "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, 2, true> (general tier)" if (args.general_only or redo_share > 0.6) else "uhc_step_kernel<0, 1, true> (fast tier)", "kernel_ms": ms / max(k, 1), "launches": k,
                         "achieved": 8 * (2 * m.nq + 3 * m.nv + ctrl.action_dim + 7 * m.nbody) * n_env / (ms / max(k, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "note": "fast-kernel launches only (HIP events); envs beyond its capacity (64 rows / 16 contacts / 12 body-body rows) are redone by the general "
-                                "kernel in a second launch, which ms_per_step includes"},
+                        "note": "HIP events around the first tier launched (the fast kernel, or the general tier when the adaptive path skips the fast one); envs beyond a "
+                                "tier's capacity (fast: 64 rows / 16 contacts / 12 body-body rows; general: 128 / 64 / 16) are redone by the next tier in a further launch, "
+                                "which ms_per_step includes"},
            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()), "ncon_max": int(ncon.max()),
-                              "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129])[0].tolist(),
+                              "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257])[0].tolist(),
                               "general_kernel_share_of_env_steps": float(redo_tot.double().sum().item()) / (n_env * args.steps),
                               "sweeps_fallback_share_of_env_steps": float(sweep_tot.double().sum().item()) / (n_env * args.steps),
                               "sweeps_fallback_share_of_substeps": float(sub_tot.item()) / (n_env * args.steps * 15),
                               "sweeps_fallback_reasons_env_steps": dict(zip(["friction_rows", "island_needs_over_64_rows", "no_convergence", "unsolved_working_set"], why_tot.cpu().tolist())),
                               "efc_overflow_envs": int(sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(sim.field(S.F_FAIL).sum().item())}}
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
-    print(json.dumps(out))
+    out["workload_stats"]["large_tier_share_of_env_steps"] = float(big_tot.double().sum().item()) / (n_env * args.steps)
+    sim.close()
+    return out
 
 
 def main():
     args = parse()
     if args.workload == "ball_objects":
-        return bench_ball_objects(args)
+        print(json.dumps(bench_ball_objects(args)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -337,50 +436,8 @@ def main():
             td.init_process_group(args.backend, rank=rank, world_size=world)
     dtype = torch.float64 if args.ppo_dtype == "float64" else torch.float32
     torch.set_default_dtype(dtype)
-    import tempfile
     from uhc_amd import sim as S
-    from uhc_amd.agents.agent_copycat import AgentCopycat
-    from uhc_amd.data_loaders.dataset_amass_single import DatasetAMASSSingle
-    from uhc_amd.data_loaders.synthetic import make_synthetic_amass
-    from uhc_amd.utils.config_utils.copycat_config import Config
-
-    cfg = Config(cfg_id="copycat_mi355x", base_dir=tempfile.mkdtemp(prefix="uhc_bench_"))
-    cfg.n_env = args.envs
-    if args.pgs_iterations:
-        cfg.pgs_iterations = args.pgs_iterations
-    if args.solver is not None:
-        cfg.contact_solver = args.solver
-    cfg.no_log = True
-    specs = dict(cfg.data_specs)
-    specs["file_path"] = "synthetic"
-    torch.manual_seed(cfg.seed)
-    np.random.seed(cfg.seed + rank)
-    n_clips = max(args.clips, args.shapes + 1) if args.shapes else args.clips
-    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(n_clips, seed=1 + rank))
-    shape_models = clip_model = None
-    if args.shapes:  # per-body length scale s_b ~ U(0.85, 1.15) (mass ~ s^3, inertia ~ s^5), default_rng(7); one shape per clip
-        from uhc_amd.model.mjcf import kinematics_np, quat_to_mat, scale_model_per_body
-        base = S.load_asset_model()
-        srng = np.random.default_rng(7)
-        stand = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))["qpos"]
-
-        def lowest(m):  # lowest hull vertex of the standing pose: the clip of a longer-legged body carries its root higher
-            xp, xq, _, _ = kinematics_np(m, stand)
-            return min((m.mesh_vert[m.geom_vertadr[g]:m.geom_vertadr[g] + m.geom_vertnum[g]] @ quat_to_mat(xq[m.geom_bodyid[g]]).T + xp[m.geom_bodyid[g]])[:, 2].min()
-                       for g in range(m.ngeom) if m.geom_type[g] == 7)
-
-        z0 = lowest(base)
-        shape_models, lift = [], [0.0]
-        for _ in range(args.shapes):
-            sm = scale_model_per_body(base, np.r_[1.0, srng.uniform(0.85, 1.15, size=base.nbody - 1)])
-            shape_models.append(sm)
-            lift.append(z0 - lowest(sm))
-        keys = list(dl.data_keys)
-        clip_model = {k: (i % (args.shapes + 1)) for i, k in enumerate(keys)}
-        for k, mi in clip_model.items():
-            dl.data["trans"][k] = dl.data["trans"][k] + np.array([0.0, 0.0, lift[mi]])
-    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl, shape_models=shape_models, clip_model=clip_model)
-    agent.logger.handlers = [h for h in agent.logger.handlers if not isinstance(h, __import__("logging").StreamHandler) or hasattr(h, "baseFilename")]
+    agent = build_agent(args, rank, local, dtype, shapes=args.shapes)
     agent.per_epoch_update(0)
     env = agent.env
     n_env = env.n_env
@@ -436,7 +493,7 @@ def main():
             t_up = float(tt.item())
         n_samples = batch.states.shape[0] * world
         flops = n_samples * 503e6  # ~503 MFLOP per sample per iteration (10 epochs, both nets)
-        ppo = {"samples": n_samples, "update_s": t_up, "samples_per_s": n_samples / t_up, "dtype": args.ppo_dtype, "epochs": cfg.num_optim_epoch,
+        ppo = {"samples": n_samples, "update_s": t_up, "samples_per_s": n_samples / t_up, "dtype": args.ppo_dtype, "epochs": agent.cfg.num_optim_epoch,
                "gemm_tflops": flops / t_up / 1e12, "mfma_util": flops / t_up / 1e12 / (78.6 if args.ppo_dtype == "float64" else 157.3),
                "mfma_peak_tflops": 78.6 if args.ppo_dtype == "float64" else 157.3, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
         if ncalls:  # rank 0's view of the gradient exchange: one flat all-reduce per network per optimisation step
@@ -465,6 +522,18 @@ def main():
             agent.rollout_end()
             pgs[f"sweep_cap_{cap}"] = {"kernel_ms": ms / max(k, 1), "kernel_only_env_steps_per_s": n_env / (ms / max(k, 1) * 1e-3), "mean_sweeps_last_substep": sweeps, "launches": k}
         env.sim.set_solver(*orig)
+    # ---- the other configs of BASELINE.json as short probes of the same rollout step (driver-visible; the full-length lines are under profiles/)
+    probes = {}
+    if world == 1 and not args.no_probes and not args.shapes:
+        probes["self_collision"] = rollout_probe(args, local, dtype, "configs[1] on the model class the reference generates: body-body collisions on (smpl_parser.py:327-328), "
+                                                 "Chest / shoulder excludes, rel_joint_lm joint ranges; same clips, same policy", robot_cfg={"mesh": True, "model": "smpl"})
+        probes["shapes"] = rollout_probe(args, local, dtype, "configs[3] smpl_shape: 64 body shapes (per-body length scales ~ U(0.85, 1.15), default_rng(7)), one model blob per clip "
+                                         "(`--shapes 1023` runs 1024 of them)", shapes=63)
+        ba = argparse.Namespace(**vars(args))
+        ba.steps, ba.warmup, ba.general_only, ba.fixed_path = 24, 12, False, False
+        bo = bench_ball_objects(ba)
+        probes["ball_objects"] = {"env_steps_per_s": bo["value"], "ms_per_step": bo["ms_per_step"], "steps": ba.steps, "warmup": ba.warmup, "workload": bo["config"]["workload"],
+                                  "first_tier_kernel_ms": bo["roofline"]["kernel_ms"], **bo["workload_stats"]}
     if rank == 0:
         kern_ms = max(kern_total_ms / max(kern_n, 1), 1e-9)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
@@ -511,6 +580,7 @@ def main():
         }
         if pgs:
             out["pgs"] = pgs
+        out.update(probes)
         if ppo:
             out["ppo"] = ppo
         if world == 1 and not args.no_cpu_baseline:

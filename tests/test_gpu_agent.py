@@ -279,3 +279,55 @@ def test_facade_accessors_match_device_fields(tmp_path):
     t = env.cur_t
     np.testing.assert_allclose(env.data.qpos, env.expert["qpos"][min(t, env.expert["len"] - 1)], atol=1e-12)
     env.vec.close()
+
+
+def test_agent_iteration_on_the_generated_model_class(tmp_path):
+    """A reference config carries no `self_collision` / `rel_joint_lm` key: the env then runs the model class Robot(cfg.robot_cfg)
+    generates (body-body collisions on, Chest / shoulder excludes, tight knee / ankle / toe ranges: uhc/envs/humanoid_im.py:52-64,
+    uhc/smpllib/smpl_parser.py:327-328).  One full agent iteration (rollout through the dense-row kernels and the general tier, GAE,
+    PPO update, checkpoint, evaluation) on it, and nothing exceeds the capacity of the last tier."""
+    import torch
+    from uhc_amd import sim as S
+    from uhc_amd.agents import agent_dict
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path)
+    cfg.robot_cfg = {"mesh": True, "model": "smpl"}  # config/release/uhc_implicit_shape.yml:92-98
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
+    m = agent.env.model
+    assert (np.asarray(m.geom_contype)[1:] == 1).all() and m.nexclude == 2
+    assert m.jnt_range[m.joint_names.index("R_Knee_z")] == pytest.approx([-np.pi / 16, np.pi / 16])
+    info = agent.optimize_policy(0)
+    log = info["log"]
+    assert log.num_steps == 64 * 8 and 0.0 < log.avg_c_reward <= 1.0 and np.isfinite(log.avg_c_info).all()
+    assert int(agent.env.sim.field(S.F_FAIL).sum().item()) == 0 and int(agent.env.sim.field(S.F_EFC_OVERFLOW).sum().item()) == 0
+    assert "log_eval" in info and os.path.exists(os.path.join(cfg.model_dir, "iter_0001.p"))
+    agent.env.close()
+
+
+def test_agent_runs_every_clip_on_the_model_generated_from_its_beta(tmp_path):
+    """The reference's load_expert rebuilds the MuJoCo model from the clip's beta / gender (reset_robot, uhc/envs/humanoid_im.py:154-190).
+    Here the generator runs once per distinct (beta, gender) when the agent is built (body_provider: a synthetic stand-in for the
+    licensed SMPL forward pass), the models share the batch, and the device switches an env's model blob when it starts a clip."""
+    import torch
+    from uhc_amd import sim as S
+    from uhc_amd.agents import agent_dict
+    from uhc_amd.data_loaders.synthetic import make_synthetic_body_provider
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path)
+    cfg.robot_cfg = {"mesh": True, "model": "smpl"}
+    dl = _loader(cfg)
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=dl, body_provider=make_synthetic_body_provider())
+    env = agent.env
+    assert len(env.models) == len(dl.data_keys) == 6  # six clips, six betas, six bodies
+    masses = [float(m.body_mass.sum()) for m in env.models]
+    assert max(masses) - min(masses) > 1.0
+    assert all((np.asarray(m.geom_contype)[1:] == 1).all() for m in env.models)
+    info = agent.optimize_policy(0)
+    log = info["log"]
+    assert log.num_steps == 64 * 8 and 0.0 < log.avg_c_reward <= 1.0
+    assert int(env.sim.field(S.F_FAIL).sum().item()) == 0 and int(env.sim.field(S.F_EFC_OVERFLOW).sum().item()) == 0
+    # each env sits on the blob of the clip it is running (uhc_env_set_clip_models): total mass on the root translation of qM
+    qm00 = env.sim.field(S.F_QM)[:, 0].cpu().numpy()
+    assert len(set(np.round(qm00, 6))) > 1 and all(min(abs(q - m) for m in masses) < 1e-9 for q in qm00)
+    assert "log_eval" in info
+    env.close()

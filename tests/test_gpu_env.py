@@ -61,6 +61,24 @@ def _oracle_obs(E, obs_v, o, w, t, beta):
 
 @pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1), (3, 0), (5, 2), (0, 4), (2, 5), (2, 3)])
 def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
+    _rollout_check(model, ctrl, obs_v, reward_v)
+
+
+def test_env_rollout_on_the_generated_model_class(model, ctrl):
+    """The env layer (observation, reward, termination) on the model class the reference actually runs: what Robot(cfg.robot_cfg)
+    generates -- body-body collisions on (smpl_parser.py:327-328), Chest / shoulder excludes, rel_joint_lm knee / ankle / toe ranges
+    (smpl_robot.py:1087-1110) -- instead of the floor-only static asset.  The steps run through the dense-row kernels (and the general
+    tier when an env exceeds the fast one); the oracle follows the device's per-substep solver word."""
+    import dataclasses
+    from uhc_amd.smpllib.smpl_robot import robot_variant
+    gen = dataclasses.replace(robot_variant(model, {"mesh": True, "model": "smpl"}), solver=1)
+    assert (gen.geom_contype[1:] == 1).all() and gen.nexclude == 2
+    assert gen.jnt_range[gen.joint_names.index("L_Knee_x")] == pytest.approx([-np.pi / 16, np.pi])
+    stats = _rollout_check(gen, ctrl, 2, 0)
+    assert stats["max_ncon_two_body"] > 0  # body-body contacts did occur: the test is not the floor-only one in disguise
+
+
+def _rollout_check(model, ctrl, obs_v, reward_v):
     import torch
     from oracle import env_oracle as E
     from oracle.physics import OracleSim
@@ -94,6 +112,7 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     # ---- steps
     cur_t = np.zeros(n, dtype=int)
     alive = np.ones(n, dtype=bool)
+    two_body = 0
     for t in range(14):
         act = rng.normal(scale=0.1, size=(n, ctrl.action_dim))
         active = torch.from_numpy(alive.astype(np.int32)).cuda()
@@ -103,13 +122,15 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
         gdone, gfail, gend = (eb.field(f).cpu().numpy() for f in (S.E_DONE, S.E_FAIL, S.E_END))
         gpct, gparts = eb.field(S.E_PERCENT).cpu().numpy(), eb.field(S.E_REWARD_PARTS).cpu().numpy()
         gq = sb.field(S.F_QPOS).cpu().numpy()
+        redo = sb.field(S.F_REDO).cpu().numpy()
         for e in range(n):
             if not alive[e]:
                 continue
             o, w = os_[e], wins[e]
             prev_bquat = E.get_body_quat(o.get("qpos"))
             tb = w["qpos"][E.expert_index(cur_t[e] + 1, 0, w["len"])][7:]
-            o.do_simulation(act[e], tb)
+            o.do_simulation(act[e], tb, redo=redo[e])  # UHC_F_REDO bits 8+: substeps the general tier solved by sweeps (0 on the fast path)
+            two_body = max(two_body, _two_body_contacts(model, o))
             cur_t[e] += 1
             xpos, xquat, xipos = o.get("xpos").reshape(-1, 3), o.get("xquat").reshape(-1, 4), o.get("xipos").reshape(-1, 3)
             np.testing.assert_allclose(gq[e], o.get("qpos"), atol=1e-9)
@@ -137,6 +158,17 @@ def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
             if fail or end:
                 alive[e] = False
     assert not alive[3]  # the 12-frame window must have ended
+    return {"max_ncon_two_body": two_body}
+
+
+def _two_body_contacts(model, o):
+    """Contacts of the oracle's last forward pass that are not with the floor (ncon minus the plane contacts, by height of the normal)."""
+    n = o.geti("ncon")
+    if n == 0:
+        return 0
+    fr = o.get("con_frame").reshape(-1, 9)[:n]
+    pos = o.get("con_pos").reshape(-1, 3)[:n]
+    return int(((np.abs(fr[:, 2]) < 0.999) | (np.abs(pos[:, 2]) > 0.02)).sum())
 
 
 def test_env_inactive_and_second_clip(model, ctrl):

@@ -353,3 +353,54 @@ def test_per_body_scaled_models_share_one_batch(model, ctrl, standing, kernel_pa
         np.testing.assert_allclose(gv[e], os_[e].get("qvel"), atol=1e-7)
         np.testing.assert_allclose(gm[e], os_[e].get("qM"), atol=1e-9)
     assert np.abs(gm[1] - gm[0]).max() > 1e-3  # different bodies indeed
+
+
+def test_generated_shape_models_share_one_batch(model, ctrl, standing, kernel_path):
+    """(f)-1 end to end: beta -> vertices (synthetic body provider: the SMPL files are licensed) -> per-joint hulls -> MJCF -> compiled
+    model, for three betas whose hulls differ in size (`common_mesh_layout` pads them to one vertex layout; the hull graphs travel in the
+    model blobs).  The generated hinge models self-collide and carry the rel_joint_lm ranges.  GPU vs oracle over 20 control steps, every
+    env on its own model, as the reference rebuilds its model at every load_expert (uhc/envs/humanoid_im.py:154-190)."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.data_loaders.synthetic import make_synthetic_body_provider
+    from uhc_amd.model.mjcf import kinematics_np, quat_to_mat
+    from uhc_amd.smpllib.smpl_robot import generate_shape_models
+    clips = {f"c{i}": dict(beta=np.array([0.4 * i, -0.3 * i, 0.3 * i] + [0.0] * 7), gender=i % 3) for i in range(3)}
+    models, cm = generate_shape_models({"mesh": True, "model": "smpl"}, clips, make_synthetic_body_provider())
+    models = [dataclasses.replace(m, solver=1) for m in models]
+    assert len(models) == 3 and all((m.nq, m.nv, m.nu) == (76, 75, 69) for m in models)
+    assert all((np.asarray(m.geom_contype)[1:] == 1).all() and m.nexclude == 2 for m in models)
+    assert any(np.diff(m.mesh_adjadr).min() == 0 for m in models)  # some hull was padded: the layouts really differed
+    assert not np.array_equal(models[0].mesh_adj, models[2].mesh_adj)
+
+    def lowest(m, q):
+        xp, xq, _, _ = kinematics_np(m, q)
+        return min((m.mesh_vert[m.geom_vertadr[g]:m.geom_vertadr[g] + m.geom_vertnum[g]] @ quat_to_mat(xq[m.geom_bodyid[g]]).T + xp[m.geom_bodyid[g]])[:, 2].min()
+                   for g in range(m.ngeom) if m.geom_type[g] == 7)
+
+    env_model = [0, 1, 2, 2, 1]
+    n = len(env_model)
+    qpos, qvel = _states(standing, model, n, 21, noise=0.03, vel=0.1)
+    for e in range(n):
+        qpos[e, 2] += 0.002 - lowest(models[env_model[e]], qpos[e])  # feet 2 mm above the floor whatever the stature
+    act = np.random.default_rng(22).normal(scale=0.1, size=(n, ctrl.action_dim))
+    b = S.SimBatch(models, ctrl, n, env_model=env_model)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(models[env_model[e]], ctrl) for e in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    worst, ncon = 0.0, 0
+    for t in range(20):
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])
+            ncon += os_[e].geti("ncon")
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    assert ncon > 0 and worst < 1e-6, (ncon, worst)
+    assert int(b.field(S.F_FAIL).sum().item()) == 0 and int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0

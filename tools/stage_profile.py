@@ -39,7 +39,7 @@ if __name__ == "__main__":
     rng = np.random.default_rng(1)
     scene = os.environ.get("MODEL", "copycat")  # copycat | selfcol (body-body collisions on) | ball_objects (bench.py --workload ball_objects)
     if scene == "ball_objects":
-        from tests.helpers import box_triangles
+        from uhc_amd.model.shapes import box_triangles
         from uhc_amd.model.mjcf import add_free_bodies, ball_variant, hinge_to_ball_qpos, self_collision_variant
         base = model
         K = int(os.environ.get("OBJECTS", "4"))

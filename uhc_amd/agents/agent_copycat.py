@@ -40,11 +40,14 @@ def create_logger(filename):
 
 
 class AgentCopycat(AgentPPO):
-    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None, shape_models=None, clip_model=None):
+    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None, shape_models=None, clip_model=None, body_provider=None):
         """shape_models / clip_model: optional body shapes (models with the topology of the config's model) and the map clip key -> index
-        into [config model] + shape_models: smpl_shape-style training where every clip runs on its own body."""
+        into [config model] + shape_models: smpl_shape-style training where every clip runs on its own body.
+        body_provider: callable (betas, gender) -> (vertices, joints, skin weights) feeding the shape -> model generator (default: the SMPL
+        model files under <base_dir>/data/smpl when present): every clip then runs on the model generated from ITS beta and gender, as
+        the reference rebuilds its model at every load_expert (uhc/envs/humanoid_im.py:154-190)."""
         self.cfg = self.cc_cfg = cfg
-        self._shape_models, self._clip_model = shape_models, clip_model
+        self._shape_models, self._clip_model, self._body_provider = shape_models, clip_model, body_provider
         self.device, self.dtype, self.training = device, dtype, training
         self.max_freq = 50
         self.epoch = 0
@@ -81,8 +84,19 @@ class AgentCopycat(AgentPPO):
 
     def setup_env(self):
         dev_index = self.device.index if isinstance(self.device, torch.device) and self.device.index is not None else 0
-        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train", shape_models=self._shape_models)
-        self.env.set_clip_bank_from_loader(self.data_loader, clip_model=self._clip_model)
+        model = None
+        if self._shape_models is None:
+            from ..smpllib.smpl_robot import default_body_provider, generate_shape_models
+            provider = self._body_provider or default_body_provider(self.cfg)
+            if provider is not None:  # reset_robot for every distinct (beta, gender) of the data set, once
+                dl = self.data_loader
+                clips = {k: dict(beta=dl.data["beta"][k], gender=dl.data["gender"][k]) for k in dl.data_keys}
+                for tl in self.test_data_loaders[1:]:
+                    clips.update({k: dict(beta=tl.data["beta"][k], gender=tl.data["gender"][k]) for k in tl.data_keys})
+                models, self._clip_model = generate_shape_models(self.cfg.robot_cfg, clips, provider)
+                model, self._shape_models = models[0], models[1:]
+        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train", model=model, shape_models=self._shape_models)
+        self.env.set_clip_bank_from_loader(self.data_loader, clip_model={k: v for k, v in self._clip_model.items() if k in set(self.data_loader.data_keys)} if self._clip_model else None)
 
     def setup_policy(self):
         cfg, env = self.cfg, self.env
@@ -358,8 +372,9 @@ def _eval_seqs(self, take_keys, loader):
     n = min(len(take_keys), cfg.n_env)
     ev = getattr(self, "_eval_envs", {}).get((loader.name, n))
     if ev is None:
-        ev = VecHumanoidEnv(cfg, n_env=n, device=self.env.device.index or 0, mode="test", model=self.env.model)
-        ev.set_clip_bank_from_loader(loader)
+        ev = VecHumanoidEnv(cfg, n_env=n, device=self.env.device.index or 0, mode="test", model=self.env.model, shape_models=self.env.models[1:])
+        cm = getattr(self, "_clip_model", None)  # every clip is evaluated on its own body, as it is trained
+        ev.set_clip_bank_from_loader(loader, clip_model={k: cm[k] for k in loader.data_keys} if cm else None)
         self._eval_envs = getattr(self, "_eval_envs", {})
         self._eval_envs[(loader.name, n)] = ev
     ev.set_rfc_rate(self.env.rfc_rate)

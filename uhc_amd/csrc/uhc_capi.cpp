@@ -179,19 +179,18 @@ static int dalloc(UhcBatch* b, size_t n, T** dptr) {
 
 static bool same_topology(const UhcModelDesc& a, const UhcModelDesc& b) {
     if (a.nq != b.nq || a.nv != b.nv || a.nu != b.nu || a.nbody != b.nbody || a.njnt != b.njnt || a.ngeom != b.ngeom ||
-        a.nmeshvert != b.nmeshvert || a.nmeshadj != b.nmeshadj || a.nexclude != b.nexclude)
+        a.nmeshvert != b.nmeshvert || a.nexclude != b.nexclude)  // (hull graphs may differ: they live in the model blobs)
         return false;
     auto eq = [](const int32_t* x, const int32_t* y, size_t n) { return !memcmp(x, y, n * 4); };
     return eq(a.body_parentid, b.body_parentid, a.nbody) && eq(a.jnt_type, b.jnt_type, a.njnt) &&
            eq(a.jnt_bodyid, b.jnt_bodyid, a.njnt) && eq(a.dof_parentid, b.dof_parentid, a.nv) &&
            eq(a.geom_type, b.geom_type, a.ngeom) && eq(a.geom_bodyid, b.geom_bodyid, a.ngeom) &&
            eq(a.geom_vertadr, b.geom_vertadr, a.ngeom) && eq(a.geom_vertnum, b.geom_vertnum, a.ngeom) &&
-           eq(a.mesh_adjadr, b.mesh_adjadr, a.nmeshvert + 1) && eq(a.mesh_adj, b.mesh_adj, a.nmeshadj) &&
            eq(a.geom_contype, b.geom_contype, a.ngeom) && eq(a.geom_conaffinity, b.geom_conaffinity, a.ngeom) &&
            eq(a.jnt_limited, b.jnt_limited, a.njnt) && eq(a.geom_condim, b.geom_condim, a.ngeom);
 }
 
-static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>& blob) {
+static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>& blob, int adjdeg) {
     blob.clear();
     auto put = [&](const double* p, size_t n) { int off = (int)blob.size(); blob.insert(blob.end(), p, p + n); return off; };
     o.body_pos = put(d.body_pos, 3 * d.nbody); o.body_quat = put(d.body_quat, 4 * d.nbody);
@@ -211,6 +210,14 @@ static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>&
     o.mesh_vert = put(d.mesh_vert, 3 * (size_t)d.nmeshvert);
     o.actuator_gear = put(d.actuator_gear, 3 * (size_t)d.nu);
     o.meaninertia = put(&d.meaninertia, 1);
+    {   // hull graph: fixed stride, neighbour order = the CSR's order (the multi-contact rule takes neighbours in that order)
+        std::vector<int32_t> adj((size_t)std::max(d.nmeshvert, 1) * adjdeg + 2, -1);
+        for (int v = 0; v < d.nmeshvert; v++)
+            for (int e = d.mesh_adjadr[v], k = 0; e < d.mesh_adjadr[v + 1]; e++, k++) adj[(size_t)v * adjdeg + k] = d.mesh_adj[e];
+        std::vector<double> packed((adj.size() + 1) / 2, 0.0);
+        memcpy(packed.data(), adj.data(), adj.size() / 2 * 2 * sizeof(int32_t));
+        o.mesh_adj = put(packed.data(), packed.size());
+    }
     while (blob.size() % 2) blob.push_back(0.0);
     o.stride = (int)blob.size();
 }
@@ -341,15 +348,18 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(upload(b, ivec(d.geom_type, ng), &T.geom_type)); TRY(upload(b, ivec(d.geom_bodyid, ng), &T.geom_bodyid));
     TRY(upload(b, ivec(d.geom_condim, ng), &T.geom_condim)); TRY(upload(b, ivec(d.geom_vertadr, ng), &T.geom_vertadr));
     TRY(upload(b, ivec(d.geom_vertnum, ng), &T.geom_vertnum));
-    TRY(upload(b, ivec(d.mesh_adjadr, d.nmeshvert + 1), &T.mesh_adjadr)); TRY(upload(b, ivec(d.mesh_adj, d.nmeshadj), &T.mesh_adj));
     TRY(upload(b, pg1, &T.pair_g1)); TRY(upload(b, pg2, &T.pair_g2));
     TRY(upload(b, cg1, &T.cpair_g1)); TRY(upload(b, cg2, &T.cpair_g2)); TRY(upload(b, dof_rootid, &T.dof_rootid));
     TRY(upload(b, ivec(d.actuator_dofid, d.nu), &T.actuator_dofid));
 
     // ---- numeric blobs, one per model
     std::vector<double> all, one;
+    A.adjdeg = 1;
+    for (int k = 0; k < n_models; k++)
+        for (int v = 0; v < models[k]->d.nmeshvert; v++) A.adjdeg = std::max(A.adjdeg, models[k]->d.mesh_adjadr[v + 1] - models[k]->d.mesh_adjadr[v]);
+    if (A.adjdeg > UHC_WAVE - 1) { delete b; return fail("uhc_batch_create: a hull vertex with %d neighbours (> 63)", A.adjdeg); }
     for (int k = 0; k < n_models; k++) {
-        build_blob(models[k]->d, A.o, one);
+        build_blob(models[k]->d, A.o, one, A.adjdeg);
         all.insert(all.end(), one.begin(), one.end());
     }
     TRY(upload(b, all, &A.s.model_blob));
@@ -460,7 +470,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.dcol = F.con;  // the dense rows' Delassus columns are built when nothing reads the contacts any more (k_as_general)
         F.rowMisc = carve(maxefc * 2);  // 4 ints per row; the collision pass keeps its candidate-pair list here (256 ints)
         F.ncon_nefc = carve(2 + UHC_MAXTWO);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids, slot -> lane of the working set
-        F.rowY = carve(maxefc / 2);
+        F.rowY = carve(maxefc / 2 + 1);  // + the end of the last row
         F.rowR = carve(maxefc); F.rowAref = carve(maxefc); F.rowB = carve(maxefc); F.rowF = carve(maxefc); F.rowDa = carve(maxefc); F.rowW = carve(maxefc);
         // MPR walks hull vertices once per support call and lane: staged in LDS they cost an LDS read instead of an L2 round trip.  The
         // dense rows, their scalars and Yhat (contiguous) are not written before the collision pass is over: the vertices borrow them.

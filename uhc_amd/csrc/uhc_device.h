@@ -37,7 +37,6 @@ struct DevTopo {
     const unsigned short* m_ij;  // [nM (+pad)] the same, packed i << 8 | j (nv <= 128)
     const unsigned char* dof_ncommon;  // [nv][nv] number of common chain entries of two dofs (depth of LCA + 1, 0 if none)
     const int *geom_type, *geom_bodyid, *geom_condim, *geom_vertadr, *geom_vertnum;
-    const int *mesh_adjadr, *mesh_adj;
     const int *pair_g1, *pair_g2;  // statically filtered candidate geom pairs (g1 = plane, g2 = mesh)
     const int *cpair_g1, *cpair_g2;  // statically filtered convex-convex candidate pairs (mesh, mesh), g1 < g2, in (g1, g2) order
     int ncpair;
@@ -62,6 +61,7 @@ struct DevNumOff {
     int dof_armature, dof_damping, dof_frictionloss, dof_invweight0;
     int geom_pos, geom_quat, geom_friction, geom_margin, geom_gap, geom_solref, geom_solimp, geom_rbound, geom_center;
     int mesh_vert, actuator_gear, meaninertia;
+    int mesh_adj;  // int32 [nmeshvert][adjdeg] neighbours of every hull vertex (global vertex ids, -1 = none), packed two per double
     int stride;  // doubles per model
 };
 
@@ -125,6 +125,7 @@ struct KernelArgs {
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
+    int adjdeg;              // stride of the per-model hull adjacency table (largest vertex degree over the batch's models)
     DevCtrl c;
     DevState s;
     int n_env;

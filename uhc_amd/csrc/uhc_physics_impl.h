@@ -839,11 +839,13 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             }
             if (bd > margin) continue;
             // candidate 0 = support vertex, candidates 1.. = its hull neighbours (adjacency order)
-            const int e0 = T.mesh_adjadr[bv], deg = T.mesh_adjadr[bv + 1] - e0;
+            // (the hull graph belongs to the env's model: body shapes generated from different betas have different hulls.  Fixed-stride
+            //  table of neighbour ids in the model blob, -1 past a vertex's own degree)
+            const int* adj = (const int*)(mb + A.o.mesh_adj) + (size_t)bv * A.adjdeg;
             bool ok = false;
             double w[3] = {0, 0, 0}, dist = 0;
-            if (LANE <= deg && LANE < UHC_WAVE) {
-                const int v = LANE == 0 ? bv : T.mesh_adj[e0 + LANE - 1];
+            const int v = LANE == 0 ? bv : (LANE <= A.adjdeg ? adj[LANE - 1] : -1);
+            if (v >= 0) {
                 double lv[3] = {mb[A.o.mesh_vert + 3 * v], mb[A.o.mesh_vert + 3 * v + 1], mb[A.o.mesh_vert + 3 * v + 2]};
                 mat_vec(w, m2, lv);
                 for (int k = 0; k < 3; k++) { w[k] += xp2[k]; dist += n[k] * (w[k] - ppos[k]); }
@@ -1097,6 +1099,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
         ytot += tot;
     }
     if (ytot + 8 > cap_of<TIER>(A).ycap) return 1;
+    if (LANE == 0) RY[nefc] = ytot;  // (so that a row's length is RY[r + 1] - RY[r])
     const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
     for (int k = 0; k < ntwo; k++) {  // dense rows first (wave-cooperative); their scalars wait in dcol for the lane that owns the row
         const DenseOut o = k_dense_row<TIER>(A, S, NI[4 + k], k, LC);
@@ -1213,6 +1216,18 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
     double* z = S + L.z;
     const int* NI = (const int*)(S + L.ncon_nefc);
     const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
+    // the dof chains (which dof sits at position q of the chain that ends in dof i) are read once per row and sweep: from L2 that is a
+    // ~600-cycle round trip on the row-to-row critical path (hundreds of rows x up to `iterations` sweeps).  The contacts' storage is
+    // dead by now (the rows are built, the working sets -- if any -- have given up): the table is staged there.
+    const short* anc_tab = T.dof_anc;
+    if constexpr (TIER != 1) {
+        short* dst = (short*)(S + L.con);
+        if ((size_t)T.nv * YS * sizeof(short) <= (size_t)cap_of<TIER>(A).maxcon * UHC_CON_STRIDE * sizeof(double)) {
+            for (int i = LANE; i < T.nv * YS; i += UHC_WAVE) dst[i] = T.dof_anc[i];
+            anc_tab = dst;
+            wsync();
+        }
+    }
     // z from the warm-start forces: dof-per-lane pull over all rows (dense rows carry last = -1 and are added from their slots)
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
         const int di = T.dof_depth[i], nd = T.dof_ndesc[i];
@@ -1236,7 +1251,7 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
             for (int i = 0; i < T.nv; i++) af += D[i] * z[i];
         } else {
             const int last = rm.last, len = T.dof_depth[last] + 1;
-            const short* anc = T.dof_anc + last * YS;
+            const short* anc = anc_tab + last * YS;
             for (int q = 0; q < len; q++) af += S[L.Y + RY[r] + q] * z[anc[q]];
         }
         cost += f * (0.5 * af + S[L.rowB + r]);
@@ -1254,7 +1269,7 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
         for (int r = 0; r < nefc; r++) {
             const RowMisc rm = RM[r];
             const bool two = (rm.type & ROW_TWO) != 0;
-            const int len = two ? 0 : T.dof_depth[rm.last] + 1;
+            const int len = RY[r + 1] - RY[r];  // 0 for dense rows
             int dof = 0;
             double y = 0, part = 0, y1 = 0;
             if (two) {  // dense row: lane = dof (two per lane)
@@ -1262,7 +1277,7 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
                 if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
                 if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
             } else if (LANE < len) {
-                dof = T.dof_anc[rm.last * YS + LANE];
+                dof = anc_tab[rm.last * YS + LANE];
                 y = S[L.Y + RY[r] + LANE];
                 part = y * z[dof];
             }

@@ -31,3 +31,48 @@ def make_synthetic_amass(n_clips=64, seed=1, t_range=(150, 300), amp=0.3, root_h
         out[f"0-synth_{c:04d}"] = {"pose_aa": pose, "pose_6d": pose_6d, "trans": trans, "beta": rng.normal(scale=0.5, size=10),
                                   "gender": "neutral", "seq_name": f"0-synth_{c:04d}"}
     return out
+
+
+def make_synthetic_body_provider(vary_hulls=True):
+    """A stand-in for the SMPL forward pass (licensed model files: absent) with the same interface as uhc_amd.smpllib.smpl_robot.SMPLBody:
+    (betas, gender) -> (vertices (V, 3), joints (24, 3), skin weights (V, 24)), everything in the SMPL rest pose and joint order.
+    The "body" is the shipped neutral asset's own hulls; beta[0] scales the stature (all joint offsets), beta[1] the girth (vertices about
+    their joint), gender shifts the girth a little; with `vary_hulls`, beta[2] drops a few vertices of the hands and feet, so that
+    different betas give hulls of different sizes (what real shapes do after decimation).  Feeds the shape -> model generator in tests
+    and in `bench.py`; it is NOT an SMPL model."""
+    from ..model.mjcf import kinematics_np, quat_to_mat
+    from ..sim import load_asset_model
+    from ..smpllib.smpl_mujoco import SMPL_BONE_ORDER_NAMES
+    model = load_asset_model()
+    xpos, xquat, _, _ = kinematics_np(model, model.qpos0)
+    verts, owner = [], []
+    for g in range(model.ngeom):
+        if model.geom_type[g] != 7:
+            continue
+        b = model.geom_bodyid[g]
+        v = model.mesh_vert[model.geom_vertadr[g]:model.geom_vertadr[g] + model.geom_vertnum[g]] @ quat_to_mat(xquat[b]).T + xpos[b]
+        verts.append(v)
+        owner += [SMPL_BONE_ORDER_NAMES.index(model.body_names[b])] * len(v)
+    verts0, owner = np.concatenate(verts), np.array(owner)
+    joints0 = np.stack([xpos[model.body_names.index(n)] for n in SMPL_BONE_ORDER_NAMES])
+    small = [SMPL_BONE_ORDER_NAMES.index(n) for n in ("L_Hand", "R_Hand", "L_Toe", "R_Toe")]
+
+    def provider(betas, gender):
+        b = np.r_[np.asarray(betas, dtype=np.float64).reshape(-1), np.zeros(3)]
+        stature = 1.0 + 0.04 * np.tanh(b[0])
+        girth = 1.0 + 0.08 * np.tanh(b[1]) + 0.02 * (int(gender) - 1)
+        joints = joints0[0] + (joints0 - joints0[0]) * stature
+        v = joints[owner] + (verts0 - joints0[owner]) * girth * stature
+        keep = np.ones(len(v), dtype=bool)
+        if vary_hulls:
+            k = int(abs(b[2]) * 4) % 4  # 0..3 vertices dropped per small hull
+            for j in small:
+                idx = np.nonzero(owner == j)[0]
+                # the vertices closest to the hull's centre line go first: the hull keeps its extent
+                d = np.linalg.norm(v[idx] - v[idx].mean(0), axis=1)
+                keep[idx[np.argsort(d)[:k]]] = False
+        W = np.zeros((int(keep.sum()), 24))
+        W[np.arange(int(keep.sum())), owner[keep]] = 1
+        return v[keep], joints, W
+
+    return provider

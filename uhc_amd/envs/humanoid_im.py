@@ -33,7 +33,16 @@ class VecHumanoidEnv:
         self.cc_cfg = self.cfg = cfg
         self.mode = mode
         self.n_env = int(n_env)
-        self.model = model if model is not None else S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh"))
+        if model is None:
+            # the reference never loads the asset file: its env model comes out of Robot(cfg.robot_cfg) (humanoid_im.py:52-64) -- body-body
+            # collisions on, rel_joint_lm ranges, ball joints if asked.  Without the licensed SMPL files the shipped asset stands in for
+            # the generator's body, put into the form the generator emits; `model=` / `shape_models=` take generated models as they are
+            from ..smpllib.smpl_robot import robot_variant
+            model = robot_variant(S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh")), cfg.robot_cfg)
+            shape_models = [robot_variant(m, cfg.robot_cfg) for m in (shape_models or [])]  # shapes of the asset: converted with it
+        if int(model.nq) != int(model.nv) + 1:
+            raise NotImplementedError("robot.ball: the quaternion observation / reward of the ball-joint env are not built (the physics is: sim.SimBatch)")
+        self.model = model
         self.models = [self.model] + list(shape_models or [])
         iters = int(getattr(cfg, "pgs_iterations", 300))
         self.models = [dataclasses.replace(m, iterations=iters, solver=int(getattr(cfg, "contact_solver", 0))) for m in self.models]

@@ -1203,3 +1203,49 @@ def export_mjcf(m: Model, density: Optional[float] = None) -> str:
         out.append("  </actuator>")
     out.append("</mujoco>")
     return "\n".join(out) + "\n"
+
+
+def common_mesh_layout(models: List[Model]) -> List[Model]:
+    """Make models of one kinematic topology share ONE batch although their hulls differ (body shapes generated from different betas:
+    uhc/envs/humanoid_im.py:154-190 rebuilds the model per clip; hulls are decimated to <= 50 vertices, smaller ones keep their own count).
+    The batch wants the same vertex range per geom in every model: each geom is padded to the largest count it has in any of the models
+    by repeating its FIRST vertex at the end.  A repeated vertex changes nothing: support queries break ties towards the lowest vertex
+    id (plane-mesh arg-min and MPR's first arg-max, in the kernels and in the oracle alike), and the copies have no hull-graph
+    neighbours.  Hull graphs stay per model (they travel in the model blobs)."""
+    if len(models) < 2:
+        return list(models)
+    ng = models[0].ngeom
+    assert all(m.ngeom == ng and np.array_equal(m.geom_type, models[0].geom_type) for m in models), "same geoms expected"
+    vmax = np.max(np.stack([m.geom_vertnum for m in models]), axis=0)
+    out = []
+    for m in models:
+        if np.array_equal(m.geom_vertnum, vmax):
+            out.append(m)
+            continue
+        o = m.copy()
+        verts, adr_new, remap = [], np.full(ng, -1, dtype=np.int32), np.full(m.nmeshvert, -1, dtype=np.int64)
+        base = 0
+        for g in range(ng):
+            if m.geom_type[g] != GEOM_MESH:
+                continue
+            a, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
+            v = m.mesh_vert[a:a + n]
+            verts.append(np.concatenate([v, np.repeat(v[:1], int(vmax[g]) - n, axis=0)]))
+            adr_new[g] = base
+            remap[a:a + n] = base + np.arange(n)
+            base += int(vmax[g])
+        o.mesh_vert = np.concatenate(verts) if verts else np.zeros((0, 3))
+        o.nmeshvert = base
+        o.geom_vertadr, o.geom_vertnum = adr_new, vmax.astype(np.int32)
+        adjadr = np.zeros(base + 1, dtype=np.int32)
+        deg = np.zeros(base, dtype=np.int32)
+        old_deg = np.diff(m.mesh_adjadr)
+        deg[remap[:m.nmeshvert]] = old_deg
+        adjadr[1:] = np.cumsum(deg)
+        adj = np.zeros(int(adjadr[-1]), dtype=np.int32)
+        for v_old in range(m.nmeshvert):
+            s, e = int(m.mesh_adjadr[v_old]), int(m.mesh_adjadr[v_old + 1])
+            adj[adjadr[remap[v_old]]:adjadr[remap[v_old]] + (e - s)] = remap[m.mesh_adj[s:e]]
+        o.mesh_adjadr, o.mesh_adj, o.nmeshadj = adjadr, adj, int(adjadr[-1])
+        out.append(o)
+    return out

@@ -168,6 +168,33 @@ def default_joint_range(joint_names, rel_joint_lm=True):
     return r
 
 
+def robot_variant(model, robot_cfg: dict):
+    """The shipped static asset turned into the model `Robot(robot_cfg)` GENERATES for the same body (what the reference's env runs on:
+    HumanoidEnv.__init__ builds its MuJoCo model from `cfg.robot_cfg`, never from the asset file, uhc/envs/humanoid_im.py:52-64):
+      * body-body collisions on, Chest excluded against both shoulders (smpl_parser.py:327-328, smpl_robot.py:1177-1198) -- unless the
+        config says `self_collision: false` (this build's own key: the floor-only behaviour of the static asset);
+      * `rel_joint_lm` (default true): the tight knee / ankle / toe ranges (smpl_robot.py:1087-1110);
+      * `ball: true`: one ball joint + three gear-vector motors per bone (skeleton_mesh_v2.py:183-193, :243-267).
+    Used where the SMPL model files (licensed, absent here) are not available to run the generator itself."""
+    from ..model.mjcf import JNT_HINGE, ball_variant, self_collision_variant, set_const
+    cfg = dict(robot_cfg or {})
+    m = model
+    if cfg.get("mesh", True) and cfg.get("self_collision", True):
+        m = self_collision_variant(m)
+    if cfg.get("rel_joint_lm", True) and not cfg.get("ball", False):
+        rng = default_joint_range([n for n in m.body_names[1:]], True)
+        m = m.copy()
+        for j, name in enumerate(m.joint_names):
+            if m.jnt_type[j] != JNT_HINGE or "_" not in name:
+                continue
+            body, ax = name.rsplit("_", 1)
+            if body in rng and ax in ("z", "y", "x"):
+                m.jnt_range[j] = np.deg2rad(rng[body]["zyx".index(ax)])
+    if cfg.get("ball", False):
+        m = ball_variant(m)
+    return m
+
+
 class Robot:
     """`Robot(cfg).load_from_skeleton(betas, gender)` -> `export_xml_string()` / `get_model()` (smpl_robot.py:917-1016, :1018-1257).
     cfg: the `robot` block of a config (mesh, ball, flatfoot, rel_joint_lm, model).  body_provider: callable (betas, gender) ->
@@ -252,3 +279,33 @@ class Robot:
         """The compiled model of the current shape (what reload_sim_model + load_model_from_xml produce, humanoid_im.py:1441-1454)."""
         from ..model.mjcf import compile_mjcf
         return compile_mjcf(self.xml, meshes=self.meshes)
+
+
+def default_body_provider(cfg):
+    """SMPLBody over <base_dir>/data/smpl when the (licensed) SMPL model files are there, else None."""
+    import os
+    d = os.path.join(getattr(cfg, "base_dir", "."), "data", "smpl")
+    if all(os.path.exists(os.path.join(d, f)) for f in ("SMPL_NEUTRAL.pkl", "SMPL_MALE.pkl", "SMPL_FEMALE.pkl")):
+        return SMPLBody(d)
+    return None
+
+
+def generate_shape_models(robot_cfg: dict, clips: dict, body_provider: Callable, solver_fields: Optional[dict] = None):
+    """What the reference does at every load_expert -- reset_robot: Robot.load_from_skeleton(beta, gender) -> export_xml_string ->
+    reload_sim_model (uhc/envs/humanoid_im.py:154-190, :1441-1454) -- done once for every distinct (beta, gender) among the clips.
+    clips: {key: {"beta": (10|16,) or (T, 16), "gender": ...}}.  Returns (models, clip_model): compiled models brought to one mesh layout
+    (`common_mesh_layout`: they share a batch, one blob each) and {key: index into models}."""
+    from ..model.mjcf import common_mesh_layout
+    robot = Robot(robot_cfg, body_provider=body_provider)
+    seen, models, clip_model = {}, [], {}
+    for k, c in clips.items():
+        beta = np.asarray(c["beta"], dtype=np.float64)
+        beta = beta[0] if beta.ndim == 2 else beta
+        g = int(np.asarray(c["gender"]).reshape(-1)[0])
+        tag = (beta.round(6).tobytes(), g)
+        if tag not in seen:
+            robot.load_from_skeleton(beta, gender=[g])
+            seen[tag] = len(models)
+            models.append(robot.get_model())
+        clip_model[k] = seen[tag]
+    return common_mesh_layout(models), clip_model
