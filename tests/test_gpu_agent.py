@@ -331,3 +331,34 @@ def test_agent_runs_every_clip_on_the_model_generated_from_its_beta(tmp_path):
     assert len(set(np.round(qm00, 6))) > 1 and all(min(abs(q - m) for m in masses) < 1e-9 for q in qm00)
     assert "log_eval" in info
     env.close()
+
+
+def test_facade_load_expert_rebuilds_the_robot(tmp_path):
+    """HumanoidEnv.load_expert(expert, reload_robot=True) -> reset_robot: a clip with another beta / gender gets the model generated from
+    it (uhc/envs/humanoid_im.py:154-190, 182-190); the same beta keeps the model; reload_robot=False never rebuilds."""
+    import torch
+    from uhc_amd.data_loaders.synthetic import make_synthetic_body_provider
+    from uhc_amd.envs import env_dict
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path)
+    cfg.robot_cfg = {"mesh": True, "model": "smpl"}
+    dl = _loader(cfg)
+    keys = list(dl.data_keys)
+    e0, e1 = dl.get_sample_from_key(keys[0], full_sample=True), dl.get_sample_from_key(keys[1], full_sample=True)
+    env = env_dict["humanoid_im"](cfg, init_expert=e0, data_specs=cfg.data_specs, mode="test", body_provider=make_synthetic_body_provider())
+    m0 = float(env.model.body_mass.sum())
+    assert (np.asarray(env.model.geom_contype)[1:] == 1).all()
+    env.reset()
+    env.step(np.zeros(env.action_dim))
+    env.load_expert(e1)  # another beta: another body
+    m1 = float(env.model.body_mass.sum())
+    assert abs(m1 - m0) > 1e-3 and env.vec.model is env.model
+    obs = env.reset()
+    assert np.isfinite(obs).all()
+    np.testing.assert_allclose(env.data.qpos, env.expert["qpos"][0], atol=1e-12)
+    vec = env.vec
+    env.load_expert(e1)
+    assert env.vec is vec  # same beta: nothing rebuilt
+    env.load_expert(e0, reload_robot=False)
+    assert env.vec is vec and float(env.model.body_mass.sum()) == m1
+    env.vec.close()

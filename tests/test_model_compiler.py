@@ -205,3 +205,40 @@ def test_scale_model_per_body_equals_a_recompile_of_the_scaled_meshes(model):
     np.testing.assert_allclose(o.body_mass, model.body_mass * s ** 3, rtol=1e-14)
     np.testing.assert_allclose(o.body_inertia, model.body_inertia * (s ** 5)[:, None], rtol=1e-14)
     assert o.nq == model.nq and np.array_equal(o.dof_madr, model.dof_madr)
+
+
+def test_pose_body_and_height_fix():
+    """fix_height_smpl_vanilla (uhc/data_process/process_amass_db.py:194-219) through a body provider: linear blend skinning on the SMPL
+    tree (known answers: a knee bent by 90 degrees carries its own vertices about the knee joint, a root yaw turns the body about the
+    pelvis), then the lowest vertex of frame 0 at z = 0 -- hooked into process_qpos_list (`fix_height=`)."""
+    from uhc_amd.data_loaders.synthetic import make_synthetic_body_provider
+    from uhc_amd.data_process.process_amass_db import process_qpos_list
+    from uhc_amd.smpllib.smpl_robot import make_fix_height, pose_body
+    J = np.array([[0.1 * j, 0.0, 1.0 - 0.03 * j] for j in range(24)])
+    v = np.array([J[4] + [0, 0, -0.2], J[0] + [0, 0.1, 0]])
+    W = np.zeros((2, 24))
+    W[0, 4] = W[1, 0] = 1
+    pose = np.zeros((24, 3))
+    pose[4] = [np.pi / 2, 0, 0]
+    np.testing.assert_allclose(pose_body(v, J, W, pose) - v, [[0, 0.2, 0.2], [0, 0, 0]], atol=1e-15)
+    pose = np.zeros((24, 3))
+    pose[0] = [0, 0, np.pi / 2]
+    np.testing.assert_allclose(pose_body(v, J, W, pose)[1] - J[0], [-0.1, 0, 0], atol=1e-15)
+    # blended weights: a vertex half on a rotating joint, half on its parent moves half way
+    W2 = np.zeros((1, 24))
+    W2[0, 4] = W2[0, 1] = 0.5
+    pose = np.zeros((24, 3))
+    pose[4] = [np.pi / 2, 0, 0]
+    np.testing.assert_allclose(pose_body(v[:1], J, W2, pose) - v[:1], [[0, 0.1, 0.1]], atol=1e-15)
+    # the hook: every kept clip starts with its lowest vertex on the floor
+    prov = make_synthetic_body_provider()
+    rng = np.random.default_rng(0)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "uhc_amd", "assets", "standing_neutral.npz"))
+    poses = np.tile(z["pose_aa"][10], (40, 1)) + rng.normal(scale=0.02, size=(40, 72))
+    db = [("ACCAD_s1_walk", {"poses": poses, "trans": np.tile([0.3, -0.2, 1.7], (40, 1)), "betas": rng.normal(size=16), "gender": "female", "mocap_framerate": 60.0})]
+    res = process_qpos_list(db, {}, fix_height=make_fix_height(prov), log=lambda *a: None)
+    (k, c), = res.items()
+    assert c["height_fixed"] is True and c["pose_aa"].shape[0] == 20
+    verts, joints, Wt = prov(c["beta"][:10], 2)
+    low = (pose_body(verts, joints, Wt, c["pose_aa"][0]) + c["trans"][0])[:, 2].min()
+    assert abs(low) < 1e-12 and np.ptp(c["trans"][:, 2]) == 0 and c["trans"][0, 0] == 0.3

@@ -5,9 +5,10 @@ annotations `sample_data/amass_copycat_occlusion_v2.pkl` {"0-" + name: {issue, i
   * subsample to 30 fps by integer stride int(mocap_framerate / 30);
   * annotated sequences: issue "sitting" / "airborne" with idxes -> truncated at idxes[0] (dropped if that leaves < 10 frames),
     any other issue -> dropped;  sequences shorter than 10 frames -> dropped;
-  * height fix (fix_height_smpl_vanilla, :199-219): shift trans z so that the lowest SMPL vertex of frame 0 touches z = 0 -- needs the
-    licensed SMPL model files, which this image lacks: pass `fix_height=` (callable (pose_aa, betas, trans, gender) -> trans) to
-    apply one; without it trans is kept and the fact is recorded under key "height_fixed": False;
+  * height fix (fix_height_smpl_vanilla, :199-219): shift trans z so that the lowest SMPL vertex of frame 0 touches z = 0:
+    `fix_height=uhc_amd.smpllib.smpl_robot.make_fix_height(body_provider)` (SMPLBody over the licensed SMPL files, which this image
+    lacks, or any (betas, gender) -> (vertices, joints, skin weights) provider; linear blend skinning without the pose blend shapes);
+    without the hook trans is kept and the fact is recorded under key "height_fixed": False;
   * pose_6d = first two columns of every joint's rotation matrix, float32 like the reference's convert_aa_to_orth6d
     (uhc/utils/transform_utils.py:91-100, 76-78).
 Split (:294-368): by the data-set prefix of the sequence name; as in the reference the table spells the validation split
@@ -109,10 +110,19 @@ if __name__ == "__main__":
     ap.add_argument("--occlusion", default="sample_data/amass_copycat_occlusion_v2.pkl")
     ap.add_argument("--take", default="copycat_take5")
     ap.add_argument("--out_dir", default="sample_data")
+    ap.add_argument("--smpl_dir", default="data/smpl", help="SMPL model files (licensed): with them the height fix of the reference is applied")
     args = ap.parse_args()
     np.random.seed(0)
     qpos_list = list(joblib.load(args.amass_db).items())
     np.random.shuffle(qpos_list)
-    train, test, valid = split_amass(process_qpos_list(qpos_list, joblib.load(args.occlusion)))
+    fix = None
+    try:
+        from ..smpllib.smpl_robot import SMPLBody, make_fix_height
+        body = SMPLBody(args.smpl_dir)
+        body._load(0)
+        fix = make_fix_height(body)
+    except (FileNotFoundError, ImportError) as e:
+        print(f"no height fix ({e})")
+    train, test, valid = split_amass(process_qpos_list(qpos_list, joblib.load(args.occlusion), fix_height=fix))
     for name, d in (("train", train), ("test", test), ("valid", valid)):
         joblib.dump(d, f"{args.out_dir}/amass_{args.take}_{name}.pkl")

@@ -227,20 +227,42 @@ class _Data:
 class HumanoidEnv:
     """Single-environment facade with the reference's constructor and methods (humanoid_im.py:49-70)."""
 
-    def __init__(self, cfg, init_expert, data_specs, mode="train", no_root=False, device=0):
-        self.vec = VecHumanoidEnv(cfg, 1, device=device, mode=mode)
-        self.cc_cfg, self.mode, self.no_root = cfg, mode, no_root
+    def __init__(self, cfg, init_expert, data_specs, mode="train", no_root=False, device=0, body_provider=None):
+        """body_provider: (betas, gender) -> (vertices, joints, skin weights) for the shape -> model generator; default: the SMPL files
+        under <base_dir>/data/smpl when present, else the shipped asset in generated form stands for every body (robot_variant)."""
+        from ..smpllib.smpl_robot import Robot, default_body_provider
+        self.cc_cfg, self.mode, self.no_root, self._device = cfg, mode, no_root, device
+        provider = body_provider or default_body_provider(cfg)
+        self.smpl_robot = Robot(cfg.robot_cfg, body_provider=provider) if provider is not None else None  # humanoid_im.py:53-58
+        self._robot_tag = None
+        self.vec = VecHumanoidEnv(cfg, 1, device=device, mode=mode, model=self._robot_model(init_expert))
+        self._bind()
+        self.body_diffw = self.vec.converter.get_new_diff_weight()[1:]
+        self.jpos_diffw = self.vec.converter.get_new_diff_weight()[:, None]
+        self.end_reward, self.start_ind, self.expert = 0.0, 0, None
+        self.prev_bquat = None
+        self.load_expert(init_expert, reload_robot=False)  # (the model of the first clip is already in place)
+
+    def _robot_model(self, expert_data):
+        """reset_robot (humanoid_im.py:154-180): the model generated from the clip's beta and gender, or None without a generator."""
+        if self.smpl_robot is None:
+            return None
+        beta = np.asarray(expert_data["beta"], dtype=np.float64)
+        beta = beta[0] if beta.ndim == 2 else beta
+        g = int(np.asarray(expert_data["gender"]).reshape(-1)[0])
+        self._robot_tag = (beta.round(6).tobytes(), g)
+        cache = self.__dict__.setdefault("_robot_models", {})
+        if self._robot_tag not in cache:
+            cache[self._robot_tag] = self.smpl_robot.load_from_skeleton(beta, gender=[g]).get_model()
+        return cache[self._robot_tag]
+
+    def _bind(self):
         v = self.vec
         self.model, self.converter, self.humanoid = v.model, v.converter, v.humanoid
         self.observation_space, self.action_space = v.observation_space, v.action_space
         self.ndof, self.vf_dim, self.meta_pd_dim, self.action_dim, self.obs_dim = v.ndof, v.vf_dim, v.meta_pd_dim, v.action_dim, v.obs_dim
-        self.body_diffw = v.converter.get_new_diff_weight()[1:]
-        self.jpos_diffw = v.converter.get_new_diff_weight()[:, None]
         self.base_rot, self.dt, self.frame_skip = v.base_rot, v.dt, 15
         self.np_random = v.np_random
-        self.end_reward, self.start_ind, self.expert = 0.0, 0, None
-        self.prev_bquat = None
-        self.load_expert(init_expert)
 
     rfc_rate = property(lambda self: self.vec.rfc_rate, lambda self, r: self.vec.set_rfc_rate(r))
     cur_t = property(lambda self: int(self.vec.cur_t[0].item()))
@@ -256,6 +278,16 @@ class HumanoidEnv:
         self.vec.set_mode(mode)
 
     def load_expert(self, expert_data, reload_robot=True):
+        if reload_robot and self.smpl_robot is not None:  # humanoid_im.py:189-190: a new body for a new beta / gender
+            tag = self._robot_tag
+            model = self._robot_model(expert_data)
+            if tag != self._robot_tag:
+                rate, seed_state = self.vec.rfc_rate, self.vec.np_random
+                self.vec.close()
+                self.vec = VecHumanoidEnv(self.cc_cfg, 1, device=self._device, mode=self.mode, model=model)
+                self.vec.np_random = seed_state
+                self.vec.set_rfc_rate(rate)
+                self._bind()
         self.expert = dict(expert_data)
         self.expert["meta"] = {"cyclic": False, "seq_name": expert_data["seq_name"]}
         self.expert.update(self.vec.expert_features(expert_data))

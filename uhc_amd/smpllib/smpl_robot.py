@@ -62,6 +62,46 @@ class SMPLBody:
         return verts, joints, d["weights"]
 
 
+def pose_body(verts, joints, skin_weights, pose_aa):
+    """Linear blend skinning of a rest-pose body (what `body_provider` returns) by 24 axis-angle joint rotations on the SMPL tree:
+    v' = sum_j w_j G_j [v; 1], G_j = prod over the chain of [R_k | J_k - R_k J_k] (smplx's lbs without the pose blend shapes, whose
+    effect on the lowest vertex of a standing or walking frame is millimetres).  Returns the posed vertices, root at its rest position."""
+    from scipy.spatial.transform import Rotation as sRot
+    R = sRot.from_rotvec(np.asarray(pose_aa, dtype=np.float64).reshape(24, 3)).as_matrix()
+    J = np.asarray(joints, dtype=np.float64)
+    G = np.zeros((24, 4, 4))
+    for j in range(24):
+        L = np.eye(4)
+        L[:3, :3] = R[j]
+        L[:3, 3] = J[j] - (J[SMPL_PARENTS[j]] if j > 0 else 0.0)
+        G[j] = L if j == 0 else G[SMPL_PARENTS[j]] @ L
+    for j in range(24):  # to transforms of rest-pose points: subtract the rest joint position first
+        G[j][:3, 3] -= G[j][:3, :3] @ J[j]
+    v = np.asarray(verts, dtype=np.float64)
+    T = np.einsum("vj,jab->vab", np.asarray(skin_weights, dtype=np.float64), G)
+    return np.einsum("vab,vb->va", T[:, :3, :3], v) + T[:, :3, 3]
+
+
+def make_fix_height(body_provider: Callable):
+    """fix_height_smpl_vanilla (uhc/data_process/process_amass_db.py:194-219): shift the clip so that the lowest vertex of its FIRST frame
+    touches z = 0.  -> callable (pose_aa (T, 72), betas, trans (T, 3), gender) -> trans, the `fix_height=` hook of process_qpos_list.
+    body_provider: SMPLBody (the licensed files) or any (betas, gender) -> (vertices, joints, skin weights)."""
+    names = {"neutral": 0, "male": 1, "female": 2}
+
+    def fix(pose_aa, betas, trans, gender):
+        g = gender.item() if isinstance(gender, np.ndarray) else gender
+        g = g.decode("utf-8") if isinstance(g, bytes) else g
+        if g not in names and g not in (0, 1, 2):
+            raise Exception("Gender Not Supported!!")
+        verts, joints, W = body_provider(np.asarray(betas, dtype=np.float64).reshape(-1)[:10], names.get(g, g))
+        v0 = pose_body(verts, joints, W, np.asarray(pose_aa)[0]) + np.asarray(trans, dtype=np.float64)[0]
+        out = np.array(trans, dtype=np.float64, copy=True)
+        out[:, 2] -= v0[:, 2].min()
+        return out
+
+    return fix
+
+
 # --------------------------------------------------------------------------------------------------------------------- hulls
 def _outward(tris: np.ndarray, centre: np.ndarray) -> np.ndarray:
     n = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
