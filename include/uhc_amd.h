@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UHC_ABI_VERSION 6
+#define UHC_ABI_VERSION 7
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -114,13 +114,15 @@ enum UhcField {
     UHC_F_SOLVER_ITER = 12, /* int32 [n_env] PGS sweeps used by the last solve */
     UHC_F_QFRC_APPLIED = 13, /* [n_env][nv] data.qfrc_applied of the last substep */
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
-    UHC_F_STAGE_PROF = 15,   /* int64 [n_env][32] per-stage shader-cycle counters (profiling builds only) */
-    UHC_F_REDO = 16          /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast kernel's capacity (64 rows, 16 contacts, packed
-                              * row storage, 12 body-body rows) and was computed by the general kernel (128 rows, 64 contacts, 32 body-body rows), which
-                              * solves the QP exactly too (working sets of <= 64 rows); bit 1: in at least one substep that solve fell back to solver 0
-                              * (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one island with 64 rows that carry a force and more that want in /
-                              * no convergence of the working sets / a working set the pivoting could not solve); bit 8 + k: substep k (< 23)
-                              * of the step was one of those (a checker that follows the same path needs to know which) */
+    UHC_F_STAGE_PROF = 15,   /* int64 [n_env][40] per-stage shader-cycle counters (profiling builds only) */
+    UHC_F_REDO = 16,         /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast tier's capacity (64 rows, 16 contacts, packed
+                              * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 16 body-body rows) or the
+                              * large one (256 / 128 / 32; bit 6), which solve the QP exactly too (working sets of <= 64 rows); bit 1: in at least one
+                              * substep that solve fell back to solver 0 (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one
+                              * island with 64 rows that carry a force and more that want in / no convergence of the working sets / a working set the
+                              * pivoting could not solve); bit 8 + k: substep k (< 23) of the step was one of those (a checker that follows the same
+                              * path needs to know which) */
+    UHC_F_TIER = 17          /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
 };
 
 const char* uhc_last_error(void);
@@ -148,12 +150,21 @@ int32_t uhc_batch_sync(UhcBatch* b);
 /* change rfc_scale between iterations (rfc_decay: uhc/agents/agent_copycat.py:283-290) */
 int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
 
-/* Which kernel computes a step: 0 (default) = the fast kernel on every env, then the general kernel on the envs beyond its capacity
- * (UHC_F_REDO); 1 = the general kernel alone -- for scenes where most envs exceed 64 rows (objects, self-collision on the ground) the
- * first pass is wasted work; 2 = adaptive: the library switches between the two from the kernels' own counts (to the general kernel alone
- * when > 60 % of the env-steps of an 8-step window were handed on, back when > 70 % of what it computed would have fitted the fast
- * kernel), read with a fixed lag, so the same sequence of calls switches at the same step.  Timing (uhc_batch_set_timing) brackets the
- * kernel that runs first. */
+/* Which kernel tier computes a step.  The fused step kernel exists in three tiers: fast (<= 64 constraint rows / 16 contacts / 12
+ * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 16; working sets; two workgroups per CU) and large
+ * (<= 256 / 128 / 32; a whole CU's LDS).  A tier that cannot hold an env leaves it untouched and hands it to the next one; what exceeds
+ * the large tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask MuJoCo for njmax 2500 / nconmax 500,
+ * uhc/khrylib/mocap/skeleton_mesh.py:46).
+ *   0 (default) = chain: the fast tier on every env, then the general tier on the envs it handed on, then the large tier;
+ *   1 = the general tier first (then the large one): for scenes where nearly every env exceeds the fast tier;
+ *   2 = sticky tiers: every env starts a step in the tier that computed its previous step (it comes down a tier only with room to
+ *       spare), and the general / large tiers' own envs run on a side stream BESIDE the fast tier's -- their launches last several times
+ *       longer per env, in a chain behind the fast tier the whole step would wait for them.  Results do not depend on the mode beyond
+ *       rounding (every tier solves the same QP exactly), and a rerun of the same calls takes the same tiers.  Not capture-safe across
+ *       uhc_batch_set_stream changes: the side stream forks from and joins the batch's stream with events.
+ * UHC_F_REDO of a step: bit 0 = computed by the general or large tier, bit 1 = its exact solve swept in some substep (bits 2-5 why,
+ * bits 8+ which substeps), bit 6 = computed by the large tier.  Timing (uhc_batch_set_timing) brackets the fast tier's launch (modes
+ * 0, 2) or the general tier's (mode 1). */
 int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode);
 
 /* switch the contact solver of the dual QP between launches: solver 0 / 1 and the sweep cap, as in UhcModelDesc (MuJoCo's opt.solver /

@@ -32,11 +32,14 @@ def _run(models, q0s, v0s, n_steps, applied=None, settle=0):
     b = S.SimBatch(models, passive_ctrl(models[0]), n, env_model=list(range(len(models))) if len(models) > 1 else None)
     b.set_state(torch.from_numpy(np.stack(q0s)), torch.from_numpy(np.stack(v0s)))
     act = torch.zeros(n, b.ctrl.action_dim, dtype=torch.float64, device="cuda")
+    swept = torch.zeros(n, dtype=torch.int64, device="cuda")
     for t in range(settle + n_steps):
         if applied is not None and t == settle:
             b.field(S.F_QFRC_APPLIED).copy_(torch.from_numpy(np.stack(applied)).cuda())
         b.simulate(act, act)
+        swept += ((b.field(S.F_REDO) & 2) != 0).long()  # steps whose exact solve gave up and swept to tolerance (general tier)
     b.sync()
+    b.swept_steps = swept.cpu().numpy()
     return b
 
 
@@ -59,9 +62,11 @@ def test_friction_cone_slip_threshold_gpu(kernel_path):
     ms, q0s = zip(*[scenario_tilted_gravity_box(t) for t in tans])
     n = 500
     q = np.zeros((4, 7))
+    swept = np.zeros(4, dtype=int)
     for e in range(4):  # gravity is a batch-wide option (MuJoCo's opt.gravity): one batch per slope
         b = _run([ms[e]], [q0s[e]], [np.zeros(6)], n)
         q[e] = b.field(S.F_QPOS).cpu().numpy()[0]
+        swept[e] = b.swept_steps[0]
         assert b.field(S.F_FAIL).sum().item() == 0
     t = n * ms[0].timestep
     for e, tt in enumerate(tans):
@@ -70,9 +75,12 @@ def test_friction_cone_slip_threshold_gpu(kernel_path):
             assert q[e, 0] == pytest.approx(0.5 * 9.81 * (np.sin(th) - np.cos(th)) * t * t, rel=0.12)
         else:
             assert abs(q[e, 0]) < 0.02 * 0.5 * 9.81 * np.sin(th) * t * t
-        # and the oracle's trajectory (both kernels solve the QP exactly: active set in registers / by working sets)
+        # and the oracle's trajectory.  Both tiers solve the QP exactly (active set in registers / working sets) and then agree with the
+        # oracle's exact solve to rounding over the 500 steps; only where the general tier's working sets gave up in some step and swept to
+        # the PGS tolerance (UHC_F_REDO bit 1, counted per env) the free-running oracle -- exact in every step -- is followed to 5e-5 only
         o = _oracle(ms[e], q0s[e], np.zeros(6), n, solver=1)
-        np.testing.assert_allclose(q[e], o.get("qpos"), atol=5e-5 if kernel_path == "general" else 1e-7)
+        print(f"tan(theta) = {tt}: steps solved by sweeps {swept[e]} / {n}, |gpu - oracle| = {np.abs(q[e] - o.get('qpos')).max():.2e}")
+        np.testing.assert_allclose(q[e], o.get("qpos"), atol=5e-5 if swept[e] else 1e-7)
 
 
 def test_tipping_threshold_gpu(kernel_path):

@@ -404,3 +404,38 @@ def test_generated_shape_models_share_one_batch(model, ctrl, standing, kernel_pa
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert ncon > 0 and worst < 1e-6, (ncon, worst)
     assert int(b.field(S.F_FAIL).sum().item()) == 0 and int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0
+
+
+def test_oracle_decides_its_own_solver(model, ctrl, standing, kernel_path):
+    """The other trajectory tests hand the device's UHC_F_REDO word to the oracle, which then takes the sweeps in exactly the substeps the
+    device swept -- a wrong fallback decision on the device would be invisible there.  Here nothing is handed over: the oracle runs its own
+    exact solve in every substep, free-running for 60 control steps, on a scene that stays within every tier's capacity (a few floor
+    contacts); the device must not have swept anywhere (bit 1 clear), whichever tier computed the step, and the two must agree."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    model = dataclasses.replace(model, solver=1)
+    n = 4
+    qpos, qvel = _states(standing, model, n, 14, noise=0.02, vel=0.05)
+    rng = np.random.default_rng(15)
+    b = _sim(model, ctrl, n)
+    b.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    os_ = [OracleSim(model, ctrl) for _ in range(n)]
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    worst, swept = 0.0, 0
+    for t in range(60):
+        act = rng.normal(scale=0.05, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq, gv = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        swept += int(((redo & 2) != 0).sum())
+        assert ((redo & 1) != 0).all() == (kernel_path == "general") or kernel_path == "fast"
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:])  # no redo= : the checker's own decision
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max(), np.abs(gv[e] - os_[e].get("qvel")).max())
+    assert swept == 0, swept
+    assert worst < 1e-8, worst

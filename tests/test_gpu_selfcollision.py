@@ -144,18 +144,20 @@ def test_self_collision_humanoid_matches_oracle(model, standing, kernel_path, li
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0
 
 
-def test_adaptive_kernel_path_switches_with_the_scene(model, standing):
-    """uhc_batch_set_kernel_path(2): seven self-colliding humanoids standing on the floor (> 64 rows each) and one in the air.  While the
-    fast kernel runs first, the airborne env is its own (UHC_F_REDO 0); after the decision window the library skips the fast kernel and
-    the airborne env too is computed by the general one (UHC_F_REDO 1); with everybody in the air it goes back.  The states follow the
-    oracle through both switches.  (Every step restarts from the same states, so the scene stays what it is.)"""
+def test_sticky_tiers_follow_the_scene(model, standing):
+    """uhc_batch_set_kernel_path(2): seven self-colliding humanoids standing on the floor (> 64 rows each) and one in the air.  In the
+    first step every env starts in the fast tier, which hands the standing ones on (UHC_F_TIER becomes 2); from the second step on they
+    start in the general tier, on the side stream beside the fast tier's launch, while the airborne env stays with the fast tier
+    (UHC_F_REDO 0).  With everybody lifted into the air the general tier computes its envs once more and lets them go (room to spare):
+    the next step is all fast tier.  The states follow the oracle through it all, and equal a run on the plain tier chain up to the
+    rounding of the two exact solvers.  (Every step restarts from the same states, so the scene stays what it is.)"""
     import torch
     from oracle.physics import OracleSim
     from uhc_amd import sim as S
     from uhc_amd.model.mjcf import self_collision_variant
     from uhc_amd.sim import make_ctrl
     if os.environ.get("UHC_FORCE_GENERAL") == "1":
-        pytest.skip("the batch has no fast kernel to switch from")
+        pytest.skip("the batch has no fast tier to start from")
     sc = dataclasses.replace(self_collision_variant(model), solver=1)
     ctrl = make_ctrl(sc)
     n = 8
@@ -172,28 +174,36 @@ def test_adaptive_kernel_path_switches_with_the_scene(model, standing):
     a = torch.from_numpy(act).cuda()
 
     def steps(q, k):
-        worst, hist = 0.0, []
+        worst, hist, tiers = 0.0, [], []
         for _ in range(k):
             b.set_state(torch.from_numpy(q), torch.from_numpy(qvel))
             b.simulate(a, tb)
             b.sync()
             redo, gq = b.field(S.F_REDO).cpu().numpy().copy(), b.field(S.F_QPOS).cpu().numpy()
             hist.append(redo)
+            tiers.append(b.field(S.F_TIER).cpu().numpy().copy())
             for e in range(n):
                 os_[e].set_state(q[e], qvel[e])
                 os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])
                 worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
-        return worst, np.array(hist)
+        return worst, np.array(hist), np.array(tiers), gq
 
-    w1, h1 = steps(qpos, 20)
-    assert (h1[0, :7] != 0).sum() >= 6 and h1[0, 7] == 0  # the standing envs are beyond the fast kernel, the airborne one is not
-    assert h1[-1, 7] != 0 and (h1[-1] != 0).all()  # ... and now the general kernel computes all of them
-    first = int(np.argmax(h1[:, 7] != 0))
-    assert 12 <= first <= 17, first  # decided at step 16 from the window that ended at step 11 (fixed lag: reproducible)
+    assert (b.field(S.F_TIER).cpu().numpy() == 1).all()
+    w1, h1, t1, q_sticky = steps(qpos, 4)
+    heavy = h1[0, :7] != 0
+    assert heavy.sum() >= 6 and (h1[:, 7] == 0).all()  # the standing envs are beyond the fast tier, the airborne one never is
+    assert (t1[:, :7][:, heavy] == 2).all() and (t1[:, 7] == 1).all()  # ... and they stay with the general tier
+    assert (h1[1:, :7][:, heavy] != 0).all()
+    chain = S.SimBatch(sc, ctrl, n)  # the same step on the plain chain: same physics
+    chain.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    chain.simulate(a, tb)
+    chain.sync()
+    np.testing.assert_allclose(chain.field(S.F_QPOS).cpu().numpy(), q_sticky, atol=1e-10)
     lifted = qpos.copy()
     lifted[:, 2] += 50.0
-    w2, h2 = steps(lifted, 20)
-    assert (h2[0] != 0).all() and (h2[-1] == 0).all()  # airborne: back on the fast kernel
+    w2, h2, t2, _ = steps(lifted, 3)
+    assert (h2[0, :7][heavy] != 0).all() and h2[0, 7] == 0  # airborne now, but this step still starts where the last one ended
+    assert (t2[0] == 1).all() and (h2[1:] == 0).all()       # ... came down with room to spare: fast tier from the next step on
     assert max(w1, w2) < 1e-9, (w1, w2)
 
 

@@ -12,7 +12,8 @@ PROF_LIB = os.path.join(CSRC, "libuhc_amd_prof.so")
 NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "smooth", "collision", "rows", "A-build",
          "pgs-sweeps", "z+rest/pgs-general", "qacc-solve", "euler", "store",
          "pd: M->LD + gains", "pd: factor", "pd: solve", "kin: pass 1 (local poses)", "kin: pass 2 (levels)", "crb: subtree sums", "crb: I*cdof",
-         "rne: levels", "pd: M -> LD", "as: W load (+loop tail)", "as: elimination", "as: back substitution", "as: y = A f + b", "as: pre-sweeps", "ws: islands + compaction + row load", "ws: y on the other rows"]
+         "rne: levels", "pd: M -> LD", "as: W load (+loop tail)", "as: elimination", "as: back substitution", "as: y = A f + b", "as: pre-sweeps", "ws: islands + compaction + row load", "ws: y on the other rows",
+         "col: plane-mesh pairs", "col: convex pairs sphere cull", "col: vertex staging", "col: MPR"]
 
 
 def build():

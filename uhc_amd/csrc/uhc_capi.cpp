@@ -40,6 +40,7 @@ static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, siz
     if ((e = uhc_launch_m1_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m1_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
     return uhc_launch_m2_fast_lds(lds_bytes_fast);
 }
+extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, hipStream_t stream);
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream);
 
@@ -137,14 +138,15 @@ struct UhcBatch {
     size_t lds_bytes = 0, lds_bytes_fast = 0, lds_bytes_big = 0;
     bool use_fast = true;
     bool general_only = false;
-    // uhc_batch_set_kernel_path(2): the library picks the path from the kernels' own counts (DevState::path_stats), read with a fixed
-    // lag of 4 control steps every 8 steps -- the same sequence of calls always switches at the same step
+    // uhc_batch_set_kernel_path(2): sticky tiers -- every env starts a step in the tier that computed its last one (DevState::tier)
     int path_mode = 0;
-    bool auto_general = false;
-    unsigned long long* h_stats = nullptr;  // pinned [8][3]
-    hipEvent_t st_ev[8] = {};
-    long long st_step = 0;
-    unsigned long long st_prev[3] = {0, 0, 0};
+    hipStream_t side_stream = nullptr, side_stream3 = nullptr;  // kernel path 2: the general / large tiers' own envs run beside the fast tier's
+    hipEvent_t ev_fork = nullptr, ev_side1 = nullptr, ev_side2 = nullptr;
+    int* tier_now = nullptr;
+    int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr;
+    int* h_counts = nullptr;  // pinned [8][4]: list sizes of the last steps, copied back asynchronously
+    hipEvent_t cnt_ev[8] = {};
+    long long cnt_step = 0;
     std::vector<void*> allocs;
     int nM = 0;
     int* reset_mask = nullptr;
@@ -152,8 +154,8 @@ struct UhcBatch {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
     int n_models = 1;
     // field table
-    void* field_ptr[17] = {nullptr};
-    int64_t field_count[17] = {0};
+    void* field_ptr[18] = {nullptr};
+    int64_t field_count[18] = {0};
 };
 
 template <class T>
@@ -593,7 +595,10 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
     TRY(dalloc(b, 4, &S.path_stats));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 2 * E, &S.redo)); S.redo2 = S.redo + E; TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 32, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 2 * E, &S.redo)); S.redo2 = S.redo + E;
+    TRY(dalloc(b, E, &S.tier)); TRY(dalloc(b, E, &b->tier_now)); S.tier_now = b->tier_now;
+    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors));
+    { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
@@ -610,11 +615,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         HIP_OK(hipMemcpy(S.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     void* fp[] = {S.qpos, S.qvel, S.xpos, S.xquat, S.xipos, S.qM, S.bias, S.qacc, S.ctrl, S.ncon, S.nefc, S.fail,
-                  S.solver_iter, S.applied, S.overflow, S.prof, S.redo};
+                  S.solver_iter, S.applied, S.overflow, S.prof, S.redo, S.tier};
     int64_t fc[] = {(int64_t)E * d.nq, (int64_t)E * nv, (int64_t)E * 3 * nb, (int64_t)E * 4 * nb, (int64_t)E * 3 * nb,
                     (int64_t)E * T.nM, (int64_t)E * nv, (int64_t)E * nv, (int64_t)E * d.nu, (int64_t)E, (int64_t)E, (int64_t)E,
-                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 32, (int64_t)E};
-    for (int k = 0; k < 17; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
+                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 40, (int64_t)E, (int64_t)E};
+    for (int k = 0; k < 18; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
     HIP_OK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     b->stream = b->own_stream;
     *out = b;
@@ -628,8 +633,11 @@ extern "C" void uhc_batch_free(UhcBatch* b) {
     for (void* p : b->allocs) hipFree(p);
     for (auto& ev : b->ev_used) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& ev : b->ev_free) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    for (hipEvent_t e : b->st_ev) if (e) hipEventDestroy(e);
-    if (b->h_stats) hipHostFree(b->h_stats);
+    for (hipEvent_t e : {b->ev_fork, b->ev_side1, b->ev_side2}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : b->cnt_ev) if (e) hipEventDestroy(e);
+    if (b->h_counts) hipHostFree(b->h_counts);
+    if (b->side_stream) hipStreamDestroy(b->side_stream);
+    if (b->side_stream3) hipStreamDestroy(b->side_stream3);
     if (b->own_stream) hipStreamDestroy(b->own_stream);
     delete b;
 }
@@ -653,29 +661,17 @@ extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode) {
     if (mode < 0 || mode > 2) return fail("uhc_batch_set_kernel_path: mode %d (0 fast then general, 1 general only, 2 adaptive)", mode);
     b->general_only = mode == 1;
     b->path_mode = mode;
-    b->auto_general = false;
-    if (mode == 2 && !b->h_stats) {
+    if (mode == 2 && !b->side_stream) {
         HIP_OK(hipSetDevice(b->device));
-        HIP_OK(hipHostMalloc((void**)&b->h_stats, sizeof(unsigned long long) * 8 * 3, hipHostMallocDefault));
-        for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&b->st_ev[k], hipEventDisableTiming));
+        HIP_OK(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&b->side_stream3, hipStreamNonBlocking));
+        HIP_OK(hipHostMalloc((void**)&b->h_counts, sizeof(int) * 8 * 4, hipHostMallocDefault));
+        memset(b->h_counts, 0, sizeof(int) * 8 * 4);
+        for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&b->cnt_ev[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&b->ev_side1, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&b->ev_side2, hipEventDisableTiming));
     }
-    b->st_step = 0;
-    return 0;
-}
-// adaptive path: snapshot the counters after this control step; every 8 steps decide from the snapshot taken 4 steps ago
-static int path_update(UhcBatch* b) {
-    const int slot = (int)(b->st_step % 8);
-    HIP_OK(hipMemcpyAsync(b->h_stats + 3 * slot, b->A.s.path_stats, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, b->stream));
-    HIP_OK(hipEventRecord(b->st_ev[slot], b->stream));
-    b->st_step++;
-    if (b->st_step % 8 != 0 || b->st_step < 8) return 0;
-    const int old = (int)((b->st_step - 5) % 8);  // the snapshot written after step st_step - 5 (0-based): long since landed
-    HIP_OK(hipEventSynchronize(b->st_ev[old]));
-    unsigned long long cur[3], d[3];
-    for (int k = 0; k < 3; k++) { cur[k] = b->h_stats[3 * old + k]; d[k] = cur[k] - b->st_prev[k]; b->st_prev[k] = cur[k]; }
-    const double env_steps = 8.0 * b->n_env;  // (the first window is 4 steps long: it only makes the thresholds harder to reach)
-    if (!b->auto_general) { if ((double)d[0] > 0.6 * env_steps) b->auto_general = true; }
-    else if (d[2] > 0 && (double)d[1] > 0.7 * (double)d[2]) b->auto_general = false;
     return 0;
 }
 extern "C" int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t iterations) {
@@ -685,7 +681,7 @@ extern "C" int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t ite
     return 0;
 }
 extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n) {
-    if (!b || f < 0 || f > 16 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
+    if (!b || f < 0 || f > 17 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
     if (p) *p = b->field_ptr[f];
     if (n) *n = b->field_count[f];
     return 0;
@@ -698,10 +694,55 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (b->ev_free.empty()) { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
         else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
     }
-    const bool general = b->general_only || (b->path_mode == 2 && b->auto_general);
+    const bool general = b->general_only;
     const bool big = b->A.last_tier == 3;
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
     HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * (big ? 2 : 1), b->stream));  // redo and redo2 are one allocation
+    if (mode == 0 && b->path_mode == 2 && b->use_fast && !general) {
+        // sticky tiers: an env starts in the tier that computed its last step.  The general / large tiers' own envs run on a side stream
+        // BESIDE the fast tier (their launches last several times longer per env; in a chain behind it the step would wait for them);
+        // only the envs a tier hands on this very step go through the chain.  All launches filter on one snapshot of the tier table.
+        KernelArgs K = b->A;
+        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->stream));
+        // how long the lists are is known on the host with a lag (asynchronous copies, never waited for): the newest copy that has landed
+        // sizes this step's list launches.  An env whose tier has no launch of its own this step (its list was empty when last seen) goes
+        // through the fast tier's chain like everybody else; a list longer than expected is worked off by fewer workgroups.
+        const int slot = (int)(b->cnt_step % 8);
+        HIP_OK(hipMemcpyAsync(b->h_counts + 4 * slot, b->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        HIP_OK(hipEventRecord(b->cnt_ev[slot], b->stream));
+        int est2 = 0, est3 = 0;
+        for (long long k = b->cnt_step - 1; k >= 0 && k > b->cnt_step - 8; k--)
+            if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) { est2 = b->h_counts[4 * (k % 8) + 2]; est3 = b->h_counts[4 * (k % 8) + 3]; break; }
+        b->cnt_step++;
+        if (!big) est3 = 0;
+        K.sticky_mask = (est2 > 0 ? 4 : 0) | (est3 > 0 ? 8 : 0);
+        HIP_OK(hipEventRecord(b->ev_fork, b->stream));
+        if (est3 > 0) {  // the slowest envs first, on their own stream
+            HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
+            K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
+            K.grid = std::min(est3 + est3 / 4 + 4, std::min(b->n_env, 256));
+            HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
+            HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
+        }
+        if (est2 > 0) {
+            HIP_OK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+            K.tier_want = 0; K.list = b->d_lists; K.list_count = b->d_counts + 2; K.list_cursor = b->d_cursors + 2;
+            K.grid = std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));
+            HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, nullptr, b->lds_bytes, b->side_stream));
+            HIP_OK(hipEventRecord(b->ev_side1, b->side_stream));
+        }
+        K.list = nullptr; K.list_count = nullptr; K.list_cursor = nullptr; K.grid = 0;
+        K.tier_want = 1;
+        if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
+        HIP_OK(uhc_launch_step(mode, 1, &K, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
+        if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
+        K.tier_want = 0; K.sticky_mask = 0;
+        HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
+        if (est2 > 0) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side1, 0));  // the list launch of the general tier may have handed envs on as well
+        if (big) HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, b->A.s.redo2, b->lds_bytes_big, b->stream));
+        if (est3 > 0) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side2, 0));
+        return 0;
+    }
     if (b->use_fast && !general) {
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
@@ -713,7 +754,8 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
     }
     if (big) HIP_OK(uhc_launch_step(mode, 3, &b->A, d_action, d_tbase, b->A.s.redo2, b->lds_bytes_big, b->stream));
-    if (mode == 0 && b->path_mode == 2 && b->use_fast) return path_update(b);
+    return 0;
+
     return 0;
 }
 
@@ -772,7 +814,7 @@ extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, c
     HIP_OK(uhc_launch_set_state_masked(&b->A.s, b->A.t.nq, b->A.t.nv, b->A.t.nu, b->n_env, d_select, d_qpos, d_qvel, b->reset_mask, b->stream));
     // only the kinematics now (the reset observation reads body poses); the dynamics part of sim.forward() runs at the head of the
     // env's next step kernel (DevState::fresh), which saves a forward-pass-long launch per control step
-    const bool kf = b->use_fast && !(b->general_only || (b->path_mode == 2 && b->auto_general));
+    const bool kf = b->use_fast && !b->general_only;
     HIP_OK(uhc_launch_step(2, kf ? 1 : 2, &b->A, nullptr, nullptr, b->reset_mask, kf ? b->lds_bytes_fast : b->lds_bytes, b->stream));
     return 0;
 }

@@ -95,6 +95,8 @@ struct DevState {  // HBM, env-major
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     int* redo2;  // envs the general tier handed on to the large tier this step
+    int* tier;   // per env: the tier that computed its last control step (minus hysteresis): where its next step starts (kernel path 2)
+    const int* tier_now;  // snapshot of `tier` taken at the head of the step: what the tier filter of a launch reads
     int* fresh;  // 1: the env was restarted on the device (set_state done, kinematics refreshed); its mj_forward runs at the head of its next step
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)
@@ -122,6 +124,12 @@ struct KernelArgs {
     DevLds lh;  // large tier: <= 160 KiB
     TierCap cf, cg, ch;
     int last_tier;  // 2 or 3: the tier that drops what exceeds it instead of handing the env on
+    int tier_want;  // 0: the launch works on every active env; else (sticky tiers) it leaves out the envs whose tier_now differs AND has its own launch
+    int sticky_mask;  // bit t: tier t has its own (list) launch this step
+    const int* list;  // != NULL: persistent launch over this compacted env list (list_count entries, shared cursor)
+    const int* list_count;
+    int* list_cursor;
+    int grid;  // workgroups of a list launch (0: one per env)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)

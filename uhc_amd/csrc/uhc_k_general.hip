@@ -2,7 +2,7 @@
 #include "uhc_physics_impl.h"
 
 extern "C" hipError_t uhc_launch_m0_gen(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((uhc_step_kernel<0, 2, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    hipLaunchKernelGGL((uhc_step_kernel<0, 2, true>), dim3(A->grid ? A->grid : A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
 }
 extern "C" hipError_t uhc_launch_m0_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }

@@ -2,12 +2,12 @@
 #include "uhc_physics_impl.h"
 
 extern "C" hipError_t uhc_launch_m1_gen(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((uhc_step_kernel<1, 2, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    hipLaunchKernelGGL((uhc_step_kernel<1, 2, true>), dim3(A->grid ? A->grid : A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
 }
 extern "C" hipError_t uhc_launch_m1_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }
 extern "C" hipError_t uhc_launch_m2_gen(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((uhc_step_kernel<2, 2, true>), dim3(A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
+    hipLaunchKernelGGL((uhc_step_kernel<2, 2, true>), dim3(A->grid ? A->grid : A->n_env), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase, d_active);
     return hipGetLastError();
 }
 extern "C" hipError_t uhc_launch_m2_gen_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }
@@ -56,5 +56,21 @@ extern "C" hipError_t uhc_launch_set_state_masked(const DevState* s, int nq, int
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream) {
     hipLaunchKernelGGL(uhc_set_state_kernel, dim3(n), dim3(UHC_WAVE), 0, stream, *s, nq, nv, nu, env_ids, n, qpos, qvel, mask);
+    return hipGetLastError();
+}
+
+// sticky tiers, head of a control step: snapshot of the tier table + the compacted lists of the active envs that start in the general /
+// large tier (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; the cursors the persistent launches share)
+__global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors) {
+    if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int env = threadIdx.x; env < n_env; env += blockDim.x) {
+        const int t = tier[env];
+        tier_now[env] = t;
+        if ((t == 2 || t == 3) && (!d_active || d_active[env])) lists[(t - 2) * n_env + atomicAdd(&counts[t], 1)] = env;
+    }
+}
+extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors);
     return hipGetLastError();
 }

@@ -36,9 +36,12 @@ __device__ __forceinline__ bool ccd_eq(double a, double b) {
     return b > a ? ab < UHC_CCD_EPS * b : ab < UHC_CCD_EPS * a;
 }
 
-struct CcdSup { V3 v, v1, v2; };  // point of the Minkowski difference + its witnesses on hull 1 / hull 2
+// A point of the Minkowski difference, v = v1 - v2, and the SUM s = v1 + v2 of its witnesses on hull 1 / hull 2: the contact position is
+// the only consumer of the witnesses and it reads them as (v1 + v2) / 2 (findPos; the margin push along +-dir cancels in the sum), so the
+// portal carries 6 doubles per point instead of libccd's 9 -- 15 doubles less live state through the refinement loops of every lane.
+struct CcdSup { V3 v, s; };
 __device__ __forceinline__ CcdSup sup_sel(bool c, const CcdSup& a, const CcdSup& b) {
-    CcdSup r = {vsel(c, a.v, b.v), vsel(c, a.v1, b.v1), vsel(c, a.v2, b.v2)};
+    CcdSup r = {vsel(c, a.v, b.v), vsel(c, a.s, b.s)};
     return r;
 }
 
@@ -74,9 +77,9 @@ __device__ __forceinline__ V3 hull_support(const double* __restrict__ VB, const 
 }
 __device__ __forceinline__ CcdSup ccd_support(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& dir, double margin) {
     CcdSup s;
-    s.v1 = hull_support(VB, H1, dir, margin);
-    s.v2 = hull_support(VB, H2, neg(dir), margin);
-    s.v = s.v1 - s.v2;
+    const V3 v1 = hull_support(VB, H1, dir, margin), v2 = hull_support(VB, H2, neg(dir), margin);
+    s.v = v1 - v2;
+    s.s = v1 + v2;
     return s;
 }
 __device__ __forceinline__ V3 portal_dir(const CcdSup& p1, const CcdSup& p2, const CcdSup& p3) {
@@ -134,12 +137,12 @@ __device__ __forceinline__ V3 find_pos(const CcdSup& p0, const CcdSup& p1, const
         sum = b1 + b2 + b3;
     }
     const double inv = 1.0 / sum;
-    V3 a = v3(0, 0, 0), c = v3(0, 0, 0);
-    a = a + p0.v1 * b0; c = c + p0.v2 * b0;
-    a = a + p1.v1 * b1; c = c + p1.v2 * b1;
-    a = a + p2.v1 * b2; c = c + p2.v2 * b2;
-    a = a + p3.v1 * b3; c = c + p3.v2 * b3;
-    return v3((a.x * inv + c.x * inv) * 0.5, (a.y * inv + c.y * inv) * 0.5, (a.z * inv + c.z * inv) * 0.5);
+    V3 a = v3(0, 0, 0);  // sum_k b_k (v1_k + v2_k): libccd accumulates the two witnesses apart and adds at the end (rounding aside, the same)
+    a = a + p0.s * b0;
+    a = a + p1.s * b1;
+    a = a + p2.s * b2;
+    a = a + p3.s * b3;
+    return v3(a.x * inv * 0.5, a.y * inv * 0.5, a.z * inv * 0.5);
 }
 
 // true: the hulls (each inflated by margin / 2) penetrate; depth, dir (from hull 1 to hull 2, zero if undefined) and pos are set.
@@ -149,7 +152,7 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
     CcdSup p0, p1, p2, p3, v4;
     double dt;
     // ---- discoverPortal
-    p0.v1 = c1; p0.v2 = c2; p0.v = c1 - c2;
+    p0.s = c1 + c2; p0.v = c1 - c2;
     if (ccd_eq(p0.v.x, 0) && ccd_eq(p0.v.y, 0) && ccd_eq(p0.v.z, 0)) p0.v.x += UHC_CCD_EPS * 10;
     dir = vnorm(neg(p0.v));
     p1 = ccd_support(VB, H1, H2, dir, margin);
@@ -159,7 +162,7 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
     if (ccd_zero(vdot(dir, dir))) {
         if (ccd_eq(p1.v.x, 0) && ccd_eq(p1.v.y, 0) && ccd_eq(p1.v.z, 0)) { depth = 0; dir = v3(0, 0, 0); }   // origin on v1: touching
         else { depth = sqrt(vdot(p1.v, p1.v)); dir = vnorm(p1.v); }                                             // origin on the segment v0-v1
-        pos = v3(0.5 * (p1.v1.x + p1.v2.x), 0.5 * (p1.v1.y + p1.v2.y), 0.5 * (p1.v1.z + p1.v2.z));
+        pos = v3(0.5 * p1.s.x, 0.5 * p1.s.y, 0.5 * p1.s.z);
         return true;
     }
     dir = vnorm(dir);
@@ -205,5 +208,188 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
             return true;
         }
         expand_portal(p0, p1, p2, p3, v4);
+    }
+}
+
+// ------------------------------------------------------------------ the same refinement, supports computed by the whole wave
+// Lane = candidate pair for the PORTAL LOGIC (short, branchy, serial: lanes diverge freely), but the support function -- the only wide
+// operation and, with one pair per lane walking its own two hulls, ~85 % of the pass: 64 lanes reading 24-byte vertices at unrelated LDS
+// addresses meet ~7-way bank conflicts, ~115 cycles per vertex and lane -- is taken out of the lanes: the refinement runs in ROUNDS.
+// In a round every live pair asks for one support point (a direction); the wave then serves the requests one pair at a time with
+// lane = hull vertex (one coalesced, conflict-free read of <= 64 vertices per hull, dot product, DPP arg-max, lowest lane among equal
+// maxima = the scan's "first maximum wins"), hands the point to the pair's lane, and all lanes advance their own state machine to the
+// next request.  Same arithmetic as mpr_penetration, same portal, same result bits; the cost of a round is ~300 cycles per live pair
+// instead of ~11 000 for the slowest lane's two hull walks.
+enum { MPR_DONE = 0, MPR_D1, MPR_D2, MPR_D3, MPR_REFINE, MPR_PEN };
+struct MprLane {     // one candidate pair (valid in lanes whose `st` is not MPR_DONE at entry)
+    int b1, b2;      // bodies of the two hulls (poses are read from LDS: xmat, xpos)
+    int voff1, vn1, voff2, vn2;  // vertex ranges (doubles offset into VB, count)
+    V3 c1, c2;       // hull centres in the world
+    double margin;
+    // results
+    bool hit;
+    double depth;
+    V3 dir, pos;
+};
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64<DPP_QUAD_1032>(v));
+    v = fmax(v, dpp_f64<DPP_QUAD_2301>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    return fmax(fmax(bcast(v, 0), bcast(v, 16)), fmax(bcast(v, 32), bcast(v, 48)));
+}
+// support point of one hull for the pair owned by lane p (all arguments wave-uniform): the hull vertex with the largest projection on
+// dir (first maximum), in the world, pushed out by margin / 2 along dir -- bit for bit hull_support's value
+__device__ __forceinline__ V3 hull_support_wave(const double* __restrict__ VB, const double* __restrict__ R, const double* __restrict__ P, int voff, int vn, const V3& dir,
+                                                double margin) {
+    const double lx = R[0] * dir.x + R[3] * dir.y + R[6] * dir.z;  // R^T dir
+    const double ly = R[1] * dir.x + R[4] * dir.y + R[7] * dir.z;
+    const double lz = R[2] * dir.x + R[5] * dir.y + R[8] * dir.z;
+    double bd = -1e300, bx = 0, by = 0, bz = 0;
+    for (int v0 = 0; v0 < vn; v0 += UHC_WAVE) {  // (hulls of the generated models have <= 50 vertices: one trip)
+        const int v = v0 + LANE;
+        const bool in = v < vn;
+        const double* c = VB + voff + 3 * (in ? v : 0);
+        const double cx = c[0], cy = c[1], cz = c[2];
+        const double s = in ? lx * cx + ly * cy + lz * cz : -1e300;
+        const double mx = wave_max_f64(s);
+        if (mx > bd) {  // strict: an equal maximum in a later chunk does not replace the first
+            const int k = __ffsll((long long)__builtin_amdgcn_ballot_w64(s == mx)) - 1;
+            bd = mx; bx = bcast(cx, k); by = bcast(cy, k); bz = bcast(cz, k);
+        }
+    }
+    const double hm = 0.5 * margin;
+    return v3((R[0] * bx + R[1] * by + R[2] * bz) + (P[0] + dir.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (P[1] + dir.y * hm),
+              (R[6] * bx + R[7] * by + R[8] * bz) + (P[2] + dir.z * hm));
+}
+// Both hulls of a pair at once when each fits one trip (<= 64 vertices: every generated model): straight-line code, the two loads, dot
+// products and DPP reductions interleave instead of running one after the other through a loop branch.
+__device__ __forceinline__ void pair_support_wave(const double* __restrict__ VB, const double* __restrict__ R1, const double* __restrict__ P1, int voff1, int vn1,
+                                                  const double* __restrict__ R2, const double* __restrict__ P2, int voff2, int vn2, const V3& d, double margin, V3& a, V3& b) {
+    if (vn1 > UHC_WAVE || vn2 > UHC_WAVE) {
+        a = hull_support_wave(VB, R1, P1, voff1, vn1, d, margin);
+        b = hull_support_wave(VB, R2, P2, voff2, vn2, neg(d), margin);
+        return;
+    }
+    const bool in1 = LANE < vn1, in2 = LANE < vn2;
+    const double* c1 = VB + voff1 + 3 * (in1 ? LANE : 0);
+    const double* c2 = VB + voff2 + 3 * (in2 ? LANE : 0);
+    const double x1 = c1[0], y1 = c1[1], z1 = c1[2], x2 = c2[0], y2 = c2[1], z2 = c2[2];
+    const V3 e = neg(d);
+    const double l1x = R1[0] * d.x + R1[3] * d.y + R1[6] * d.z, l1y = R1[1] * d.x + R1[4] * d.y + R1[7] * d.z, l1z = R1[2] * d.x + R1[5] * d.y + R1[8] * d.z;
+    const double l2x = R2[0] * e.x + R2[3] * e.y + R2[6] * e.z, l2y = R2[1] * e.x + R2[4] * e.y + R2[7] * e.z, l2z = R2[2] * e.x + R2[5] * e.y + R2[8] * e.z;
+    const double s1 = in1 ? l1x * x1 + l1y * y1 + l1z * z1 : -1e300;
+    const double s2 = in2 ? l2x * x2 + l2y * y2 + l2z * z2 : -1e300;
+    double m1 = s1, m2 = s2;  // two independent reduction chains, issued alternately
+    m1 = fmax(m1, dpp_f64<DPP_QUAD_1032>(m1)); m2 = fmax(m2, dpp_f64<DPP_QUAD_1032>(m2));
+    m1 = fmax(m1, dpp_f64<DPP_QUAD_2301>(m1)); m2 = fmax(m2, dpp_f64<DPP_QUAD_2301>(m2));
+    m1 = fmax(m1, dpp_f64<DPP_ROW_HALF_MIRROR>(m1)); m2 = fmax(m2, dpp_f64<DPP_ROW_HALF_MIRROR>(m2));
+    m1 = fmax(m1, dpp_f64<DPP_ROW_MIRROR>(m1)); m2 = fmax(m2, dpp_f64<DPP_ROW_MIRROR>(m2));
+    m1 = fmax(fmax(bcast(m1, 0), bcast(m1, 16)), fmax(bcast(m1, 32), bcast(m1, 48)));
+    m2 = fmax(fmax(bcast(m2, 0), bcast(m2, 16)), fmax(bcast(m2, 32), bcast(m2, 48)));
+    const int k1 = __ffsll((long long)__builtin_amdgcn_ballot_w64(s1 == m1)) - 1, k2 = __ffsll((long long)__builtin_amdgcn_ballot_w64(s2 == m2)) - 1;
+    const double b1x = bcast(x1, k1), b1y = bcast(y1, k1), b1z = bcast(z1, k1), b2x = bcast(x2, k2), b2y = bcast(y2, k2), b2z = bcast(z2, k2);
+    const double hm = 0.5 * margin;
+    a = v3((R1[0] * b1x + R1[1] * b1y + R1[2] * b1z) + (P1[0] + d.x * hm), (R1[3] * b1x + R1[4] * b1y + R1[5] * b1z) + (P1[1] + d.y * hm),
+           (R1[6] * b1x + R1[7] * b1y + R1[8] * b1z) + (P1[2] + d.z * hm));
+    b = v3((R2[0] * b2x + R2[1] * b2y + R2[2] * b2z) + (P2[0] + e.x * hm), (R2[3] * b2x + R2[4] * b2y + R2[5] * b2z) + (P2[1] + e.y * hm),
+           (R2[6] * b2x + R2[7] * b2y + R2[8] * b2z) + (P2[2] + e.z * hm));
+}
+// xmat / xpos: the bodies' poses in LDS ([nbody][9], [nbody][3])
+__device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const double* __restrict__ xmat, const double* __restrict__ xpos, bool active, MprLane& M) {
+    CcdSup p0, p1, p2, p3, v4;
+    V3 dir = v3(0, 0, 0);
+    double dt;
+    int st = MPR_DONE, it = 0;
+    M.hit = false; M.depth = 0; M.dir = v3(0, 0, 0); M.pos = v3(0, 0, 0);
+    p0.v = p0.s = p1.v = p1.s = p2.v = p2.s = p3.v = p3.s = v4.v = v4.s = v3(0, 0, 0);
+    if (active) {
+        p0.s = M.c1 + M.c2; p0.v = M.c1 - M.c2;
+        if (ccd_eq(p0.v.x, 0) && ccd_eq(p0.v.y, 0) && ccd_eq(p0.v.z, 0)) p0.v.x += UHC_CCD_EPS * 10;
+        dir = vnorm(neg(p0.v));
+        st = MPR_D1;
+    }
+    for (;;) {
+        unsigned long long live = __builtin_amdgcn_ballot_w64(st != MPR_DONE);
+        if (!live) break;
+        // ---- serve this round's support requests, one pair at a time, lane = hull vertex
+        while (live) {
+            const int p = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            const V3 d = v3(bcast(dir.x, p), bcast(dir.y, p), bcast(dir.z, p));
+            const int b1 = __builtin_amdgcn_readlane(M.b1, p), b2 = __builtin_amdgcn_readlane(M.b2, p);
+            const double mg = bcast(M.margin, p);
+            V3 a, b;
+            pair_support_wave(VB, xmat + 9 * b1, xpos + 3 * b1, __builtin_amdgcn_readlane(M.voff1, p), __builtin_amdgcn_readlane(M.vn1, p), xmat + 9 * b2, xpos + 3 * b2,
+                              __builtin_amdgcn_readlane(M.voff2, p), __builtin_amdgcn_readlane(M.vn2, p), d, mg, a, b);
+            const bool mine = LANE == p;
+            v4.v = vsel(mine, a - b, v4.v);
+            v4.s = vsel(mine, a + b, v4.s);
+        }
+        // ---- every live pair advances to its next request (or finishes)
+        bool to_refine = false, to_pen = false;
+        if (st == MPR_D1) {
+            p1 = v4;
+            dt = vdot(p1.v, dir);
+            if (ccd_zero(dt) || dt < 0) st = MPR_DONE;
+            else {
+                dir = vcross(p0.v, p1.v);
+                if (ccd_zero(vdot(dir, dir))) {
+                    if (ccd_eq(p1.v.x, 0) && ccd_eq(p1.v.y, 0) && ccd_eq(p1.v.z, 0)) { M.depth = 0; M.dir = v3(0, 0, 0); }  // origin on v1: touching
+                    else { M.depth = sqrt(vdot(p1.v, p1.v)); M.dir = vnorm(p1.v); }                                          // origin on the segment v0-v1
+                    M.pos = v3(0.5 * p1.s.x, 0.5 * p1.s.y, 0.5 * p1.s.z);
+                    M.hit = true;
+                    st = MPR_DONE;
+                } else { dir = vnorm(dir); st = MPR_D2; }
+            }
+        } else if (st == MPR_D2) {
+            p2 = v4;
+            dt = vdot(p2.v, dir);
+            if (ccd_zero(dt) || dt < 0) st = MPR_DONE;
+            else {
+                dir = vnorm(vcross(p1.v - p0.v, p2.v - p0.v));
+                if (vdot(dir, p0.v) > 0) { const CcdSup t = p1; p1 = p2; p2 = t; dir = neg(dir); }
+                st = MPR_D3;
+            }
+        } else if (st == MPR_D3) {
+            dt = vdot(v4.v, dir);
+            if (ccd_zero(dt) || dt < 0) st = MPR_DONE;
+            else {
+                bool cont = false;
+                dt = vdot(vcross(p1.v, v4.v), p0.v);
+                if (dt < 0 && !ccd_zero(dt)) { p2 = v4; cont = true; }
+                if (!cont) {
+                    dt = vdot(vcross(v4.v, p2.v), p0.v);
+                    if (dt < 0 && !ccd_zero(dt)) { p1 = v4; cont = true; }
+                }
+                if (cont) dir = vnorm(vcross(p1.v - p0.v, p2.v - p0.v));
+                else { p3 = v4; to_refine = true; }
+            }
+        } else if (st == MPR_REFINE) {
+            dt = vdot(v4.v, dir);
+            if (!(ccd_zero(dt) || dt > 0) || portal_reach_tolerance(p1, p2, p3, v4, dir)) st = MPR_DONE;
+            else { expand_portal(p0, p1, p2, p3, v4); to_refine = true; }
+        } else if (st == MPR_PEN) {
+            if (portal_reach_tolerance(p1, p2, p3, v4, dir) || it > UHC_MPR_MAXIT) {
+                V3 pd;
+                M.depth = sqrt(point_tri_dist2(p1.v, p2.v, p3.v, pd));
+                if (ccd_zero(pd.x) && ccd_zero(pd.y) && ccd_zero(pd.z)) pd = dir;
+                M.dir = vnorm(pd);
+                M.pos = find_pos(p0, p1, p2, p3);
+                M.hit = true;
+                st = MPR_DONE;
+            } else {
+                expand_portal(p0, p1, p2, p3, v4);
+                it++;
+                dir = portal_dir(p1, p2, p3);
+            }
+        }
+        if (to_refine) {  // head of refinePortal: does the portal already enclose the origin?
+            dir = portal_dir(p1, p2, p3);
+            dt = vdot(dir, p1.v);
+            if (ccd_zero(dt) || dt > 0) to_pen = true;
+            else st = MPR_REFINE;
+        }
+        if (to_pen) { dir = portal_dir(p1, p2, p3); it = 0; st = MPR_PEN; }  // head of findPenetr
     }
 }

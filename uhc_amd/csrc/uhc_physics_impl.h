@@ -13,14 +13,13 @@
 #include <type_traits>
 #include "../../include/uhc_amd.h"
 #include "uhc_device.h"
-#include "uhc_mpr.h"
 
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
 #define LANE ((int)threadIdx.x)
 // optional per-stage cycle accounting (build with -DUHC_STAGE_PROF; see tools/stage_profile.py)
 #ifdef UHC_STAGE_PROF
-#define UHC_NPROF 32
+#define UHC_NPROF 40
 #define PROF_DECL long long pt_[UHC_NPROF] = {}; long long pt_last_ = __builtin_readcyclecounter();
 #define PROF_ARGS , long long* pt_, long long& pt_last_
 #define PROF_PASS , pt_, pt_last_
@@ -78,6 +77,7 @@ __device__ __forceinline__ double wave_min(double v) {
     return fmin(fmin(bcast(v, 0), bcast(v, 16)), fmin(bcast(v, 32), bcast(v, 48)));
 }
 __device__ __forceinline__ int wave_or(int v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }  // used as "any lane set"
+#include "uhc_mpr.h"  // (uses the lane helpers above)
 
 // ------------------------------------------------------------------ small math (registers)
 __device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
@@ -768,7 +768,7 @@ __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const doubl
 }
 // returns ncon (wave-uniform)
 template <int TIER, bool DENSE>
-__device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow, const PairConst& PC) {
+__device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow, const PairConst& PC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     int ncon = 0;
@@ -864,6 +864,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
     }
     // ---- convex-convex pairs (hull vs hull): one candidate pair per lane through bounding-sphere cull and MPR (uhc_mpr.h); the hits
     //      become contacts in pair order.  Contact = (pos, normal from geom 1 to geom 2, dist = margin - depth) [MJ-ext mjc_Convex].
+    PROF(32)
     if constexpr (DENSE) {
         // phase 1: bounding-sphere cull of every pair, survivors compacted (in pair order) into a list -- phase 2 then needs one
         // MPR pass for the 10-40 candidates of a typical pose instead of one per block of 64 pairs
@@ -890,49 +891,52 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             ncand += (int)__popcll(cm);
         }
         if (ncand > CAND_CAP) { *overflow |= hands_on<TIER>(A) ? 1 : 2; ncand = CAND_CAP; }
+        PROF(33)
         // the hull vertices (body frame, model constants) into the LDS region the constraint rows will use after this pass
         const int vstage = cap_of<TIER>(A).vstage;
         if (vstage >= 0 && ncand > 0)
             for (int i = LANE; i < 3 * T.nmeshvert; i += UHC_WAVE) S[vstage + i] = mb[A.o.mesh_vert + i];
         wsync();
-        // phase 2: MPR, one candidate pair per lane
+        PROF(34)
+        // phase 2: MPR -- lane = candidate pair for the portal logic, the whole wave for every support query (uhc_mpr.h: mpr_wave)
         for (int c0 = 0; c0 < ncand; c0 += UHC_WAVE) {
             const int ci = c0 + LANE;
-            bool hit = false;
-            int g1 = 0, g2 = 0, b1 = 0, b2 = 0;
-            double depth = 0, margin = 0, gap = 0;
-            V3 dir = v3(0, 0, 0), pos = v3(0, 0, 0);
-            if (ci < ncand) {
+            const bool act = ci < ncand;
+            int g1 = 0, g2 = 0;
+            double gap = 0;
+            MprLane M;
+            M.b1 = M.b2 = M.voff1 = M.vn1 = M.voff2 = M.vn2 = 0;
+            M.margin = 0; M.c1 = M.c2 = v3(0, 0, 0);
+            if (act) {
                 const int p = cand[ci];
                 g1 = T.cpair_g1[p]; g2 = T.cpair_g2[p];
-                b1 = T.geom_bodyid[g1]; b2 = T.geom_bodyid[g2];
-                CcdHull H1, H2;
-                for (int k = 0; k < 9; k++) { H1.R[k] = S[L.xmat + 9 * b1 + k]; H2.R[k] = S[L.xmat + 9 * b2 + k]; }
-                H1.p = v3(S[L.xpos + 3 * b1], S[L.xpos + 3 * b1 + 1], S[L.xpos + 3 * b1 + 2]);
-                H2.p = v3(S[L.xpos + 3 * b2], S[L.xpos + 3 * b2 + 1], S[L.xpos + 3 * b2 + 2]);
-                H1.voff = 3 * T.geom_vertadr[g1]; H1.vn = T.geom_vertnum[g1];
-                H2.voff = 3 * T.geom_vertadr[g2]; H2.vn = T.geom_vertnum[g2];
-                double ce1[3], ce2[3], t1[3], t2[3];
+                M.b1 = T.geom_bodyid[g1]; M.b2 = T.geom_bodyid[g2];
+                M.voff1 = 3 * T.geom_vertadr[g1]; M.vn1 = T.geom_vertnum[g1];
+                M.voff2 = 3 * T.geom_vertadr[g2]; M.vn2 = T.geom_vertnum[g2];
+                double ce1[3], ce2[3], t1[3], t2[3], R1[9], R2[9];
+                for (int k = 0; k < 9; k++) { R1[k] = S[L.xmat + 9 * M.b1 + k]; R2[k] = S[L.xmat + 9 * M.b2 + k]; }
                 for (int k = 0; k < 3; k++) { ce1[k] = mb[A.o.geom_center + 3 * g1 + k]; ce2[k] = mb[A.o.geom_center + 3 * g2 + k]; }
-                mat_vec(t1, H1.R, ce1); mat_vec(t2, H2.R, ce2);
-                const V3 c1 = v3(t1[0] + H1.p.x, t1[1] + H1.p.y, t1[2] + H1.p.z), c2 = v3(t2[0] + H2.p.x, t2[1] + H2.p.y, t2[2] + H2.p.z);
-                margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                mat_vec(t1, R1, ce1); mat_vec(t2, R2, ce2);
+                M.c1 = v3(t1[0] + S[L.xpos + 3 * M.b1], t1[1] + S[L.xpos + 3 * M.b1 + 1], t1[2] + S[L.xpos + 3 * M.b1 + 2]);
+                M.c2 = v3(t2[0] + S[L.xpos + 3 * M.b2], t2[1] + S[L.xpos + 3 * M.b2 + 1], t2[2] + S[L.xpos + 3 * M.b2 + 2]);
+                M.margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
                 gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
-                // two copies of the refinement so that each knows its address space at compile time (ds_read vs global_load)
-                if (vstage >= 0) hit = mpr_penetration(S + vstage, H1, H2, c1, c2, margin, depth, dir, pos);
-                else hit = mpr_penetration(mb + A.o.mesh_vert, H1, H2, c1, c2, margin, depth, dir, pos);
-                hit = hit && !(dir.x == 0 && dir.y == 0 && dir.z == 0);
             }
+            // two copies of the refinement so that each knows its address space at compile time (ds_read vs global_load)
+            if (vstage >= 0) mpr_wave(S + vstage, S + L.xmat, S + L.xpos, act, M);
+            else mpr_wave(mb + A.o.mesh_vert, S + L.xmat, S + L.xpos, act, M);
+            const bool hit = act && M.hit && !(M.dir.x == 0 && M.dir.y == 0 && M.dir.z == 0);
             const unsigned long long hm = __ballot(hit);
             const int rank = __popcll(hm & ((1ull << LANE) - 1ull));
             if (hit && ncon + rank < cap_of<TIER>(A).maxcon) {
-                const double cp[3] = {pos.x, pos.y, pos.z}, nn[3] = {dir.x, dir.y, dir.z};
-                k_write_contact<TIER>(A, mb, S, ncon + rank, g1, g2, b1, b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - depth, margin, gap);
+                const double cp[3] = {M.pos.x, M.pos.y, M.pos.z}, nn[3] = {M.dir.x, M.dir.y, M.dir.z};
+                k_write_contact<TIER>(A, mb, S, ncon + rank, g1, g2, M.b1, M.b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, M.margin - M.depth, M.margin, gap);
             }
             const int want = ncon + (int)__popcll(hm);
             if (want > cap_of<TIER>(A).maxcon) *overflow |= hands_on<TIER>(A) ? 1 : 2;
             ncon = min(cap_of<TIER>(A).maxcon, want);
         }
+        PROF(35)
     }
     wsync();
     return ncon;
@@ -2090,7 +2094,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(6)
     k_smooth<TIER>(A, mb, S, LC);
     PROF(7)
-    out.ncon = k_collision<TIER, DENSE>(A, mb, S, &out.overflow, PC);
+    out.ncon = k_collision<TIER, DENSE>(A, mb, S, &out.overflow, PC PROF_PASS);
     PROF(8)
     out.nefc = k_enumerate_rows<TIER, DENSE>(A, mb, S, out.ncon, &out.overflow);
     DofVec x = {0.0, 0.0};
@@ -2324,11 +2328,7 @@ __device__ __forceinline__ void k_rfc_explicit(const KernelArgs& A, double* S, c
 // DENSE: the model has contacts between two moving bodies (convex-convex pairs): MPR narrow phase + dense rows are compiled in.  The
 // floor-only stock model runs the DENSE = false instantiation, whose code and register allocation are those of the kernel without them.
 template <int MODE, int TIER, bool DENSE>
-__global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
-                                                            const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
-    const int env = blockIdx.x;
-    if (env >= A.n_env) return;
-    if (d_active && !d_active[env]) return;
+__device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* __restrict__ d_action, const double* __restrict__ d_tbase, const int env) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     double* S = smem;
@@ -2381,7 +2381,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     wsync();
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
-    bool ran = false, fits = true;  // fits (general kernel): every substep of this step was within the fast kernel's capacity
+    bool ran = false, fits = true;  // fits (general / large tier): every substep of this step was within the fast kernel's capacity
+    bool fits_hyst = true, fits_gen = true;  // ... within it with room to spare (tier hysteresis); (large tier) within the general tier's
     PROF_DECL
     if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
         k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
@@ -2425,6 +2426,12 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
             if (TIER != 1 && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
             if (TIER != 1) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= UHC_FAST_MAXCON &&
                               (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= UHC_FAST_MAXTWO);
+            if (TIER != 1) {
+                const int ntwo = (DENSE && cap_of<TIER>(A).ndense > 0) ? ((const int*)(S + L.ncon_nefc))[2] : 0;
+                fits_hyst = fits_hyst && fo.nefc <= UHC_WAVE - 8 && fo.ncon <= UHC_FAST_MAXCON - 2 && ntwo <= UHC_FAST_MAXTWO - 2;
+                if (TIER == 3) fits_gen = fits_gen && fo.nefc <= A.cg.maxefc - 16 && fo.ncon <= A.cg.maxcon - 8 && ntwo <= A.cg.ndense - 2 &&
+                                          ((const int*)(S + L.rowY))[fo.nefc] + 64 <= A.cg.ycap;
+            }
             ran = true;
             if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
                 wsync();
@@ -2487,6 +2494,8 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         A.s.fail[env] = fail;
         if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
+        // where the env's next step starts (uhc_batch_set_kernel_path 2): an env comes down a tier only with room to spare
+        if (MODE == 0 && ran) A.s.tier[env] = TIER == 1 ? 1 : (TIER == 2 ? (fits_hyst ? 1 : 2) : (!fits_gen ? 3 : (fits_hyst ? 1 : 2)));
         if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | swept;
         if (TIER != 1 && MODE == 0) {
             atomicAdd(A.s.path_stats + 2, 1ull);
@@ -2495,3 +2504,30 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     }
 }
 
+// The launch forms.  (1) one workgroup per env of the batch (blockIdx = env), filtered by the active mask and -- under sticky tiers -- by
+// the tier the env starts its step in: the fast tier's launch skips the envs that have a launch of their own this step.  (2) a PERSISTENT
+// launch over a compacted env list (sticky general / large tiers): the grid is as large as the host expects the list to be, every
+// workgroup takes envs off the list until it is empty, so an underestimate costs time, never an env -- and no workgroup is started (and
+// has to be given its 79 / 160 KiB of LDS) only to find that its env belongs to another tier.
+template <int MODE, int TIER, bool DENSE>
+__global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
+                                                            const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
+    if (A.list) {
+        for (;;) {
+            int i = 0;
+            if (LANE == 0) i = atomicAdd(A.list_cursor, 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i >= *A.list_count) return;
+            uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, A.list[i]);
+            wsync();
+        }
+    }
+    const int env = blockIdx.x;
+    if (env >= A.n_env) return;
+    if (d_active && !d_active[env]) return;
+    if (A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
+        const int t = A.s.tier_now[env];
+        if (t != A.tier_want && ((A.sticky_mask >> t) & 1)) return;
+    }
+    uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+}

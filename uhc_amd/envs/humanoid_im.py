@@ -56,7 +56,8 @@ class VecHumanoidEnv:
                                 pd_mul=cfg.get("pd_mul", 1), tq_mul=cfg.get("tq_mul", 1), base_rot=self.base_rot,
                                 residual_force_bodies=cfg.residual_force_bodies, residual_force_torque=cfg.residual_force_torque)
         self.sim = S.SimBatch(self.models, self.ctrl, self.n_env, device=device)
-        self.sim.set_kernel_path(2)  # adaptive: when most envs exceed the fast kernel's capacity (bodies on the ground, objects) it is skipped
+        import os
+        self.sim.set_kernel_path(int(os.environ.get("UHC_KERNEL_PATH", "2")))  # 2 = sticky tiers: every env starts a step in the tier that computed its last one
         self.device = self.sim.device
         thresh = cfg.get("body_diff_thresh", 0.5) if mode == "train" else cfg.get("body_diff_thresh_test", 0.5)
         if cfg.env_term_body not in ("body", "root"):

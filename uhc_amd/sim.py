@@ -13,8 +13,8 @@ from ._capi import UhcCtrlDesc, UhcEnvDesc, model_desc
 from ._lib import check, lib
 
 F_QPOS, F_QVEL, F_XPOS, F_XQUAT, F_XIPOS, F_QM, F_QFRC_BIAS, F_QACC, F_CTRL = range(9)
-F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF, F_REDO = range(9, 17)
-_INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW, F_REDO}
+F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF, F_REDO, F_TIER = range(9, 18)
+_INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW, F_REDO, F_TIER}
 
 
 class _DevView:
@@ -77,7 +77,7 @@ class SimBatch:
         check(self.L.uhc_batch_field(self._b, f, C.byref(p), C.byref(n)))
         per = n.value // self.n_env
         if f == F_STAGE_PROF:
-            t = torch.as_tensor(_DevView(p.value, (self.n_env, 32), "<i8", self), device=self.device)
+            t = torch.as_tensor(_DevView(p.value, (self.n_env, 40), "<i8", self), device=self.device)
         elif f in _INT_FIELDS:
             t = torch.as_tensor(_DevView(p.value, (self.n_env,), "<i4", self), device=self.device)
         else:
@@ -97,8 +97,9 @@ class SimBatch:
         check(self.L.uhc_batch_set_overflow_mode(self._b, int(bool(truncate))))
 
     def set_kernel_path(self, mode):
-        """0 / False: fast kernel, then the general kernel on the envs beyond its capacity; 1 / True: the general kernel alone (scenes where
-        most envs exceed the fast kernel's 64 rows); 2: adaptive -- the library switches between the two from the kernels' own counts."""
+        """0 / False: tier chain (fast kernel, then the general tier on the envs beyond its capacity, then the large tier); 1 / True: general
+        tier first (scenes where most envs exceed the fast kernel's 64 rows); 2: sticky tiers -- every env starts in the tier that computed
+        its last step, the slower tiers run beside the fast one on a side stream (include/uhc_amd.h)."""
         check(self.L.uhc_batch_set_kernel_path(self._b, int(mode)))
 
     def set_solver(self, solver: int, iterations: int = 0):
