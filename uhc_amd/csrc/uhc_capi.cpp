@@ -40,7 +40,7 @@ static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, siz
     if ((e = uhc_launch_m1_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m1_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
     return uhc_launch_m2_fast_lds(lds_bytes_fast);
 }
-extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, hipStream_t stream);
+extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin, hipStream_t stream);
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream);
 
@@ -143,7 +143,8 @@ struct UhcBatch {
     hipStream_t side_stream = nullptr, side_stream3 = nullptr;  // kernel path 2: the general / large tiers' own envs run beside the fast tier's
     hipEvent_t ev_fork = nullptr, ev_side1 = nullptr, ev_side2 = nullptr;
     int* tier_now = nullptr;
-    int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr;
+    int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr, *d_fin = nullptr;
+    bool queues_off = false;
     int* h_counts = nullptr;  // pinned [8][4]: list sizes of the last steps, copied back asynchronously
     hipEvent_t cnt_ev[8] = {};
     long long cnt_step = 0;
@@ -595,9 +596,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
     TRY(dalloc(b, 4, &S.path_stats));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 2 * E, &S.redo)); S.redo2 = S.redo + E;
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 3 * E, &S.redo)); S.pend2 = S.redo + E; S.pend3 = S.redo + 2 * E; TRY(dalloc(b, 1, &S.q_abort));
     TRY(dalloc(b, E, &S.tier)); TRY(dalloc(b, E, &b->tier_now)); S.tier_now = b->tier_now;
-    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors));
+    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 4, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
@@ -663,8 +664,14 @@ extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode) {
     b->path_mode = mode;
     if (mode == 2 && !b->side_stream) {
         HIP_OK(hipSetDevice(b->device));
-        HIP_OK(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
-        HIP_OK(hipStreamCreateWithFlags(&b->side_stream3, hipStreamNonBlocking));
+        // The consumers WAIT for launches of the batch's own stream, so they must never sit behind them in one hardware queue (streams beyond
+        // the runtime's pool of hardware queues share one and then run in order).  Streams of another priority get their queues from
+        // another pool.  The two side streams may still share a queue with each other: the general tier's consumers are launched first,
+        // the large tier's (which wait for them) second, so that in-order execution is merely slower.
+        int least = 0, greatest = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_OK(hipStreamCreateWithPriority(&b->side_stream, hipStreamNonBlocking, greatest));
+        HIP_OK(hipStreamCreateWithPriority(&b->side_stream3, hipStreamNonBlocking, greatest));
         HIP_OK(hipHostMalloc((void**)&b->h_counts, sizeof(int) * 8 * 4, hipHostMallocDefault));
         memset(b->h_counts, 0, sizeof(int) * 8 * 4);
         for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&b->cnt_ev[k], hipEventDisableTiming));
@@ -697,63 +704,89 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
     const bool general = b->general_only;
     const bool big = b->A.last_tier == 3;
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
-    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * (big ? 2 : 1), b->stream));  // redo and redo2 are one allocation
+    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 3, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3: one allocation
     if (mode == 0 && b->path_mode == 2 && b->use_fast && !general) {
         // sticky tiers: an env starts in the tier that computed its last step.  The general / large tiers' own envs run on a side stream
         // BESIDE the fast tier (their launches last several times longer per env; in a chain behind it the step would wait for them);
         // only the envs a tier hands on this very step go through the chain.  All launches filter on one snapshot of the tier table.
         KernelArgs K = b->A;
-        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->stream));
-        // how long the lists are is known on the host with a lag (asynchronous copies, never waited for): the newest copy that has landed
-        // sizes this step's list launches.  An env whose tier has no launch of its own this step (its list was empty when last seen) goes
-        // through the fast tier's chain like everybody else; a list longer than expected is worked off by fewer workgroups.
-        const int slot = (int)(b->cnt_step % 8);
-        HIP_OK(hipMemcpyAsync(b->h_counts + 4 * slot, b->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
-        HIP_OK(hipEventRecord(b->cnt_ev[slot], b->stream));
+        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->d_fin, b->stream));
+        HIP_OK(hipEventRecord(b->ev_fork, b->stream));
+        // how long the queues got is known on the host with a lag (asynchronous copies of the final counts, never waited for): the newest
+        // copy that has landed sizes this step's consumer launches.  While the general tier's queue was empty when last seen there are no
+        // consumers at all: an env the fast tier hands on is flagged and goes through the chained launches like in mode 0.
+        // (the host may not run more than two steps ahead of the device here: a launch sized for a queue of five that meets nine hundred
+        //  envs works them off five at a time)
+        if (b->cnt_step >= 2) HIP_OK(hipEventSynchronize(b->cnt_ev[(b->cnt_step - 2) % 8]));
         int est2 = 0, est3 = 0;
         for (long long k = b->cnt_step - 1; k >= 0 && k > b->cnt_step - 8; k--)
-            if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) { est2 = b->h_counts[4 * (k % 8) + 2]; est3 = b->h_counts[4 * (k % 8) + 3]; break; }
-        b->cnt_step++;
-        if (!big) est3 = 0;
-        K.sticky_mask = (est2 > 0 ? 4 : 0) | (est3 > 0 ? 8 : 0);
-        HIP_OK(hipEventRecord(b->ev_fork, b->stream));
-        if (est3 > 0) {  // the slowest envs first, on their own stream
-            HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
-            K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
-            K.grid = std::min(est3 + est3 / 4 + 4, std::min(b->n_env, 256));
-            HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
-            HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
-        }
-        if (est2 > 0) {
+            if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) {
+                est2 = b->h_counts[4 * (k % 8) + 2]; est3 = b->h_counts[4 * (k % 8) + 3];
+                if (b->h_counts[4 * (k % 8)] > 0) b->queues_off = true;  // a consumer gave up waiting: its producers do not run beside it here
+                break;
+            }
+        // Three regimes.  No env in the general tier when last seen: no side launches, plain chain.  A minority there (<= a quarter of the
+        // batch): its launch is a CONSUMER that also waits for what the fast tier hands on while both run -- and is kept small enough that
+        // the fast tier's workgroups always find LDS beside it (a consumer that holds all LDS while it waits for a launch that cannot
+        // start would only end by its time-out).  The majority there: the fast tier is the side show; the general tier's launch takes
+        // its list at full width and does not wait, what the fast tier hands on goes through the chained launch.
+        const bool queues = est2 > 0;
+        const bool waiting = queues && est2 <= b->n_env / 4 && !b->queues_off;
+        const bool q3 = queues && big;  // (a large-tier consumer waits beside the general tier's launch whenever there is one: what that hands on is rare and slow)
+        // (a waiting consumer works through its queue during the fast tier's two rounds: half as many workgroups as envs leave the LDS to the fast tier)
+        const int grid2 = waiting ? std::min(est2 / 2 + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));
+        K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
+        if (queues) {
             HIP_OK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
             K.tier_want = 0; K.list = b->d_lists; K.list_count = b->d_counts + 2; K.list_cursor = b->d_cursors + 2;
-            K.grid = std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));
+            K.grid = grid2;
+            K.prod_fin = waiting ? b->d_fin + 1 : nullptr; K.prod_total = b->n_env;  // every workgroup of the fast tier's launch below
+            K.fin = b->d_fin + 2;
+            K.q_next = q3 ? b->d_lists + b->n_env : nullptr; K.q_next_count = q3 ? b->d_counts + 3 : nullptr;
             HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, nullptr, b->lds_bytes, b->side_stream));
             HIP_OK(hipEventRecord(b->ev_side1, b->side_stream));
         }
-        K.list = nullptr; K.list_count = nullptr; K.list_cursor = nullptr; K.grid = 0;
+        if (q3) {
+            HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
+            K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
+            K.grid = std::min(est3 + est3 / 4 + 2, 64);  // (each holds a whole CU's LDS)
+            K.prod_fin = b->d_fin + 2; K.prod_total = grid2;  // the general tier's workgroups above: they never wait for this launch
+            K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
+            HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
+            HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
+        }
+        K.list = nullptr; K.list_count = nullptr; K.list_cursor = nullptr; K.grid = 0; K.prod_fin = nullptr; K.prod_total = 0;
         K.tier_want = 1;
+        K.fin = waiting ? b->d_fin + 1 : nullptr;
+        K.q_next = waiting ? b->d_lists : nullptr; K.q_next_count = waiting ? b->d_counts + 2 : nullptr;
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &K, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
-        K.tier_want = 0; K.sticky_mask = 0;
-        HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
-        if (est2 > 0) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side1, 0));  // the list launch of the general tier may have handed envs on as well
-        if (big) HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, b->A.s.redo2, b->lds_bytes_big, b->stream));
-        if (est3 > 0) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side2, 0));
+        K.tier_want = 0; K.sticky_mask = 0; K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
+        // chained launches on what is still flagged: everything handed on when no consumers run, nothing (two empty launches) when they do
+        if (queues) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side1, 0));
+        HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, b->A.s.pend2, b->lds_bytes, b->stream));
+        if (q3) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side2, 0));
+        if (big) HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, b->A.s.pend3, b->lds_bytes_big, b->stream));
+        // the final queue lengths of this step, for the steps to come
+        const int slot = (int)(b->cnt_step % 8);
+        HIP_OK(hipMemcpyAsync(b->d_counts, b->A.s.q_abort, sizeof(int), hipMemcpyDeviceToDevice, b->stream));  // counts[0] carries the give-up count
+        HIP_OK(hipMemcpyAsync(b->h_counts + 4 * slot, b->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        HIP_OK(hipEventRecord(b->cnt_ev[slot], b->stream));
+        b->cnt_step++;
         return 0;
     }
     if (b->use_fast && !general) {
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &b->A, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
-        HIP_OK(uhc_launch_step(mode, 2, &b->A, d_action, d_tbase, b->A.s.redo, b->lds_bytes, b->stream));
+        HIP_OK(uhc_launch_step(mode, 2, &b->A, d_action, d_tbase, b->A.s.pend2, b->lds_bytes, b->stream));
     } else {
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 2, &b->A, d_action, d_tbase, d_active, b->lds_bytes, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
     }
-    if (big) HIP_OK(uhc_launch_step(mode, 3, &b->A, d_action, d_tbase, b->A.s.redo2, b->lds_bytes_big, b->stream));
+    if (big) HIP_OK(uhc_launch_step(mode, 3, &b->A, d_action, d_tbase, b->A.s.pend3, b->lds_bytes_big, b->stream));
     return 0;
 
     return 0;

@@ -94,7 +94,8 @@ struct DevState {  // HBM, env-major
     double *qpos, *qvel, *qacc, *qacc_ws, *xpos, *xquat, *xipos, *qM, *bias, *ctrl, *applied;
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
-    int* redo2;  // envs the general tier handed on to the large tier this step
+    int *pend2, *pend3;  // envs handed on to the general / large tier this step and not yet taken (the chained launches' active masks)
+    int* q_abort;  // consumers that gave up waiting for their producers (queue_claim)
     int* tier;   // per env: the tier that computed its last control step (minus hysteresis): where its next step starts (kernel path 2)
     const int* tier_now;  // snapshot of `tier` taken at the head of the step: what the tier filter of a launch reads
     int* fresh;  // 1: the env was restarted on the device (set_state done, kinematics refreshed); its mj_forward runs at the head of its next step
@@ -126,9 +127,14 @@ struct KernelArgs {
     int last_tier;  // 2 or 3: the tier that drops what exceeds it instead of handing the env on
     int tier_want;  // 0: the launch works on every active env; else (sticky tiers) it leaves out the envs whose tier_now differs AND has its own launch
     int sticky_mask;  // bit t: tier t has its own (list) launch this step
-    const int* list;  // != NULL: persistent launch over this compacted env list (list_count entries, shared cursor)
-    const int* list_count;
+    int* list;        // != NULL: persistent launch over this env queue (list_count entries so far, shared cursor; slots beyond hold -1)
+    int* list_count;
     int* list_cursor;
+    const int* prod_fin;  // the queue's producers: exit only when this counter has reached prod_total (NULL: the queue does not grow)
+    int prod_total;
+    int* fin;             // this launch's own exit counter (bumped once per workgroup), or NULL
+    int* q_next;          // hand-on target: the next tier's queue (NULL: flag the env in redo / redo2 for a chained launch)
+    int* q_next_count;
     int grid;  // workgroups of a list launch (0: one per env)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS

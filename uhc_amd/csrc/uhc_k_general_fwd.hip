@@ -59,10 +59,12 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
     return hipGetLastError();
 }
 
-// sticky tiers, head of a control step: snapshot of the tier table + the compacted lists of the active envs that start in the general /
-// large tier (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; the cursors the persistent launches share)
-__global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors) {
-    if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; }
+// sticky tiers, head of a control step: snapshot of the tier table + the queues of the general / large tier, which start with the active
+// envs that begin the step there (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; free slots = -1),
+// the cursors the persistent launches share and the producers' exit counters (fin[1]: fast tier's workgroups, fin[2]: general tier's)
+__global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin) {
+    if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; fin[threadIdx.x] = 0; }
+    for (int i = threadIdx.x; i < 2 * n_env; i += blockDim.x) lists[i] = -1;
     __syncthreads();
     for (int env = threadIdx.x; env < n_env; env += blockDim.x) {
         const int t = tier[env];
@@ -70,7 +72,7 @@ __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int 
         if ((t == 2 || t == 3) && (!d_active || d_active[env])) lists[(t - 2) * n_env + atomicAdd(&counts[t], 1)] = env;
     }
 }
-extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, hipStream_t stream) {
-    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors);
+extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors, fin);
     return hipGetLastError();
 }

@@ -2449,7 +2449,12 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
     }
     if (overflow & 1) {  // nothing committed: the next tier redoes this env from the same inputs
         if (LANE == 0) {
-            if (TIER == 1) A.s.redo[env] = 1; else A.s.redo2[env] = 1;
+            if (A.q_next) {  // the next tier's consumers are running beside this launch: straight into their queue
+                const int k = atomicAdd(A.q_next_count, 1);
+                __hip_atomic_store(A.q_next + k, env, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ... and flagged for the chained launch of the next tier, which takes whatever no consumer took (none running, or given up)
+            if (TIER == 1) A.s.pend2[env] = 1; else { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
             if (TIER == 1 && MODE == 0) atomicAdd(A.s.path_stats, 1ull);
         }
         return;
@@ -2494,6 +2499,8 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         A.s.fail[env] = fail;
         if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
+        if (TIER == 2) A.s.pend2[env] = 0;  // taken: the chained launch of this tier has nothing left to do for the env
+        if (TIER == 3) A.s.pend3[env] = 0;
         // where the env's next step starts (uhc_batch_set_kernel_path 2): an env comes down a tier only with room to spare
         if (MODE == 0 && ran) A.s.tier[env] = TIER == 1 ? 1 : (TIER == 2 ? (fits_hyst ? 1 : 2) : (!fits_gen ? 3 : (fits_hyst ? 1 : 2)));
         if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | swept;
@@ -2506,28 +2513,53 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
 
 // The launch forms.  (1) one workgroup per env of the batch (blockIdx = env), filtered by the active mask and -- under sticky tiers -- by
 // the tier the env starts its step in: the fast tier's launch skips the envs that have a launch of their own this step.  (2) a PERSISTENT
-// launch over a compacted env list (sticky general / large tiers): the grid is as large as the host expects the list to be, every
-// workgroup takes envs off the list until it is empty, so an underestimate costs time, never an env -- and no workgroup is started (and
-// has to be given its 79 / 160 KiB of LDS) only to find that its env belongs to another tier.
+// launch over an env QUEUE (sticky general / large tiers): the queue starts with the envs that begin the step in this tier and grows by
+// the envs the tier below hands on WHILE both launches run; every workgroup takes envs off the queue until it is empty AND all its
+// producers have finished (a counter every producer workgroup bumps on exit).  The grid is as large as the host expects the queue to
+// get: an underestimate costs time, never an env -- and no workgroup is started (and has to be given its 79 / 160 KiB of LDS) only to
+// find that its env belongs to another tier.  A handed-on env is picked up a fraction of a step after the fast tier found it too big,
+// instead of after the fast tier's whole launch.
+__device__ __forceinline__ int queue_claim(const KernelArgs& A) {  // lane 0 only
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    for (;;) {
+        const int f = A.prod_fin ? __hip_atomic_load(A.prod_fin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int c = __hip_atomic_load(A.list_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const int cur = __hip_atomic_load(A.list_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur < c) {
+            if (atomicCAS(A.list_cursor, cur, cur + 1) != cur) continue;
+            int env;  // (the producer bumps the count before it fills the slot: slots start at -1)
+            while ((env = __hip_atomic_load(A.list + cur, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(8);
+            return env;
+        }
+        if (!A.prod_fin || f >= A.prod_total) return -1;  // (f was read before the count: every append of a finished producer was seen)
+        // Never wait for ever: if the producers' launch cannot run beside this one (streams that share a hardware queue run in order) the
+        // wait would not end.  After 50 ms with nothing to do the consumer leaves; what is handed on later stays flagged for the chained
+        // launches, and the host stops starting consumers when it sees the count (DevState::q_abort).
+        if (wall_clock64() - t0 > 5000000ull) { atomicAdd(A.s.q_abort, 1); return -1; }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
 template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
-    if (A.list) {
-        for (;;) {
-            int i = 0;
-            if (LANE == 0) i = atomicAdd(A.list_cursor, 1);
-            i = __builtin_amdgcn_readfirstlane(i);
-            if (i >= *A.list_count) return;
-            uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, A.list[i]);
-            wsync();
+    bool first = true;
+    for (;;) {  // (one call site of the step: the body is ~100 K instructions)
+        int env = -1;
+        if (A.list) {
+            if (LANE == 0) env = queue_claim(A);
+            env = __builtin_amdgcn_readfirstlane(env);
+        } else if (first) {
+            first = false;
+            env = blockIdx.x;
+            if (env >= A.n_env || (d_active && !d_active[env])) env = -1;
+            else if (A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
+                const int t = A.s.tier_now[env];
+                if (t != A.tier_want && ((A.sticky_mask >> t) & 1)) env = -1;
+            }
         }
+        if (env < 0) break;
+        uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+        wsync();
     }
-    const int env = blockIdx.x;
-    if (env >= A.n_env) return;
-    if (d_active && !d_active[env]) return;
-    if (A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
-        const int t = A.s.tier_now[env];
-        if (t != A.tier_want && ((A.sticky_mask >> t) & 1)) return;
-    }
-    uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+    if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer / consumer bookkeeping of the queues
 }
