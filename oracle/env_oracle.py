@@ -81,6 +81,57 @@ def full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, 
     return np.concatenate(obs)
 
 
+def full_obs_v2_quat(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, gender=None, base_rot=BASE_ROT):
+    """humanoid_im.py:668-756 (robot.ball: qpos = root position + 24 quaternions, nq 99), with the expert's QUATERNION pose
+    (expert["qpos_quat"], the `expert_qpos_quat` that load_expert computes at :193-200) as `get_expert_qpos`: as shipped the
+    reference hands the 76-wide Euler pose to this function and its reshape(-1, 4) of 73 numbers raises."""
+    qpos, qvel = qpos.copy(), qvel.copy()
+    qvel[:3] = transform_vec(qvel[:3], qpos[3:7], "root")
+    obs = []
+    curr_root_quat = remove_base_rot(qpos[3:7], base_rot)
+    hq = get_heading_q(curr_root_quat)
+    obs.append(hq)
+    ind = expert_index(cur_t + 1, start_ind, expert["len"])
+    target_body_qpos = expert["qpos_quat"][ind].copy()
+    target_quat = expert["wbquat"][ind].reshape(-1, 4)
+    target_jpos = expert["wbpos"][ind]
+    target_root_quat = remove_base_rot(target_body_qpos[3:7], base_rot)
+    diff_qpos = target_body_qpos.copy()
+    diff_qpos[2] -= qpos[2]
+    obs += [target_body_qpos[2:3], qpos[2:3], diff_qpos[2:3]]
+    diff_qpos[3:7] = target_root_quat
+    qpos_copy = qpos.copy()
+    qpos_copy[3:7] = curr_root_quat
+    obs.append(quaternion_multiply_batch(quaternion_inverse_batch(qpos_copy[3:].reshape(-1, 4)), diff_qpos[3:].reshape(-1, 4)).ravel())
+    qvel[:3] = transform_vec(qvel[:3], curr_root_quat, "root")
+    obs.append(qvel)
+    rel_h = get_heading(target_root_quat) - get_heading(curr_root_quat)
+    if rel_h > np.pi:
+        rel_h -= 2 * np.pi
+    if rel_h < -np.pi:
+        rel_h += 2 * np.pi
+    obs.append(np.array([rel_h]))
+    rel_pos = target_root_quat[:3] - qpos[:3]
+    obs.append(transform_vec(rel_pos, curr_root_quat, "root")[:2])
+    curr_jpos = xpos[1:].copy()
+    obs.append(transform_vec_batch(curr_jpos - qpos[None, :3], curr_root_quat, "root").ravel())
+    obs.append(transform_vec_batch(target_jpos.reshape(-1, 3) - curr_jpos, curr_root_quat, "root").ravel())
+    cur_quat = xquat[1:].copy()
+    if cur_quat[0, 0] == 0:
+        cur_quat = target_quat.copy()
+    hq_inv = np.repeat(quaternion_inverse(hq)[None], cur_quat.shape[0], axis=0)
+    obs.append(quaternion_multiply_batch(hq_inv, cur_quat).ravel())
+    obs.append(quaternion_multiply_batch(quaternion_inverse_batch(cur_quat), target_quat).ravel())
+    if beta is not None:
+        obs += [beta, [gender]]
+    return np.concatenate(obs)
+
+
+def get_body_quat_ball(qpos):
+    """humanoid_im.py:927-935 (use_quat): the quaternions of the ball qpos as they are."""
+    return qpos[3:99].copy()
+
+
 def full_obs_v1(qpos, qvel, xpos, xquat, xipos, expert, cur_t, start_ind=0, base_rot=BASE_ROT):
     """humanoid_im.py:323-417: the v2 blocks plus current / difference body-COM positions before the quaternions; no shape."""
     v2 = full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t, start_ind, None, None, base_rot)
@@ -164,11 +215,12 @@ def world_rfc_explicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur
     return float((ws * parts).sum() / ws.sum()), parts
 
 
-def world_rfc_implicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur_t, start_ind, dt, body_diffw, w, ndof=69, vf_dim=6):
-    """reward_function.py:12-88.  `w` is the reward_weights dict; returns (reward, 5 components)."""
+def world_rfc_implicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur_t, start_ind, dt, body_diffw, w, ndof=69, vf_dim=6, ball=False):
+    """reward_function.py:12-88 (= world_rfc_implicit_quat, :92-171, whose body quaternions come straight out of a ball-joint qpos: `ball`).
+    `w` is the reward_weights dict; returns (reward, 5 components).  vf_dim 0 = residual_force off: the fifth term is 0 (:74-77)."""
     ind = expert_index(cur_t, start_ind, expert["len"])
     cur_ee = xpos[EE_BODY_IDS].ravel()
-    cur_bquat = get_body_quat(qpos)
+    cur_bquat = get_body_quat_ball(qpos) if ball else get_body_quat(qpos)
     cur_bangvel = get_angvel_fd(prev_bquat, cur_bquat, dt)
     e_ee, e_com = expert["ee_wpos"][ind], expert["com"][ind]
     e_bquat, e_bangvel = expert["bquat"][ind], expert["bangvel"][ind]
@@ -181,7 +233,7 @@ def world_rfc_implicit_reward(qpos, xpos, xipos, prev_bquat, action, expert, cur
     ee_r = math.exp(-w["k_e"] * np.linalg.norm(cur_ee - e_ee) ** 2)
     com_r = math.exp(-w["k_c"] * np.linalg.norm(xipos[1] - e_com) ** 2)
     vf = action[ndof:ndof + vf_dim]
-    vf_r = math.exp(-w["k_vf"] * np.linalg.norm(vf) ** 2)
+    vf_r = math.exp(-w["k_vf"] * np.linalg.norm(vf) ** 2) if vf_dim > 0 else 0.0
     parts = np.array([pose_r, vel_r, ee_r, com_r, vf_r])
     ws = np.array([w["w_p"], w["w_v"], w["w_e"], w["w_c"], w["w_vf"]])
     return float((ws * parts).sum() / ws.sum()), parts

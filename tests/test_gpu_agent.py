@@ -362,3 +362,29 @@ def test_facade_load_expert_rebuilds_the_robot(tmp_path):
     env.load_expert(e0, reload_robot=False)
     assert env.vec is vec and float(env.model.body_mass.sum()) == m1
     env.vec.close()
+
+
+def test_agent_iteration_on_the_ball_joint_humanoid(tmp_path):
+    """config/copycat_ball/copycat_ball_1.yml's env: robot.ball, action_type torque (tq_mul 4), no residual force, no meta-PD, reward
+    world_rfc_implicit_quat, obs_v 2 -> get_full_obs_v2_quat (534 numbers).  One agent iteration on it (self-collision on, as every
+    generated model): the env layer that makes configs[4] a rollout and not a physics-only loop."""
+    import torch
+    from uhc_amd import sim as S
+    from uhc_amd.agents import agent_dict
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path)
+    cfg.robot_cfg = {"mesh": True, "model": "smpl", "ball": True}
+    cfg.action_type, cfg.residual_force, cfg.meta_pd, cfg.meta_pd_joint = "torque", False, False, False
+    cfg.reward_id, cfg.obs_v = "world_rfc_implicit_quat", 2
+    cfg.cfg_dict["tq_mul"] = 4
+    cfg.env_init_noise = 0.0
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
+    env = agent.env
+    assert env.use_quat and (env.model.nq, env.model.nv) == (99, 75) and agent.state_dim == 534 and agent.action_dim == 69
+    info = agent.optimize_policy(0)
+    log = info["log"]
+    assert log.num_steps == 64 * 8 and 0.0 < log.avg_c_reward <= 1.0 and np.isfinite(log.avg_c_info).all()
+    assert int(env.sim.field(S.F_FAIL).sum().item()) == 0 and int(env.sim.field(S.F_EFC_OVERFLOW).sum().item()) == 0
+    q = env.sim.field(S.F_QPOS).cpu().numpy()
+    assert np.abs(np.linalg.norm(q[:, 3:99].reshape(-1, 24, 4), axis=2) - 1).max() < 1e-9
+    env.close()

@@ -373,3 +373,83 @@ def test_deferred_reset_forward_matches_explicit_reset(model, ctrl, solver):
         sb.close()
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+def test_ball_env_rollout_matches_oracles(model):
+    """The ball-joint env (robot.ball / `use_quat`, config/copycat_ball: torque actions, no residual force, reward world_rfc_implicit_quat,
+    observation get_full_obs_v2_quat): reset state = the expert's quaternion pose, body quaternions straight out of qpos, the 534-wide
+    observation -- device kernels vs env_oracle (pinned by the reference fixture G14) + the physics oracle on the ball model."""
+    import dataclasses
+    import torch
+    from oracle import env_oracle as E
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd._capi import env_desc
+    from uhc_amd.model.mjcf import ball_variant
+    from uhc_amd.smpllib.smpl_mujoco import SMPLConverter, smpl_to_qpose
+    from uhc_amd.smpllib.torch_smpl_humanoid import Humanoid
+    g = np.load(os.path.join(G, "g14_ball_env.npz"))
+    ball = dataclasses.replace(ball_variant(model), solver=1)
+    ctrl = S.make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    jw = SMPLConverter(model, model).get_new_diff_weight()
+    n = 3
+    sb = S.SimBatch(ball, ctrl, n)
+    eb = S.EnvBatch(sb, env_desc(model, obs_v=2, has_shape=True, reward_weights=REWARD_W, reward_v=0, jpos_diffw=jw))
+    assert eb.obs_dim == 534
+    qpos_q = g["qpos_quat"]
+    starts, lens = np.array([0, 4, 12]), np.array([30, 20, 9])
+
+    def window(s, l):
+        w = Humanoid(model=model).qpos_fk(torch.from_numpy(g["qpos_euler"][s:s + l].copy()))
+        w["qpos_quat"] = qpos_q[s:s + l]
+        return w
+
+    whole = Humanoid(model=model).qpos_fk(torch.from_numpy(g["qpos_euler"].copy()))
+    rec = np.array(whole["qpos"], copy=True)
+    rec[:, 3:7] = qpos_q[:, 3:7]
+    frames = S.pack_expert_frames(dict(whole, qpos=rec))
+    beta = g["c0_beta"]
+    eb.set_bank(torch.from_numpy(frames), torch.tensor([0], dtype=torch.int32), torch.from_numpy(np.r_[beta, 2.0][None]))
+    ids = torch.arange(n, dtype=torch.int32)
+    eb.assign(ids, torch.zeros(n, dtype=torch.int32), torch.from_numpy(starts), torch.from_numpy(lens))
+    eb.reset(ids.cuda(), None)
+    sb.sync()
+    wins = [window(starts[e], lens[e]) for e in range(n)]
+    os_ = []
+    gq0 = sb.field(S.F_QPOS).cpu().numpy()
+    for e in range(n):
+        o = OracleSim(ball, ctrl)
+        o.set_state(wins[e]["qpos_quat"][0], wins[e]["qvel"][0])
+        np.testing.assert_allclose(gq0[e], wins[e]["qpos_quat"][0], atol=1e-15)  # reset to the quaternion expert pose
+        os_.append(o)
+    gobs = eb.field(S.E_OBS).cpu().numpy()
+    for e in range(n):
+        xpos, xquat = os_[e].get("xpos").reshape(-1, 3), os_[e].get("xquat").reshape(-1, 4)
+        np.testing.assert_allclose(gobs[e], E.full_obs_v2_quat(os_[e].get("qpos"), os_[e].get("qvel"), xpos, xquat, wins[e], 0, 0, beta, 2.0), atol=1e-11)
+    rng = np.random.default_rng(17)
+    cur_t, alive = np.zeros(n, dtype=int), np.ones(n, dtype=bool)
+    for t in range(10):
+        act = rng.normal(scale=0.003, size=(n, ctrl.action_dim))
+        eb.step(torch.from_numpy(act).cuda(), torch.from_numpy(alive.astype(np.int32)).cuda())
+        sb.sync()
+        gobs, grew, gparts = eb.field(S.E_OBS).cpu().numpy(), eb.field(S.E_REWARD).cpu().numpy(), eb.field(S.E_REWARD_PARTS).cpu().numpy()
+        gdone, gq, redo = eb.field(S.E_DONE).cpu().numpy(), sb.field(S.F_QPOS).cpu().numpy(), sb.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            if not alive[e]:
+                continue
+            o, w = os_[e], wins[e]
+            prev_bquat = E.get_body_quat_ball(o.get("qpos"))
+            o.do_simulation(act[e], np.zeros(69), redo=redo[e])
+            cur_t[e] += 1
+            xpos, xquat, xipos = o.get("xpos").reshape(-1, 3), o.get("xquat").reshape(-1, 4), o.get("xipos").reshape(-1, 3)
+            np.testing.assert_allclose(gq[e], o.get("qpos"), atol=1e-9)
+            r, parts = E.world_rfc_implicit_reward(o.get("qpos"), xpos, xipos, prev_bquat, act[e], w, cur_t[e], 0, model.timestep * 15, jw[1:], REWARD_W, vf_dim=0, ball=True)
+            bd = E.calc_body_diff(xpos, w["wbpos"][E.expert_index(cur_t[e], 0, w["len"])], jw)
+            fail, end = bool(o.geti("fail")) or bd > 0.5, cur_t[e] >= w["len"] - 1
+            assert bool(gdone[e]) == (fail or end)
+            assert grew[e] == pytest.approx(r, abs=1e-9) and parts[4] == 0.0
+            np.testing.assert_allclose(gparts[e][:5], parts, atol=1e-9)
+            np.testing.assert_allclose(gobs[e], E.full_obs_v2_quat(o.get("qpos"), o.get("qvel"), xpos, xquat, w, cur_t[e], 0, beta, 2.0), atol=1e-8)
+            if fail or end:
+                alive[e] = False
+    assert not alive[2]  # the 9-frame window has ended

@@ -299,3 +299,37 @@ def test_process_amass_db_matches_reference():
     want = dict(zip([str(k) for k in g["split_keys"]], [str(v) for v in g["split_vals"]]))
     got = {**{k: "train" for k in train}, **{k: "test" for k in test}, **{k: "valid" for k in valid}}
     assert got == want and valid == {}   # HumanEva (a validation set) lands in train: the reference's 'vald' / 'valid' slip
+
+
+def test_ball_env_quaternion_paths_match_reference(model):
+    """G14: the ball-joint env (robot.ball / use_quat, config/copycat_ball): expert conversion with use_quat, get_body_quat on the ball
+    qpos, world_rfc_implicit_quat, and get_full_obs_v2_quat given the quaternion expert pose (the pose the function was written for;
+    the reference hands it the Euler one and raises -- tools/gen_golden.py: g14_ball_env)."""
+    from oracle import env_oracle as E
+    from uhc_amd.model.mjcf import ball_variant
+    from uhc_amd.smpllib.smpl_mujoco import SMPLConverter, smpl_to_qpose
+    g = load("g14_ball_env")
+    ball = ball_variant(model)
+    # (the reference converts axis-angle -> rotation with a float32-grade routine: 2e-6, as for the Euler pose of G2)
+    np.testing.assert_allclose(smpl_to_qpose(g["pose_aa"], ball, trans=g["trans"], count_offset=True, use_quat=True), g["qpos_quat"], atol=2e-6)
+    expert = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    expert["len"] = int(expert["len"])
+    expert["qpos_quat"] = g["qpos_quat"]
+    # the joints of the quaternion expert pose ARE the expert's local body quaternions (bquat), sign included: the bank record needs no
+    # new field for them; the ROOT quaternions of the two poses come out of different routines of the reference (1.5e-3 rad apart)
+    np.testing.assert_allclose(g["qpos_quat"][:, 7:], expert["bquat"][:, 4:], atol=1e-12)
+    root_dot = np.abs((g["qpos_quat"][:, 3:7] * expert["bquat"][:, :4]).sum(1))
+    assert root_dot.min() > 1 - 1e-6 and root_dot.min() < 1 - 1e-9
+    jw = SMPLConverter(model, model).get_new_diff_weight()
+    w = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0)
+    for c in range(int(g["ncase"])):
+        p = f"c{c}_"
+        t = int(g[p + "cur_t"])
+        obs = E.full_obs_v2_quat(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], g[p + "xquat"], expert, t, 0, g[p + "beta"], float(g["gender"]))
+        assert obs.shape == (534,)
+        np.testing.assert_allclose(obs, g[p + "obs"], atol=1e-12)
+        np.testing.assert_allclose(E.get_body_quat_ball(g[p + "qpos"]), g[p + "bquat"], atol=0)
+        r, parts = E.world_rfc_implicit_reward(g[p + "qpos"], g[p + "xpos"], g[p + "xipos"], g[p + "prev_bquat"], g[p + "action"], expert, t, 0,
+                                               model.timestep * 15, jw[1:], w, vf_dim=0, ball=True)
+        assert r == pytest.approx(float(g[p + "reward"]), abs=1e-12)
+        np.testing.assert_allclose(parts, g[p + "reward_info"], atol=1e-12)

@@ -566,7 +566,62 @@ def g13_process_amass():
     save("g13_process_amass", **out)
 
 
+# --------------------------------------------------------------------------- G14 ball-joint env (robot.ball / use_quat)
+def g14_ball_env():
+    """The quaternion paths of the ball-joint humanoid (config/copycat_ball): `smpl_to_qpose(use_quat=True)` (:590-600), `get_body_quat`
+    with use_quat (humanoid_im.py:927-935), `world_rfc_implicit_quat` on them, and `get_full_obs_v2_quat` (:668-756) with the
+    QUATERNION expert pose behind `get_expert_qpos` -- the array `load_expert` computes as `expert_qpos_quat` (:193-200) but never
+    stores: as shipped the function receives the 76-wide Euler pose and raises on `reshape(-1, 4)`.  The fixture therefore pins what
+    the function computes when it is given the pose it was written for."""
+    from uhc.envs.humanoid_im import HumanoidEnv
+    from uhc.losses import reward_function as RF
+    from uhc.smpllib.smpl_mujoco import smpl_to_qpose
+    from uhc.smpllib.torch_smpl_humanoid import Humanoid
+    from uhc_amd.model.mjcf import ball_variant
+    ball = ball_variant(MODEL)
+    dmb, dmh = DuckModel(ball), DuckModel(MODEL)
+    rng = np.random.default_rng(1414)
+    pose, trans = make_clip(rng, 40)
+    qpos_e = smpl_to_qpose(pose, dmh, trans=trans, count_offset=True)                   # Euler expert (what qpos_fk consumes)
+    qpos_q = smpl_to_qpose(pose, dmb, trans=trans, count_offset=True, use_quat=True)    # quaternion expert, (T, 99)
+    feat = {k: np.asarray(v) for k, v in Humanoid(model=dmh).qpos_fk(torch.from_numpy(qpos_e)).items()}
+    cases = {"pose_aa": pose, "trans": trans, "qpos_quat": qpos_q, "qpos_euler": qpos_e}
+    for c, cur_t in enumerate([2, 9, 30]):
+        env = fake_env(dmb, feat, rng, cur_t=cur_t)
+        env.use_quat = True
+        env.qpos_lim, env.qvel_lim, env.body_lim = 99, 75, 25
+        env.expert = dict(env.expert)
+        env.expert["qpos"] = qpos_q  # get_expert_qpos -> the quaternion pose
+        env.cc_cfg.update(residual_force=False)
+        env.vf_dim, env.meta_pd_dim = 0, 0
+        q = qpos_q[cur_t].copy()
+        q[:3] += rng.normal(scale=0.05, size=3)
+        qq = q[3:].reshape(24, 4) + rng.normal(scale=0.05, size=(24, 4))
+        q[3:] = (qq / np.linalg.norm(qq, axis=1, keepdims=True)).ravel()
+        env.data.qpos = q
+        obs = HumanoidEnv.get_full_obs_v2_quat(env)
+        bquat = HumanoidEnv.get_body_quat(env)
+        prev = q.copy()
+        pq = prev[3:].reshape(24, 4) + rng.normal(scale=0.01, size=(24, 4))
+        prev[3:] = (pq / np.linalg.norm(pq, axis=1, keepdims=True)).ravel()
+        env.data.qpos = prev
+        env.prev_bquat = HumanoidEnv.get_body_quat(env)
+        env.data.qpos = q
+        action = rng.normal(scale=0.3, size=69)
+        r, info = RF.reward_func["world_rfc_implicit_quat"](env, None, action, None)
+        pre = f"c{c}_"
+        cases.update({pre + "cur_t": cur_t, pre + "qpos": q, pre + "qvel": env.data.qvel, pre + "xpos": env.data.body_xpos, pre + "xquat": env.data.body_xquat,
+                      pre + "xipos": env.data.xipos, pre + "obs": obs, pre + "bquat": bquat, pre + "prev_bquat": env.prev_bquat, pre + "action": action,
+                      pre + "reward": r, pre + "reward_info": info, pre + "beta": env.expert["beta"][0]})
+    cases["gender"] = env.expert["gender"][0]
+    cases["ncase"] = 3
+    for k, v in feat.items():
+        cases["f_" + k] = v
+    save("g14_ball_env", **cases)
+
+
 def main():
+    g14_ball_env()
     g1_math()
     dm, qpos, feat = g2_g3_expert()
     g4_g6_obs_reward(dm, feat)

@@ -16,6 +16,7 @@
 
 struct EnvArgs {
     int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip, obs_flags, term_body;
+    int ball;  // the humanoid has ball joints (robot.ball, `use_quat` in the reference): qpos = root position + nbody - 1 quaternions
     int ee_body[5];
     double dt, body_diff_thresh;
     double rw[16];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf | w_wp w_j k_wp k_j

@@ -29,6 +29,10 @@ __device__ __forceinline__ void qinv(double* r, const double* q) {  // conj / |q
     const double n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
     r[0] = q[0] / n; r[1] = -q[1] / n; r[2] = -q[2] / n; r[3] = -q[3] / n;
 }
+__device__ __forceinline__ void qinv_batch(double* r, const double* q) {  // conj / |q| (quaternion_inverse_batch, transformation.py:1523-1534: the norm, not its square)
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    r[0] = q[0] / n; r[1] = -q[1] / n; r[2] = -q[2] / n; r[3] = -q[3] / n;
+}
 // rotation of a (not necessarily unit) quaternion: normalises like quaternion_matrix (transformation.py:1344-1368)
 __device__ __forceinline__ void qmat(double* m, const double* q) {
     const double n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
@@ -61,10 +65,15 @@ __device__ __forceinline__ void euler_rzyx(double* q, double az, double ay, doub
     q[0] = cx * cy * cz + sx * sy * sz; q[1] = sx * cy * cz - cx * sy * sz;
     q[2] = cx * sy * cz + sx * cy * sz; q[3] = cx * cy * sz - sx * sy * cz;
 }
-// local body quaternion b (0 = root) from a hinge-model qpos (humanoid_im.py:925-947)
-__device__ __forceinline__ void body_quat(double* q, const double* qpos, int b) {
-    if (b == 0) { q[0] = qpos[3]; q[1] = qpos[4]; q[2] = qpos[5]; q[3] = qpos[6]; }
+// local body quaternion b (0 = root) from a hinge-model qpos, or -- ball joints -- the qpos entries themselves (humanoid_im.py:925-947)
+__device__ __forceinline__ void body_quat(double* q, const double* qpos, int b, int ball) {
+    if (b == 0 || ball) { q[0] = qpos[3 + 4 * b]; q[1] = qpos[4 + 4 * b]; q[2] = qpos[5 + 4 * b]; q[3] = qpos[6 + 4 * b]; }
     else euler_rzyx(q, qpos[7 + 3 * (b - 1)], qpos[8 + 3 * (b - 1)], qpos[9 + 3 * (b - 1)]);
+}
+// entry i of the expert pose an env is reset to: the record's qpos, or -- ball joints -- root position, the quaternion pose's root
+// quaternion (kept in the record's root slot) and the expert's local body quaternions (smpl_to_qpose(use_quat=True), smpl_mujoco.py:590-600)
+__device__ __forceinline__ double expert_qpos(const double* fr, int i, int ball) {
+    return (!ball || i < 7) ? fr[UHC_FR_QPOS + i] : fr[UHC_FR_BQUAT + 4 + (i - 7)];
 }
 __device__ __forceinline__ int expert_index(int t, int start_ind, int len) { return min(start_ind + t, len - 1); }
 
@@ -114,8 +123,8 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             if (w != 0) { dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); wcount = 1; }
             // ---- reward terms per body (reward_function.py:44-63)
             double cq[4], pq[4], eq[4], ei[4], dq[4], pi[4];
-            body_quat(cq, s_qpos, LANE);
-            body_quat(pq, s_prev, LANE);
+            body_quat(cq, s_qpos, LANE, E.ball);
+            body_quat(pq, s_prev, LANE, E.ball);
             for (int k = 0; k < 4; k++) eq[k] = fr[UHC_FR_BQUAT + 4 * LANE + k];
             qinv(ei, eq);
             qmul(dq, cq, ei);
@@ -264,7 +273,7 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
                 for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
                 rotT(r, Rc, d);
                 for (int k = 0; k < 3; k++) obs[o2 + k * (nb - 1) + (b - 1)] = r[k];
-                body_quat(cq, s_qpos, b);
+                body_quat(cq, s_qpos, b, E.ball);
                 for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_BQUAT + 4 * b + k]; obs[o3 + 4 * (b - 1) + k] = cq[k]; }
                 qinv(ci, cq);
                 qmul(o, ci, tb);
@@ -272,6 +281,58 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             }
         }
         shape_base = o4 + 4 * (nb - 1);
+    } else if (E.ball) {
+        // get_full_obs_v2_quat (:668-756), fed with the quaternion expert pose (the reference hands it the Euler one and raises):
+        // [0:4] heading quaternion | target z, z, dz | inv(current quaternions, root without base rotation) x target quaternions (4 nb) |
+        // qvel (first three rotated twice, as in v2) | heading difference | "relative position" (bug-compatible, :717) | body positions
+        // and differences in the root frame (component-major) | hq^-1 x world quaternions | world quaternions^-1 x expert's | shape
+        const int nvh = E.nu + 6;
+        const int oq = 7, ov = oq + 4 * nb, oh = ov + nvh, oj = oh + 3, oqw = oj + 6 * nb;
+        heading_q(hq, crq);
+        qinv(hqi, hq);
+        qmat(Rr, rootq);
+        qmat(Rc, crq);
+        if (LANE == 0) {
+            double v0[3], v1[3], rel[3], rl[3];
+            for (int k = 0; k < 4; k++) obs[k] = hq[k];
+            obs[4] = fr[UHC_FR_QPOS + 2]; obs[5] = s_qpos[2]; obs[6] = fr[UHC_FR_QPOS + 2] - s_qpos[2];
+            const double qv[3] = {qvel[0], qvel[1], qvel[2]};
+            rotT(v0, Rr, qv);
+            rotT(v1, Rc, v0);
+            for (int k = 0; k < 3; k++) obs[ov + k] = v1[k];
+            double rel_h = heading(trq) - heading(crq);
+            if (rel_h > M_PI) rel_h -= 2 * M_PI;
+            if (rel_h < -M_PI) rel_h += 2 * M_PI;
+            obs[oh] = rel_h;
+            for (int k = 0; k < 3; k++) rel[k] = trq[k] - s_qpos[k];
+            rotT(rl, Rc, rel);
+            obs[oh + 1] = rl[0]; obs[oh + 2] = rl[1];
+        }
+        for (int i = LANE + 3; i < nvh; i += WAVE) obs[ov + i] = qvel[i];
+        if (LANE < nb) {
+            const int b = LANE;
+            double d[3], r[3], cq[4], tb[4], o[4], ci[4];
+            // pose difference: current quaternion b (root: base rotation removed) inverted, times the target's
+            if (b == 0) { for (int k = 0; k < 4; k++) { cq[k] = crq[k]; tb[k] = trq[k]; } }
+            else { for (int k = 0; k < 4; k++) { cq[k] = s_qpos[3 + 4 * b + k]; tb[k] = fr[UHC_FR_BQUAT + 4 * b + k]; } }
+            qinv_batch(ci, cq);  // (the root quaternion is off the unit sphere by the rounded base rotation 0.7071: the two inverses differ at 1e-5)
+            qmul(o, ci, tb);
+            for (int k = 0; k < 4; k++) obs[oq + 4 * b + k] = o[k];
+            for (int k = 0; k < 3; k++) d[k] = xpos[3 * (b + 1) + k] - s_qpos[k];
+            rotT(r, Rc, d);
+            for (int k = 0; k < 3; k++) obs[oj + k * nb + b] = r[k];
+            for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
+            rotT(r, Rc, d);
+            for (int k = 0; k < 3; k++) obs[oj + 3 * nb + k * nb + b] = r[k];
+            const bool unset = xquat[4] == 0.0;
+            for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_WBQUAT + 4 * b + k]; cq[k] = unset ? tb[k] : xquat[4 * (b + 1) + k]; }
+            qmul(o, hqi, cq);
+            for (int k = 0; k < 4; k++) obs[oqw + 4 * b + k] = o[k];
+            qinv_batch(ci, cq);  // quaternion_inverse_batch(cur_quat)
+            qmul(o, ci, tb);
+            for (int k = 0; k < 4; k++) obs[oqw + 4 * nb + 4 * b + k] = o[k];
+        }
+        shape_base = oqw + 8 * nb;
     } else {
         // v5 (:505-594) = v2 without the leading heading quaternion, with the atan2 yaw, one velocity rotation and a real root offset
         const bool v5 = E.obs_v == 5;
@@ -328,7 +389,7 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_WBQUAT + 4 * b + k]; cq[k] = unset ? tb[k] : xquat[4 * (b + 1) + k]; }
             qmul(o, hqi, cq);
             for (int k = 0; k < 4; k++) obs[qb + 4 * b + k] = o[k];
-            qinv(ci, cq);
+            qinv_batch(ci, cq);  // quaternion_inverse_batch(cur_quat)
             qmul(o, ci, tb);
             for (int k = 0; k < 4; k++) obs[qb + 4 * nb + 4 * b + k] = o[k];
         }
@@ -363,8 +424,8 @@ __global__ void uhc_env_reset_stage_kernel(EnvArgs E, const int* env_ids, int n,
     // (torch_smpl_humanoid.py:202-207: qvel = cat(qvel[0:1], qvel)); the bank stores whole clips, so read frame 1
     const double* frv = fr + (E.e_len[env] > 1 ? UHC_FRAME_STRIDE : 0);
     for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
-        double v = fr[UHC_FR_QPOS + i];
-        if (noise && i >= 7) v += noise[(size_t)r * E.nu + (i - 7)];
+        double v = expert_qpos(fr, i, E.ball);
+        if (noise && i >= 7 && !E.ball) v += noise[(size_t)r * E.nu + (i - 7)];  // (the init noise is defined on joint angles)
         out_qpos[(size_t)r * E.nq + i] = v;
     }
     for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = frv[UHC_FR_QVEL + i];
@@ -441,8 +502,8 @@ __global__ void uhc_env_auto_stage_kernel(EnvArgs E, double* out_qpos, double* o
     const double* fr = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE;
     const double* frv = fr + (E.e_len[env] > 1 ? UHC_FRAME_STRIDE : 0);
     for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
-        double v = fr[UHC_FR_QPOS + i];
-        if (had && i >= 7) v += E.next_noise[(size_t)env * E.nu + (i - 7)];
+        double v = expert_qpos(fr, i, E.ball);
+        if (had && i >= 7 && !E.ball) v += E.next_noise[(size_t)env * E.nu + (i - 7)];
         out_qpos[(size_t)env * E.nq + i] = v;
     }
     for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)env * E.nv + i] = frv[UHC_FR_QVEL + i];

@@ -63,8 +63,11 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     void* stream;
     int* mask;
     uhc_internal_batch_info(b, &E.n_env, &E.nq, &E.nv, &E.nu, &E.nbody, &E.action_dim, &E.vf_dim, &E.dt, E.base_rot_inv, &stream, &mask);
-    if (E.nq != E.nv + 1 || E.nq > 128) { delete e; return uhc_internal_set_error("uhc_env_create: hinge humanoid (free root + scalar joints, nq <= 128) expected"); }
     const int nb = E.nbody - 1;
+    // ball-joint humanoid (robot.ball): free root + one ball joint per further body; nothing else in the model (no objects in the env layer)
+    E.ball = E.nq == 7 + 4 * (nb - 1) && E.nv == 6 + 3 * (nb - 1) && nb > 1 && E.nq != E.nv + 1;
+    if ((E.nq != E.nv + 1 && !E.ball) || E.nq > 128) { delete e; return uhc_internal_set_error("uhc_env_create: hinge humanoid (free root + scalar joints) or ball-joint humanoid (free root + one ball joint per body), nq <= 128, expected"); }
+    if (E.ball && (d->obs_v != 2 || d->reward_v != 0)) { delete e; return uhc_internal_set_error("uhc_env_create: the ball-joint env has observation v2 (get_full_obs_v2_quat) and reward 0 (world_rfc_implicit_quat)"); }
     E.has_shape = d->has_shape;
     E.obs_v = d->obs_v;
     E.reward_v = d->reward_v;
@@ -74,6 +77,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
         E.obs_dim = (d->obs_flags & 1) + (E.nq - 2) + ((d->obs_flags & 8) ? 6 : E.nv) + E.nu + ((d->obs_flags >> 2) & 1);
     else
         E.obs_dim = (d->obs_v == 6 ? 8 + E.nv + 2 * nb + 11 * (nb - 1) : (d->obs_v == 5 ? 300 : 304) + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
+    if (E.ball) E.obs_dim = 7 + 4 * nb + (E.nu + 6) + 3 + 6 * nb + 8 * nb + (d->has_shape ? 17 : 0);  // get_full_obs_v2_quat (:668-756)
     if (d->obs_v == 0) E.has_shape = 0;
     E.fut_frames = d->obs_v == 3 ? d->fut_frames : 1;
     E.fut_skip = d->obs_v == 3 ? d->fut_skip : 0;

@@ -40,8 +40,21 @@ class VecHumanoidEnv:
             from ..smpllib.smpl_robot import robot_variant
             model = robot_variant(S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh")), cfg.robot_cfg)
             shape_models = [robot_variant(m, cfg.robot_cfg) for m in (shape_models or [])]  # shapes of the asset: converted with it
-        if int(model.nq) != int(model.nv) + 1:
-            raise NotImplementedError("robot.ball: the quaternion observation / reward of the ball-joint env are not built (the physics is: sim.SimBatch)")
+        # robot.ball (config/copycat_ball): one ball joint per bone, nq = 99 -- `use_quat` in the reference (humanoid_im.py:52).  Gains, limits
+        # and the expert's forward kinematics are read off the hinge twin of the model (same bodies, same motor order).
+        self.use_quat = int(model.nq) != int(model.nv) + 1
+        self.hinge_model = None
+        if self.use_quat:
+            if int(model.nq) != 7 + 4 * (int(model.nbody) - 2) or int(model.nv) != 6 + 3 * (int(model.nbody) - 2):
+                raise NotImplementedError("the ball-joint env layer covers the humanoid alone (objects: physics only, sim.SimBatch)")
+            if cfg.action_type != "torque" or cfg.residual_force or cfg.meta_pd or cfg.meta_pd_joint:
+                raise NotImplementedError("robot.ball runs with action_type torque and no residual force / meta-PD (config/copycat_ball/*.yml); "
+                                          "the stable-PD controller is written for scalar joints")
+            if cfg.obs_v != 2 or cfg.reward_id not in ("world_rfc_implicit_quat", "world_rfc_implicit"):
+                raise NotImplementedError("robot.ball: obs_v 2 (get_full_obs_v2_quat) and reward world_rfc_implicit_quat are built")
+            from ..smpllib.smpl_robot import robot_variant
+            self.hinge_model = robot_variant(S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh")),
+                                             dict(cfg.robot_cfg, ball=False, self_collision=False, rel_joint_lm=False))
         self.model = model
         self.models = [self.model] + list(shape_models or [])
         iters = int(getattr(cfg, "pgs_iterations", 300))
@@ -49,8 +62,9 @@ class VecHumanoidEnv:
         self.model = self.models[0]
         self.base_rot = cfg.data_specs.get("base_rot", [0.7071, 0.7071, 0.0, 0.0])
         self.rfc_rate = 1 if not cfg.rfc_decay else 0
-        self.converter = SMPLConverter(self.model, self.model, smpl_model=cfg.robot_cfg.get("model", "smpl"))
-        self.ctrl = S.make_ctrl(self.model, meta_pd=cfg.meta_pd, meta_pd_joint=cfg.meta_pd_joint, residual_force=cfg.residual_force,
+        kin = self.hinge_model if self.use_quat else self.model
+        self.converter = SMPLConverter(kin, kin, smpl_model=cfg.robot_cfg.get("model", "smpl"))
+        self.ctrl = S.make_ctrl(kin, meta_pd=cfg.meta_pd, meta_pd_joint=cfg.meta_pd_joint, residual_force=cfg.residual_force,
                                 residual_force_mode=cfg.residual_force_mode, residual_force_scale=cfg.residual_force_scale,
                                 residual_force_lim=cfg.residual_force_lim, rfc_rate=self.rfc_rate, action_type=cfg.action_type,
                                 pd_mul=cfg.get("pd_mul", 1), tq_mul=cfg.get("tq_mul", 1), base_rot=self.base_rot,
@@ -82,7 +96,7 @@ class VecHumanoidEnv:
         self.action_dim = self.ctrl.action_dim
         self.obs_dim = self.env.obs_dim
         self.observation_space, self.action_space = _Box(self.obs_dim), _Box(self.action_dim)
-        self.humanoid = Humanoid(model=self.model)
+        self.humanoid = Humanoid(model=kin)
         self._humanoids = {0: self.humanoid}
         self.np_random = np.random.RandomState()
         self._end_reward = 0.0
@@ -93,11 +107,21 @@ class VecHumanoidEnv:
     def expert_features(self, sample, model_index=0):
         """load_expert's feature computation (humanoid_im.py:182-215): AMASS window -> qpos -> qpos_fk, on the clip's model."""
         m = self.models[model_index]
+        kin = self.hinge_model if self.use_quat else m  # (ball: body offsets of the hinge twin = the model's own)
         if model_index not in self._humanoids:
-            self._humanoids[model_index] = Humanoid(model=m)
-        qpos = smpl_to_qpose(pose=sample["pose_aa"], mj_model=m, trans=np.asarray(sample["trans"]).squeeze(),
-                             model=self.cc_cfg.robot_cfg.get("model", "smpl"), count_offset=self.cc_cfg.robot_cfg.get("mesh", True))
-        return self._humanoids[model_index].qpos_fk(torch.from_numpy(qpos))
+            self._humanoids[model_index] = Humanoid(model=kin)
+        kw = dict(pose=sample["pose_aa"], trans=np.asarray(sample["trans"]).squeeze(), model=self.cc_cfg.robot_cfg.get("model", "smpl"),
+                  count_offset=self.cc_cfg.robot_cfg.get("mesh", True))
+        feat = self._humanoids[model_index].qpos_fk(torch.from_numpy(smpl_to_qpose(mj_model=kin, **kw)))
+        if self.use_quat:
+            # load_expert computes the quaternion pose too (humanoid_im.py:193-200).  Its joint quaternions ARE the expert's local body
+            # quaternions (bquat); its root quaternion comes out of another conversion routine than the Euler pose's (1.5e-3 rad apart):
+            # the frame record carries it in the root slot of qpos, the joint angles behind it stay (unused by a torque-driven env)
+            feat["qpos_quat"] = smpl_to_qpose(mj_model=m, use_quat=True, **kw)
+            q = np.array(feat["qpos"], dtype=np.float64, copy=True)
+            q[:, 3:7] = feat["qpos_quat"][:, 3:7]
+            feat["qpos_record"] = q
+        return feat
 
     def set_clip_bank(self, clips: dict, clip_model: dict = None):
         """clips: {key: sample dict with pose_aa/trans/beta/gender of the WHOLE clip}.  Builds the HBM bank once.
@@ -108,7 +132,8 @@ class VecHumanoidEnv:
         cm = [int(clip_model[k]) if clip_model else 0 for k in self.clip_keys]
         for k, mi in zip(self.clip_keys, cm):
             c = clips[k]
-            fr = S.pack_expert_frames(self.expert_features(c, mi))
+            ft = self.expert_features(c, mi)
+            fr = S.pack_expert_frames(dict(ft, qpos=ft["qpos_record"]) if self.use_quat else ft)
             frames.append(fr)
             starts.append(n)
             lens.append(fr.shape[0])
@@ -158,7 +183,7 @@ class VecHumanoidEnv:
         """reset_model (humanoid_im.py:1245-1299) on the listed envs; returns the obs tensor view (n_env, obs_dim)."""
         ids = torch.arange(self.n_env, dtype=torch.int32) if env_ids is None else torch.as_tensor(env_ids, dtype=torch.int32)
         noise = None
-        if self.mode == "train" and self.cc_cfg.env_init_noise > 0:
+        if self.mode == "train" and self.cc_cfg.env_init_noise > 0 and not self.use_quat:  # (noise is defined on joint ANGLES, :1262-1266)
             noise = torch.from_numpy(self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof)))
         self.env.reset(ids, noise)
         return self.obs
@@ -170,7 +195,7 @@ class VecHumanoidEnv:
         fs = np.asarray(fr_start, dtype=np.int32)
         fl = np.asarray(self._window_len(fr_start, fr_end), dtype=np.int32)
         noise = None
-        if self.mode == "train" and self.cc_cfg.env_init_noise > 0:
+        if self.mode == "train" and self.cc_cfg.env_init_noise > 0 and not self.use_quat:
             noise = self.np_random.normal(loc=0.0, scale=self.cc_cfg.env_init_noise, size=(ids.shape[0], self.ndof))
         self.env.set_next_host(ids, cid, fs, fl, noise)  # one asynchronous copy: the sampling loop must not wait for the GPU here
 
@@ -362,6 +387,8 @@ class HumanoidEnv:
         """Root quaternion + one quaternion per body from its hinge triple, quaternion_from_euler(z, y, x, 'rzyx') (humanoid_im.py:925-947)."""
         from ..utils.transformation import quaternion_from_euler
         qpos = self.get_humanoid_qpos()
+        if self.vec.use_quat:  # :927-935: the ball joints' quaternions as they are
+            return qpos[3:7 + 4 * (self.model.nbody - 2)].copy()
         out = [qpos[3:7]]
         for b in range(2, self.model.nbody):
             a = 7 + 3 * (b - 2)

@@ -152,9 +152,10 @@ def smpl_to_qpose(pose, mj_model, trans=None, normalize=False, random_root=False
     """AMASS axis-angle pose (B,72) [+ trans (B,3)] -> qpos (B,76) of the hinge humanoid
     (reference: uhc/smpllib/smpl_mujoco.py:543-607).  Per joint: axis-angle -> rotation -> intrinsic
     ZYX Euler angles, reordered from SMPL joint order to the model's depth-first body order; the root
-    keeps a quaternion; the root position gets the model's root offset when count_offset."""
+    keeps a quaternion; the root position gets the model's root offset when count_offset.
+    use_quat (robot.ball): every joint as a (w, x, y, z) quaternion instead -> qpos (B, 99) of the ball-joint humanoid (:590-600)."""
     from scipy.spatial.transform import Rotation as sRot
-    if normalize or random_root or use_quat or model != "smpl":
+    if normalize or random_root or model != "smpl":
         raise NotImplementedError("only the options the copycat path uses are built (SURVEY.md 8f-4)")
     pose = np.asarray(pose, dtype=np.float64).reshape(-1, 72)
     B = pose.shape[0]
@@ -165,6 +166,12 @@ def smpl_to_qpose(pose, mj_model, trans=None, normalize=False, random_root=False
     names = SMPL_BONE_ORDER_NAMES
     smpl_2_mujoco = [names.index(q) for q in get_body_qposaddr(mj_model).keys() if q in names]
     rot = sRot.from_rotvec(pose.reshape(-1, 3))
+    if use_quat:
+        quat = rot.as_quat()[:, [3, 0, 1, 2]].reshape(B, 24, 4)[:, smpl_2_mujoco, :].reshape(B, 96)
+        qpos = np.concatenate((trans, quat), axis=1)
+        if count_offset:
+            qpos[:, :3] = trans + np.asarray(mj_model.body_pos)[1]
+        return qpos
     eul = rot.as_euler(euler_order, degrees=False).reshape(B, 24, 3)[:, smpl_2_mujoco, :].reshape(B, 72)
     root_quat = rotation_matrix_to_quaternion(rot.as_matrix().reshape(B, 24, 3, 3)[:, 0])
     qpos = np.concatenate((trans, root_quat, eul[:, 3:]), axis=1)

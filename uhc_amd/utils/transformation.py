@@ -40,7 +40,7 @@ def quaternion_inverse(q):
 def quaternion_inverse_batch(q):
     q = np.asarray(q, dtype=np.float64)
     c = q * np.array([1.0, -1.0, -1.0, -1.0])
-    return c / np.sum(q * q, axis=-1, keepdims=True)
+    return c / np.linalg.norm(q, axis=-1, keepdims=True)  # by the NORM, not its square (transformation.py:1532-1534): differs from quaternion_inverse off the unit sphere
 
 
 def quaternion_matrix(q):
