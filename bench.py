@@ -43,7 +43,7 @@ def pmc_traffic():
         if not files:
             return None, None
         for line in open(files[-1]):
-            if line.startswith("void uhc_step_kernel<0, true") and f"| {kind} |" in line:
+            if line.startswith(("void uhc_step_kernel<0, 1, false>", "void uhc_step_kernel<0, true")) and f"| {kind} |" in line:
                 tot += float(line.split("|")[2]) * 1024.0
                 src.append(os.path.basename(files[-1]))
                 break
@@ -81,7 +81,7 @@ def valu_f64_counters():
         return None
     c = {}
     for line in open(f):
-        if line.startswith("void uhc_step_kernel<0, true") and "|" in line:
+        if line.startswith(("void uhc_step_kernel<0, 1, false>", "void uhc_step_kernel<0, true")) and "|" in line:
             parts = [x.strip() for x in line.split("|")]
             c[parts[1]] = float(parts[2])
     need = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64")
@@ -203,7 +203,7 @@ def cpu_ppo_baseline(agent, batch):
             "ppo_sample": f"median of {len(ts)} full epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads (physical cores)"}
 
 
-def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None):
+def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None, cfg_over=None):
     """AgentCopycat on synthetic clips for the copycat rollout: `shapes` body shapes (configs[3]), `robot_cfg` overriding the config's
     robot block (None: config/uhc_amd/copycat_mi355x.yml = the floor-only static asset; {} keys of a reference config = the generated
     model class: body-body collisions on, rel_joint_lm ranges)."""
@@ -218,6 +218,9 @@ def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None):
     cfg.n_env = args.envs
     if robot_cfg is not None:
         cfg.robot_cfg = dict(robot_cfg)
+    for k, v in (cfg_over or {}).items():  # config keys of another reference config (e.g. copycat_ball_1.yml's controller block)
+        setattr(cfg, k, v)
+        cfg.cfg_dict[k] = v
     if args.pgs_iterations:
         cfg.pgs_iterations = args.pgs_iterations
     if args.solver is not None:
@@ -366,7 +369,7 @@ def bench_ball_objects(args):
             steps_done += 1
             if timed:
                 redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync
-                big_tot += ((sim.field(S.F_REDO) & 0x40) != 0).int()  # computed by the large tier (> 128 rows / 64 contacts / 16 body-body rows)
+                big_tot += ((sim.field(S.F_REDO) & 0x40) != 0).int()  # computed by the large tier (> 128 rows / 64 contacts / 20 body-body rows)
                 sweep_tot += ((sim.field(S.F_REDO) & 2) != 0).int()
                 r = sim.field(S.F_REDO)
                 for j in range(4):  # bits 2-5: why the working sets gave up (friction rows / > 64 candidates in one island / no convergence / unsolved set)
@@ -400,7 +403,7 @@ def bench_ball_objects(args):
            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, 2, true> (general tier)" if (args.general_only or redo_share > 0.6) else "uhc_step_kernel<0, 1, true> (fast tier)", "kernel_ms": ms / max(k, 1), "launches": k,
                         "achieved": 8 * (2 * m.nq + 3 * m.nv + ctrl.action_dim + 7 * m.nbody) * n_env / (ms / max(k, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "note": "HIP events around the first tier launched (the fast kernel, or the general tier when the adaptive path skips the fast one); envs beyond a "
-                                "tier's capacity (fast: 64 rows / 16 contacts / 12 body-body rows; general: 128 / 64 / 16) are redone by the next tier in a further launch, "
+                                "tier's capacity (fast: 64 rows / 16 contacts / 12 body-body rows; general: 128 / 64 / 20) are redone by the next tier in a further launch, "
                                 "which ms_per_step includes"},
            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()), "ncon_max": int(ncon.max()),
                               "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257])[0].tolist(),
@@ -529,6 +532,11 @@ def main():
                                                  "Chest / shoulder excludes, rel_joint_lm joint ranges; same clips, same policy", robot_cfg={"mesh": True, "model": "smpl"})
         probes["shapes"] = rollout_probe(args, local, dtype, "configs[3] smpl_shape: 64 body shapes (per-body length scales ~ U(0.85, 1.15), default_rng(7)), one model blob per clip "
                                          "(`--shapes 1023` runs 1024 of them)", shapes=63)
+        probes["ball_rollout"] = rollout_probe(args, local, dtype, "configs[4] env: config/copycat_ball/copycat_ball_1.yml's humanoid and controller -- ball joints (nq 99), "
+                                               "body-body collisions on, action_type torque (tq_mul 4), no residual force, reward world_rfc_implicit_quat, observation "
+                                               "get_full_obs_v2_quat (534) -- as a rollout through env + policy; same clips", robot_cfg={"mesh": True, "model": "smpl", "ball": True},
+                                               cfg_over=dict(action_type="torque", residual_force=False, meta_pd=False, meta_pd_joint=False, reward_id="world_rfc_implicit_quat",
+                                                             obs_v=2, tq_mul=4, env_init_noise=0.0))
         ba = argparse.Namespace(**vars(args))
         ba.steps, ba.warmup, ba.general_only, ba.fixed_path = 24, 12, False, False
         bo = bench_ball_objects(ba)
@@ -562,7 +570,7 @@ def main():
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
                                    "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "contact_solver": ("exact optimum of the dual QP: active set in registers (fast kernel), working sets of <= 64 rows in the general kernel for envs beyond its capacity" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, false, true>" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, true, false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, 2, true> (general tier)" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, 1, false> (fast tier, floor-only model)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),

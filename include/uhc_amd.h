@@ -116,7 +116,7 @@ enum UhcField {
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
     UHC_F_STAGE_PROF = 15,   /* int64 [n_env][40] per-stage shader-cycle counters (profiling builds only) */
     UHC_F_REDO = 16,         /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast tier's capacity (64 rows, 16 contacts, packed
-                              * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 16 body-body rows) or the
+                              * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 20 body-body rows) or the
                               * large one (256 / 128 / 32; bit 6), which solve the QP exactly too (working sets of <= 64 rows); bit 1: in at least one
                               * substep that solve fell back to solver 0 (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one
                               * island with 64 rows that carry a force and more that want in / no convergence of the working sets / a working set the
@@ -151,7 +151,7 @@ int32_t uhc_batch_sync(UhcBatch* b);
 int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
 
 /* Which kernel tier computes a step.  The fused step kernel exists in three tiers: fast (<= 64 constraint rows / 16 contacts / 12
- * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 16; working sets; two workgroups per CU) and large
+ * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 20; working sets; two workgroups per CU) and large
  * (<= 256 / 128 / 32; a whole CU's LDS).  A tier that cannot hold an env leaves it untouched and hands it to the next one; what exceeds
  * the large tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask MuJoCo for njmax 2500 / nconmax 500,
  * uhc/khrylib/mocap/skeleton_mesh.py:46).

@@ -406,6 +406,14 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (T.nM > 64 * 24) { delete b; return fail("uhc_batch_create: nM %d > 1536 (the register tile that carries M between substeps)", T.nM); }
     A.nvp = (nv + 1) & ~1;
     { const char* dbg = getenv("UHC_DEBUG"); A.dbg = dbg ? atoi(dbg) : 0; }
+    {   // sticky-tier marks: an env goes up a tier when it no longer fits (64 rows / 16 contacts / 12 body-body rows; the general tier's
+        // capacities) and comes down again at 56 / 14 / 10 and at 7/8 of the general tier's.  Going up EARLIER (at 3/4 of a capacity, so
+        // that no env finds out in mid-step) was measured on the self-colliding rollout: 51-55 k env-steps/s against 57 k -- the envs
+        // parked a tier up cost more than the late hand-ons they avoid (profiles/r03_marks_sweep.txt)
+        const int def[8] = {64, 16, 12, 56, 14, 10, 8, 7};
+        for (int k = 0; k < 8; k++) A.marks[k] = def[k];
+        if (const char* m = getenv("UHC_TIER_MARKS")) sscanf(m, "%d,%d,%d,%d,%d,%d,%d,%d", A.marks, A.marks + 1, A.marks + 2, A.marks + 3, A.marks + 4, A.marks + 5, A.marks + 6, A.marks + 7);
+    }
     int end1 = 0;
     auto common = [&](DevLds& F, bool fast) {  // persistent part + phase 1; returns the offset where phase 2 starts
         off = 0;
@@ -725,16 +733,16 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
                 if (b->h_counts[4 * (k % 8)] > 0) b->queues_off = true;  // a consumer gave up waiting: its producers do not run beside it here
                 break;
             }
-        // Three regimes.  No env in the general tier when last seen: no side launches, plain chain.  A minority there (<= a quarter of the
-        // batch): its launch is a CONSUMER that also waits for what the fast tier hands on while both run -- and is kept small enough that
+        // Three regimes.  No env in the general tier when last seen: no side launches, plain chain.  Up to three quarters of the batch
+        // there: its launch is a CONSUMER that also waits for what the fast tier hands on while both run -- and is kept small enough that
         // the fast tier's workgroups always find LDS beside it (a consumer that holds all LDS while it waits for a launch that cannot
         // start would only end by its time-out).  The majority there: the fast tier is the side show; the general tier's launch takes
         // its list at full width and does not wait, what the fast tier hands on goes through the chained launch.
         const bool queues = est2 > 0;
-        const bool waiting = queues && est2 <= b->n_env / 4 && !b->queues_off;
+        const bool waiting = queues && est2 <= (3 * b->n_env) / 4 && !b->queues_off;
         const bool q3 = queues && big;  // (a large-tier consumer waits beside the general tier's launch whenever there is one: what that hands on is rare and slow)
         // (a waiting consumer works through its queue during the fast tier's two rounds: half as many workgroups as envs leave the LDS to the fast tier)
-        const int grid2 = waiting ? std::min(est2 / 2 + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));
+        const int grid2 = waiting ? std::min(est2 / 2 + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));  // (320 x 79 KiB + 64 x 160 KiB leave a seventh of the LDS)
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
         if (queues) {
             HIP_OK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));

@@ -13,7 +13,7 @@
 #define UHC_FAST_MAXTWO 12
 #define UHC_GEN_MAXEFC 128   // two rows per lane, working sets of <= 64 rows
 #define UHC_GEN_MAXCON 64
-#define UHC_GEN_MAXTWO 16
+#define UHC_GEN_MAXTWO 20
 #define UHC_BIG_MAXEFC 256   // four rows per lane
 #define UHC_BIG_MAXCON 128
 #define UHC_BIG_MAXTWO 32
@@ -136,6 +136,7 @@ struct KernelArgs {
     int* q_next;          // hand-on target: the next tier's queue (NULL: flag the env in redo / redo2 for a chained launch)
     int* q_next_count;
     int grid;  // workgroups of a list launch (0: one per env)
+    int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)

@@ -2382,7 +2382,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
     FwdOut fo = {0, 0, 0, 0};
     int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
     bool ran = false, fits = true;  // fits (general / large tier): every substep of this step was within the fast kernel's capacity
-    bool fits_hyst = true, fits_gen = true;  // ... within it with room to spare (tier hysteresis); (large tier) within the general tier's
+    int pk_nefc = 0, pk_ncon = 0, pk_ntwo = 0, pk_y = 0;  // the step's peaks over its substeps: rows, contacts, body-body rows, packed Yhat entries (sticky tiers)
     PROF_DECL
     if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
         k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
@@ -2426,11 +2426,10 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             if (TIER != 1 && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
             if (TIER != 1) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= UHC_FAST_MAXCON &&
                               (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= UHC_FAST_MAXTWO);
-            if (TIER != 1) {
+            {
                 const int ntwo = (DENSE && cap_of<TIER>(A).ndense > 0) ? ((const int*)(S + L.ncon_nefc))[2] : 0;
-                fits_hyst = fits_hyst && fo.nefc <= UHC_WAVE - 8 && fo.ncon <= UHC_FAST_MAXCON - 2 && ntwo <= UHC_FAST_MAXTWO - 2;
-                if (TIER == 3) fits_gen = fits_gen && fo.nefc <= A.cg.maxefc - 16 && fo.ncon <= A.cg.maxcon - 8 && ntwo <= A.cg.ndense - 2 &&
-                                          ((const int*)(S + L.rowY))[fo.nefc] + 64 <= A.cg.ycap;
+                pk_nefc = max(pk_nefc, fo.nefc); pk_ncon = max(pk_ncon, fo.ncon); pk_ntwo = max(pk_ntwo, ntwo);
+                if (TIER != 1 && fo.nefc > 0) pk_y = max(pk_y, ((const int*)(S + L.rowY))[fo.nefc]);
             }
             ran = true;
             if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
@@ -2502,7 +2501,23 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         if (TIER == 2) A.s.pend2[env] = 0;  // taken: the chained launch of this tier has nothing left to do for the env
         if (TIER == 3) A.s.pend3[env] = 0;
         // where the env's next step starts (uhc_batch_set_kernel_path 2): an env comes down a tier only with room to spare
-        if (MODE == 0 && ran) A.s.tier[env] = TIER == 1 ? 1 : (TIER == 2 ? (fits_hyst ? 1 : 2) : (!fits_gen ? 3 : (fits_hyst ? 1 : 2)));
+        // An env that comes CLOSE to a tier's capacity starts its next step one tier up: finding out in the middle of a step that it no
+        // longer fits costs that tier's work so far, and the step then ends a whole general- (or large-) tier env-step after the moment
+        // of the hand-on -- with a thousand envs some env does that every step, and every step lasts fast + general + large.  It comes
+        // down again only well below the mark (hysteresis).  The marks are the batch's (KernelArgs::marks, UHC_TIER_MARKS).
+        if (MODE == 0 && ran) {
+            const int* mk = A.marks;  // up2: rows, contacts, body-body rows | dn1: the same | up3, dn2: eighths of the general tier's capacities
+            const bool up2 = pk_nefc > mk[0] || pk_ncon > mk[1] || pk_ntwo > mk[2];   // of 64 rows / 16 contacts / 12 body-body rows
+            const bool dn1 = pk_nefc <= mk[3] && pk_ncon <= mk[4] && pk_ntwo <= mk[5];
+            const bool up3 = pk_nefc > (mk[6] * A.cg.maxefc) / 8 || pk_ncon > (mk[6] * A.cg.maxcon) / 8 || pk_ntwo > (mk[6] * A.cg.ndense) / 8 || pk_y > (mk[6] * A.cg.ycap) / 8;
+            const bool dn2 = pk_nefc <= (mk[7] * A.cg.maxefc) / 8 && pk_ncon <= (mk[7] * A.cg.maxcon) / 8 && pk_ntwo <= (mk[7] * A.cg.ndense) / 8 && pk_y <= (mk[7] * A.cg.ycap) / 8;
+            const int big = A.last_tier == 3 ? 3 : 2;
+            int next;
+            if (TIER == 1) next = up2 ? 2 : 1;
+            else if (TIER == 2) next = (up3 && big == 3) ? 3 : (dn1 ? 1 : 2);
+            else next = !dn2 ? 3 : (dn1 ? 1 : 2);
+            A.s.tier[env] = next;
+        }
         if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | swept;
         if (TIER != 1 && MODE == 0) {
             atomicAdd(A.s.path_stats + 2, 1ull);

@@ -222,6 +222,7 @@ class Agent:
             self._seg_post()
         env.sim.use_current_stream()  # back from the capture stream
         R.graphs = (g_pre, g_post)
+        R.graph_gen = getattr(getattr(env, "env", None), "generation", 0)
 
     @torch.no_grad()
     def rollout_step(self):
@@ -232,6 +233,8 @@ class Agent:
             raise RuntimeError(f"rollout_step: the pass was begun for {R.T} steps")
         dev = env.device
         graphed = self.use_graph and dev.type == "cuda"
+        if graphed and R.graphs is not None and R.graph_gen != getattr(getattr(env, "env", None), "generation", 0):
+            R.graphs = None  # the clip bank / clip models were replaced: the captured env launches carry the old device pointers by value
         if graphed and R.graphs is None and R.t >= 2:  # two eager steps first: library handles, allocator pools and the filter's device state exist
             self._capture()
         if graphed and R.graphs is not None:
@@ -278,6 +281,8 @@ class Agent:
         self.sync_running_state()
         R.logger.add_steps(N, float(R.c_reward_sum.item()), R.c_info_sum.cpu().numpy())
         R.logger.end_sampling()
+        # Lifetime: `states` / `actions` / `masks` / `exps` are VIEWS of this pass length's buffers, which the next rollout_begin(T) of the
+        # same T overwrites in place (the captured graphs keep their addresses); a caller that keeps a batch across passes clones it.
         return RolloutBatch(R.states.reshape(N, -1), R.actions.reshape(N, -1), rewards.reshape(N, 1), R.masks.reshape(N, 1), R.exps.reshape(N), T), R.logger
 
     def sync_running_state(self):

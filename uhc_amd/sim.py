@@ -201,7 +201,11 @@ class EnvBatch:
         self._fields[f] = t
         return t
 
+    generation = 0  # bumped whenever a device pointer the env kernels take BY VALUE changes (clip bank, clip -> model map): HIP graphs that
+                    # captured env launches hold the old pointers and must be captured again (khrylib.rl.agents.Agent.rollout_step)
+
     def set_bank(self, frames: torch.Tensor, clip_start: torch.Tensor, clip_beta: torch.Tensor):
+        self.generation += 1
         frames = frames.to(self.device, torch.float64).contiguous()
         clip_start = clip_start.to(self.device, torch.int32).contiguous()
         clip_beta = clip_beta.to(self.device, torch.float64).contiguous()
@@ -211,6 +215,7 @@ class EnvBatch:
         self._bank = (frames, clip_start, clip_beta)  # keep alive: the library borrows the pointers
 
     def set_clip_models(self, clip_model: Optional[torch.Tensor]):
+        self.generation += 1
         """Which of the batch's models the episodes of each clip run on (per-clip body shape); None switches it off."""
         if clip_model is None:
             check(self.L.uhc_env_set_clip_models(self._e, None))
