@@ -123,8 +123,24 @@ def cpu_baseline(agent, n_env_gpu):
     import ctypes as C
     from oracle.physics import OracleSim, lib
     env = agent.env
-    # the threads this process may actually run on (a cgroup / affinity-limited lease sees fewer than os.cpu_count() reports)
+    # the threads this process may actually run on: the affinity mask, cut down to the cgroup's CPU quota where one is set (a lease of a
+    # few cores on a 256-thread host reports 256 CPUs either way; 256 OpenMP threads on an 8-core quota are throttled to a crawl)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2: "max 100000" or "<quota> <period>"
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1: -1 = unlimited
+            if q > 0:
+                quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    affinity = cores
+    if quota is not None:
+        cores = max(1, min(cores, int(quota + 0.5)))
     frames = env.env._bank[0].cpu().numpy()
     starts = env.env._bank[1].cpu().numpy()
     L = lib()
@@ -160,7 +176,7 @@ def cpu_baseline(agent, n_env_gpu):
     note = "" if eff is None or eff >= 0.5 else (f"; the all-thread run reaches only {eff:.2f} of {cores} x the one-thread rate: the lease's host threads are shared / SMT siblings, "
                                                  "so `value` understates a dedicated host")
     return {"value": vall, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1_thread": v1, "scaling_efficiency": eff,
-            "os_cpu_count": os.cpu_count(), "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
+            "os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "cgroup_cpu_quota": quota, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
             "sample": f"{na} envs x {sa} physics control steps (15 substeps, PD + RFC) of the same clips on {cores} OpenMP threads (sched_getaffinity), and {n1} envs x {s1} on one thread; "
                       f"oracle/physics_oracle.c; MuJoCo itself is not installed" + note}
 

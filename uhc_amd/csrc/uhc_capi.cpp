@@ -20,12 +20,13 @@
     extern "C" hipError_t fn##_lds(size_t lds_bytes);
 UHC_DECL_LAUNCH(uhc_launch_m0_fast) UHC_DECL_LAUNCH(uhc_launch_m0_fast_dense) UHC_DECL_LAUNCH(uhc_launch_m1_fast) UHC_DECL_LAUNCH(uhc_launch_m1_fast_dense)
 UHC_DECL_LAUNCH(uhc_launch_m2_fast) UHC_DECL_LAUNCH(uhc_launch_m0_gen) UHC_DECL_LAUNCH(uhc_launch_m1_gen) UHC_DECL_LAUNCH(uhc_launch_m2_gen)
-UHC_DECL_LAUNCH(uhc_launch_m0_big) UHC_DECL_LAUNCH(uhc_launch_m1_big)
+UHC_DECL_LAUNCH(uhc_launch_m0_big) UHC_DECL_LAUNCH(uhc_launch_m1_big) UHC_DECL_LAUNCH(uhc_launch_m0_gen_q) UHC_DECL_LAUNCH(uhc_launch_m0_big_q)
 // mode 0: control step, 1: forward only, 2: kinematics only; tier 1: the fast kernel, 2: general, 3: large; dense: the model has body-body contacts
 static hipError_t uhc_launch_step(int mode, int tier, const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active,
                                   size_t lds_bytes, hipStream_t stream) {
     const bool dense = A->cf.ndense > 0;
     const bool fast = tier == 1;
+    if (A->list) return (tier == 3 ? uhc_launch_m0_big_q : uhc_launch_m0_gen_q)(A, d_action, d_tbase, d_active, lds_bytes, stream);  // queue consumers (mode 0, tiers 2 / 3)
     if (tier == 3) return (mode == 0 ? uhc_launch_m0_big : uhc_launch_m1_big)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (!fast) return (mode == 0 ? uhc_launch_m0_gen : mode == 1 ? uhc_launch_m1_gen : uhc_launch_m2_gen)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (mode == 2) return uhc_launch_m2_fast(A, d_action, d_tbase, d_active, lds_bytes, stream);
@@ -34,7 +35,8 @@ static hipError_t uhc_launch_step(int mode, int tier, const KernelArgs* A, const
 }
 static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, size_t lds_bytes_big) {
     hipError_t e;
-    if (lds_bytes_big && ((e = uhc_launch_m0_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m1_big_lds(lds_bytes_big)) != hipSuccess)) return e;
+    if (lds_bytes_big && ((e = uhc_launch_m0_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m1_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m0_big_q_lds(lds_bytes_big)) != hipSuccess)) return e;
+    if ((e = uhc_launch_m0_gen_q_lds(lds_bytes)) != hipSuccess) return e;
     if ((e = uhc_launch_m0_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m1_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m2_gen_lds(lds_bytes)) != hipSuccess) return e;
     if ((e = uhc_launch_m0_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m0_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
     if ((e = uhc_launch_m1_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m1_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;

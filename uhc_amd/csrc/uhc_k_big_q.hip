@@ -1,0 +1,9 @@
+// uhc_k_big_q.hip -- one translation unit of the fused step kernel: the large tier as a persistent consumer of an env queue (sticky tiers).
+#include "uhc_physics_impl.h"
+
+extern "C" hipError_t uhc_launch_m0_big_q(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {
+    (void)d_active;
+    hipLaunchKernelGGL((uhc_step_queue_kernel<0, 3, true>), dim3(A->grid), dim3(UHC_WAVE), lds_bytes, stream, *A, d_action, d_tbase);
+    return hipGetLastError();
+}
+extern "C" hipError_t uhc_launch_m0_big_q_lds(size_t lds_bytes) { return hipFuncSetAttribute((const void*)uhc_step_queue_kernel<0, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }

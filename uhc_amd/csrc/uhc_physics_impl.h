@@ -2557,24 +2557,25 @@ __device__ __forceinline__ int queue_claim(const KernelArgs& A) {  // lane 0 onl
 template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
-    bool first = true;
-    for (;;) {  // (one call site of the step: the body is ~100 K instructions)
+    const int env = blockIdx.x;
+    bool go = env < A.n_env && !(d_active && !d_active[env]);
+    if (go && A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
+        const int t = A.s.tier_now[env];
+        go = t == A.tier_want || !((A.sticky_mask >> t) & 1);
+    }
+    if (go) uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+    if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer bookkeeping of the queues
+}
+// (2): its own entry point, so that the one-workgroup-per-env kernels keep the register allocation of a straight-line body
+template <int MODE, int TIER, bool DENSE>
+__global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, const double* __restrict__ d_action, const double* __restrict__ d_tbase) {
+    for (;;) {
         int env = -1;
-        if (A.list) {
-            if (LANE == 0) env = queue_claim(A);
-            env = __builtin_amdgcn_readfirstlane(env);
-        } else if (first) {
-            first = false;
-            env = blockIdx.x;
-            if (env >= A.n_env || (d_active && !d_active[env])) env = -1;
-            else if (A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
-                const int t = A.s.tier_now[env];
-                if (t != A.tier_want && ((A.sticky_mask >> t) & 1)) env = -1;
-            }
-        }
+        if (LANE == 0) env = queue_claim(A);
+        env = __builtin_amdgcn_readfirstlane(env);
         if (env < 0) break;
         uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
         wsync();
     }
-    if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer / consumer bookkeeping of the queues
+    if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // consumer bookkeeping (the next tier's consumers wait for it)
 }
