@@ -68,7 +68,9 @@ def contact_solve_share():
     share = 0.0
     for line in open(f):
         name = line.strip().split("  ")[0]
-        if name.startswith("as:") or name.startswith("pgs-sweeps"):
+        if line.startswith("slowest"):
+            break  # (the per-stage table of the slowest envs follows: ratios, not shares)
+        if (name.startswith("as:") or name.startswith("pgs-sweeps")) and line.rstrip().endswith("%"):
             share += float(line.strip().split()[-1].rstrip("%")) / 100.0
     return (share or None), os.path.basename(f)
 

@@ -52,3 +52,27 @@ def test_bench_defaults_are_the_drivers_contract():
     finally:
         sys.argv = argv
     assert (b.gpus, b.steps, b.warmup) == (8, 20, 5)
+
+
+def test_bench_reads_every_committed_profile():
+    """bench.py quotes two numbers from the committed profiles (contact-solve share of the stage profile, float64 VALU counters of the PMC
+    pass); whatever a measurement pass leaves under profiles/ must parse -- a profile format change may not break the bench line."""
+    import glob
+    import importlib.util
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_cli2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    share, src = bench.contact_solve_share()
+    assert src and 0.02 < share < 0.6
+    c = bench.valu_f64_counters()
+    assert c and c["flop_per_launch"] > 1e9
+    latest, bench._latest = bench._latest, None
+    try:  # ... and every older file of the same kinds, not only the latest
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_stage_profile.txt"))):
+            bench._latest = lambda pattern, f=f: f
+            s, _ = bench.contact_solve_share()
+            assert s is None or 0.02 < s < 0.6, f
+    finally:
+        bench._latest = latest

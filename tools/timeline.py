@@ -22,7 +22,7 @@ def main(db, out, nsteps=3):
             if cur:
                 steps.append(cur)
             cur = []
-        if "uhc_step_kernel" in name or "uhc_tier_lists" in name or "uhc_env_post" in name or "uhc_env_pre" in name:
+        if "uhc_step_kernel" in name or "uhc_step_queue_kernel" in name or "uhc_tier_lists" in name or "uhc_env_post" in name or "uhc_env_pre" in name:
             cur.append((name, s, e, g, lds))
     if cur:
         steps.append(cur)

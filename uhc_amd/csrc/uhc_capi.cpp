@@ -42,7 +42,9 @@ static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, siz
     if ((e = uhc_launch_m1_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m1_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
     return uhc_launch_m2_fast_lds(lds_bytes_fast);
 }
-extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin, hipStream_t stream);
+extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
+                                            const int* cost, const int* fresh, int* order, hipStream_t stream);
+extern "C" hipError_t uhc_launch_gate(const int* started, int want, int* waited, long long* trace, hipStream_t stream);
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream);
 
@@ -145,6 +147,9 @@ struct UhcBatch {
     hipStream_t side_stream = nullptr, side_stream3 = nullptr;  // kernel path 2: the general / large tiers' own envs run beside the fast tier's
     hipEvent_t ev_fork = nullptr, ev_side1 = nullptr, ev_side2 = nullptr;
     int* tier_now = nullptr;
+    int* d_order = nullptr;  // launch order of the fast tier under sticky tiers (uhc_tier_lists_kernel)
+    int q2_wait_min = 24;    // at least so many general-tier consumers wait for hand-ons (UHC_Q2_WAIT)
+    int q2_div = 1;          // waiting general-tier consumers per expected env: 1 / q2_div (UHC_Q2_DIV)
     int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr, *d_fin = nullptr;
     bool queues_off = false;
     int* h_counts = nullptr;  // pinned [8][4]: list sizes of the last steps, copied back asynchronously
@@ -458,7 +463,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.dense = carve(A.cf.ndense * A.nvp);
         F.dcol = carve(A.cf.ndense * UHC_WAVE);
         F.Y = off;
-        const int budget = T.ncpair > 0 ? (160 * 1024 / 3) / 8 : 40 * 1024 / 8;
+        // (52 KiB, not 160 / 3 = 53.3: the LDS is handed out in granules, and 54 608 B rounded up no longer fits three times -- the tier
+        //  trace showed 512 of 1 024 workgroups resident, two per CU; 52 KiB is a whole number of every granule up to 4 KiB)
+        const int budget = T.ncpair > 0 ? (52 * 1024) / 8 : 40 * 1024 / 8;
         int ycap = budget - off;
         const int need1 = end1 - off;  // phase 1 may need more than the constraint data
         if (ycap < need1) ycap = need1;
@@ -606,8 +613,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
     TRY(dalloc(b, 4, &S.path_stats));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 3 * E, &S.redo)); S.pend2 = S.redo + E; S.pend3 = S.redo + 2 * E; TRY(dalloc(b, 1, &S.q_abort));
-    TRY(dalloc(b, E, &S.tier)); TRY(dalloc(b, E, &b->tier_now)); S.tier_now = b->tier_now;
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 4 * E, &S.redo)); S.pend2 = S.redo + E; S.pend3 = S.redo + 2 * E; S.resume = S.redo + 3 * E; TRY(dalloc(b, 1, &S.q_abort));
+    TRY(dalloc(b, E, &S.tier)); TRY(dalloc(b, E, &b->tier_now)); S.tier_now = b->tier_now; TRY(dalloc(b, E, &S.cost));
+    if (!(A.dbg & 8)) TRY(dalloc(b, E, &b->d_order));  // (UHC_DEBUG bit 3: the fast tier launches in env order)
+    if (const char* q = getenv("UHC_Q2_DIV")) b->q2_div = std::max(1, atoi(q));
+    if (const char* q = getenv("UHC_Q2_WAIT")) b->q2_wait_min = std::max(1, atoi(q));
     TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 4, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
@@ -714,13 +724,13 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
     const bool general = b->general_only;
     const bool big = b->A.last_tier == 3;
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
-    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 3, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3: one allocation
+    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 4, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3, resume: one allocation
     if (mode == 0 && b->path_mode == 2 && b->use_fast && !general) {
         // sticky tiers: an env starts in the tier that computed its last step.  The general / large tiers' own envs run on a side stream
         // BESIDE the fast tier (their launches last several times longer per env; in a chain behind it the step would wait for them);
         // only the envs a tier hands on this very step go through the chain.  All launches filter on one snapshot of the tier table.
         KernelArgs K = b->A;
-        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->d_fin, b->stream));
+        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->d_fin, b->A.s.cost, b->A.s.fresh, b->d_order, b->stream));
         HIP_OK(hipEventRecord(b->ev_fork, b->stream));
         // how long the queues got is known on the host with a lag (asynchronous copies of the final counts, never waited for): the newest
         // copy that has landed sizes this step's consumer launches.  While the general tier's queue was empty when last seen there are no
@@ -732,6 +742,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         for (long long k = b->cnt_step - 1; k >= 0 && k > b->cnt_step - 8; k--)
             if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) {
                 est2 = b->h_counts[4 * (k % 8) + 2]; est3 = b->h_counts[4 * (k % 8) + 3];
+                if (b->A.dbg & 64) fprintf(stderr, "uhc step %lld: queues %d / %d envs, gate waited %.1f us, gave up %d, queues_off %d\n", k, est2, est3, 0.01 * b->h_counts[4 * (k % 8) + 1], b->h_counts[4 * (k % 8)], (int)b->queues_off);
                 if (b->h_counts[4 * (k % 8)] > 0) b->queues_off = true;  // a consumer gave up waiting: its producers do not run beside it here
                 break;
             }
@@ -743,15 +754,19 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         const bool queues = est2 > 0;
         const bool waiting = queues && est2 <= (3 * b->n_env) / 4 && !b->queues_off;
         const bool q3 = queues && big;  // (a large-tier consumer waits beside the general tier's launch whenever there is one: what that hands on is rare and slow)
-        // (a waiting consumer works through its queue during the fast tier's two rounds: half as many workgroups as envs leave the LDS to the fast tier)
-        const int grid2 = waiting ? std::min(est2 / 2 + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));  // (320 x 79 KiB + 64 x 160 KiB leave a seventh of the LDS)
+        // (one waiting consumer per env expected in the queue: its own envs are done within one general-tier env-step and the consumers are
+        //  free when the fast tier hands envs on.  Half as many -- more LDS for the fast tier, two envs in a row per consumer -- was
+        //  measured on the self-colliding rollout: 59 k env-steps/s against 66 k)
+        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));  // (320 x 79 KiB + 64 x 160 KiB leave a seventh of the LDS)
+        const int grid3 = std::min(est3 + est3 / 4 + 2, 64);  // (each holds a whole CU's LDS)
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
         if (queues) {
             HIP_OK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
             K.tier_want = 0; K.list = b->d_lists; K.list_count = b->d_counts + 2; K.list_cursor = b->d_cursors + 2;
             K.grid = grid2;
             K.prod_fin = waiting ? b->d_fin + 1 : nullptr; K.prod_total = b->n_env;  // every workgroup of the fast tier's launch below
-            K.fin = b->d_fin + 2;
+            K.fin = b->d_fin + 2; K.started = waiting ? b->d_fin + 3 : nullptr;
+            K.n_wait = std::max(b->q2_wait_min, est2 / 2); K.spares = b->d_fin;  // (the envs handed on in a step are a fraction of those that start it in the tier)
             K.q_next = q3 ? b->d_lists + b->n_env : nullptr; K.q_next_count = q3 ? b->d_counts + 3 : nullptr;
             HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, nullptr, b->lds_bytes, b->side_stream));
             HIP_OK(hipEventRecord(b->ev_side1, b->side_stream));
@@ -759,20 +774,26 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (q3) {
             HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
             K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
-            K.grid = std::min(est3 + est3 / 4 + 2, 64);  // (each holds a whole CU's LDS)
+            K.grid = grid3; K.n_wait = grid3; K.spares = nullptr;
             K.prod_fin = b->d_fin + 2; K.prod_total = grid2;  // the general tier's workgroups above: they never wait for this launch
             K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
             HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
             HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
         }
-        K.list = nullptr; K.list_count = nullptr; K.list_cursor = nullptr; K.grid = 0; K.prod_fin = nullptr; K.prod_total = 0;
+        K.list = nullptr; K.list_count = nullptr; K.list_cursor = nullptr; K.grid = 0; K.prod_fin = nullptr; K.prod_total = 0; K.started = nullptr; K.spares = nullptr;
+        // The fast tier's launch fills every CU's LDS the moment it starts; consumers that are not resident by then get theirs only when
+        // its first workgroups leave (the tier trace showed them starting 3.7 ms into the step).  A one-thread gate on this stream holds
+        // the launch back until every consumer workgroup has reported in (or 200 us have passed).
+        if (waiting && !(b->A.dbg & 32)) HIP_OK(uhc_launch_gate(b->d_fin + 3, grid2 + (q3 ? grid3 : 0), b->d_counts + 1,
+                                                                     (b->A.dbg & 16) ? b->A.s.prof + (size_t)(b->n_env - 1) * 40 + 16 : nullptr, b->stream));
         K.tier_want = 1;
+        K.order = b->d_order;  // (costliest envs first; null with UHC_DEBUG bit 3: env order)
         K.fin = waiting ? b->d_fin + 1 : nullptr;
         K.q_next = waiting ? b->d_lists : nullptr; K.q_next_count = waiting ? b->d_counts + 2 : nullptr;
         if (timed) HIP_OK(hipEventRecord(ev.first, b->stream));
         HIP_OK(uhc_launch_step(mode, 1, &K, d_action, d_tbase, d_active, b->lds_bytes_fast, b->stream));
         if (timed) { HIP_OK(hipEventRecord(ev.second, b->stream)); b->ev_used.push_back(ev); }
-        K.tier_want = 0; K.sticky_mask = 0; K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
+        K.tier_want = 0; K.sticky_mask = 0; K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr; K.order = nullptr;
         // chained launches on what is still flagged: everything handed on when no consumers run, nothing (two empty launches) when they do
         if (queues) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side1, 0));
         HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, b->A.s.pend2, b->lds_bytes, b->stream));

@@ -95,9 +95,11 @@ struct DevState {  // HBM, env-major
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     int *pend2, *pend3;  // envs handed on to the general / large tier this step and not yet taken (the chained launches' active masks)
+    int* resume;         // substep at which the tier below handed the env on (its state then is in qpos / qvel / qacc_ws / ctrl / applied); 0: from the start
     int* q_abort;  // consumers that gave up waiting for their producers (queue_claim)
     int* tier;   // per env: the tier that computed its last control step (minus hysteresis): where its next step starts (kernel path 2)
     const int* tier_now;  // snapshot of `tier` taken at the head of the step: what the tier filter of a launch reads
+    int* cost;   // per env: how close its last step came to the fast tier's capacity, in sixty-fourths (orders the fast tier's launch)
     int* fresh;  // 1: the env was restarted on the device (set_state done, kinematics refreshed); its mj_forward runs at the head of its next step
     const int* env_model;
     long long* prof;  // [n_env][16] stage cycle accumulators (only written by -DUHC_STAGE_PROF builds)
@@ -125,6 +127,7 @@ struct KernelArgs {
     DevLds lh;  // large tier: <= 160 KiB
     TierCap cf, cg, ch;
     int last_tier;  // 2 or 3: the tier that drops what exceeds it instead of handing the env on
+    const int* order;  // launch order: workgroup k works on env order[k] (null: env k)
     int tier_want;  // 0: the launch works on every active env; else (sticky tiers) it leaves out the envs whose tier_now differs AND has its own launch
     int sticky_mask;  // bit t: tier t has its own (list) launch this step
     int* list;        // != NULL: persistent launch over this env queue (list_count entries so far, shared cursor; slots beyond hold -1)
@@ -132,13 +135,16 @@ struct KernelArgs {
     int* list_cursor;
     const int* prod_fin;  // the queue's producers: exit only when this counter has reached prod_total (NULL: the queue does not grow)
     int prod_total;
+    int n_wait;           // queue consumers: so many workgroups that find the queue empty on entry stay and wait for the producers' hand-ons
+    int* spares;          // ... the seats taken so far (NULL: every such workgroup waits)
+    int* started;         // queue consumers: bumped once per workgroup on entry (the gate before the fast tier's launch waits for it), or NULL
     int* fin;             // this launch's own exit counter (bumped once per workgroup), or NULL
     int* q_next;          // hand-on target: the next tier's queue (NULL: flag the env in redo / redo2 for a chained launch)
     int* q_next_count;
     int grid;  // workgroups of a list launch (0: one per env)
     int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
-    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS
+    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     int adjdeg;              // stride of the per-model hull adjacency table (largest vertex degree over the batch's models)
     DevCtrl c;

@@ -62,17 +62,57 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
 // sticky tiers, head of a control step: snapshot of the tier table + the queues of the general / large tier, which start with the active
 // envs that begin the step there (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; free slots = -1),
 // the cursors the persistent launches share and the producers' exit counters (fin[1]: fast tier's workgroups, fin[2]: general tier's)
-__global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin) {
+#define UHC_ORDER_BUCKETS 6
+__global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
+                                      const int* cost, const int* fresh, int* order) {
+    __shared__ int nb[UHC_ORDER_BUCKETS + 1];
     if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; fin[threadIdx.x] = 0; }
+    if (threadIdx.x <= UHC_ORDER_BUCKETS) nb[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 2 * n_env; i += blockDim.x) lists[i] = -1;
     __syncthreads();
+    // the fast tier's launch order: its envs from the costliest bucket down (cost = how close the env's last step came to the tier's
+    // capacity, which is also what its step time grows with), then the envs that are not this launch's.  The launch does not fit the chip
+    // at once; whatever starts in its second round is then cheap and far from the capacity -- the envs that may still be handed on are
+    // handed on EARLY, while the consumers of the next tier have time left, and the launch's last workgroups are its shortest.
+    auto bucket = [&](int env) {
+        if (tier[env] != 1 || (d_active && !d_active[env])) return UHC_ORDER_BUCKETS;
+        // (an env restarted since its last step has no history: its reset pose may not fit the tier at all -- many do not -- and it is handed
+        //  on in its first forward pass; at the head of the launch that happens while the next tier's consumers still have the step ahead)
+        if (fresh[env]) return 0;
+        const int c = cost[env];  // 0 .. 64+ (sixty-fourths of the capacity)
+        return c >= 56 ? 0 : c >= 48 ? 1 : c >= 40 ? 2 : c >= 32 ? 3 : c >= 24 ? 4 : 5;
+    };
     for (int env = threadIdx.x; env < n_env; env += blockDim.x) {
         const int t = tier[env];
         tier_now[env] = t;
         if ((t == 2 || t == 3) && (!d_active || d_active[env])) lists[(t - 2) * n_env + atomicAdd(&counts[t], 1)] = env;
+        if (order) atomicAdd(&nb[bucket(env)], 1);
     }
+    if (!order) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k <= UHC_ORDER_BUCKETS; k++) { const int c = nb[k]; nb[k] = run; run += c; }
+    }
+    __syncthreads();
+    for (int env = threadIdx.x; env < n_env; env += blockDim.x) order[atomicAdd(&nb[bucket(env)], 1)] = env;
 }
-extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin, hipStream_t stream) {
-    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors, fin);
+extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
+                                            const int* cost, const int* fresh, int* order, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors, fin, cost, fresh, order);
+    return hipGetLastError();
+}
+
+// Holds a stream until `want` consumer workgroups have started (their LDS is then theirs), or 200 us have passed: what follows on the
+// stream -- the fast tier's launch -- would otherwise take every CU's LDS first.  waited: 100 MHz ticks spent here (diagnostic).
+__global__ void uhc_gate_kernel(const int* started, int want, int* waited, long long* trace) {
+    const unsigned long long t0 = wall_clock64();
+    const int s0 = __hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < 20000ull) __builtin_amdgcn_s_sleep(16);
+    if (waited) *waited = (int)(wall_clock64() - t0);
+    if (trace) { trace[0] = (long long)t0; trace[1] = (long long)wall_clock64(); trace[2] = s0; trace[3] = __hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); trace[4] = want; }
+}
+extern "C" hipError_t uhc_launch_gate(const int* started, int want, int* waited, long long* trace, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_gate_kernel, dim3(1), dim3(1), 0, stream, started, want, waited, trace);
     return hipGetLastError();
 }

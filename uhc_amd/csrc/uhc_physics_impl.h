@@ -18,8 +18,8 @@ extern __shared__ __attribute__((aligned(16))) double smem[];
 
 #define LANE ((int)threadIdx.x)
 // optional per-stage cycle accounting (build with -DUHC_STAGE_PROF; see tools/stage_profile.py)
+#define UHC_NPROF 40  // int64 words per env of the stage-profile record (UHC_F_STAGE_PROF)
 #ifdef UHC_STAGE_PROF
-#define UHC_NPROF 40
 #define PROF_DECL long long pt_[UHC_NPROF] = {}; long long pt_last_ = __builtin_readcyclecounter();
 #define PROF_ARGS , long long* pt_, long long& pt_last_
 #define PROF_PASS , pt_, pt_last_
@@ -536,6 +536,49 @@ __device__ __forceinline__ void solve_sweep(const unsigned int* tab, const char*
         }
     }
 }
+// The same sweep for NR right-hand sides at once: the L entries are read once, and the NR serial chains (readlane -> FMA) interleave --
+// the sweep is latency-bound, so four right-hand sides cost little more than one (the dense rows of a contact pyramid go through together).
+template <bool BACK, int NR>
+__device__ __forceinline__ void solve_sweep_n(const unsigned int* tab, const char* SB, int n, DofVec (&x)[NR]) {
+    constexpr int U = 8;
+    const int np = (n + U - 1) & ~(U - 1);
+    unsigned int wn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) wn[u] = tab[(size_t)u * UHC_WAVE];
+    for (int s0 = 0; s0 < np; s0 += U) {
+        double l0[U], l1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned int ww = wn[u];
+            wn[u] = tab[(size_t)(s0 + U + u) * UHC_WAVE];
+            l0[u] = lds_at(SB, ww & 0xffffu);
+            l1[u] = lds_at(SB, ww >> 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (BACK ? n - s0 < UHC_WAVE : s0 + U <= UHC_WAVE) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const double xs = bcast(x[j].a, BACK ? max(n - s0 - u, 0) : s0 + u);
+                    x[j].a = fma(-l0[u], xs, x[j].a);
+                    x[j].b = fma(-l1[u], xs, x[j].b);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u;
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const double xs = dv_get_nb(x[j], BACK ? max(n - s, 0) : s);
+                    x[j].a = fma(-l0[u], xs, x[j].a);
+                    x[j].b = fma(-l1[u], xs, x[j].b);
+                }
+            }
+        }
+    }
+}
 template <int TIER>
 __device__ __forceinline__ void k_solve(const KernelArgs& A, const double* S, int ld, DofVec& x, int half, const LaneConst& LC) {
     const DevTopo& T = A.t;
@@ -1025,48 +1068,64 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
 // cancel exactly), the back substitution is the register-resident sweep of k_solve.  Returns the row's
 // J.qvel, J.qacc_smooth, J.qacc_warmstart and |Yhat|^2 (wave-uniform).
 struct DenseOut { double vel, jas, jaw, yy; };
+#define UHC_DENSE_GROUP 4  // dense rows per back substitution (a contact pyramid)
+// rows[j] < 0: no row in position j of the group.  The rows' Yhat go to the dense slots slot0 + j.
 template <int TIER>
-__device__ __forceinline__ DenseOut k_dense_row(const KernelArgs& A, double* S, int r, int slot, const LaneConst& LC) {
+__device__ __forceinline__ void k_dense_rows(const KernelArgs& A, double* S, const int (&rows)[UHC_DENSE_GROUP], int slot0, const LaneConst& LC,
+                                             DenseOut (&o)[UHC_DENSE_GROUP]) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
-    const RowMisc rm = ((const RowMisc*)(S + L.rowMisc))[r];
-    const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
-    const int l1 = T.body_lastdof[(int)C[19]], l2 = T.body_lastdof[(int)C[20]];
-    double dv[3];
-    if (RTYPE(rm.type) == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
-    else {
-        const double sgn = (rm.edge & 1) ? -1.0 : 1.0, mu = C[14];
-        const int td = 1 + rm.edge / 2;
-        for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
-    }
-    DofVec x = {0.0, 0.0};
+    DofVec x[UHC_DENSE_GROUP];
     double qv[2] = {0, 0}, qs[2] = {0, 0}, qw[2] = {0, 0};
     for (int h = 0; h < 2; h++) {
-        const int i = LANE + h * UHC_WAVE, nd = h ? LC.n1 : LC.n0, root = h ? LC.r1 : LC.r0;
+        const int i = LANE + h * UHC_WAVE;
         if (!(h ? LC.v1 : LC.v0)) continue;
-        const int sg = (int)(i <= l2 && l2 <= i + nd) - (int)(i <= l1 && l1 <= i + nd);
-        double j = 0.0;
-        if (sg != 0) {
-            double cd[6], off[3], cr[3];
-            for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
-            for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
-            cross3(cr, cd, off);
-            j = (double)sg * (dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]));
-        }
-        if (h) x.b = j; else x.a = j;
         qv[h] = S[L.qvel + i]; qs[h] = S[L.smooth + i]; qw[h] = S[L.qacc + i];
     }
-    DenseOut o;
-    o.vel = wave_sum(x.a * qv[0] + x.b * qv[1]);
-    o.jas = wave_sum(x.a * qs[0] + x.b * qs[1]);
-    o.jaw = wave_sum(x.a * qw[0] + x.b * qw[1]);
-    if (T.nv >= 2) solve_sweep<true>(T.sol_back + LANE, (const char*)S + cap_of<TIER>(A).ld_delta, T.nv - 1, x);  // x <- L^-T x
-    double* D = S + L.dense + slot * A.nvp;
-    double y0 = 0.0, y1 = 0.0;
-    if (LC.v0) { y0 = x.a * S[L.sdinv + LANE]; D[LANE] = y0; }
-    if (LC.v1) { y1 = x.b * S[L.sdinv + LANE + UHC_WAVE]; D[LANE + UHC_WAVE] = y1; }
-    o.yy = wave_sum(y0 * y0 + y1 * y1);
-    return o;
+#pragma unroll
+    for (int j = 0; j < UHC_DENSE_GROUP; j++) {
+        x[j].a = 0.0; x[j].b = 0.0;
+        o[j].vel = o[j].jas = o[j].jaw = o[j].yy = 0.0;
+        if (rows[j] < 0) continue;  // (wave-uniform)
+        const RowMisc rm = ((const RowMisc*)(S + L.rowMisc))[rows[j]];
+        const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
+        const int l1 = T.body_lastdof[(int)C[19]], l2 = T.body_lastdof[(int)C[20]];
+        double dv[3];
+        if (RTYPE(rm.type) == ROW_CONTACT) for (int k = 0; k < 3; k++) dv[k] = C[3 + k];
+        else {
+            const double sgn = (rm.edge & 1) ? -1.0 : 1.0, mu = C[14];
+            const int td = 1 + rm.edge / 2;
+            for (int k = 0; k < 3; k++) dv[k] = C[3 + k] + sgn * mu * C[3 + 3 * td + k];
+        }
+        for (int h = 0; h < 2; h++) {
+            const int i = LANE + h * UHC_WAVE, nd = h ? LC.n1 : LC.n0, root = h ? LC.r1 : LC.r0;
+            if (!(h ? LC.v1 : LC.v0)) continue;
+            const int sg = (int)(i <= l2 && l2 <= i + nd) - (int)(i <= l1 && l1 <= i + nd);
+            double jv = 0.0;
+            if (sg != 0) {
+                double cd[6], off[3], cr[3];
+                for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
+                for (int k = 0; k < 3; k++) off[k] = C[k] - S[L.rootcom + 3 * root + k];
+                cross3(cr, cd, off);
+                jv = (double)sg * (dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]));
+            }
+            if (h) x[j].b = jv; else x[j].a = jv;
+        }
+        o[j].vel = wave_sum(x[j].a * qv[0] + x[j].b * qv[1]);
+        o[j].jas = wave_sum(x[j].a * qs[0] + x[j].b * qs[1]);
+        o[j].jaw = wave_sum(x[j].a * qw[0] + x[j].b * qw[1]);
+    }
+    if (T.nv >= 2) solve_sweep_n<true, UHC_DENSE_GROUP>(T.sol_back + LANE, (const char*)S + cap_of<TIER>(A).ld_delta, T.nv - 1, x);  // x <- L^-T x
+    const double sd0 = LC.v0 ? S[L.sdinv + LANE] : 0.0, sd1 = LC.v1 ? S[L.sdinv + LANE + UHC_WAVE] : 0.0;
+#pragma unroll
+    for (int j = 0; j < UHC_DENSE_GROUP; j++) {
+        if (rows[j] < 0) continue;
+        double* D = S + L.dense + (slot0 + j) * A.nvp;
+        const double y0 = x[j].a * sd0, y1 = x[j].b * sd1;
+        if (LC.v0) D[LANE] = y0;
+        if (LC.v1) D[LANE + UHC_WAVE] = y1;
+        o[j].yy = wave_sum(y0 * y0 + y1 * y1);
+    }
 }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
@@ -1105,9 +1164,15 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
     if (ytot + 8 > cap_of<TIER>(A).ycap) return 1;
     if (LANE == 0) RY[nefc] = ytot;  // (so that a row's length is RY[r + 1] - RY[r])
     const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
-    for (int k = 0; k < ntwo; k++) {  // dense rows first (wave-cooperative); their scalars wait in dcol for the lane that owns the row
-        const DenseOut o = k_dense_row<TIER>(A, S, NI[4 + k], k, LC);
-        if (LANE == 0) { S[L.dsc + 4 * k] = o.vel; S[L.dsc + 4 * k + 1] = o.jas; S[L.dsc + 4 * k + 2] = o.jaw; S[L.dsc + 4 * k + 3] = o.yy; }
+    for (int k0 = 0; k0 < ntwo; k0 += UHC_DENSE_GROUP) {  // dense rows first (wave-cooperative); their scalars wait in dsc for the lane that owns the row
+        int rr[UHC_DENSE_GROUP];
+#pragma unroll
+        for (int j = 0; j < UHC_DENSE_GROUP; j++) rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
+        DenseOut o[UHC_DENSE_GROUP];
+        k_dense_rows<TIER>(A, S, rr, k0, LC, o);
+#pragma unroll
+        for (int j = 0; j < UHC_DENSE_GROUP; j++)
+            if (rr[j] >= 0 && LANE == 0) { const int k = k0 + j; S[L.dsc + 4 * k] = o[j].vel; S[L.dsc + 4 * k + 1] = o[j].jas; S[L.dsc + 4 * k + 2] = o[j].jaw; S[L.dsc + 4 * k + 3] = o[j].yy; }
     }
     wsync();
     for (int r = LANE; r < nefc; r += UHC_WAVE) {
@@ -1418,11 +1483,17 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     if constexpr (DENSE) {  // dense rows: wave-cooperative (lane = dof), their scalars go to the lane that owns the row
         const int* NI = (const int*)(S + L.ncon_nefc);
         const int ntwo = NI[2];
-        for (int k = 0; k < ntwo; k++) {
-            const int rr = __builtin_amdgcn_readfirstlane(NI[4 + k]);
-            if (rr >= nefc) break;  // dropped by the truncation above
-            const DenseOut o = k_dense_row<1>(A, S, rr, k, LC);
-            if (LANE == rr) { vel = o.vel; jas = o.jas; jaw = o.jaw; }
+        for (int k0 = 0; k0 < ntwo; k0 += UHC_DENSE_GROUP) {
+            int rr[UHC_DENSE_GROUP];
+#pragma unroll
+            for (int j = 0; j < UHC_DENSE_GROUP; j++) {
+                rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
+                if (rr[j] >= nefc) rr[j] = -1;  // dropped by the truncation above
+            }
+            DenseOut o[UHC_DENSE_GROUP];
+            k_dense_rows<1>(A, S, rr, k0, LC, o);
+#pragma unroll
+            for (int j = 0; j < UHC_DENSE_GROUP; j++) if (LANE == rr[j]) { vel = o[j].vel; jas = o[j].jas; jaw = o[j].jaw; }
         }
     }
     // chain positions in groups of four: one uniform test per group (a branch costs 25-60 cycles here) and the LDS reads of four
@@ -2337,8 +2408,21 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
     wsync();
 #endif
     const double* mb = A.s.model_blob + (size_t)(A.s.env_model ? A.s.env_model[env] : 0) * A.o.stride;
+    // tier trace (UHC_DEBUG bit 4, product builds; tools/tier_trace.py): when each tier took the env up and let it go (100 MHz wall clock)
+    // and the substep of a hand-on, in the first words of the env's stage-profile record
+#ifndef UHC_STAGE_PROF
+#define TRACE(slot, v) if (MODE == 0 && (A.dbg & 16) && LANE == 0) A.s.prof[(size_t)env * UHC_NPROF + (slot)] = (long long)(v);
+#else
+#define TRACE(slot, v)
+#endif
+    TRACE(2 * (TIER - 1), wall_clock64())
     int fail = MODE == 0 ? A.s.fail[env] : 0;
-    const bool fresh = MODE == 0 && A.s.fresh[env] != 0;  // restarted by uhc_env_auto_reset: sim.forward() of the reset is still due
+    // A tier that finds an env too big in substep k >= 1 hands it on WITH the substeps it has done: the state at the start of substep k
+    // (qpos, qvel, warm start) and that substep's controls (ctrl, applied: PD torque and residual force are already computed) are in
+    // the state arrays, and this tier goes on from substep k instead of repeating the step -- the work below is not lost, and the step
+    // ends (15 - k) / 15 of an env-step after the hand-on instead of a whole one.
+    const int res = (MODE == 0 && TIER != 1) ? A.s.resume[env] : 0;
+    const bool fresh = MODE == 0 && res == 0 && A.s.fresh[env] != 0;  // restarted by uhc_env_auto_reset: sim.forward() of the reset is still due
     // ---- load state (coalesced: consecutive lanes, consecutive doubles)
     for (int i = LANE; i < T.nq; i += UHC_WAVE) S[L.qpos + i] = A.s.qpos[(size_t)env * T.nq + i];
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
@@ -2380,6 +2464,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
     }
     wsync();
     FwdOut fo = {0, 0, 0, 0};
+    int it = 0;
     int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
     bool ran = false, fits = true;  // fits (general / large tier): every substep of this step was within the fast kernel's capacity
     int pk_nefc = 0, pk_ncon = 0, pk_ntwo = 0, pk_y = 0;  // the step's peaks over its substeps: rows, contacts, body-body rows, packed Yhat entries (sticky tiers)
@@ -2402,9 +2487,10 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         const double* tbase = d_tbase + (size_t)env * T.nu;
         // a freshly restarted env first runs the forward pass of its reset (it = -1: no control, no integration), through the
         // same inlined k_forward as the substeps
-        for (int it = fresh ? -1 : 0; it < A.c.n_substeps; it++) {
+        for (it = fresh ? -1 : res; it < A.c.n_substeps; it++) {
             int b = 0;
             if (it >= 0) {
+            if (!(res > 0 && it == res)) {  // (the controls of the substep an env was handed on in came with it)
             if (A.c.action_type == 0) k_pd_torque<TIER>(A, S, action, tbase, it, MP, LC PROF_PASS);
             else {
                 for (int a = LANE; a < T.nu; a += UHC_WAVE)
@@ -2413,6 +2499,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             }
             if (A.c.rfc_mode == 1) k_rfc_implicit<TIER>(A, S, action);
             else if (A.c.rfc_mode == 2) k_rfc_explicit<TIER>(A, S, action);
+            }
             // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
@@ -2446,7 +2533,19 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             PROF(14)
         }
     }
-    if (overflow & 1) {  // nothing committed: the next tier redoes this env from the same inputs
+    if (overflow & 1) {  // nothing committed: the next tier takes the env over -- from the substep that did not fit, or from the same inputs
+        if (MODE == 0 && it >= 1 && it > res && !(A.dbg & 4)) {  // (UHC_DEBUG bit 2: hand on from the start of the step, for A/B measurements)
+            for (int i = LANE; i < T.nq; i += UHC_WAVE) A.s.qpos[(size_t)env * T.nq + i] = S[L.qpos + i];
+            for (int i = LANE; i < T.nv; i += UHC_WAVE) {
+                A.s.qvel[(size_t)env * T.nv + i] = S[L.qvel + i];
+                A.s.qacc_ws[(size_t)env * T.nv + i] = S[L.qacc + i];
+                A.s.applied[(size_t)env * T.nv + i] = S[L.applied + i];
+            }
+            for (int i = LANE; i < T.nu; i += UHC_WAVE) A.s.ctrl[(size_t)env * T.nu + i] = S[L.ctrl + i];
+            if (LANE == 0) A.s.resume[env] = it;
+            TRACE(5 + TIER, it)
+            __threadfence();  // (the queue append below publishes the env: its state must be visible first)
+        }
         if (LANE == 0) {
             if (A.q_next) {  // the next tier's consumers are running beside this launch: straight into their queue
                 const int k = atomicAdd(A.q_next_count, 1);
@@ -2456,6 +2555,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             if (TIER == 1) A.s.pend2[env] = 1; else { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
             if (TIER == 1 && MODE == 0) atomicAdd(A.s.path_stats, 1ull);
         }
+        TRACE(2 * (TIER - 1) + 1, wall_clock64())
         return;
     }
     // ---- store state
@@ -2493,6 +2593,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         if (LANE < UHC_NPROF) A.s.prof[(size_t)env * UHC_NPROF + LANE] += mine;
     }
 #endif
+    TRACE(2 * (TIER - 1) + 1, wall_clock64())
     if (LANE == 0) {
         if (ran) { A.s.ncon[env] = fo.ncon; A.s.nefc[env] = fo.nefc; A.s.solver_iter[env] = fo.iters; }
         A.s.fail[env] = fail;
@@ -2517,6 +2618,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             else if (TIER == 2) next = (up3 && big == 3) ? 3 : (dn1 ? 1 : 2);
             else next = !dn2 ? 3 : (dn1 ? 1 : 2);
             A.s.tier[env] = next;
+            A.s.cost[env] = max(pk_nefc, max(pk_ncon * (UHC_FAST_MAXEFC / UHC_FAST_MAXCON), (pk_ntwo * UHC_FAST_MAXEFC) / UHC_FAST_MAXTWO));
         }
         if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | swept;
         if (TIER != 1 && MODE == 0) {
@@ -2534,7 +2636,13 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
 // get: an underestimate costs time, never an env -- and no workgroup is started (and has to be given its 79 / 160 KiB of LDS) only to
 // find that its env belongs to another tier.  A handed-on env is picked up a fraction of a step after the fast tier found it too big,
 // instead of after the fast tier's whole launch.
-__device__ __forceinline__ int queue_claim(const KernelArgs& A) {  // lane 0 only
+// Not every consumer WAITS when the queue is empty.  A workgroup that found an env when it came in is a WORKER: it works the queue off
+// and leaves when there is nothing left -- its 79 KiB go back to the launch beside it, whose second round can use them.  A workgroup
+// that found the queue empty when it came in (the host sizes the launch for the envs the step begins with PLUS the hand-ons it expects)
+// is a SPARE: it takes one of n_wait seats and waits for the producers' hand-ons until they have all finished; with no seat left it
+// leaves too (with one consumer per expected env and all of them waiting, an overestimate starved the fast tier to the point that the
+// idle consumers ran into their time-out).
+__device__ __forceinline__ int queue_claim(const KernelArgs& A, int& role) {  // lane 0 only; role: 0 undecided, 1 worker, 2 spare
     const unsigned long long t0 = wall_clock64();  // 100 MHz
     for (;;) {
         const int f = A.prod_fin ? __hip_atomic_load(A.prod_fin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -2544,9 +2652,14 @@ __device__ __forceinline__ int queue_claim(const KernelArgs& A) {  // lane 0 onl
             if (atomicCAS(A.list_cursor, cur, cur + 1) != cur) continue;
             int env;  // (the producer bumps the count before it fills the slot: slots start at -1)
             while ((env = __hip_atomic_load(A.list + cur, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(8);
+            if (role == 0) role = 1;
             return env;
         }
-        if (!A.prod_fin || f >= A.prod_total) return -1;  // (f was read before the count: every append of a finished producer was seen)
+        if (!A.prod_fin || role == 1 || f >= A.prod_total) return -1;  // (f was read before the count: every append of a finished producer was seen)
+        if (role == 0) {
+            if (A.spares && atomicAdd(A.spares, 1) >= A.n_wait) return -1;
+            role = 2;
+        }
         // Never wait for ever: if the producers' launch cannot run beside this one (streams that share a hardware queue run in order) the
         // wait would not end.  After 50 ms with nothing to do the consumer leaves; what is handed on later stays flagged for the chained
         // launches, and the host stops starting consumers when it sees the count (DevState::q_abort).
@@ -2557,7 +2670,7 @@ __device__ __forceinline__ int queue_claim(const KernelArgs& A) {  // lane 0 onl
 template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
-    const int env = blockIdx.x;
+    const int env = (A.order && (int)blockIdx.x < A.n_env) ? A.order[blockIdx.x] : (int)blockIdx.x;
     bool go = env < A.n_env && !(d_active && !d_active[env]);
     if (go && A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
         const int t = A.s.tier_now[env];
@@ -2569,13 +2682,21 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
 // (2): its own entry point, so that the one-workgroup-per-env kernels keep the register allocation of a straight-line body
 template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, const double* __restrict__ d_action, const double* __restrict__ d_tbase) {
+    if (A.started && LANE == 0) atomicAdd(A.started, 1);  // resident: holds its LDS from here on
+    // (tier trace, UHC_DEBUG bit 4: the consumer's own record -- entry, first env claimed, exit, envs processed -- in words 8 .. 11 (general
+    //  tier) / 12 .. 15 (large tier) of the stage-profile record of env blockIdx.x)
+    long long* tr = ((A.dbg & 16) && (int)blockIdx.x < A.n_env) ? A.s.prof + (size_t)blockIdx.x * UHC_NPROF + 8 + 4 * (TIER - 2) : nullptr;
+    if (tr && LANE == 0) { tr[0] = (long long)wall_clock64(); tr[1] = 0; tr[3] = 0; }
+    int role = 0;
     for (;;) {
         int env = -1;
-        if (LANE == 0) env = queue_claim(A);
+        if (LANE == 0) env = queue_claim(A, role);
         env = __builtin_amdgcn_readfirstlane(env);
         if (env < 0) break;
+        if (tr && LANE == 0) { if (tr[1] == 0) tr[1] = (long long)wall_clock64(); tr[3]++; }
         uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
         wsync();
     }
+    if (tr && LANE == 0) tr[2] = (long long)wall_clock64();
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // consumer bookkeeping (the next tier's consumers wait for it)
 }
