@@ -377,13 +377,18 @@ def bench_ball_objects(args):
     gen = torch.Generator(device="cuda").manual_seed(11)
     acts = 0.1 * torch.randn(16, n_env, ctrl.action_dim, dtype=torch.float64, device="cuda", generator=gen)  # init-policy noise (log_std -2.3): torques ~ N(0, 10 N m)
     hist_nefc, hist_ncon, redo_tot, steps_done = [], [], 0, 0
+    hooks = getattr(args, "hooks", None)  # (tools/tier_trace.py: called around chosen control steps)
 
     def run(k, timed):
         nonlocal redo_tot, sweep_tot, big_tot, steps_done
         for i in range(k):
             if steps_done % 30 == 0:
                 sim.set_state(q0d, v0d)
+            if hooks and timed:
+                hooks[0](sim, i)
             sim.simulate(acts[steps_done % 16], tb)
+            if hooks and timed:
+                hooks[1](sim, i)
             steps_done += 1
             if timed:
                 redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync

@@ -147,6 +147,8 @@ struct UhcBatch {
     hipStream_t side_stream = nullptr, side_stream3 = nullptr;  // kernel path 2: the general / large tiers' own envs run beside the fast tier's
     hipEvent_t ev_fork = nullptr, ev_side1 = nullptr, ev_side2 = nullptr;
     int* tier_now = nullptr;
+    bool large_first = false;  // the large tier's consumers are launched (and resident) before the general tier's
+    int n_cu = 256;
     int* d_order = nullptr;  // launch order of the fast tier under sticky tiers (uhc_tier_lists_kernel)
     int q2_wait_min = 24;    // at least so many general-tier consumers wait for hand-ons (UHC_Q2_WAIT)
     int q2_div = 1;          // waiting general-tier consumers per expected env: 1 / q2_div (UHC_Q2_DIV)
@@ -460,12 +462,17 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         // get a third of the CU's LDS (3 workgroups per CU) instead of a quarter -- the stock floor-only model keeps its 40 KiB layout
         A.cf.maxefc = UHC_FAST_MAXEFC; A.cf.maxcon = UHC_FAST_MAXCON; A.cf.ld_delta = 0;
         A.cf.ndense = T.ncpair > 0 ? UHC_FAST_MAXTWO : 0;
+        int dense_kib = 52;
+        if (const char* fd = getenv("UHC_FAST_DENSE")) {  // "KiB,dense rows" of the dense fast tier (experiments: 40,4 = four workgroups per CU)
+            int kib = 0, nd = 0;
+            if (sscanf(fd, "%d,%d", &kib, &nd) == 2 && kib >= 32 && kib <= 160 && nd >= 0 && nd <= UHC_FAST_MAXTWO) { dense_kib = kib; if (T.ncpair > 0) A.cf.ndense = nd; }
+        }
         F.dense = carve(A.cf.ndense * A.nvp);
         F.dcol = carve(A.cf.ndense * UHC_WAVE);
         F.Y = off;
         // (52 KiB, not 160 / 3 = 53.3: the LDS is handed out in granules, and 54 608 B rounded up no longer fits three times -- the tier
         //  trace showed 512 of 1 024 workgroups resident, two per CU; 52 KiB is a whole number of every granule up to 4 KiB)
-        const int budget = T.ncpair > 0 ? (52 * 1024) / 8 : 40 * 1024 / 8;
+        const int budget = T.ncpair > 0 ? (dense_kib * 1024) / 8 : 40 * 1024 / 8;
         int ycap = budget - off;
         const int need1 = end1 - off;  // phase 1 may need more than the constraint data
         if (ycap < need1) ycap = need1;
@@ -618,7 +625,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (!(A.dbg & 8)) TRY(dalloc(b, E, &b->d_order));  // (UHC_DEBUG bit 3: the fast tier launches in env order)
     if (const char* q = getenv("UHC_Q2_DIV")) b->q2_div = std::max(1, atoi(q));
     if (const char* q = getenv("UHC_Q2_WAIT")) b->q2_wait_min = std::max(1, atoi(q));
-    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 4, &b->d_fin));
+    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
@@ -691,7 +698,12 @@ extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode) {
         int least = 0, greatest = 0;
         HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_OK(hipStreamCreateWithPriority(&b->side_stream, hipStreamNonBlocking, greatest));
-        HIP_OK(hipStreamCreateWithPriority(&b->side_stream3, hipStreamNonBlocking, greatest));
+        // (the large tier's stream at the LOWEST priority when the device has three levels: a pool of its own, so that its consumers can be
+        //  launched BEFORE the general tier's -- they need whole CUs, which they only find while nothing else is resident -- without ever
+        //  sharing a queue with the launch they wait for)
+        HIP_OK(hipStreamCreateWithPriority(&b->side_stream3, hipStreamNonBlocking, (least != greatest && least != 0) ? least : greatest));
+        b->large_first = least != greatest && least != 0;
+        { hipDeviceProp_t pr; HIP_OK(hipGetDeviceProperties(&pr, b->device)); b->n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         HIP_OK(hipHostMalloc((void**)&b->h_counts, sizeof(int) * 8 * 4, hipHostMallocDefault));
         memset(b->h_counts, 0, sizeof(int) * 8 * 4);
         for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&b->cnt_ev[k], hipEventDisableTiming));
@@ -757,11 +769,32 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // (one waiting consumer per env expected in the queue: its own envs are done within one general-tier env-step and the consumers are
         //  free when the fast tier hands envs on.  Half as many -- more LDS for the fast tier, two envs in a row per consumer -- was
         //  measured on the self-colliding rollout: 59 k env-steps/s against 66 k)
-        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, 512));  // (320 x 79 KiB + 64 x 160 KiB leave a seventh of the LDS)
-        const int grid3 = std::min(est3 + est3 / 4 + 2, 64);  // (each holds a whole CU's LDS)
+        // The large tier's share of the chip: each of its workgroups holds a whole CU, two of the general tier's fit one.  With g3 CUs for
+        // the large tier both queues take equally long when est3 / g3 = est2 / (2 (n_cu - g3)) (their env-steps last about as long); never
+        // more consumers than envs expected, never fewer than 64 when there are that many envs.  (A fixed 64 was measured on the
+        // ball_objects scene late in its cycle: 370 envs in the large tier's queue, six in a row per consumer, the step 61 ms of which the
+        // general tier's launch took the first 20 -- tools/tier_trace.py --workload ball_objects.)
+        const int share3 = est3 > 0 ? (int)((2ll * b->n_cu * est3) / std::max(1, est2 + 2 * est3)) : 0;
+        const int grid3 = std::min(est3 + est3 / 4 + 2, std::max(64, std::min(share3, (3 * b->n_cu) / 4)));
+        const int room2 = 2 * (b->n_cu - (b->large_first && q3 ? std::min(grid3, std::max(est3, 1)) : 0));  // general-tier workgroups beside the large tier's
+        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
+        auto launch_large = [&]() -> int {
+            HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
+            K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
+            K.grid = grid3; K.n_wait = grid3; K.spares = nullptr; K.started = b->d_fin + 4;
+            K.prod_fin = b->d_fin + 2; K.prod_total = grid2;  // the general tier's workgroups: they never wait for this launch
+            K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
+            HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
+            HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
+            return 0;
+        };
+        // (the large tier's consumers first where their stream has a queue pool of its own: whole CUs are only free while nothing else is
+        //  resident, so the general tier's launch waits behind a gate until they have reported in)
+        if (q3 && b->large_first) { if (launch_large()) return -1; }
         if (queues) {
             HIP_OK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+            if (q3 && b->large_first && !(b->A.dbg & 32)) HIP_OK(uhc_launch_gate(b->d_fin + 4, grid3, nullptr, nullptr, b->side_stream));
             K.tier_want = 0; K.list = b->d_lists; K.list_count = b->d_counts + 2; K.list_cursor = b->d_cursors + 2;
             K.grid = grid2;
             K.prod_fin = waiting ? b->d_fin + 1 : nullptr; K.prod_total = b->n_env;  // every workgroup of the fast tier's launch below
@@ -771,20 +804,12 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
             HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, nullptr, b->lds_bytes, b->side_stream));
             HIP_OK(hipEventRecord(b->ev_side1, b->side_stream));
         }
-        if (q3) {
-            HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
-            K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
-            K.grid = grid3; K.n_wait = grid3; K.spares = nullptr;
-            K.prod_fin = b->d_fin + 2; K.prod_total = grid2;  // the general tier's workgroups above: they never wait for this launch
-            K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
-            HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
-            HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
-        }
+        if (q3 && !b->large_first) { if (launch_large()) return -1; }
         K.list = nullptr; K.list_count = nullptr; K.list_cursor = nullptr; K.grid = 0; K.prod_fin = nullptr; K.prod_total = 0; K.started = nullptr; K.spares = nullptr;
         // The fast tier's launch fills every CU's LDS the moment it starts; consumers that are not resident by then get theirs only when
         // its first workgroups leave (the tier trace showed them starting 3.7 ms into the step).  A one-thread gate on this stream holds
         // the launch back until every consumer workgroup has reported in (or 200 us have passed).
-        if (waiting && !(b->A.dbg & 32)) HIP_OK(uhc_launch_gate(b->d_fin + 3, grid2 + (q3 ? grid3 : 0), b->d_counts + 1,
+        if (waiting && !(b->A.dbg & 32)) HIP_OK(uhc_launch_gate(b->d_fin + 3, grid2, b->d_counts + 1,
                                                                      (b->A.dbg & 16) ? b->A.s.prof + (size_t)(b->n_env - 1) * 40 + 16 : nullptr, b->stream));
         K.tier_want = 1;
         K.order = b->d_order;  // (costliest envs first; null with UHC_DEBUG bit 3: env order)

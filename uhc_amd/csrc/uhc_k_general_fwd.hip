@@ -66,7 +66,8 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
 __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
                                       const int* cost, const int* fresh, int* order) {
     __shared__ int nb[UHC_ORDER_BUCKETS + 1];
-    if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; fin[threadIdx.x] = 0; }
+    if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; }
+    if (threadIdx.x < 8) fin[threadIdx.x] = 0;  // exit counters of the fast / general tier's workgroups [1], [2]; spare seats taken [0]; consumers resident [3], [4]
     if (threadIdx.x <= UHC_ORDER_BUCKETS) nb[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 2 * n_env; i += blockDim.x) lists[i] = -1;
     __syncthreads();

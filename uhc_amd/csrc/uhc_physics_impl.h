@@ -2609,7 +2609,9 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         if (MODE == 0 && ran) {
             const int* mk = A.marks;  // up2: rows, contacts, body-body rows | dn1: the same | up3, dn2: eighths of the general tier's capacities
             const bool up2 = pk_nefc > mk[0] || pk_ncon > mk[1] || pk_ntwo > mk[2];   // of 64 rows / 16 contacts / 12 body-body rows
-            const bool dn1 = pk_nefc <= mk[3] && pk_ncon <= mk[4] && pk_ntwo <= mk[5];
+            // (... and only if its packed rows fit the fast tier's storage: with objects in the model that storage is small, and an env that
+            //  fits by rows and contacts alone came down every step only to be handed on in its first forward pass)
+            const bool dn1 = pk_nefc <= mk[3] && pk_ncon <= mk[4] && pk_ntwo <= mk[5] && (TIER == 1 || pk_y + 8 <= (7 * A.cf.ycap) / 8);
             const bool up3 = pk_nefc > (mk[6] * A.cg.maxefc) / 8 || pk_ncon > (mk[6] * A.cg.maxcon) / 8 || pk_ntwo > (mk[6] * A.cg.ndense) / 8 || pk_y > (mk[6] * A.cg.ycap) / 8;
             const bool dn2 = pk_nefc <= (mk[7] * A.cg.maxefc) / 8 && pk_ncon <= (mk[7] * A.cg.maxcon) / 8 && pk_ntwo <= (mk[7] * A.cg.ndense) / 8 && pk_y <= (mk[7] * A.cg.ycap) / 8;
             const int big = A.last_tier == 3 ? 3 : 2;
