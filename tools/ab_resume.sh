@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-echo "selfcol"; python tools/probe_selfcol.py 2>/dev/null | cut -c1-200
-echo "ball_objects"; python bench.py --workload ball_objects --steps 60 --warmup 20 2>/dev/null | cut -c1-200
-python tools/tier_trace.py gpurun_out/tier_trace_bo2.txt --workload ball_objects 2>&1 | grep -v amdgpu | grep -v "  env" | tail -24
-timeout 1200 python -m pytest tests/test_gpu_selfcollision.py tests/test_gpu_env.py tests/test_gpu_behaviour.py tests/test_gpu_ball.py tests/test_gpu_agent.py -m gpu -q 2>&1 | grep -v amdgpu | tail -5
+python bench.py --no-cpu-baseline --no-ppo --no-pgs-probe 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'])
+for k in ('self_collision','shapes','ball_rollout','ball_objects'): print(k, round(d[k]['env_steps_per_s']), d[k]['ms_per_step'])"
+TRACE_BALL=1 UHC_DEBUG=64 python tools/tier_trace.py gpurun_out/tier_trace_ball2.txt 2>&1 | grep -v amdgpu | grep "^## \|gave up [1-9]"

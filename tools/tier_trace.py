@@ -2,7 +2,9 @@
 let it go, and at which substep it was handed on.  Needs UHC_DEBUG bit 4 (set here): the product kernel then stamps a 100 MHz wall
 clock into the first words of the env's stage-profile record (uhc_physics_impl.h, TRACE).
 
-  python tools/tier_trace.py [out.txt] [--workload-args of bench.py]
+  python tools/tier_trace.py [out.txt] [flags of bench.py]           the self-colliding rollout (bench line `self_collision`)
+  TRACE_BALL=1 python tools/tier_trace.py [out.txt]                   the ball-joint humanoid's rollout (`ball_rollout`)
+  python tools/tier_trace.py [out.txt] --workload ball_objects        the physics-only scene with objects (`ball_objects`)
 """
 import os
 import sys
@@ -83,7 +85,12 @@ def main():
         args.steps, args.warmup = 30, 20
         bench.bench_ball_objects(args)
     else:
-        agent = bench.build_agent(args, 0, 0, torch.float64, robot_cfg={"mesh": True, "model": "smpl"})
+        if os.environ.get("TRACE_BALL") == "1":  # the ball-joint humanoid of the bench line `ball_rollout`
+            agent = bench.build_agent(args, 0, 0, torch.float64, robot_cfg={"mesh": True, "model": "smpl", "ball": True},
+                                      cfg_over=dict(action_type="torque", residual_force=False, meta_pd=False, meta_pd_joint=False, reward_id="world_rfc_implicit_quat",
+                                                    obs_v=2, tq_mul=4, env_init_noise=0.0))
+        else:
+            agent = bench.build_agent(args, 0, 0, torch.float64, robot_cfg={"mesh": True, "model": "smpl"})
         agent.per_epoch_update(0)
         env = agent.env
         agent.rollout_begin(40)

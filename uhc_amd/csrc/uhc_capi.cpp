@@ -150,11 +150,13 @@ struct UhcBatch {
     bool large_first = false;  // the large tier's consumers are launched (and resident) before the general tier's
     int n_cu = 256;
     int* d_order = nullptr;  // launch order of the fast tier under sticky tiers (uhc_tier_lists_kernel)
-    int q2_wait_min = 24;    // at least so many general-tier consumers wait for hand-ons (UHC_Q2_WAIT)
+    int aborts_seen = 0, abort_events = 0;
+    long long queues_off_until = 0;
+    int q2_wait_min = 16;    // at least so many general-tier consumers wait for hand-ons (UHC_Q2_WAIT)
     int q2_div = 1;          // waiting general-tier consumers per expected env: 1 / q2_div (UHC_Q2_DIV)
     int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr, *d_fin = nullptr;
     bool queues_off = false;
-    int* h_counts = nullptr;  // pinned [8][4]: list sizes of the last steps, copied back asynchronously
+    int* h_counts = nullptr;  // pinned [8][8]: give-ups, gate wait, final queue lengths [2], [3], queue lengths at the head of the step [4], [5]; the last steps', copied back asynchronously
     hipEvent_t cnt_ev[8] = {};
     long long cnt_step = 0;
     std::vector<void*> allocs;
@@ -220,6 +222,20 @@ static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>&
     o.geom_solimp = put(d.geom_solimp, 5 * d.ngeom); o.geom_rbound = put(d.geom_rbound, d.ngeom);
     o.geom_center = put(d.geom_center, 3 * d.ngeom);
     o.mesh_vert = put(d.mesh_vert, 3 * (size_t)d.nmeshvert);
+    {   // box around every hull in its body's frame (centre, half extents): the second cull of the convex pairs (after the bounding spheres)
+        std::vector<double> box((size_t)6 * std::max(d.ngeom, 1), 0.0);
+        for (int g = 0; g < d.ngeom; g++) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            const int v0 = d.geom_vertadr ? d.geom_vertadr[g] : 0, nvt = d.geom_vertnum ? d.geom_vertnum[g] : 0;
+            for (int v = v0; v < v0 + nvt; v++)
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], d.mesh_vert[3 * v + k]); hi[k] = std::max(hi[k], d.mesh_vert[3 * v + k]); }
+            for (int k = 0; k < 3; k++) {
+                if (nvt > 0) { box[6 * g + k] = 0.5 * (lo[k] + hi[k]); box[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]); }
+                else { box[6 * g + k] = d.geom_center[3 * g + k]; box[6 * g + 3 + k] = d.geom_rbound[g]; }  // (no hull: the bounding sphere's box)
+            }
+        }
+        o.geom_box = put(box.data(), box.size());
+    }
     o.actuator_gear = put(d.actuator_gear, 3 * (size_t)d.nu);
     o.meaninertia = put(&d.meaninertia, 1);
     {   // hull graph: fixed stride, neighbour order = the CSR's order (the multi-contact rule takes neighbours in that order)
@@ -625,7 +641,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (!(A.dbg & 8)) TRY(dalloc(b, E, &b->d_order));  // (UHC_DEBUG bit 3: the fast tier launches in env order)
     if (const char* q = getenv("UHC_Q2_DIV")) b->q2_div = std::max(1, atoi(q));
     if (const char* q = getenv("UHC_Q2_WAIT")) b->q2_wait_min = std::max(1, atoi(q));
-    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 4, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
+    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
@@ -704,8 +720,8 @@ extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode) {
         HIP_OK(hipStreamCreateWithPriority(&b->side_stream3, hipStreamNonBlocking, (least != greatest && least != 0) ? least : greatest));
         b->large_first = least != greatest && least != 0;
         { hipDeviceProp_t pr; HIP_OK(hipGetDeviceProperties(&pr, b->device)); b->n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-        HIP_OK(hipHostMalloc((void**)&b->h_counts, sizeof(int) * 8 * 4, hipHostMallocDefault));
-        memset(b->h_counts, 0, sizeof(int) * 8 * 4);
+        HIP_OK(hipHostMalloc((void**)&b->h_counts, sizeof(int) * 8 * 8, hipHostMallocDefault));
+        memset(b->h_counts, 0, sizeof(int) * 8 * 8);
         for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&b->cnt_ev[k], hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&b->ev_side1, hipEventDisableTiming));
@@ -750,12 +766,17 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // (the host may not run more than two steps ahead of the device here: a launch sized for a queue of five that meets nine hundred
         //  envs works them off five at a time)
         if (b->cnt_step >= 2) HIP_OK(hipEventSynchronize(b->cnt_ev[(b->cnt_step - 2) % 8]));
-        int est2 = 0, est3 = 0;
+        int est2 = 0, est3 = 0, handed2 = 0;  // queue lengths at the end of the newest step seen, and how many of the general tier's came in during the step
         for (long long k = b->cnt_step - 1; k >= 0 && k > b->cnt_step - 8; k--)
             if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) {
-                est2 = b->h_counts[4 * (k % 8) + 2]; est3 = b->h_counts[4 * (k % 8) + 3];
-                if (b->A.dbg & 64) fprintf(stderr, "uhc step %lld: queues %d / %d envs, gate waited %.1f us, gave up %d, queues_off %d\n", k, est2, est3, 0.01 * b->h_counts[4 * (k % 8) + 1], b->h_counts[4 * (k % 8)], (int)b->queues_off);
-                if (b->h_counts[4 * (k % 8)] > 0) b->queues_off = true;  // a consumer gave up waiting: its producers do not run beside it here
+                const int* hc = b->h_counts + 8 * (k % 8);
+                est2 = hc[2]; est3 = hc[3]; handed2 = std::max(0, hc[2] - hc[4]);
+                if (b->A.dbg & 64) fprintf(stderr, "uhc step %lld: queues %d / %d envs (%d handed on), gate waited %.1f us, gave up %d, queues_off %d\n", k, est2, est3, handed2, 0.01 * hc[1], hc[0], (int)b->queues_off);
+                if (hc[0] > b->aborts_seen) {  // a consumer gave up waiting: its producers did not run beside it (or too slowly).  No waiting
+                    b->aborts_seen = hc[0];     // consumers for the next 32 steps; after the third time, for good
+                    b->queues_off_until = ++b->abort_events >= 3 ? (long long)1 << 62 : b->cnt_step + 32;
+                }
+                b->queues_off = b->cnt_step < b->queues_off_until;
                 break;
             }
         // Three regimes.  No env in the general tier when last seen: no side launches, plain chain.  Up to three quarters of the batch
@@ -775,9 +796,12 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // ball_objects scene late in its cycle: 370 envs in the large tier's queue, six in a row per consumer, the step 61 ms of which the
         // general tier's launch took the first 20 -- tools/tier_trace.py --workload ball_objects.)
         const int share3 = est3 > 0 ? (int)((2ll * b->n_cu * est3) / std::max(1, est2 + 2 * est3)) : 0;
-        const int grid3 = std::min(est3 + est3 / 4 + 2, std::max(64, std::min(share3, (3 * b->n_cu) / 4)));
+        // (beside a fast tier that still has most of the envs -- `waiting` -- the consumers are kept to a third of the chip: at most 32 CUs
+        //  for the large tier, 256 workgroups of the general tier, 64 waiting spares.  Sized for their queues alone they left the fast tier 28
+        //  CUs in the ball-joint rollout's first steps, and consumers that waited for it ran into their time-out.)
+        const int grid3 = waiting ? std::min(est3 + est3 / 4 + 2, 32) : std::min(est3 + est3 / 4 + 2, std::max(64, std::min(share3, (3 * b->n_cu) / 4)));
         const int room2 = 2 * (b->n_cu - (b->large_first && q3 ? std::min(grid3, std::max(est3, 1)) : 0));  // general-tier workgroups beside the large tier's
-        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, 320) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
+        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, 256) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
         auto launch_large = [&]() -> int {
             HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
@@ -799,7 +823,10 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
             K.grid = grid2;
             K.prod_fin = waiting ? b->d_fin + 1 : nullptr; K.prod_total = b->n_env;  // every workgroup of the fast tier's launch below
             K.fin = b->d_fin + 2; K.started = waiting ? b->d_fin + 3 : nullptr;
-            K.n_wait = std::max(b->q2_wait_min, est2 / 2); K.spares = b->d_fin;  // (the envs handed on in a step are a fraction of those that start it in the tier)
+            // (seats for twice the hand-ons last seen: when the queue shrinks from step to step -- after a restart of many envs -- the launch
+            //  is sized for a queue that is no longer there, and idle consumers that stay hold LDS the fast tier is waiting for: 150 of
+            //  them made its last workgroups start 25 ms into the step on the ball-joint rollout's first steps)
+            K.n_wait = std::min(64, std::max(b->q2_wait_min, 2 * handed2 + 8)); K.spares = b->d_fin;
             K.q_next = q3 ? b->d_lists + b->n_env : nullptr; K.q_next_count = q3 ? b->d_counts + 3 : nullptr;
             HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, nullptr, b->lds_bytes, b->side_stream));
             HIP_OK(hipEventRecord(b->ev_side1, b->side_stream));
@@ -827,7 +854,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // the final queue lengths of this step, for the steps to come
         const int slot = (int)(b->cnt_step % 8);
         HIP_OK(hipMemcpyAsync(b->d_counts, b->A.s.q_abort, sizeof(int), hipMemcpyDeviceToDevice, b->stream));  // counts[0] carries the give-up count
-        HIP_OK(hipMemcpyAsync(b->h_counts + 4 * slot, b->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        HIP_OK(hipMemcpyAsync(b->h_counts + 8 * slot, b->d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
         HIP_OK(hipEventRecord(b->cnt_ev[slot], b->stream));
         b->cnt_step++;
         return 0;

@@ -59,7 +59,7 @@ struct DevNumOff {
     int body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0;
     int jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_margin, qpos0, qpos_spring;
     int dof_armature, dof_damping, dof_frictionloss, dof_invweight0;
-    int geom_pos, geom_quat, geom_friction, geom_margin, geom_gap, geom_solref, geom_solimp, geom_rbound, geom_center;
+    int geom_pos, geom_quat, geom_friction, geom_margin, geom_gap, geom_solref, geom_solimp, geom_rbound, geom_center, geom_box;
     int mesh_vert, actuator_gear, meaninertia;
     int mesh_adj;  // int32 [nmeshvert][adjdeg] neighbours of every hull vertex (global vertex ids, -1 = none), packed two per double
     int stride;  // doubles per model
@@ -144,7 +144,7 @@ struct KernelArgs {
     int grid;  // workgroups of a list launch (0: one per env)
     int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
-    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step
+    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step, bit 7 = no box cull of the convex pairs
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     int adjdeg;              // stride of the per-model hull adjacency table (largest vertex degree over the batch's models)
     DevCtrl c;

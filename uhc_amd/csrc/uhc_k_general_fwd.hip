@@ -89,8 +89,9 @@ __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int 
         if ((t == 2 || t == 3) && (!d_active || d_active[env])) lists[(t - 2) * n_env + atomicAdd(&counts[t], 1)] = env;
         if (order) atomicAdd(&nb[bucket(env)], 1);
     }
-    if (!order) return;
     __syncthreads();
+    if (threadIdx.x < 2) counts[4 + threadIdx.x] = counts[2 + threadIdx.x];  // the queues as the step begins (the host compares with how they end)
+    if (!order) return;
     if (threadIdx.x == 0) {
         int run = 0;
         for (int k = 0; k <= UHC_ORDER_BUCKETS; k++) { const int c = nb[k]; nb[k] = run; run += c; }

@@ -925,8 +925,33 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 mat_vec(t1, R1, ce1); mat_vec(t2, R2, ce2);
                 double d2 = 0;
                 for (int k = 0; k < 3; k++) { const double d = (t1[k] + S[L.xpos + 3 * b1 + k]) - (t2[k] + S[L.xpos + 3 * b2 + k]); d2 += d * d; }
-                const double bound = mb[A.o.geom_rbound + g1] + mb[A.o.geom_rbound + g2] + fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                const double margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                const double bound = mb[A.o.geom_rbound + g1] + mb[A.o.geom_rbound + g2] + margin;
                 c = !(d2 > bound * bound);
+                // second cull: the hulls' boxes in their body frames (model constants), separating-axis test on the six face normals.  A
+                // limb's bounding sphere reaches far beyond its sides; side by side (thighs, arm along the torso) the spheres overlap in
+                // every pose and the pair went through the whole portal search only to be found apart.  Conservative: a box holds its
+                // hull, and boxes further apart than the margin along an axis mean hulls further apart than the margin.
+                if (c && !(A.dbg & 128)) {
+                    const double* B1 = mb + A.o.geom_box + 6 * g1;
+                    const double* B2 = mb + A.o.geom_box + 6 * g2;
+                    double c1[3], c2[3], dw[3];
+                    mat_vec(c1, R1, B1); mat_vec(c2, R2, B2);
+                    for (int k = 0; k < 3; k++) dw[k] = (c2[k] + S[L.xpos + 3 * b2 + k]) - (c1[k] + S[L.xpos + 3 * b1 + k]);
+                    // columns of R are the body axes in the world: C[i][k] = axis_i(1) . axis_k(2)
+                    double C[3][3], ta[3], tb[3];
+                    for (int i = 0; i < 3; i++) {
+                        ta[i] = dw[0] * R1[i] + dw[1] * R1[3 + i] + dw[2] * R1[6 + i];
+                        tb[i] = dw[0] * R2[i] + dw[1] * R2[3 + i] + dw[2] * R2[6 + i];
+                        for (int k = 0; k < 3; k++) C[i][k] = fabs(R1[i] * R2[k] + R1[3 + i] * R2[3 + k] + R1[6 + i] * R2[6 + k]);
+                    }
+                    bool apart = false;
+                    for (int i = 0; i < 3; i++) {
+                        apart |= fabs(ta[i]) > B1[3 + i] + B2[3] * C[i][0] + B2[4] * C[i][1] + B2[5] * C[i][2] + margin;
+                        apart |= fabs(tb[i]) > B2[3 + i] + B1[3] * C[0][i] + B1[4] * C[1][i] + B1[5] * C[2][i] + margin;
+                    }
+                    c = !apart;
+                }
             }
             const unsigned long long cm = __ballot(c);
             const int rank = ncand + __popcll(cm & ((1ull << LANE) - 1ull));
