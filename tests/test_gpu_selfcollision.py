@@ -207,6 +207,64 @@ def test_sticky_tiers_follow_the_scene(model, standing):
     assert max(w1, w2) < 1e-9, (w1, w2)
 
 
+def test_hand_on_resumes_at_the_substep(model, standing):
+    """A tier that finds an env too big in the middle of a control step hands it on WITH the substeps it has done: the next tier goes on
+    from the substep that did not fit.  Self-colliding humanoids dropped from 4-12 mm: the feet land during a control step, the rows go
+    past 64 in one of its substeps.  The tier trace (UHC_DEBUG bit 4) shows hand-ons at a substep >= 1; the states equal those of a build
+    switch that makes the next tier repeat the step (bit 2) up to the rounding of the tiers' solvers, and follow the oracle."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import self_collision_variant
+    from uhc_amd.sim import make_ctrl
+    if os.environ.get("UHC_FORCE_GENERAL") == "1":
+        pytest.skip("the batch has no fast tier to hand on from")
+    sc = dataclasses.replace(self_collision_variant(model), solver=1)
+    ctrl = make_ctrl(sc)
+    n = 6
+    rng = np.random.default_rng(67)
+    qpos = np.tile(standing["qpos"], (n, 1))
+    qpos[:, 7:] += rng.normal(scale=0.002, size=(n, 69))
+    qpos[:, 2] += np.linspace(0.004, 0.012, n)
+    qvel = np.zeros((n, 75))
+    old = os.environ.get("UHC_DEBUG")
+    try:
+        os.environ["UHC_DEBUG"] = "16"
+        resume = S.SimBatch(sc, ctrl, n)
+        os.environ["UHC_DEBUG"] = "20"
+        restart = S.SimBatch(sc, ctrl, n)
+    finally:
+        if old is None:
+            os.environ.pop("UHC_DEBUG", None)
+        else:
+            os.environ["UHC_DEBUG"] = old
+    os_ = [OracleSim(sc, ctrl) for _ in range(n)]
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    act = np.zeros((n, ctrl.action_dim))
+    a = torch.from_numpy(act).cuda()
+    for bb in (resume, restart):
+        bb.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+    for e in range(n):
+        os_[e].set_state(qpos[e], qvel[e])
+    substeps, worst, apart = [], 0.0, 0.0
+    for _ in range(5):
+        resume.field(S.F_STAGE_PROF).zero_()
+        for bb in (resume, restart):
+            bb.simulate(a, tb)
+            bb.sync()
+        redo, gq = resume.field(S.F_REDO).cpu().numpy(), resume.field(S.F_QPOS).cpu().numpy()
+        tr = resume.field(S.F_STAGE_PROF).cpu().numpy()
+        substeps.append(np.where((redo & 1) != 0, tr[:, 6], -1))  # word 6 of the trace: the substep the fast tier handed the env on in
+        apart = max(apart, np.abs(gq - restart.field(S.F_QPOS).cpu().numpy()).max())
+        for e in range(n):
+            os_[e].do_simulation(act[e], qpos[e, 7:], redo=redo[e])
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    substeps = np.array(substeps)
+    assert (substeps >= 1).any(), substeps  # some env was handed on in mid-step ...
+    assert apart < 1e-8 and worst < 1e-5, (apart, worst)
+    assert int(resume.field(S.F_EFC_OVERFLOW).sum().item()) == 0
+
+
 def test_lying_humanoid_among_boxes_exceeds_128_rows(model, standing):
     """The reference's models ask MuJoCo for njmax 2500 / nconmax 500 (uhc/khrylib/mocap/skeleton_mesh.py:46).  A self-colliding
     humanoid lying face down among four boxes has 100-150 constraint rows: beyond the general tier (128 rows / 64 contacts), so the env is
