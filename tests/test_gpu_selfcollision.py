@@ -209,8 +209,8 @@ def test_sticky_tiers_follow_the_scene(model, standing):
 
 def test_hand_on_resumes_at_the_substep(model, standing):
     """A tier that finds an env too big in the middle of a control step hands it on WITH the substeps it has done: the next tier goes on
-    from the substep that did not fit.  Self-colliding humanoids dropped from 4-12 mm: the feet land during a control step, the rows go
-    past 64 in one of its substeps.  The tier trace (UHC_DEBUG bit 4) shows hand-ons at a substep >= 1; the states equal those of a build
+    from the substep that did not fit.  Self-colliding humanoids dropped from 2-7 cm: the feet land during the third or fourth control step, and the
+    impact takes the rows past 64 in one of its substeps.  The tier trace (UHC_DEBUG bit 4) shows hand-ons at a substep >= 1; the states equal those of a build
     switch that makes the next tier repeat the step (bit 2) up to the rounding of the tiers' solvers, and follow the oracle."""
     import torch
     from oracle.physics import OracleSim
@@ -225,7 +225,7 @@ def test_hand_on_resumes_at_the_substep(model, standing):
     rng = np.random.default_rng(67)
     qpos = np.tile(standing["qpos"], (n, 1))
     qpos[:, 7:] += rng.normal(scale=0.002, size=(n, 69))
-    qpos[:, 2] += np.linspace(0.004, 0.012, n)
+    qpos[:, 2] += np.linspace(0.02, 0.07, n)
     qvel = np.zeros((n, 75))
     old = os.environ.get("UHC_DEBUG")
     try:
@@ -247,7 +247,7 @@ def test_hand_on_resumes_at_the_substep(model, standing):
     for e in range(n):
         os_[e].set_state(qpos[e], qvel[e])
     substeps, worst, apart = [], 0.0, 0.0
-    for _ in range(5):
+    for _ in range(6):
         resume.field(S.F_STAGE_PROF).zero_()
         for bb in (resume, restart):
             bb.simulate(a, tb)
