@@ -439,3 +439,37 @@ def test_oracle_decides_its_own_solver(model, ctrl, standing, kernel_path):
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max(), np.abs(gv[e] - os_[e].get("qvel")).max())
     assert swept == 0, swept
     assert worst < 1e-8, worst
+
+
+def test_step_inside_a_hip_graph_replays_the_eager_step(model, ctrl, standing, kernel_path):
+    """`uhc_batch_simulate` captured into a HIP graph (torch.cuda.graph) with sticky tiers selected: the sticky launch reads queue
+    lengths on the host between steps, which a capture cannot do, so a captured step takes the plain tier chain -- and a replay computes
+    what the eager step computes, from whatever state the batch is in when it is replayed."""
+    import torch
+    from uhc_amd import sim as S
+    n = 32
+    qpos, qvel = _states(standing, model, n, 23)
+    a = torch.from_numpy(np.random.default_rng(5).normal(scale=0.2, size=(n, ctrl.action_dim))).cuda()
+    tb = torch.from_numpy(qpos[:, 7:].copy()).cuda()
+    eager, graphed = _sim(model, ctrl, n), _sim(model, ctrl, n)
+    for bb in (eager, graphed):
+        bb.set_kernel_path(2)
+        bb.set_state(torch.from_numpy(qpos), torch.from_numpy(qvel))
+        bb.sync()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graphed.use_current_stream()
+        graphed.simulate(a, tb)  # (warm-up on the capture stream, as torch asks for)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            graphed.use_current_stream()
+            graphed.simulate(a, tb)
+        g.replay()
+        g.replay()
+        side.synchronize()
+    for _ in range(3):
+        eager.simulate(a, tb)
+    eager.sync()
+    np.testing.assert_allclose(graphed.field(S.F_QPOS).cpu().numpy(), eager.field(S.F_QPOS).cpu().numpy(), atol=1e-9)
+    assert int(graphed.field(S.F_FAIL).sum().item()) == 0

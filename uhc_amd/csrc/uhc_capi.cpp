@@ -753,7 +753,16 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
     const bool big = b->A.last_tier == 3;
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
     HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 4, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3, resume: one allocation
-    if (mode == 0 && b->path_mode == 2 && b->use_fast && !general) {
+    // (inside a stream capture the sticky launch cannot be used: it sizes its consumer launches from counts the host reads between steps
+    //  -- event queries and a wait that are not allowed while capturing, and a replay would repeat the capture step's sizes anyway.  A
+    //  captured step takes the plain tier chain, which computes the same step.)
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(b->stream, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
+        else (void)hipGetLastError();
+    }
+    if (mode == 0 && b->path_mode == 2 && b->use_fast && !general && !capturing) {
         // sticky tiers: an env starts in the tier that computed its last step.  The general / large tiers' own envs run on a side stream
         // BESIDE the fast tier (their launches last several times longer per env; in a chain behind it the step would wait for them);
         // only the envs a tier hands on this very step go through the chain.  All launches filter on one snapshot of the tier table.
