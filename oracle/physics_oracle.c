@@ -439,6 +439,7 @@ static void collide_plane_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2
 #define CCD_EPS 2.220446049250313e-16
 #define MPR_TOLERANCE 1e-6
 #define MPR_MAXIT 50
+#define MPR_MAXSUP 256 /* support points a pair may ask for before it counts as apart (uhc_mpr.h: UHC_MPR_MAXSUP) */
 typedef struct { double v[3], v1[3], v2[3]; } CcdSup; /* a point of the Minkowski difference and its two witnesses */
 typedef struct { const UhcModelDesc* m; const OrcData* d; int g1, g2; double margin; } CcdPair;
 static int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
@@ -545,13 +546,14 @@ static void find_pos(const CcdSup p[4], double pos[3]) {
 static int mpr_penetration(const CcdPair* P, double* depth, double dir[3], double pos[3]) {
     CcdSup p[4], v4;
     double va[3], vb[3], dt;
-    int size;
+    int size, nsup = 0;
     /* ---- discoverPortal */
     geom_centre(P->m, P->d, P->g1, p[0].v1); geom_centre(P->m, P->d, P->g2, p[0].v2);
     v3sub(p[0].v, p[0].v1, p[0].v2);
     if (ccd_eq(p[0].v[0], 0) && ccd_eq(p[0].v[1], 0) && ccd_eq(p[0].v[2], 0)) p[0].v[0] += CCD_EPS * 10;
     for (int k = 0; k < 3; k++) dir[k] = -p[0].v[k];
     v3norm(dir);
+    if (++nsup > MPR_MAXSUP) return -1;
     ccd_support(P, dir, &p[1]);
     dt = dot3(p[1].v, dir);
     if (ccd_zero(dt) || dt < 0) return -1;
@@ -567,6 +569,7 @@ static int mpr_penetration(const CcdPair* P, double* depth, double dir[3], doubl
         return 0;
     }
     v3norm(dir);
+    if (++nsup > MPR_MAXSUP) return -1;
     ccd_support(P, dir, &p[2]);
     dt = dot3(p[2].v, dir);
     if (ccd_zero(dt) || dt < 0) return -1;
@@ -576,6 +579,7 @@ static int mpr_penetration(const CcdPair* P, double* depth, double dir[3], doubl
     size = 3;
     while (size < 4) {
         int cont = 0;
+        if (++nsup > MPR_MAXSUP) return -1;
         ccd_support(P, dir, &v4);
         dt = dot3(v4.v, dir);
         if (ccd_zero(dt) || dt < 0) return -1;
@@ -597,6 +601,7 @@ static int mpr_penetration(const CcdPair* P, double* depth, double dir[3], doubl
         portal_dir(p, dir);
         dt = dot3(dir, p[1].v);
         if (ccd_zero(dt) || dt > 0) break; /* the portal encapsulates the origin */
+        if (++nsup > MPR_MAXSUP) return -1;
         ccd_support(P, dir, &v4);
         dt = dot3(v4.v, dir);
         if (!(ccd_zero(dt) || dt > 0) || portal_reach_tolerance(p, &v4, dir)) return -1;
@@ -605,6 +610,7 @@ static int mpr_penetration(const CcdPair* P, double* depth, double dir[3], doubl
     /* ---- findPenetr */
     for (unsigned long it = 0;; it++) {
         portal_dir(p, dir);
+        if (++nsup > MPR_MAXSUP) return -1;
         ccd_support(P, dir, &v4);
         if (portal_reach_tolerance(p, &v4, dir) || it > MPR_MAXIT) {
             double pd[3];

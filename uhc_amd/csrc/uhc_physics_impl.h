@@ -2322,6 +2322,9 @@ __device__ __forceinline__ void k_pd_torque(const KernelArgs& A, double* S, cons
         if (a >= 0 && a < nu) {
             const double cur = S[L.qpos + 7 + a];
             double base = tbase[a];
+            // (the reference's unwrapping loops; a joint angle that has run away -- a physics blow-up on its way to the failure check --
+            //  would keep them turning for seconds, so anything beyond 32 turns is taken off in one go first)
+            if (!(fabs(base - cur) <= 64 * M_PI)) { const double turns = rint((base - cur) / (2 * M_PI)); base = fabs(turns) < 1e300 ? base - 2 * M_PI * turns : cur; }
             while (base - cur > M_PI) base -= 2 * M_PI;
             while (base - cur < -M_PI) base += 2 * M_PI;
             double gkp = C.jkp[a], gkd = C.jkd[a];
@@ -2446,7 +2449,9 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
     // (qpos, qvel, warm start) and that substep's controls (ctrl, applied: PD torque and residual force are already computed) are in
     // the state arrays, and this tier goes on from substep k instead of repeating the step -- the work below is not lost, and the step
     // ends (15 - k) / 15 of an env-step after the hand-on instead of a whole one.
-    const int res = (MODE == 0 && TIER != 1) ? A.s.resume[env] : 0;
+    // (read past the scalar cache: `env` is wave-uniform, and a consumer workgroup that lives through many envs of a launch must not meet a
+    //  line another wave fetched before the tier below wrote its word)
+    const int res = (MODE == 0 && TIER != 1) ? __hip_atomic_load(A.s.resume + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool fresh = MODE == 0 && res == 0 && A.s.fresh[env] != 0;  // restarted by uhc_env_auto_reset: sim.forward() of the reset is still due
     // ---- load state (coalesced: consecutive lanes, consecutive doubles)
     for (int i = LANE; i < T.nq; i += UHC_WAVE) S[L.qpos + i] = A.s.qpos[(size_t)env * T.nq + i];

@@ -362,7 +362,9 @@ class HumanoidEnv:
 
     def fail_safe(self):
         """Teleport to the expert state of the current frame and refresh the kinematics (humanoid_im.py:902-905)."""
-        q = torch.as_tensor(self.get_expert_qpos()[None], dtype=torch.float64)
+        ind = self.get_expert_index(self.cur_t)
+        # (ball joints: the quaternion expert pose -- the model's own 99 coordinates -- not the hinge angles)
+        q = torch.as_tensor(self.get_expert_attr("qpos_quat" if self.vec.use_quat and "qpos_quat" in self.expert else "qpos", ind)[None], dtype=torch.float64)
         v = torch.as_tensor(self.get_expert_qvel()[None], dtype=torch.float64)
         self.vec.sim.set_state(q, v, torch.zeros(1, dtype=torch.int32))
 

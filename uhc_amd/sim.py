@@ -113,6 +113,10 @@ class SimBatch:
         qpos = qpos.to(self.device, torch.float64).contiguous()
         qvel = qvel.to(self.device, torch.float64).contiguous()
         n = qpos.shape[0]
+        # the library reads n x nq and n x nv doubles: a pose of another model's width (a hinge pose handed to the ball-joint model) is a read
+        # past the tensor and a humanoid put together from whatever lies there
+        if qpos.ndim != 2 or qvel.ndim != 2 or qpos.shape[1] != self.model.nq or qvel.shape != (n, self.model.nv):
+            raise ValueError(f"set_state: qpos {tuple(qpos.shape)} / qvel {tuple(qvel.shape)} for a model with nq {self.model.nq}, nv {self.model.nv}")
         ids = None
         if env_ids is not None:
             env_ids = env_ids.to(self.device, torch.int32).contiguous()
