@@ -320,6 +320,17 @@ def test_ball_env_quaternion_paths_match_reference(model):
     np.testing.assert_allclose(g["qpos_quat"][:, 7:], expert["bquat"][:, 4:], atol=1e-12)
     root_dot = np.abs((g["qpos_quat"][:, 3:7] * expert["bquat"][:, :4]).sum(1))
     assert root_dot.min() > 1 - 1e-6 and root_dot.min() < 1 - 1e-9
+    # the fail-safe teleport of the evaluation loop puts an env on the expert pose in the MODEL's coordinates: for the ball-joint model
+    # that is the quaternion pose (99 numbers) rebuilt from the frame record, not the record's 76 hinge angles
+    from uhc_amd import sim as S
+    q_rec = np.array(expert["qpos"], dtype=np.float64, copy=True)
+    q_rec[:, 3:7] = g["qpos_quat"][:, 3:7]
+    fr = S.pack_expert_frames(dict(expert, qpos=q_rec))
+    qp, qv = S.expert_pose_of_frames(fr, True)
+    assert qp.shape == (expert["len"], 99) and qv.shape == (expert["len"], 75)
+    np.testing.assert_allclose(qp, g["qpos_quat"], atol=1e-12)
+    qh, _ = S.expert_pose_of_frames(fr, False)
+    np.testing.assert_array_equal(qh, q_rec)
     jw = SMPLConverter(model, model).get_new_diff_weight()
     w = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0)
     for c in range(int(g["ncase"])):

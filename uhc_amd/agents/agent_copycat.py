@@ -440,9 +440,8 @@ def _eval_seqs(self, take_keys, loader):
                     cur = ev.cur_t[:m].cpu().numpy()[tele]
                     fr = frames[torch.from_numpy(clip0[tele] + np.minimum(cur, lens[tele] - 1)).to(frames.device)]
                     # the expert pose in the model's own coordinates: hinge angles, or -- ball joints -- root pose + the joints' quaternions
-                    # (uhc_env.hip: expert_qpos; frame words 0:76 = qpos, 319:415 = body quaternions, 76:151 = qvel)
-                    qp = torch.cat([fr[:, 0:7], fr[:, 323:415]], dim=1) if ev.use_quat else fr[:, 0:76]
-                    ev.sim.set_state(qp.contiguous(), fr[:, 76:151].contiguous(), torch.from_numpy(tele).to(torch.int32))
+                    qp, qv = S.expert_pose_of_frames(fr, ev.use_quat)
+                    ev.sim.set_state(qp.contiguous(), qv.contiguous(), torch.from_numpy(tele).to(torch.int32))
             t = t + 1
             state = self.running_state(ev.obs.to(self.dtype), update=False) if self.running_state is not None else ev.obs.to(self.dtype)
         for e, k in enumerate(keys):

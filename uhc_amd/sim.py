@@ -165,6 +165,19 @@ def pack_expert_frames(feat) -> np.ndarray:
     return out
 
 
+def expert_pose_of_frames(frames, ball: bool):
+    """(qpos, qvel) of the model's own coordinates from frame records of the clip bank (numpy or torch, rows = frames): hinge angles as
+    they are; ball joints -- root pose + the joints' quaternions (the record's body quaternions behind the root's), as the device-side
+    reset builds it (uhc_env.hip: expert_qpos)."""
+    import torch as _t
+    cat = _t.cat if isinstance(frames, _t.Tensor) else np.concatenate
+    q0, qn = FR["qpos"]
+    b0, bn = FR["bquat"]
+    v0, vn = FR["qvel"]
+    qpos = cat([frames[:, q0:q0 + 7], frames[:, b0 + 4:b0 + bn]], 1) if ball else frames[:, q0:q0 + qn]
+    return qpos, frames[:, v0:v0 + vn]
+
+
 class EnvBatch:
     """Device env layer (uhc_env_* of the C-ABI) on top of a SimBatch."""
 
