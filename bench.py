@@ -380,7 +380,7 @@ def bench_ball_objects(args):
     hooks = getattr(args, "hooks", None)  # (tools/tier_trace.py: called around chosen control steps)
 
     def run(k, timed):
-        nonlocal redo_tot, sweep_tot, big_tot, steps_done
+        nonlocal redo_tot, sweep_tot, big_tot, over_tot, steps_done
         for i in range(k):
             if steps_done % 30 == 0:
                 sim.set_state(q0d, v0d)
@@ -392,6 +392,7 @@ def bench_ball_objects(args):
             steps_done += 1
             if timed:
                 redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync
+                over_tot += sim.field(S.F_EFC_OVERFLOW)  # (the flag is sticky only until the env's next set_state: add it up step by step)
                 big_tot += ((sim.field(S.F_REDO) & 0x40) != 0).int()  # computed by the large tier (> 128 rows / 64 contacts / 20 body-body rows)
                 sweep_tot += ((sim.field(S.F_REDO) & 2) != 0).int()
                 r = sim.field(S.F_REDO)
@@ -404,6 +405,7 @@ def bench_ball_objects(args):
     redo_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     sweep_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     big_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    over_tot = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     why_tot = torch.zeros(4, dtype=torch.int64, device="cuda")
     sub_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
     run(args.warmup, False)
@@ -434,7 +436,10 @@ def bench_ball_objects(args):
                               "sweeps_fallback_share_of_env_steps": float(sweep_tot.double().sum().item()) / (n_env * args.steps),
                               "sweeps_fallback_share_of_substeps": float(sub_tot.item()) / (n_env * args.steps * 15),
                               "sweeps_fallback_reasons_env_steps": dict(zip(["friction_rows", "island_needs_over_64_rows", "no_convergence", "unsolved_working_set"], why_tot.cpu().tolist())),
-                              "efc_overflow_envs": int(sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(sim.field(S.F_FAIL).sum().item())}}
+                              "efc_overflow_envs": int(sim.field(S.F_EFC_OVERFLOW).sum().item()),
+                              # (the flag above is sticky only until an env's next set_state -- every 30 steps here; this one counts every timed step)
+                              "efc_overflow_env_steps": int(over_tot.sum().item()),
+                              "failed_envs": int(sim.field(S.F_FAIL).sum().item())}}
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     out["workload_stats"]["large_tier_share_of_env_steps"] = float(big_tot.double().sum().item()) / (n_env * args.steps)
     sim.close()
