@@ -4,7 +4,10 @@ A "step" is one control step of EVERY environment of the batch, exactly as a tra
 observation filter -> policy MLP forward (sampling) -> PD-target gather -> fused physics kernel (15 substeps of
 stable-PD, residual force, forward dynamics, contact solve, Euler) -> termination, imitation reward and next
 observation -> rollout-buffer writes -> reset of finished episodes (new clip window, set_state, forward).
-Workload = BASELINE.json configs[1]: copycat config, 1024 batched envs per GPU, synthetic clips.
+Workload = BASELINE.json configs[1]: copycat config, 1024 batched envs per GPU, synthetic clips, on the model class the reference's
+env runs -- what Robot(cfg.robot_cfg) generates: body-body collisions on, Chest / shoulder excludes, rel_joint_lm joint ranges
+(uhc/smpllib/smpl_parser.py:327-328, smpl_robot.py:1087-1110, 1177-1198).  `--floor-only` runs the shipped static asset as it is
+(floor contacts only: rounds 1-3's headline; kept as the `floor_only` sub-line).
 value = env-steps/s summed over all ranks (weak scaling: envs shard across ranks, no data-path collective).
 After the timed region one full PPO update (GAE + 10 full-batch epochs, gradients all-reduced over RCCL when
 n_gpus > 1) over the collected samples is timed and reported as ppo_samples_per_s.
@@ -30,20 +33,23 @@ ALGO_BYTES_PER_ENV_STEP = 8 * (76 + 75 + 75 + 105 + 69 + 76 + 75 + 75 + 75 + 100
 HBM_PEAK_GBS = 8000.0
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the fused step kernel from the committed rocprofv3 PMC passes of this same workload
-    (profiles/*_pmc_{FETCH,WRITE}_SIZE.txt, written by tools/profile_on_gpu.sh; the counters are reported in KB).  PMC
+FAST_KERNEL = {False: "void uhc_step_kernel<0, 1, false>", True: "void uhc_step_kernel<0, 1, true>"}  # floor-only | with body-body contacts compiled in
+
+
+def pmc_traffic(kernel, tag=""):
+    """HBM-side bytes per launch of a step kernel from the committed rocprofv3 PMC passes of the same workload
+    (profiles/*_pmc_{FETCH,WRITE}_SIZE<tag>.txt, written by tools/profile_on_gpu.sh; the counters are reported in KB).  PMC
     collection needs rocprofv3 around the process, so the live run quotes the latest committed pass (null if none)."""
     import glob
     import re
     tot, src = 0.0, []
     for kind in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.txt")),
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}{tag}.txt")),
                        key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r01_v12 after r01_v9
         if not files:
             return None, None
         for line in open(files[-1]):
-            if line.startswith(("void uhc_step_kernel<0, 1, false>", "void uhc_step_kernel<0, true")) and f"| {kind} |" in line:
+            if line.startswith(kernel) and f"| {kind} |" in line:
                 tot += float(line.split("|")[2]) * 1024.0
                 src.append(os.path.basename(files[-1]))
                 break
@@ -59,10 +65,10 @@ def _latest(pattern):
     return files[-1] if files else None
 
 
-def contact_solve_share():
+def contact_solve_share(tag=""):
     """Share of the fused kernel's cycles spent in the contact solve proper (active-set factorisations + pre-sweeps, or the PGS sweeps),
     from the latest committed stage profile (tools/stage_profile.py, an instrumented build: cannot run inside the timed region)."""
-    f = _latest("*_stage_profile.txt")
+    f = _latest(f"*_stage_profile{tag}.txt")
     if not f:
         return None, None
     share = 0.0
@@ -75,15 +81,15 @@ def contact_solve_share():
     return (share or None), os.path.basename(f)
 
 
-def valu_f64_counters():
-    """float64 VALU instructions per launch of the fused kernel from the latest committed PMC pass (profiles/*_pmc_VALU_F64.txt):
+def valu_f64_counters(kernel, tag=""):
+    """float64 VALU instructions per launch of a step kernel from the latest committed PMC pass (profiles/*_pmc_VALU_F64<tag>.txt):
     flop = (ADD + MUL + TRANS + 2 FMA) wave-instructions x 64 lanes (an upper bound on useful flops: inactive lanes count too)."""
-    f = _latest("*_pmc_VALU_F64.txt")
+    f = _latest(f"*_pmc_VALU_F64{tag}.txt")
     if not f:
         return None
     c = {}
     for line in open(f):
-        if line.startswith(("void uhc_step_kernel<0, 1, false>", "void uhc_step_kernel<0, true")) and "|" in line:
+        if line.startswith(kernel) and "|" in line:
             parts = [x.strip() for x in line.split("|")]
             c[parts[1]] = float(parts[2])
     need = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64")
@@ -91,6 +97,18 @@ def valu_f64_counters():
         return None
     flop = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
     return {"flop_per_launch": flop, "counters": {k: v for k, v in c.items() if "F64" in k or k == "SQ_INSTS_VALU"}, "source": os.path.basename(f)}
+
+
+def alu_per_env_step(name):
+    """float64 flop per env-step of a whole workload -- every tier's step kernels added up -- from the committed counter pass of that
+    workload (profiles/*_alu_<name>.json, written by tools/pmc_alu.py from a rocprofv3 --pmc run of the probe): what the probes' ALU
+    roofline uses, because their env-steps are spread over three kernels that run side by side."""
+    f = _latest(f"*_alu_{name}.json")
+    if not f:
+        return None
+    d = json.load(open(f))
+    d["source"] = os.path.basename(f)
+    return d
 
 
 def parse():
@@ -111,7 +129,13 @@ def parse():
     p.add_argument("--general-only", action="store_true", help="ball_objects: skip the fast kernel (uhc_batch_set_kernel_path 1)")
     p.add_argument("--fixed-path", action="store_true", help="ball_objects: fast kernel then general kernel on every step (uhc_batch_set_kernel_path 0) instead of the adaptive default")
     p.add_argument("--no-pgs-probe", action="store_true", help="skip the short PGS (solver 0) kernel timings after the timed region")
-    p.add_argument("--no-probes", action="store_true", help="skip the self_collision / shapes / ball_objects sub-lines after the timed region")
+    p.add_argument("--no-probes", action="store_true", help="skip the floor_only / shapes / ball_rollout / configs4 sub-lines after the timed region")
+    p.add_argument("--floor-only", action="store_true", help="headline on the shipped static asset as it is (floor contacts only, +-180 degree joint ranges: "
+                   "config/uhc_amd/copycat_mi355x.yml) instead of the model class the reference generates")
+    p.add_argument("--probe-steps", type=int, default=60, help="timed steps per repetition of a probe")
+    p.add_argument("--probe-warmup", type=int, default=40, help="untimed steps of a probe before its first repetition (outlasts the transient after the restart of all envs)")
+    p.add_argument("--probe-reps", type=int, default=3, help="repetitions of a probe; the sub-line reports the median")
+    p.add_argument("--only-probe", default=None, help="run one probe alone and print its sub-line (profiling: floor_only | shapes | ball_rollout | configs4)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
@@ -221,10 +245,14 @@ def cpu_ppo_baseline(agent, batch):
             "ppo_sample": f"median of {len(ts)} full epochs over {n} samples, torch CPU float64, {torch.get_num_threads()} threads (physical cores)"}
 
 
-def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None, cfg_over=None):
-    """AgentCopycat on synthetic clips for the copycat rollout: `shapes` body shapes (configs[3]), `robot_cfg` overriding the config's
-    robot block (None: config/uhc_amd/copycat_mi355x.yml = the floor-only static asset; {} keys of a reference config = the generated
-    model class: body-body collisions on, rel_joint_lm ranges)."""
+GENERATED_CLASS = {"mesh": True, "model": "smpl"}  # a reference config's robot block: Robot() then emits body-body collisions, the excludes and rel_joint_lm ranges
+
+
+def build_agent(args, rank, local, dtype, shapes=0, robot_cfg="default", cfg_over=None, objects=0):
+    """AgentCopycat on synthetic clips for the copycat rollout: `shapes` body shapes (configs[3]); `robot_cfg` = the config's robot block
+    ("default": the model class the reference generates -- body-body collisions on, rel_joint_lm ranges --, or with --floor-only the shipped
+    static asset as config/uhc_amd/copycat_mi355x.yml has it; None: that yml; a dict: a reference config's own keys); `objects` = K free
+    5 kg boxes of 0.3 m behind every humanoid with synthetic obj_pose clips (configs[4])."""
     import tempfile
     from uhc_amd import sim as S
     from uhc_amd.agents.agent_copycat import AgentCopycat
@@ -234,6 +262,8 @@ def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None, cfg_over=Non
 
     cfg = Config(cfg_id="copycat_mi355x", base_dir=tempfile.mkdtemp(prefix="uhc_bench_"))
     cfg.n_env = args.envs
+    if isinstance(robot_cfg, str):
+        robot_cfg = None if getattr(args, "floor_only", False) else GENERATED_CLASS
     if robot_cfg is not None:
         cfg.robot_cfg = dict(robot_cfg)
     for k, v in (cfg_over or {}).items():  # config keys of another reference config (e.g. copycat_ball_1.yml's controller block)
@@ -249,7 +279,7 @@ def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None, cfg_over=Non
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed + rank)
     n_clips = max(args.clips, shapes + 1) if shapes else args.clips
-    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(n_clips, seed=1 + rank))
+    dl = DatasetAMASSSingle(specs, "train", pickle_data=make_synthetic_amass(n_clips, seed=1 + rank, objects=objects))
     shape_models = clip_model = None
     if shapes:  # per-body length scale s_b ~ U(0.85, 1.15) (mass ~ s^3, inertia ~ s^5), default_rng(7); one shape per clip
         from uhc_amd.model.mjcf import kinematics_np, quat_to_mat, scale_model_per_body
@@ -272,47 +302,107 @@ def build_agent(args, rank, local, dtype, shapes=0, robot_cfg=None, cfg_over=Non
         clip_model = {k: (i % (shapes + 1)) for i, k in enumerate(keys)}
         for k, mi in clip_model.items():
             dl.data["trans"][k] = dl.data["trans"][k] + np.array([0.0, 0.0, lift[mi]])
-    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl, shape_models=shape_models, clip_model=clip_model)
+    obj = None
+    if objects:  # K free boxes (0.3 m, 5 kg, contype 1) dropped around each humanoid
+        from uhc_amd.model.shapes import box_triangles
+        obj = dict(hulls=[box_triangles(0.15, 0.15, 0.15)] * objects, density=5.0 / 0.027, friction=1.0, condim=1)
+    agent = AgentCopycat(cfg, dtype, torch.device("cuda", local), data_loader=dl, shape_models=shape_models, clip_model=clip_model, objects=obj)
     agent.logger.handlers = [h for h in agent.logger.handlers if not isinstance(h, __import__("logging").StreamHandler) or hasattr(h, "baseFilename")]
     return agent
 
 
-def rollout_probe(args, local, dtype, name, warmup=6, steps=14, **kw):
-    """A short rollout of a VARIANT of the metric's workload after the timed region (like the `pgs` lines): same step, same envs per
-    GPU, own agent.  Returns the sub-line: env-steps/s, kernel time, which tier computed the env-steps, row statistics."""
+def step_roofline(name, n_env, env_steps_per_s, kernel_ms, nq, nv, nbody, action_dim):
+    """Roofline block of a probe.  ALU: the workload's f64 flop per env-step (all tiers' step kernels, committed counter pass) x the
+    measured env-steps/s against the FP64 vector peak.  HBM: algorithmic state bytes per env-step x env-steps/s against the HBM peak."""
+    algo = 8 * (2 * nq + 3 * nv + action_dim + 69 + 10 * nbody)  # read qpos, qvel, warm start, action, target; write qpos, qvel, qacc, xpos, xquat, xipos
+    alu = alu_per_env_step(name)
+    out = {"bound": "fp64_valu", "unit": "TFLOP/s", "peak": 78.6, "first_tier_kernel_ms": kernel_ms,
+           "hbm": {"algorithmic_bytes_per_env_step": algo, "achieved_GBs": algo * env_steps_per_s / 1e9, "peak_GBs": HBM_PEAK_GBS, "frac": algo * env_steps_per_s / 1e9 / HBM_PEAK_GBS}}
+    if alu:
+        out.update({"achieved": alu["flop_per_env_step"] * env_steps_per_s / 1e12, "frac": alu["flop_per_env_step"] * env_steps_per_s / 78.6e12,
+                    "flop_per_env_step": alu["flop_per_env_step"], "f64_share_of_valu_instructions": alu.get("f64_share_of_valu"), "source": alu["source"]})
+        if alu.get("hbm_bytes_per_env_step") is not None:
+            out["hbm"]["traffic_bytes_per_env_step"] = alu["hbm_bytes_per_env_step"]
+            out["hbm"]["traffic_over_algorithmic"] = alu["hbm_bytes_per_env_step"] / algo
+    else:
+        out.update({"achieved": None, "frac": None, "source": f"no committed counter pass for this workload (profiles/*_alu_{name}.json)"})
+    return out
+
+
+def rollout_probe(args, local, dtype, name, warmup=None, steps=None, reps=None, key=None, **kw):
+    """A rollout of a VARIANT of the metric's workload after the timed region: same step, same envs per GPU, own agent.  `reps`
+    repetitions of `steps` timed steps after `warmup` untimed ones (the restart of all envs at the head of a pass is a transient of a
+    few episode lengths); the sub-line is the MEDIAN repetition, every repetition is listed.  Constraint rows dropped beyond the last
+    tier's capacity are counted per step on the device (UHC_F_REDO bit 7 through uhc_rollout_record), not read off sticky flags."""
     from uhc_amd import sim as S
+    warmup = args.probe_warmup if warmup is None else warmup
+    steps = args.probe_steps if steps is None else steps
+    reps = args.probe_reps if reps is None else reps
     agent = build_agent(args, 0, local, dtype, **kw)
     agent.per_epoch_update(0)
     env = agent.env
     n_env = env.n_env
-    agent.rollout_begin(warmup + steps)
+    agent.rollout_begin(warmup + reps * steps)
     for _ in range(warmup):
         agent.rollout_step()
     torch.cuda.synchronize()
-    env.sim.set_timing(True)
-    redo0 = agent._ro.redo_counts.clone()
-    big = torch.zeros(n_env, dtype=torch.int32, device="cuda")
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        agent.rollout_step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    redo_d = (agent._ro.redo_counts - redo0).cpu().tolist()
-    ms, k = env.sim.kernel_time()
-    env.sim.set_timing(False)
-    nefc, ncon = env.sim.field(S.F_NEFC).cpu().numpy(), env.sim.field(S.F_NCON).cpu().numpy()
+    runs, hist = [], []
+    nefc_max = ncon_max = 0
+    for _ in range(reps):
+        env.sim.kernel_time()
+        env.sim.set_timing(True)
+        redo0 = agent._ro.redo_counts.clone()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            agent.rollout_step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        redo_d = (agent._ro.redo_counts - redo0).cpu().tolist()
+        ms, k = env.sim.kernel_time()
+        env.sim.set_timing(False)
+        nefc, ncon = env.sim.field(S.F_NEFC).cpu().numpy(), env.sim.field(S.F_NCON).cpu().numpy()
+        hist.append(nefc)
+        nefc_max, ncon_max = max(nefc_max, int(nefc.max())), max(ncon_max, int(ncon.max()))
+        runs.append({"env_steps_per_s": n_env * steps / el, "ms_per_step": 1e3 * el / steps, "first_tier_kernel_ms": ms / max(k, 1),
+                     "general_or_large_tier_share_of_env_steps": redo_d[0] / (n_env * steps), "large_tier_share_of_env_steps": redo_d[3] / (n_env * steps),
+                     "sweeps_fallback_share_of_env_steps": redo_d[1] / (n_env * steps), "efc_overflow_env_steps": int(redo_d[2])})
     _, logger = agent.rollout_end()
-    out = {"env_steps_per_s": n_env * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup, "first_tier_kernel_ms": ms / max(k, 1),
-           "general_tier_share_of_env_steps": redo_d[0] / (n_env * steps), "sweeps_fallback_share_of_env_steps": redo_d[1] / (n_env * steps),
-           "large_tier_envs_last_step": int(((env.sim.field(S.F_REDO) & 0x40) != 0).sum().item()),
-           "nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()),
-           "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 257])[0].tolist(),
-           "efc_overflow_envs": int(env.sim.field(S.F_EFC_OVERFLOW).sum().item()), "failed_envs": int(env.sim.field(S.F_FAIL).sum().item()),
-           "avg_episode_len": logger.avg_episode_len, "avg_reward": logger.avg_c_reward, "workload": name}
+    med = sorted(runs, key=lambda r: r["env_steps_per_s"])[len(runs) // 2]
+    nefc = np.concatenate(hist)
+    m = env.model
+    out = dict(med)
+    out.update({"steps": steps, "warmup": warmup, "reps": reps, "env_steps_per_s_each_rep": [r["env_steps_per_s"] for r in runs],
+                "efc_overflow_env_steps_all_reps": int(sum(r["efc_overflow_env_steps"] for r in runs)),
+                "nefc_mean": float(nefc.mean()), "nefc_max_at_rep_ends": nefc_max, "ncon_max_at_rep_ends": ncon_max,
+                "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257])[0].tolist(),
+                "failed_envs_now": int(env.sim.field(S.F_FAIL).sum().item()),
+                "avg_episode_len": logger.avg_episode_len, "avg_reward": logger.avg_c_reward,
+                "model": {"nq": int(m.nq), "nv": int(m.nv), "nbody": int(m.nbody), "objects": int(getattr(env, "num_obj", 0))},
+                "roofline": step_roofline(key or name, n_env, med["env_steps_per_s"], med["first_tier_kernel_ms"], int(m.nq), int(m.nv), int(m.nbody), env.action_dim),
+                "workload": name})
     env.close()
     del agent
     torch.cuda.empty_cache()
     return out
+
+
+PROBES = {
+    "floor_only": dict(name="configs[1] on the shipped static asset as it is: floor contacts only, +-180 degree joint ranges (the headline of rounds 1-3; "
+                            "no reference config runs it -- their env model comes out of Robot(cfg.robot_cfg))", robot_cfg=None),
+    "shapes": dict(name="configs[3] smpl_shape: 64 body shapes (per-body length scales ~ U(0.85, 1.15), default_rng(7)), one model blob per clip, on the generated model "
+                        "class (`--shapes 1023` runs 1024 of them)", shapes=63),
+    "ball_rollout": dict(name="configs[4]'s env without objects: config/copycat_ball/copycat_ball_1.yml's humanoid and controller -- ball joints (nq 99), body-body collisions "
+                              "on, action_type torque (tq_mul 4), no residual force, reward world_rfc_implicit_quat, observation get_full_obs_v2_quat (534) -- as a rollout "
+                              "through env + policy; same clips", robot_cfg={"mesh": True, "model": "smpl", "ball": True},
+                         cfg_over=dict(action_type="torque", residual_force=False, meta_pd=False, meta_pd_joint=False, reward_id="world_rfc_implicit_quat", obs_v=2, tq_mul=4,
+                                       env_init_noise=0.0)),
+    "configs4": dict(name="configs[4]: copycat_ball config WITH object contacts as ONE rollout through env + policy: the ball-joint humanoid above + 4 free 5 kg boxes of 0.3 m "
+                          "per env (SURVEY 8d-5 stand-in for the licensed GRAB objects), dropped around the humanoid at every reset from the clip's obj_pose "
+                          "(uhc/envs/humanoid_im.py:1284-1287); observation / reward / termination read the humanoid (qpos[:qpos_lim])",
+                     robot_cfg={"mesh": True, "model": "smpl", "ball": True}, objects=4,
+                     cfg_over=dict(action_type="torque", residual_force=False, meta_pd=False, meta_pd_joint=False, reward_id="world_rfc_implicit_quat", obs_v=2, tq_mul=4,
+                                   env_init_noise=0.0)),
+}
 
 
 def spawn_ranks(args):
@@ -391,8 +481,8 @@ def bench_ball_objects(args):
                 hooks[1](sim, i)
             steps_done += 1
             if timed:
-                redo_tot += (sim.field(S.F_REDO) != 0).int()  # device-side accumulation, no sync
-                over_tot += sim.field(S.F_EFC_OVERFLOW)  # (the flag is sticky only until the env's next set_state: add it up step by step)
+                redo_tot += ((sim.field(S.F_REDO) & 1) != 0).int()  # device-side accumulation, no sync
+                over_tot += ((sim.field(S.F_REDO) & 0x80) != 0).int()  # rows dropped beyond the last tier's capacity in THIS step (the sticky flag is cleared by the next set_state)
                 big_tot += ((sim.field(S.F_REDO) & 0x40) != 0).int()  # computed by the large tier (> 128 rows / 64 contacts / 20 body-body rows)
                 sweep_tot += ((sim.field(S.F_REDO) & 2) != 0).int()
                 r = sim.field(S.F_REDO)
@@ -450,6 +540,12 @@ def main():
     args = parse()
     if args.workload == "ball_objects":
         print(json.dumps(bench_ball_objects(args)))
+        return
+    if args.only_probe:  # one probe alone (profiling runs: rocprofv3 around this process sees that workload's kernels only)
+        torch.cuda.set_device(0)
+        torch.set_default_dtype(torch.float64)
+        pr = dict(PROBES[args.only_probe])
+        print(json.dumps(rollout_probe(args, 0, torch.float64, pr.pop("name"), key=args.only_probe, **pr)))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -553,65 +649,71 @@ def main():
             agent.rollout_end()
             pgs[f"sweep_cap_{cap}"] = {"kernel_ms": ms / max(k, 1), "kernel_only_env_steps_per_s": n_env / (ms / max(k, 1) * 1e-3), "mean_sweeps_last_substep": sweeps, "launches": k}
         env.sim.set_solver(*orig)
-    # ---- the other configs of BASELINE.json as short probes of the same rollout step (driver-visible; the full-length lines are under profiles/)
+    # ---- the other configs of BASELINE.json as probes of the same rollout step (own agent each; median of `--probe-reps` repetitions)
     probes = {}
     if world == 1 and not args.no_probes and not args.shapes:
-        probes["self_collision"] = rollout_probe(args, local, dtype, "configs[1] on the model class the reference generates: body-body collisions on (smpl_parser.py:327-328), "
-                                                 "Chest / shoulder excludes, rel_joint_lm joint ranges; same clips, same policy", robot_cfg={"mesh": True, "model": "smpl"})
-        probes["shapes"] = rollout_probe(args, local, dtype, "configs[3] smpl_shape: 64 body shapes (per-body length scales ~ U(0.85, 1.15), default_rng(7)), one model blob per clip "
-                                         "(`--shapes 1023` runs 1024 of them)", shapes=63)
-        probes["ball_rollout"] = rollout_probe(args, local, dtype, "configs[4] env: config/copycat_ball/copycat_ball_1.yml's humanoid and controller -- ball joints (nq 99), "
-                                               "body-body collisions on, action_type torque (tq_mul 4), no residual force, reward world_rfc_implicit_quat, observation "
-                                               "get_full_obs_v2_quat (534) -- as a rollout through env + policy; same clips", robot_cfg={"mesh": True, "model": "smpl", "ball": True},
-                                               cfg_over=dict(action_type="torque", residual_force=False, meta_pd=False, meta_pd_joint=False, reward_id="world_rfc_implicit_quat",
-                                                             obs_v=2, tq_mul=4, env_init_noise=0.0))
-        ba = argparse.Namespace(**vars(args))
-        ba.steps, ba.warmup, ba.general_only, ba.fixed_path = 24, 12, False, False
-        bo = bench_ball_objects(ba)
-        probes["ball_objects"] = {"env_steps_per_s": bo["value"], "ms_per_step": bo["ms_per_step"], "steps": ba.steps, "warmup": ba.warmup, "workload": bo["config"]["workload"],
-                                  "first_tier_kernel_ms": bo["roofline"]["kernel_ms"], **bo["workload_stats"]}
+        for key, pr in PROBES.items():
+            if key == "floor_only" and args.floor_only:
+                continue  # (it is the headline of this run)
+            pr = dict(pr)
+            probes[key] = rollout_probe(args, local, dtype, pr.pop("name"), key=key, **pr)
+        if args.floor_only:  # the reference's model class as a sub-line when the headline is the static asset
+            probes["self_collision"] = rollout_probe(args, local, dtype, "configs[1] on the model class the reference generates (body-body collisions on, rel_joint_lm ranges)",
+                                                     key="self_collision", robot_cfg=GENERATED_CLASS)
     if rank == 0:
         kern_ms = max(kern_total_ms / max(kern_n, 1), 1e-9)
-        achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic() if n_env == 1024 else (None, None)
+        dense = int(env.model.geom_contype[1:].sum()) > 0  # body-body contacts compiled in: the <0, 1, true> instantiation
+        kname = FAST_KERNEL[dense]
+        tag = "" if not dense else "_selfcol"  # the committed counter passes of the self-colliding workload carry this tag
+        hbm_achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(kname, tag) if n_env == 1024 else (None, None)
         # the bound that matters: float64 vector issue / latency.  Flops from the PMC instruction counters of the same workload when a
-        # committed pass exists (profiles/*_pmc_VALU_F64.txt, 1024 envs), else the SURVEY 8d estimate of ~20 MFLOP per env-step
-        vc = valu_f64_counters() if n_env == 1024 else None
+        # committed pass exists (profiles/*_pmc_VALU_F64<tag>.txt, 1024 envs), else the SURVEY 8d estimate of ~20 MFLOP per env-step.
+        # Under sticky tiers the fast tier's launch does not compute every env of the step (a few per cent run in the general / large tier
+        # beside it), and the counters are per launch of THIS kernel: flops and time belong to the same launches.
+        vc = valu_f64_counters(kname, tag) if n_env == 1024 else None
         flop_launch = vc["flop_per_launch"] if vc else 20e6 * n_env
-        alu = {"flop_per_env_step": flop_launch / n_env, "source": (vc["source"] + ": 64 x (ADD + MUL + TRANS + 2 FMA) f64 wave-instructions") if vc else "estimate (SURVEY 8d)",
-               "achieved_tflops": flop_launch / (kern_ms * 1e-3) / 1e12, "peak_tflops": 78.6, "frac": flop_launch / (kern_ms * 1e-3) / 78.6e12}
-        if vc:
-            alu["counters_per_launch"] = vc["counters"]
+        tflops = flop_launch / (kern_ms * 1e-3) / 1e12
         # SURVEY 8d's stand-alone contact-solve accounting: A (nefc^2) + b, R, f in + f out = 8 (nefc^2 + 4 nefc) bytes per solve, 15 solves per
         # launch; the time is the kernel's contact-solve share (stage profile).  The solve keeps A in registers: it is nowhere near HBM-bound.
-        share, share_src = contact_solve_share()
+        share, share_src = contact_solve_share(tag)
         cs_bytes = float((8.0 * (nefc.astype(np.float64) ** 2 + 4.0 * nefc)).sum()) * 15
         csolve = {"algorithmic_bytes_per_launch": cs_bytes, "share_of_kernel": share, "share_source": share_src,
                   "achieved_GBs": (cs_bytes / (kern_ms * 1e-3 * share) / 1e9) if share else None,
                   "frac_of_hbm_peak": (cs_bytes / (kern_ms * 1e-3 * share) / 1e9 / HBM_PEAK_GBS) if share else None,
                   "formula": "sum over envs of 8 (nefc^2 + 4 nefc) x 15 substeps, nefc of the last substep"}
+        whole = alu_per_env_step("floor_only" if not dense else "headline")
+        model_class = ("the model class the reference's env runs: what Robot(cfg.robot_cfg) generates -- body-body collisions on, Chest / shoulder excludes, rel_joint_lm "
+                       "joint ranges" if dense else "the shipped static asset as it is (floor contacts only; --floor-only)")
         out = {
             "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "per_rank_env_steps_per_s": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
-                                   "random-init policy", "envs_per_gpu": n_env, "substeps": 15, "contact_solver": ("exact optimum of the dual QP: active set in registers (fast kernel), working sets of <= 64 rows in the general kernel for envs beyond its capacity" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
+                                   f"random-init policy, on {model_class}", "envs_per_gpu": n_env, "substeps": 15, "body_body_collisions": bool(dense),
+                       "contact_solver": ("exact optimum of the dual QP: active set in registers (fast kernel), working sets of <= 64 rows in the general kernel for envs beyond its capacity" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "uhc_step_kernel<0, 2, true> (general tier)" if os.environ.get("UHC_FORCE_GENERAL") == "1" else "uhc_step_kernel<0, 1, false> (fast tier, floor-only model)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "launches": kern_n,
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
-                         "alu_f64": alu,
+            "roofline": {"bound": "fp64_valu", "kernel": "uhc_step_kernel<0, 2, true> (general tier)" if os.environ.get("UHC_FORCE_GENERAL") == "1" else kname[5:] + (" (fast tier, body-body contacts compiled in)" if dense else " (fast tier, floor-only model)"),
+                         "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": tflops / 78.6,
+                         "flop_per_launch": flop_launch, "flop_source": (vc["source"] + ": 64 x (ADD + MUL + TRANS + 2 FMA) f64 wave-instructions of this kernel, per launch") if vc else "estimate (SURVEY 8d: ~20 MFLOP per env-step)",
+                         "counters_per_launch": vc["counters"] if vc else None,
+                         "kernel_ms": kern_ms, "launches": kern_n, "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "traffic": traffic, "traffic_over_algorithmic": (traffic / (ALGO_BYTES_PER_ENV_STEP * n_env)) if traffic else None},
+                         "whole_step": step_roofline("floor_only" if not dense else "headline", n_env, n_env * args.steps / elapsed, kern_ms, int(env.model.nq), int(env.model.nv), int(env.model.nbody), env.action_dim) if world == 1 else None,
                          "contact_solve": csolve,
-                         "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by "
-                                 "dependent f64 VALU / LDS / readlane latency with one wave per SIMD, not by HBM (DESIGN.md section 5); traffic "
-                                 "above the algorithmic bytes is L2 misses of the schedule tables / kernel code and register spills to scratch"},
-            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int((env.sim.field(S.F_REDO) != 0).sum().item()), "general_kernel_env_steps_timed_region": int(redo_d[0]), "sweeps_fallback_env_steps_timed_region": int(redo_d[1]),
-                               "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65],
-                               "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65])[0].tolist(),
-                               "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17])[0].tolist(),
-                              "efc_overflow_envs": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
+                         "note": "fused f64 step, one env per wavefront: the state crosses HBM once per 15 substeps, so the kernel is bound by dependent f64 VALU / LDS / readlane "
+                                 "latency with one wave per SIMD, not by HBM (DESIGN.md section 5): `frac` is the share of the 78.6 TFLOP/s FP64 vector peak, the HBM view is the "
+                                 "`hbm` sub-block; traffic above the algorithmic bytes is L2 misses of the schedule tables / kernel code and register spills to scratch"},
+            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int((env.sim.field(S.F_REDO) != 0).sum().item()),
+                               "general_or_large_tier_env_steps_timed_region": int(redo_d[0]), "large_tier_env_steps_timed_region": int(redo_d[3]), "sweeps_fallback_env_steps_timed_region": int(redo_d[1]),
+                               "efc_overflow_env_steps_timed_region": int(redo_d[2]),
+                               "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257],
+                               "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257])[0].tolist(),
+                               "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17, 33, 65], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17, 33, 65])[0].tolist(),
+                               "efc_overflow_envs_sticky_flags": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},
         }
         if pgs:

@@ -24,8 +24,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is its whole export table */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define UHC_ABI_VERSION 7
+#define UHC_ABI_VERSION 8
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -121,7 +125,8 @@ enum UhcField {
                               * substep that solve fell back to solver 0 (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one
                               * island with 64 rows that carry a force and more that want in / no convergence of the working sets / a working set the
                               * pivoting could not solve); bit 8 + k: substep k (< 23) of the step was one of those (a checker that follows the same
-                              * path needs to know which) */
+                              * path needs to know which); bit 7: constraint rows / contacts beyond the last tier's capacity were DROPPED in this
+                              * step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state) */
     UHC_F_TIER = 17          /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
 };
 
@@ -234,6 +239,9 @@ typedef struct UhcEnvDesc {
     const double* reward_jpos_diffw; /* reward_v 4, 5: reward_weights["jpos_diffw"] [nbody-1] (host); NULL = ones */
     int32_t term_body;           /* cfg.env_term_body (humanoid_im.py:1223-1230): 0 "body" (mean body distance > body_diff_thresh), 1 "root" (root height
                                   * below the window's lowest expert root height - 0.1); "Head" reads a key the reference never sets */
+    int32_t num_obj;             /* expert["num_obj"] (humanoid_im.py:1284-1287): free objects, the LAST num_obj bodies of the model (one free joint
+                                  * each).  Observation, reward and termination read the humanoid in front of them -- qpos[:qpos_lim], qvel[:qvel_lim],
+                                  * body_xpos[1:body_lim] (humanoid_im.py:113-115, 421-422) --, a reset puts the objects at obj_pose[ind] with zero velocity */
 } UhcEnvDesc;
 
 /* expert frame record layout of the clip bank (doubles; see uhc_amd/csrc/uhc_device_env.h) */
@@ -263,6 +271,10 @@ int32_t uhc_env_field(UhcEnv* e, int32_t field, void** d_ptr, int64_t* count);
  * d_frames [n_frames][UHC_FRAME_STRIDE], d_clip_start int32 [n_clips], d_clip_beta [n_clips][17] */
 int32_t uhc_env_set_bank(UhcEnv* e, const double* d_frames, int64_t n_frames, const int32_t* d_clip_start,
                          const double* d_clip_beta, int32_t n_clips);
+/* expert["obj_pose"] of every frame of the bank (device pointer, borrowed): d_obj_pose [n_frames][7 num_obj], object k at columns
+ * 7k .. 7k + 6 (position, quaternion wxyz); reset / auto_reset read the row of the window's first frame (reset_model, humanoid_im.py:
+ * 1284-1287: init_pose = concat(expert pose, obj_pose[0]), init_vel = concat(expert velocity, zeros)).  Call after uhc_env_set_bank. */
+int32_t uhc_env_set_obj_pose(UhcEnv* e, const double* d_obj_pose, int64_t n_frames);
 /* Per-clip body shape (the reference rebuilds the MuJoCo model from the clip's beta in load_expert -> reset_robot,
  * humanoid_im.py:154-180,204): d_clip_model int32 [n_clips] (borrowed, NULL to switch off) names, for every clip of the
  * bank, which of the batch's models (uhc_batch_create) its episodes run on; assign / auto_reset switch the env's model. */
@@ -305,7 +317,8 @@ int32_t uhc_rollout_act(void* stream, int32_t n_env, int32_t T, const int64_t* d
                         double* d_actions, double* d_action);
 /* agent.py:80-92: rewards[:, t] = reward + end * end_reward, dones[:, t] = done, c_reward_sum += sum(reward),
  * c_info_sum[k] += sum(parts[:, k]) (LoggerRL.step, logger_rl.py:29-33); n_parts <= 8.  d_redo (may be NULL): UHC_F_REDO of the step;
- * d_redo_counts[0] += envs the general kernel computed, [1] += envs whose exact contact solve fell back to sweeps (diagnostics) */
+ * d_redo_counts (int64 [4]): [0] += envs the general / large tier computed, [1] += envs whose exact contact solve fell back to sweeps,
+ * [2] += envs that lost constraint rows beyond the last tier's capacity in this step, [3] += envs the large tier computed (diagnostics) */
 int32_t uhc_rollout_record(void* stream, int32_t n_env, int32_t T, const int64_t* d_t, const double* d_reward, const int32_t* d_done,
                            const int32_t* d_end, const double* d_end_reward, const double* d_parts, int32_t parts_stride, int32_t n_parts,
                            double* d_rewards, double* d_dones, double* d_c_reward_sum, double* d_c_info_sum, const int32_t* d_redo,
@@ -320,6 +333,9 @@ int32_t uhc_filter_push(void* stream, const double* d_x, int32_t n_rows, int32_t
 int32_t uhc_filter_apply(void* stream, const double* d_x, int32_t n_rows, int32_t dim, const double* d_n, const double* d_mean, const double* d_S,
                          int32_t demean, int32_t destd, double clip, double* d_out, int64_t* d_t_inc);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

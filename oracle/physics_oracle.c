@@ -441,7 +441,14 @@ static void collide_plane_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2
 #define MPR_MAXIT 50
 #define MPR_MAXSUP 256 /* support points a pair may ask for before it counts as apart (uhc_mpr.h: UHC_MPR_MAXSUP) */
 typedef struct { double v[3], v1[3], v2[3]; } CcdSup; /* a point of the Minkowski difference and its two witnesses */
-typedef struct { const UhcModelDesc* m; const OrcData* d; int g1, g2; double margin; } CcdPair;
+typedef struct { const UhcModelDesc* m; const OrcData* d; int g1, g2; double margin; int idx1, idx2; /* hill-climb caches (vertex of the last support call) */ } CcdPair;
+/* Sensitivity switch (tools/sensitivity.py; NOT part of the checked path): how a hull's support vertex is found.
+ *   0 (default, what the device kernels do): scan all vertices, first maximum wins;
+ *   1: hill-climbing on the hull graph from the vertex the previous support call of the same MPR run ended at (vertex 0 at first), to a
+ *      vertex none of whose neighbours projects further -- [MJ-ext] mjc_MeshSupport takes this route when the mesh has a graph.  On a convex
+ *      hull both find a maximum; they differ where several vertices project equally far (a face or edge normal to the direction). */
+static int g_support_mode = 0;
+void orc_set_support_mode(int mode) { g_support_mode = mode; }
 static int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
 static int ccd_eq(double a, double b) {
     double ab = fabs(a - b);
@@ -451,12 +458,26 @@ static int ccd_eq(double a, double b) {
 }
 static void v3sub(double r[3], const double a[3], const double b[3]) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
 static void v3norm(double a[3]) { double n = sqrt(dot3(a, a)); a[0] /= n; a[1] /= n; a[2] /= n; }
-static void mesh_support(const UhcModelDesc* m, const OrcData* d, int g, const double dir[3], double margin, double out[3]) {
+static void mesh_support(const UhcModelDesc* m, const OrcData* d, int g, const double dir[3], double margin, double out[3], int* cache) {
     int b = m->geom_bodyid[g], va = m->geom_vertadr[g], vn = m->geom_vertnum[g], best = va;
     const double* R = d->xmat + 9 * b;
     double loc[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
                      R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]}; /* R^T dir */
     double bd = -1e300;
+    if (g_support_mode == 1 && cache && m->mesh_adjadr) {
+        best = (*cache >= va && *cache < va + vn) ? *cache : va;
+        bd = dot3(loc, m->mesh_vert + 3 * best);
+        for (int moved = 1; moved;) {
+            moved = 0;
+            int from = best;
+            for (int e = m->mesh_adjadr[from]; e < m->mesh_adjadr[from + 1]; e++) {
+                int v = m->mesh_adj[e];
+                double s = dot3(loc, m->mesh_vert + 3 * v);
+                if (s > bd) { bd = s; best = v; moved = 1; }
+            }
+        }
+        *cache = best;
+    } else
     for (int v = va; v < va + vn; v++) {
         double s = dot3(loc, m->mesh_vert + 3 * v);
         if (s > bd) { bd = s; best = v; }
@@ -471,8 +492,8 @@ static void geom_centre(const UhcModelDesc* m, const OrcData* d, int g, double o
 }
 static void ccd_support(const CcdPair* P, const double dir[3], CcdSup* s) {
     double nd[3] = {-dir[0], -dir[1], -dir[2]};
-    mesh_support(P->m, P->d, P->g1, dir, P->margin, s->v1);
-    mesh_support(P->m, P->d, P->g2, nd, P->margin, s->v2);
+    mesh_support(P->m, P->d, P->g1, dir, P->margin, s->v1, (int*)&P->idx1);
+    mesh_support(P->m, P->d, P->g2, nd, P->margin, s->v2, (int*)&P->idx2);
     v3sub(s->v, s->v1, s->v2);
 }
 static void portal_dir(const CcdSup p[4], double dir[3]) {
@@ -630,7 +651,7 @@ static void collide_mesh_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2,
     v3sub(dc, c1, c2);
     double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
     if (dot3(dc, dc) > bound * bound) return; /* [MJ-ext] mj_collideGeoms bounding-sphere filter */
-    CcdPair P = {m, d, g1, g2, margin};
+    CcdPair P = {m, d, g1, g2, margin, -1, -1};
     if (mpr_penetration(&P, &depth, dir, pos)) return;
     if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return; /* normal undefined (mjc_MPRIteration) */
     add_contact(m, d, g1, g2, pos, dir, margin - depth, margin - gap);
@@ -700,7 +721,28 @@ void orc_make_constraint(const UhcModelDesc* m, OrcData* d) {
     for (int j = 0; j < m->njnt; j++) {
         if (!m->jnt_limited[j]) continue;
         int t = m->jnt_type[j];
-        if (t != UHC_JNT_HINGE && t != UHC_JNT_SLIDE) continue; /* ball limits: later row */
+        if (t == UHC_JNT_BALL) {
+            /* [MJ-ext] mj_instantiateLimit, ball joint: the joint's rotation as angle * axis (mju_quat2Vel with dt = 1: unit quaternion ->
+             * axis = vector part / |vector part|, angle = 2 atan2(|vector part|, w) taken into (-pi, pi]); value = |angle|,
+             * dist = max(range[0], range[1]) - value; ONE row whose Jacobian is -axis (the rotation's own direction) on the joint's three
+             * dofs (the angular velocity of a ball joint lives in the child body's frame, which is the quaternion's) */
+            double q[4], ax[3], margin = m->jnt_margin[j];
+            memcpy(q, d->qpos + m->jnt_qposadr[j], 32);
+            quat_normalize(q);
+            double sn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            if (sn < MINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; sn = 0; } else { ax[0] = q[1] / sn; ax[1] = q[2] / sn; ax[2] = q[3] / sn; }
+            double ang = 2 * atan2(sn, q[0]);
+            if (ang > M_PI) ang -= 2 * M_PI;
+            double value = fabs(ang), sg = ang < 0 ? -1.0 : 1.0;
+            if (value < MINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; sg = 1; value = 0; }  /* mju_normalize3 of a zero vector: (1, 0, 0), length 0 */
+            double dist = fmax(m->jnt_range[2 * j], m->jnt_range[2 * j + 1]) - value;
+            if (dist < margin) {
+                int r = add_row(m, d, ORC_EFC_LIMIT, dist, margin, m->dof_invweight0[m->jnt_dofadr[j]], dsolref, dsolimp, 0);
+                if (r >= 0) for (int k = 0; k < 3; k++) d->efc_J[(size_t)r * nv + m->jnt_dofadr[j] + k] = -sg * ax[k];
+            }
+            continue;
+        }
+        if (t != UHC_JNT_HINGE && t != UHC_JNT_SLIDE) continue;
         double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
         for (int side = -1; side <= 1; side += 2) {
             double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);

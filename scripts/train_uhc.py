@@ -44,10 +44,10 @@ if __name__ == "__main__":
         import torch.distributed as dist
         args.gpu_index = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # rank 0 alone evaluates on the test clips every save_n_epochs while the others wait in the next collective: a full AMASS
-        # evaluation takes far longer than the default 10-minute collective timeout
+        # every rank evaluates its share of the test clips every save_n_epochs (eval_policy deals the keys out over the ranks), so no rank
+        # waits for another's whole evaluation; the timeout still leaves room for uneven shares of long clips
         import datetime
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", timeout=datetime.timedelta(hours=12))
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", timeout=datetime.timedelta(hours=1))
     cfg = Config(cfg_id=args.cfg, create_dirs=not (args.render or args.epoch > 0))
     over = {k: getattr(args, k) for k in ("num_epoch", "n_env", "min_batch_size")}
     for k in over:

@@ -66,8 +66,15 @@ def test_bench_reads_every_committed_profile():
     spec.loader.exec_module(bench)
     share, src = bench.contact_solve_share()
     assert src and 0.02 < share < 0.6
-    c = bench.valu_f64_counters()
+    c = bench.valu_f64_counters(bench.FAST_KERNEL[False])
     assert c and c["flop_per_launch"] > 1e9
+    t, tsrc = bench.pmc_traffic(bench.FAST_KERNEL[False])
+    assert tsrc and t > 1e6
+    for name in ("headline", "floor_only", "configs4", "ball_rollout"):  # per-workload counter passes (tools/pmc_alu.py), where committed
+        a = bench.alu_per_env_step(name)
+        assert a is None or (a["flop_per_env_step"] > 1e6 and a["source"].endswith(".json")), name
+    r = bench.step_roofline("no_such_workload", 1024, 1e5, 3.5, 76, 75, 25, 105)
+    assert r["bound"] == "fp64_valu" and r["achieved"] is None and r["hbm"]["achieved_GBs"] > 0
     latest, bench._latest = bench._latest, None
     try:  # ... and every older file of the same kinds, not only the latest
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_stage_profile.txt"))):

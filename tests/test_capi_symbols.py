@@ -22,6 +22,11 @@ def test_header_symbols_are_exported_and_listed():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/uhc_amd.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+    # ... and nothing else: the launchers / accessors the translation units share (uhc_launch_*, uhc_internal_*) are not exports
+    import subprocess
+    dyn = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted({l.split()[-1] for l in dyn.splitlines() if " T " in l and l.split()[-1].startswith("uhc_")})
+    assert exported == names, sorted(set(exported) ^ set(names))
     L.uhc_abi_version.restype = ctypes.c_int32
     header = open(os.path.join(ROOT, "include", "uhc_amd.h")).read()
     assert L.uhc_abi_version() == int(re.search(r"#define UHC_ABI_VERSION (\d+)", header).group(1))

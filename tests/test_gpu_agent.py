@@ -378,16 +378,20 @@ def test_agent_iteration_on_the_ball_joint_humanoid(tmp_path):
     cfg.reward_id, cfg.obs_v = "world_rfc_implicit_quat", 2
     cfg.cfg_dict["tq_mul"] = 4
     cfg.env_init_noise = 0.0
-    # (no evaluation pass in this test: eval_seqs' fail-safe teleport handed the 76-number hinge pose to the 99-number ball-joint model --
-    #  a read past the tensor and a humanoid assembled from what lay there, which aborted this test in one run out of ten.  Fixed in
-    #  agent_copycat.py and guarded in SimBatch.set_state, after the round's GPU minutes were spent: DESIGN.md section 8)
-    cfg.save_n_epochs = 1000
+    # WITH the evaluation pass (checkpoint + eval_policy in the same iteration): eval_seqs' fail-safe teleports a failed clip to the expert
+    # pose -- in round 3 it handed the 76-number hinge pose to the 99-number ball-joint model (a device read past the tensor: a GPU fault
+    # and SIGABRT in nine fresh processes out of ten).  The pose now has the model's width, SimBatch.set_state refuses any other, and
+    # tools/r04_pass.sh `loop` runs this test 20 x as the first test of a fresh process (profiles/r04_*_ball_agent_loop.txt)
+    cfg.save_n_epochs = 1
     agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg))
     env = agent.env
     assert env.use_quat and (env.model.nq, env.model.nv) == (99, 75) and agent.state_dim == 534 and agent.action_dim == 69
     info = agent.optimize_policy(0)
     log = info["log"]
     assert log.num_steps == 64 * 8 and 0.0 < log.avg_c_reward <= 1.0 and np.isfinite(log.avg_c_info).all()
+    assert "log_eval" in info and np.isfinite(list(info["log_eval"][0].values())[0]["mpjpe"])
+    ev = next(iter(agent._eval_envs.values()))  # the evaluation batch: its fail-safe teleports went through set_state at the model's width
+    assert ev.use_quat and int(ev.sim.field(S.F_FAIL).sum().item()) == 0
     assert int(env.sim.field(S.F_FAIL).sum().item()) == 0 and int(env.sim.field(S.F_EFC_OVERFLOW).sum().item()) == 0
     q = env.sim.field(S.F_QPOS).cpu().numpy()
     assert np.abs(np.linalg.norm(q[:, 3:99].reshape(-1, 24, 4), axis=2) - 1).max() < 1e-9

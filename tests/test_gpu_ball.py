@@ -122,3 +122,60 @@ def test_ball_humanoid_with_objects_and_self_collision(model, standing, kernel_p
             worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
     assert worst < 1e-5, worst
     assert int(b.field(S.F_FAIL).sum().item()) == 0
+
+
+@pytest.mark.parametrize("self_collision", [False, True], ids=["floor_only", "self_collision"])
+def test_ball_joint_limits_match_oracle(model, standing, kernel_path, self_collision):
+    """[MJ-ext] mj_instantiateLimit's ball branch on the device (k_enumerate_rows / k_rows / k_rows_fast: one row per ball joint whose rotation
+    angle comes within the margin of max(range), Jacobian -axis on its three dofs) against the oracle's (pinned by the cone KAT in
+    tests/test_oracle_physics.py).  The generated ball humanoid carries no ranges (uhc/khrylib/mocap/skeleton_mesh_v2.py:256-267 writes
+    none); a model that does bounds how far a torque policy can fold it.  The floor-only variant runs the fast tier's DENSE
+    instantiation too (KernelArgs::ball_limits): the limit rows live there."""
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import JNT_BALL
+    ball, ctrl = _ball_setup(model, self_collision=self_collision)
+    ball = ball.copy()
+    isb = np.asarray(ball.jnt_type) == JNT_BALL
+    ball.jnt_limited = isb.astype(np.int32)
+    # every joint's cone = its angle in the standing pose + 0.05 rad; the states add 0.1 rad of noise per hinge axis: some joints start beyond it
+    from uhc_amd.model.mjcf import hinge_to_ball_qpos
+    q_stand = hinge_to_ball_qpos(model, ball, standing["qpos"])[7:99].reshape(23, 4)
+    ang0 = 2 * np.arctan2(np.linalg.norm(q_stand[:, 1:], axis=1), np.abs(q_stand[:, 0]))
+    rng_ = np.zeros((ball.njnt, 2))
+    rng_[isb, 1] = ang0 + 0.05
+    ball.jnt_range = rng_
+    n = 4
+    q, v = _states(model, ball, standing, n, 47, 0.3)
+    b = S.SimBatch(ball, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    os_ = [OracleSim(ball, ctrl) for _ in range(n)]
+    redo = b.field(S.F_REDO).cpu().numpy()
+    for e in range(n):
+        os_[e].desc.solver = 0 if (redo[e] & 2) else 1
+        os_[e].set_state(q[e], v[e])
+        assert int(b.field(S.F_NEFC)[e].item()) == os_[e].geti("nefc")
+        np.testing.assert_allclose(b.field(S.F_QACC)[e].cpu().numpy(), os_[e].get("qacc"), atol=1e-5, rtol=1e-6)
+    assert min(o.geti("nefc") for o in os_) >= 3  # airborne (lift 0.3): every row is a ball-joint limit
+    for o in os_:
+        o.desc.solver = 1
+    rng = np.random.default_rng(48)
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for t in range(12):
+        act = rng.normal(scale=0.003, size=(n, ctrl.action_dim))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            os_[e].do_simulation(act[e], np.zeros(69), redo=redo[e])
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+    assert worst < 1e-6, worst
+    # the limits hold: no joint ends far beyond its cone (soft limits: a few hundredths of a radian in flight, up to ~0.2 under the landing's contact forces)
+    ang = 2 * np.arctan2(np.linalg.norm(gq[:, 7:99].reshape(n, 23, 4)[..., 1:], axis=-1), np.abs(gq[:, 7:99].reshape(n, 23, 4)[..., 0]))
+    assert (ang - (ang0 + 0.05)[None]).max() < 0.35
+    assert int(b.field(S.F_FAIL).sum().item()) == 0
+    b.close()

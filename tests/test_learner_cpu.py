@@ -195,7 +195,7 @@ def test_config_defaults_and_schedules(tmp_path):
 
 
 # ---- data-parallel learner: 2 gloo ranks with half the batch each == 1 process with the whole batch ----------
-def _update(rank, world, port, out_path):
+def _update(rank, world, port, out_path, wire=None, fused=True):
     import torch.distributed as dist
     torch.set_default_dtype(torch.float64)
     sys.path.insert(0, ROOT)
@@ -209,6 +209,11 @@ def _update(rank, world, port, out_path):
     ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None,
                   tau=0.95, optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=3, clip_epsilon=0.2,
                   policy_grad_clip=[(pol.parameters(), 0.5)])
+    ag.grad_wire_dtype, ag.fuse_grad_exchange = wire, fused
+    calls = []
+    if world > 1:  # count the collectives of the update: one flat gradient exchange per optimisation epoch + the advantage statistics
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(int(t.numel())), real(t, *a, **k))[1]
     rng = np.random.default_rng(0)
     n_env, T = 8, 12
     st = torch.from_numpy(rng.normal(size=(n_env, T, 23)))
@@ -223,7 +228,7 @@ def _update(rank, world, port, out_path):
     batch = RolloutBatch(st[sl].reshape(n, -1), ac[sl].reshape(n, -1), rw[sl].reshape(n, 1), mk[sl].reshape(n, 1), ex[sl].reshape(n), T)
     ag.update_params(batch)
     if rank == 0:
-        torch.save({"pol": pol.state_dict(), "val": val.state_dict()}, out_path)
+        torch.save({"pol": pol.state_dict(), "val": val.state_dict(), "calls": calls}, out_path)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -239,6 +244,27 @@ def test_two_rank_gloo_update_equals_single_process(tmp_path):
     for net in ("pol", "val"):
         for k in a[net]:
             np.testing.assert_allclose(a[net][k].numpy(), b[net][k].numpy(), atol=1e-10, err_msg=f"{net}.{k}")
+    # ONE gradient exchange per optimisation epoch -- policy and value gradients in one flat buffer (+ their two sample counts)
+    npar = sum(v.numel() for k, v in a["pol"].items() if k != "action_log_std") + sum(v.numel() for v in a["val"].values())
+    big = [c for c in b["calls"] if c > 100]
+    assert big == [npar + 2] * 3, (big, npar)
+
+
+def test_two_rank_gloo_float32_wire_and_separate_exchanges(tmp_path):
+    """`grad_allreduce_dtype: float32` (half the bytes per exchange): the 2-rank update stays within float32 rounding of the float64 one;
+    two exchanges per epoch (value, then policy: the reference's order of the two steps) give the same update as the fused exchange."""
+    import torch.multiprocessing as mp
+    single, w32, sep = str(tmp_path / "single.pt"), str(tmp_path / "w32.pt"), str(tmp_path / "sep.pt")
+    _update(0, 1, 0, single)
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_update, args=(2, port, w32, torch.float32, True), nprocs=2, join=True)
+    mp.spawn(_update, args=(2, port + 1, sep, None, False), nprocs=2, join=True)
+    a, b, c = torch.load(single), torch.load(w32), torch.load(sep)
+    for net in ("pol", "val"):
+        for k in a[net]:
+            np.testing.assert_allclose(a[net][k].numpy(), c[net][k].numpy(), atol=1e-10, err_msg=f"{net}.{k}")
+            np.testing.assert_allclose(a[net][k].numpy(), b[net][k].numpy(), atol=2e-5, rtol=1e-4, err_msg=f"float32 wire {net}.{k}")
+    assert len([x for x in c["calls"] if x > 100]) == 6  # value and policy apart: two exchanges per epoch
 
 
 def test_process_amass_raw_collects_action_files(tmp_path):

@@ -125,3 +125,60 @@ def test_two_hundred_control_steps_track_mujoco(model, standing):
         if o2.geti("fail"):
             break
     assert worst < 1e-4, worst
+
+
+def test_ball_joint_limit_rows_equal_mujocos(model, standing):
+    """Round 4: mj_instantiateLimit's ball branch (one row per limited ball joint: angle of the joint's quaternion against max(range),
+    Jacobian -axis on its three dofs) -- rows, distances, reference accelerations and the resulting acceleration."""
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import JNT_BALL, ball_variant, hinge_to_ball_qpos
+    ball = ball_variant(model).copy()
+    isb = np.asarray(ball.jnt_type) == JNT_BALL
+    ball.jnt_limited = isb.astype(np.int32)
+    ball.jnt_range = np.where(isb[:, None], np.array([0.0, 0.3]), ball.jnt_range)
+    mm, md = _mj(ball)
+    for seed in range(3):
+        qh, qvel = _state(standing, 20 + seed, lift=3.0, noise=0.15, vel=0.5)
+        qpos = hinge_to_ball_qpos(model, ball, qh)
+        md.qpos[:], md.qvel[:] = qpos, qvel
+        mujoco.mj_forward(mm, md)
+        o = OracleSim(ball)
+        o.set_state(qpos, qvel)
+        assert o.geti("nefc") == md.nefc and md.nefc > 0
+        np.testing.assert_allclose(np.sort(o.get("efc_pos")), np.sort(md.efc_pos[:md.nefc]), atol=1e-10)
+        np.testing.assert_allclose(np.sort(o.get("efc_R")), np.sort(md.efc_R[:md.nefc]), rtol=1e-7)
+        np.testing.assert_allclose(np.sort(o.get("efc_aref")), np.sort(md.efc_aref[:md.nefc]), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o.get("qacc"), md.qacc, rtol=1e-5, atol=1e-5)
+
+
+def test_humanoid_with_free_objects_tracks_mujoco(model, standing):
+    """Round 4: the env layer's objects (free bodies appended behind the humanoid, uhc/smpllib/smpl_robot.py:1200-1252): contacts between
+    boxes, humanoid and floor through MuJoCo's own mesh collider vs this build's plane-mesh rule and MPR, 30 control steps."""
+    from oracle.physics import OracleSim
+    from tests.helpers import box_triangles
+    from uhc_amd.model.mjcf import add_free_bodies, self_collision_variant
+    from uhc_amd.sim import make_ctrl
+    poses = np.array([[0.45, 0.0, 0.151, 1, 0, 0, 0], [-0.1, 0.5, 0.6, 0.9, 0.1, 0, 0]])
+    m = add_free_bodies(self_collision_variant(model), [box_triangles(0.15, 0.15, 0.15), box_triangles(0.1, 0.2, 0.08)], poses, density=400.0, friction=1.0, condim=3)
+    ctrl = make_ctrl(model)
+    mm, md = _mj(m)
+    qpos, qvel = np.r_[standing["qpos"], (poses / np.r_[np.ones(3), np.full(4, 1.0)]).ravel()], np.zeros(m.nv)
+    qpos[76 + 7 + 3:76 + 14] /= np.linalg.norm(qpos[76 + 7 + 3:76 + 14])
+    o = OracleSim(m, ctrl)
+    o.set_state(qpos, qvel)
+    oc = OracleSim(m, ctrl)
+    oc.set_state(qpos, qvel)
+    md.qpos[:], md.qvel[:] = qpos, qvel
+    mujoco.mj_forward(mm, md)
+    assert o.geti("ncon") == md.ncon
+    worst = 0.0
+    for step in range(30):
+        act = np.zeros(ctrl.action_dim)
+        for it in range(ctrl.n_substeps):
+            oc.set("qpos", md.qpos.copy()); oc.set("qvel", md.qvel.copy()); oc.set("qM", md.qM.copy()); oc.set("qfrc_bias", md.qfrc_bias.copy())
+            md.ctrl[:] = oc.pd_torque(act, standing["qpos"][7:], it)
+            md.qfrc_applied[:] = oc.rfc_implicit(act)
+            mujoco.mj_step(mm, md)
+        o.do_simulation(act, standing["qpos"][7:])
+        worst = max(worst, np.abs(o.get("qpos") - md.qpos).max())
+    assert worst < 1e-4, worst

@@ -663,3 +663,59 @@ def test_ball_joint_free_flight_conserves_angular_momentum(model, standing):
             s.step()
         errs.append(np.abs(ang_mom() - L0).max() / np.abs(L0).max())
     assert errs[0] < 2e-2 and errs[0] / errs[1] == pytest.approx(2.0, rel=0.25)  # first-order integrator: the drift halves with the step
+
+
+BALL_PENDULUM_XML = """
+<mujoco>
+  <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
+  <option timestep="0.0005"/>
+  <default><geom contype="0" conaffinity="0" margin="0.001"/></default>
+  <asset><mesh name="bob" file="unused.stl"/></asset>
+  <worldbody>
+    <body name="arm" pos="0 0 2">
+      <joint name="ball" type="ball" pos="0 0 0" limited="true" range="0 0.5"/>
+      <geom type="mesh" mesh="bob"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def test_ball_joint_limit_row_and_cone():
+    """[MJ-ext] mj_instantiateLimit, ball joint: value = the rotation angle of the joint's quaternion, dist = max(range) - angle, ONE row
+    with Jacobian -axis on the three dofs, active when dist < margin; the soft limit then keeps a swinging ball pendulum inside its cone."""
+    from oracle.physics import OracleSim
+    from tests.helpers import box_triangles
+    from uhc_amd.model.mjcf import compile_mjcf
+    m = compile_mjcf(BALL_PENDULUM_XML, meshes={"bob": box_triangles(0.05, 0.05, 0.05, center=(0, 0, -0.5))})
+    assert (m.nq, m.nv) == (4, 3) and m.jnt_limited[0] == 1 and m.jnt_range[0] == pytest.approx([0, 0.5])
+    s = OracleSim(m)
+    axis = np.array([0.6, -0.48, 0.64])
+    for ang, active in ((0.3, False), (0.6, True), (-0.6, True), (2 * np.pi - 0.6, True), (0.5 - 1e-4, False), (0.5 + 1e-4, True)):
+        q = np.r_[np.cos(ang / 2), np.sin(ang / 2) * axis]
+        s.set_state(q, np.array([0.1, 0.2, -0.3]))
+        assert s.geti("nefc") == int(active), ang
+        if active:
+            wrapped = (ang + np.pi) % (2 * np.pi) - np.pi
+            J = s.get("efc_J").reshape(-1, 3)[0]
+            np.testing.assert_allclose(J, -np.sign(wrapped) * axis, atol=1e-12)
+            assert s.get("efc_pos")[0] == pytest.approx(0.5 - abs(wrapped), abs=1e-12)
+    # J . qvel = d(dist)/dt: integrate a tiny step and compare the change of the angle
+    ang = 0.7
+    q = np.r_[np.cos(ang / 2), np.sin(ang / 2) * axis]
+    w = np.array([0.4, -0.1, 0.25])
+    s.set_state(q, w)
+    J, pos0 = s.get("efc_J").reshape(-1, 3)[0].copy(), s.get("efc_pos")[0]
+    h = 1e-6
+    dq = np.r_[1.0, 0.5 * h * w]  # q <- q (x) exp(h w / 2), w in the child frame
+    qn = np.array([q[0] * dq[0] - q[1:] @ dq[1:], *(q[0] * dq[1:] + dq[0] * q[1:] + np.cross(q[1:], dq[1:]))])
+    s.set_state(qn / np.linalg.norm(qn), w)
+    assert (s.get("efc_pos")[0] - pos0) / h == pytest.approx(J @ w, abs=1e-5)
+    # a pendulum thrown sideways against its 0.5 rad cone: the soft limit stops it a little beyond (impedance width), nothing blows up
+    s.set_state(np.array([1.0, 0, 0, 0]), np.array([3.0, 0.75, 0.0]))
+    peak = 0.0
+    for _ in range(4000):
+        s.step()
+        qq = s.get("qpos")
+        peak = max(peak, 2 * np.arctan2(np.linalg.norm(qq[1:]), abs(qq[0])))
+    assert 0.5 < peak < 0.55 and s.geti("fail") == 0  # (the hinge limit above: 0.3 < peak < 0.33)

@@ -88,7 +88,7 @@ class UhcEnvDesc(C.Structure):
     _fields_ = [("obs_v", C.c_int32), ("has_shape", C.c_int32), ("env_episode_len", C.c_int32),
                 ("env_expert_trail_steps", C.c_int32), ("ee_body", C.c_int32 * 5), ("reward_v", C.c_int32),
                 ("body_diff_thresh", C.c_double), ("reward_weights", C.c_double * 16), ("jpos_diffw", _F64P),
-                ("fut_frames", C.c_int32), ("fut_skip", C.c_int32), ("obs_flags", C.c_int32), ("reward_jpos_diffw", _F64P), ("term_body", C.c_int32)]
+                ("fut_frames", C.c_int32), ("fut_skip", C.c_int32), ("obs_flags", C.c_int32), ("reward_jpos_diffw", _F64P), ("term_body", C.c_int32), ("num_obj", C.c_int32)]
 
 
 REWARD_KEYS = ("w_p", "w_v", "w_e", "w_c", "w_vf", "k_p", "k_v", "k_e", "k_c", "k_vf", "w_wp", "w_j", "k_wp", "k_j")
@@ -103,7 +103,8 @@ REWARD_PARTS = {0: 5, 1: 5, 2: 5, 3: 5, 4: 6, 5: 6}
 
 def env_desc(model, *, obs_v=2, has_shape=True, env_episode_len=100000, env_expert_trail_steps=0, body_diff_thresh=0.5,
              reward_weights=None, jpos_diffw=None, reward_v=0, fut_frames=10, fut_skip=10, obs_heading=False, root_deheading=False,
-             obs_phase=True, obs_vel="full", env_term_body="body") -> UhcEnvDesc:
+             obs_phase=True, obs_vel="full", env_term_body="body", num_obj=0) -> UhcEnvDesc:
+    """`model`: the HUMANOID's model (body names, weights); num_obj: free objects behind it in the batch's model (expert["num_obj"])."""
     from .smpllib.smpl_mujoco import SMPL_EE_NAMES, SMPLConverter
     d = UhcEnvDesc()
     d.obs_v, d.has_shape, d.env_episode_len, d.env_expert_trail_steps = obs_v, int(has_shape), int(env_episode_len), int(env_expert_trail_steps)
@@ -112,6 +113,7 @@ def env_desc(model, *, obs_v=2, has_shape=True, env_episode_len=100000, env_expe
     d.reward_v = int(reward_v)
     d.fut_frames, d.fut_skip = int(fut_frames), int(fut_skip)
     d.term_body = {"body": 0, "root": 1}[env_term_body]
+    d.num_obj = int(num_obj)
     d.obs_flags = int(bool(obs_heading)) | int(bool(root_deheading)) << 1 | int(bool(obs_phase)) << 2 | int(obs_vel == "root") << 3
     rw = dict(REWARD_DEFAULTS_V23) if reward_v >= 4 else dict(zip(REWARD_KEYS, REWARD_DEFAULTS))
     given = dict(reward_weights or {})

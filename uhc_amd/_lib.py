@@ -18,7 +18,7 @@ SYMBOLS = [
     "uhc_batch_field", "uhc_batch_set_state", "uhc_batch_simulate", "uhc_batch_forward", "uhc_batch_set_timing",
     "uhc_batch_kernel_time", "uhc_batch_set_overflow_mode", "uhc_batch_set_solver", "uhc_batch_set_kernel_path",
     "uhc_env_create", "uhc_env_free", "uhc_env_obs_dim", "uhc_env_field", "uhc_env_set_bank", "uhc_env_assign",
-    "uhc_env_reset", "uhc_env_step", "uhc_env_set_next", "uhc_env_auto_reset", "uhc_env_set_clip_models", "uhc_env_set_end_reward",
+    "uhc_env_reset", "uhc_env_step", "uhc_env_set_next", "uhc_env_auto_reset", "uhc_env_set_clip_models", "uhc_env_set_end_reward", "uhc_env_set_obj_pose",
     "uhc_rollout_act", "uhc_rollout_record", "uhc_filter_scratch_doubles", "uhc_filter_push", "uhc_filter_apply",
 ]
 
@@ -72,6 +72,7 @@ def lib():
     L.uhc_env_set_next.argtypes = [P, P, C.c_int32, P, P, P, P]
     L.uhc_env_auto_reset.argtypes = [P]
     L.uhc_env_set_clip_models.argtypes = [P, P]
+    L.uhc_env_set_obj_pose.argtypes = [P, P, C.c_int64]
     L.uhc_env_set_end_reward.argtypes = [P, C.c_double]
     L.uhc_env_step.argtypes = [P, P, P]
     I, D = C.c_int32, C.c_double

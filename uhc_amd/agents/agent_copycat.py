@@ -40,14 +40,17 @@ def create_logger(filename):
 
 
 class AgentCopycat(AgentPPO):
-    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None, shape_models=None, clip_model=None, body_provider=None):
+    def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None, shape_models=None, clip_model=None, body_provider=None,
+                 objects=None):
         """shape_models / clip_model: optional body shapes (models with the topology of the config's model) and the map clip key -> index
         into [config model] + shape_models: smpl_shape-style training where every clip runs on its own body.
         body_provider: callable (betas, gender) -> (vertices, joints, skin weights) feeding the shape -> model generator (default: the SMPL
         model files under <base_dir>/data/smpl when present): every clip then runs on the model generated from ITS beta and gender, as
-        the reference rebuilds its model at every load_expert (uhc/envs/humanoid_im.py:154-190)."""
+        the reference rebuilds its model at every load_expert (uhc/envs/humanoid_im.py:154-190).
+        objects: free objects behind every env's humanoid (VecHumanoidEnv(objects=): the meshes the reference's generator reads from
+        expert["obj_info"], uhc/smpllib/smpl_robot.py:1200-1252); every clip of the data set then carries `obj_pose` (T, 7 K)."""
         self.cfg = self.cc_cfg = cfg
-        self._shape_models, self._clip_model, self._body_provider = shape_models, clip_model, body_provider
+        self._shape_models, self._clip_model, self._body_provider, self._objects = shape_models, clip_model, body_provider, objects
         self.device, self.dtype, self.training = device, dtype, training
         self.max_freq = 50
         self.epoch = 0
@@ -72,6 +75,7 @@ class AgentCopycat(AgentPPO):
                          opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
                          policy_grad_clip=[(self.policy_net.parameters(), 40)], end_reward=cfg.end_reward, use_mini_batch=False,
                          mini_batch_size=0)
+        self.grad_wire_dtype = {"float32": torch.float32, "float64": torch.float64}[str(getattr(cfg, "grad_allreduce_dtype", "float64"))]
         if getattr(self, "_loaded_shared_filter", False):
             self.mark_running_state_shared()  # every rank loaded the same filter statistics: they are not new samples
 
@@ -95,7 +99,7 @@ class AgentCopycat(AgentPPO):
                     clips.update({k: dict(beta=tl.data["beta"][k], gender=tl.data["gender"][k]) for k in tl.data_keys})
                 models, self._clip_model = generate_shape_models(self.cfg.robot_cfg, clips, provider)
                 model, self._shape_models = models[0], models[1:]
-        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train", model=model, shape_models=self._shape_models)
+        self.env = VecHumanoidEnv(self.cfg, n_env=self.cfg.n_env, device=dev_index, mode="train", model=model, shape_models=self._shape_models, objects=self._objects)
         self.env.set_clip_bank_from_loader(self.data_loader, clip_model={k: v for k, v in self._clip_model.items() if k in set(self.data_loader.data_keys)} if self._clip_model else None)
 
     def setup_policy(self):
@@ -287,9 +291,8 @@ class AgentCopycat(AgentPPO):
         t2 = time.time()
         info = {"log": log, "T_sample": t1 - t0, "T_update": t2 - t1, "T_total": t2 - t0}
         if save_model and (self.epoch + 1) % cfg.save_n_epochs == 0:
-            if getattr(self, "rank", 0) == 0:
-                self.save_checkpoint(epoch)
-                info["log_eval"] = self.eval_policy(epoch)  # rank 0 evaluates (the process group is created with a long timeout for this)
+            self.save_checkpoint(epoch)  # (rank 0 writes)
+            info["log_eval"] = self.eval_policy(epoch)  # every rank evaluates its share of the clips (keys[rank::world]); the metrics are reduced
         self.sync_freq_dict()  # every iteration, as the reference merges its workers' histories after every sample(); eval-driven entries included
         if getattr(self, "rank", 0) == 0:
             self.log_train(info)
@@ -311,19 +314,35 @@ class AgentCopycat(AgentPPO):
 
     def sync_freq_dict(self):
         """Data-parallel runs: merge the per-clip success history of all ranks, as the reference merges its workers' (agent_copycat.py:
-        598-604: concatenate per key, keep the last `max_freq`), rank 0's evaluation entries included -- every rank then draws its next
+        598-604: concatenate per key, keep the last `max_freq`), the evaluation entries included -- every rank then draws its next
         windows from the same distribution.  Each rank contributes what it appended since the last merge; the history before that is
-        already common."""
+        already common.  On the wire: flat (clip index, value, first frame) float64 records, one count exchange + one padded all-gather
+        (tensors over RCCL / gloo, no pickling of Python objects on the host)."""
         if not _dist_on():
             return
         new = self.__dict__.setdefault("_freq_new", {})
-        parts = [None] * dist.get_world_size()
-        dist.all_gather_object(parts, new)
-        for k in self.freq_dict:
-            mine = len(new.get(k, []))
-            base = self.freq_dict[k][:len(self.freq_dict[k]) - mine] if mine else self.freq_dict[k]
-            add = [row for p in parts for row in p.get(k, [])]  # rank order: the same list on every rank
-            self.freq_dict[k] = (base + add)[-self.max_freq:]
+        keys = list(self.freq_dict.keys())  # the data set's clip keys: the same order on every rank
+        dev = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        rows = [[float(ki), float(r[0]), float(r[1])] for ki, k in enumerate(keys) for r in new.get(k, [])]
+        world = dist.get_world_size()
+        cnt = torch.tensor([len(rows)], dtype=torch.int64, device=dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        cnts = [int(c.item()) for c in cnts]
+        add = {k: [] for k in keys}
+        if max(cnts) > 0:
+            mine = torch.zeros(max(cnts), 3, dtype=torch.float64, device=dev)
+            if rows:
+                mine[:len(rows)] = torch.tensor(rows, dtype=torch.float64, device=dev)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            for p, c in zip(parts, cnts):  # rank order: the same list on every rank
+                for ki, v, fs in p[:c].cpu().tolist():
+                    add[keys[int(ki)]].append([v, int(fs)])
+        for k in keys:
+            mine_n = len(new.get(k, []))
+            base = self.freq_dict[k][:len(self.freq_dict[k]) - mine_n] if mine_n else self.freq_dict[k]
+            self.freq_dict[k] = (base + add[k])[-self.max_freq:]
         self._freq_new = {}
 
     def log_train(self, info):
@@ -336,12 +355,17 @@ class AgentCopycat(AgentPPO):
 
 # ---- evaluation (agent_copycat.py:354-494), batched: one env per test clip --------------------------------
 def _eval_policy(self, epoch=0, dump=False):
+    """agent_copycat.py:354-436.  Data-parallel: the clips of every loader are dealt out over the ranks (keys[rank::world]); the per-clip
+    metrics are summed over the ranks (one small all-reduce per loader) and every rank logs / returns the same global means; the
+    clip-success entries go into each rank's freq_dict contribution and reach the others with the next sync_freq_dict."""
     from collections import defaultdict
     cfg = self.cfg
     res_dicts = []
     names = ["mpjpe", "mpjpe_g", "accel_dist", "vel_dist", "succ", "reward", "root_dist", "pentration", "skate"]
+    world, rank = (dist.get_world_size(), dist.get_rank()) if _dist_on() else (1, 0)
     for loader in self.test_data_loaders:
-        cov = self.eval_seqs(loader.data_keys, loader)
+        keys = list(loader.data_keys)[rank::world]
+        cov = self.eval_seqs(keys, loader) if keys else {}
         for k, res in cov.items():
             if k in self.freq_dict:
                 self._freq_add(k, [[res["succ"][0], 0]] * (1 if res["succ"][0] else 3))
@@ -350,15 +374,28 @@ def _eval_policy(self, epoch=0, dump=False):
             for k, v in res.items():
                 if k in names:
                     m[k].append(v if np.ndim(v) == 0 else np.mean(v))
-        m = {k: float(np.mean(v)) for k, v in m.items()}
+        present = sorted(m.keys())
+        if world > 1:  # sums and counts of every metric over the ranks
+            dev = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor([[float(np.sum(m.get(k, []))), float(len(m.get(k, [])))] for k in names], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            m = {k: float(t[i, 0] / t[i, 1]) for i, k in enumerate(names) if t[i, 1] > 0}
+        else:
+            m = {k: float(np.mean(m[k])) for k in present}
         coverage = int(m["succ"] * loader.get_len())
-        self.logger.info(f"Coverage {loader.name} of {coverage} out of {loader.get_len()} | " + " \t".join(f"{k}: {v:.3f}" for k, v in m.items()))
+        if rank == 0:
+            self.logger.info(f"Coverage {loader.name} of {coverage} out of {loader.get_len()} | " + " \t".join(f"{k}: {v:.3f}" for k, v in m.items()))
         m.update({"mean_coverage": coverage / loader.get_len(), "num_coverage": coverage, "all_coverage": loader.get_len()})
         del m["succ"]
         res_dicts.append({f"coverage_{loader.name}": m})
         if dump:
             import joblib
-            joblib.dump(cov, osp.join(cfg.output_dir, f"{epoch}_{loader.name}_coverage_full.pkl"))
+            if world > 1:
+                parts = [None] * world
+                dist.all_gather_object(parts, cov)  # (the per-clip trajectories: evaluation dumps only)
+                cov = {k: v for p in parts for k, v in p.items()}
+            if rank == 0:
+                joblib.dump(cov, osp.join(cfg.output_dir, f"{epoch}_{loader.name}_coverage_full.pkl"))
     return res_dicts
 
 
@@ -372,9 +409,10 @@ def _eval_seqs(self, take_keys, loader):
     n = min(len(take_keys), cfg.n_env)
     ev = getattr(self, "_eval_envs", {}).get((loader.name, n))
     if ev is None:
-        ev = VecHumanoidEnv(cfg, n_env=n, device=self.env.device.index or 0, mode="test", model=self.env.model, shape_models=self.env.models[1:])
-        cm = getattr(self, "_clip_model", None)  # every clip is evaluated on its own body, as it is trained
-        ev.set_clip_bank_from_loader(loader, clip_model={k: cm[k] for k in loader.data_keys} if cm else None)
+        ev = VecHumanoidEnv(cfg, n_env=n, device=self.env.device.index or 0, mode="test", model=self.env.body_model, shape_models=self.env.body_models[1:],
+                            objects=self.env.objects)
+        cm = getattr(self, "_clip_model", None)  # every clip is evaluated on its own body, as it is trained (a clip the map does not name: body 0)
+        ev.set_clip_bank_from_loader(loader, clip_model={k: cm.get(k, 0) for k in loader.data_keys} if cm else None)
         self._eval_envs = getattr(self, "_eval_envs", {})
         self._eval_envs[(loader.name, n)] = ev
     ev.set_rfc_rate(self.env.rfc_rate)
@@ -399,9 +437,11 @@ def _eval_seqs(self, take_keys, loader):
         clip0 = np.array([starts[ev._clip_index[k]] for k in keys])
         t = np.zeros(m, dtype=int)
 
+        ql, bl = ev.qpos_lim, ev.body_lim  # the humanoid's part of qpos / of the bodies (objects come behind it)
+
         def snap():
-            q = ev.sim.field(S.F_QPOS)[:m].cpu().numpy()
-            x = ev.sim.field(S.F_XPOS)[:m].cpu().numpy()[:, 3:]
+            q = ev.sim.field(S.F_QPOS)[:m, :ql].cpu().numpy()
+            x = ev.sim.field(S.F_XPOS)[:m].cpu().numpy()[:, 3:3 * bl]
             gi = clip0 + np.minimum(t, lens - 1)
             g = frames[torch.from_numpy(gi).to(frames.device)].cpu().numpy()
             for e in np.nonzero(alive)[0]:
@@ -420,8 +460,8 @@ def _eval_seqs(self, take_keys, loader):
             for e in np.nonzero(alive)[0]:
                 rec["reward"][e].append(r[e])
             if done.any():
-                q = ev.sim.field(S.F_QPOS)[:m].cpu().numpy()
-                x = ev.sim.field(S.F_XPOS)[:m].cpu().numpy()[:, 3:]
+                q = ev.sim.field(S.F_QPOS)[:m, :ql].cpu().numpy()
+                x = ev.sim.field(S.F_XPOS)[:m].cpu().numpy()[:, 3:3 * bl]
                 gi = clip0 + np.minimum(t, lens - 1)
                 g = frames[torch.from_numpy(gi).to(frames.device)].cpu().numpy()
                 tele = []
@@ -441,6 +481,10 @@ def _eval_seqs(self, take_keys, loader):
                     fr = frames[torch.from_numpy(clip0[tele] + np.minimum(cur, lens[tele] - 1)).to(frames.device)]
                     # the expert pose in the model's own coordinates: hinge angles, or -- ball joints -- root pose + the joints' quaternions
                     qp, qv = S.expert_pose_of_frames(fr, ev.use_quat)
+                    if ev.num_obj:  # data.qpos[:qpos_lim] = expert pose (humanoid_im.py:902-905): the objects stay where they are
+                        ti = torch.from_numpy(tele).to(frames.device)
+                        qp = torch.cat([qp, ev.sim.field(S.F_QPOS)[ti, ql:]], 1)
+                        qv = torch.cat([qv, ev.sim.field(S.F_QVEL)[ti, ev.qvel_lim:]], 1)
                     ev.sim.set_state(qp.contiguous(), qv.contiguous(), torch.from_numpy(tele).to(torch.int32))
             t = t + 1
             state = self.running_state(ev.obs.to(self.dtype), update=False) if self.running_state is not None else ev.obs.to(self.dtype)

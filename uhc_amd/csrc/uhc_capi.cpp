@@ -24,7 +24,7 @@ UHC_DECL_LAUNCH(uhc_launch_m0_big) UHC_DECL_LAUNCH(uhc_launch_m1_big) UHC_DECL_L
 // mode 0: control step, 1: forward only, 2: kinematics only; tier 1: the fast kernel, 2: general, 3: large; dense: the model has body-body contacts
 static hipError_t uhc_launch_step(int mode, int tier, const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active,
                                   size_t lds_bytes, hipStream_t stream) {
-    const bool dense = A->cf.ndense > 0;
+    const bool dense = A->cf.ndense > 0 || A->ball_limits;  // (limited ball joints: the instantiation that carries their rows)
     const bool fast = tier == 1;
     if (A->list) return (tier == 3 ? uhc_launch_m0_big_q : uhc_launch_m0_gen_q)(A, d_action, d_tbase, d_active, lds_bytes, stream);  // queue consumers (mode 0, tiers 2 / 3)
     if (tier == 3) return (mode == 0 ? uhc_launch_m0_big : uhc_launch_m1_big)(A, d_action, d_tbase, d_active, lds_bytes, stream);
@@ -165,6 +165,7 @@ struct UhcBatch {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
     int n_models = 1;
+    int n_trailing_free = 0;  // free bodies at the end of the model (objects)
     // field table
     void* field_ptr[18] = {nullptr};
     int64_t field_count[18] = {0};
@@ -263,12 +264,18 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     HIP_OK(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail("uhc_batch_create: device %d not present (%d devices)", device_id, ndev);
     HIP_OK(hipSetDevice(device_id));
-    if (ctrl->action_type == 0 && d.nq != d.nv + 1) return fail("uhc_batch_create: PD control expects a free root + scalar joints");
-    if (ctrl->action_type == 0 && d.nu != d.nv - 6) return fail("uhc_batch_create: PD control expects one motor per non-root dof");
+    // free bodies at the end of the model (objects: a body under the world with one free joint and no children, after the humanoid)
+    int n_trail = 0;
+    for (int j = d.njnt - 1; j >= 1 && d.jnt_type[j] == UHC_JNT_FREE && d.body_parentid[d.jnt_bodyid[j]] == 0 && d.jnt_bodyid[j] == d.nbody - 1 - n_trail; j--) n_trail++;
+    // the stable-PD controller works on the humanoid's block of M (the reference cuts M to [:qvel_lim, :qvel_lim], humanoid_im.py:1021-1022;
+    // objects are separate trees, so the solve over all dofs gives the same humanoid accelerations)
+    if (ctrl->action_type == 0 && d.nq - 7 * n_trail != d.nv - 6 * n_trail + 1) return fail("uhc_batch_create: PD control expects a free root + scalar joints (+ free objects behind them)");
+    if (ctrl->action_type == 0 && d.nu != d.nv - 6 * n_trail - 6) return fail("uhc_batch_create: PD control expects one motor per non-root dof of the humanoid");
 
     UhcBatch* b = new UhcBatch();
     b->n_env = n_env;
     b->device = device_id;
+    b->n_trailing_free = n_trail;
     KernelArgs& A = b->A;
     memset(&A, 0, sizeof A);
     DevTopo& T = A.t;
@@ -282,6 +289,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     T.has_damping = 0;
     for (int k = 0; k < n_models; k++)
         for (int i = 0; i < nv; i++) T.has_damping |= models[k]->d.dof_damping[i] > 0;
+    for (int j = 0; j < d.njnt; j++) A.ball_limits |= d.jnt_type[j] == UHC_JNT_BALL && d.jnt_limited[j] != 0;
 
     // ---- derived topology tables
     std::vector<int> body_depth(nb, 0), body_rootid(nb, 0), body_nsub(nb, 1), body_lastdof(nb, -1);
@@ -944,6 +952,7 @@ extern "C" int uhc_internal_set_state_masked(UhcBatch* b, const int* d_select, c
     return 0;
 }
 
+extern "C" int uhc_internal_trailing_free(UhcBatch* b) { return b->n_trailing_free; }
 extern "C" int* uhc_internal_env_model(UhcBatch* b, int* n_models) { *n_models = b->n_models; return const_cast<int*>(b->A.s.env_model); }
 // ------------------------------------------------------------------ internal accessors for the env layer (uhc_env_capi.cpp)
 extern "C" int uhc_internal_set_error(const char* msg) { return fail("%s", msg); }

@@ -144,6 +144,7 @@ struct KernelArgs {
     int grid;  // workgroups of a list launch (0: one per env)
     int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
+    int ball_limits;  // the model has limited ball joints: the fast tier launches its DENSE instantiation (which carries the ball-limit rows)
     int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step, bit 7 = no box cull of the convex pairs
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     int adjdeg;              // stride of the per-model hull adjacency table (largest vertex degree over the batch's models)

@@ -17,6 +17,10 @@
 struct EnvArgs {
     int n_env, nq, nv, nu, nbody, action_dim, vf_dim, obs_dim, obs_v, reward_v, has_shape, env_episode_len, expert_trail_steps, fut_frames, fut_skip, obs_flags, term_body;
     int ball;  // the humanoid has ball joints (robot.ball, `use_quat` in the reference): qpos = root position + nbody - 1 quaternions
+    // free objects behind the humanoid (expert["obj_pose"], humanoid_im.py:1284-1287): n_obj free bodies at the END of the model; the
+    // humanoid's own extents -- the reference's qpos_lim / qvel_lim / body_lim (humanoid_im.py:113-115) -- are nqh / nvh / nbh
+    int n_obj, nqh, nvh, nbh;
+    const double* obj_pose;   // [n_frames][7 n_obj], one row per frame of the bank (uhc_env_set_obj_pose), or NULL
     int ee_body[5];
     double dt, body_diff_thresh;
     double rw[16];            // w_p w_v w_e w_c w_vf k_p k_v k_e k_c k_vf | w_wp w_j k_wp k_j

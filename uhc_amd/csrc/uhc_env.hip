@@ -95,8 +95,8 @@ template <int MODE>
 __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const double* __restrict__ d_action, const int* __restrict__ d_active) {
     const int env = blockIdx.x;
     if (env >= E.n_env || (d_active && !d_active[env])) return;
-    __shared__ double s_qpos[128], s_prev[128], s_q[4 * 32];
-    const int nb = E.nbody - 1;  // bodies without the world
+    __shared__ double s_qpos[192], s_prev[192], s_q[4 * 32];
+    const int nb = E.nbh - 1;  // the humanoid's bodies without the world (objects, if any, come after them: body_lim)
     const double* qpos_g = E.qpos + (size_t)env * E.nq;
     for (int i = LANE; i < E.nq; i += WAVE) { s_qpos[i] = qpos_g[i]; if (MODE == 0) s_prev[i] = E.qpos_prev[(size_t)env * E.nq + i]; }
     __syncthreads();
@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
     if (E.obs_v == 0) {
         // get_full_obs (:290-317): raw root quaternion (no base-rotation removal), expert joint angles of the CURRENT frame, phase
         const double* fr0 = bank0 + (size_t)expert_index(cur_t, start_ind, len) * UHC_FRAME_STRIDE;
-        const int oh = E.obs_flags & 1, nvel = (E.obs_flags & 8) ? 6 : E.nv;
-        const int oq = oh, ov = oq + E.nq - 2, oe = ov + nvel, op = oe + E.nu;
+        const int oh = E.obs_flags & 1, nvel = (E.obs_flags & 8) ? 6 : E.nvh;
+        const int oq = oh, ov = oq + E.nqh - 2, oe = ov + nvel, op = oe + E.nu;
         if (LANE == 0) {
             double v0[3], dh[4];
             if (oh) obs[0] = heading(rootq);
@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             rotT(v1, Rc, qv);
             for (int k = 0; k < 3; k++) obs[8 + k] = v1[k];
         }
-        for (int i = LANE + 3; i < E.nv; i += WAVE) obs[8 + i] = qvel[i];
-        const int o1 = 8 + E.nv, o2 = o1 + 2 * nb, o3 = o2 + 3 * (nb - 1), o4 = o3 + 4 * (nb - 1);
+        for (int i = LANE + 3; i < E.nvh; i += WAVE) obs[8 + i] = qvel[i];
+        const int o1 = 8 + E.nvh, o2 = o1 + 2 * nb, o3 = o2 + 3 * (nb - 1), o4 = o3 + 4 * (nb - 1);
         if (LANE < nb) {
             const int b = LANE;
             double d[3], r[3];
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             const double t = fr[UHC_FR_QPOS + 7 + i], c = s_qpos[7 + i];
             obs[9 + i] = t; obs[83 + i] = c; obs[157 + i] = t - c;
         }
-        for (int i = LANE + 3; i < E.nv; i += WAVE) obs[226 + i] = qvel[i];
+        for (int i = LANE + 3; i < E.nvh; i += WAVE) obs[226 + i] = qvel[i];
         const int qb = 304 + (E.obs_v == 1 ? 12 : 6) * nb;   // v1 inserts the two body-COM blocks before the quaternions
         if (LANE < nb) {
             const int b = LANE;
@@ -423,12 +423,14 @@ __global__ void uhc_env_reset_stage_kernel(EnvArgs E, const int* env_ids, int n,
     // the expert velocity of a window's first frame is a copy of its second frame's finite difference
     // (torch_smpl_humanoid.py:202-207: qvel = cat(qvel[0:1], qvel)); the bank stores whole clips, so read frame 1
     const double* frv = fr + (E.e_len[env] > 1 ? UHC_FRAME_STRIDE : 0);
+    // objects: init_pose = concat(expert pose, obj_pose[ind]), init_vel = concat(expert velocity, zeros) (humanoid_im.py:1284-1287)
+    const double* op = E.obj_pose + (size_t)E.e_start[env] * 7 * E.n_obj;
     for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
-        double v = expert_qpos(fr, i, E.ball);
-        if (noise && i >= 7 && !E.ball) v += noise[(size_t)r * E.nu + (i - 7)];  // (the init noise is defined on joint angles)
+        double v = i < E.nqh ? expert_qpos(fr, i, E.ball) : op[i - E.nqh];
+        if (noise && i >= 7 && i < E.nqh && !E.ball) v += noise[(size_t)r * E.nu + (i - 7)];  // (the init noise is defined on joint angles)
         out_qpos[(size_t)r * E.nq + i] = v;
     }
-    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = frv[UHC_FR_QVEL + i];
+    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)r * E.nv + i] = i < E.nvh ? frv[UHC_FR_QVEL + i] : 0.0;
     if (threadIdx.x == 0) { E.cur_t[env] = 0; E.start_ind[env] = 0; E.done[env] = 0; E.fail[env] = 0; E.end[env] = 0; E.episode[env] = 0.0; E.episode[E.n_env + env] = 0.0; }
 }
 extern "C" hipError_t uhc_launch_env_reset_stage(const EnvArgs* E, const int* env_ids, int n, const double* noise, double* out_qpos,
@@ -501,12 +503,13 @@ __global__ void uhc_env_auto_stage_kernel(EnvArgs E, double* out_qpos, double* o
     __syncthreads();
     const double* fr = E.bank + (size_t)E.e_start[env] * UHC_FRAME_STRIDE;
     const double* frv = fr + (E.e_len[env] > 1 ? UHC_FRAME_STRIDE : 0);
+    const double* op = E.obj_pose + (size_t)E.e_start[env] * 7 * E.n_obj;
     for (int i = threadIdx.x; i < E.nq; i += blockDim.x) {
-        double v = expert_qpos(fr, i, E.ball);
-        if (had && i >= 7 && !E.ball) v += E.next_noise[(size_t)env * E.nu + (i - 7)];
+        double v = i < E.nqh ? expert_qpos(fr, i, E.ball) : op[i - E.nqh];
+        if (had && i >= 7 && i < E.nqh && !E.ball) v += E.next_noise[(size_t)env * E.nu + (i - 7)];
         out_qpos[(size_t)env * E.nq + i] = v;
     }
-    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)env * E.nv + i] = frv[UHC_FR_QVEL + i];
+    for (int i = threadIdx.x; i < E.nv; i += blockDim.x) out_qvel[(size_t)env * E.nv + i] = i < E.nvh ? frv[UHC_FR_QVEL + i] : 0.0;
 }
 extern "C" hipError_t uhc_launch_env_auto_stage(const EnvArgs* E, double* out_qpos, double* out_qvel, int* select, hipStream_t s) {
     hipLaunchKernelGGL(uhc_env_auto_stage_kernel, dim3(E->n_env), dim3(WAVE), 0, s, *E, out_qpos, out_qvel, select);

@@ -23,6 +23,7 @@ extern "C" hipError_t uhc_launch_env_assign(const EnvArgs* E, const int* env_ids
 extern "C" int uhc_internal_batch_info(UhcBatch* b, int* n_env, int* nq, int* nv, int* nu, int* nbody, int* action_dim, int* vf_dim,
                                        double* dt, double* base_rot_inv, void** stream, int** reset_mask);
 extern "C" int uhc_internal_set_error(const char* msg);
+extern "C" int uhc_internal_trailing_free(UhcBatch* b);
 
 #define HIP_OK(expr)                                                                                   \
     do {                                                                                               \
@@ -63,10 +64,16 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     void* stream;
     int* mask;
     uhc_internal_batch_info(b, &E.n_env, &E.nq, &E.nv, &E.nu, &E.nbody, &E.action_dim, &E.vf_dim, &E.dt, E.base_rot_inv, &stream, &mask);
-    const int nb = E.nbody - 1;
-    // ball-joint humanoid (robot.ball): free root + one ball joint per further body; nothing else in the model (no objects in the env layer)
-    E.ball = E.nq == 7 + 4 * (nb - 1) && E.nv == 6 + 3 * (nb - 1) && nb > 1 && E.nq != E.nv + 1;
-    if ((E.nq != E.nv + 1 && !E.ball) || E.nq > 128) { delete e; return uhc_internal_set_error("uhc_env_create: hinge humanoid (free root + scalar joints) or ball-joint humanoid (free root + one ball joint per body), nq <= 128, expected"); }
+    // free objects (expert["obj_pose"], humanoid_im.py:1284-1287): the LAST num_obj bodies of the model, one free joint each; what is in front of
+    // them is the humanoid -- the reference's qpos_lim / qvel_lim / body_lim (humanoid_im.py:113-115), which its observations, rewards and
+    // termination stop at
+    E.n_obj = d->num_obj;
+    if (E.n_obj < 0 || E.n_obj > uhc_internal_trailing_free(b)) { delete e; return uhc_internal_set_error("uhc_env_create: num_obj exceeds the free bodies at the end of the model"); }
+    E.nqh = E.nq - 7 * E.n_obj; E.nvh = E.nv - 6 * E.n_obj; E.nbh = E.nbody - E.n_obj;
+    const int nb = E.nbh - 1;
+    // ball-joint humanoid (robot.ball): free root + one ball joint per further body
+    E.ball = E.nqh == 7 + 4 * (nb - 1) && E.nvh == 6 + 3 * (nb - 1) && nb > 1 && E.nqh != E.nvh + 1;
+    if ((E.nqh != E.nvh + 1 && !E.ball) || E.nq > 192 || nb < 1 || nb > 64) { delete e; return uhc_internal_set_error("uhc_env_create: hinge humanoid (free root + scalar joints) or ball-joint humanoid (free root + one ball joint per body), followed by num_obj free bodies, nq <= 192, expected"); }
     if (E.ball && (d->obs_v != 2 || d->reward_v != 0)) { delete e; return uhc_internal_set_error("uhc_env_create: the ball-joint env has observation v2 (get_full_obs_v2_quat) and reward 0 (world_rfc_implicit_quat)"); }
     E.has_shape = d->has_shape;
     E.obs_v = d->obs_v;
@@ -74,9 +81,9 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
     E.obs_flags = d->obs_flags;
     E.term_body = d->term_body;
     if (d->obs_v == 0)  // [heading] qpos[2:] velocities expert joint angles [phase]; get_full_obs never appends the shape
-        E.obs_dim = (d->obs_flags & 1) + (E.nq - 2) + ((d->obs_flags & 8) ? 6 : E.nv) + E.nu + ((d->obs_flags >> 2) & 1);
+        E.obs_dim = (d->obs_flags & 1) + (E.nqh - 2) + ((d->obs_flags & 8) ? 6 : E.nvh) + E.nu + ((d->obs_flags >> 2) & 1);
     else
-        E.obs_dim = (d->obs_v == 6 ? 8 + E.nv + 2 * nb + 11 * (nb - 1) : (d->obs_v == 5 ? 300 : 304) + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
+        E.obs_dim = (d->obs_v == 6 ? 8 + E.nvh + 2 * nb + 11 * (nb - 1) : (d->obs_v == 5 ? 300 : 304) + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
     if (E.ball) E.obs_dim = 7 + 4 * nb + (E.nu + 6) + 3 + 6 * nb + 8 * nb + (d->has_shape ? 17 : 0);  // get_full_obs_v2_quat (:668-756)
     if (d->obs_v == 0) E.has_shape = 0;
     E.fut_frames = d->obs_v == 3 ? d->fut_frames : 1;
@@ -150,6 +157,14 @@ extern "C" int32_t uhc_env_set_bank(UhcEnv* e, const double* d_frames, int64_t n
     if (!e || !d_frames || !d_clip_start || !d_clip_beta || n_frames < 1 || n_clips < 1) return uhc_internal_set_error("uhc_env_set_bank: bad argument");
     e->E.bank = d_frames; e->E.clip_start = d_clip_start; e->E.clip_beta = d_clip_beta;
     e->n_clips = n_clips; e->n_frames = n_frames;
+    e->E.obj_pose = nullptr;  // rows of another bank
+    return 0;
+}
+extern "C" int32_t uhc_env_set_obj_pose(UhcEnv* e, const double* d_obj_pose, int64_t n_frames) {
+    if (!e) return uhc_internal_set_error("uhc_env_set_obj_pose: null env");
+    if (e->E.n_obj == 0) return d_obj_pose ? uhc_internal_set_error("uhc_env_set_obj_pose: the env was created with num_obj = 0") : 0;
+    if (!d_obj_pose || !e->E.bank || n_frames != e->n_frames) return uhc_internal_set_error("uhc_env_set_obj_pose: one row of 7 num_obj numbers per frame of the clip bank (set the bank first)");
+    e->E.obj_pose = d_obj_pose;
     return 0;
 }
 extern "C" int32_t uhc_env_set_clip_models(UhcEnv* e, const int32_t* d_clip_model) {
@@ -175,6 +190,7 @@ extern "C" int32_t uhc_env_assign(UhcEnv* e, const int32_t* ids, int32_t n, cons
 extern "C" int32_t uhc_env_reset(UhcEnv* e, const int32_t* ids, int32_t n, const double* d_noise) {
     if (!e || !ids || n < 1 || n > e->E.n_env) return uhc_internal_set_error("uhc_env_reset: bad argument");
     if (!e->E.bank) return uhc_internal_set_error("uhc_env_reset: no clip bank set");
+    if (e->E.n_obj > 0 && !e->E.obj_pose) return uhc_internal_set_error("uhc_env_reset: the model has objects but no obj_pose rows are set (uhc_env_set_obj_pose)");
     hipStream_t s = stream_of(e);
     HIP_OK(uhc_launch_env_reset_stage(&e->E, ids, n, d_noise, e->stage_qpos, e->stage_qvel, s));
     if (uhc_batch_set_state(e->b, ids, n, e->stage_qpos, e->stage_qvel)) return 1;  // set_state + forward on those envs
@@ -198,6 +214,7 @@ extern "C" int32_t uhc_env_set_end_reward(UhcEnv* e, double end_reward) {
 extern "C" int32_t uhc_env_auto_reset(UhcEnv* e) {
     if (!e) return uhc_internal_set_error("uhc_env_auto_reset: null env");
     if (!e->E.bank) return uhc_internal_set_error("uhc_env_auto_reset: no clip bank set");
+    if (e->E.n_obj > 0 && !e->E.obj_pose) return uhc_internal_set_error("uhc_env_auto_reset: the model has objects but no obj_pose rows are set (uhc_env_set_obj_pose)");
     hipStream_t s = stream_of(e);
     HIP_OK(uhc_launch_env_auto_stage(&e->E, e->stage_qpos, e->stage_qvel, e->select, s));
     if (uhc_internal_set_state_masked(e->b, e->select, e->stage_qpos, e->stage_qvel)) return 1;

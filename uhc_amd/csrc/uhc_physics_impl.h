@@ -809,6 +809,21 @@ __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const doubl
     C[18] = mb[A.o.body_invweight0 + 2 * b1] + mb[A.o.body_invweight0 + 2 * b2];
     C[19] = b1; C[20] = b2; C[21] = dim;
 }
+// [MJ-ext] mj_instantiateLimit, ball joint: the joint's rotation as angle * axis (mju_quat2Vel with dt = 1: axis = the unit quaternion's
+// vector part normalised, angle = 2 atan2(|vector part|, w) taken into (-pi, pi]); value = |angle|, dist = max(range) - value.  Returns dist
+// and the row's Jacobian on the joint's three dofs, -axis of the rotation as it is signed (jac).
+__device__ __forceinline__ double ball_limit(const double* qp, const double* range, double* jac) {
+    double q[4] = {qp[0], qp[1], qp[2], qp[3]}, ax[3] = {1, 0, 0};
+    quat_normalize(q);
+    double sn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (sn < UHC_MINVAL) sn = 0; else { ax[0] = q[1] / sn; ax[1] = q[2] / sn; ax[2] = q[3] / sn; }
+    double ang = 2 * atan2(sn, q[0]);
+    if (ang > M_PI) ang -= 2 * M_PI;
+    double value = fabs(ang), sg = ang < 0 ? -1.0 : 1.0;
+    if (value < UHC_MINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; sg = 1; value = 0; }
+    for (int k = 0; k < 3; k++) jac[k] = -sg * ax[k];
+    return fmax(range[0], range[1]) - value;
+}
 // returns ncon (wave-uniform)
 template <int TIER, bool DENSE>
 __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb, double* S, int* overflow, const PairConst& PC PROF_ARGS) {
@@ -880,7 +895,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 }
                 bd = mn; bv = cand;
             }
-            if (bd > margin) continue;
+            if (bd > margin || bv == 0x7fffffff) continue;
             // candidate 0 = support vertex, candidates 1.. = its hull neighbours (adjacency order)
             // (the hull graph belongs to the env's model: body shapes generated from different betas have different hulls.  Fixed-stride
             //  table of neighbour ids in the model blob, -1 past a vertex's own degree)
@@ -1039,18 +1054,22 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     // (2) joint limits: lower side then upper side of each joint, joints in order
     for (int j0 = 0; j0 < T.njnt; j0 += UHC_WAVE) {
         const int j = j0 + LANE;
-        bool lo = false, hi = false;
+        bool lo = false, hi = false, ball = false;
         if (j < T.njnt && T.jnt_limited[j]) {
             const int jt = T.jnt_type[j];
             if (jt == UHC_JNT_HINGE || jt == UHC_JNT_SLIDE) {
                 const double v = S[L.qpos + T.jnt_qposadr[j]], mg = mb[A.o.jnt_margin + j];
                 lo = (v - mb[A.o.jnt_range + 2 * j]) < mg;
                 hi = (mb[A.o.jnt_range + 2 * j + 1] - v) < mg;
+            } else if (jt == UHC_JNT_BALL) {  // one row: the rotation angle against max(range); the row ends at the joint's third dof
+                double jac[3];
+                ball = true;
+                lo = ball_limit(S + L.qpos + T.jnt_qposadr[j], mb + A.o.jnt_range + 2 * j, jac) < mb[A.o.jnt_margin + j];
             }
         }
         const unsigned long long ml = __ballot(lo), mh = __ballot(hi), below = (1ull << LANE) - 1ull;
         int r = nefc + __popcll(ml & below) + __popcll(mh & below);
-        if (lo) { if (r < cap_of<TIER>(A).maxefc) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = -1; } r++; }
+        if (lo) { if (r < cap_of<TIER>(A).maxefc) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j] + (ball ? 2 : 0); RM[r].aux = j; RM[r].edge = ball ? 2 : -1; } r++; }
         if (hi) { if (r < cap_of<TIER>(A).maxefc) { RM[r].type = ROW_LIMIT; RM[r].last = T.jnt_dofadr[j]; RM[r].aux = j; RM[r].edge = 1; } }
         nefc += __popcll(ml) + __popcll(mh);
     }
@@ -1213,7 +1232,16 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
             const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
             K = 1.0 / (dmax * dmax * timeconst * timeconst);
             B = 2.0 / (dmax * timeconst);
-            if (rt == ROW_LIMIT) {
+            int inv_dof = last;
+            if (rt == ROW_LIMIT && rm.edge == 2) {  // ball joint: Jacobian -axis on its three dofs (the last three positions of the chain)
+                const int j = rm.aux;
+                double jac[3];
+                margin = mb[A.o.jnt_margin + j];
+                pos = ball_limit(S + L.qpos + T.jnt_qposadr[j], mb + A.o.jnt_range + 2 * j, jac);
+                for (int q = 0; q < len; q++) Y[q] = 0;
+                Y[len - 3] = jac[0]; Y[len - 2] = jac[1]; Y[len - 1] = jac[2];
+                inv_dof = T.jnt_dofadr[j];
+            } else if (rt == ROW_LIMIT) {
                 const int j = rm.aux;
                 const double v = S[L.qpos + T.jnt_qposadr[j]];
                 margin = mb[A.o.jnt_margin + j];
@@ -1225,7 +1253,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
                 for (int q = 0; q < len; q++) Y[q] = 0;
                 Y[len - 1] = 1;
             }
-            diagApprox = mb[A.o.dof_invweight0 + last];
+            diagApprox = mb[A.o.dof_invweight0 + inv_dof];
             imp = impedance(dsolimp, pos, margin);
         } else {
             const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
@@ -1464,13 +1492,23 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     }
     const bool is_con = valid && (rm.type == ROW_CONTACT || rm.type == ROW_PYR);
     double pos = 0, margin = 0, diagApprox = 0, K = 0, B = 0, imp = 1, floss = 0, unit = 0;
+    double unit1 = 0, unit2 = 0;  // ball-joint limit rows: the Jacobian entries of chain positions len - 2 and len - 3 (DENSE instantiations only:
+                                  // a model with limited ball joints is launched on them, KernelArgs::ball_limits)
     double off[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
     if (valid && !is_con) {
         const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
         const double timeconst = fmax(0.02, 2 * T.timestep), dmax = 0.95;
         K = 1.0 / (dmax * dmax * timeconst * timeconst);
         B = 2.0 / (dmax * timeconst);
-        if (rm.type == ROW_LIMIT) {
+        int inv_dof = rm.last;
+        if (DENSE && rm.type == ROW_LIMIT && rm.edge == 2) {
+            const int j = rm.aux;
+            double jac[3];
+            margin = mb[A.o.jnt_margin + j];
+            pos = ball_limit(S + L.qpos + T.jnt_qposadr[j], mb + A.o.jnt_range + 2 * j, jac);
+            unit2 = jac[0]; unit1 = jac[1]; unit = jac[2];
+            inv_dof = T.jnt_dofadr[j];
+        } else if (rm.type == ROW_LIMIT) {
             const int j = rm.aux;
             const double v = S[L.qpos + T.jnt_qposadr[j]];
             margin = mb[A.o.jnt_margin + j];
@@ -1480,7 +1518,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
             floss = mb[A.o.dof_frictionloss + rm.last];
             unit = 1;
         }
-        diagApprox = mb[A.o.dof_invweight0 + rm.last];
+        diagApprox = mb[A.o.dof_invweight0 + inv_dof];
         imp = impedance(dsolimp, pos, margin);
     } else if (is_con) {
         const double* C = S + L.con + rm.aux * UHC_CON_STRIDE;
@@ -1534,7 +1572,9 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
             for (int t = 0; t < 6; t++) cd[t] = S[L.cdof + 6 * i + t];
             cross3(cr, cd, off);
             const double yc = dv[0] * (cd[3] + cr[0]) + dv[1] * (cd[4] + cr[1]) + dv[2] * (cd[5] + cr[2]);
-            const double y = q < len ? (is_con ? yc : (q == len - 1 ? unit : 0.0)) : 0.0;
+            double yu = q == len - 1 ? unit : 0.0;
+            if constexpr (DENSE) yu = q == len - 2 ? unit1 : (q == len - 3 ? unit2 : yu);
+            const double y = q < len ? (is_con ? yc : yu) : 0.0;
             Y[q] = y;
             vel = fma(y, S[L.qvel + i], vel);
             jas = fma(y, S[L.smooth + i], jas);
@@ -2509,9 +2549,18 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         return;
     }
     if (MODE == 1) {
-        fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
-        overflow |= fo.overflow;
-        ran = true;
+        // set_state + sim.forward(): a pose that is not a pose (NaN, beyond +-1e10: what mj_checkPos / mj_checkVel reject at the head of
+        // mj_step [MJ-ext]) never enters the forward pass -- the env is flagged `fail` and left as it was handed over (the reference turns
+        // MuJoCo's warning into `fail`, uhc/envs/humanoid_im.py:1207-1211); every stage behind this line sees finite inputs
+        int b = 0;
+        for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
+        for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
+        if (wave_or(b)) fail = 1;
+        else {
+            fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+            overflow |= fo.overflow;
+            ran = true;
+        }
     } else if (!fail) {
         const double* action = d_action + (size_t)env * A.c.action_dim;
         const double* tbase = d_tbase + (size_t)env * T.nu;
@@ -2530,11 +2579,11 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             if (A.c.rfc_mode == 1) k_rfc_implicit<TIER>(A, S, action);
             else if (A.c.rfc_mode == 2) k_rfc_explicit<TIER>(A, S, action);
             }
-            // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler
+            }
+            // mj_step: checkPos / checkVel -> forward -> checkAcc -> Euler  (also ahead of the forward pass a device-side restart still owes)
             for (int i = LANE; i < T.nq; i += UHC_WAVE) b |= bad(S[L.qpos + i]);
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
-            }
             PROF(0)
             fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
             PROF(13)
@@ -2577,12 +2626,14 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             __threadfence();  // (the queue append below publishes the env: its state must be visible first)
         }
         if (LANE == 0) {
+            // flagged for the chained launch of the next tier, which takes whatever no consumer took (none running, or given up) -- BEFORE the
+            // env is published: a consumer that claims and finishes it clears the flag, and that clear must be the last write
+            if (TIER == 1) A.s.pend2[env] = 1; else { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
+            __threadfence();
             if (A.q_next) {  // the next tier's consumers are running beside this launch: straight into their queue
                 const int k = atomicAdd(A.q_next_count, 1);
                 __hip_atomic_store(A.q_next + k, env, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // ... and flagged for the chained launch of the next tier, which takes whatever no consumer took (none running, or given up)
-            if (TIER == 1) A.s.pend2[env] = 1; else { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
             if (TIER == 1 && MODE == 0) atomicAdd(A.s.path_stats, 1ull);
         }
         TRACE(2 * (TIER - 1) + 1, wall_clock64())
@@ -2652,7 +2703,8 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             A.s.tier[env] = next;
             A.s.cost[env] = max(pk_nefc, max(pk_ncon * (UHC_FAST_MAXEFC / UHC_FAST_MAXCON), (pk_ntwo * UHC_FAST_MAXEFC) / UHC_FAST_MAXTWO));
         }
-        if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | swept;
+        if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | ((overflow & 2) ? 0x80 : 0) | swept;
+        else if (overflow & 2) A.s.redo[env] = 0x80;  // (fast tier in truncate mode; bit 7 = rows / contacts were dropped in this step)
         if (TIER != 1 && MODE == 0) {
             atomicAdd(A.s.path_stats + 2, 1ull);
             if (fits) atomicAdd(A.s.path_stats + 1, 1ull);

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/uhc_amd.h"  // (declares the entry points below with default visibility: the library is built -fvisibility=hidden)
+
 #include <string>
 
 #define WAVE 64
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(1024) uhc_rollout_record_kernel(int n_env, int
     const long long t = t_dev[0];
     if (t < 0 || t >= T) return;  // (uniform: every thread reads the same counter)
     const double er = end_reward[0];
-    double acc[11];  // reward, up to 8 reward terms, two env counts (exact in float64)
-    const int nacc = n_parts + 3;
+    double acc[13];  // reward, up to 8 reward terms, four env counts (exact in float64)
+    const int nacc = n_parts + 5;
     for (int k = 0; k < nacc; k++) acc[k] = 0.0;
     for (int e = tid; e < n_env; e += blockDim.x) {
         const double r = reward[e];
@@ -71,8 +73,10 @@ __global__ void __launch_bounds__(1024) uhc_rollout_record_kernel(int n_env, int
         acc[0] += r;
         for (int k = 0; k < n_parts; k++) acc[1 + k] += parts[(size_t)e * parts_stride + k];
         if (redo) {  // UHC_F_REDO of the step: computed by the general kernel / its exact contact solve fell back to sweeps
-            acc[n_parts + 1] += redo[e] != 0;
+            acc[n_parts + 1] += (redo[e] & 1) != 0;
             acc[n_parts + 2] += (redo[e] & 2) != 0;
+            acc[n_parts + 3] += (redo[e] & 0x80) != 0;  // rows / contacts beyond the last tier's capacity were dropped in THIS step
+            acc[n_parts + 4] += (redo[e] & 0x40) != 0;  // computed by the large tier
         }
     }
     for (int k = 0; k < nacc; k++) {

@@ -9,7 +9,10 @@ from scipy.spatial.transform import Rotation as sRot
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
 
 
-def make_synthetic_amass(n_clips=64, seed=1, t_range=(150, 300), amp=0.3, root_height=0.91437225, model_root_z=0.0282):
+def make_synthetic_amass(n_clips=64, seed=1, t_range=(150, 300), amp=0.3, root_height=0.91437225, model_root_z=0.0282, objects=0, obj_seed=11):
+    """objects: K > 0 adds `obj_pose` (T, 7 K) to every clip -- where a reset puts K free objects (the reference's GRAB clips carry the
+    objects' recorded trajectory there; a reset reads the window's first row, uhc/envs/humanoid_im.py:1284-1287): K poses on a circle of
+    0.75 m around the humanoid, stacked in height (objects dropped around each humanoid, default_rng(11))."""
     z = np.load(os.path.join(_ASSETS, "standing_neutral.npz"))
     base = z["pose_aa"][10].copy()
     rng = np.random.default_rng(seed)
@@ -30,6 +33,11 @@ def make_synthetic_amass(n_clips=64, seed=1, t_range=(150, 300), amp=0.3, root_h
         pose_6d = R[..., :2].transpose(0, 1, 3, 2).reshape(T, 144)
         out[f"0-synth_{c:04d}"] = {"pose_aa": pose, "pose_6d": pose_6d, "trans": trans, "beta": rng.normal(scale=0.5, size=10),
                                   "gender": "neutral", "seq_name": f"0-synth_{c:04d}"}
+        if objects:
+            orng = np.random.default_rng(obj_seed + c)
+            ang = orng.uniform(0, 2 * np.pi, size=objects)
+            row = np.concatenate([np.r_[-0.15 + 0.75 * np.cos(a), -0.05 + 0.75 * np.sin(a), 0.3 + 0.45 * k, 1.0, 0.0, 0.0, 0.0] for k, a in enumerate(ang)])
+            out[f"0-synth_{c:04d}"]["obj_pose"] = np.tile(row, (T, 1))
     return out
 
 

@@ -27,9 +27,14 @@ class _Box:
 
 
 class VecHumanoidEnv:
-    def __init__(self, cfg, n_env, device=0, mode="train", model=None, shape_models=None):
+    def __init__(self, cfg, n_env, device=0, mode="train", model=None, shape_models=None, objects=None):
         """shape_models: optional list of further models with the topology of `model` (body shapes, cf. the smpl_shape configs:
-        the reference rebuilds the model from each clip's beta); `set_clip_bank(..., clip_model=)` maps clips onto them."""
+        the reference rebuilds the model from each clip's beta); `set_clip_bank(..., clip_model=)` maps clips onto them.
+        objects: free objects behind the humanoid (the reference appends them in the generator from expert["obj_info"], a body with a free
+        joint and a mesh geom each, contype = conaffinity = 1, friction 1: uhc/smpllib/smpl_robot.py:1200-1252): dict(hulls=[(ntri, 3, 3)
+        triangle soup per object], density=1000.0, friction=1.0, condim=3) or just the list of hulls.  Every clip of the bank then carries
+        `obj_pose` (T, 7 K): a reset puts the objects there (reset_model, humanoid_im.py:1284-1287); observation, reward and termination keep
+        reading the humanoid alone (qpos[:qpos_lim], :421-422)."""
         self.cc_cfg = self.cfg = cfg
         self.mode = mode
         self.n_env = int(n_env)
@@ -40,29 +45,42 @@ class VecHumanoidEnv:
             from ..smpllib.smpl_robot import robot_variant
             model = robot_variant(S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh")), cfg.robot_cfg)
             shape_models = [robot_variant(m, cfg.robot_cfg) for m in (shape_models or [])]  # shapes of the asset: converted with it
+        from ..model.mjcf import add_free_bodies, trailing_free_bodies
+        if trailing_free_bodies(model):
+            raise ValueError("pass the humanoid's model and the objects apart (objects=): the env needs the humanoid alone for its kinematics")
         # robot.ball (config/copycat_ball): one ball joint per bone, nq = 99 -- `use_quat` in the reference (humanoid_im.py:52).  Gains, limits
-        # and the expert's forward kinematics are read off the hinge twin of the model (same bodies, same motor order).
+        # and the expert's forward kinematics are read off each model itself (body names and offsets: the same in both joint layouts), as
+        # the reference builds converter and Humanoid from the model the clip's Robot(beta) produced (:104-124, :192)
         self.use_quat = int(model.nq) != int(model.nv) + 1
-        self.hinge_model = None
         if self.use_quat:
             if int(model.nq) != 7 + 4 * (int(model.nbody) - 2) or int(model.nv) != 6 + 3 * (int(model.nbody) - 2):
-                raise NotImplementedError("the ball-joint env layer covers the humanoid alone (objects: physics only, sim.SimBatch)")
+                raise NotImplementedError("robot.ball: a free root and one ball joint per further body is what the generator emits")
             if cfg.action_type != "torque" or cfg.residual_force or cfg.meta_pd or cfg.meta_pd_joint:
                 raise NotImplementedError("robot.ball runs with action_type torque and no residual force / meta-PD (config/copycat_ball/*.yml); "
                                           "the stable-PD controller is written for scalar joints")
             if cfg.obs_v != 2 or cfg.reward_id not in ("world_rfc_implicit_quat", "world_rfc_implicit"):
                 raise NotImplementedError("robot.ball: obs_v 2 (get_full_obs_v2_quat) and reward world_rfc_implicit_quat are built")
-            from ..smpllib.smpl_robot import robot_variant
-            self.hinge_model = robot_variant(S.load_asset_model(getattr(cfg, "mujoco_model", "humanoid_smpl_neutral_mesh")),
-                                             dict(cfg.robot_cfg, ball=False, self_collision=False, rel_joint_lm=False))
-        self.model = model
-        self.models = [self.model] + list(shape_models or [])
         iters = int(getattr(cfg, "pgs_iterations", 300))
-        self.models = [dataclasses.replace(m, iterations=iters, solver=int(getattr(cfg, "contact_solver", 0))) for m in self.models]
+        self.body_models = [dataclasses.replace(m, iterations=iters, solver=int(getattr(cfg, "contact_solver", 0))) for m in [model] + list(shape_models or [])]
+        self.body_model = self.body_models[0]  # the humanoid alone: kinematics of the expert, gains, body names
+        self.num_obj, self.objects = 0, None
+        if objects is not None:
+            spec = dict(objects) if isinstance(objects, dict) else dict(hulls=list(objects))
+            hulls = [np.asarray(h, dtype=np.float64) for h in spec["hulls"]]
+            self.num_obj = len(hulls)
+            self.objects = dict(hulls=hulls, density=float(spec.get("density", 1000.0)), friction=spec.get("friction", 1.0), condim=int(spec.get("condim", 3)))
+        if self.num_obj:
+            # (qpos0 of the objects: side by side above the floor, overwritten by every reset's obj_pose)
+            park = np.stack([np.r_[2.0 + 1.0 * k, 2.0, 1.0, 1.0, 0.0, 0.0, 0.0] for k in range(self.num_obj)])
+            self.models = [add_free_bodies(m, self.objects["hulls"], park, density=self.objects["density"], friction=self.objects["friction"],
+                                           condim=self.objects["condim"]) for m in self.body_models]
+        else:
+            self.models = list(self.body_models)
         self.model = self.models[0]
+        self.qpos_lim, self.qvel_lim, self.body_lim = int(self.body_model.nq), int(self.body_model.nv), int(self.body_model.nbody)  # humanoid_im.py:113-115
         self.base_rot = cfg.data_specs.get("base_rot", [0.7071, 0.7071, 0.0, 0.0])
         self.rfc_rate = 1 if not cfg.rfc_decay else 0
-        kin = self.hinge_model if self.use_quat else self.model
+        kin = self.body_model
         self.converter = SMPLConverter(kin, kin, smpl_model=cfg.robot_cfg.get("model", "smpl"))
         self.ctrl = S.make_ctrl(kin, meta_pd=cfg.meta_pd, meta_pd_joint=cfg.meta_pd_joint, residual_force=cfg.residual_force,
                                 residual_force_mode=cfg.residual_force_mode, residual_force_scale=cfg.residual_force_scale,
@@ -84,11 +102,11 @@ class VecHumanoidEnv:
         if cfg.obs_coord != "root" or (cfg.obs_v != 0 and cfg.obs_vel != "full"):
             raise NotImplementedError("obs_coord 'root' (every reference config) and, for obs_v >= 1, obs_vel 'full' are built")
         self.n_reward_parts = REWARD_PARTS[reward_v]
-        self.env = S.EnvBatch(self.sim, env_desc(self.model, obs_v=cfg.obs_v, reward_v=reward_v, obs_heading=cfg.obs_heading, root_deheading=cfg.root_deheading,
+        self.env = S.EnvBatch(self.sim, env_desc(kin, obs_v=cfg.obs_v, reward_v=reward_v, obs_heading=cfg.obs_heading, root_deheading=cfg.root_deheading,
                                                  obs_phase=cfg.obs_phase, obs_vel=cfg.obs_vel, env_term_body=cfg.env_term_body, fut_frames=cfg.get("fut_frames", 10), fut_skip=cfg.get("skip", 10), has_shape=cfg.has_shape and cfg.get("has_shape_obs", True),
                                                  env_episode_len=cfg.env_episode_len, env_expert_trail_steps=cfg.env_expert_trail_steps,
                                                  body_diff_thresh=thresh, reward_weights=cfg.reward_weights,
-                                                 jpos_diffw=self.converter.get_new_diff_weight()))
+                                                 jpos_diffw=self.converter.get_new_diff_weight(), num_obj=self.num_obj))
         self.ndof = self.model.nu
         self.body_vf_dim = self.ctrl.body_vf_dim
         self.vf_dim = 0 if not cfg.residual_force else (6 if cfg.residual_force_mode == "implicit" else self.ctrl.n_vf_body * self.body_vf_dim)
@@ -105,9 +123,9 @@ class VecHumanoidEnv:
 
     # ---- expert clips -------------------------------------------------------------------------------------
     def expert_features(self, sample, model_index=0):
-        """load_expert's feature computation (humanoid_im.py:182-215): AMASS window -> qpos -> qpos_fk, on the clip's model."""
-        m = self.models[model_index]
-        kin = self.hinge_model if self.use_quat else m  # (ball: body offsets of the hinge twin = the model's own)
+        """load_expert's feature computation (humanoid_im.py:182-215): AMASS window -> qpos -> qpos_fk, on the clip's OWN model (the
+        reference rebuilds model, converter and Humanoid from the clip's Robot(beta) before it computes them)."""
+        kin = self.body_models[model_index]
         if model_index not in self._humanoids:
             self._humanoids[model_index] = Humanoid(model=kin)
         kw = dict(pose=sample["pose_aa"], trans=np.asarray(sample["trans"]).squeeze(), model=self.cc_cfg.robot_cfg.get("model", "smpl"),
@@ -117,16 +135,25 @@ class VecHumanoidEnv:
             # load_expert computes the quaternion pose too (humanoid_im.py:193-200).  Its joint quaternions ARE the expert's local body
             # quaternions (bquat); its root quaternion comes out of another conversion routine than the Euler pose's (1.5e-3 rad apart):
             # the frame record carries it in the root slot of qpos, the joint angles behind it stay (unused by a torque-driven env)
-            feat["qpos_quat"] = smpl_to_qpose(mj_model=m, use_quat=True, **kw)
+            feat["qpos_quat"] = smpl_to_qpose(mj_model=kin, use_quat=True, **kw)
             q = np.array(feat["qpos"], dtype=np.float64, copy=True)
             q[:, 3:7] = feat["qpos_quat"][:, 3:7]
             feat["qpos_record"] = q
         return feat
 
+    def _clip_obj_pose(self, c, T):
+        """expert["obj_pose"] of a clip as (T, 7 num_obj); the loader stores pose_aa under that key for clips without objects
+        (dataset_amass_single.py:133, `has_obj` = the shapes differ, :246)."""
+        op = c.get("obj_pose") if isinstance(c, dict) else None
+        op = None if op is None else np.asarray(op, dtype=np.float64)
+        if op is None or op.ndim != 2 or op.shape != (T, 7 * self.num_obj):
+            raise ValueError(f"the env carries {self.num_obj} objects: every clip needs obj_pose of shape (T, {7 * self.num_obj})")
+        return op
+
     def set_clip_bank(self, clips: dict, clip_model: dict = None):
-        """clips: {key: sample dict with pose_aa/trans/beta/gender of the WHOLE clip}.  Builds the HBM bank once.
-        clip_model: {key: index into [model] + shape_models}: the body shape every episode of that clip runs on."""
-        frames, starts, betas, lens = [], [], [], []
+        """clips: {key: sample dict with pose_aa/trans/beta/gender (+ obj_pose when the env carries objects) of the WHOLE clip}.  Builds the
+        HBM bank once.  clip_model: {key: index into [model] + shape_models}: the body shape every episode of that clip runs on."""
+        frames, starts, betas, lens, objs = [], [], [], [], []
         n = 0
         self.clip_keys = list(clips.keys())
         cm = [int(clip_model[k]) if clip_model else 0 for k in self.clip_keys]
@@ -135,6 +162,8 @@ class VecHumanoidEnv:
             ft = self.expert_features(c, mi)
             fr = S.pack_expert_frames(dict(ft, qpos=ft["qpos_record"]) if self.use_quat else ft)
             frames.append(fr)
+            if self.num_obj:
+                objs.append(self._clip_obj_pose(c, fr.shape[0]))
             starts.append(n)
             lens.append(fr.shape[0])
             n += fr.shape[0]
@@ -146,11 +175,12 @@ class VecHumanoidEnv:
         self._clip_index = {k: i for i, k in enumerate(self.clip_keys)}
         self._clip_len = np.array(lens)
         self.env.set_bank(torch.from_numpy(np.concatenate(frames)), torch.tensor(starts, dtype=torch.int32), torch.from_numpy(np.stack(betas)))
+        self.env.set_obj_pose(torch.from_numpy(np.concatenate(objs)) if self.num_obj else None)
         self.env.set_clip_models(torch.tensor(cm, dtype=torch.int32) if clip_model else None)
 
     def set_clip_bank_from_loader(self, data_loader, clip_model=None):
         clips = {k: dict(pose_aa=data_loader.data["pose_aa"][k], trans=data_loader.data["trans"][k], beta=data_loader.data["beta"][k],
-                         gender=data_loader.data["gender"][k]) for k in data_loader.data_keys}
+                         gender=data_loader.data["gender"][k], obj_pose=data_loader.data.get("obj_pose", {}).get(k)) for k in data_loader.data_keys}
         self.set_clip_bank(clips, clip_model=clip_model)
 
     def _window_len(self, fr_start, fr_end):
@@ -261,7 +291,8 @@ class HumanoidEnv:
         provider = body_provider or default_body_provider(cfg)
         self.smpl_robot = Robot(cfg.robot_cfg, body_provider=provider) if provider is not None else None  # humanoid_im.py:53-58
         self._robot_tag = None
-        self.vec = VecHumanoidEnv(cfg, 1, device=device, mode=mode, model=self._robot_model(init_expert))
+        self._obj_tag, objects = self._objects_of(init_expert)
+        self.vec = VecHumanoidEnv(cfg, 1, device=device, mode=mode, model=self._robot_model(init_expert), objects=objects)
         self._bind()
         self.body_diffw = self.vec.converter.get_new_diff_weight()[1:]
         self.jpos_diffw = self.vec.converter.get_new_diff_weight()[:, None]
@@ -281,6 +312,25 @@ class HumanoidEnv:
         if self._robot_tag not in cache:
             cache[self._robot_tag] = self.smpl_robot.load_from_skeleton(beta, gender=[g]).get_model()
         return cache[self._robot_tag]
+
+    @staticmethod
+    def _objects_of(expert_data):
+        """reset_robot hands expert["obj_info"] to the generator, which appends one free body + mesh geom per entry (humanoid_im.py:154-170,
+        smpl_robot.py:1200-1252: mesh files named after the GRAB objects).  Here: expert["obj_mesh"] = list of (ntri, 3, 3) triangle soups, or
+        obj_info = paths of binary STL files.  Returns (tag, objects spec or None)."""
+        if not expert_data.get("has_obj", False) or int(expert_data.get("num_obj", 0)) == 0:
+            return None, None
+        if expert_data.get("obj_mesh") is not None:
+            hulls = [np.asarray(h, dtype=np.float64) for h in expert_data["obj_mesh"]]
+        elif expert_data.get("obj_info") is not None:
+            from ..model.mjcf import load_binary_stl
+            hulls = [load_binary_stl(str(f)) for f in np.asarray(expert_data["obj_info"]).reshape(-1)]
+        else:
+            raise ValueError("a clip with objects needs their meshes: expert['obj_mesh'] (triangle soups) or expert['obj_info'] (STL paths)")
+        if len(hulls) != int(expert_data["num_obj"]):
+            raise ValueError(f"{len(hulls)} object meshes for num_obj = {expert_data['num_obj']}")
+        tag = tuple(h.round(9).tobytes() for h in hulls)
+        return tag, dict(hulls=hulls, density=float(expert_data.get("obj_density", 1000.0)))
 
     def _bind(self):
         v = self.vec
@@ -304,13 +354,14 @@ class HumanoidEnv:
         self.vec.set_mode(mode)
 
     def load_expert(self, expert_data, reload_robot=True):
-        if reload_robot and self.smpl_robot is not None:  # humanoid_im.py:189-190: a new body for a new beta / gender
-            tag = self._robot_tag
-            model = self._robot_model(expert_data)
-            if tag != self._robot_tag:
+        if reload_robot:  # humanoid_im.py:189-190: a new body for a new beta / gender, new objects for a new obj_info
+            tag, otag = self._robot_tag, self._obj_tag
+            model = self._robot_model(expert_data) if self.smpl_robot is not None else None
+            self._obj_tag, objects = self._objects_of(expert_data)
+            if tag != self._robot_tag or otag != self._obj_tag:
                 rate, seed_state = self.vec.rfc_rate, self.vec.np_random
                 self.vec.close()
-                self.vec = VecHumanoidEnv(self.cc_cfg, 1, device=self._device, mode=self.mode, model=model)
+                self.vec = VecHumanoidEnv(self.cc_cfg, 1, device=self._device, mode=self.mode, model=model, objects=objects)
                 self.vec.np_random = seed_state
                 self.vec.set_rfc_rate(rate)
                 self._bind()
@@ -342,13 +393,19 @@ class HumanoidEnv:
 
     def get_wbody_pos(self, selectList=None):
         d = self.data
-        return d.body_xpos[1:].copy().ravel() if selectList is None else np.concatenate([d.get_body_xpos(b) for b in selectList])
+        return d.body_xpos[1:self.vec.body_lim].copy().ravel() if selectList is None else np.concatenate([d.get_body_xpos(b) for b in selectList])
 
     def get_humanoid_qpos(self):
-        return self.data.qpos.copy()
+        return self.data.qpos.copy()[:self.vec.qpos_lim]  # humanoid_im.py:1417-1421
 
     def get_humanoid_qvel(self):
-        return self.data.qvel.copy()
+        return self.data.qvel.copy()[:self.vec.qvel_lim]
+
+    def get_obj_qpos(self):
+        return self.data.qpos.copy()[self.vec.qpos_lim:]  # humanoid_im.py:1423-1428
+
+    def get_obj_qvel(self):
+        return self.data.qvel.copy()[self.vec.qvel_lim:]
 
     def get_world_vf(self):
         return None
@@ -364,9 +421,11 @@ class HumanoidEnv:
         """Teleport to the expert state of the current frame and refresh the kinematics (humanoid_im.py:902-905)."""
         ind = self.get_expert_index(self.cur_t)
         # (ball joints: the quaternion expert pose -- the model's own 99 coordinates -- not the hinge angles)
-        q = torch.as_tensor(self.get_expert_attr("qpos_quat" if self.vec.use_quat and "qpos_quat" in self.expert else "qpos", ind)[None], dtype=torch.float64)
-        v = torch.as_tensor(self.get_expert_qvel()[None], dtype=torch.float64)
-        self.vec.sim.set_state(q, v, torch.zeros(1, dtype=torch.int32))
+        q = self.get_expert_attr("qpos_quat" if self.vec.use_quat and "qpos_quat" in self.expert else "qpos", ind)
+        v = self.get_expert_qvel()
+        if self.vec.num_obj:  # data.qpos[:qpos_lim] = expert pose: the objects stay where they are
+            q, v = np.r_[q, self.get_obj_qpos()], np.r_[v, self.get_obj_qvel()]
+        self.vec.sim.set_state(torch.as_tensor(q[None], dtype=torch.float64), torch.as_tensor(v[None], dtype=torch.float64), torch.zeros(1, dtype=torch.int32))
 
     def get_head_idx(self):
         return self.model._body_name2id["Head"] - 1
@@ -390,9 +449,9 @@ class HumanoidEnv:
         from ..utils.transformation import quaternion_from_euler
         qpos = self.get_humanoid_qpos()
         if self.vec.use_quat:  # :927-935: the ball joints' quaternions as they are
-            return qpos[3:7 + 4 * (self.model.nbody - 2)].copy()
+            return qpos[3:7 + 4 * (self.vec.body_lim - 2)].copy()
         out = [qpos[3:7]]
-        for b in range(2, self.model.nbody):
+        for b in range(2, self.vec.body_lim):
             a = 7 + 3 * (b - 2)
             out.append(quaternion_from_euler(qpos[a], qpos[a + 1], qpos[a + 2], "rzyx"))
         return np.concatenate(out)
@@ -400,7 +459,7 @@ class HumanoidEnv:
     def get_wbody_quat(self, selectList=None):
         d = self.data
         if selectList is None:
-            return d.body_xquat[1:].copy().ravel()
+            return d.body_xquat[1:self.vec.body_lim].copy().ravel()
         return np.concatenate([d.body_xquat[self.model._body_name2id[b]] for b in selectList])
 
     def get_com(self):
@@ -409,7 +468,7 @@ class HumanoidEnv:
     def get_body_com(self, selectList=None):
         d = self.data
         if selectList is None:
-            return d.xipos[1:].copy().ravel()
+            return d.xipos[1:self.vec.body_lim].copy().ravel()
         return np.concatenate([d.get_body_xipos(b) for b in selectList])
 
     def calc_body_diff(self):

@@ -95,7 +95,7 @@ class Agent:
             R.c_info_sum = torch.zeros(getattr(env, "n_reward_parts", 5), dtype=self.dtype, device=dev)
             R.c_reward_sum = torch.zeros((), dtype=self.dtype, device=dev)
             R.t_dev = torch.zeros(1, dtype=torch.long, device=dev)
-            R.redo_counts = torch.zeros(2, dtype=torch.long, device=dev)  # env-steps through the general kernel / its sweeps fallback, this pass
+            R.redo_counts = torch.zeros(4, dtype=torch.long, device=dev)  # env-steps of this pass: through the general / large tier, its sweeps fallback, rows dropped beyond the last tier's capacity, large tier
             R.end_reward_dev = torch.zeros((), dtype=self.dtype, device=dev)
             R.state = torch.zeros(n_env, env.obs_dim, dtype=self.dtype, device=dev)
             R.action = torch.zeros(n_env, env.action_dim, dtype=torch.float64, device=dev)
@@ -195,8 +195,10 @@ class Agent:
                 t.add_(1)
             return
         redo = env.sim.field(_S.F_REDO)  # UHC_F_REDO: which envs the general kernel computed / solved by sweeps in this step (diagnostics)
-        R.redo_counts[0] += (redo != 0).sum()
+        R.redo_counts[0] += ((redo & 1) != 0).sum()
         R.redo_counts[1] += ((redo & 2) != 0).sum()
+        R.redo_counts[2] += ((redo & 0x80) != 0).sum()
+        R.redo_counts[3] += ((redo & 0x40) != 0).sum()
         r = env.reward.to(self.dtype)
         R.c_reward_sum.add_(r.sum())  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
         if self.running_state is not None:
@@ -352,18 +354,22 @@ class AgentPG(Agent):
             return
         plist = [p for ps, _ in params_and_scale for p in ps if p.grad is not None]
         total = sum(p.numel() for p in plist) + len(params_and_scale)
-        if self._flat_grad is None or self._flat_grad.numel() != total or self._flat_grad.dtype != plist[0].dtype:
-            self._flat_grad = torch.empty(total, dtype=plist[0].dtype, device=plist[0].device)
+        # the wire: the parameters' own dtype (float64 like the reference's arithmetic: the 2-rank update then equals the single-process
+        # one to rounding), or float32 when asked (`grad_allreduce_dtype: float32` -- SURVEY 8e's 32 MB per exchange instead of 64;
+        # the local gradient MEANS go on the wire scaled by the rank's share n_r / 1024-ths are not needed: |n g| stays far inside float32)
+        wire = getattr(self, "grad_wire_dtype", None) or plist[0].dtype
+        if self._flat_grad is None or self._flat_grad.numel() != total or self._flat_grad.dtype != wire:
+            self._flat_grad = torch.empty(total, dtype=wire, device=plist[0].device)
         buf, off = self._flat_grad, 0
         for ps, n in params_and_scale:
             for p in ps:
                 if p.grad is None:
                     continue
                 k = p.numel()
-                buf[off:off + k] = p.grad.reshape(-1) * float(n)
+                buf[off:off + k] = (p.grad.reshape(-1) * float(n)).to(wire)
                 off += k
         for i, (_, n) in enumerate(params_and_scale):
-            buf[off + i] = float(n)
+            buf[off + i] = float(n)  # (sample counts up to 2^24 per rank are exact in float32)
         timed = getattr(self, "time_comm", False) and buf.is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -380,7 +386,7 @@ class AgentPG(Agent):
                 if p.grad is None:
                     continue
                 k = p.numel()
-                p.grad.copy_((buf[off:off + k] / counts[i].clamp(min=1.0)).view_as(p.grad))
+                p.grad.copy_((buf[off:off + k].to(p.grad.dtype) / counts[i].to(p.grad.dtype).clamp(min=1.0)).view_as(p.grad))
                 off += k
 
     def comm_summary(self):
@@ -443,7 +449,25 @@ class AgentPPO(AgentPG):
             fixed_log_probs = self.policy_net.get_log_prob(self.trans_policy(states), actions)
         ind = exps.nonzero(as_tuple=False).squeeze(1)
         self.last_losses = []
+        fused = _dist_on() and self.value_opt_niter == 1 and getattr(self, "fuse_grad_exchange", True)
         for _ in range(self.opt_num_epochs):
+            if fused:
+                # data-parallel: ONE exchange per optimisation epoch: the value gradient and the surrogate's gradient travel in
+                # one flat buffer.  The surrogate does not read the value net (the advantages are fixed for the update), so taking both
+                # gradients before either Adam step is the same computation as the reference's value step followed by the policy step.
+                value_loss = (self.value_net(self.trans_value(states)) - returns).pow(2).mean()
+                surr_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind)
+                self.optimizer_value.zero_grad()
+                self.optimizer_policy.zero_grad()
+                value_loss.backward()
+                surr_loss.backward()
+                self._allreduce_grads([(list(self.value_net.parameters()), states.shape[0]),
+                                       ([p for p in self.policy_net.parameters() if p.requires_grad], ind.shape[0])])
+                self.optimizer_value.step()
+                self.clip_policy_grad()
+                self.optimizer_policy.step()
+                self.last_losses.append((value_loss.detach(), surr_loss.detach()))
+                continue
             vl = self.update_value(states, returns)
             surr_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind)
             self.optimizer_policy.zero_grad()

@@ -1034,7 +1034,7 @@ def hinge_to_ball_qpos(m_hinge: Model, m_ball: Model, qpos: np.ndarray) -> np.nd
 
 
 def add_free_bodies(m: Model, hulls: List[np.ndarray], poses: np.ndarray, density: float = 1000.0, names: Optional[List[str]] = None,
-                    contype: int = 1, conaffinity: int = 1, condim: int = 1) -> Model:
+                    contype: int = 1, conaffinity: int = 1, condim: int = 1, friction: Optional[float] = None) -> Model:
     """Append free-floating convex bodies (objects) to a model: one body, one free joint and one mesh geom each (the reference appends
     objects the same way: a body with a `free` joint and a mesh geom, contype = conaffinity = 1, uhc/smpllib/smpl_robot.py:1205-1224).
     hulls: list of (ntri, 3, 3) triangle soups in the object frame; poses: (K, 7) pos + quat of each object in qpos0."""
@@ -1071,6 +1071,8 @@ def add_free_bodies(m: Model, hulls: List[np.ndarray], poses: np.ndarray, densit
         for name in ("geom_friction", "geom_margin", "geom_gap", "geom_solref", "geom_solimp"):
             a = getattr(o, name)
             setattr(o, name, ap(a, a[g0]))
+        if friction is not None:  # the reference writes friction="1 0.005 0.0001" on its object geoms (uhc/smpllib/smpl_robot.py:1216-1224)
+            o.geom_friction[-1] = [float(friction), 0.005, 0.0001]
         o.geom_rbound = ap(o.geom_rbound, np.linalg.norm(verts - com, axis=1).max()); o.geom_center = ap(o.geom_center, com)
         o.geom_vertadr = ap(o.geom_vertadr, o.nmeshvert); o.geom_vertnum = ap(o.geom_vertnum, len(verts))
         o.mesh_adjadr = np.concatenate([o.mesh_adjadr[:-1], adr[:-1] + o.nmeshadj, [o.nmeshadj + len(idx)]]).astype(np.int32)
@@ -1092,6 +1094,17 @@ def add_free_bodies(m: Model, hulls: List[np.ndarray], poses: np.ndarray, densit
     o.dof_frictionloss = np.concatenate([m.dof_frictionloss, z6])
     set_const(o)
     return o
+
+
+def trailing_free_bodies(m: Model) -> int:
+    """How many free bodies (objects: a body under the world with one free joint, no children) sit at the END of the model, behind the
+    humanoid -- what `add_free_bodies` appends and the reference's `get_obj_qpos` reads as qpos[qpos_lim:] (uhc/envs/humanoid_im.py:1423-1428)."""
+    k = 0
+    for j in range(int(m.njnt) - 1, 0, -1):
+        if int(m.jnt_type[j]) != JNT_FREE or int(m.body_parentid[int(m.jnt_bodyid[j])]) != 0 or int(m.jnt_bodyid[j]) != int(m.nbody) - 1 - k:
+            break
+        k += 1
+    return k
 
 
 def scale_model_per_body(m: Model, scales) -> Model:

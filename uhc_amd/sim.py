@@ -231,9 +231,21 @@ class EnvBatch:
                                       C.c_void_p(clip_beta.data_ptr()), clip_start.shape[0]))
         self._bank = (frames, clip_start, clip_beta)  # keep alive: the library borrows the pointers
 
-    def set_clip_models(self, clip_model: Optional[torch.Tensor]):
+    def set_obj_pose(self, obj_pose: Optional[torch.Tensor]):
+        """expert["obj_pose"] of every frame of the bank ([n_frames][7 num_obj]): where a reset puts the objects (humanoid_im.py:1284-1287)."""
         self.generation += 1
+        if obj_pose is None:
+            check(self.L.uhc_env_set_obj_pose(self._e, None, 0))
+            self._obj_pose = None
+            return
+        op = obj_pose.to(self.device, torch.float64).contiguous()
+        assert op.ndim == 2 and op.shape[0] == self._bank[0].shape[0] and op.shape[1] == 7 * int(self.desc.num_obj)
+        check(self.L.uhc_env_set_obj_pose(self._e, C.c_void_p(op.data_ptr()), op.shape[0]))
+        self._obj_pose = op  # borrowed by the library
+
+    def set_clip_models(self, clip_model: Optional[torch.Tensor]):
         """Which of the batch's models the episodes of each clip run on (per-clip body shape); None switches it off."""
+        self.generation += 1
         if clip_model is None:
             check(self.L.uhc_env_set_clip_models(self._e, None))
             self._clip_model = None

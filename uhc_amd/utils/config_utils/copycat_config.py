@@ -94,6 +94,9 @@ class Config(Base_Config):
         self.pgs_iterations = g("pgs_iterations", 300)
         self.n_env = g("n_env", 1024)
         self.ppo_dtype = g("ppo_dtype", "float64")
+        # data-parallel gradient exchange: the dtype on the wire.  float64 (default) = the learner's own arithmetic: the N-rank update equals
+        # the single-process one to rounding; float32 halves the bytes of every exchange (SURVEY 8e's 32 MB per epoch)
+        self.grad_allreduce_dtype = g("grad_allreduce_dtype", "float64")
 
     def update_adaptive_params(self, i_iter):
         cp = self.adp_iter_cp
