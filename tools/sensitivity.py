@@ -70,7 +70,7 @@ def main():
     base = dataclasses.replace(robot_variant(S.load_asset_model(), {"mesh": True, "model": "smpl"}), solver=1, iterations=300)
     ctrl = S.make_ctrl(base)
     stand = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))
-    clips = {"standing_neutral (187 frames)": stand["qpos"]}
+    clips = {"standing_neutral (187 frames of the shipped standing pose)": np.tile(np.asarray(stand["qpos"]).reshape(1, -1), (187, 1))}
     syn = make_synthetic_amass(1, seed=3, t_range=(220, 220), amp=0.3)
     c = next(iter(syn.values()))
     clips["synthetic perturbed-standing clip (seed 3, 220 frames, joint amplitudes <= 0.3 rad)"] = smpl_to_qpose(c["pose_aa"], base, trans=c["trans"], count_offset=True)
