@@ -25,7 +25,9 @@ def _obj_rows(T, root_xy):
     """obj_pose (T, 14): two boxes near the humanoid, moving a little from frame to frame (the reset must read the WINDOW's first row)."""
     t = np.arange(T)[:, None]
     a = np.c_[root_xy[0] + 0.42 + 0.001 * t, root_xy[1] + 0.0 * t, 0.151 + 0.0 * t, np.ones((T, 1)), np.zeros((T, 3))]
-    b = np.c_[root_xy[0] - 0.1 + 0.0 * t, root_xy[1] + 0.5 - 0.001 * t, 0.55 + 0.002 * t, np.full((T, 1), 0.9), np.full((T, 1), 0.1), np.zeros((T, 2))]
+    # (a generic orientation: a box tilted about ONE axis lands on an edge whose two vertices tie to the last bit, and which of them is "within
+    #  the margin" in the first touching substep is then decided by rounding -- differently in two correct implementations)
+    b = np.c_[root_xy[0] - 0.1 + 0.0 * t, root_xy[1] + 0.5 - 0.001 * t, 0.55 + 0.002 * t, np.full((T, 1), 0.9), np.full((T, 1), 0.1), np.full((T, 1), 0.07), np.full((T, 1), -0.04)]
     return np.concatenate([a, b], 1)
 
 
@@ -126,7 +128,8 @@ def test_env_with_objects_matches_oracles(model, ctrl, ball):
             tb = np.zeros(69) if ball else w["qpos"][E.expert_index(cur_t[e] + 1, 0, w["len"])][7:]
             o.do_simulation(act[e], tb, redo=redo[e])
             cur_t[e] += 1
-            np.testing.assert_allclose(gq[e], o.get("qpos"), atol=1e-9)  # humanoid AND objects
+            dq = np.abs(gq[e] - o.get("qpos"))
+            assert dq.max() < 1e-9, (t, e, np.nonzero(dq > 1e-9)[0].tolist(), gq[e][dq > 1e-9].tolist(), o.get("qpos")[dq > 1e-9].tolist(), int(redo[e]), o.geti("ncon"), o.geti("nefc"))  # humanoid AND objects
             np.testing.assert_allclose(gv[e], o.get("qvel"), atol=1e-7)
             xpos, xipos = o.get("xpos").reshape(-1, 3)[:nbh], o.get("xipos").reshape(-1, 3)[:nbh]
             r, parts = E.world_rfc_implicit_reward(o.get("qpos")[:nqh], xpos, xipos, prev_bquat, act[e], w, cur_t[e], 0, model.timestep * 15, jw[1:], REWARD_W,

@@ -85,7 +85,11 @@ def main():
         args.steps, args.warmup = 30, 20
         bench.bench_ball_objects(args)
     else:
-        if os.environ.get("TRACE_BALL") == "1":  # the ball-joint humanoid of the bench line `ball_rollout`
+        if os.environ.get("TRACE_PROBE"):  # any probe of bench.py by its key (configs4, ball_rollout, floor_only, shapes)
+            pr = dict(bench.PROBES[os.environ["TRACE_PROBE"]])
+            pr.pop("name")
+            agent = bench.build_agent(args, 0, 0, torch.float64, **pr)
+        elif os.environ.get("TRACE_BALL") == "1":  # the ball-joint humanoid of the bench line `ball_rollout`
             agent = bench.build_agent(args, 0, 0, torch.float64, robot_cfg={"mesh": True, "model": "smpl", "ball": True},
                                       cfg_over=dict(action_type="torque", residual_force=False, meta_pd=False, meta_pd_joint=False, reward_id="world_rfc_implicit_quat",
                                                     obs_v=2, tq_mul=4, env_init_noise=0.0))
@@ -93,17 +97,33 @@ def main():
             agent = bench.build_agent(args, 0, 0, torch.float64, robot_cfg={"mesh": True, "model": "smpl"})
         agent.per_epoch_update(0)
         env = agent.env
-        agent.rollout_begin(40)
-        for _ in range(12):
+        warm = int(os.environ.get("TRACE_WARM", "12"))  # (12: inside the transient after the restart of all envs; 50: steady state)
+        agent.rollout_begin(warm + 28)
+        for _ in range(warm):
             agent.rollout_step()
         torch.cuda.synchronize()
         prof = env.sim.field(S.F_STAGE_PROF)
-        for step in range(4):
-            prof.zero_()
+        why_hist = np.zeros((2, 6), dtype=np.int64)  # per tier: contacts, rows, body-body slots, row storage, candidate list, (any)
+        sub_hist = np.zeros(16, dtype=np.int64)
+        for step in range(24):
+            if step < 4:
+                prof.zero_()
             torch.cuda.synchronize()
             agent.rollout_step()
             torch.cuda.synchronize()
-            analyze(prof, env.n_env, step, lines)
+            if step < 4:
+                analyze(prof, env.n_env, step, lines)
+            w = env.sim.field(S.F_HANDON_WHY).cpu().numpy()
+            for tier in range(2):
+                b = (w >> (8 * tier)) & 0xff
+                for k in range(5):
+                    why_hist[tier, k] += int(((b >> k) & 1).sum())
+                why_hist[tier, 5] += int((b != 0).sum())
+            s = (w >> 16) & 0xff
+            for k in np.unique(s[(w & 0xffff) != 0]):
+                sub_hist[min(int(k) if k < 128 else 0, 15)] += int(((s == k) & ((w & 0xffff) != 0)).sum())
+        lines.append(f"## hand-ons over 24 steps x {env.n_env} envs (UHC_F_HANDON_WHY; an env can name several reasons): [contacts, rows, body-body row slots, packed row storage, MPR candidate list, envs]")
+        lines.append(f"fast tier -> general: {why_hist[0].tolist()};  general tier -> large: {why_hist[1].tolist()};  substep of the last hand-on (0 = the reset's forward pass / first substep): {sub_hist.tolist()}")
     txt = "\n".join(lines)
     print(txt)
     if out_path:

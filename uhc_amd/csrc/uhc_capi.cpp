@@ -167,8 +167,8 @@ struct UhcBatch {
     int n_models = 1;
     int n_trailing_free = 0;  // free bodies at the end of the model (objects)
     // field table
-    void* field_ptr[18] = {nullptr};
-    int64_t field_count[18] = {0};
+    void* field_ptr[19] = {nullptr};
+    int64_t field_count[19] = {0};
 };
 
 template <class T>
@@ -445,10 +445,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         // parked a tier up cost more than the late hand-ons they avoid (profiles/r03_marks_sweep.txt)
         const int def[8] = {64, 16, 12, 56, 14, 10, 8, 7};
         for (int k = 0; k < 8; k++) A.marks[k] = def[k];
+        A.marks[2] = -1;  // (body-body rows: set from the fast layout's dense slots below unless UHC_TIER_MARKS names them)
         if (const char* m = getenv("UHC_TIER_MARKS")) sscanf(m, "%d,%d,%d,%d,%d,%d,%d,%d", A.marks, A.marks + 1, A.marks + 2, A.marks + 3, A.marks + 4, A.marks + 5, A.marks + 6, A.marks + 7);
     }
     int end1 = 0;
-    auto common = [&](DevLds& F, bool fast) {  // persistent part + phase 1; returns the offset where phase 2 starts
+    auto common = [&](DevLds& F, bool fast) {  // persistent part + phase 1; returns the offset where phase 2 starts (fast: with the (row, col) table of M in LDS)
         off = 0;
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
         F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.sdinv = carve(nv);
@@ -478,21 +479,28 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     // ---- fast tier: target 40 KiB per workgroup => 4 workgroups (one per SIMD) per CU
     {
         DevLds& F = A.lf;
-        common(F, true);
-        F.con = carve(UHC_FAST_MAXCON * UHC_CON_STRIDE);
+        common(F, T.ncpair == 0);  // (the DENSE instantiations read the (row, col) table of M from L2, like the larger tiers: 2.4 KiB for rows)
+        // UHC_FAST_DENSE = "KiB,dense rows[,contacts]": the dense fast tier's LDS budget, body-body row slots and contact capacity (experiments)
+        int dense_kib = 52, fast_maxcon = UHC_FAST_MAXCON, fast_ndense = UHC_FAST_MAXTWO;
+        if (T.ncpair > 0) fast_maxcon = UHC_FAST_MAXCON_DENSE;
+        if (const char* fd = getenv("UHC_FAST_DENSE")) {
+            int kib = 0, nd = 0, nc = 0;
+            const int got = sscanf(fd, "%d,%d,%d", &kib, &nd, &nc);
+            if (got >= 2 && kib >= 32 && kib <= 160 && nd >= 0 && nd <= UHC_FAST_MAXTWO) { dense_kib = kib; fast_ndense = nd; }
+            if (got == 3 && nc >= 8 && nc <= UHC_GEN_MAXCON && T.ncpair > 0) fast_maxcon = nc;
+        }
+        F.con = carve(fast_maxcon * UHC_CON_STRIDE);
         F.rowMisc = carve(UHC_WAVE * 2);
         F.ncon_nefc = carve(2 + UHC_MAXTWO / 2);
         // models with body-body contacts (self-collision, objects) keep up to UHC_FAST_MAXTWO dense rows + their Delassus columns; they
         // get a third of the CU's LDS (3 workgroups per CU) instead of a quarter -- the stock floor-only model keeps its 40 KiB layout
-        A.cf.maxefc = UHC_FAST_MAXEFC; A.cf.maxcon = UHC_FAST_MAXCON; A.cf.ld_delta = 0;
-        A.cf.ndense = T.ncpair > 0 ? UHC_FAST_MAXTWO : 0;
-        int dense_kib = 52;
-        if (const char* fd = getenv("UHC_FAST_DENSE")) {  // "KiB,dense rows" of the dense fast tier (experiments: 40,4 = four workgroups per CU)
-            int kib = 0, nd = 0;
-            if (sscanf(fd, "%d,%d", &kib, &nd) == 2 && kib >= 32 && kib <= 160 && nd >= 0 && nd <= UHC_FAST_MAXTWO) { dense_kib = kib; if (T.ncpair > 0) A.cf.ndense = nd; }
-        }
+        A.cf.maxefc = UHC_FAST_MAXEFC; A.cf.maxcon = fast_maxcon; A.cf.ld_delta = 0;
+        A.cf.ndense = T.ncpair > 0 ? fast_ndense : 0;
         F.dense = carve(A.cf.ndense * A.nvp);
-        F.dcol = carve(A.cf.ndense * UHC_WAVE);
+        // the dense rows' Delassus columns are written by the contact solve, when nothing reads the contacts any more (the rows are built):
+        // they take the contacts' storage when they fit it (6 slots x 64 lanes = 16 contacts x 24 doubles), as in the larger tiers
+        const bool dcol_alias = A.cf.ndense * UHC_WAVE <= fast_maxcon * UHC_CON_STRIDE && !(getenv("UHC_FAST_DCOL_OWN") && getenv("UHC_FAST_DCOL_OWN")[0] == '1');
+        F.dcol = dcol_alias ? F.con : carve(A.cf.ndense * UHC_WAVE);
         F.Y = off;
         // (52 KiB, not 160 / 3 = 53.3: the LDS is handed out in granules, and 54 608 B rounded up no longer fits three times -- the tier
         //  trace showed 512 of 1 024 workgroups resident, two per CU; 52 KiB is a whole number of every granule up to 4 KiB)
@@ -502,10 +510,14 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         if (ycap < need1) ycap = need1;
         if (ycap < 8 * YS) ycap = 8 * YS;
         A.cf.ycap = ycap;
-        A.cf.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= A.cf.ndense * A.nvp + A.cf.ndense * UHC_WAVE + ycap) ? F.dense : -1;  // dense, dcol, Y are contiguous
+        A.cf.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= A.cf.ndense * A.nvp + (dcol_alias ? 0 : A.cf.ndense * UHC_WAVE) + ycap) ? F.dense : -1;  // dense, (dcol,) Y are contiguous
         off += ycap;
         F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.rowW = F.rowY = F.dsc = F.Y;  // unused by the fast kernel
         F.total = off;
+        if (A.marks[2] < 0) {  // the marks follow the layout: up at the capacity, down with a little room to spare
+            A.marks[2] = A.cf.ndense > 0 ? A.cf.ndense : UHC_FAST_MAXTWO; A.marks[5] = A.cf.ndense > 0 ? std::max(1, A.cf.ndense - (A.cf.ndense > 8 ? 2 : 1)) : 10;
+            A.marks[1] = A.cf.maxcon; A.marks[4] = A.cf.maxcon - std::max(2, A.cf.maxcon / 8);
+        }
         b->lds_bytes_fast = (size_t)off * sizeof(double);
         const char* env = getenv("UHC_FORCE_GENERAL");
         b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024;
@@ -644,7 +656,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     TRY(dalloc(b, E * d.nq, &S.qpos)); TRY(dalloc(b, E * nv, &S.qvel)); TRY(dalloc(b, E * nv, &S.qacc)); TRY(dalloc(b, E * nv, &S.qacc_ws));
     TRY(dalloc(b, E * 3 * nb, &S.xpos)); TRY(dalloc(b, E * 4 * nb, &S.xquat)); TRY(dalloc(b, E * 3 * nb, &S.xipos));
     TRY(dalloc(b, 4, &S.path_stats));
-    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 4 * E, &S.redo)); S.pend2 = S.redo + E; S.pend3 = S.redo + 2 * E; S.resume = S.redo + 3 * E; TRY(dalloc(b, 1, &S.q_abort));
+    TRY(dalloc(b, E * T.nM, &S.qM)); TRY(dalloc(b, 5 * E, &S.redo)); S.pend2 = S.redo + E; S.pend3 = S.redo + 2 * E; S.resume = S.redo + 3 * E; S.why = S.redo + 4 * E; TRY(dalloc(b, 1, &S.q_abort));
     TRY(dalloc(b, E, &S.tier)); TRY(dalloc(b, E, &b->tier_now)); S.tier_now = b->tier_now; TRY(dalloc(b, E, &S.cost));
     if (!(A.dbg & 8)) TRY(dalloc(b, E, &b->d_order));  // (UHC_DEBUG bit 3: the fast tier launches in env order)
     if (const char* q = getenv("UHC_Q2_DIV")) b->q2_div = std::max(1, atoi(q));
@@ -667,11 +679,11 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         HIP_OK(hipMemcpy(S.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     void* fp[] = {S.qpos, S.qvel, S.xpos, S.xquat, S.xipos, S.qM, S.bias, S.qacc, S.ctrl, S.ncon, S.nefc, S.fail,
-                  S.solver_iter, S.applied, S.overflow, S.prof, S.redo, S.tier};
+                  S.solver_iter, S.applied, S.overflow, S.prof, S.redo, S.tier, S.why};
     int64_t fc[] = {(int64_t)E * d.nq, (int64_t)E * nv, (int64_t)E * 3 * nb, (int64_t)E * 4 * nb, (int64_t)E * 3 * nb,
                     (int64_t)E * T.nM, (int64_t)E * nv, (int64_t)E * nv, (int64_t)E * d.nu, (int64_t)E, (int64_t)E, (int64_t)E,
-                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 40, (int64_t)E, (int64_t)E};
-    for (int k = 0; k < 18; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
+                    (int64_t)E, (int64_t)E * nv, (int64_t)E, (int64_t)E * 40, (int64_t)E, (int64_t)E, (int64_t)E};
+    for (int k = 0; k < 19; k++) { b->field_ptr[k] = fp[k]; b->field_count[k] = fc[k]; }
     HIP_OK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     b->stream = b->own_stream;
     *out = b;
@@ -744,7 +756,7 @@ extern "C" int32_t uhc_batch_set_solver(UhcBatch* b, int32_t solver, int32_t ite
     return 0;
 }
 extern "C" int32_t uhc_batch_field(UhcBatch* b, int32_t f, void** p, int64_t* n) {
-    if (!b || f < 0 || f > 17 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
+    if (!b || f < 0 || f > 18 || !b->field_ptr[f]) return fail("uhc_batch_field: unknown field %d", f);
     if (p) *p = b->field_ptr[f];
     if (n) *n = b->field_count[f];
     return 0;
@@ -760,7 +772,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
     const bool general = b->general_only;
     const bool big = b->A.last_tier == 3;
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
-    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 4, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3, resume: one allocation
+    HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 5, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3, resume, why: one allocation
     // (inside a stream capture the sticky launch cannot be used: it sizes its consumer launches from counts the host reads between steps
     //  -- event queries and a wait that are not allowed while capturing, and a replay would repeat the capture step's sizes anyway.  A
     //  captured step takes the plain tier chain, which computes the same step.)

@@ -10,6 +10,7 @@
 // exceeds the last tier is dropped and flagged (UHC_F_EFC_OVERFLOW).
 #define UHC_FAST_MAXEFC 64   // one row per lane, Delassus matrix in registers
 #define UHC_FAST_MAXCON 16
+#define UHC_FAST_MAXCON_DENSE 16  // models with body-body contacts (1 row each at condim 1) reach the contact cap long before the row cap
 #define UHC_FAST_MAXTWO 12
 #define UHC_GEN_MAXEFC 128   // two rows per lane, working sets of <= 64 rows
 #define UHC_GEN_MAXCON 64
@@ -20,6 +21,12 @@
 #define UHC_MAXTWO 32        // dense-row slots of the largest tier (sizes the slot tables of every layout)
 #define UHC_DOF_MAXACT 4
 #define UHC_CON_STRIDE 24
+// why a tier could not hold an env (bits 16+ of the forward pass's overflow word; UHC_F_HANDON_WHY = the word >> 16 of the env's last hand-on)
+#define UHC_WHY_CONTACTS (1 << 16)
+#define UHC_WHY_ROWS (1 << 17)
+#define UHC_WHY_DENSE_SLOTS (1 << 18)
+#define UHC_WHY_ROW_STORAGE (1 << 19)
+#define UHC_WHY_CANDIDATES (1 << 20)
 #define UHC_MINVAL 1e-15
 #define UHC_MAXVAL 1e10
 
@@ -95,6 +102,8 @@ struct DevState {  // HBM, env-major
     double *cdof, *rootcom;  // explicit RFC only: kinematics of the last forward pass carried between launches
     int *ncon, *nefc, *fail, *solver_iter, *overflow, *redo;
     int *pend2, *pend3;  // envs handed on to the general / large tier this step and not yet taken (the chained launches' active masks)
+    int* why;            // diagnostic (UHC_F_HANDON_WHY): bits 0-7 why the fast tier handed the env on in this step, bits 8-15 why the general tier did
+                         // (1 contacts, 2 rows, 4 body-body row slots, 8 packed row storage, 16 MPR candidate list), bits 16+ the substep of the last hand-on
     int* resume;         // substep at which the tier below handed the env on (its state then is in qpos / qvel / qacc_ws / ctrl / applied); 0: from the start
     int* q_abort;  // consumers that gave up waiting for their producers (queue_claim)
     int* tier;   // per env: the tier that computed its last control step (minus hysteresis): where its next step starts (kernel path 2)

@@ -372,7 +372,7 @@ __device__ __forceinline__ void k_com_pos(const KernelArgs& A, const double* mb,
 }
 
 // ------------------------------------------------------------------ P3 composite inertias + sparse M
-template <int TIER>
+template <int TIER, bool DENSE>
 __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, double* S, MPark& MP, const BodyConst& BC PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
@@ -407,7 +407,8 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
         const int e = LANE + UHC_WAVE * m;
         double v = 0.0;
         if (e < T.nM) {
-            const int ij = TIER == 1 ? ((const unsigned short*)(S + L.mij))[e] : T.m_ij[e], i = ij >> 8, j = ij & 0xff;  // (the larger tiers keep their LDS for rows)
+            // (the larger tiers, and the fast tier of models with body-body contacts, keep their LDS for rows: the table comes from L2)
+            const int ij = (TIER == 1 && !DENSE) ? ((const unsigned short*)(S + L.mij))[e] : T.m_ij[e], i = ij >> 8, j = ij & 0xff;
             double a[6], c[6];
             for (int k = 0; k < 6; k++) { a[k] = S[L.cdof + 6 * j + k]; c[k] = S[L.cdofdot + 6 * i + k]; }
             v = dot6(a, c);
@@ -916,7 +917,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 k_write_contact<TIER>(A, mb, S, ncon + rank, P.g1, P.g2, P.b1, P.b2, P.dim, cp, n, dist, margin, gap);
             }
             const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
-            if (want > cap_of<TIER>(A).maxcon) *overflow |= hands_on<TIER>(A) ? 1 : 2;  // 1: needs the next tier, 2: dropped
+            if (want > cap_of<TIER>(A).maxcon) *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_CONTACTS;  // 1: needs the next tier, 2: dropped
             ncon = min(cap_of<TIER>(A).maxcon, want);
         }
     }
@@ -973,7 +974,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             if (c && rank < CAND_CAP) cand[rank] = p;
             ncand += (int)__popcll(cm);
         }
-        if (ncand > CAND_CAP) { *overflow |= hands_on<TIER>(A) ? 1 : 2; ncand = CAND_CAP; }
+        if (ncand > CAND_CAP) { *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_CANDIDATES; ncand = CAND_CAP; }
         PROF(33)
         // the hull vertices (body frame, model constants) into the LDS region the constraint rows will use after this pass
         const int vstage = cap_of<TIER>(A).vstage;
@@ -1016,7 +1017,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 k_write_contact<TIER>(A, mb, S, ncon + rank, g1, g2, M.b1, M.b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, M.margin - M.depth, M.margin, gap);
             }
             const int want = ncon + (int)__popcll(hm);
-            if (want > cap_of<TIER>(A).maxcon) *overflow |= hands_on<TIER>(A) ? 1 : 2;
+            if (want > cap_of<TIER>(A).maxcon) *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_CONTACTS;
             ncon = min(cap_of<TIER>(A).maxcon, want);
         }
         PROF(35)
@@ -1100,8 +1101,8 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
     wsync();
     nefc = ((int*)(S + L.ncon_nefc))[1];
     if (((int*)(S + L.ncon_nefc))[0]) *overflow |= 2;
-    if (((int*)(S + L.ncon_nefc))[3]) *overflow |= hands_on<TIER>(A) ? 1 : 2;  // the next tier has more dense slots; the last one dropped the rows
-    if (nefc > cap_of<TIER>(A).maxefc) { *overflow |= hands_on<TIER>(A) ? 1 : 2; nefc = cap_of<TIER>(A).maxefc; }
+    if (((int*)(S + L.ncon_nefc))[3]) *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_DENSE_SLOTS;  // the next tier has more dense slots; the last one dropped the rows
+    if (nefc > cap_of<TIER>(A).maxefc) { *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_ROWS; nefc = cap_of<TIER>(A).maxefc; }
     return nefc;
 }
 
@@ -2220,7 +2221,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(1)
     k_com_pos<TIER>(A, mb, S, BC);
     PROF(2)
-    k_crb<TIER>(A, mb, S, MP, BC PROF_PASS);
+    k_crb<TIER, DENSE>(A, mb, S, MP, BC PROF_PASS);
     PROF(3)
     k_factor<TIER>(A, S, L.LD, LC);
     PROF(4)
@@ -2240,14 +2241,14 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             FastRow row;
             double Yreg[UHC_YM];
             const int st = k_rows_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
-            out.overflow |= st;
+            out.overflow |= st | (st == 1 ? UHC_WHY_ROW_STORAGE : 0);
             if (st == 1) return out;
             PROF(9)
             const int* NI = (const int*)(S + L.ncon_nefc);
             out.iters = k_pgs_fast<1, DENSE>(A, mb, S, out.nefc, row, Yreg, LC, NI + 4, DENSE ? NI[2] : 0 PROF_PASS);
             PROF(12)
         } else {
-            if (k_rows<TIER>(A, mb, S, out.nefc, LC)) { out.overflow |= 1; return out; }  // the packed rows need the next tier's storage
+            if (k_rows<TIER>(A, mb, S, out.nefc, LC)) { out.overflow |= 1 | UHC_WHY_ROW_STORAGE; return out; }  // the packed rows need the next tier's storage
             PROF(9)
             int it = -1;
             if (T.solver == 1) it = k_as_general<TIER, DENSE>(A, mb, S, out.nefc, LC PROF_PASS);
@@ -2502,7 +2503,8 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         if (MODE == 0) S[L.bias + i] = A.s.bias[(size_t)env * T.nv + i];
     }
     for (int i = LANE; i < T.nu; i += UHC_WAVE) S[L.ctrl + i] = A.s.ctrl[(size_t)env * T.nu + i];
-    if (TIER == 1) {   // (row, col) of the sparse mass-matrix entries, two per 32-bit word
+    if (TIER == 1 && !DENSE && L.mij > 0) {   // (row, col) of the sparse mass-matrix entries, two per 32-bit word (the kinematics-only launch
+                                              // <2, 1, false> also serves layouts without the table: models with body-body contacts)
         unsigned int* dst = (unsigned int*)(S + L.mij);
         const unsigned int* src = (const unsigned int*)T.m_ij;
         for (int w = LANE; w < (T.nM + 1) / 2; w += UHC_WAVE) dst[w] = src[w];
@@ -2590,8 +2592,8 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             overflow |= fo.overflow;
             if (overflow & 1) break;
             if (TIER != 1 && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
-            if (TIER != 1) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= UHC_FAST_MAXCON &&
-                              (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= UHC_FAST_MAXTWO);
+            if (TIER != 1) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= A.cf.maxcon &&
+                              (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= A.cf.ndense);
             {
                 const int ntwo = (DENSE && cap_of<TIER>(A).ndense > 0) ? ((const int*)(S + L.ncon_nefc))[2] : 0;
                 pk_nefc = max(pk_nefc, fo.nefc); pk_ncon = max(pk_ncon, fo.ncon); pk_ntwo = max(pk_ntwo, ntwo);
@@ -2629,6 +2631,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             // flagged for the chained launch of the next tier, which takes whatever no consumer took (none running, or given up) -- BEFORE the
             // env is published: a consumer that claims and finishes it clears the flag, and that clear must be the last write
             if (TIER == 1) A.s.pend2[env] = 1; else { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
+            A.s.why[env] = (A.s.why[env] & (TIER == 1 ? 0xff00 : 0x00ff)) | (((overflow >> 16) & 0xff) << (TIER == 1 ? 0 : 8)) | ((it & 0xff) << 16);  // diagnostic: why, and at which substep
             __threadfence();
             if (A.q_next) {  // the next tier's consumers are running beside this launch: straight into their queue
                 const int k = atomicAdd(A.q_next_count, 1);
@@ -2701,7 +2704,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             else if (TIER == 2) next = (up3 && big == 3) ? 3 : (dn1 ? 1 : 2);
             else next = !dn2 ? 3 : (dn1 ? 1 : 2);
             A.s.tier[env] = next;
-            A.s.cost[env] = max(pk_nefc, max(pk_ncon * (UHC_FAST_MAXEFC / UHC_FAST_MAXCON), (pk_ntwo * UHC_FAST_MAXEFC) / UHC_FAST_MAXTWO));
+            A.s.cost[env] = max(pk_nefc, max((pk_ncon * UHC_FAST_MAXEFC) / max(A.cf.maxcon, 1), (pk_ntwo * UHC_FAST_MAXEFC) / max(A.cf.ndense, 1)));
         }
         if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | ((overflow & 2) ? 0x80 : 0) | swept;
         else if (overflow & 2) A.s.redo[env] = 0x80;  // (fast tier in truncate mode; bit 7 = rows / contacts were dropped in this step)

@@ -13,6 +13,7 @@ re-designed around a batched on-device environment:
 from __future__ import annotations
 
 import math
+import os
 import time
 import types
 
@@ -78,7 +79,7 @@ class Agent:
     # device-side restart of finished episodes, next filtered state).  The torch pieces are ~60 small launches whose Python dispatch cost
     # more than their GPU time; on a GPU they are captured once into two HIP graphs (per pass length T) and replayed, the step index living
     # in a device counter.  Every buffer a graph touches is allocated once and updated in place across passes.
-    use_graph = True  # class default; set agent.use_graph = False to run the eager path (CPU runs always do)
+    use_graph = os.environ.get("UHC_NO_GRAPHS") != "1"  # class default; agent.use_graph = False (or UHC_NO_GRAPHS=1) runs the eager path (CPU runs always do)
 
     def _buffers(self, T):
         env = self.env

@@ -13,8 +13,8 @@ from ._capi import UhcCtrlDesc, UhcEnvDesc, model_desc
 from ._lib import check, lib
 
 F_QPOS, F_QVEL, F_XPOS, F_XQUAT, F_XIPOS, F_QM, F_QFRC_BIAS, F_QACC, F_CTRL = range(9)
-F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF, F_REDO, F_TIER = range(9, 18)
-_INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW, F_REDO, F_TIER}
+F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_QFRC_APPLIED, F_EFC_OVERFLOW, F_STAGE_PROF, F_REDO, F_TIER, F_HANDON_WHY = range(9, 19)
+_INT_FIELDS = {F_NCON, F_NEFC, F_FAIL, F_SOLVER_ITER, F_EFC_OVERFLOW, F_REDO, F_TIER, F_HANDON_WHY}
 
 
 class _DevView:
