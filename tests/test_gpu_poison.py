@@ -22,7 +22,8 @@ def test_parity_holds_with_poisoned_lds():
     if any(not hasattr(dbg, sym) for sym in _lib.SYMBOLS) or dbg.uhc_abi_version() != _lib.lib().uhc_abi_version():
         pytest.skip("debug library is older than the sources (python tools/poison_build.py)")
     env = dict(os.environ, UHC_LIB=POISON_LIB)
-    sel = ["tests/test_gpu_physics.py", "tests/test_gpu_selfcollision.py", "tests/test_gpu_ball.py", "tests/test_gpu_behaviour.py"]
+    sel = ["tests/test_gpu_physics.py", "tests/test_gpu_selfcollision.py", "tests/test_gpu_ball.py", "tests/test_gpu_behaviour.py", "tests/test_gpu_env.py",
+           "tests/test_gpu_env_objects.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "--tb=short", "-m", "gpu"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:]

@@ -10,7 +10,9 @@
 // exceeds the last tier is dropped and flagged (UHC_F_EFC_OVERFLOW).
 #define UHC_FAST_MAXEFC 64   // one row per lane, Delassus matrix in registers
 #define UHC_FAST_MAXCON 16
-#define UHC_FAST_MAXCON_DENSE 16  // models with body-body contacts (1 row each at condim 1) reach the contact cap long before the row cap
+#define UHC_FAST_MAXCON_DENSE 24  // models with body-body contacts (1 row each at condim 1) reach a 16-contact cap long before the row cap: on the
+                                 // self-colliding rollout 98 % of the fast tier's hand-ons named the contacts (tools/tier_trace.py, UHC_F_HANDON_WHY);
+                                 // 24 leaves a third of them (profiles/r04_ab_layout.txt; 32 buys nothing more and costs packed-row storage)
 #define UHC_FAST_MAXTWO 12
 #define UHC_GEN_MAXEFC 128   // two rows per lane, working sets of <= 64 rows
 #define UHC_GEN_MAXCON 64

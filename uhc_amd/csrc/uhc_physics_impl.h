@@ -1062,8 +1062,8 @@ __device__ __forceinline__ int k_enumerate_rows(const KernelArgs& A, const doubl
                 const double v = S[L.qpos + T.jnt_qposadr[j]], mg = mb[A.o.jnt_margin + j];
                 lo = (v - mb[A.o.jnt_range + 2 * j]) < mg;
                 hi = (mb[A.o.jnt_range + 2 * j + 1] - v) < mg;
-            } else if (jt == UHC_JNT_BALL) {  // one row: the rotation angle against max(range); the row ends at the joint's third dof
-                double jac[3];
+            } else if (DENSE && jt == UHC_JNT_BALL) {  // one row: the rotation angle against max(range); the row ends at the joint's third dof
+                double jac[3];                         // (DENSE instantiations only: a model with limited ball joints runs on them in every tier)
                 ball = true;
                 lo = ball_limit(S + L.qpos + T.jnt_qposadr[j], mb + A.o.jnt_range + 2 * j, jac) < mb[A.o.jnt_margin + j];
             }
