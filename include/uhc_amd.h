@@ -121,12 +121,15 @@ enum UhcField {
     UHC_F_STAGE_PROF = 15,   /* int64 [n_env][40] per-stage shader-cycle counters (profiling builds only) */
     UHC_F_REDO = 16,         /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast tier's capacity (64 rows, 16 contacts, packed
                               * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 20 body-body rows) or the
-                              * large one (256 / 128 / 32; bit 6), which solve the QP exactly too (working sets of <= 64 rows); bit 1: in at least one
-                              * substep that solve fell back to solver 0 (sweeps to tolerance); bits 2-5, diagnostic: why (friction-loss rows / one
-                              * island with 64 rows that carry a force and more that want in / no convergence of the working sets / a working set the
+                              * large one (256 / 128 / 32; bit 6), which solve the QP exactly too (working sets of <= 64 rows; an island with more
+                              * force-carrying rows than that in windows of 64 rows, to a KKT residual of 1e-9 (1 + max |b|): bit 3 reports that it
+                              * happened, it is not a fallback); bit 1: in at least one substep that solve fell back to solver 0 (sweeps to
+                              * tolerance); bits 2, 4, 5, diagnostic: why (friction-loss rows / no convergence of the working sets / a working set the
                               * pivoting could not solve); bit 8 + k: substep k (< 23) of the step was one of those (a checker that follows the same
                               * path needs to know which); bit 7: constraint rows / contacts beyond the last tier's capacity were DROPPED in this
-                              * step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state) */
+                              * step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state); a forward pass that dropped
+                              * rows is not the reference's QP any more and is given 32 sweeps from the warm start instead of the exact solve
+                              * (bits 1 and 7 together) */
     UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
     UHC_F_HANDON_WHY = 18    /* int32 [n_env] diagnostic of the last step: bits 0-7 why the fast tier handed the env on, bits 8-15 why the general tier did
                               * (1 contacts, 2 constraint rows, 4 body-body row slots, 8 packed row storage, 16 MPR candidate list beyond the tier's
@@ -320,8 +323,9 @@ int32_t uhc_rollout_act(void* stream, int32_t n_env, int32_t T, const int64_t* d
                         double* d_actions, double* d_action);
 /* agent.py:80-92: rewards[:, t] = reward + end * end_reward, dones[:, t] = done, c_reward_sum += sum(reward),
  * c_info_sum[k] += sum(parts[:, k]) (LoggerRL.step, logger_rl.py:29-33); n_parts <= 8.  d_redo (may be NULL): UHC_F_REDO of the step;
- * d_redo_counts (int64 [4]): [0] += envs the general / large tier computed, [1] += envs whose exact contact solve fell back to sweeps,
- * [2] += envs that lost constraint rows beyond the last tier's capacity in this step, [3] += envs the large tier computed (diagnostics) */
+ * d_redo_counts (int64 [5]): [0] += envs the general / large tier computed, [1] += envs whose exact contact solve fell back to sweeps,
+ * [2] += envs that lost constraint rows beyond the last tier's capacity in this step, [3] += envs the large tier computed, [4] += envs with
+ * an island of more than 64 force-carrying rows, solved exactly in windows of 64 rows (diagnostics) */
 int32_t uhc_rollout_record(void* stream, int32_t n_env, int32_t T, const int64_t* d_t, const double* d_reward, const int32_t* d_done,
                            const int32_t* d_end, const double* d_end_reward, const double* d_parts, int32_t parts_stride, int32_t n_parts,
                            double* d_rewards, double* d_dones, double* d_c_reward_sum, double* d_c_info_sum, const int32_t* d_redo,

@@ -24,19 +24,25 @@ def test_bench_json_contract():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert d["value"] == pytest.approx(64 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the dominant kernel is FP64-vector bound: the top-level block is priced against the FP64 vector peak, the HBM
+    # figures (algorithmic bytes per launch / the kernel's launch time, and the PMC traffic) sit in its "hbm" sub-block
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["kernel_ms"] > 0 and r["launches"] == 4
-    assert r["achieved"] == pytest.approx(7008 * 64 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert r["kernel_ms"] > 0 and r["launches"] == 4 and (r["frac"] is None or r["frac"] == pytest.approx(r["achieved"] / r["peak"]))
+    h = r["hbm"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and h["frac"] == pytest.approx(h["achieved"] / h["peak"])
+    assert h["achieved"] == pytest.approx(7008 * 64 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "env-steps/s" and "sample" in c
     assert d["ppo"]["samples"] == 64 * 6 and d["ppo"]["samples_per_s"] > 0
     assert 0.0 < d["ppo"]["mfma_util"] == pytest.approx(d["ppo"]["gemm_tflops"] / 78.6)
     assert 1 <= c["cores"] <= len(os.sched_getaffinity(0)) == c["sched_affinity"] and c["scaling_efficiency"] == pytest.approx(c["value"] / (c["cores"] * c["value_1_thread"]))
     # the other BASELINE configs ride along as short probes of the same step: driver-visible lines, not builder-run extras
-    for k in ("self_collision", "shapes", "ball_rollout", "ball_objects"):
-        assert d[k]["env_steps_per_s"] > 0 and d[k]["efc_overflow_envs"] == 0 and d[k]["failed_envs"] == 0 and "workload" in d[k], k
-    assert d["self_collision"]["nefc_mean"] >= d["workload_stats"]["nefc_mean"] - 8  # (body-body rows add to the floor rows)
+    for k in ("floor_only", "shapes", "ball_rollout", "configs4"):
+        assert d[k]["env_steps_per_s"] > 0 and len(d[k]["env_steps_per_s_each_rep"]) == d[k]["reps"] and "workload" in d[k] and d[k]["roofline"]["bound"] == "fp64_valu", k
+    assert d["floor_only"]["efc_overflow_env_steps_all_reps"] == 0 and d["shapes"]["efc_overflow_env_steps_all_reps"] == 0
+    assert d["configs4"]["model"]["objects"] == 4 and d["configs4"]["model"]["nq"] == 99 + 28
+    assert d["workload_stats"]["nefc_mean"] >= d["floor_only"]["nefc_mean"] - 8  # (the headline's body-body rows add to the floor rows)
 
 
 def test_bench_two_ranks_over_rccl():
@@ -51,7 +57,7 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
     assert d["n_gpus"] == 2 and len(d["per_rank_env_steps_per_s"]) == 2
-    assert d["ppo"]["allreduce"]["calls"] == 20 and d["ppo"]["allreduce"]["busbw_GBs"] > 0
+    assert d["ppo"]["allreduce"]["calls"] == 10 and d["ppo"]["allreduce"]["busbw_GBs"] > 0
 
 
 def test_bench_spawns_its_own_ranks():
@@ -67,5 +73,5 @@ def test_bench_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and len(d["per_rank_env_steps_per_s"]) == 2
     assert d["value"] == pytest.approx(2 * 64 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
     assert d["value"] <= sum(d["per_rank_env_steps_per_s"]) * (1 + 1e-9)
-    assert d["ppo"]["samples"] == 2 * 64 * 6 and d["ppo"]["allreduce"]["calls"] == 20 and d["ppo"]["allreduce"]["busbw_GBs"] > 0
+    assert d["ppo"]["samples"] == 2 * 64 * 6 and d["ppo"]["allreduce"]["calls"] == 10 and d["ppo"]["allreduce"]["busbw_GBs"] > 0  # (one fused value + policy exchange per epoch)
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only

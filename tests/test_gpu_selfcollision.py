@@ -321,3 +321,60 @@ def test_lying_humanoid_among_boxes_exceeds_128_rows(model, standing):
     assert max_nefc > 128 and big_steps > 0
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
     assert worst < 1e-5, worst
+
+
+def test_island_with_more_than_64_force_rows_is_solved_exactly_in_windows(model, standing):
+    """MuJoCo's Newton solver (humanoid_template.xml:13) solves the contact QP to 1e-8 whatever its size.  Here the exact solve keeps the
+    Delassus matrix of at most 64 rows in registers; an island with more force-carrying rows than that is solved in windows of 64 rows
+    (block coordinate descent to a KKT residual of 1e-9 (1 + max |b|), UHC_F_REDO bit 3) instead of falling back to the sweeps (bit 1).
+    Scene: seven 5 kg boxes side by side on the floor, yawed +-3.4 degrees so that every corner digs a millimetre into its neighbour --
+    one island of 90-120 rows (28 floor contacts and 6 box-box contacts, pyramids of 4), 61-78 of them with a force in the first four
+    control steps (later nearly all of them carry one and the windows need more rounds than they are given: tools/proto_block_cd.py)
+    -- beside a humanoid.  Every control step is checked against the oracle, which solves all rows at once, started from the
+    device's state (the scene is a pile-up: trajectories of two solvers that agree to 1e-9 per step still drift apart)."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    K = 7
+    m = self_collision_variant(model)
+    yaw = [0.06 * (-1) ** k for k in range(K)]
+    poses = np.array([[1.0 + 0.305 * k, 1.0 + 0.01 * k, 0.1495, np.cos(y / 2), 0, 0, np.sin(y / 2)] for k, y in enumerate(yaw)], dtype=np.float64)
+    m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
+    m = dataclasses.replace(m, solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n = 2
+    q = np.tile(m.qpos0, (n, 1))
+    q[:, :76] = standing["qpos"]
+    q[1, 76 + 7 * 3] += 0.0005  # (env 1: the fourth box half a millimetre further along)
+    v = np.zeros((n, m.nv))
+    b = S.SimBatch(m, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    os_ = [OracleSim(m, ctrl) for _ in range(n)]
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    act = np.zeros((n, ctrl.action_dim))
+    windowed, swept, worst_q, worst_v, max_nefc = 0, 0, 0.0, 0.0, 0
+    for t in range(4):
+        gq0, gv0 = b.field(S.F_QPOS).cpu().numpy().copy(), b.field(S.F_QVEL).cpu().numpy().copy()
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq, gv = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        for e in range(n):
+            windowed += int((redo[e] & 8) != 0)
+            swept += int((redo[e] & 2) != 0)
+            os_[e].set_state(gq0[e], gv0[e])
+            os_[e].do_simulation(act[e], np.zeros(69))
+            dq, dv = np.abs(gq[e] - os_[e].get("qpos")).max(), np.abs(gv[e] - os_[e].get("qvel")).max()
+            worst_q, worst_v = max(worst_q, dq), max(worst_v, dv)
+            max_nefc = max(max_nefc, os_[e].geti("max_nefc"))
+    print(f"raft of {K} boxes: env-steps with a windowed exact solve {windowed} / {4 * n}, sweeps fallbacks {swept}, max nefc {max_nefc}; "
+          f"one control step from the device's state, device vs oracle: |dqpos| {worst_q:.2e} |dqvel| {worst_v:.2e}")
+    assert windowed > 0, "no island exceeded 64 force-carrying rows: the scene no longer exercises the windows"
+    assert swept == 0
+    assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
+    assert worst_q < 1e-10 and worst_v < 1e-8, (worst_q, worst_v)

@@ -154,6 +154,8 @@ struct UhcBatch {
     long long queues_off_until = 0;
     int q2_wait_min = 16;    // at least so many general-tier consumers wait for hand-ons (UHC_Q2_WAIT)
     int q2_div = 1;          // waiting general-tier consumers per expected env: 1 / q2_div (UHC_Q2_DIV)
+    int q2_max = 256;        // most general-tier consumers beside a fast tier that still has most of the envs (UHC_Q2_MAX)
+    int q3_max = 32;         // most large-tier consumers in that regime (UHC_Q3_MAX)
     int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr, *d_fin = nullptr;
     bool queues_off = false;
     int* h_counts = nullptr;  // pinned [8][8]: give-ups, gate wait, final queue lengths [2], [3], queue lengths at the head of the step [4], [5]; the last steps', copied back asynchronously
@@ -661,6 +663,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (!(A.dbg & 8)) TRY(dalloc(b, E, &b->d_order));  // (UHC_DEBUG bit 3: the fast tier launches in env order)
     if (const char* q = getenv("UHC_Q2_DIV")) b->q2_div = std::max(1, atoi(q));
     if (const char* q = getenv("UHC_Q2_WAIT")) b->q2_wait_min = std::max(1, atoi(q));
+    if (const char* q = getenv("UHC_Q2_MAX")) b->q2_max = std::max(16, atoi(q));
+    if (const char* q = getenv("UHC_Q3_MAX")) b->q3_max = std::max(2, atoi(q));
     TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
@@ -828,9 +832,9 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // (beside a fast tier that still has most of the envs -- `waiting` -- the consumers are kept to a third of the chip: at most 32 CUs
         //  for the large tier, 256 workgroups of the general tier, 64 waiting spares.  Sized for their queues alone they left the fast tier 28
         //  CUs in the ball-joint rollout's first steps, and consumers that waited for it ran into their time-out.)
-        const int grid3 = waiting ? std::min(est3 + est3 / 4 + 2, 32) : std::min(est3 + est3 / 4 + 2, std::max(64, std::min(share3, (3 * b->n_cu) / 4)));
+        const int grid3 = waiting ? std::min(est3 + est3 / 4 + 2, b->q3_max) : std::min(est3 + est3 / 4 + 2, std::max(64, std::min(share3, (3 * b->n_cu) / 4)));
         const int room2 = 2 * (b->n_cu - (b->large_first && q3 ? std::min(grid3, std::max(est3, 1)) : 0));  // general-tier workgroups beside the large tier's
-        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, 256) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
+        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, b->q2_max) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
         auto launch_large = [&]() -> int {
             HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
