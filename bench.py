@@ -103,7 +103,7 @@ def alu_per_env_step(name):
     """float64 flop per env-step of a whole workload -- every tier's step kernels added up -- from the committed counter pass of that
     workload (profiles/*_alu_<name>.json, written by tools/pmc_alu.py from a rocprofv3 --pmc run of the probe): what the probes' ALU
     roofline uses, because their env-steps are spread over three kernels that run side by side."""
-    f = _latest(f"*_alu_{name}.json")
+    f = _latest(f"*_alu_{ {'configs2_per_gpu': 'headline'}.get(name, name) }.json")  # (the same workload at 4096 envs: flop per env-step of the 1024-env pass)
     if not f:
         return None
     d = json.load(open(f))
@@ -248,7 +248,7 @@ def cpu_ppo_baseline(agent, batch):
 GENERATED_CLASS = {"mesh": True, "model": "smpl"}  # a reference config's robot block: Robot() then emits body-body collisions, the excludes and rel_joint_lm ranges
 
 
-def build_agent(args, rank, local, dtype, shapes=0, robot_cfg="default", cfg_over=None, objects=0):
+def build_agent(args, rank, local, dtype, shapes=0, robot_cfg="default", cfg_over=None, objects=0, envs=None):
     """AgentCopycat on synthetic clips for the copycat rollout: `shapes` body shapes (configs[3]); `robot_cfg` = the config's robot block
     ("default": the model class the reference generates -- body-body collisions on, rel_joint_lm ranges --, or with --floor-only the shipped
     static asset as config/uhc_amd/copycat_mi355x.yml has it; None: that yml; a dict: a reference config's own keys); `objects` = K free
@@ -261,7 +261,7 @@ def build_agent(args, rank, local, dtype, shapes=0, robot_cfg="default", cfg_ove
     from uhc_amd.utils.config_utils.copycat_config import Config
 
     cfg = Config(cfg_id="copycat_mi355x", base_dir=tempfile.mkdtemp(prefix="uhc_bench_"))
-    cfg.n_env = args.envs
+    cfg.n_env = envs or args.envs  # (envs: a probe at another batch size, e.g. configs[2]'s 4096 per GPU)
     if isinstance(robot_cfg, str):
         robot_cfg = None if getattr(args, "floor_only", False) else GENERATED_CLASS
     if robot_cfg is not None:
@@ -388,6 +388,8 @@ def rollout_probe(args, local, dtype, name, warmup=None, steps=None, reps=None, 
 
 
 PROBES = {
+    "configs2_per_gpu": dict(name="configs[2]'s share of one GPU: the headline's rollout step at 4096 envs per GPU (the config shards 8 x 4096 over 8 GPUs with no "
+                                  "data-path collective: SURVEY 8e); 3 x 20 steps", envs=4096, steps=20),
     "floor_only": dict(name="configs[1] on the shipped static asset as it is: floor contacts only, +-180 degree joint ranges (the headline of rounds 1-3; "
                             "no reference config runs it -- their env model comes out of Robot(cfg.robot_cfg))", robot_cfg=None),
     "shapes": dict(name="configs[3] smpl_shape: 64 body shapes (per-body length scales ~ U(0.85, 1.15), default_rng(7)), one model blob per clip, on the generated model "

@@ -103,3 +103,28 @@ def test_forward_is_idempotent_and_free_fall_keeps_g(model, ctrl, standing):
     print(f"COM acceleration error: horizontal {np.abs(acc[..., :2]).max():.2e}, vertical {np.abs(acc[..., 2] + 9.81).max():.2e}")
     assert np.abs(acc[..., :2]).max() < 1e-3 and np.abs(acc[..., 2] + 9.81).max() < 1e-3  # measured 1.2e-4 (discretisation of the PD-driven joints)
     b.close()
+
+
+def test_self_colliding_batch_does_not_depend_on_the_fast_tier_layout(model, ctrl, standing):
+    """A batch of >= 3072 self-colliding humanoids gets the fast tier's 40 KiB / 6 body-body-row layout (four workgroups per CU), a smaller
+    one the 52 KiB / 12-row layout: more envs of the big batch are handed to the general tier.  Every tier solves the same QP exactly, so
+    an env of the 3072-env batch agrees with the same env inside a 16-env batch to rounding -- not to the bit: another tier sums in another
+    order -- and a rerun of the big batch is bit-identical."""
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import self_collision_variant
+    m = dataclasses.replace(self_collision_variant(model), solver=1)
+    n_env, steps = 3072, 6
+    qpos, qvel = _states(m, standing, n_env, 4242)
+    actions = np.random.default_rng(8).normal(scale=np.exp(-2.3), size=(steps, n_env, ctrl.action_dim))
+    fields = dict(qpos=S.F_QPOS, qvel=S.F_QVEL, nefc=S.F_NEFC, fail=S.F_FAIL, redo=S.F_REDO, ov=S.F_EFC_OVERFLOW)
+    full = _run(m, ctrl, qpos, qvel, actions, fields, steps)
+    assert not full["fail"].any() and not full["ov"].any() and not (full["redo"] & 2).any()
+    again = _run(m, ctrl, qpos, qvel, actions, fields, steps)
+    assert np.array_equal(full["qpos"], again["qpos"]) and np.array_equal(full["qvel"], again["qvel"])
+    pick = np.random.default_rng(3).choice(n_env, 16, replace=False)
+    small = _run(m, ctrl, qpos[pick], qvel[pick], np.ascontiguousarray(actions[:, pick]), fields, steps)
+    moved = int(((full["redo"][pick] & 1) != (small["redo"] & 1)).sum())
+    dq, dv = np.abs(full["qpos"][pick] - small["qpos"]).max(), np.abs(full["qvel"][pick] - small["qvel"]).max()
+    print(f"3072-env batch vs 16-env batch: {moved} of 16 envs ended in another tier; |dqpos| {dq:.2e} |dqvel| {dv:.2e}; general-tier share of the big batch {(full['redo'] & 1).mean():.3f}")
+    assert np.array_equal(full["nefc"][pick], small["nefc"])
+    assert dq < 1e-9 and dv < 1e-7, (dq, dv)

@@ -485,6 +485,12 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         // UHC_FAST_DENSE = "KiB,dense rows[,contacts]": the dense fast tier's LDS budget, body-body row slots and contact capacity (experiments)
         int dense_kib = 52, fast_maxcon = UHC_FAST_MAXCON, fast_ndense = UHC_FAST_MAXTWO;
         if (T.ncpair > 0) fast_maxcon = UHC_FAST_MAXCON_DENSE;
+        // A batch of four or more rounds of the 3-per-CU layout (>= 3072 envs on 256 CUs) is throughput-bound by how many fast-tier
+        // workgroups a CU holds, not by the general tier's slowest env: it gets the 40 KiB layout with 6 body-body row slots -- 4 per CU, one
+        // per SIMD; 12 % of the env-steps go through the general tier instead of 2.6 %.  Measured on the generated model class, env-steps/s
+        // with 52 KiB / 12 slots -> 40 KiB / 6 slots: 1024 envs 88 k -> 88 k, 2048 envs 119 k -> 98 k (250 envs per step queue for the general
+        // tier's consumers), 3072 envs 112 k -> 141 k, 4096 envs (configs[2]'s share of one GPU) 100 k -> 141 k.
+        if (T.ncpair > 0 && n_env >= 3072) { dense_kib = 40; fast_ndense = 6; }
         if (const char* fd = getenv("UHC_FAST_DENSE")) {
             int kib = 0, nd = 0, nc = 0;
             const int got = sscanf(fd, "%d,%d,%d", &kib, &nd, &nc);

@@ -2001,7 +2001,7 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // window starts at the row after the last one taken, cyclically.  Every window solve minimises the dual cost over its rows with the others
 // held, so the cost falls monotonically and the iteration converges to the QP's optimum; it ends when every row of the island satisfies
 // KKT to 1e-9 (1 + max |b|): y >= -tol on rows without a force, |y| <= tol on rows with one.  (Rounds measured on Delassus matrices from
-// oracle roll-outs, tools/proto_block_cd.py: 10 in the median and 30 at most while up to ~90 rows carry a force; an island of 110 rows that
+// CPU roll-outs of the checker, tools/proto_block_cd.py: 10 in the median and 30 at most while up to ~90 rows carry a force; an island of 110 rows that
 // ALL carry one -- seven boxes pushed into each other -- needs 30-120: two windows that couple through every box-box row.  Past
 // UHC_WS_BLOCK_MAXIT rounds the sweeps take over, as before.)
 // Returns the number of factorisations (bit 16 set: some island went through windows), or a negative reason (friction-loss rows, -2 unused,
