@@ -7,6 +7,8 @@
 #   prof_headline   kernel trace + PMC passes of the headline workload (self-colliding model class), tag _selfcol
 #   prof_floor      kernel trace + VALU / FETCH / WRITE passes of --floor-only
 #   prof_configs4   kernel trace + VALU / FETCH / WRITE passes of the configs[4] rollout probe, and of ball_rollout
+#   prof_shapes     the same for the shapes probe (configs[3])
+#   slowest         tools/diag_slowest.py on the headline and on configs4 (instrumented library): what the slowest general-tier env of a step does
 #   stage     instrumented stage profiles (selfcol fast / general, ball_objects general)
 #   meta      code-object metadata of every kernel
 set -u
@@ -62,8 +64,9 @@ prof_floor)
   pmc fl "$LDS" -- $P;        python tools/pmc_summary.py /tmp/prof_fl/p_results.db ${O}_pmc_SQ_INSTS_LDS.txt "$TAG: --pmc $LDS, --floor-only" > /dev/null
   python tools/pmc_alu.py ${O}_alu_floor_only.json 11264 /tmp/prof_fv/p_results.db /tmp/prof_ff/p_results.db /tmp/prof_fw/p_results.db -- "$TAG: --floor-only, 11 control steps x 1024 envs"
   grep "uhc_step" ${O}_kernel_stats.txt | cut -c1-160 ;;
-prof_configs4)
-  for w in configs4 ball_rollout; do
+prof_configs4|prof_shapes)
+  if [ $stage = prof_shapes ]; then WL="shapes"; else WL="configs4 ball_rollout"; fi
+  for w in $WL; do
     P="python $GRAFT_REPO_ROOT/bench.py --only-probe $w --probe-warmup 8 --probe-steps 12 --probe-reps 1"
     (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_$w -o kt -- $P > $GRAFT_REPO_ROOT/${O}_${w}_under_rocprof.json 2> /tmp/kt_$w.err)
     python tools/rocpd_summary.py /tmp/prof_kt_$w/kt_results.db ${O}_kernel_stats_$w.txt "$TAG: rocprofv3 --kernel-trace --stats -- bench.py --only-probe $w --probe-warmup 8 --probe-steps 12 --probe-reps 1" > /dev/null
@@ -79,6 +82,10 @@ stage)
   MODEL=selfcol SOLVER=1 CAP=300 python tools/stage_profile.py 1024 10 > ${O}_stage_profile_selfcol.txt 2>&1
   SOLVER=1 python tools/stage_profile.py 1024 10 > ${O}_stage_profile.txt 2>&1
   MODEL=ball_objects SOLVER=1 CAP=300 UHC_FORCE_GENERAL=1 python tools/stage_profile.py 512 12 > ${O}_stage_profile_ball_objects_general.txt 2>&1 ;;
+slowest)
+  python tools/diag_slowest.py headline 40 50 2>&1 | grep -v amdgpu > ${O}_diag_slowest_headline.txt
+  python tools/diag_slowest.py configs4 40 50 2>&1 | grep -v amdgpu > ${O}_diag_slowest_configs4.txt
+  head -2 ${O}_diag_slowest_configs4.txt | cut -c1-400 ;;
 meta)
   bash tools/kernel_meta.sh > ${O}_kernel_meta.txt 2>&1 ;;
 *) echo "unknown stage $stage" ;;

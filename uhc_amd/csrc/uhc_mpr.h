@@ -299,6 +299,52 @@ __device__ __forceinline__ void pair_support_wave(const double* __restrict__ VB,
     b = v3((R2[0] * b2x + R2[1] * b2y + R2[2] * b2z) + (P2[0] + e.x * hm), (R2[3] * b2x + R2[4] * b2y + R2[5] * b2z) + (P2[1] + e.y * hm),
            (R2[6] * b2x + R2[7] * b2y + R2[8] * b2z) + (P2[2] + e.z * hm));
 }
+// Two pairs' requests at once (every hull <= 64 vertices): four independent load / dot / reduction chains in straight-line code.  A support
+// query is a dependent chain of ~300 cycles that keeps the VALU busy a third of the time; the second pair's chain fills the gaps.  Per pair
+// the arithmetic is pair_support_wave's, operation for operation: same bits.
+#ifndef UHC_MPR_PAIRWISE
+#define UHC_MPR_PAIRWISE 1
+#endif
+struct SupArgs { const double *R1, *P1, *R2, *P2; int voff1, vn1, voff2, vn2; V3 d; double margin; };
+__device__ __forceinline__ void pair_support_wave2(const double* __restrict__ VB, const SupArgs& A, const SupArgs& B, V3& aA, V3& bA, V3& aB, V3& bB) {
+    const bool iA1 = LANE < A.vn1, iA2 = LANE < A.vn2, iB1 = LANE < B.vn1, iB2 = LANE < B.vn2;
+    const double* cA1 = VB + A.voff1 + 3 * (iA1 ? LANE : 0);
+    const double* cA2 = VB + A.voff2 + 3 * (iA2 ? LANE : 0);
+    const double* cB1 = VB + B.voff1 + 3 * (iB1 ? LANE : 0);
+    const double* cB2 = VB + B.voff2 + 3 * (iB2 ? LANE : 0);
+    const double xA1 = cA1[0], yA1 = cA1[1], zA1 = cA1[2], xA2 = cA2[0], yA2 = cA2[1], zA2 = cA2[2];
+    const double xB1 = cB1[0], yB1 = cB1[1], zB1 = cB1[2], xB2 = cB2[0], yB2 = cB2[1], zB2 = cB2[2];
+    const V3 dA = A.d, eA = neg(A.d), dB = B.d, eB = neg(B.d);
+    const double* R;
+    R = A.R1; const double lA1x = R[0] * dA.x + R[3] * dA.y + R[6] * dA.z, lA1y = R[1] * dA.x + R[4] * dA.y + R[7] * dA.z, lA1z = R[2] * dA.x + R[5] * dA.y + R[8] * dA.z;
+    R = A.R2; const double lA2x = R[0] * eA.x + R[3] * eA.y + R[6] * eA.z, lA2y = R[1] * eA.x + R[4] * eA.y + R[7] * eA.z, lA2z = R[2] * eA.x + R[5] * eA.y + R[8] * eA.z;
+    R = B.R1; const double lB1x = R[0] * dB.x + R[3] * dB.y + R[6] * dB.z, lB1y = R[1] * dB.x + R[4] * dB.y + R[7] * dB.z, lB1z = R[2] * dB.x + R[5] * dB.y + R[8] * dB.z;
+    R = B.R2; const double lB2x = R[0] * eB.x + R[3] * eB.y + R[6] * eB.z, lB2y = R[1] * eB.x + R[4] * eB.y + R[7] * eB.z, lB2z = R[2] * eB.x + R[5] * eB.y + R[8] * eB.z;
+    const double sA1 = iA1 ? lA1x * xA1 + lA1y * yA1 + lA1z * zA1 : -1e300;
+    const double sA2 = iA2 ? lA2x * xA2 + lA2y * yA2 + lA2z * zA2 : -1e300;
+    const double sB1 = iB1 ? lB1x * xB1 + lB1y * yB1 + lB1z * zB1 : -1e300;
+    const double sB2 = iB2 ? lB2x * xB2 + lB2y * yB2 + lB2z * zB2 : -1e300;
+    double mA1 = sA1, mA2 = sA2, mB1 = sB1, mB2 = sB2;
+    mA1 = fmax(mA1, dpp_f64<DPP_QUAD_1032>(mA1)); mA2 = fmax(mA2, dpp_f64<DPP_QUAD_1032>(mA2)); mB1 = fmax(mB1, dpp_f64<DPP_QUAD_1032>(mB1)); mB2 = fmax(mB2, dpp_f64<DPP_QUAD_1032>(mB2));
+    mA1 = fmax(mA1, dpp_f64<DPP_QUAD_2301>(mA1)); mA2 = fmax(mA2, dpp_f64<DPP_QUAD_2301>(mA2)); mB1 = fmax(mB1, dpp_f64<DPP_QUAD_2301>(mB1)); mB2 = fmax(mB2, dpp_f64<DPP_QUAD_2301>(mB2));
+    mA1 = fmax(mA1, dpp_f64<DPP_ROW_HALF_MIRROR>(mA1)); mA2 = fmax(mA2, dpp_f64<DPP_ROW_HALF_MIRROR>(mA2)); mB1 = fmax(mB1, dpp_f64<DPP_ROW_HALF_MIRROR>(mB1)); mB2 = fmax(mB2, dpp_f64<DPP_ROW_HALF_MIRROR>(mB2));
+    mA1 = fmax(mA1, dpp_f64<DPP_ROW_MIRROR>(mA1)); mA2 = fmax(mA2, dpp_f64<DPP_ROW_MIRROR>(mA2)); mB1 = fmax(mB1, dpp_f64<DPP_ROW_MIRROR>(mB1)); mB2 = fmax(mB2, dpp_f64<DPP_ROW_MIRROR>(mB2));
+    mA1 = fmax(fmax(bcast(mA1, 0), bcast(mA1, 16)), fmax(bcast(mA1, 32), bcast(mA1, 48)));
+    mA2 = fmax(fmax(bcast(mA2, 0), bcast(mA2, 16)), fmax(bcast(mA2, 32), bcast(mA2, 48)));
+    mB1 = fmax(fmax(bcast(mB1, 0), bcast(mB1, 16)), fmax(bcast(mB1, 32), bcast(mB1, 48)));
+    mB2 = fmax(fmax(bcast(mB2, 0), bcast(mB2, 16)), fmax(bcast(mB2, 32), bcast(mB2, 48)));
+    const int kA1 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sA1 == mA1)) - 1, kA2 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sA2 == mA2)) - 1;
+    const int kB1 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sB1 == mB1)) - 1, kB2 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sB2 == mB2)) - 1;
+    double bx, by, bz, hm;
+    bx = bcast(xA1, kA1); by = bcast(yA1, kA1); bz = bcast(zA1, kA1); hm = 0.5 * A.margin; R = A.R1;
+    aA = v3((R[0] * bx + R[1] * by + R[2] * bz) + (A.P1[0] + dA.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (A.P1[1] + dA.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (A.P1[2] + dA.z * hm));
+    bx = bcast(xA2, kA2); by = bcast(yA2, kA2); bz = bcast(zA2, kA2); R = A.R2;
+    bA = v3((R[0] * bx + R[1] * by + R[2] * bz) + (A.P2[0] + eA.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (A.P2[1] + eA.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (A.P2[2] + eA.z * hm));
+    bx = bcast(xB1, kB1); by = bcast(yB1, kB1); bz = bcast(zB1, kB1); hm = 0.5 * B.margin; R = B.R1;
+    aB = v3((R[0] * bx + R[1] * by + R[2] * bz) + (B.P1[0] + dB.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (B.P1[1] + dB.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (B.P1[2] + dB.z * hm));
+    bx = bcast(xB2, kB2); by = bcast(yB2, kB2); bz = bcast(zB2, kB2); R = B.R2;
+    bB = v3((R[0] * bx + R[1] * by + R[2] * bz) + (B.P2[0] + eB.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (B.P2[1] + eB.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (B.P2[2] + eB.z * hm));
+}
 // xmat / xpos: the bodies' poses in LDS ([nbody][9], [nbody][3])
 __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const double* __restrict__ xmat, const double* __restrict__ xpos, bool active, MprLane& M) {
     CcdSup p0, p1, p2, p3, v4;
@@ -320,12 +366,37 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
         while (live) {
             const int p = __ffsll((long long)live) - 1;
             live &= live - 1;
-            const V3 d = v3(bcast(dir.x, p), bcast(dir.y, p), bcast(dir.z, p));
-            const int b1 = __builtin_amdgcn_readlane(M.b1, p), b2 = __builtin_amdgcn_readlane(M.b2, p);
-            const double mg = bcast(M.margin, p);
+            SupArgs Ap;
+            {
+                const int b1 = __builtin_amdgcn_readlane(M.b1, p), b2 = __builtin_amdgcn_readlane(M.b2, p);
+                Ap.R1 = xmat + 9 * b1; Ap.P1 = xpos + 3 * b1; Ap.R2 = xmat + 9 * b2; Ap.P2 = xpos + 3 * b2;
+                Ap.voff1 = __builtin_amdgcn_readlane(M.voff1, p); Ap.vn1 = __builtin_amdgcn_readlane(M.vn1, p);
+                Ap.voff2 = __builtin_amdgcn_readlane(M.voff2, p); Ap.vn2 = __builtin_amdgcn_readlane(M.vn2, p);
+                Ap.d = v3(bcast(dir.x, p), bcast(dir.y, p), bcast(dir.z, p)); Ap.margin = bcast(M.margin, p);
+            }
             V3 a, b;
-            pair_support_wave(VB, xmat + 9 * b1, xpos + 3 * b1, __builtin_amdgcn_readlane(M.voff1, p), __builtin_amdgcn_readlane(M.vn1, p), xmat + 9 * b2, xpos + 3 * b2,
-                              __builtin_amdgcn_readlane(M.voff2, p), __builtin_amdgcn_readlane(M.vn2, p), d, mg, a, b);
+            if (live && UHC_MPR_PAIRWISE) {  // a second request of this round: served together with the first
+                const int q = __ffsll((long long)live) - 1;
+                SupArgs Aq;
+                const int b1 = __builtin_amdgcn_readlane(M.b1, q), b2 = __builtin_amdgcn_readlane(M.b2, q);
+                Aq.R1 = xmat + 9 * b1; Aq.P1 = xpos + 3 * b1; Aq.R2 = xmat + 9 * b2; Aq.P2 = xpos + 3 * b2;
+                Aq.voff1 = __builtin_amdgcn_readlane(M.voff1, q); Aq.vn1 = __builtin_amdgcn_readlane(M.vn1, q);
+                Aq.voff2 = __builtin_amdgcn_readlane(M.voff2, q); Aq.vn2 = __builtin_amdgcn_readlane(M.vn2, q);
+                Aq.d = v3(bcast(dir.x, q), bcast(dir.y, q), bcast(dir.z, q)); Aq.margin = bcast(M.margin, q);
+                if (max(max(Ap.vn1, Ap.vn2), max(Aq.vn1, Aq.vn2)) <= UHC_WAVE) {
+                    live &= live - 1;
+                    V3 a2, b2v;
+                    pair_support_wave2(VB, Ap, Aq, a, b, a2, b2v);
+                    const bool mq = LANE == q;
+                    v4.v = vsel(mq, a2 - b2v, v4.v);
+                    v4.s = vsel(mq, a2 + b2v, v4.s);
+                    const bool mine = LANE == p;
+                    v4.v = vsel(mine, a - b, v4.v);
+                    v4.s = vsel(mine, a + b, v4.s);
+                    continue;
+                }
+            }
+            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.margin, a, b);
             const bool mine = LANE == p;
             v4.v = vsel(mine, a - b, v4.v);
             v4.s = vsel(mine, a + b, v4.s);
