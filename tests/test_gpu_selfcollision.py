@@ -378,3 +378,53 @@ def test_island_with_more_than_64_force_rows_is_solved_exactly_in_windows(model,
     assert swept == 0
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
     assert worst_q < 1e-10 and worst_v < 1e-8, (worst_q, worst_v)
+
+
+def test_pass_that_drops_rows_is_flagged_and_gets_the_short_solve(model, standing):
+    """Beyond the large tier's 256 rows constraint rows are dropped (the reference's njmax is 2500: uhc/khrylib/mocap/skeleton_mesh.py:46) and the
+    pass is no longer the reference's QP.  It is reported where it happens -- UHC_F_REDO bit 7 of that step, UHC_F_EFC_OVERFLOW until the next
+    set_state -- and solved by at most 32 sweeps from the warm start instead of the exact solve (bit 1 with bit 7).  Scene: a
+    humanoid laid flat into the floor (its chest 16 cm up: 130-190 rows) beside the seven-box raft of the test above (110-120 rows): 270-330
+    rows in the first step."""
+    import dataclasses
+    import torch
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    K = 7
+    m = self_collision_variant(model)
+    yaw = [0.06 * (-1) ** k for k in range(K)]
+    poses = np.array([[1.0 + 0.305 * k, 1.0 + 0.01 * k, 0.1495, np.cos(y / 2), 0, 0, np.sin(y / 2)] for k, y in enumerate(yaw)], dtype=np.float64)
+    m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
+    m = dataclasses.replace(m, solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n = 2
+    q = np.tile(m.qpos0, (n, 1))
+    for e in range(n):
+        qh = standing["qpos"].copy()
+        a = np.pi / 2 + 0.1 * e
+        qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])  # tipped forward: face down
+        qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+        q[e, :76] = qh
+    v = np.zeros((n, m.nv))
+    b = S.SimBatch(m, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    act = torch.zeros(n, ctrl.action_dim, dtype=torch.float64, device="cuda")
+    lost_steps, nefc_max, words = 0, 0, []
+    for t in range(4):
+        b.simulate(act, tb)
+        b.sync()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        nefc_max = max(nefc_max, int(b.field(S.F_NEFC).max().item()))
+        for e in range(n):
+            if redo[e] & 0x80:
+                lost_steps += 1
+                words.append(hex(int(redo[e])))
+                assert redo[e] & 2 and redo[e] & 0x40, hex(int(redo[e]))  # swept (the short solve), in the large tier
+                assert not redo[e] & 0x34, hex(int(redo[e]))             # ... and not because the working sets gave up
+    print(f"humanoid face down + raft of {K} boxes: {lost_steps} of {4 * n} env-steps lost rows beyond 256 (nefc at the steps' ends up to {nefc_max}); UHC_F_REDO of those: {words[:4]}")
+    assert lost_steps > 0  # (UHC_F_NEFC is the step's LAST substep: the rows were lost in its first ones)
+    assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) > 0 and int(b.field(S.F_FAIL).sum().item()) == 0
+    assert np.isfinite(b.field(S.F_QPOS).cpu().numpy()).all()
