@@ -25,7 +25,7 @@ def main():
     args = bench.parse()
     torch.cuda.set_device(0)
     torch.set_default_dtype(torch.float64)
-    kw = {k: v for k, v in bench.PROBES[name].items() if k != "name"}
+    kw = {k: v for k, v in bench.PROBES[name].items() if k not in ("name", "steps")}
     agent = bench.build_agent(args, 0, 0, torch.float64, **kw)
     agent.per_epoch_update(0)
     env = agent.env
