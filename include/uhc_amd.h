@@ -128,8 +128,8 @@ enum UhcField {
                               * pivoting could not solve); bit 8 + k: substep k (< 23) of the step was one of those (a checker that follows the same
                               * path needs to know which); bit 7: constraint rows / contacts beyond the last tier's capacity were DROPPED in this
                               * step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state); a forward pass that dropped
-                              * rows is not the reference's QP any more and is given 32 sweeps from the warm start instead of the exact solve
-                              * (bits 1 and 7 together) */
+                              * rows is not the reference's QP any more: its truncated QP gets a bounded exact attempt (six working-set rounds, no
+                              * windows) and, when that gives up, 32 sweeps from the warm start instead of `iterations` (bits 1 and 7 together) */
     UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
     UHC_F_HANDON_WHY = 18    /* int32 [n_env] diagnostic of the last step: bits 0-7 why the fast tier handed the env on, bits 8-15 why the general tier did
                               * (1 contacts, 2 constraint rows, 4 body-body row slots, 8 packed row storage, 16 MPR candidate list beyond the tier's

@@ -2007,16 +2007,18 @@ __device__ __forceinline__ int k_pgs_fast(const KernelArgs& A, const double* mb,
 // CPU roll-outs of the checker, tools/proto_block_cd.py: 10 in the median and 30 at most while up to ~90 rows carry a force; an island of 110 rows that
 // ALL carry one -- seven boxes pushed into each other -- needs 30-120: two windows that couple through every box-box row.  Past
 // UHC_WS_BLOCK_MAXIT rounds the sweeps take over, as before.)
-// Returns the number of factorisations (bit 16 set: some island went through windows), or a negative reason (friction-loss rows, -2 unused,
+// Returns the number of factorisations (bit 16 set: some island went through windows), or a negative reason (friction-loss rows, -2: `lost`
+// and an island needs windows,
 // no convergence in UHC_WS_MAXIT / UHC_WS_BLOCK_MAXIT rounds, a working set the pivoting cannot solve: -1 .. -4): the caller then runs the sweeps.
 #define UHC_WS_MAXIT 16
 #define UHC_WS_BLOCK_MAXIT 80
+#define UHC_WS_LOST_MAXIT 6   // working-set rounds of a pass that has dropped rows (k_forward)
 #define UHC_WS_WINDOWED 0x10000
 #define UHC_WS_FILL 64  // lanes of an island's first working set that are filled by rank (k_as_general); 48 / 56 / 64 measured: 95.2 / 96.1 / 98.3 k env-steps/s on the headline
 #define UHC_LOST_SWEEPS 32  // sweeps of an env-step that lost constraint rows beyond the last tier's capacity (k_forward)
 // NRL = rows per lane: 2 in the general tier (<= 128 rows), 4 in the large tier (<= 256 rows); row r lives in lane r % 64, slot r / 64.
 template <int TIER, bool DENSE>
-__device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC PROF_ARGS) {
+__device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, bool lost PROF_ARGS) {
     constexpr int NRL = TIER == 3 ? 4 : 2;
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
@@ -2145,7 +2147,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
         int cursor = 0;       // first row of the next window
         double tol = 0.0;     // KKT tolerance (0 while every force-carrying row is inside the working set: the solve is direct)
         for (int outer = 0; !done; outer++) {
-            if (outer >= (block ? UHC_WS_BLOCK_MAXIT : UHC_WS_MAXIT)) break;
+            if (outer >= (block ? UHC_WS_BLOCK_MAXIT : lost ? UHC_WS_LOST_MAXIT : UHC_WS_MAXIT)) break;
             // ---- compact the group's working set into the lanes (row order kept)
             unsigned long long m[NRL];
             int nC = 0;
@@ -2163,6 +2165,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
 #pragma unroll
                 for (int h = 0; h < NRL; h++) { q[h] = __builtin_amdgcn_ballot_w64(c[h] && !p[h]); nq += __builtin_popcountll(q[h]); }
                 const int room = UHC_WAVE - (nC - nq);
+                if (room <= 0 && lost) return -2;  // (a pass that dropped rows is not worth the windows: k_forward)
                 if (room <= 0 || block) {
                     // 64 rows carry a force and more want in: the next window of 64 candidates, cyclically from the cursor
                     if (!block) {
@@ -2393,20 +2396,21 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             PROF(9)
             int it = -1;
             // An env that has just lost rows or contacts beyond the last tier's capacity (overflow bit 1; UHC_F_REDO bit 7) is no longer
-            // solving the reference's QP.  Every such env-step of the configs[4] probe that was looked at (tools/diag_redo.py, replayed
-            // on the oracle) was a simulation on its way to the bad-value flag: joint speeds of 160 - 20 000 rad/s at the head of the
-            // step, |b| of 1e7 - 5e16 (median 2e13) in the substep, one island of 250 rows that the working sets cannot finish.  It gets
-            // UHC_LOST_SWEEPS sweeps from the warm start instead of the exact solve and its <= `iterations` sweeps fallback (34 ms per
-            // substep in the large tier, a third of that probe's time).
+            // solving the reference's QP.  Most such passes are ordinary pile-ups and their truncated QP is solved exactly like any other.
+            // One in twelve is a simulation on its way to the bad-value flag (tools/diag_redo.py on the configs[4] probe, replayed on
+            // the checker: joint speeds of 160 - 20 000 rad/s at the head of the step, |b| of 1e7 - 5e16 in the substep, one island of 250
+            // rows that the working sets cannot finish), and used to end in `iterations` sweeps: 34 ms per substep in the large tier, a
+            // third of that probe's time.  A pass that has dropped rows therefore gets a bounded attempt -- UHC_WS_LOST_MAXIT working-set
+            // rounds, no windows -- and, when that gives up, UHC_LOST_SWEEPS sweeps from the warm start.
             const bool lost = T.solver == 1 && (out.overflow & 2) != 0;
-            if (T.solver == 1 && !lost) it = k_as_general<TIER, DENSE>(A, mb, S, out.nefc, LC PROF_PASS);
+            if (T.solver == 1) it = k_as_general<TIER, DENSE>(A, mb, S, out.nefc, LC, lost PROF_PASS);
             if (it >= 0 && (it & UHC_WS_WINDOWED)) { it &= UHC_WS_WINDOWED - 1; out.overflow |= 16; }  // (UHC_F_REDO bit 3: an island was solved in windows)
             if (it < 0) {
-                if (T.solver == 1 && !lost) {  // the working sets gave up: sweep from the warm start, as the reference's PGS does
+                if (T.solver == 1) {  // the working sets gave up: sweep from the warm start, as the reference's PGS does
                     for (int r = LANE; r < out.nefc; r += UHC_WAVE) S[L.rowF + r] = S[L.rowW + r];
                     wsync();
                 }
-                out.overflow |= 4 | ((T.solver == 1 && !lost) ? (4 << (-it)) : 0);
+                out.overflow |= 4 | ((T.solver == 1 && it != -2) ? (4 << (-it)) : 0);  // (-2: a pass that dropped rows met an island that needs windows)
                 it = k_pgs<TIER>(A, mb, S, out.nefc, lost ? min(T.iterations, UHC_LOST_SWEEPS) : T.iterations);
             }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1; 8 / 32 / 64: why the working sets gave up (bits 2, 4, 5); 16: not a fallback (above)
             out.iters = it;
