@@ -2,7 +2,7 @@
 general / large tier ended -- direct, in windows of 64 rows (bit 3), or by the sweeps fallback with its reason (bits 2, 4, 5) -- and (b) the
 wall time of the steps in which a fallback / a windowed solve happened against the others.
 
-  python tools/diag_redo.py configs4 [steps] [warmup]
+  python tools/diag_redo.py configs4 [steps] [warmup] [envs]
 """
 import os
 import sys
@@ -20,12 +20,15 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "configs4"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 120
     warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    envs = int(sys.argv[4]) if len(sys.argv) > 4 else None
     from uhc_amd import sim as S
     sys.argv = sys.argv[:1]
     args = bench.parse()
     torch.cuda.set_device(0)
     torch.set_default_dtype(torch.float64)
     kw = {k: v for k, v in bench.PROBES[name].items() if k not in ("name", "steps")}
+    if envs:
+        kw["envs"] = envs
     agent = bench.build_agent(args, 0, 0, torch.float64, **kw)
     agent.per_epoch_update(0)
     env = agent.env
