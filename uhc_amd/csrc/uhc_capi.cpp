@@ -490,7 +490,12 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         // per SIMD; 12 % of the env-steps go through the general tier instead of 2.6 %.  Measured on the generated model class, env-steps/s
         // with 52 KiB / 12 slots -> 40 KiB / 6 slots: 1024 envs 88 k -> 88 k, 2048 envs 119 k -> 98 k (250 envs per step queue for the general
         // tier's consumers), 3072 envs 112 k -> 141 k, 4096 envs (configs[2]'s share of one GPU) 100 k -> 141 k.
-        if (T.ncpair > 0 && n_env >= 3072) { dense_kib = 40; fast_ndense = 6; }
+        // Only for a humanoid of hinge joints without objects: a ball-joint humanoid folds into itself and boxes bring 16 rows each, their envs
+        // need the 12 slots -- with 6, 95 % of configs[4]'s env-steps at 4096 envs went through the general tier (tier trace
+        // r04_v6_tier_trace_configs4_4096.txt), `ball_rollout` took 53 ms per step against 37-43 ms with the wide layout.
+        bool hinge_only = n_trail == 0;
+        for (int j = 0; j < d.njnt; j++) hinge_only = hinge_only && d.jnt_type[j] != UHC_JNT_BALL;
+        if (T.ncpair > 0 && n_env >= 3072 && hinge_only) { dense_kib = 40; fast_ndense = 6; }
         if (const char* fd = getenv("UHC_FAST_DENSE")) {
             int kib = 0, nd = 0, nc = 0;
             const int got = sscanf(fd, "%d,%d,%d", &kib, &nd, &nc);
