@@ -70,9 +70,14 @@ def test_bench_reads_every_committed_profile():
     assert c and c["flop_per_launch"] > 1e9
     t, tsrc = bench.pmc_traffic(bench.FAST_KERNEL[False])
     assert tsrc and t > 1e6
-    for name in ("headline", "floor_only", "configs4", "ball_rollout"):  # per-workload counter passes (tools/pmc_alu.py), where committed
+    for name in ("headline", "floor_only", "shapes", "configs4", "ball_rollout"):  # per-workload counter passes (tools/pmc_alu.py), where committed
         a = bench.alu_per_env_step(name)
         assert a is None or (a["flop_per_env_step"] > 1e6 and a["source"].endswith(".json")), name
+    # the probe at configs[2]'s batch size is the headline's workload: it is priced with the headline's flop per env-step
+    assert (bench.alu_per_env_step("configs2_per_gpu") or {}).get("source") == (bench.alu_per_env_step("headline") or {}).get("source")
+    # every BASELINE config that fits one GPU has a probe, and the probe of configs[2] runs at its 4096 envs per GPU
+    assert set(bench.PROBES) == {"configs2_per_gpu", "floor_only", "shapes", "ball_rollout", "configs4"} and bench.PROBES["configs2_per_gpu"]["envs"] == 4096
+    assert bench.PROBES["configs4"]["objects"] == 4 and bench.PROBES["configs4"]["robot_cfg"]["ball"] and bench.PROBES["ball_rollout"]["robot_cfg"]["ball"]
     r = bench.step_roofline("no_such_workload", 1024, 1e5, 3.5, 76, 75, 25, 105)
     assert r["bound"] == "fp64_valu" and r["achieved"] is None and r["hbm"]["achieved_GBs"] > 0
     latest, bench._latest = bench._latest, None
