@@ -845,7 +845,15 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         //  CUs in the ball-joint rollout's first steps, and consumers that waited for it ran into their time-out.)
         const int grid3 = waiting ? std::min(est3 + est3 / 4 + 2, b->q3_max) : std::min(est3 + est3 / 4 + 2, std::max(64, std::min(share3, (3 * b->n_cu) / 4)));
         const int room2 = 2 * (b->n_cu - (b->large_first && q3 ? std::min(grid3, std::max(est3, 1)) : 0));  // general-tier workgroups beside the large tier's
-        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, b->q2_max) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
+        // (the cap grows with the general tier's share of the step's LDS-time: x consumers and s1 fast-tier workgroups on each of the
+        //  remaining n_cu - x / 2 CUs take equally long when x = est2 s1 n_cu / (est1 + est2 s1 / 2) -- env-steps of the two tiers last
+        //  about as long.  7/8 of that, never below UHC_Q2_MAX, never above 3/4 of the chip: 300 for configs[4] at 1024 envs, where 256 / 320 /
+        //  384 consumers were measured at 65.5 / 66.5 k env-steps/s / worse.)
+        const int s1 = std::max(1, std::min(4, (int)(160 * 1024 / std::max<size_t>(b->lds_bytes_fast, 1))));
+        const int est1 = std::max(0, b->n_env - est2 - est3);
+        const int bal = (int)(((long long)est2 * s1 * b->n_cu) / std::max(1, est1 + (est2 * s1) / 2));
+        const int cap2 = (b->A.dbg & 2048) ? b->q2_max : std::max(b->q2_max, std::min((7 * bal) / 8, (3 * b->n_cu) / 2));
+        const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, cap2) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
         auto launch_large = [&]() -> int {
             HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
