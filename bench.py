@@ -81,6 +81,21 @@ def contact_solve_share(tag=""):
     return (share or None), os.path.basename(f)
 
 
+def rocprof_avg_ms(kernel, tag=""):
+    """Average launch duration (ms) of a step kernel in the latest committed `rocprofv3 --kernel-trace --stats` summary of the same workload
+    (profiles/*_kernel_stats<tag>.txt): printed beside the HIP-event figure of this run so that the two can be compared on the line itself."""
+    try:
+        f = _latest(f"*_kernel_stats{tag}.txt")
+        if not f:
+            return None, None
+        for line in open(f):
+            if line.startswith(kernel) and "|" in line:
+                return float(line.split("|")[3]), os.path.basename(f)
+    except Exception:
+        pass
+    return None, None
+
+
 def valu_f64_counters(kernel, tag=""):
     """float64 VALU instructions per launch of a step kernel from the latest committed PMC pass (profiles/*_pmc_VALU_F64<tag>.txt):
     flop = (ADD + MUL + TRANS + 2 FMA) wave-instructions x 64 lanes (an upper bound on useful flops: inactive lanes count too)."""
@@ -702,6 +717,7 @@ def main():
                          "flop_per_launch": flop_launch, "flop_source": (vc["source"] + ": 64 x (ADD + MUL + TRANS + 2 FMA) f64 wave-instructions of this kernel, per launch") if vc else "estimate (SURVEY 8d: ~20 MFLOP per env-step)",
                          "counters_per_launch": vc["counters"] if vc else None,
                          "kernel_ms": kern_ms, "launches": kern_n, "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
+                         "rocprofv3_avg_ms": rocprof_avg_ms(kname, tag)[0] if n_env == 1024 else None, "rocprofv3_source": rocprof_avg_ms(kname, tag)[1] if n_env == 1024 else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "traffic": traffic, "traffic_over_algorithmic": (traffic / (ALGO_BYTES_PER_ENV_STEP * n_env)) if traffic else None},

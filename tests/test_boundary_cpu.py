@@ -69,6 +69,8 @@ def test_bench_reads_every_committed_profile():
     c = bench.valu_f64_counters(bench.FAST_KERNEL[False])
     assert c and c["flop_per_launch"] > 1e9
     t, tsrc = bench.pmc_traffic(bench.FAST_KERNEL[False])
+    ms, msrc = bench.rocprof_avg_ms(bench.FAST_KERNEL[True], "_selfcol")  # the kernel trace of the headline workload, quoted beside the HIP-event time
+    assert msrc and 1.0 < ms < 50.0 and bench.rocprof_avg_ms("no such kernel") == (None, None)
     assert tsrc and t > 1e6
     for name in ("headline", "floor_only", "shapes", "configs4", "ball_rollout"):  # per-workload counter passes (tools/pmc_alu.py), where committed
         a = bench.alu_per_env_step(name)
