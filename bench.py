@@ -151,6 +151,9 @@ def parse():
     p.add_argument("--probe-warmup", type=int, default=40, help="untimed steps of a probe before its first repetition (outlasts the transient after the restart of all envs)")
     p.add_argument("--probe-reps", type=int, default=3, help="repetitions of a probe; the sub-line reports the median")
     p.add_argument("--only-probe", default=None, help="run one probe alone and print its sub-line (profiling: floor_only | shapes | ball_rollout | configs4)")
+    p.add_argument("--preroll", type=int, default=40, help="untimed rollout steps BEFORE --warmup: all envs restart together at the head of a pass and the first one or two "
+                   "episode lengths (24 steps under the random-init policy) are a transient with fewer contacts than the steady state -- the driver's "
+                   "--warmup 5 alone measured +6 %% (VERDICT r4); the headline is the steady state")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ppo", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
@@ -586,7 +589,7 @@ def main():
     agent.per_epoch_update(0)
     env = agent.env
     n_env = env.n_env
-    T = args.warmup + args.steps
+    T = args.preroll + args.warmup + args.steps
 
     def fence():
         torch.cuda.synchronize()
@@ -595,7 +598,7 @@ def main():
             torch.cuda.synchronize()
 
     agent.rollout_begin(T)
-    for _ in range(args.warmup):
+    for _ in range(args.preroll + args.warmup):  # (pre-roll: past the restart transient; then the W warm-up steps the contract asks for)
         agent.rollout_step()
     fence()
     env.sim.set_timing(True)
@@ -637,7 +640,9 @@ def main():
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             t_up = float(tt.item())
         n_samples = batch.states.shape[0] * world
-        flops = n_samples * 503e6  # ~503 MFLOP per sample per iteration (10 epochs, both nets)
+        # update_params alone: value forward (7.93 M) + fixed-log-prob forward (8.04 M) + 10 epochs x 3 x (8.04 + 7.93 M) = 495 MFLOP per sample
+        # (SURVEY 8d's 503 M per iteration includes the rollout's policy forward, which the timed update does not perform: VERDICT r4 weak 11)
+        flops = n_samples * (7.934976e6 + 8.041472e6 + 10 * 3 * (8.041472e6 + 7.934976e6))
         ppo = {"samples": n_samples, "update_s": t_up, "samples_per_s": n_samples / t_up, "dtype": args.ppo_dtype, "epochs": agent.cfg.num_optim_epoch,
                "gemm_tflops": flops / t_up / 1e12, "mfma_util": flops / t_up / 1e12 / (78.6 if args.ppo_dtype == "float64" else 157.3),
                "mfma_peak_tflops": 78.6 if args.ppo_dtype == "float64" else 157.3, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
@@ -705,7 +710,7 @@ def main():
                        "joint ranges" if dense else "the shipped static asset as it is (floor contacts only; --floor-only)")
         out = {
             "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
-            "n_gpus": world, "per_rank_env_steps_per_s": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "n_gpus": world, "per_rank_env_steps_per_s": per_rank, "steps": args.steps, "warmup": args.warmup, "preroll": args.preroll, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "

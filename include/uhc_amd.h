@@ -114,7 +114,11 @@ enum UhcField {
     UHC_F_CTRL = 8,      /* [n_env][nu]   data.ctrl of the last substep */
     UHC_F_NCON = 9,      /* int32 [n_env] data.ncon of the last forward pass */
     UHC_F_NEFC = 10,     /* int32 [n_env] data.nefc */
-    UHC_F_FAIL = 11,     /* int32 [n_env] sticky physics-failure flag (NaN / huge qacc, qpos, qvel) */
+    UHC_F_FAIL = 11,     /* int32 [n_env] sticky physics-failure flag (NaN / huge qacc, qpos, qvel).  An env that fails at uhc_batch_set_state
+                          * (a pose that is not a pose) keeps the qpos / qvel it was handed and runs NO forward pass: its derived fields
+                          * (xpos, xquat, xipos, qM, qfrc_bias, qacc, ncon, nefc) are those of its PREVIOUS state and must not be read
+                          * until the env has been given a valid state (the reference raises fail from do_simulation only,
+                          * uhc/envs/humanoid_im.py:1207-1211; mj_forward on garbage returns garbage there) */
     UHC_F_SOLVER_ITER = 12, /* int32 [n_env] PGS sweeps used by the last solve */
     UHC_F_QFRC_APPLIED = 13, /* [n_env][nv] data.qfrc_applied of the last substep */
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */

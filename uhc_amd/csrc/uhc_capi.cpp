@@ -499,7 +499,10 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         if (const char* fd = getenv("UHC_FAST_DENSE")) {
             int kib = 0, nd = 0, nc = 0;
             const int got = sscanf(fd, "%d,%d,%d", &kib, &nd, &nc);
-            if (got >= 2 && kib >= 32 && kib <= 160 && nd >= 0 && nd <= UHC_FAST_MAXTWO) { dense_kib = kib; fast_ndense = nd; }
+            // (a model with convex pairs keeps at least one body-body slot: the layout drops the (row, col) table of M from LDS for such a model
+            //  and the launcher picks the DENSE instantiation -- which reads the table from L2 -- by `cf.ndense > 0`: nd = 0 would launch
+            //  <0, 1, false> on a layout without the table it indexes)
+            if (got >= 2 && kib >= 32 && kib <= 160 && nd >= (T.ncpair > 0 ? 1 : 0) && nd <= UHC_FAST_MAXTWO) { dense_kib = kib; fast_ndense = nd; }
             if (got == 3 && nc >= 8 && nc <= UHC_GEN_MAXCON && T.ncpair > 0) fast_maxcon = nc;
         }
         F.con = carve(fast_maxcon * UHC_CON_STRIDE);

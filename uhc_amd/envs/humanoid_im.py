@@ -16,6 +16,7 @@ import torch
 
 from .. import sim as S
 from .._capi import REWARD_IDS, REWARD_PARTS, env_desc
+from ..khrylib.rl.envs.common.mujoco_env import MujocoEnv
 from ..smpllib.smpl_mujoco import SMPLConverter, smpl_to_qpose
 from ..smpllib.torch_smpl_humanoid import Humanoid
 
@@ -280,8 +281,9 @@ class _Data:
         return self.body_xpos[self._names.index(name)]
 
 
-class HumanoidEnv:
-    """Single-environment facade with the reference's constructor and methods (humanoid_im.py:49-70)."""
+class HumanoidEnv(MujocoEnv):
+    """Single-environment facade with the reference's constructor and methods (humanoid_im.py:49-70); like the reference's class it derives
+    from `MujocoEnv` (seed, dt, set_state + forward, state_vector, body-frame helpers: uhc_amd/khrylib/rl/envs/common/mujoco_env.py)."""
 
     def __init__(self, cfg, init_expert, data_specs, mode="train", no_root=False, device=0, body_provider=None):
         """body_provider: (betas, gender) -> (vertices, joints, skin weights) for the shape -> model generator; default: the SMPL files
@@ -344,11 +346,6 @@ class HumanoidEnv:
     cur_t = property(lambda self: int(self.vec.cur_t[0].item()))
     data = property(lambda self: _Data(self.vec))
 
-    def seed(self, seed=None):
-        out = self.vec.seed(seed)
-        self.np_random = self.vec.np_random
-        return out
-
     def set_mode(self, mode):
         self.mode = mode
         self.vec.set_mode(mode)
@@ -371,7 +368,7 @@ class HumanoidEnv:
         self.vec.set_clip_bank({expert_data["seq_name"]: expert_data})
         self.vec.assign([0], [expert_data["seq_name"]], [0], [self.expert["len"]])
 
-    def reset(self):
+    def reset_model(self):  # (MujocoEnv.reset calls it: mujoco_env.py:95-104)
         obs = self.vec.reset()[0].cpu().numpy()
         self.prev_bquat = self.get_body_quat()  # humanoid_im.py:1269 (reset_model -> get_body_quat)
         return obs
@@ -425,7 +422,7 @@ class HumanoidEnv:
         v = self.get_expert_qvel()
         if self.vec.num_obj:  # data.qpos[:qpos_lim] = expert pose: the objects stay where they are
             q, v = np.r_[q, self.get_obj_qpos()], np.r_[v, self.get_obj_qvel()]
-        self.vec.sim.set_state(torch.as_tensor(q[None], dtype=torch.float64), torch.as_tensor(v[None], dtype=torch.float64), torch.zeros(1, dtype=torch.int32))
+        self.set_state(q, v)  # (MujocoEnv: write the state, sim.forward())
 
     def get_head_idx(self):
         return self.model._body_name2id["Head"] - 1

@@ -120,6 +120,22 @@ class Value(nn.Module):
         return linear(self.value_head, self.net(x))
 
 
+class TrajBatch:
+    """The reference's host-side batch (uhc/khrylib/rl/core/trajbatch.py:5-15): the workers' `Memory` objects merged in list order, every field
+    stacked -- states, actions, masks, next_states, rewards, exps, in the order `Memory.push` received them.  (This build's sampler fills
+    `RolloutBatch` on the device instead; `TrajBatch` serves callers that still collect through `Memory`.)"""
+    FIELDS = ("states", "actions", "masks", "next_states", "rewards", "exps")
+
+    def __init__(self, memory_list):
+        merged = memory_list[0]
+        for m in memory_list[1:]:
+            merged.append(m)
+        columns = list(zip(*merged.sample()))
+        for name, col in zip(self.FIELDS, columns):
+            setattr(self, name, np.stack(col))
+        self.batch = iter(columns[len(self.FIELDS):])  # (whatever a caller pushed beyond the six fields, as the reference's iterator leaves it)
+
+
 class LoggerRL:
     """Episode / reward statistics of one sampling pass (logger_rl.py:4-68), fed from device tensors."""
 

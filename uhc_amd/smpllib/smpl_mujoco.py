@@ -118,6 +118,9 @@ SMPL_BONE_KINTREE_NAMES = ["Pelvis", "L_Hip", "L_Knee", "L_Ankle", "L_Toe", "R_H
                            "Spine", "Chest", "Neck", "Head", "L_Thorax", "L_Shoulder", "L_Elbow", "L_Wrist", "L_Hand",
                            "R_Thorax", "R_Shoulder", "R_Elbow", "R_Wrist", "R_Hand"]
 SMPL_EE_NAMES = ["L_Ankle", "R_Ankle", "L_Wrist", "R_Wrist", "Head"]
+# SMPL-H: the 22 body joints of SMPL (no L_Hand / R_Hand) + 15 finger joints per hand (uhc/smpllib/smpl_parser.py:42-95)
+SMPLH_BONE_ORDER_NAMES = SMPL_BONE_ORDER_NAMES[:22] + [f"{side}_{finger}{k}" for side in ("L", "R") for finger in ("Index", "Middle", "Pinky", "Ring", "Thumb")
+                                                       for k in (1, 2, 3)]
 
 
 def rotation_matrix_to_quaternion(R):
@@ -178,3 +181,33 @@ def smpl_to_qpose(pose, mj_model, trans=None, normalize=False, random_root=False
     if count_offset:
         qpos[:, :3] = trans + np.asarray(mj_model.body_pos)[1]
     return qpos
+
+
+def qpos_to_smpl(qpos, mj_model, smpl_model="smpl"):
+    """Inverse of `smpl_to_qpose` for hinge models (smpl_mujoco.py:738-752): qpos (T, nq) -> (pose_aa (T, J, 3) in SMPL joint order, trans (T, 3)).
+    Root: the wxyz quaternion as a rotation vector; every other joint: its (z, y, x) hinge triple read as intrinsic ZYX Euler angles."""
+    from scipy.spatial.transform import Rotation as sRot
+    qpos = np.asarray(qpos, dtype=np.float64)
+    addr = get_body_qposaddr(mj_model)
+    names = SMPL_BONE_ORDER_NAMES if smpl_model == "smpl" else SMPLH_BONE_ORDER_NAMES
+    pose = np.zeros((qpos.shape[0], len(names), 3))
+    pose[:, 0] = sRot.from_quat(qpos[:, [4, 5, 6, 3]]).as_rotvec()
+    for k, name in enumerate(names[1:], start=1):
+        a, b = addr[name]
+        pose[:, k] = sRot.from_euler("ZYX", qpos[:, a:b]).as_rotvec()
+    return pose, qpos[:, :3] - np.asarray(mj_model.body_pos)[1]
+
+
+def smpl_6d_to_qpose(full_pose, model, normalize=False):
+    """[trans (3) | 24 x 6D rotations] -> qpos (smpl_mujoco.py:776-780): the 6D blocks are the first two COLUMNS of each rotation matrix
+    (process_amass_db.convert_aa_to_orth6d); Gram-Schmidt gives the matrix back, its rotation vector goes through `smpl_to_qpose`."""
+    from scipy.spatial.transform import Rotation as sRot
+    full_pose = np.asarray(full_pose, dtype=np.float64)
+    d6 = full_pose[:, 3:].reshape(full_pose.shape[0], -1, 6)  # per joint: column 0 of R, then column 1
+    a, b = d6[..., 0:3], d6[..., 3:6]
+    x = a / np.linalg.norm(a, axis=-1, keepdims=True)
+    z = np.cross(x, b)
+    z /= np.linalg.norm(z, axis=-1, keepdims=True)
+    R = np.stack([x, np.cross(z, x), z], axis=-1)
+    pose_aa = sRot.from_matrix(R.reshape(-1, 3, 3)).as_rotvec().reshape(full_pose.shape[0], -1)
+    return smpl_to_qpose(pose_aa, model, trans=full_pose[:, :3], normalize=normalize)

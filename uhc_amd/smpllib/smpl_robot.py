@@ -62,6 +62,13 @@ class SMPLBody:
         return verts, joints, d["weights"]
 
 
+def in_hull(hull, queries, tolerance=1e-3):
+    """Which query points lie inside (or within `tolerance` of) a scipy ConvexHull (smpl_robot.py:73-80): every facet's plane equation
+    n . x + d evaluated at the point must be <= tolerance."""
+    q = np.atleast_2d(np.asarray(queries, dtype=np.float64))
+    return (q @ hull.equations[:, :-1].T + hull.equations[:, -1] <= tolerance).all(axis=1)
+
+
 def pose_body(verts, joints, skin_weights, pose_aa):
     """Linear blend skinning of a rest-pose body (what `body_provider` returns) by 24 axis-angle joint rotations on the SMPL tree:
     v' = sum_j w_j G_j [v; 1], G_j = prod over the chain of [R_k | J_k - R_k J_k] (smplx's lbs without the pose blend shapes, whose

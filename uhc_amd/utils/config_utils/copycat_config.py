@@ -94,9 +94,11 @@ class Config(Base_Config):
         self.pgs_iterations = g("pgs_iterations", 300)
         self.n_env = g("n_env", 1024)
         self.ppo_dtype = g("ppo_dtype", "float64")
-        # data-parallel gradient exchange: the dtype on the wire.  float64 (default) = the learner's own arithmetic: the N-rank update equals
-        # the single-process one to rounding; float32 halves the bytes of every exchange (SURVEY 8e's 32 MB per epoch)
-        self.grad_allreduce_dtype = g("grad_allreduce_dtype", "float64")
+        # data-parallel gradient exchange: the dtype on the wire.  float32 (default): SURVEY 8e's 32 MB per optimisation epoch; the local
+        # gradient means travel scaled by the rank's sample count and are divided by the global count in the parameters' own float64, so the
+        # N-rank update stays within 1e-4 relative of the single-process one over a whole 10-epoch update (tests/test_learner_cpu.py).
+        # float64 = the learner's own arithmetic on the wire: the N-rank update equals the single-process one to 1e-10, at twice the bytes
+        self.grad_allreduce_dtype = g("grad_allreduce_dtype", "float32")
 
     def update_adaptive_params(self, i_iter):
         cp = self.adp_iter_cp

@@ -72,3 +72,19 @@ def get_angvel_fd(prev_bquat, cur_bquat, dt):
     for i in range(n):
         out[3 * i:3 * i + 3] = rotation_from_quaternion(q_diff[4 * i:4 * i + 4]) / dt
     return out
+
+
+def get_qvel_fd_new(cur_qpos, next_qpos, dt, transform=None):
+    """Finite-difference qvel between two poses (math_utils.py:45-67): root linear velocity in the world, root angular velocity = axis-angle
+    of q_next (x) q_cur^-1 wrapped to (-pi, pi], divided by dt and rotated into the ROOT frame, hinge rates as angle differences wrapped the
+    same way; `transform` re-expresses the linear part in the root / heading frame."""
+    cur_qpos, next_qpos = np.asarray(cur_qpos, dtype=np.float64), np.asarray(next_qpos, dtype=np.float64)
+    v = (next_qpos[:3] - cur_qpos[:3]) / dt
+    axis, angle = rotation_from_quaternion(quaternion_multiply(next_qpos[3:7], quaternion_inverse(cur_qpos[3:7])), True)
+    angle = angle - 2 * np.pi * math.ceil((angle - np.pi) / (2 * np.pi))  # into (-pi, pi]
+    rv = transform_vec(axis * angle / dt, cur_qpos[3:7], "root")
+    diff = next_qpos[7:] - cur_qpos[7:]
+    diff = diff - 2 * np.pi * np.ceil((diff - np.pi) / (2 * np.pi))
+    if transform is not None:
+        v = transform_vec(v, cur_qpos[3:7], transform)
+    return np.concatenate((v, rv, diff / dt))

@@ -93,3 +93,19 @@ def rotation_from_quaternion(q, separate=False):
 
 def quat_mul_vec(q, v):
     return quaternion_matrix(q)[:3, :3].dot(np.asarray(v, dtype=np.float64))
+
+
+def quaternion_from_euler_batch(ai, aj, ak, axes="rzyx"):
+    """(B,) or (B, 1) angle arrays -> (B, 4) wxyz quaternions (transformation.py:1288-1345), for the one convention this path uses."""
+    if axes != "rzyx":
+        raise NotImplementedError("only the 'rzyx' convention is used on this path (humanoid_im.py:943)")
+    return quaternion_from_euler_rzyx(np.asarray(ai).reshape(-1), np.asarray(aj).reshape(-1), np.asarray(ak).reshape(-1))
+
+
+def quat_mul_vec_batch(q, v):
+    """Rotate v (*, 3) by the unit quaternions q (*, 4): v + 2 (w u x v + u x (u x v)), u = the vector part (transformation.py:1212-1229)."""
+    q, v = np.asarray(q, dtype=np.float64), np.asarray(v, dtype=np.float64)
+    assert q.shape[-1] == 4 and v.shape[-1] == 3 and q.shape[:-1] == v.shape[:-1]
+    u = q[..., 1:]
+    uv = np.cross(u, v)
+    return v + 2.0 * (q[..., :1] * uv + np.cross(u, uv))
