@@ -124,7 +124,7 @@ OrcData* orc_data_create(const UhcModelDesc* m) {
     d->efc_vel = calloc(ORC_MAXEFC, 8); d->efc_diagApprox = calloc(ORC_MAXEFC, 8);
     d->efc_floss = calloc(ORC_MAXEFC, 8);
     d->efc_type = calloc(ORC_MAXEFC, 4); d->efc_id = calloc(ORC_MAXEFC, 4); d->efc_edge = calloc(ORC_MAXEFC, 4);
-    d->efc_AR = calloc((size_t)ORC_MAXEFC * ORC_MAXEFC, 8);
+    d->ar_cap = 128; d->efc_AR = calloc((size_t)d->ar_cap * d->ar_cap, 8);
     d->work = calloc((size_t)ORC_MAXEFC * nv + 16 * nv, 8);
     memcpy(d->qpos, m->qpos0, m->nq * 8);
     return d;
@@ -879,8 +879,23 @@ void orc_fwd_acceleration(const UhcModelDesc* m, OrcData* d) {
 }
 
 /* ------------------------------------------------------------------ P6 + P9: dual problem and PGS [MJ-ext] */
+#define ORC_AS_MAXROWS 256  /* rows up to which solver 1 pivots on the dual (the device's first three tiers); beyond: Newton on the primal */
 void orc_project_constraint(const UhcModelDesc* m, OrcData* d) {
     int nv = m->nv, n = d->nefc;
+    for (int r = 0; r < n; r++) {
+        double a = 0;
+        for (int i = 0; i < nv; i++) a += d->efc_J[(size_t)r * nv + i] * d->qacc_smooth[i];
+        d->efc_b[r] = a - d->efc_aref[r];
+    }
+    /* the Delassus matrix, for the solvers that work on the dual (the primal Newton solver does not: it is what takes the big problems) */
+    int fric = 0;
+    for (int r = 0; r < n; r++) fric |= d->efc_type[r] == ORC_EFC_FRICTION;
+    if (m->solver >= 1 && !fric && (m->solver == 2 || n > ORC_AS_MAXROWS)) return;
+    if (n > d->ar_cap) {
+        free(d->efc_AR);
+        d->ar_cap = n + 64;
+        d->efc_AR = malloc((size_t)d->ar_cap * d->ar_cap * 8);
+    }
     double* MinvJt = d->work; /* n*nv: row r = M^-1 J_r^T */
     for (int r = 0; r < n; r++) {
         memcpy(MinvJt + (size_t)r * nv, d->efc_J + (size_t)r * nv, nv * 8);
@@ -893,11 +908,6 @@ void orc_project_constraint(const UhcModelDesc* m, OrcData* d) {
             d->efc_AR[(size_t)r * n + s] = a;
         }
     for (int r = 0; r < n; r++) d->efc_AR[(size_t)r * n + r] += d->efc_R[r];
-    for (int r = 0; r < n; r++) {
-        double a = 0;
-        for (int i = 0; i < nv; i++) a += d->efc_J[(size_t)r * nv + i] * d->qacc_smooth[i];
-        d->efc_b[r] = a - d->efc_aref[r];
-    }
 }
 static double project_force(const OrcData* d, int r, double f) {
     switch (d->efc_type[r]) {
@@ -1037,11 +1047,171 @@ int orc_solve_active_set(const UhcModelDesc* m, OrcData* d) {
     for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
     return 0;
 }
+/* Exact solve of the same problem in its PRIMAL form (UhcModelDesc.solver == 2, and whatever the active set above cannot finish or is too
+ * big for): [MJ-ext] MuJoCo's default solver is Newton on
+ *     min_a  1/2 (a - a_s)^T M (a - a_s) + sum_r s_r(J_r a - aref_r),      s_r(x) = 1/2 D_r x^2 for x < 0, else 0
+ * (unilateral rows: limits, frictionless contacts, pyramid edges; D = 1/R) -- strictly convex, its minimiser is qacc_smooth + M^-1 J^T f*
+ * with f* the optimum of the dual QP the two solvers above work on (f_r = -D_r min(0, J_r a - aref_r)).  The cost of an iteration does not
+ * depend on how many rows carry a force (an nv x nv Hessian, H = M + sum_active D_r J_r^T J_r), which is why the device's last tier uses it for
+ * environments with hundreds of rows (k_primal, uhc_amd/csrc/uhc_physics_impl.h).  Restated here in a-space with dense algebra; the device works
+ * in u = D^1/2 L (a - a_s), where M becomes the identity -- Newton's method with an exact line search is invariant under that change of variables.
+ *   start: a_s + M^-1 J^T f_ws (f_ws = the forces the warm-start acceleration implies, as the PGS above starts) if its cost is below cost(a_s), else a_s
+ *   step:  active = {J_r a - aref_r < 0};  Cholesky of H;  dir = -H^-1 grad;  exact line search along dir (the derivative is piecewise linear and
+ *          increasing: safeguarded Newton on it);  a += alpha dir
+ *   stop:  a full step (alpha = 1 to 1e-12) that leaves the active set as it was -- the minimiser of that set's quadratic, KKT holds -- or a gradient
+ *          below 1e-14 of its first norm; ORC_PRIMAL_MAXIT iterations otherwise (returns 1: not converged, the result is still the best iterate). */
+#define ORC_PRIMAL_MAXIT 100
+#define ORC_PRIMAL_LS_MAXIT 60
+static double primal_cost(int nv, int n, const double* Mx, const double* a, const double* as, const double* J, const double* D, const double* aref, double* jar) {
+    double c = 0;
+    for (int i = 0; i < nv; i++) {
+        double mi = 0;
+        for (int j = 0; j < nv; j++) mi += Mx[(size_t)i * nv + j] * (a[j] - as[j]);
+        c += 0.5 * (a[i] - as[i]) * mi;
+    }
+    for (int r = 0; r < n; r++) {
+        double x = -aref[r];
+        for (int i = 0; i < nv; i++) x += J[(size_t)r * nv + i] * a[i];
+        jar[r] = x;
+        if (x < 0) c += 0.5 * D[r] * x * x;
+    }
+    return c;
+}
+int orc_solve_primal(const UhcModelDesc* m, OrcData* d) {
+    int nv = m->nv, n = d->nefc;
+    const double *J = d->efc_J, *D = d->efc_D, *aref = d->efc_aref, *as = d->qacc_smooth;
+    double* Mx = (double*)malloc((size_t)nv * nv * 8), *H = (double*)malloc((size_t)nv * nv * 8);
+    double* a = (double*)malloc((size_t)nv * 8), *g = (double*)malloc((size_t)nv * 8), *dir = (double*)malloc((size_t)nv * 8), *Md = (double*)malloc((size_t)nv * 8);
+    double* jar = (double*)malloc((size_t)(n + 1) * 8), *p = (double*)malloc((size_t)(n + 1) * 8);
+    unsigned char* act = (unsigned char*)malloc(n + 1);
+    orc_full_m(m, d->qM, Mx);
+    /* start point */
+    for (int i = 0; i < nv; i++) a[i] = 0;
+    for (int r = 0; r < n; r++) {
+        double x = -aref[r];
+        for (int i = 0; i < nv; i++) x += J[(size_t)r * nv + i] * d->qacc_warmstart[i];
+        const double f = x < 0 ? -D[r] * x : 0;
+        for (int i = 0; i < nv; i++) a[i] += J[(size_t)r * nv + i] * f;
+    }
+    orc_solve_sparse(m, d->qLD, a);
+    for (int i = 0; i < nv; i++) a[i] += as[i];
+    if (!(primal_cost(nv, n, Mx, a, as, J, D, aref, jar) < primal_cost(nv, n, Mx, as, as, J, D, aref, p))) memcpy(a, as, nv * 8);
+    int it = 0, ok = 0;
+    double g0 = -1;
+    for (; it < ORC_PRIMAL_MAXIT; it++) {
+        for (int r = 0; r < n; r++) {
+            double x = -aref[r];
+            for (int i = 0; i < nv; i++) x += J[(size_t)r * nv + i] * a[i];
+            jar[r] = x; act[r] = x < 0;
+        }
+        memcpy(H, Mx, (size_t)nv * nv * 8);
+        double gn = 0;
+        for (int i = 0; i < nv; i++) {
+            double mi = 0;
+            for (int j = 0; j < nv; j++) mi += Mx[(size_t)i * nv + j] * (a[j] - as[j]);
+            g[i] = mi;
+        }
+        for (int r = 0; r < n; r++) {
+            if (!act[r]) continue;
+            const double* Jr = J + (size_t)r * nv;
+            for (int i = 0; i < nv; i++) {
+                if (Jr[i] == 0) continue;
+                g[i] += D[r] * jar[r] * Jr[i];
+                for (int j = 0; j < nv; j++) H[(size_t)i * nv + j] += D[r] * Jr[i] * Jr[j];
+            }
+        }
+        for (int i = 0; i < nv; i++) gn += g[i] * g[i];
+        gn = sqrt(gn);
+        if (g0 < 0) g0 = gn;
+        if (gn <= 1e-14 * g0 || gn == 0) { ok = 1; break; }
+        /* Cholesky H = C C^T (lower, in place), dir = -H^-1 g */
+        int bad_h = 0;
+        for (int k = 0; k < nv && !bad_h; k++) {
+            double s = H[(size_t)k * nv + k];
+            for (int q = 0; q < k; q++) s -= H[(size_t)k * nv + q] * H[(size_t)k * nv + q];
+            if (!(s > 0)) { bad_h = 1; break; }
+            const double c = sqrt(s);
+            H[(size_t)k * nv + k] = c;
+            for (int i = k + 1; i < nv; i++) {
+                double t = H[(size_t)i * nv + k];
+                for (int q = 0; q < k; q++) t -= H[(size_t)i * nv + q] * H[(size_t)k * nv + q];
+                H[(size_t)i * nv + k] = t / c;
+            }
+        }
+        if (bad_h) break;
+        for (int i = 0; i < nv; i++) {
+            double t = -g[i];
+            for (int q = 0; q < i; q++) t -= H[(size_t)i * nv + q] * dir[q];
+            dir[i] = t / H[(size_t)i * nv + i];
+        }
+        for (int i = nv - 1; i >= 0; i--) {
+            double t = dir[i];
+            for (int q = i + 1; q < nv; q++) t -= H[(size_t)q * nv + i] * dir[q];
+            dir[i] = t / H[(size_t)i * nv + i];
+        }
+        /* exact line search: phi'(alpha) = (a - a_s + alpha dir)^T M dir + sum_r D_r min(0, jar_r + alpha p_r) p_r */
+        double lin0 = 0, quad = 0;
+        for (int i = 0; i < nv; i++) {
+            double mi = 0;
+            for (int j = 0; j < nv; j++) mi += Mx[(size_t)i * nv + j] * dir[j];
+            Md[i] = mi;
+            lin0 += (a[i] - as[i]) * mi;
+            quad += dir[i] * mi;
+        }
+        for (int r = 0; r < n; r++) {
+            double x = 0;
+            for (int i = 0; i < nv; i++) x += J[(size_t)r * nv + i] * dir[i];
+            p[r] = x;
+        }
+        double alpha = 1.0, lo = 0.0, hi = -1.0;  /* phi'(lo) < 0; hi < 0: no upper bracket yet */
+        for (int ls = 0; ls < ORC_PRIMAL_LS_MAXIT; ls++) {
+            double d1 = lin0 + alpha * quad, d2 = quad;
+            for (int r = 0; r < n; r++) {
+                const double x = jar[r] + alpha * p[r];
+                if (x < 0) { d1 += D[r] * x * p[r]; d2 += D[r] * p[r] * p[r]; }
+            }
+            if (fabs(d1) <= 1e-15 * (fabs(lin0) + 1e-300)) break;
+            if (d1 < 0) lo = alpha; else hi = alpha;
+            double nx = alpha - d1 / d2;
+            if (!(nx > lo) || (hi > 0 && !(nx < hi))) nx = hi > 0 ? 0.5 * (lo + hi) : 2 * alpha;
+            if (nx == alpha) break;
+            alpha = nx;
+        }
+        for (int i = 0; i < nv; i++) a[i] += alpha * dir[i];
+        int same = fabs(alpha - 1.0) <= 1e-12;
+        for (int r = 0; r < n && same; r++) same = ((jar[r] + alpha * p[r]) < 0) == act[r];
+        if (same) { ok = 1; it++; break; }
+    }
+    /* forces, constraint force, acceleration */
+    for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+    for (int r = 0; r < n; r++) {
+        double x = -aref[r];
+        for (int i = 0; i < nv; i++) x += J[(size_t)r * nv + i] * a[i];
+        const double f = x < 0 ? -D[r] * x : 0;
+        d->efc_force[r] = f;
+        if (f != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += J[(size_t)r * nv + i] * f;
+    }
+    memcpy(d->qacc, d->qfrc_constraint, nv * 8);
+    orc_solve_sparse(m, d->qLD, d->qacc);
+    for (int i = 0; i < nv; i++) d->qacc[i] += as[i];
+    d->solver_iter = it;
+    free(Mx); free(H); free(a); free(g); free(dir); free(Md); free(jar); free(p); free(act);
+    return !ok;
+}
+/* solver 0: PGS sweeps.  solver 1 (the package default): the exact optimum -- block pivoting on the dual while the problem is small enough for
+ * it (ORC_AS_MAXROWS rows: what the device's first three tiers hold), Newton on the primal beyond that and wherever the pivoting does not
+ * finish: the same optimum either way.  solver 2: the primal solver alone (tests).  Friction-loss rows (box constraints) go to the sweeps. */
 static void orc_solve_constraints(const UhcModelDesc* m, OrcData* d) {
     int fric = 0;
     for (int r = 0; r < d->nefc; r++) fric |= d->efc_type[r] == ORC_EFC_FRICTION;
-    if (m->solver == 1 && d->nefc > 0 && !fric && !orc_solve_active_set(m, d)) return;
-    orc_solve_pgs(m, d);  /* solver 0, friction-loss rows (box constraints), or no convergence within ORC_AS_MAXIT factorisations */
+    if (m->solver >= 1 && d->nefc > 0 && !fric) {
+        if (m->solver == 1 && d->nefc <= ORC_AS_MAXROWS && !orc_solve_active_set(m, d)) return;
+        d->primal_solves++;
+        if (!orc_solve_primal(m, d)) return;
+        d->primal_unconverged++;
+        return;  /* (the best iterate of a Newton run that hit its cap: an env with |b| of 1e16 on its way to the bad-value flag) */
+    }
+    orc_solve_pgs(m, d);  /* solver 0, or friction-loss rows */
 }
 
 /* ------------------------------------------------------------------ mj_forward / mj_step [MJ-ext] */
@@ -1124,7 +1294,7 @@ void orc_set_state(const UhcModelDesc* m, OrcData* d, const double* qpos, const 
     memset(d->qacc_warmstart, 0, m->nv * 8);
     memset(d->qfrc_applied, 0, m->nv * 8);
     memset(d->ctrl, 0, (m->nu > 0 ? m->nu : 1) * 8);
-    d->fail = 0; d->efc_overflow = 0; d->max_ncon = 0; d->max_nefc = 0;
+    d->fail = 0; d->efc_overflow = 0; d->max_ncon = 0; d->max_nefc = 0; d->primal_solves = 0; d->primal_unconverged = 0;
     orc_forward(m, d);
 }
 
@@ -1290,6 +1460,8 @@ int orc_get_int(const OrcData* d, const char* name) {
     if (!strcmp(name, "nM")) return d->nM;
     if (!strcmp(name, "max_ncon")) return d->max_ncon;
     if (!strcmp(name, "max_nefc")) return d->max_nefc;
+    if (!strcmp(name, "primal_solves")) return d->primal_solves;
+    if (!strcmp(name, "primal_unconverged")) return d->primal_unconverged;
     return -1;
 }
 void orc_set(const UhcModelDesc* m, OrcData* d, const char* name, const double* in) {

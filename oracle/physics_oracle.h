@@ -3,13 +3,17 @@
 #define PHYSICS_ORACLE_H
 #include "../include/uhc_amd.h"
 
-#define ORC_MAXCON 256
-#define ORC_MAXEFC 512
+/* capacities: above what the device path's last tier holds (KernelArgs::cx: up to 1024 rows / 256 contacts), towards the reference's njmax 2500 / nconmax 500
+ * (uhc/khrylib/mocap/skeleton_mesh.py:46) */
+#define ORC_MAXCON 512
+#define ORC_MAXEFC 1280
 
 enum { ORC_EFC_FRICTION = 1, ORC_EFC_LIMIT = 2, ORC_EFC_CONTACT = 3, ORC_EFC_CONTACT_PYR = 4 };
 
 typedef struct OrcData {
     int nM, ncon, nefc, fail, solver_iter, efc_overflow, max_ncon, max_nefc; /* max_*: running maxima since set_state */
+    int primal_solves, primal_unconverged; /* forward passes solved by Newton on the primal since set_state, and how many of those hit the iteration cap */
+    int ar_cap; /* rows the Delassus matrix efc_AR is allocated for (grown on demand: the primal solver does not need it) */
     double *qpos, *qvel, *qacc, *qacc_warmstart, *ctrl, *qfrc_applied;
     double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis;
     double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel;
@@ -59,5 +63,7 @@ void orc_batch_do_simulation(const UhcModelDesc* m, const UhcCtrlDesc* c, OrcDat
                              const double* actions, const double* target_base);
 int orc_get(const UhcModelDesc* m, const OrcData* d, const char* name, double* out, int max);
 int orc_get_int(const OrcData* d, const char* name);
+int orc_solve_primal(const UhcModelDesc* m, OrcData* d);
+int orc_solve_active_set(const UhcModelDesc* m, OrcData* d);
 void orc_set(const UhcModelDesc* m, OrcData* d, const char* name, const double* in);
 #endif

@@ -719,3 +719,95 @@ def test_ball_joint_limit_row_and_cone():
         qq = s.get("qpos")
         peak = max(peak, 2 * np.arctan2(np.linalg.norm(qq[1:]), abs(qq[0])))
     assert 0.5 < peak < 0.55 and s.geti("fail") == 0  # (the hinge limit above: 0.3 < peak < 0.33)
+
+
+def _face_down_beside_a_raft(model, standing, K=7):
+    """A humanoid laid face down into the floor beside a raft of K boxes whose corners dig into each other (tests/test_gpu_selfcollision.py):
+    270-330 constraint rows in the first step, 150-250 of them carrying a force -- beyond the 256 rows of the device's first three tiers."""
+    import dataclasses
+    from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    m = self_collision_variant(model)
+    yaw = [0.06 * (-1) ** k for k in range(K)]
+    poses = np.array([[1.0 + 0.305 * k, 1.0 + 0.01 * k, 0.1495, np.cos(y / 2), 0, 0, np.sin(y / 2)] for k, y in enumerate(yaw)], dtype=np.float64)
+    m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
+    m = dataclasses.replace(m, solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    q = m.qpos0.copy()
+    qh = standing["qpos"].copy()
+    qh[3:7] = quat_mul(np.array([np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0]), qh[3:7])  # tipped forward: face down
+    qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+    q[:76] = qh
+    return m, ctrl, q, np.zeros(m.nv)
+
+
+def test_primal_newton_reaches_the_dual_optimum(model, standing):
+    """orc_solve_primal (Newton on MuJoCo's primal problem, the reference's default solver [MJ-ext]) against orc_solve_active_set (block
+    pivoting on the dual) on identical forward passes along roll-outs of the generated model class and of the ball-joint humanoid among
+    boxes: the same acceleration to 1e-10 (relative), a handful of Newton iterations from the warm start, never the iteration cap."""
+    import dataclasses
+    from oracle.physics import OracleSim
+    from uhc_amd.model.mjcf import add_free_bodies, hinge_to_ball_qpos, ball_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    from uhc_amd.smpllib.smpl_robot import robot_variant
+    rng = np.random.default_rng(21)
+    gen = dataclasses.replace(robot_variant(model, {"mesh": True, "model": "smpl"}), solver=1)
+    ball = robot_variant(model, {"mesh": True, "model": "smpl", "ball": True})
+    poses = np.stack([np.r_[-0.15 + 0.75 * np.cos(a), -0.05 + 0.75 * np.sin(a), 0.16 + 0.35 * k, 1, 0, 0, 0] for k, a in enumerate(rng.uniform(0, 2 * np.pi, size=4))])
+    ball = dataclasses.replace(add_free_bodies(ball, [box_triangles(0.15, 0.15, 0.15)] * 4, poses, density=5.0 / 0.027, friction=1.0, condim=1), solver=1)
+    qb = ball.qpos0.copy()
+    qb[:99] = hinge_to_ball_qpos(model, ball_variant(model), standing["qpos"])
+    cases = [(gen, make_ctrl(gen), standing["qpos"].copy(), np.zeros(75), 0.05, standing["qpos"][7:].copy()),
+             (ball, make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4), qb, np.zeros(ball.nv), 0.003, np.zeros(69))]
+    for m, ctrl, q0, v0, a_sc, tb in cases:
+        o, p = OracleSim(m, ctrl), OracleSim(dataclasses.replace(m, solver=2), ctrl)
+        o.set_state(q0, v0)
+        worst, iters, rows = 0.0, [], 0
+        for t in range(90):
+            for k in ("qacc_warmstart", "ctrl", "qfrc_applied"):
+                p.set(k, o.get(k)) if t else None
+            p.set_state(o.get("qpos"), o.get("qvel"))
+            for k in ("qacc_warmstart", "ctrl", "qfrc_applied"):
+                p.set(k, o.get(k))
+            o.forward(); p.forward()
+            qa, qp = o.get("qacc"), p.get("qacc")
+            worst = max(worst, np.abs(qa - qp).max() / (1.0 + np.abs(qa).max()))
+            if p.geti("nefc"):
+                iters.append(p.geti("solver_iter"))
+            rows = max(rows, p.geti("nefc"))
+            np.testing.assert_allclose(p.get("efc_force"), o.get("efc_force"), atol=1e-8 * (1 + np.abs(o.get("efc_force")).max()))
+            o.do_simulation(rng.normal(scale=a_sc, size=ctrl.action_dim), tb)
+        assert rows > 100 and worst < 1e-10, (rows, worst)
+        assert p.geti("primal_unconverged") == 0 and np.mean(iters) < 6 and max(iters) <= 12, (np.mean(iters), max(iters))
+
+
+def test_primal_newton_on_more_rows_than_the_dual_tiers_hold(model, standing):
+    """The face-down humanoid beside the seven-box raft: 270-330 rows.  solver 1 takes the primal path there by itself (more than 256 rows);
+    its forces satisfy the KKT conditions of the dual QP, with the Delassus matrix formed independently in numpy from J, M and R:
+    f >= 0, y = A f + b >= -tol, f . y = 0 -- and the sweeps run far beyond their tolerance approach the same forces."""
+    import dataclasses
+    from oracle.physics import OracleSim
+    m, ctrl, q, v = _face_down_beside_a_raft(model, standing)
+    o = OracleSim(m, ctrl)
+    o.set_state(q, v)
+    seen = 0
+    for t in range(6):  # the first substeps of the fall: 330 ... 300 rows (then the pile settles below 256)
+        n = o.geti("nefc")
+        assert n > 256 and o.geti("primal_solves") == t + 1 and o.geti("primal_unconverged") == 0 and o.geti("efc_overflow") == 0, (t, n, o.geti("primal_solves"))
+        J, R, b, f = o.get("efc_J").reshape(n, m.nv), o.get("efc_R"), o.get("efc_b"), o.get("efc_force")
+        A = J @ np.linalg.solve(o.full_m(), J.T) + np.diag(R)
+        y = A @ f + b
+        scale = np.abs(b).max()
+        assert (f >= 0).all() and y.min() > -1e-9 * scale and np.abs(f * y).max() < 1e-9 * scale * max(f.max(), 1.0), (y.min(), np.abs(f * y).max(), scale)
+        assert (f > 0).sum() > 64  # more force-carrying rows than one register-resident working set holds
+        np.testing.assert_allclose(o.get("qacc"), o.get("qacc_smooth") + np.linalg.solve(o.full_m(), J.T @ f), atol=1e-8 * (1 + np.abs(o.get("qacc")).max()))
+        seen = max(seen, n)
+        its = o.geti("solver_iter")
+        o.step()
+    sw = OracleSim(dataclasses.replace(m, solver=0, iterations=20000, tolerance=1e-20), ctrl)
+    ex = OracleSim(m, ctrl)
+    sw.set_state(q, v); ex.set_state(q, v)
+    assert np.abs(sw.get("efc_force") - ex.get("efc_force")).max() < 1e-5 * (1 + np.abs(ex.get("efc_force")).max())
+    print(f"face-down humanoid + raft: up to {seen} rows, Newton iterations of the last pass checked {its}")

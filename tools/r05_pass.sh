@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-5 GPU pass (through gpurun): tools/r05_pass.sh TAG STAGE [STAGE ...]; everything lands under gpurun_out/ with the tag, the summaries worth
+# keeping are copied into profiles/ by hand.  Stages of its own:
+#   parity200   tests/test_gpu_parity_200.py alone (north_star's 200-step bar on the bench's model classes); its per-run records land in
+#               gpurun_out/parity200.jsonl and are copied to ${TAG}_parity200.jsonl
+#   occupancy   tools/occupancy_sweep.sh (instrumented library): the fast tier's kernel at 1 / 2 / 3 / 4 workgroups per CU
+#   tests_fast  the GPU suite without the 200-step file (which `parity200` runs)
+#   ppo_prof    kernel trace of one PPO update (bench.py --no-probes --no-cpu-baseline --no-pgs-probe with a short rollout): which kernels the update spends its time in
+# every other stage name is handed to tools/r04_pass.sh (tests, loop, bench, prof_headline, prof_floor, prof_configs4, prof_shapes, slowest, stage, meta).
+set -u
+TAG=${1:-r05_x}; shift
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+O=gpurun_out/${TAG}
+for stage in "$@"; do
+case $stage in
+parity200)
+  rm -f gpurun_out/parity200.jsonl
+  (timeout 1500 python -m pytest tests/test_gpu_parity_200.py -m gpu -q --tb=line -rs 2>&1 | grep -v amdgpu | tail -60) > ${O}_parity200_pytest.txt 2>&1
+  cp gpurun_out/parity200.jsonl ${O}_parity200.jsonl 2>/dev/null
+  tail -3 ${O}_parity200_pytest.txt ;;
+occupancy)
+  bash tools/occupancy_sweep.sh > ${O}_occupancy_sweep.txt 2>&1
+  grep "===\|mean cycles" ${O}_occupancy_sweep.txt | cut -c1-200 ;;
+tests_fast)
+  (timeout 1700 python -m pytest tests -m gpu -q --tb=short -rs --deselect tests/test_gpu_parity_200.py 2>&1 | grep -v amdgpu | tail -45) > ${O}_pytest_gpu.txt 2>&1
+  tail -4 ${O}_pytest_gpu.txt ;;
+ppo_prof)
+  B="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --preroll 6 --no-cpu-baseline --no-pgs-probe --no-probes"
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_ppo -o kt -- $B > $GRAFT_REPO_ROOT/${O}_bench_ppo_under_rocprof.json 2> /tmp/ppo.err)
+  python tools/rocpd_summary.py /tmp/prof_ppo/kt_results.db ${O}_ppo_kernel_stats.txt "$TAG: rocprofv3 --kernel-trace --stats -- bench.py --steps 8 --warmup 2 --preroll 6 --no-cpu-baseline --no-pgs-probe --no-probes (16 rollout steps of 1024 envs + two full PPO updates over 16384 samples: the update's kernels are the Cijk_* / elementwise rows)" > /dev/null
+  head -30 ${O}_ppo_kernel_stats.txt | cut -c1-180 ;;
+*)
+  bash tools/r04_pass.sh "$TAG" "$stage" ;;
+esac
+done

@@ -535,6 +535,12 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             A.marks[1] = A.cf.maxcon; A.marks[4] = A.cf.maxcon - std::max(2, A.cf.maxcon / 8);
         }
         b->lds_bytes_fast = (size_t)off * sizeof(double);
+        // occupancy experiments (tools/occupancy_sweep.sh): UHC_LDS_PAD_FAST = KiB the fast tier's launch ASKS for -- the layout
+        // is unchanged, the workgroup merely occupies more of the CU's 160 KiB, so fewer of them share a CU (64: two, 100: one)
+        if (const char* pad = getenv("UHC_LDS_PAD_FAST")) {
+            const size_t want = (size_t)atoi(pad) * 1024;
+            if (want > b->lds_bytes_fast && want <= 160 * 1024) b->lds_bytes_fast = want;
+        }
         const char* env = getenv("UHC_FORCE_GENERAL");
         b->use_fast = !(env && env[0] == '1') && b->lds_bytes_fast <= 160 * 1024;
     }
