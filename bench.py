@@ -384,6 +384,7 @@ def rollout_probe(args, local, dtype, name, warmup=None, steps=None, reps=None, 
         runs.append({"env_steps_per_s": n_env * steps / el, "ms_per_step": 1e3 * el / steps, "first_tier_kernel_ms": ms / max(k, 1),
                      "general_or_large_tier_share_of_env_steps": redo_d[0] / (n_env * steps), "large_tier_share_of_env_steps": redo_d[3] / (n_env * steps),
                      "sweeps_fallback_share_of_env_steps": redo_d[1] / (n_env * steps), "windowed_exact_solve_share_of_env_steps": redo_d[4] / (n_env * steps),
+                     "tier4_primal_newton_share_of_env_steps": redo_d[5] / (n_env * steps), "tier4_newton_hit_its_cap_env_steps": int(redo_d[6]),
                      "efc_overflow_env_steps": int(redo_d[2])})
     _, logger = agent.rollout_end()
     med = sorted(runs, key=lambda r: r["env_steps_per_s"])[len(runs) // 2]
@@ -734,6 +735,7 @@ def main():
             "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "solver_iters_mean": float(iters.mean()), "general_kernel_envs_last_step": int((env.sim.field(S.F_REDO) != 0).sum().item()),
                                "general_or_large_tier_env_steps_timed_region": int(redo_d[0]), "large_tier_env_steps_timed_region": int(redo_d[3]), "sweeps_fallback_env_steps_timed_region": int(redo_d[1]),
                                "efc_overflow_env_steps_timed_region": int(redo_d[2]), "windowed_exact_solve_env_steps_timed_region": int(redo_d[4]),
+                               "tier4_primal_newton_env_steps_timed_region": int(redo_d[5]), "tier4_newton_hit_its_cap_env_steps_timed_region": int(redo_d[6]),
                                "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257],
                                "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257])[0].tolist(),
                                "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17, 33, 65], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17, 33, 65])[0].tolist(),

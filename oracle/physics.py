@@ -86,7 +86,7 @@ class OracleSim:
         exact solve gave up, and the checker takes solver 0 in exactly those."""
         action = np.ascontiguousarray(action, dtype=np.float64)
         target_base = np.ascontiguousarray(target_base, dtype=np.float64)
-        self.L.orc_do_simulation_mixed(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action), _dp(target_base), (int(redo) >> 8) & 0x7fffff)
+        self.L.orc_do_simulation_mixed(C.byref(self.desc), C.byref(self.ctrl), self.d, _dp(action), _dp(target_base), (int(redo) >> 8) & 0x1fffff)
 
     def pd_torque(self, action, target_base, it):
         action = np.ascontiguousarray(action, dtype=np.float64)

@@ -1058,8 +1058,9 @@ int orc_solve_active_set(const UhcModelDesc* m, OrcData* d) {
  *   start: a_s + M^-1 J^T f_ws (f_ws = the forces the warm-start acceleration implies, as the PGS above starts) if its cost is below cost(a_s), else a_s
  *   step:  active = {J_r a - aref_r < 0};  Cholesky of H;  dir = -H^-1 grad;  exact line search along dir (the derivative is piecewise linear and
  *          increasing: safeguarded Newton on it);  a += alpha dir
- *   stop:  a full step (alpha = 1 to 1e-12) that leaves the active set as it was -- the minimiser of that set's quadratic, KKT holds -- or a gradient
- *          below 1e-14 of its first norm; ORC_PRIMAL_MAXIT iterations otherwise (returns 1: not converged, the result is still the best iterate). */
+ *   stop:  a full step (alpha = 1 to 1e-12) that leaves the active set as it was -- the minimiser of that set's quadratic, KKT holds --, a gradient
+ *          below 1e-14 of its first norm, or a Newton step below 1e-13 of the iterate (M-norm); ORC_PRIMAL_MAXIT iterations otherwise (returns 1:
+ *          not converged, the result is still the best iterate). */
 #define ORC_PRIMAL_MAXIT 100
 #define ORC_PRIMAL_LS_MAXIT 60
 static double primal_cost(int nv, int n, const double* Mx, const double* a, const double* as, const double* J, const double* D, const double* aref, double* jar) {
@@ -1162,6 +1163,15 @@ int orc_solve_primal(const UhcModelDesc* m, OrcData* d) {
             double x = 0;
             for (int i = 0; i < nv; i++) x += J[(size_t)r * nv + i] * dir[i];
             p[r] = x;
+        }
+        {   /* a step below the rounding of the iterate (both measured in the M-norm, which is what the device's u-coordinates measure): converged */
+            double un = 0;
+            for (int i = 0; i < nv; i++) {
+                double mi = 0;
+                for (int j = 0; j < nv; j++) mi += Mx[(size_t)i * nv + j] * (a[j] - as[j]);
+                un += (a[i] - as[i]) * mi;
+            }
+            if (quad <= 1e-26 * (1.0 + un)) { ok = 1; it++; break; }
         }
         double alpha = 1.0, lo = 0.0, hi = -1.0;  /* phi'(lo) < 0; hi < 0: no upper bracket yet */
         for (int ls = 0; ls < ORC_PRIMAL_LS_MAXIT; ls++) {

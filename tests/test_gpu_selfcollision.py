@@ -323,8 +323,12 @@ def test_lying_humanoid_among_boxes_exceeds_128_rows(model, standing):
     assert worst < 1e-5, worst
 
 
-def test_island_with_more_than_64_force_rows_is_solved_exactly_in_windows(model, standing):
-    """MuJoCo's Newton solver (humanoid_template.xml:13) solves the contact QP to 1e-8 whatever its size.  Here the exact solve keeps the
+@pytest.mark.parametrize("tiers", ["4", "3"])
+def test_island_with_more_than_64_force_rows_is_solved_exactly(model, standing, tiers, monkeypatch):
+    """(tiers = 4, the default: the general / large tier hands such an island on to tier 4, whose Newton iteration on the primal problem -- MuJoCo's own
+    default solver -- has no limit on the rows that carry a force: UHC_F_REDO bit 30, no windows, no sweeps.  tiers = 3, UHC_TIERS=3: the three-tier chain of
+    rounds 3-4, described next.)
+    MuJoCo's Newton solver (humanoid_template.xml:13) solves the contact QP to 1e-8 whatever its size.  Here the exact solve keeps the
     Delassus matrix of at most 64 rows in registers; an island with more force-carrying rows than that is solved in windows of 64 rows
     (block coordinate descent to a KKT residual of 1e-9 (1 + max |b|), UHC_F_REDO bit 3) instead of falling back to the sweeps (bit 1).
     Scene: seven 5 kg boxes side by side on the floor, yawed +-3.4 degrees so that every corner digs a millimetre into its neighbour --
@@ -339,6 +343,7 @@ def test_island_with_more_than_64_force_rows_is_solved_exactly_in_windows(model,
     from uhc_amd.model.mjcf import add_free_bodies, self_collision_variant
     from uhc_amd.model.shapes import box_triangles
     from uhc_amd.sim import make_ctrl
+    monkeypatch.setenv("UHC_TIERS", tiers)
     K = 7
     m = self_collision_variant(model)
     yaw = [0.06 * (-1) ** k for k in range(K)]
@@ -357,7 +362,7 @@ def test_island_with_more_than_64_force_rows_is_solved_exactly_in_windows(model,
     os_ = [OracleSim(m, ctrl) for _ in range(n)]
     tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
     act = np.zeros((n, ctrl.action_dim))
-    windowed, swept, worst_q, worst_v, max_nefc = 0, 0, 0.0, 0.0, 0
+    windowed, swept, primal, worst_q, worst_v, max_nefc = 0, 0, 0, 0.0, 0.0, 0
     for t in range(4):
         gq0, gv0 = b.field(S.F_QPOS).cpu().numpy().copy(), b.field(S.F_QVEL).cpu().numpy().copy()
         b.simulate(torch.from_numpy(act).cuda(), tb)
@@ -366,22 +371,28 @@ def test_island_with_more_than_64_force_rows_is_solved_exactly_in_windows(model,
         redo = b.field(S.F_REDO).cpu().numpy()
         for e in range(n):
             windowed += int((redo[e] & 8) != 0)
+            primal += int((redo[e] & (1 << 30)) != 0)
+            assert not (redo[e] & (1 << 29)), hex(int(redo[e]))  # (the Newton iteration never ran into its cap)
             swept += int((redo[e] & 2) != 0)
             os_[e].set_state(gq0[e], gv0[e])
             os_[e].do_simulation(act[e], np.zeros(69))
             dq, dv = np.abs(gq[e] - os_[e].get("qpos")).max(), np.abs(gv[e] - os_[e].get("qvel")).max()
             worst_q, worst_v = max(worst_q, dq), max(worst_v, dv)
             max_nefc = max(max_nefc, os_[e].geti("max_nefc"))
-    print(f"raft of {K} boxes: env-steps with a windowed exact solve {windowed} / {4 * n}, sweeps fallbacks {swept}, max nefc {max_nefc}; "
+    print(f"raft of {K} boxes, tiers {tiers}: env-steps with a windowed exact solve {windowed} / {4 * n}, solved by Newton on the primal {primal}, sweeps fallbacks {swept}, max nefc {max_nefc}; "
           f"one control step from the device's state, device vs oracle: |dqpos| {worst_q:.2e} |dqvel| {worst_v:.2e}")
-    assert windowed > 0, "no island exceeded 64 force-carrying rows: the scene no longer exercises the windows"
+    if tiers == "3":
+        assert windowed > 0 and primal == 0, "no island exceeded 64 force-carrying rows: the scene no longer exercises the windows"
+    else:
+        assert primal > 0 and windowed == 0, (primal, windowed)
     assert swept == 0
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
     assert worst_q < 1e-10 and worst_v < 1e-8, (worst_q, worst_v)
 
 
-def test_pass_that_drops_rows_is_flagged_and_bounded(model, standing):
-    """Beyond the large tier's 256 rows constraint rows are dropped (the reference's njmax is 2500: uhc/khrylib/mocap/skeleton_mesh.py:46) and the
+def test_pass_that_drops_rows_is_flagged_and_bounded(model, standing, monkeypatch):
+    """(UHC_TIERS=3: the three-tier chain.  With tier 4 behind the large tier -- the default -- these rows are not dropped: next test.)
+    Beyond the large tier's 256 rows constraint rows are dropped (the reference's njmax is 2500: uhc/khrylib/mocap/skeleton_mesh.py:46) and the
     pass is no longer the reference's QP.  It is reported where it happens -- UHC_F_REDO bit 7 of that step, UHC_F_EFC_OVERFLOW until the next
     set_state -- and its truncated QP gets a bounded exact attempt (six working-set rounds, no windows) and, if that gives up, at most 32
     sweeps (bit 1 with bit 7, and none of the "gave up" reasons that would mean 300 sweeps).  Scene: a
@@ -393,6 +404,7 @@ def test_pass_that_drops_rows_is_flagged_and_bounded(model, standing):
     from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
     from uhc_amd.model.shapes import box_triangles
     from uhc_amd.sim import make_ctrl
+    monkeypatch.setenv("UHC_TIERS", "3")
     K = 7
     m = self_collision_variant(model)
     yaw = [0.06 * (-1) ** k for k in range(K)]
@@ -429,3 +441,68 @@ def test_pass_that_drops_rows_is_flagged_and_bounded(model, standing):
     assert lost_steps > 0  # (UHC_F_NEFC is the step's LAST substep: the rows were lost in its first ones)
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) > 0 and int(b.field(S.F_FAIL).sum().item()) == 0
     assert np.isfinite(b.field(S.F_QPOS).cpu().numpy()).all()
+
+
+def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing):
+    """The reference asks MuJoCo for njmax 2500 / nconmax 500 (uhc/khrylib/mocap/skeleton_mesh.py:46) and solves with Newton on the primal.  The scene of
+    the test above -- a humanoid face down in the floor beside the seven-box raft, 270-330 rows in the first substeps, more than 150 of them
+    carrying a force -- is beyond the 256 rows / 128 contacts of the large tier: its workgroup goes on as tier 4 (rows in HBM, the nv x nv
+    Hessian in LDS, uhc_primal.h).  Nothing is dropped (UHC_F_EFC_OVERFLOW clear, UHC_F_REDO bit 7 clear), bit 30 reports the primal solve, and
+    every control step from the device's own state equals the oracle's (which takes its own primal path above 256 rows) to 1e-9."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    K = 7
+    m = self_collision_variant(model)
+    yaw = [0.06 * (-1) ** k for k in range(K)]
+    poses = np.array([[1.0 + 0.305 * k, 1.0 + 0.01 * k, 0.1495, np.cos(y / 2), 0, 0, np.sin(y / 2)] for k, y in enumerate(yaw)], dtype=np.float64)
+    m = add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027)
+    m = dataclasses.replace(m, solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n = 3
+    q = np.tile(m.qpos0, (n, 1))
+    for e in range(n):
+        qh = standing["qpos"].copy()
+        a = np.pi / 2 + 0.1 * e
+        qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])  # tipped forward: face down
+        qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+        q[e, :76] = qh
+    v = np.zeros((n, m.nv))
+    for mode in (0, 2):  # the tier chain, and the sticky queues (the large tier's consumers go on as tier 4)
+        b = S.SimBatch(m, ctrl, n)
+        b.set_kernel_path(mode)
+        b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+        b.sync()
+        os_ = [OracleSim(m, ctrl) for _ in range(n)]
+        for e in range(n):  # the forward pass of set_state: already more rows than the large tier holds
+            os_[e].set_state(q[e], v[e])
+            assert os_[e].geti("nefc") > 256
+            assert int(b.field(S.F_NEFC)[e].item()) == os_[e].geti("nefc") and int(b.field(S.F_NCON)[e].item()) == os_[e].geti("ncon")
+            np.testing.assert_allclose(b.field(S.F_QACC)[e].cpu().numpy(), os_[e].get("qacc"), atol=1e-7 * (1 + np.abs(os_[e].get("qacc")).max()))
+        tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+        act = np.zeros((n, ctrl.action_dim))
+        primal, worst_q, worst_v, max_nefc = 0, 0.0, 0.0, 0
+        for t in range(5):
+            gq0, gv0 = b.field(S.F_QPOS).cpu().numpy().copy(), b.field(S.F_QVEL).cpu().numpy().copy()
+            b.simulate(torch.from_numpy(act).cuda(), tb)
+            b.sync()
+            gq, gv = b.field(S.F_QPOS).cpu().numpy(), b.field(S.F_QVEL).cpu().numpy()
+            redo = b.field(S.F_REDO).cpu().numpy()
+            for e in range(n):
+                assert not (redo[e] & 0x80) and not (redo[e] & 2) and not (redo[e] & (1 << 29)), (t, e, hex(int(redo[e])))
+                primal += int((redo[e] & (1 << 30)) != 0)
+                os_[e].set_state(gq0[e], gv0[e])
+                os_[e].do_simulation(act[e], np.zeros(69))
+                worst_q = max(worst_q, np.abs(gq[e] - os_[e].get("qpos")).max())
+                worst_v = max(worst_v, np.abs(gv[e] - os_[e].get("qvel")).max())
+                max_nefc = max(max_nefc, os_[e].geti("max_nefc"))
+        print(f"face-down humanoid + raft of {K} boxes, kernel path {mode}: up to {max_nefc} rows, {primal} of {5 * n} env-steps went through tier 4; one control step from the "
+              f"device's state, device vs oracle: |dqpos| {worst_q:.2e} |dqvel| {worst_v:.2e}")
+        assert max_nefc > 256 and primal > 0
+        assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
+        assert worst_q < 1e-9 and worst_v < 1e-7, (worst_q, worst_v)
+        b.close()

@@ -23,6 +23,18 @@ parity200)
 occupancy)
   bash tools/occupancy_sweep.sh > ${O}_occupancy_sweep.txt 2>&1
   grep "===\|mean cycles" ${O}_occupancy_sweep.txt | cut -c1-200 ;;
+parity_ball)
+  rm -f gpurun_out/parity200.jsonl
+  (timeout 1500 python -m pytest tests/test_gpu_parity_200.py -m gpu -q --tb=line -rs -k "ball" 2>&1 | grep -v amdgpu | tail -40) > ${O}_parity200_ball_pytest.txt 2>&1
+  cp gpurun_out/parity200.jsonl ${O}_parity200_ball.jsonl 2>/dev/null
+  tail -3 ${O}_parity200_ball_pytest.txt ;;
+tier4)
+  (timeout 900 python -m pytest tests/test_gpu_selfcollision.py -m gpu -q --tb=short -rs -s -k "tier_4 or solved_exactly or drops_rows or lying" 2>&1 | grep -v amdgpu | tail -60) > ${O}_tier4_pytest.txt 2>&1
+  tail -25 ${O}_tier4_pytest.txt ;;
+probe_configs4)
+  python bench.py --only-probe configs4 > ${O}_probe_configs4.json 2> ${O}_probe_configs4.err
+  python bench.py --only-probe ball_rollout > ${O}_probe_ball_rollout.json 2>> ${O}_probe_configs4.err
+  cut -c1-1500 ${O}_probe_configs4.json ;;
 tests_fast)
   (timeout 1700 python -m pytest tests -m gpu -q --tb=short -rs --deselect tests/test_gpu_parity_200.py 2>&1 | grep -v amdgpu | tail -45) > ${O}_pytest_gpu.txt 2>&1
   tail -4 ${O}_pytest_gpu.txt ;;

@@ -572,6 +572,31 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.total = off;
         return off <= budget_doubles;
     };
+    // ---- tier 4 (huge): what the large tier cannot hold (more than 256 rows / 128 contacts / 32 body-body rows) or cannot finish (islands with
+    //      more force-carrying rows than a 64-row working set).  Persistent part + contacts + per-row scalars + the nv x nv Hessian of the
+    //      primal problem (packed lower triangle) in LDS; the Yhat rows themselves -- chain rows packed, body-body rows as dense nv-vectors --
+    //      in HBM (KernelArgs::gY / gD, one slice per env, L2-resident while the env's workgroup runs).  Rows: the largest multiple of 128 up
+    //      to UHC_HUGE_MAXEFC that the LDS holds (nv 75: 1024; nv 99, the humanoid among four boxes: 768).
+    auto huge_layout = [&](DevLds& F, TierCap& cp, int maxefc) -> bool {
+        common(F, false);
+        cp.maxefc = maxefc; cp.maxcon = UHC_HUGE_MAXCON; cp.ndense = T.ncpair > 0 ? UHC_HUGE_MAXTWO : 0;
+        cp.ld_delta = (F.LD - A.lf.LD) * 8;
+        F.con = carve(cp.maxcon * UHC_CON_STRIDE);
+        F.dcol = F.con;
+        F.rowMisc = carve(std::max(maxefc * 2, 128));  // (the collision pass keeps its candidate-pair list here: 256 ints)
+        F.ncon_nefc = carve(2 + (cp.ndense + 1) / 2 + 1);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids
+        F.rowY = carve(maxefc / 2 + 1);
+        F.rowR = carve(maxefc); F.rowAref = carve(maxefc); F.rowB = carve(maxefc); F.rowF = carve(maxefc); F.rowDa = carve(maxefc); F.rowW = carve(maxefc);
+        F.dsc = carve(std::max(cp.ndense * 4, 2));
+        F.H = carve((nv * (nv + 1)) / 2);
+        F.Y = F.dense = F.H;  // (never addressed in this tier: the rows live in gY / gD)
+        cp.ycap = maxefc * YS + 8;
+        // MPR's hull vertices: staged where the Hessian will be (nothing of it exists during the collision pass) when they fit
+        cp.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= (nv * (nv + 1)) / 2) ? F.H : -1;
+        if (off < end1) off = end1;  // (the region also holds the dynamics temporaries of phase 1)
+        F.total = off;
+        return off <= 160 * 1024 / 8;
+    };
     {
         const char* tv = getenv("UHC_TIERS");
         A.last_tier = (tv && tv[0] == '2') ? 2 : 3;
@@ -591,6 +616,17 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             }
         }
         b->lds_bytes = (size_t)A.l.total * sizeof(double);
+        A.lx = A.lh; A.cx = A.ch; A.gY = A.gD = nullptr; A.gy_stride = A.gd_stride = 0;
+        if (A.last_tier == 3 && !(tv && tv[0] == '3')) {  // (UHC_TIERS=3: the three-tier chain of rounds 3-4, windows and all)
+            bool ok4 = false;
+            for (int me = UHC_HUGE_MAXEFC; me >= 384 && !ok4; me -= 128) ok4 = huge_layout(A.lx, A.cx, me);
+            if (ok4) {
+                A.last_tier = 4;
+                b->lds_bytes_big = std::max(b->lds_bytes_big, (size_t)A.lx.total * sizeof(double));
+                A.gy_stride = A.cx.ycap;
+                A.gd_stride = std::max(A.cx.ndense, 1) * A.nvp;
+            } else { A.lx = A.lh; A.cx = A.ch; }
+        }
     }
     // ---- static schedules for the factorisation and the triangular solves (see DevTopo).  Addresses are LDS byte
     //      addresses of the FAST layout's LD buffer (the general kernel adds its own LD offset, KernelArgs::ld_delta).
@@ -691,6 +727,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
     TRY(dalloc(b, E, &S.ncon)); TRY(dalloc(b, E, &S.nefc)); TRY(dalloc(b, E, &S.fail)); TRY(dalloc(b, E, &S.solver_iter));
     TRY(dalloc(b, E, &S.overflow));
+    if (A.last_tier == 4) { TRY(dalloc(b, E * (size_t)A.gy_stride, &A.gY)); TRY(dalloc(b, E * (size_t)A.gd_stride, &A.gD)); }
     TRY(dalloc(b, E, &b->reset_mask));
     A.n_env = n_env;
     // qpos <- qpos0 of each env's model
@@ -794,7 +831,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
     }
     const bool general = b->general_only;
-    const bool big = b->A.last_tier == 3;
+    const bool big = b->A.last_tier >= 3;  // (tier 4 has no launch of its own: the large tier's workgroups go on with it)
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
     HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 5, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3, resume, why: one allocation
     // (inside a stream capture the sticky launch cannot be used: it sizes its consumer launches from counts the host reads between steps

@@ -5,9 +5,11 @@
 #include <stdint.h>
 
 #define UHC_WAVE 64
-// capacities per env of the three kernel tiers (fast / general / large): constraint rows, contacts, rows between two moving bodies (kept
+// capacities per env of the kernel tiers (fast / general / large / huge): constraint rows, contacts, rows between two moving bodies (kept
 // as dense dof vectors).  The reference's models ask MuJoCo for njmax 2500 / nconmax 500 (uhc/khrylib/mocap/skeleton_mesh.py:46); what
-// exceeds the last tier is dropped and flagged (UHC_F_EFC_OVERFLOW).
+// exceeds the last tier is dropped and flagged (UHC_F_EFC_OVERFLOW).  The first three tiers solve the DUAL problem (Delassus blocks of <= 64
+// rows in registers) and keep their rows in LDS; the fourth -- rows in HBM / L2, the LDS for an nv x nv Hessian -- solves the PRIMAL problem by
+// Newton's method, as the reference's MuJoCo does, at a cost that does not depend on the row count (uhc_primal.h).
 #define UHC_FAST_MAXEFC 64   // one row per lane, Delassus matrix in registers
 #define UHC_FAST_MAXCON 16
 #define UHC_FAST_MAXCON_DENSE 24  // models with body-body contacts (1 row each at condim 1) reach a 16-contact cap long before the row cap: on the
@@ -20,7 +22,10 @@
 #define UHC_BIG_MAXEFC 256   // four rows per lane
 #define UHC_BIG_MAXCON 128
 #define UHC_BIG_MAXTWO 32
-#define UHC_MAXTWO 32        // dense-row slots of the largest tier (sizes the slot tables of every layout)
+#define UHC_MAXTWO 32        // dense-row slots of the largest of the first three tiers (sizes the slot tables of their layouts)
+#define UHC_HUGE_MAXEFC 1024 // tier 4: at most 16 rows per lane; the layout takes the largest multiple of 128 its LDS holds beside the Hessian
+#define UHC_HUGE_MAXCON 192  // (a humanoid of 24 hulls lying among four boxes: <= 4 floor contacts per hull = 112, + body-body contacts)
+#define UHC_HUGE_MAXTWO 128
 #define UHC_DOF_MAXACT 4
 #define UHC_CON_STRIDE 24
 // why a tier could not hold an env (bits 16+ of the forward pass's overflow word; UHC_F_HANDON_WHY = the word >> 16 of the env's last hand-on)
@@ -29,6 +34,7 @@
 #define UHC_WHY_DENSE_SLOTS (1 << 18)
 #define UHC_WHY_ROW_STORAGE (1 << 19)
 #define UHC_WHY_CANDIDATES (1 << 20)
+#define UHC_WHY_SOLVER (1 << 21)  // the working sets of the general / large tier did not finish (more than 64 force-carrying rows in an island, no convergence): Newton on the primal takes over
 #define UHC_MINVAL 1e-15
 #define UHC_MAXVAL 1e10
 
@@ -88,6 +94,7 @@ struct DevLds {
     int dcol;   // [ndense][64] column of the Delassus matrix of every dense row (A is symmetric: the row's lane reads it back); in the general /
                 // large layouts it shares the contacts' storage, which nothing reads once the rows are built
     int dsc;    // general kernel: [ndense][4] J.qvel, J.qacc_smooth, J.qacc_warmstart, |Yhat|^2 of every dense row
+    int H;      // tier 4: the Hessian of the primal problem, packed lower triangle column by column (nv (nv + 1) / 2 doubles)
     int total;  // doubles
 };
 
@@ -136,8 +143,13 @@ struct KernelArgs {
     DevLds lf;  // fast tier: 40 KiB (53 with dense-row slots): 4 (3) workgroups per CU
     DevLds l;   // general tier: <= 79 KiB: 2 workgroups per CU
     DevLds lh;  // large tier: <= 160 KiB
-    TierCap cf, cg, ch;
-    int last_tier;  // 2 or 3: the tier that drops what exceeds it instead of handing the env on
+    DevLds lx;  // tier 4 (huge): <= 160 KiB -- persistent part, contacts, per-row scalars, the Hessian; Yhat rows and dense rows in HBM (gY, gD)
+    TierCap cf, cg, ch, cx;
+    double* gY;  // tier 4: [n_env][gy_stride] packed Yhat rows of the env (L2-resident while its workgroup runs)
+    double* gD;  // tier 4: [n_env][gd_stride] dense Yhat rows (slot-major, nvp doubles each)
+    int gy_stride, gd_stride;
+    int last_tier;  // 2, 3 or 4: the tier that drops what exceeds it instead of handing the env on.  Tier 4 has no launch of its own: the large
+                    // tier's workgroup goes on with it (same LDS allocation, other carve) when its env does not fit or its working sets give up
     const int* order;  // launch order: workgroup k works on env order[k] (null: env k)
     int tier_want;  // 0: the launch works on every active env; else (sticky tiers) it leaves out the envs whose tier_now differs AND has its own launch
     int sticky_mask;  // bit t: tier t has its own (list) launch this step

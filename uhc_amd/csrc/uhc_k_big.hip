@@ -1,4 +1,6 @@
 // uhc_k_big.hip -- one translation unit of the fused step kernel (instantiations split across files so that they compile in parallel).
+// the large tier's workgroups go on as tier 4 (Newton on the primal, uhc_primal.h) when an env does not fit or its working sets give up
+#define UHC_WITH_TIER4
 #include "uhc_physics_impl.h"
 
 extern "C" hipError_t uhc_launch_m0_big(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {

@@ -34,14 +34,21 @@ extern __shared__ __attribute__((aligned(16))) double smem[];
 // sets, two workgroups per CU), TIER 3 = large (<= 256 rows, a whole CU's LDS).  A tier that cannot hold an env leaves it untouched and
 // hands it to the next one; only the last tier of a batch (KernelArgs::last_tier) drops what exceeds it and flags the env.
 template <int TIER> __device__ __forceinline__ const DevLds& lds_of(const KernelArgs& A) {
-    if constexpr (TIER == 1) return A.lf; else if constexpr (TIER == 2) return A.l; else return A.lh;
+    if constexpr (TIER == 1) return A.lf; else if constexpr (TIER == 2) return A.l; else if constexpr (TIER == 3) return A.lh; else return A.lx;
 }
 template <int TIER> __device__ __forceinline__ const TierCap& cap_of(const KernelArgs& A) {
-    if constexpr (TIER == 1) return A.cf; else if constexpr (TIER == 2) return A.cg; else return A.ch;
+    if constexpr (TIER == 1) return A.cf; else if constexpr (TIER == 2) return A.cg; else if constexpr (TIER == 3) return A.ch; else return A.cx;
 }
 // does this tier hand an env it cannot hold to the next one (true), or drop the excess and flag it (false)?
 template <int TIER> __device__ __forceinline__ bool hands_on(const KernelArgs& A) { return TIER == 1 ? !A.truncate : TIER < A.last_tier; }
 __device__ __forceinline__ void wsync() { __syncthreads(); }
+// where a tier keeps its constraint rows: LDS (tiers 1-3), or the env's slice of the HBM row store (tier 4: the LDS is the Hessian's, uhc_primal.h)
+template <int TIER> __device__ __forceinline__ double* y_store(const KernelArgs& A, double* S, int env) {
+    if constexpr (TIER == 4) return A.gY + (size_t)env * A.gy_stride; else return S + lds_of<TIER>(A).Y;
+}
+template <int TIER> __device__ __forceinline__ double* d_store(const KernelArgs& A, double* S, int env) {
+    if constexpr (TIER == 4) return A.gD + (size_t)env * A.gd_stride; else return S + lds_of<TIER>(A).dense;
+}
 
 // ------------------------------------------------------------------ lane helpers
 __device__ __forceinline__ double bcast(double v, int src) {  // src must be wave-uniform
@@ -1117,7 +1124,7 @@ struct DenseOut { double vel, jas, jaw, yy; };
 // rows[j] < 0: no row in position j of the group.  The rows' Yhat go to the dense slots slot0 + j.
 template <int TIER>
 __device__ __forceinline__ void k_dense_rows(const KernelArgs& A, double* S, const int (&rows)[UHC_DENSE_GROUP], int slot0, const LaneConst& LC,
-                                             DenseOut (&o)[UHC_DENSE_GROUP]) {
+                                             DenseOut (&o)[UHC_DENSE_GROUP], double* Db) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     DofVec x[UHC_DENSE_GROUP];
@@ -1165,7 +1172,7 @@ __device__ __forceinline__ void k_dense_rows(const KernelArgs& A, double* S, con
 #pragma unroll
     for (int j = 0; j < UHC_DENSE_GROUP; j++) {
         if (rows[j] < 0) continue;
-        double* D = S + L.dense + (slot0 + j) * A.nvp;
+        double* D = Db + (slot0 + j) * A.nvp;
         const double y0 = x[j].a * sd0, y1 = x[j].b * sd1;
         if (LC.v0) D[LANE] = y0;
         if (LC.v1) D[LANE + UHC_WAVE] = y1;
@@ -1189,7 +1196,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 // Returns 0, or 1 when the packed rows do not fit this tier's Yhat storage (-> the env goes to the next tier; the last tier's storage holds
 // maxefc full-length rows, so it cannot happen there).
 template <int TIER>
-__device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC) {
+__device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, double* Yb, double* Db) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
@@ -1214,7 +1221,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
 #pragma unroll
         for (int j = 0; j < UHC_DENSE_GROUP; j++) rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
         DenseOut o[UHC_DENSE_GROUP];
-        k_dense_rows<TIER>(A, S, rr, k0, LC, o);
+        k_dense_rows<TIER>(A, S, rr, k0, LC, o, Db);
 #pragma unroll
         for (int j = 0; j < UHC_DENSE_GROUP; j++)
             if (rr[j] >= 0 && LANE == 0) { const int k = k0 + j; S[L.dsc + 4 * k] = o[j].vel; S[L.dsc + 4 * k + 1] = o[j].jas; S[L.dsc + 4 * k + 2] = o[j].jaw; S[L.dsc + 4 * k + 3] = o[j].yy; }
@@ -1226,7 +1233,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
         const bool two = (rm.type & ROW_TWO) != 0;
         const int last = rm.last, len = two ? 0 : T.dof_depth[last] + 1;
         const short* anc = T.dof_anc + (two ? 0 : last) * (T.maxdepth + 1);
-        double* Y = S + L.Y + RY[r];
+        double* Y = Yb + RY[r];
         double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
         if (rt == ROW_FRICTION || rt == ROW_LIMIT) {
             const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
@@ -1325,7 +1332,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
     }
     // the register-resident solves of the working sets (k_as_general) read rows in chunks of 8 entries, past the row's own length and into
     // the next row: everything there must be finite (it meets a zero multiplier) -- the rows are, and so is the slack after the last one
-    if (LANE < 8) S[L.Y + ytot + LANE] = 0.0;
+    if (LANE < 8) Yb[ytot + LANE] = 0.0;
     wsync();
     return 0;
 }
@@ -1333,7 +1340,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
 // ------------------------------------------------------------------ P9 projected Gauss-Seidel on the dual (matrix-free)
 // z = sum_r f_r Yhat_r  (nv vector in LDS);  (A f)_r = Yhat_r . z[chain_r].
 template <int TIER>
-__device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc, int max_sweeps) {
+__device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, double* S, int nefc, int max_sweeps, const double* Yb, const double* Db) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
@@ -1360,9 +1367,9 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
         double acc = 0;
         for (int r = 0; r < nefc; r++) {
             const int last = RM[r].last;
-            if (last >= i && last <= i + nd) acc += S[L.rowF + r] * S[L.Y + RY[r] + di];
+            if (last >= i && last <= i + nd) acc += S[L.rowF + r] * Yb[RY[r] + di];
         }
-        for (int k = 0; k < ntwo; k++) acc += S[L.rowF + NI[4 + k]] * S[L.dense + k * A.nvp + i];
+        for (int k = 0; k < ntwo; k++) acc += S[L.rowF + NI[4 + k]] * Db[k * A.nvp + i];
         z[i] = acc;
     }
     wsync();
@@ -1373,12 +1380,12 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
         const double f = S[L.rowF + r];
         double af = S[L.rowR + r] * f;
         if (rm.type & ROW_TWO) {
-            const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
+            const double* D = Db + (rm.type >> 8) * A.nvp;
             for (int i = 0; i < T.nv; i++) af += D[i] * z[i];
         } else {
             const int last = rm.last, len = T.dof_depth[last] + 1;
             const short* anc = anc_tab + last * YS;
-            for (int q = 0; q < len; q++) af += S[L.Y + RY[r] + q] * z[anc[q]];
+            for (int q = 0; q < len; q++) af += Yb[RY[r] + q] * z[anc[q]];
         }
         cost += f * (0.5 * af + S[L.rowB + r]);
     }
@@ -1399,12 +1406,12 @@ __device__ __forceinline__ int k_pgs(const KernelArgs& A, const double* mb, doub
             int dof = 0;
             double y = 0, part = 0, y1 = 0;
             if (two) {  // dense row: lane = dof (two per lane)
-                const double* D = S + L.dense + (rm.type >> 8) * A.nvp;
+                const double* D = Db + (rm.type >> 8) * A.nvp;
                 if (LANE < T.nv) { y = D[LANE]; part = y * z[LANE]; }
                 if (LANE + UHC_WAVE < T.nv) { y1 = D[LANE + UHC_WAVE]; part += y1 * z[LANE + UHC_WAVE]; }
             } else if (LANE < len) {
                 dof = anc_tab[rm.last * YS + LANE];
-                y = S[L.Y + RY[r] + LANE];
+                y = Yb[RY[r] + LANE];
                 part = y * z[dof];
             }
             const double old = S[L.rowF + r], Rr = S[L.rowR + r], Arr = S[L.rowDa + r];
@@ -1558,7 +1565,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
                 if (rr[j] >= nefc) rr[j] = -1;  // dropped by the truncation above
             }
             DenseOut o[UHC_DENSE_GROUP];
-            k_dense_rows<1>(A, S, rr, k0, LC, o);
+            k_dense_rows<1>(A, S, rr, k0, LC, o, S + L.dense);
 #pragma unroll
             for (int j = 0; j < UHC_DENSE_GROUP; j++) if (LANE == rr[j]) { vel = o[j].vel; jas = o[j].jas; jaw = o[j].jaw; }
         }
@@ -2166,6 +2173,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
                 for (int h = 0; h < NRL; h++) { q[h] = __builtin_amdgcn_ballot_w64(c[h] && !p[h]); nq += __builtin_popcountll(q[h]); }
                 const int room = UHC_WAVE - (nC - nq);
                 if (room <= 0 && lost) return -2;  // (a pass that dropped rows is not worth the windows: k_forward)
+                if (room <= 0 && A.last_tier == 4) return -5;  // (an island with more force-carrying rows than lanes: Newton on the primal takes it, tier 4)
                 if (room <= 0 || block) {
                     // 64 rows carry a force and more want in: the next window of 64 candidates, cyclically from the cursor
                     if (!block) {
@@ -2354,10 +2362,18 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
     return iters | (windowed ? UHC_WS_WINDOWED : 0);
 }
 
+// ------------------------------------------------------------------ tier 4's solver: Newton on the primal problem (uhc_primal.h; the translation units
+// of the large tier, whose workgroups go on as tier 4, define UHC_WITH_TIER4 -- the others never instantiate it)
+template <int TIER>
+__device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db PROF_ARGS);
+#ifdef UHC_WITH_TIER4
+#include "uhc_primal.h"
+#endif
+
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow; };  // overflow bit 0: the env does not fit this tier => redone by the next one
 template <int TIER, bool DENSE>
-__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP PROF_ARGS) {
+__device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP, const int env PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     FwdOut out = {0, 0, 0, 0};
@@ -2392,29 +2408,56 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
             out.iters = k_pgs_fast<1, DENSE>(A, mb, S, out.nefc, row, Yreg, LC, NI + 4, DENSE ? NI[2] : 0 PROF_PASS);
             PROF(12)
         } else {
-            if (k_rows<TIER>(A, mb, S, out.nefc, LC)) { out.overflow |= 1 | UHC_WHY_ROW_STORAGE; return out; }  // the packed rows need the next tier's storage
+            double* Yb = y_store<TIER>(A, S, env);
+            double* Db = d_store<TIER>(A, S, env);
+            if (k_rows<TIER>(A, mb, S, out.nefc, LC, Yb, Db)) { out.overflow |= 1 | UHC_WHY_ROW_STORAGE; return out; }  // the packed rows need the next tier's storage
             PROF(9)
             int it = -1;
+            if constexpr (TIER == 4) {
+                // the last tier: Newton on the primal (exact, whatever the number of rows or of force-carrying rows: uhc_primal.h); friction-loss
+                // rows (box constraints) and solver 0 go to the sweeps as in the other tiers
+                bool fric = false;
+                for (int r = LANE; r < out.nefc; r += UHC_WAVE) fric = fric || RTYPE(((const RowMisc*)(S + L.rowMisc))[r].type) == ROW_FRICTION;
+                fric = wave_or(fric);
+                if (T.solver == 1 && !fric) {
+                    it = k_primal<TIER>(A, mb, S, out.nefc, LC, Yb, Db PROF_PASS);
+                    out.overflow |= 128;                            // UHC_F_REDO bit 30: solved by Newton on the primal
+                    if (it < 0) { out.overflow |= 256; it = -it; }  // bit 29: it stopped at its iteration cap (the best iterate is used)
+                } else {
+                    if (T.solver == 1) out.overflow |= 4 | 8;
+                    it = k_pgs<TIER>(A, mb, S, out.nefc, T.iterations, Yb, Db);
+                }
+                out.iters = it;
+                PROF(11)
+            } else {
             // An env that has just lost rows or contacts beyond the last tier's capacity (overflow bit 1; UHC_F_REDO bit 7) is no longer
             // solving the reference's QP.  Most such passes are ordinary pile-ups and their truncated QP is solved exactly like any other.
             // One in twelve is a simulation on its way to the bad-value flag (tools/diag_redo.py on the configs[4] probe, replayed on
             // the checker: joint speeds of 160 - 20 000 rad/s at the head of the step, |b| of 1e7 - 5e16 in the substep, one island of 250
             // rows that the working sets cannot finish), and used to end in `iterations` sweeps: 34 ms per substep in the large tier, a
             // third of that probe's time.  A pass that has dropped rows therefore gets a bounded attempt -- UHC_WS_LOST_MAXIT working-set
-            // rounds, no windows -- and, when that gives up, UHC_LOST_SWEEPS sweeps from the warm start.
+            // rounds, no windows -- and, when that gives up, UHC_LOST_SWEEPS sweeps from the warm start.  (Batches whose last tier is the
+            // large one, UHC_TIERS=3: with tier 4 behind it the large tier hands such an env on instead.)
             const bool lost = T.solver == 1 && (out.overflow & 2) != 0;
             if (T.solver == 1) it = k_as_general<TIER, DENSE>(A, mb, S, out.nefc, LC, lost PROF_PASS);
             if (it >= 0 && (it & UHC_WS_WINDOWED)) { it &= UHC_WS_WINDOWED - 1; out.overflow |= 16; }  // (UHC_F_REDO bit 3: an island was solved in windows)
+            if (it < -1 && T.solver == 1 && A.last_tier == 4) {
+                // the working sets did not finish (an island with more force-carrying rows than lanes, no convergence, a pivot breakdown): the env
+                // goes on to tier 4, whose Newton iteration on the primal has no such limit -- instead of the sweeps of rounds 2-4
+                out.overflow |= 1 | UHC_WHY_SOLVER;
+                return out;
+            }
             if (it < 0) {
                 if (T.solver == 1) {  // the working sets gave up: sweep from the warm start, as the reference's PGS does
                     for (int r = LANE; r < out.nefc; r += UHC_WAVE) S[L.rowF + r] = S[L.rowW + r];
                     wsync();
                 }
                 out.overflow |= 4 | ((T.solver == 1 && it != -2) ? (4 << (-it)) : 0);  // (-2: a pass that dropped rows met an island that needs windows)
-                it = k_pgs<TIER>(A, mb, S, out.nefc, lost ? min(T.iterations, UHC_LOST_SWEEPS) : T.iterations);
+                it = k_pgs<TIER>(A, mb, S, out.nefc, lost ? min(T.iterations, UHC_LOST_SWEEPS) : T.iterations, Yb, Db);
             }  // 4: solved by sweeps (to tolerance), reported in UHC_F_REDO bit 1; 8 / 32 / 64: why the working sets gave up (bits 2, 4, 5); 16: not a fallback (above)
             out.iters = it;
             PROF(11)
+            }
         }
         // qacc = qacc_smooth + L^-1 D^-1/2 z
         if (LANE < T.nv) x.a = S[L.z + LANE] * S[L.sdinv + LANE];
@@ -2620,8 +2663,9 @@ __device__ __forceinline__ void k_rfc_explicit(const KernelArgs& A, double* S, c
 // launches the general variant on exactly those envs.
 // DENSE: the model has contacts between two moving bodies (convex-convex pairs): MPR narrow phase + dense rows are compiled in.  The
 // floor-only stock model runs the DENSE = false instantiation, whose code and register allocation are those of the kernel without them.
+// returns 1 when the env was handed on to the next tier (nothing committed; the large tier's workgroup then goes on with it as tier 4), else 0
 template <int MODE, int TIER, bool DENSE>
-__device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* __restrict__ d_action, const double* __restrict__ d_tbase, const int env) {
+__device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* __restrict__ d_action, const double* __restrict__ d_tbase, const int env) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     double* S = smem;
@@ -2633,7 +2677,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
     // tier trace (UHC_DEBUG bit 4, product builds; tools/tier_trace.py): when each tier took the env up and let it go (100 MHz wall clock)
     // and the substep of a hand-on, in the first words of the env's stage-profile record
 #ifndef UHC_STAGE_PROF
-#define TRACE(slot, v) if (MODE == 0 && (A.dbg & 16) && LANE == 0) A.s.prof[(size_t)env * UHC_NPROF + (slot)] = (long long)(v);
+#define TRACE(slot, v) if (MODE == 0 && TIER < 4 && (A.dbg & 16) && LANE == 0) A.s.prof[(size_t)env * UHC_NPROF + (slot)] = (long long)(v);
 #else
 #define TRACE(slot, v)
 #endif
@@ -2701,7 +2745,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             A.s.xipos[(size_t)env * 3 * T.nbody + i] = S[L.xipos + i];
         }
         for (int i = LANE; i < 4 * T.nbody; i += UHC_WAVE) A.s.xquat[(size_t)env * 4 * T.nbody + i] = S[L.xquat + i];
-        return;
+        return 0;
     }
     if (MODE == 1) {
         // set_state + sim.forward(): a pose that is not a pose (NaN, beyond +-1e10: what mj_checkPos / mj_checkVel reject at the head of
@@ -2712,7 +2756,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
         if (wave_or(b)) fail = 1;
         else {
-            fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+            fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP, env PROF_PASS);
             overflow |= fo.overflow;
             ran = true;
         }
@@ -2740,11 +2784,11 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             for (int i = LANE; i < T.nv; i += UHC_WAVE) b |= bad(S[L.qvel + i]);
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
-            fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP PROF_PASS);
+            fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP, env PROF_PASS);
             PROF(13)
             overflow |= fo.overflow;
             if (overflow & 1) break;
-            if (TIER != 1 && (fo.overflow & 4) && it >= 0 && it < 23) swept |= 1 << (8 + it);
+            if (TIER != 1 && (fo.overflow & 4) && it >= 0 && it < 21) swept |= 1 << (8 + it);  // (bits 8 .. 28; 29 and 30 report the primal solver)
             if (TIER != 1) fits = fits && fo.nefc <= UHC_WAVE && fo.ncon <= A.cf.maxcon &&
                               (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= A.cf.ndense);
             {
@@ -2783,8 +2827,10 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         if (LANE == 0) {
             // flagged for the chained launch of the next tier, which takes whatever no consumer took (none running, or given up) -- BEFORE the
             // env is published: a consumer that claims and finishes it clears the flag, and that clear must be the last write
-            if (TIER == 1) A.s.pend2[env] = 1; else { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
-            A.s.why[env] = (A.s.why[env] & (TIER == 1 ? 0xff00 : 0x00ff)) | (((overflow >> 16) & 0xff) << (TIER == 1 ? 0 : 8)) | ((it & 0xff) << 16);  // diagnostic: why, and at which substep
+            // (the large tier hands on to tier 4 inside its own workgroup: no flag, no queue -- pend3 stays up until tier 4 has finished the env)
+            if (TIER == 1) A.s.pend2[env] = 1; else if (TIER == 2) { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
+            if (TIER <= 2) A.s.why[env] = (A.s.why[env] & (TIER == 1 ? 0xff00 : 0x00ff)) | (((overflow >> 16) & 0xff) << (TIER == 1 ? 0 : 8)) | ((it & 0xff) << 16);  // diagnostic: why, and at which substep
+            else A.s.why[env] |= ((overflow >> 16) & 0xff) << 24;  // bits 24+: why the large tier handed the env on to tier 4
             __threadfence();
             if (A.q_next) {  // the next tier's consumers are running beside this launch: straight into their queue
                 const int k = atomicAdd(A.q_next_count, 1);
@@ -2793,7 +2839,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             if (TIER == 1 && MODE == 0) atomicAdd(A.s.path_stats, 1ull);
         }
         TRACE(2 * (TIER - 1) + 1, wall_clock64())
-        return;
+        return 1;
     }
     // ---- store state
     for (int i = LANE; i < T.nq; i += UHC_WAVE) A.s.qpos[(size_t)env * T.nq + i] = S[L.qpos + i];
@@ -2837,7 +2883,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
         if (overflow & 3) A.s.overflow[env] = 1;
         A.s.fresh[env] = 0;
         if (TIER == 2) A.s.pend2[env] = 0;  // taken: the chained launch of this tier has nothing left to do for the env
-        if (TIER == 3) A.s.pend3[env] = 0;
+        if (TIER >= 3) A.s.pend3[env] = 0;
         // where the env's next step starts (uhc_batch_set_kernel_path 2): an env comes down a tier only with room to spare
         // An env that comes CLOSE to a tier's capacity starts its next step one tier up: finding out in the middle of a step that it no
         // longer fits costs that tier's work so far, and the step then ends a whole general- (or large-) tier env-step after the moment
@@ -2851,7 +2897,7 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             const bool dn1 = pk_nefc <= mk[3] && pk_ncon <= mk[4] && pk_ntwo <= mk[5] && (TIER == 1 || pk_y + 8 <= (7 * A.cf.ycap) / 8);
             const bool up3 = pk_nefc > (mk[6] * A.cg.maxefc) / 8 || pk_ncon > (mk[6] * A.cg.maxcon) / 8 || pk_ntwo > (mk[6] * A.cg.ndense) / 8 || pk_y > (mk[6] * A.cg.ycap) / 8;
             const bool dn2 = pk_nefc <= (mk[7] * A.cg.maxefc) / 8 && pk_ncon <= (mk[7] * A.cg.maxcon) / 8 && pk_ntwo <= (mk[7] * A.cg.ndense) / 8 && pk_y <= (mk[7] * A.cg.ycap) / 8;
-            const int big = A.last_tier == 3 ? 3 : 2;
+            const int big = A.last_tier >= 3 ? 3 : 2;
             int next;
             if (TIER == 1) next = up2 ? 2 : 1;
             else if (TIER == 2) next = (up3 && big == 3) ? 3 : (dn1 ? 1 : 2);
@@ -2859,13 +2905,15 @@ __device__ __forceinline__ void uhc_step_env(const KernelArgs& A, const double* 
             A.s.tier[env] = next;
             A.s.cost[env] = max(pk_nefc, max((pk_ncon * UHC_FAST_MAXEFC) / max(A.cf.maxcon, 1), (pk_ntwo * UHC_FAST_MAXEFC) / max(A.cf.ndense, 1)));
         }
-        if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER == 3 ? 0x40 : 0) | ((overflow & 2) ? 0x80 : 0) | swept;
+        if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER >= 3 ? 0x40 : 0) | ((overflow & 2) ? 0x80 : 0) | swept |
+                                       ((overflow & 128) ? (1 << 30) : 0) | ((overflow & 256) ? (1 << 29) : 0);
         else if (overflow & 2) A.s.redo[env] = 0x80;  // (fast tier in truncate mode; bit 7 = rows / contacts were dropped in this step)
         if (TIER != 1 && MODE == 0) {
             atomicAdd(A.s.path_stats + 2, 1ull);
             if (fits) atomicAdd(A.s.path_stats + 1, 1ull);
         }  // UHC_F_REDO: bit 0 = computed by the general kernel, bit 1 = its contact solve ran the sweeps
     }
+    return 0;
 }
 
 // The launch forms.  (1) one workgroup per env of the batch (blockIdx = env), filtered by the active mask and -- under sticky tiers -- by
@@ -2916,7 +2964,20 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         const int t = A.s.tier_now[env];
         go = t == A.tier_want || !((A.sticky_mask >> t) & 1);
     }
-    if (go) uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+    if (go) {
+        const int handed = uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+#ifdef UHC_WITH_TIER4
+        if constexpr (TIER == 3 && MODE != 2) {
+            if (handed && A.last_tier == 4) {  // the same workgroup, the same LDS allocation carved for tier 4: the env's state is where the hand-on left it
+                wsync();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                uhc_step_env<MODE, 4, true>(A, d_action, d_tbase, env);
+            }
+        }
+#else
+        (void)handed;
+#endif
+    }
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer bookkeeping of the queues
 }
 // (2): its own entry point, so that the one-workgroup-per-env kernels keep the register allocation of a straight-line body
@@ -2934,8 +2995,19 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, 
         env = __builtin_amdgcn_readfirstlane(env);
         if (env < 0) break;
         if (tr && LANE == 0) { if (tr[1] == 0) tr[1] = (long long)wall_clock64(); tr[3]++; }
-        uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+        const int handed = uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
         wsync();
+#ifdef UHC_WITH_TIER4
+        if constexpr (TIER == 3) {
+            if (handed && A.last_tier == 4) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                uhc_step_env<MODE, 4, true>(A, d_action, d_tbase, env);
+                wsync();
+            }
+        }
+#else
+        (void)handed;
+#endif
     }
     if (tr && LANE == 0) tr[2] = (long long)wall_clock64();
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // consumer bookkeeping (the next tier's consumers wait for it)

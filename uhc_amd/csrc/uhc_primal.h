@@ -12,8 +12,8 @@
 //     min_u  1/2 |u|^2 + sum_r 1/2 D_r min(0, Yhat_r . u + b_r)^2,      Yhat_r = D^-1/2 L^-T J_r^T (k_rows),  b_r = J_r a_s - aref_r
 //     gradient  g = u + sum_active D_r jar_r Yhat_r,     Hessian  H = I + sum_active D_r Yhat_r Yhat_r^T   (>= I: the Cholesky cannot break down)
 // and at the optimum u = sum_r f_r Yhat_r = z, f_r = -D_r min(0, jar_r): exactly what k_forward turns into qacc afterwards.
-// Newton's method with an exact line search is invariant under the change of variables, so oracle/physics_oracle.c (orc_solve_primal, dense
-// algebra in a-space) runs the same iteration:
+// Newton's method with an exact line search is invariant under the change of variables, so the test suite's checker (dense algebra in a-space)
+// runs the same iteration:
 //   start   u0 = sum f_ws Yhat (the forces the warm-start acceleration implies, k_rows) if its cost is below cost(0), else 0
 //   step    active = {jar < 0};  H (packed lower, column-major, LDS) = I + sum_active D Yhat Yhat^T;  left-looking Cholesky by one wave;
 //           dir = -H^-1 g;  p = Yhat dir;  exact line search on the piecewise-quadratic cost (safeguarded Newton on its derivative);
@@ -139,6 +139,9 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
     bool ok = false;
     double g0 = -1.0;
     for (; it < UHC_PRIMAL_MAXIT; it++) {
+        // ---- jar from u itself in every iteration (not jar += alpha p): a row that sits at jar = 0 -- touching, no force -- would otherwise carry the
+        //      rounding noise of the updates, change sides from one iteration to the next and keep the "same active set" test from ever holding
+        if (it > 0) primal_row_dots<TIER>(A, S, nefc, LC, Yb, Db, u, jar, S + L.rowB);
         // ---- active set, gradient
         unsigned act = 0u;  // bit h: row LANE + 64 h is active
         for (int r = LANE; r < nefc; r += UHC_WAVE) {
@@ -247,7 +250,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
             double* Hw = H + hcol(j, n) - j;
             if (LC.v0 && LANE >= j) Hw[LANE] = LANE == j ? rc : va * rc;
             if (LC.v1 && LANE + UHC_WAVE >= j) Hw[LANE + UHC_WAVE] = LANE + UHC_WAVE == j ? rc : vb * rc;
-            // (LDS operations of one wave retire in order: the next column reads what this one wrote)
+            wsync();  // (the next column reads what other lanes wrote here)
         }
         wsync();
         PROF(26)
@@ -274,6 +277,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
         primal_row_dots<TIER>(A, S, nefc, LC, Yb, Db, vec, pp, nullptr);
         const double ua = LC.v0 ? u[LANE] : 0.0, ub = LC.v1 ? u[LANE + UHC_WAVE] : 0.0;
         const double lin0 = wave_sum(ua * x.a + ub * x.b), quad = wave_sum(x.a * x.a + x.b * x.b);
+        if (quad <= 1e-26 * (1.0 + wave_sum(ua * ua + ub * ub))) { ok = true; it++; break; }  // a step below the rounding of u: converged
         double alpha = 1.0, lo = 0.0, hi = -1.0;
         for (int ls = 0; ls < UHC_PRIMAL_LS_MAXIT; ls++) {
             double d1 = 0.0, d2 = 0.0;
@@ -295,7 +299,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
         bool flip = false;
         for (int r = LANE; r < nefc; r += UHC_WAVE) {
             const double xr = fma(alpha, pp[r], jar[r]);
-            jar[r] = xr;
+            jar[r] = xr;  // (what the final forces are read from when this was the last step; recomputed from u otherwise)
             flip = flip || ((xr < 0) != (((act >> (r >> 6)) & 1u) != 0u));
         }
         wsync();

@@ -63,8 +63,8 @@ __global__ void __launch_bounds__(1024) uhc_rollout_record_kernel(int n_env, int
     const long long t = t_dev[0];
     if (t < 0 || t >= T) return;  // (uniform: every thread reads the same counter)
     const double er = end_reward[0];
-    double acc[14];  // reward, up to 8 reward terms, five env counts (exact in float64)
-    const int nacc = n_parts + 6;
+    double acc[16];  // reward, up to 8 reward terms, seven env counts (exact in float64)
+    const int nacc = n_parts + 8;
     for (int k = 0; k < nacc; k++) acc[k] = 0.0;
     for (int e = tid; e < n_env; e += blockDim.x) {
         const double r = reward[e];
@@ -78,6 +78,8 @@ __global__ void __launch_bounds__(1024) uhc_rollout_record_kernel(int n_env, int
             acc[n_parts + 3] += (redo[e] & 0x80) != 0;  // rows / contacts beyond the last tier's capacity were dropped in THIS step
             acc[n_parts + 4] += (redo[e] & 0x40) != 0;  // computed by the large tier
             acc[n_parts + 5] += (redo[e] & 8) != 0;     // an island with more than 64 force-carrying rows: solved exactly in windows of 64
+            acc[n_parts + 6] += (redo[e] & (1 << 30)) != 0;  // (part of) the step solved by Newton on the primal: tier 4
+            acc[n_parts + 7] += (redo[e] & (1 << 29)) != 0;  // ... and that iteration stopped at its cap
         }
     }
     for (int k = 0; k < nacc; k++) {

@@ -96,7 +96,7 @@ class Agent:
             R.c_info_sum = torch.zeros(getattr(env, "n_reward_parts", 5), dtype=self.dtype, device=dev)
             R.c_reward_sum = torch.zeros((), dtype=self.dtype, device=dev)
             R.t_dev = torch.zeros(1, dtype=torch.long, device=dev)
-            R.redo_counts = torch.zeros(5, dtype=torch.long, device=dev)  # env-steps of this pass: through the general / large tier, its sweeps fallback, rows dropped beyond the last tier's capacity, large tier, exact solve in windows of 64 rows
+            R.redo_counts = torch.zeros(7, dtype=torch.long, device=dev)  # env-steps of this pass: through the general / large tier, its sweeps fallback, rows dropped beyond the last tier's capacity, large tier (or tier 4), exact solve in windows of 64 rows, solved by Newton on the primal (tier 4), Newton stopped at its iteration cap
             R.end_reward_dev = torch.zeros((), dtype=self.dtype, device=dev)
             R.state = torch.zeros(n_env, env.obs_dim, dtype=self.dtype, device=dev)
             R.action = torch.zeros(n_env, env.action_dim, dtype=torch.float64, device=dev)
@@ -201,6 +201,8 @@ class Agent:
         R.redo_counts[2] += ((redo & 0x80) != 0).sum()
         R.redo_counts[3] += ((redo & 0x40) != 0).sum()
         R.redo_counts[4] += ((redo & 8) != 0).sum()
+        R.redo_counts[5] += ((redo & (1 << 30)) != 0).sum()
+        R.redo_counts[6] += ((redo & (1 << 29)) != 0).sum()
         r = env.reward.to(self.dtype)
         R.c_reward_sum.add_(r.sum())  # the plain imitation reward: what LoggerRL reports (logger_rl.py:29-33), before end bonus / bootstrap
         if self.running_state is not None:

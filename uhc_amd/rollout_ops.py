@@ -32,10 +32,10 @@ def act(t_dev, state, mean, log_std, noise, mean_flags, states, actions, action)
 
 def record(t_dev, reward, done, end, end_reward, parts, n_parts, rewards, dones, c_reward_sum, c_info_sum, redo=None, redo_counts=None):
     """rewards[:, t] = reward + end * end_reward; dones[:, t] = done; the pass's reward sums.  parts: [n_env][stride] (first n_parts count).
-    redo / redo_counts: UHC_F_REDO of the step and the int64 [5] counters it is added to (general-tier env-steps, sweeps fallbacks, env-steps that lost rows beyond the last tier's capacity, large-tier env-steps, env-steps with a windowed exact solve)."""
+    redo / redo_counts: UHC_F_REDO of the step and the int64 [7] counters it is added to (general-tier env-steps, sweeps fallbacks, env-steps that lost rows beyond the last tier's capacity, large-tier / tier-4 env-steps, env-steps with a windowed exact solve, env-steps solved by Newton on the primal in tier 4, env-steps in which that iteration stopped at its cap)."""
     n_env, T = rewards.shape
     assert done.dtype == torch.int32 and end.dtype == torch.int32 and parts.dim() == 2 and parts.stride(1) == 1
-    assert redo is None or (redo.dtype == torch.int32 and redo_counts is not None and redo_counts.dtype == torch.int64 and redo_counts.numel() == 5)
+    assert redo is None or (redo.dtype == torch.int32 and redo_counts is not None and redo_counts.dtype == torch.int64 and redo_counts.numel() == 7)
     check(lib().uhc_rollout_record(_stream(reward), n_env, T, _p(t_dev), _p(reward), _p(done), _p(end), _p(end_reward), _p(parts), parts.stride(0), n_parts,
                                    _p(rewards), _p(dones), _p(c_reward_sum), _p(c_info_sum), _p(redo), _p(redo_counts)))
 
