@@ -506,3 +506,60 @@ def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing
         assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
         assert worst_q < 1e-9 and worst_v < 1e-7, (worst_q, worst_v)
         b.close()
+
+
+def test_sticky_queues_hand_an_env_on_to_tier_4(model, standing):
+    """Kernel path 2 with consumers running: a batch whose envs live in different tiers -- some standing (general tier: the queue's own envs, so that the
+    consumers are launched), one in the air (fast tier), two face down beside the raft (beyond the large tier: handed from queue to queue and on to tier
+    4 INSIDE a large-tier consumer).  Several steps, every env re-posed each step so that the scene stays what it is; against the oracle, step by step."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    if os.environ.get("UHC_FORCE_GENERAL") == "1":
+        pytest.skip("the batch has no fast tier to start from")
+    K = 7
+    m = self_collision_variant(model)
+    yaw = [0.06 * (-1) ** k for k in range(K)]
+    poses = np.array([[1.0 + 0.305 * k, 1.0 + 0.01 * k, 0.1495, np.cos(y / 2), 0, 0, np.sin(y / 2)] for k, y in enumerate(yaw)], dtype=np.float64)
+    m = dataclasses.replace(add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027), solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n = 12
+    rng = np.random.default_rng(5)
+    q = np.tile(m.qpos0, (n, 1))
+    for e in range(n):
+        qh = standing["qpos"].copy()
+        qh[7:] += rng.normal(scale=0.01, size=69)
+        if e in (3, 9):  # face down beside the raft: 300+ rows
+            a = np.pi / 2 + 0.05 * e
+            qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])
+            qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+        elif e == 5:
+            qh[2] += 30.0  # airborne: fast tier
+        q[e, :76] = qh
+    v = np.zeros((n, m.nv))
+    b = S.SimBatch(m, ctrl, n)
+    b.set_kernel_path(2)
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    act = np.zeros((n, ctrl.action_dim))
+    os_ = [OracleSim(m, ctrl) for _ in range(n)]
+    primal, worst = 0, 0.0
+    for t in range(6):
+        b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        tiers = b.field(S.F_TIER).cpu().numpy()
+        for e in range(n):
+            os_[e].set_state(q[e], v[e])
+            os_[e].do_simulation(act[e], np.zeros(69))
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+            primal += int((redo[e] & (1 << 30)) != 0)
+        assert not (redo & 0x80).any() and not (redo & 2).any(), [hex(int(x)) for x in redo]
+    print(f"sticky queues + tier 4: env-steps through tier 4 {primal} / {6 * n}; next-step tiers {tiers.tolist()}; worst |dqpos| {worst:.2e}")
+    assert primal >= 6 and worst < 1e-9, (primal, worst)
+    assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0

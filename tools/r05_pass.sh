@@ -31,6 +31,12 @@ parity_ball)
 tier4)
   (timeout 900 python -m pytest tests/test_gpu_selfcollision.py -m gpu -q --tb=short -rs -s -k "tier_4 or solved_exactly or drops_rows or lying" 2>&1 | grep -v amdgpu | tail -60) > ${O}_tier4_pytest.txt 2>&1
   tail -25 ${O}_tier4_pytest.txt ;;
+bench_tier4)
+  python tools/bench_tier4.py 128 6 2>&1 | grep -v amdgpu > ${O}_bench_tier4.txt
+  cat ${O}_bench_tier4.txt ;;
+bench_tier4_prof)
+  UHC_LIB=uhc_amd/csrc/libuhc_amd_prof.so python tools/bench_tier4.py 128 6 2>&1 | grep -v amdgpu > ${O}_bench_tier4_prof.txt
+  cat ${O}_bench_tier4_prof.txt ;;
 probe_configs4)
   python bench.py --only-probe configs4 > ${O}_probe_configs4.json 2> ${O}_probe_configs4.err
   python bench.py --only-probe ball_rollout > ${O}_probe_ball_rollout.json 2>> ${O}_probe_configs4.err

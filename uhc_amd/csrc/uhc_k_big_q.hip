@@ -1,6 +1,5 @@
 // uhc_k_big_q.hip -- one translation unit of the fused step kernel: the large tier as a persistent consumer of an env queue (sticky tiers).
-// the large tier's workgroups go on as tier 4 (Newton on the primal, uhc_primal.h) when an env does not fit or its working sets give up
-#define UHC_WITH_TIER4
+// (no tier 4 in the persistent consumer: an env beyond the large tier stays flagged for the chained launch of uhc_k_big.hip)
 #include "uhc_physics_impl.h"
 
 extern "C" hipError_t uhc_launch_m0_big_q(const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active, size_t lds_bytes, hipStream_t stream) {

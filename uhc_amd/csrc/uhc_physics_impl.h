@@ -1233,7 +1233,11 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
         const bool two = (rm.type & ROW_TWO) != 0;
         const int last = rm.last, len = two ? 0 : T.dof_depth[last] + 1;
         const short* anc = T.dof_anc + (two ? 0 : last) * (T.maxdepth + 1);
-        double* Y = Yb + RY[r];
+        // (tier 4 keeps its rows in HBM: the row is built -- Jacobian, three dot products, the back substitution's read-modify-write double loop --
+        //  in the lane's own 33-double strip of LDS, where the Hessian will be, and written out once; through L2 the double loop cost 390 k cycles
+        //  per forward pass)
+        double* Yg = Yb + RY[r];
+        double* Y = (TIER == 4 && T.nv * (T.nv + 1) / 2 >= UHC_WAVE * 33) ? S + L.H + LANE * 33 : Yg;
         double pos = 0, margin = 0, diagApprox = 0, K, B, imp, floss = 0;
         if (rt == ROW_FRICTION || rt == ROW_LIMIT) {
             const double dsolimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
@@ -1318,7 +1322,7 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
         double da = R + yy;
         for (int q = 0; q < len; q++) {
             const double y = Y[q] * S[L.sdinv + anc[q]];
-            Y[q] = y;
+            Yg[q] = y;
             da += y * y;
         }
         S[L.rowR + r] = R;
@@ -2827,8 +2831,9 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
         if (LANE == 0) {
             // flagged for the chained launch of the next tier, which takes whatever no consumer took (none running, or given up) -- BEFORE the
             // env is published: a consumer that claims and finishes it clears the flag, and that clear must be the last write
-            // (the large tier hands on to tier 4 inside its own workgroup: no flag, no queue -- pend3 stays up until tier 4 has finished the env)
-            if (TIER == 1) A.s.pend2[env] = 1; else if (TIER == 2) { A.s.pend2[env] = 0; A.s.pend3[env] = 1; }
+            // (the large tier hands on to tier 4: pend3 = 2 -- in a one-workgroup-per-env launch the same workgroup goes on with it at once; a queue
+            //  consumer leaves the env flagged for the step's chained large-tier launch, which takes a `2` straight to tier 4)
+            if (TIER == 1) A.s.pend2[env] = 1; else if (TIER == 2) { A.s.pend2[env] = 0; A.s.pend3[env] = 1; } else A.s.pend3[env] = 2;
             if (TIER <= 2) A.s.why[env] = (A.s.why[env] & (TIER == 1 ? 0xff00 : 0x00ff)) | (((overflow >> 16) & 0xff) << (TIER == 1 ? 0 : 8)) | ((it & 0xff) << 16);  // diagnostic: why, and at which substep
             else A.s.why[env] |= ((overflow >> 16) & 0xff) << 24;  // bits 24+: why the large tier handed the env on to tier 4
             __threadfence();
@@ -2965,17 +2970,19 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
         go = t == A.tier_want || !((A.sticky_mask >> t) & 1);
     }
     if (go) {
-        const int handed = uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
 #ifdef UHC_WITH_TIER4
         if constexpr (TIER == 3 && MODE != 2) {
+            // an env a large-tier queue consumer has already found too big (pend3 = 2) skips the large tier's attempt
+            int handed = (A.last_tier == 4 && d_active == A.s.pend3 && A.s.pend3[env] == 2) ? 1 : 0;
+            if (!handed) handed = uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
             if (handed && A.last_tier == 4) {  // the same workgroup, the same LDS allocation carved for tier 4: the env's state is where the hand-on left it
                 wsync();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 uhc_step_env<MODE, 4, true>(A, d_action, d_tbase, env);
             }
-        }
+        } else uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
 #else
-        (void)handed;
+        uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
 #endif
     }
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer bookkeeping of the queues
@@ -2995,19 +3002,11 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, 
         env = __builtin_amdgcn_readfirstlane(env);
         if (env < 0) break;
         if (tr && LANE == 0) { if (tr[1] == 0) tr[1] = (long long)wall_clock64(); tr[3]++; }
-        const int handed = uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
+        // (a large-tier consumer that finds its env too big leaves it flagged, pend3 = 2: the step's chained large-tier launch takes it to tier 4.  Tier 4
+        //  inside the persistent consumer hung the rollout at its first use -- the 619-spill instantiation, never explained; and it would hold a whole
+        //  CU for a 20-40 ms env-step while the queue waits behind it)
+        uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
         wsync();
-#ifdef UHC_WITH_TIER4
-        if constexpr (TIER == 3) {
-            if (handed && A.last_tier == 4) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                uhc_step_env<MODE, 4, true>(A, d_action, d_tbase, env);
-                wsync();
-            }
-        }
-#else
-        (void)handed;
-#endif
     }
     if (tr && LANE == 0) tr[2] = (long long)wall_clock64();
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // consumer bookkeeping (the next tier's consumers wait for it)
