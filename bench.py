@@ -394,7 +394,7 @@ def rollout_probe(args, local, dtype, name, warmup=None, steps=None, reps=None, 
     out.update({"steps": steps, "warmup": warmup, "reps": reps, "env_steps_per_s_each_rep": [r["env_steps_per_s"] for r in runs],
                 "efc_overflow_env_steps_all_reps": int(sum(r["efc_overflow_env_steps"] for r in runs)),
                 "nefc_mean": float(nefc.mean()), "nefc_max_at_rep_ends": nefc_max, "ncon_max_at_rep_ends": ncon_max,
-                "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257])[0].tolist(),
+                "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257, 513, 1025], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257, 513, 1025])[0].tolist(),
                 "failed_envs_now": int(env.sim.field(S.F_FAIL).sum().item()),
                 "avg_episode_len": logger.avg_episode_len, "avg_reward": logger.avg_c_reward,
                 "model": {"nq": int(m.nq), "nv": int(m.nv), "nbody": int(m.nbody), "objects": int(getattr(env, "num_obj", 0))},
@@ -543,7 +543,7 @@ def bench_ball_objects(args):
                                 "tier's capacity (fast: 64 rows / 16 contacts / 12 body-body rows; general: 128 / 64 / 20) are redone by the next tier in a further launch, "
                                 "which ms_per_step includes"},
            "workload_stats": {"nefc_mean": float(nefc.mean()), "nefc_max": int(nefc.max()), "ncon_mean": float(ncon.mean()), "ncon_max": int(ncon.max()),
-                              "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257])[0].tolist(),
+                              "nefc_hist_edges": [0, 1, 17, 33, 49, 65, 97, 129, 193, 257, 513, 1025], "nefc_hist": np.histogram(nefc, bins=[0, 1, 17, 33, 49, 65, 97, 129, 193, 257, 513, 1025])[0].tolist(),
                               "general_kernel_share_of_env_steps": float(redo_tot.double().sum().item()) / (n_env * args.steps),
                               "sweeps_fallback_share_of_env_steps": float(sweep_tot.double().sum().item()) / (n_env * args.steps),
                               "sweeps_fallback_share_of_substeps": float(sub_tot.item()) / (n_env * args.steps * 15),
@@ -716,7 +716,7 @@ def main():
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "
                                    f"random-init policy, on {model_class}", "envs_per_gpu": n_env, "substeps": 15, "body_body_collisions": bool(dense),
-                       "contact_solver": ("exact optimum of the dual QP: active set in registers (fast kernel), working sets of <= 64 rows in the general kernel for envs beyond its capacity" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
+                       "contact_solver": ("exact optimum: active set on the dual QP in registers (fast tier), working sets of <= 64 rows (general / large tier), Newton on the primal problem for what those cannot hold or finish (tier 4: > 256 rows, islands with > 64 force-carrying rows)" if int(env.model.solver) == 1 else "pgs sweeps"), "pgs_sweep_cap": int(env.model.iterations), "body_shapes": 1 + args.shapes,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "fp64_valu", "kernel": "uhc_step_kernel<0, 2, true> (general tier)" if os.environ.get("UHC_FORCE_GENERAL") == "1" else kname[5:] + (" (fast tier, body-body contacts compiled in)" if dense else " (fast tier, floor-only model)"),
                          "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": tflops / 78.6,
@@ -736,8 +736,8 @@ def main():
                                "general_or_large_tier_env_steps_timed_region": int(redo_d[0]), "large_tier_env_steps_timed_region": int(redo_d[3]), "sweeps_fallback_env_steps_timed_region": int(redo_d[1]),
                                "efc_overflow_env_steps_timed_region": int(redo_d[2]), "windowed_exact_solve_env_steps_timed_region": int(redo_d[4]),
                                "tier4_primal_newton_env_steps_timed_region": int(redo_d[5]), "tier4_newton_hit_its_cap_env_steps_timed_region": int(redo_d[6]),
-                               "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257],
-                               "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257])[0].tolist(),
+                               "nefc_hist_edges": [0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257, 1025],
+                               "nefc_hist": np.histogram(nefc, bins=[0, 1, 9, 17, 25, 33, 41, 49, 57, 65, 97, 129, 257, 1025])[0].tolist(),
                                "ncon_hist_edges": [0, 1, 3, 5, 9, 13, 17, 33, 65], "ncon_hist": np.histogram(ncon, bins=[0, 1, 3, 5, 9, 13, 17, 33, 65])[0].tolist(),
                                "efc_overflow_envs_sticky_flags": overflow, "episodes": logger.num_episodes, "avg_episode_len": logger.avg_episode_len,
                                "avg_reward": logger.avg_c_reward},

@@ -29,7 +29,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UHC_ABI_VERSION 8
+#define UHC_ABI_VERSION 9  /* 9: UHC_F_REDO bits 29 / 30 (tier 4), swept-substep bits 8 .. 28; uhc_rollout_record counts int64 [7] */
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -124,17 +124,21 @@ enum UhcField {
     UHC_F_EFC_OVERFLOW = 14, /* int32 [n_env] sticky: constraint rows were dropped (nefc cap) */
     UHC_F_STAGE_PROF = 15,   /* int64 [n_env][40] per-stage shader-cycle counters (profiling builds only) */
     UHC_F_REDO = 16,         /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast tier's capacity (64 rows, 16 contacts, packed
-                              * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 20 body-body rows) or the
-                              * large one (256 / 128 / 32; bit 6), which solve the QP exactly too (working sets of <= 64 rows; an island with more
-                              * force-carrying rows than that in windows of 64 rows, to a KKT residual of 1e-9 (1 + max |b|): bit 3 reports that it
-                              * happened, it is not a fallback); bit 1: in at least one substep that solve fell back to solver 0 (sweeps to
-                              * tolerance); bits 2, 4, 5, diagnostic: why (friction-loss rows / no convergence of the working sets / a working set the
-                              * pivoting could not solve); bit 8 + k: substep k (< 23) of the step was one of those (a checker that follows the same
-                              * path needs to know which); bit 7: constraint rows / contacts beyond the last tier's capacity were DROPPED in this
-                              * step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state); a forward pass that dropped
-                              * rows is not the reference's QP any more: its truncated QP gets a bounded exact attempt (six working-set rounds, no
-                              * windows) and, when that gives up, 32 sweeps from the warm start instead of `iterations` (bits 1 and 7 together) */
-    UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
+                              * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 20 body-body rows), the
+                              * large one (256 / 128 / 32; bit 6) or tier 4 (up to 1024 rows / 192 contacts / 128 body-body rows; bits 6 and 30), all of
+                              * which solve the problem exactly: working sets of <= 64 rows on the dual QP in the general / large tier; Newton's method
+                              * on the primal problem -- the reference's MuJoCo default -- in tier 4, which takes whatever the large tier cannot hold
+                              * or whose working sets it cannot finish (an island with more than 64 force-carrying rows).  Bit 30: (part of) the step
+                              * was solved by tier 4; bit 29: one of its Newton iterations stopped at the cap of 100 (the best iterate is used).
+                              * Batches whose last tier is the large one (UHC_TIERS=3, or a model whose tier-4 layout does not fit 160 KiB of LDS)
+                              * keep rounds 3-4's behaviour: such an island in windows of 64 rows to a KKT residual of 1e-9 (1 + max |b|) (bit 3: it
+                              * happened, it is not a fallback); bit 1: in at least one substep the solve fell back to solver 0 (sweeps to tolerance;
+                              * with tier 4 only for friction-loss rows); bits 2, 4, 5, diagnostic: why (friction-loss rows / no convergence of the
+                              * working sets / a working set the pivoting could not solve); bit 8 + k: substep k (< 21) of the step was one of those
+                              * (a checker that follows the same path needs to know which); bit 7: constraint rows / contacts beyond the LAST tier's
+                              * capacity were DROPPED in this step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state);
+                              * without tier 4 a forward pass that dropped rows gets a bounded exact attempt and at most 32 sweeps (bits 1 and 7) */
+    UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) (an env that needed tier 4 starts in the large tier) */
     UHC_F_HANDON_WHY = 18    /* int32 [n_env] diagnostic of the last step: bits 0-7 why the fast tier handed the env on, bits 8-15 why the general tier did
                               * (1 contacts, 2 constraint rows, 4 body-body row slots, 8 packed row storage, 16 MPR candidate list beyond the tier's
                               * capacity), bits 16+ the substep of the last hand-on; 0 = the env stayed in the tier it started in */
@@ -165,11 +169,14 @@ int32_t uhc_batch_sync(UhcBatch* b);
 /* change rfc_scale between iterations (rfc_decay: uhc/agents/agent_copycat.py:283-290) */
 int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
 
-/* Which kernel tier computes a step.  The fused step kernel exists in three tiers: fast (<= 64 constraint rows / 16 contacts / 12
- * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 20; working sets; two workgroups per CU) and large
- * (<= 256 / 128 / 32; a whole CU's LDS).  A tier that cannot hold an env leaves it untouched and hands it to the next one; what exceeds
- * the large tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask MuJoCo for njmax 2500 / nconmax 500,
- * uhc/khrylib/mocap/skeleton_mesh.py:46).
+/* Which kernel tier computes a step.  The fused step kernel exists in four tiers: fast (<= 64 constraint rows / 16 contacts / 12
+ * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 20; working sets; two workgroups per CU), large
+ * (<= 256 / 128 / 32; a whole CU's LDS) and tier 4 (<= 1024 / 192 / 128, rows in HBM, the Hessian of MuJoCo's primal problem in LDS,
+ * Newton's method -- the reference's default solver, whose cost does not depend on the number of rows).  A tier that cannot hold an env
+ * leaves it untouched and hands it to the next one, from the substep that did not fit; tier 4 has no launch of its own (the large
+ * tier's workgroup goes on with it).  What exceeds the LAST tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask
+ * MuJoCo for njmax 2500 / nconmax 500, uhc/khrylib/mocap/skeleton_mesh.py:46).  UHC_TIERS=2 | 3 in the environment of uhc_batch_create
+ * ends the chain at the general / large tier (rounds 2-4's behaviour, kept for A/B measurements).
  *   0 (default) = chain: the fast tier on every env, then the general tier on the envs it handed on, then the large tier;
  *   1 = the general tier first (then the large one): for scenes where nearly every env exceeds the fast tier;
  *   2 = sticky tiers: every env starts a step in the tier that computed its previous step (it comes down a tier only with room to
@@ -177,8 +184,8 @@ int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
  *       longer per env, in a chain behind the fast tier the whole step would wait for them.  Results do not depend on the mode beyond
  *       rounding (every tier solves the same QP exactly), and a rerun of the same calls takes the same tiers.  Not capture-safe across
  *       uhc_batch_set_stream changes: the side stream forks from and joins the batch's stream with events.
- * UHC_F_REDO of a step: bit 0 = computed by the general or large tier, bit 1 = its exact solve swept in some substep (bits 2-5 why,
- * bits 8+ which substeps), bit 6 = computed by the large tier.  Timing (uhc_batch_set_timing) brackets the fast tier's launch (modes
+ * UHC_F_REDO of a step: bit 0 = computed by the general or large tier (or tier 4), bit 1 = its exact solve swept in some substep (bits
+ * 2-5 why, bits 8+ which substeps), bit 6 = computed by the large tier or tier 4, bit 30 = tier 4 (Newton on the primal).  Timing (uhc_batch_set_timing) brackets the fast tier's launch (modes
  * 0, 2) or the general tier's (mode 1). */
 int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode);
 
@@ -327,9 +334,10 @@ int32_t uhc_rollout_act(void* stream, int32_t n_env, int32_t T, const int64_t* d
                         double* d_actions, double* d_action);
 /* agent.py:80-92: rewards[:, t] = reward + end * end_reward, dones[:, t] = done, c_reward_sum += sum(reward),
  * c_info_sum[k] += sum(parts[:, k]) (LoggerRL.step, logger_rl.py:29-33); n_parts <= 8.  d_redo (may be NULL): UHC_F_REDO of the step;
- * d_redo_counts (int64 [5]): [0] += envs the general / large tier computed, [1] += envs whose exact contact solve fell back to sweeps,
- * [2] += envs that lost constraint rows beyond the last tier's capacity in this step, [3] += envs the large tier computed, [4] += envs with
- * an island of more than 64 force-carrying rows, solved exactly in windows of 64 rows (diagnostics) */
+ * d_redo_counts (int64 [7]): [0] += envs the general / large tier or tier 4 computed, [1] += envs whose exact contact solve fell back to
+ * sweeps, [2] += envs that lost constraint rows beyond the last tier's capacity in this step, [3] += envs the large tier or tier 4 computed,
+ * [4] += envs with an island of more than 64 force-carrying rows solved exactly in windows of 64 rows (three-tier batches), [5] += envs
+ * solved by Newton on the primal in tier 4, [6] += envs in which that iteration stopped at its cap (diagnostics) */
 int32_t uhc_rollout_record(void* stream, int32_t n_env, int32_t T, const int64_t* d_t, const double* d_reward, const int32_t* d_done,
                            const int32_t* d_end, const double* d_end_reward, const double* d_parts, int32_t parts_stride, int32_t n_parts,
                            double* d_rewards, double* d_dones, double* d_c_reward_sum, double* d_c_info_sum, const int32_t* d_redo,

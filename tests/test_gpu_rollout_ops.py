@@ -102,10 +102,11 @@ def test_act_and_record_equal_the_framework_expressions():
     dones = torch.zeros(n_env, T, dtype=torch.float64, device=dev)
     crs = torch.full((), 1.0, dtype=torch.float64, device=dev)
     cis = torch.ones(5, dtype=torch.float64, device=dev)
-    redo = torch.tensor([0, 1, 3, 0x70b, 0x80, 0xc1] * (n_env // 6) + [1] * (n_env % 6), dtype=torch.int32, device=dev)
-    rc = torch.tensor([10, 20, 30, 40, 50], dtype=torch.long, device=dev)
+    redo = torch.tensor([0, 1, 3, 0x70b, 0x80, 0xc1, 0x40000041, 0x60000041] * (n_env // 8) + [1] * (n_env % 8), dtype=torch.int32, device=dev)
+    rc = torch.tensor([10, 20, 30, 40, 50, 60, 70], dtype=torch.long, device=dev)
     ops.record(t, reward, done, end, er, parts, 5, rewards, dones, crs, cis, redo, rc)
-    assert rc.tolist() == [10 + int(((redo & 1) != 0).sum()), 20 + int(((redo & 2) != 0).sum()), 30 + int(((redo & 0x80) != 0).sum()), 40 + int(((redo & 0x40) != 0).sum()), 50 + int(((redo & 8) != 0).sum())]
+    assert rc.tolist() == [10 + int(((redo & 1) != 0).sum()), 20 + int(((redo & 2) != 0).sum()), 30 + int(((redo & 0x80) != 0).sum()), 40 + int(((redo & 0x40) != 0).sum()), 50 + int(((redo & 8) != 0).sum()),
+                           60 + int(((redo & (1 << 30)) != 0).sum()), 70 + int(((redo & (1 << 29)) != 0).sum())]  # (tier 4: solved by Newton on the primal; its iteration cap)
     assert torch.equal(rewards[:, 3], reward + end.double() * 2.5) and torch.equal(dones[:, 3], done.double())
     np.testing.assert_allclose(float(crs), 1.0 + float(reward.sum()), rtol=1e-14)
     np.testing.assert_allclose(cis.cpu().numpy(), 1.0 + parts[:, :5].sum(0).cpu().numpy(), rtol=1e-14)

@@ -24,6 +24,7 @@
 #define UHC_PRIMAL_MAXIT 100
 #define UHC_PRIMAL_LS_MAXIT 60
 #define UHC_PRIMAL_DGROUP 8  // dense rows per pass over the Hessian
+#define UHC_PRIMAL_MAXFLIP 10  // rows that may change sides between two iterations for the factor to be updated instead of rebuilt
 
 // packed lower triangle, column by column: column j holds rows j .. n-1
 __device__ __forceinline__ int hcol(int j, int n) { return j * n - (j * (j - 1)) / 2; }
@@ -216,6 +217,36 @@ __device__ __forceinline__ void primal_chol2(double* H, int n, int j) {
     }
 }
 
+// Rank-one update (sigma = +1) or downdate (-1) of the packed Cholesky factor, C C^T <- C C^T + sigma x x^T, column by column (the LINPACK rotation
+// scheme): lane = row, x in registers, one column read and written per step.  ~150 cycles per column against a fresh factorisation's 3 000: when a
+// Newton iteration moves a handful of rows across jar = 0, the factor follows them instead of being rebuilt.  Returns false when a downdate
+// loses positive definiteness to rounding (r^2 <= 0): the caller rebuilds.  The diagonal holds 1 / C_kk throughout.
+__device__ __forceinline__ bool primal_chol_rank1(double* H, int n, DofVec x, double sigma) {
+    const int ib = min(LANE + UHC_WAVE, n - 1);
+    bool good = true;
+    int base = 0;  // hcol(k) - k
+    for (int k = 0; k < n; k++) {
+        const double ca = H[base + LANE], cb = H[base + ib], rd = H[base + k];  // column k (rows above the diagonal: in-range garbage, never stored)
+        const double xk = dv_get_nb(x, k);
+        const double ckk = 1.0 / rd;
+        const double r2 = fma(sigma * xk, xk, ckk * ckk);
+        good = good && (r2 > 0.0);
+        const double r = sqrt(r2 > 0.0 ? r2 : 1.0);
+        const double ic = ckk / r, sg = sigma * xk * rd;  // 1 / c,  sigma s
+        const double sx = xk * rd, c = r * rd;            // s, c
+        const double na = (ca + sg * x.a) * ic, nb = (cb + sg * x.b) * ic;
+        if (LANE > k && LANE < n) H[base + LANE] = na;
+        if (LANE + UHC_WAVE > k && LANE + UHC_WAVE < n) H[base + LANE + UHC_WAVE] = nb;
+        if (LANE == (k & 63)) { if (k < UHC_WAVE) H[base + k] = 1.0 / r; }
+        if (k >= UHC_WAVE && LANE + UHC_WAVE == k) H[base + k] = 1.0 / r;
+        x.a = fma(c, x.a, -sx * na);
+        x.b = fma(c, x.b, -sx * nb);
+        base += n - k - 1;
+    }
+    wsync();
+    return good;
+}
+
 // returns the Newton iterations taken (>= 1), negated when the iteration cap was reached; z = u in S[L.z], the forces in S[L.rowF]
 template <int TIER>
 __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db PROF_ARGS) {
@@ -271,6 +302,8 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
     int it = 0;
     bool ok = false;
     double g0 = -1.0;
+    bool have_factor = false;  // H holds the Cholesky factor of the Hessian of act_prev
+    unsigned act_prev = 0u;
     for (; it < UHC_PRIMAL_MAXIT; it++) {
         // ---- jar from u itself in every iteration (not jar += alpha p): a row that sits at jar = 0 -- touching, no force -- would otherwise carry the
         //      rounding noise of the updates, change sides from one iteration to the next and keep the "same active set" test from ever holding
@@ -285,6 +318,46 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
             pp[r] = a ? Dr[r] : 0.0;       // weight of the row's outer product in the Hessian (pp holds p only after the factorisation)
         }
         for (int i = LANE; i < n; i += UHC_WAVE) vec[i] = u[i];
+        // ---- a few rows changed sides since the last factorisation: the factor follows them by rank-one updates (rows that joined) and downdates
+        //      (rows that left) instead of a rebuild -- typical of the second and later iterations of a warm-started solve
+        if (have_factor) {
+            const unsigned flips = act ^ act_prev;
+            int nflip = 0;
+            for (int h = 0; h * UHC_WAVE < nefc; h++) nflip += __builtin_popcountll(__builtin_amdgcn_ballot_w64((flips >> h) & 1u));
+            if (nflip > UHC_PRIMAL_MAXFLIP) have_factor = false;
+            for (int pass = 0; pass < 2 && have_factor; pass++) {  // joins first: the matrix only grows before it shrinks
+                for (int h = 0; h * UHC_WAVE < nefc && have_factor; h++) {
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(((flips >> h) & 1u) && ((((act >> h) & 1u) != 0u) == (pass == 0)));
+                    while (m && have_factor) {
+                        const int r = h * UHC_WAVE + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const RowMisc rm = RM[r];
+                        const double sq = sqrt(Dr[r]);
+                        DofVec xv = {0.0, 0.0};
+                        if (rm.type & ROW_TWO) {
+                            const double* Dk = Db + (size_t)(rm.type >> 8) * A.nvp;
+                            if (LC.v0) xv.a = sq * Dk[LANE];
+                            if (LC.v1) xv.b = sq * Dk[LANE + UHC_WAVE];
+                        } else {
+                            const int len = RY[r + 1] - RY[r];
+                            const short* anc = anc_tab + rm.last * YS;
+                            for (int i = LANE; i < n; i += UHC_WAVE) stY[i] = 0.0;
+                            wsync();
+                            if (LANE < len) stY[anc[LANE]] = sq * Yb[RY[r] + LANE];
+                            wsync();
+                            if (LC.v0) xv.a = stY[LANE];
+                            if (LC.v1) xv.b = stY[LANE + UHC_WAVE];
+                            wsync();
+                        }
+                        have_factor = primal_chol_rank1(H, n, xv, pass == 0 ? 1.0 : -1.0);
+                    }
+                }
+            }
+        }
+        if (have_factor) {  // gradient alone
+            primal_chain_pass<TIER, false>(A, S, nefc, Yb, anc_tab, pair_tab, stY, cw, cf, nullptr, vec, H, n);
+            primal_dense_scatter<TIER>(A, S, LC, Db, cf, vec);
+        } else {
         // ---- Hessian: identity + the active rows' outer products; gradient: u + sum_active D jar Yhat -- one pass over the rows for both
         const int nH = (n * (n + 1)) / 2;
         for (int e = LANE; e < nH; e += UHC_WAVE) H[e] = 0.0;
@@ -343,6 +416,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
                 wsync();
             }
         }
+        }
         DofVec x;
         x.a = LC.v0 ? vec[LANE] : 0.0; x.b = LC.v1 ? vec[LANE + UHC_WAVE] : 0.0;
         const double gn = sqrt(wave_sum(x.a * x.a + x.b * x.b));
@@ -350,10 +424,13 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
         PROF(31)
         if (gn <= 1e-14 * g0 || gn == 0.0) { ok = true; break; }
         // ---- left-looking Cholesky H = C C^T, two columns per pass (primal_chol2); the diagonal keeps 1 / C_jj
-        for (int j = 0; j < n; j += 2) {
-            if (j < UHC_WAVE) primal_chol2<true>(H, n, j); else primal_chol2<false>(H, n, j);
-            wsync();  // (the next pair reads what other lanes wrote here)
-        }
+        if (!have_factor)
+            for (int j = 0; j < n; j += 2) {
+                if (j < UHC_WAVE) primal_chol2<true>(H, n, j); else primal_chol2<false>(H, n, j);
+                wsync();  // (the next pair reads what other lanes wrote here)
+            }
+        have_factor = true;
+        act_prev = act;
         PROF(26)
         // ---- dir = -H^-1 g: forward substitution column by column (the next column's entries are fetched while this one's step runs), back
         //      substitution row by row (x_j -= C[k][j] x_k for j < k: no reduction on the serial chain); x in registers
