@@ -649,8 +649,13 @@ def main():
                "mfma_peak_tflops": 78.6 if args.ppo_dtype == "float64" else 157.3, "rollout_plus_update_samples_per_s": n_samples / (t_up + elapsed * T / args.steps)}
         if ncalls:  # rank 0's view of the gradient exchange: one flat all-reduce per network per optimisation step
             algbw = comm_bytes * ncalls / (comm_ms * 1e-3) / 1e9
+            ovl = bool(getattr(agent, "overlap_grad_exchange", True))
             ppo["allreduce"] = {"calls": ncalls, "bytes_per_call": comm_bytes, "total_ms": comm_ms, "algbw_GBs": algbw,
-                                "busbw_GBs": algbw * 2 * (world - 1) / world, "share_of_update": comm_ms * 1e-3 / t_up}
+                                "busbw_GBs": algbw * 2 * (world - 1) / world, "share_of_update": comm_ms * 1e-3 / t_up,
+                                # value half first, the surrogate's backward pass enqueued behind it: an interval (start of an exchange -> its
+                                # wait over) then contains that backward pass, the bandwidths above are lower bounds, and what the update pays is
+                                "overlapped_with_policy_backward": ovl, "exposed_ms": agent.comm_exposed_ms,
+                                "exposed_share_of_update": agent.comm_exposed_ms * 1e-3 / t_up}
     # ---- the same rollout with MuJoCo-style PGS sweeps (solver 0), kernel time only: what north_star's "PGS contact solve" costs
     pgs = None
     if world == 1 and not args.no_pgs_probe:

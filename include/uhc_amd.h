@@ -138,7 +138,7 @@ enum UhcField {
                               * (a checker that follows the same path needs to know which); bit 7: constraint rows / contacts beyond the LAST tier's
                               * capacity were DROPPED in this step (UHC_F_EFC_OVERFLOW is the sticky version, cleared by the env's next set_state);
                               * without tier 4 a forward pass that dropped rows gets a bounded exact attempt and at most 32 sweeps (bits 1 and 7) */
-    UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) (an env that needed tier 4 starts in the large tier) */
+    UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3 | 4: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
     UHC_F_HANDON_WHY = 18    /* int32 [n_env] diagnostic of the last step: bits 0-7 why the fast tier handed the env on, bits 8-15 why the general tier did
                               * (1 contacts, 2 constraint rows, 4 body-body row slots, 8 packed row storage, 16 MPR candidate list beyond the tier's
                               * capacity), bits 16+ the substep of the last hand-on; 0 = the env stayed in the tier it started in */

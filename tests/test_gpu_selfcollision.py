@@ -443,7 +443,8 @@ def test_pass_that_drops_rows_is_flagged_and_bounded(model, standing, monkeypatc
     assert np.isfinite(b.field(S.F_QPOS).cpu().numpy()).all()
 
 
-def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing):
+@pytest.mark.parametrize("sticky4", [False, True], ids=["default", "sticky_tier4"])
+def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing, sticky4, monkeypatch):
     """The reference asks MuJoCo for njmax 2500 / nconmax 500 (uhc/khrylib/mocap/skeleton_mesh.py:46) and solves with Newton on the primal.  The scene of
     the test above -- a humanoid face down in the floor beside the seven-box raft, 270-330 rows in the first substeps, more than 150 of them
     carrying a force -- is beyond the 256 rows / 128 contacts of the large tier: its workgroup goes on as tier 4 (rows in HBM, the nv x nv
@@ -456,6 +457,8 @@ def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing
     from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
     from uhc_amd.model.shapes import box_triangles
     from uhc_amd.sim import make_ctrl
+    if sticky4:
+        monkeypatch.setenv("UHC_DEBUG", "4096")  # (bit 12: the env starts its next step in tier 4, a launch of its own; not the default -- uhc_device.h)
     K = 7
     m = self_collision_variant(model)
     yaw = [0.06 * (-1) ** k for k in range(K)]
@@ -486,7 +489,7 @@ def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing
         tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
         act = np.zeros((n, ctrl.action_dim))
         primal, worst_q, worst_v, max_nefc = 0, 0.0, 0.0, 0
-        for t in range(5):
+        for t in range(8):
             gq0, gv0 = b.field(S.F_QPOS).cpu().numpy().copy(), b.field(S.F_QVEL).cpu().numpy().copy()
             b.simulate(torch.from_numpy(act).cuda(), tb)
             b.sync()
@@ -500,11 +503,13 @@ def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing
                 worst_q = max(worst_q, np.abs(gq[e] - os_[e].get("qpos")).max())
                 worst_v = max(worst_v, np.abs(gv[e] - os_[e].get("qvel")).max())
                 max_nefc = max(max_nefc, os_[e].geti("max_nefc"))
-        print(f"face-down humanoid + raft of {K} boxes, kernel path {mode}: up to {max_nefc} rows, {primal} of {5 * n} env-steps went through tier 4; one control step from the "
+        print(f"face-down humanoid + raft of {K} boxes, kernel path {mode}: up to {max_nefc} rows, {primal} of {8 * n} env-steps went through tier 4; one control step from the "
               f"device's state, device vs oracle: |dqpos| {worst_q:.2e} |dqvel| {worst_v:.2e}")
         assert max_nefc > 256 and primal > 0
         assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
         assert worst_q < 1e-9 and worst_v < 1e-7, (worst_q, worst_v)
+        if mode == 2 and sticky4:  # opt-in: an env that needed tier 4 starts its next step there (its own launch from the head of the step once the host has seen the count)
+            assert (b.field(S.F_TIER).cpu().numpy() == 4).all(), b.field(S.F_TIER).tolist()
         b.close()
 
 

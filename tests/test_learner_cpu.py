@@ -195,7 +195,7 @@ def test_config_defaults_and_schedules(tmp_path):
 
 
 # ---- data-parallel learner: 2 gloo ranks with half the batch each == 1 process with the whole batch ----------
-def _update(rank, world, port, out_path, wire=None, fused=True, epochs=3):
+def _update(rank, world, port, out_path, wire=None, fused=True, epochs=3, overlap=False):
     import torch.distributed as dist
     torch.set_default_dtype(torch.float64)
     sys.path.insert(0, ROOT)
@@ -209,7 +209,7 @@ def _update(rank, world, port, out_path, wire=None, fused=True, epochs=3):
     ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None,
                   tau=0.95, optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=epochs, clip_epsilon=0.2,
                   policy_grad_clip=[(pol.parameters(), 0.5)])
-    ag.grad_wire_dtype, ag.fuse_grad_exchange = wire, fused
+    ag.grad_wire_dtype, ag.fuse_grad_exchange, ag.overlap_grad_exchange = wire, fused, overlap
     calls = []
     if world > 1:  # count the collectives of the update: one flat gradient exchange per optimisation epoch + the advantage statistics
         real = dist.all_reduce
@@ -287,6 +287,25 @@ def test_float32_wire_is_the_default_and_its_drift_over_a_full_update_is_bounded
             worst = max(worst, float((a[net][k] - b[net][k]).abs().max()))
     assert 0.0 < worst  # (the float32 wire was really used)
     assert len([c for c in b["calls"] if c > 100]) == 10
+
+
+def test_overlapped_exchange_is_the_same_update(tmp_path):
+    """the value gradient's half of the exchange is started (async) before the surrogate's backward pass and waited for
+    after it -- two collectives of half the size per epoch, the same sums: the 2-rank update is bit-identical to the single-buffer one."""
+    import torch.multiprocessing as mp
+    from uhc_amd.utils.config_utils.copycat_config import Config
+    assert Config(cfg_id="copycat_mi355x", base_dir=str(tmp_path)).overlap_grad_exchange is True
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    port = 23500 + (os.getpid() % 2000)
+    mp.spawn(_update, args=(2, port, one, torch.float32, True, 3, False), nprocs=2, join=True)
+    mp.spawn(_update, args=(2, port + 1, two, torch.float32, True, 3, True), nprocs=2, join=True)
+    a, b = torch.load(one), torch.load(two)
+    for net in ("pol", "val"):
+        for k in a[net]:
+            np.testing.assert_array_equal(a[net][k].numpy(), b[net][k].numpy(), err_msg=f"{net}.{k}")
+    nval = sum(v.numel() for v in a["val"].values())
+    npol = sum(v.numel() for k, v in a["pol"].items() if k != "action_log_std")
+    assert [c for c in b["calls"] if c > 100] == [nval + 1, npol + 1] * 3
 
 
 def test_process_amass_raw_collects_action_files(tmp_path):

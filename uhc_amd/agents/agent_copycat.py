@@ -61,6 +61,7 @@ class AgentCopycat(AgentPPO):
                          policy_grad_clip=[(self.policy_net.parameters(), 40)], end_reward=cfg.end_reward, use_mini_batch=False,
                          mini_batch_size=0)
         self.grad_wire_dtype = {"float32": torch.float32, "float64": torch.float64}[str(getattr(cfg, "grad_allreduce_dtype", "float32"))]
+        self.overlap_grad_exchange = bool(getattr(cfg, "overlap_grad_exchange", True))
         if getattr(self, "_loaded_shared_filter", False):
             self.mark_running_state_shared()  # every rank loaded the same filter statistics: they are not new samples
 

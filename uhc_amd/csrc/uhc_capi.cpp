@@ -43,7 +43,7 @@ static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, siz
     return uhc_launch_m2_fast_lds(lds_bytes_fast);
 }
 extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
-                                            const int* cost, const int* fresh, int* order, hipStream_t stream);
+                                            const int* cost, const int* fresh, int* order, int launch4, int* pend3, hipStream_t stream);
 extern "C" hipError_t uhc_launch_gate(const int* started, int want, int* waited, long long* trace, hipStream_t stream);
 extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, int nu, const int* env_ids, int n,
                                            const double* qpos, const double* qvel, int* mask, hipStream_t stream);
@@ -144,8 +144,8 @@ struct UhcBatch {
     bool general_only = false;
     // uhc_batch_set_kernel_path(2): sticky tiers -- every env starts a step in the tier that computed its last one (DevState::tier)
     int path_mode = 0;
-    hipStream_t side_stream = nullptr, side_stream3 = nullptr;  // kernel path 2: the general / large tiers' own envs run beside the fast tier's
-    hipEvent_t ev_fork = nullptr, ev_side1 = nullptr, ev_side2 = nullptr;
+    hipStream_t side_stream = nullptr, side_stream3 = nullptr, side_stream4 = nullptr;  // kernel path 2: the general / large tiers' own envs run beside the fast tier's
+    hipEvent_t ev_fork = nullptr, ev_side1 = nullptr, ev_side2 = nullptr, ev_side3 = nullptr;
     int* tier_now = nullptr;
     bool large_first = false;  // the large tier's consumers are launched (and resident) before the general tier's
     int n_cu = 256;
@@ -724,7 +724,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (const char* q = getenv("UHC_Q2_WAIT")) b->q2_wait_min = std::max(1, atoi(q));
     if (const char* q = getenv("UHC_Q2_MAX")) b->q2_max = std::max(16, atoi(q));
     if (const char* q = getenv("UHC_Q3_MAX")) b->q3_max = std::max(2, atoi(q));
-    TRY(dalloc(b, 2 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
+    TRY(dalloc(b, 3 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
@@ -761,11 +761,12 @@ extern "C" void uhc_batch_free(UhcBatch* b) {
     for (void* p : b->allocs) hipFree(p);
     for (auto& ev : b->ev_used) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& ev : b->ev_free) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    for (hipEvent_t e : {b->ev_fork, b->ev_side1, b->ev_side2}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {b->ev_fork, b->ev_side1, b->ev_side2, b->ev_side3}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : b->cnt_ev) if (e) hipEventDestroy(e);
     if (b->h_counts) hipHostFree(b->h_counts);
     if (b->side_stream) hipStreamDestroy(b->side_stream);
     if (b->side_stream3) hipStreamDestroy(b->side_stream3);
+    if (b->side_stream4) hipStreamDestroy(b->side_stream4);
     if (b->own_stream) hipStreamDestroy(b->own_stream);
     delete b;
 }
@@ -810,6 +811,9 @@ extern "C" int32_t uhc_batch_set_kernel_path(UhcBatch* b, int32_t mode) {
         HIP_OK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&b->ev_side1, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&b->ev_side2, hipEventDisableTiming));
+        // tier 4's own launch (envs whose last step ended there): whole CUs, like the large tier's -- same priority class, launched first of all
+        HIP_OK(hipStreamCreateWithPriority(&b->side_stream4, hipStreamNonBlocking, (least != greatest && least != 0) ? least : greatest));
+        HIP_OK(hipEventCreateWithFlags(&b->ev_side3, hipEventDisableTiming));
     }
     return 0;
 }
@@ -851,8 +855,26 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // BESIDE the fast tier (their launches last several times longer per env; in a chain behind it the step would wait for them);
         // only the envs a tier hands on this very step go through the chain.  All launches filter on one snapshot of the tier table.
         KernelArgs K = b->A;
-        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->d_fin, b->A.s.cost, b->A.s.fresh, b->d_order, b->stream));
+        // tier 4 of its own: when the newest queue lengths seen say that envs ended their step in tier 4, those envs get a one-workgroup-per-env launch
+        // from the head of this step (list = d_lists + 2 n_env, flagged pend3 = 2: straight to tier 4) -- a humanoid lying among boxes stays there for
+        // many steps, and through the tier chain it would pay an abandoned large-tier pass and a place at the very end of every step
+        int est4 = 0;
+        if (b->A.last_tier == 4)
+            for (long long k = b->cnt_step - 1; k >= 0 && k > b->cnt_step - 8; k--)
+                if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) { est4 = b->h_counts[8 * (k % 8) + 7]; break; }
+        (void)hipGetLastError();
+        const bool launch4 = b->A.last_tier == 4 && est4 > 0;
+        HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->d_fin, b->A.s.cost, b->A.s.fresh, b->d_order,
+                                     launch4 ? 1 : 0, b->A.s.pend3, b->stream));
         HIP_OK(hipEventRecord(b->ev_fork, b->stream));
+        if (launch4) {
+            KernelArgs K4 = b->A;
+            K4.order = b->d_lists + 2 * b->n_env;
+            K4.grid = std::min(b->n_env, std::max(4, est4 + est4 / 2 + 4));  // (a list longer than the launch: the rest stays flagged for the chained launch)
+            HIP_OK(hipStreamWaitEvent(b->side_stream4, b->ev_fork, 0));
+            HIP_OK(uhc_launch_step(mode, 3, &K4, d_action, d_tbase, b->A.s.pend3, b->lds_bytes_big, b->side_stream4));
+            HIP_OK(hipEventRecord(b->ev_side3, b->side_stream4));
+        }
         // how long the queues got is known on the host with a lag (asynchronous copies of the final counts, never waited for): the newest
         // copy that has landed sizes this step's consumer launches.  While the general tier's queue was empty when last seen there are no
         // consumers at all: an env the fast tier hands on is flagged and goes through the chained launches like in mode 0.
@@ -903,7 +925,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         const int bal = (int)(((long long)est2 * s1 * b->n_cu) / std::max(1, est1 + (est2 * s1) / 2));
         const int cap2 = (b->A.dbg & 2048) ? b->q2_max : std::max(b->q2_max, std::min((7 * bal) / 8, (3 * b->n_cu) / 2));
         const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, cap2) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
-        K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0);
+        K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0) | (launch4 ? 16 : 0);
         auto launch_large = [&]() -> int {
             HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
             K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
@@ -951,6 +973,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (queues) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side1, 0));
         HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, b->A.s.pend2, b->lds_bytes, b->stream));
         if (q3) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side2, 0));
+        if (launch4) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side3, 0));
         if (big) HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, b->A.s.pend3, b->lds_bytes_big, b->stream));
         // the final queue lengths of this step, for the steps to come
         const int slot = (int)(b->cnt_step % 8);

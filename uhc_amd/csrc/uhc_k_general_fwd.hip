@@ -63,13 +63,16 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
 // envs that begin the step there (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; free slots = -1),
 // the cursors the persistent launches share and the producers' exit counters (fin[1]: fast tier's workgroups, fin[2]: general tier's)
 #define UHC_ORDER_BUCKETS 6
+// (tier 4, `launch4` != 0: the envs whose last step ended in tier 4 get a launch of their own this step -- lists[2 n_env ..), counts[6] -- and are flagged
+//  pend3 = 2, "straight to tier 4"; with launch4 == 0 they are the large tier's like any tier-3 env and the snapshot says 3)
 __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
-                                      const int* cost, const int* fresh, int* order) {
+                                      const int* cost, const int* fresh, int* order, int launch4, int* pend3) {
     __shared__ int nb[UHC_ORDER_BUCKETS + 1];
     if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; }
+    if (threadIdx.x >= 6 && threadIdx.x < 8) counts[threadIdx.x] = 0;
     if (threadIdx.x < 8) fin[threadIdx.x] = 0;  // exit counters of the fast / general tier's workgroups [1], [2]; spare seats taken [0]; consumers resident [3], [4]
     if (threadIdx.x <= UHC_ORDER_BUCKETS) nb[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < 2 * n_env; i += blockDim.x) lists[i] = -1;
+    for (int i = threadIdx.x; i < 3 * n_env; i += blockDim.x) lists[i] = -1;
     __syncthreads();
     // the fast tier's launch order: its envs from the costliest bucket down (cost = how close the env's last step came to the tier's
     // capacity, which is also what its step time grows with), then the envs that are not this launch's.  The launch does not fit the chip
@@ -84,9 +87,15 @@ __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int 
         return c >= 56 ? 0 : c >= 48 ? 1 : c >= 40 ? 2 : c >= 32 ? 3 : c >= 24 ? 4 : 5;
     };
     for (int env = threadIdx.x; env < n_env; env += blockDim.x) {
-        const int t = tier[env];
+        int t = tier[env];
+        const bool on = !d_active || d_active[env];
+        if (t == 4) {
+            if (on) atomicAdd(&counts[7], 1);  // (what the host sizes the NEXT steps' tier-4 launch by, and decides launch4 from)
+            if (launch4 && on) { lists[2 * n_env + atomicAdd(&counts[6], 1)] = env; pend3[env] = 2; }
+            else if (!launch4) t = 3;
+        }
         tier_now[env] = t;
-        if ((t == 2 || t == 3) && (!d_active || d_active[env])) lists[(t - 2) * n_env + atomicAdd(&counts[t], 1)] = env;
+        if ((t == 2 || t == 3) && on) lists[(t - 2) * n_env + atomicAdd(&counts[t], 1)] = env;
         if (order) atomicAdd(&nb[bucket(env)], 1);
     }
     __syncthreads();
@@ -100,8 +109,8 @@ __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int 
     for (int env = threadIdx.x; env < n_env; env += blockDim.x) order[atomicAdd(&nb[bucket(env)], 1)] = env;
 }
 extern "C" hipError_t uhc_launch_tier_lists(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
-                                            const int* cost, const int* fresh, int* order, hipStream_t stream) {
-    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors, fin, cost, fresh, order);
+                                            const int* cost, const int* fresh, int* order, int launch4, int* pend3, hipStream_t stream) {
+    hipLaunchKernelGGL(uhc_tier_lists_kernel, dim3(1), dim3(256), 0, stream, tier, d_active, n_env, tier_now, lists, counts, cursors, fin, cost, fresh, order, launch4, pend3);
     return hipGetLastError();
 }
 

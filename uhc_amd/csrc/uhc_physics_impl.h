@@ -2369,18 +2369,18 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
 // ------------------------------------------------------------------ tier 4's solver: Newton on the primal problem (uhc_primal.h; the translation units
 // of the large tier, whose workgroups go on as tier 4, define UHC_WITH_TIER4 -- the others never instantiate it)
 template <int TIER>
-__device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db PROF_ARGS);
+__device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db, int* nact PROF_ARGS);
 #ifdef UHC_WITH_TIER4
 #include "uhc_primal.h"
 #endif
 
 // ------------------------------------------------------------------ mj_forward
-struct FwdOut { int ncon, nefc, iters, overflow; };  // overflow bit 0: the env does not fit this tier => redone by the next one
+struct FwdOut { int ncon, nefc, iters, overflow, nact; };  // nact (tier 4): rows that carry a force at the optimum  // overflow bit 0: the env does not fit this tier => redone by the next one
 template <int TIER, bool DENSE>
 __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP, const int env PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
-    FwdOut out = {0, 0, 0, 0};
+    FwdOut out = {0, 0, 0, 0, 0};
     k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
     PROF(1)
     k_com_pos<TIER>(A, mb, S, BC);
@@ -2424,7 +2424,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
                 for (int r = LANE; r < out.nefc; r += UHC_WAVE) fric = fric || RTYPE(((const RowMisc*)(S + L.rowMisc))[r].type) == ROW_FRICTION;
                 fric = wave_or(fric);
                 if (T.solver == 1 && !fric) {
-                    it = k_primal<TIER>(A, mb, S, out.nefc, LC, Yb, Db PROF_PASS);
+                    it = k_primal<TIER>(A, mb, S, out.nefc, LC, Yb, Db, &out.nact PROF_PASS);
                     out.overflow |= 128;                            // UHC_F_REDO bit 30: solved by Newton on the primal
                     if (it < 0) { out.overflow |= 256; it = -it; }  // bit 29: it stopped at its iteration cap (the best iterate is used)
                 } else {
@@ -2736,11 +2736,11 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
         agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v));
     }
     wsync();
-    FwdOut fo = {0, 0, 0, 0};
+    FwdOut fo = {0, 0, 0, 0, 0};
     int it = 0;
     int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
     bool ran = false, fits = true;  // fits (general / large tier): every substep of this step was within the fast kernel's capacity
-    int pk_nefc = 0, pk_ncon = 0, pk_ntwo = 0, pk_y = 0;  // the step's peaks over its substeps: rows, contacts, body-body rows, packed Yhat entries (sticky tiers)
+    int pk_nefc = 0, pk_ncon = 0, pk_ntwo = 0, pk_y = 0, pk_act = 0;  // the step's peaks over its substeps: rows, contacts, body-body rows, packed Yhat entries (sticky tiers)
     PROF_DECL
     if (MODE == 2) {  // kinematics of a device-side restart: what the reset observation reads; the rest of sim.forward() is deferred
         k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
@@ -2797,7 +2797,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
                               (!(DENSE && cap_of<TIER>(A).ndense > 0) || ((const int*)(S + L.ncon_nefc))[2] <= A.cf.ndense);
             {
                 const int ntwo = (DENSE && cap_of<TIER>(A).ndense > 0) ? ((const int*)(S + L.ncon_nefc))[2] : 0;
-                pk_nefc = max(pk_nefc, fo.nefc); pk_ncon = max(pk_ncon, fo.ncon); pk_ntwo = max(pk_ntwo, ntwo);
+                pk_nefc = max(pk_nefc, fo.nefc); pk_ncon = max(pk_ncon, fo.ncon); pk_ntwo = max(pk_ntwo, ntwo); pk_act = max(pk_act, fo.nact);
                 if (TIER != 1 && fo.nefc > 0) pk_y = max(pk_y, ((const int*)(S + L.rowY))[fo.nefc]);
             }
             ran = true;
@@ -2907,6 +2907,13 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             if (TIER == 1) next = up2 ? 2 : 1;
             else if (TIER == 2) next = (up3 && big == 3) ? 3 : (dn1 ? 1 : 2);
             else next = !dn2 ? 3 : (dn1 ? 1 : 2);
+            // an env that needed tier 4 (beyond the large tier's capacities, or more force-carrying rows than its working sets finish) starts its next
+            // step THERE: a launch of its own from the head of the step (uhc_capi.cpp) instead of an abandoned large-tier attempt and a place at the
+            // step's very end.  It comes down with room to spare: 3/4 of the large tier's capacities and <= 48 rows with a force.
+            // OPT-IN (UHC_DEBUG bit 12): measured on the random-policy ball-joint rollouts it LOSES -- configs[4] 41.6 k -> 27.1 k env-steps/s: the envs that
+            // reach tier 4 there are diverging ones that reset within two or three steps, a reset env then runs its first step in tier 4 too, and the
+            // whole-CU workgroups at the head of the step take CUs from the fast tier -- so by default such an env starts its next step in the large tier.
+            if (TIER == 4 && (A.dbg & 4096) && A.last_tier == 4 && !(pk_nefc <= (3 * A.ch.maxefc) / 4 && pk_ncon <= (3 * A.ch.maxcon) / 4 && pk_ntwo <= (3 * A.ch.ndense) / 4 && pk_act <= 48)) next = 4;
             A.s.tier[env] = next;
             A.s.cost[env] = max(pk_nefc, max((pk_ncon * UHC_FAST_MAXEFC) / max(A.cf.maxcon, 1), (pk_ntwo * UHC_FAST_MAXEFC) / max(A.cf.ndense, 1)));
         }
@@ -2964,7 +2971,7 @@ template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const double* __restrict__ d_action,
                                                             const double* __restrict__ d_tbase, const int* __restrict__ d_active) {
     const int env = (A.order && (int)blockIdx.x < A.n_env) ? A.order[blockIdx.x] : (int)blockIdx.x;
-    bool go = env < A.n_env && !(d_active && !d_active[env]);
+    bool go = env >= 0 && env < A.n_env && !(d_active && !d_active[env]);  // (env < 0: a free slot of a list launch, A.order)
     if (go && A.tier_want) {  // sticky tiers: the envs whose tier has its own launch this step are not this launch's
         const int t = A.s.tier_now[env];
         go = t == A.tier_want || !((A.sticky_mask >> t) & 1);

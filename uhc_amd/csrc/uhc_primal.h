@@ -249,7 +249,7 @@ __device__ __forceinline__ bool primal_chol_rank1(double* H, int n, DofVec x, do
 
 // returns the Newton iterations taken (>= 1), negated when the iteration cap was reached; z = u in S[L.z], the forces in S[L.rowF]
 template <int TIER>
-__device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db PROF_ARGS) {
+__device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db, int* nact PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
@@ -503,7 +503,10 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
     if (LANE == 0 && (it >= 20 || !ok)) printf("k_primal: env block %d nefc %d nslot %d: %d iterations, ok %d, g0 %.3e\n", (int)blockIdx.x, nefc, nslot, it, (int)ok, g0);
 #endif
     // ---- forces (z = u is in place)
-    for (int r = LANE; r < nefc; r += UHC_WAVE) { const double x = jar[r]; cf[r] = x < 0 ? -Dr[r] * x : 0.0; }
+    int na = 0;
+    for (int r = LANE; r < nefc; r += UHC_WAVE) { const double x = jar[r]; cf[r] = x < 0 ? -Dr[r] * x : 0.0; na += x < 0 ? 1 : 0; }
+    for (int o = 32; o > 0; o >>= 1) na += __shfl_xor(na, o);
+    *nact = na;
     wsync();
     return ok ? max(it, 1) : -max(it, 1);
 }

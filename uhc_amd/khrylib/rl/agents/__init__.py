@@ -356,15 +356,24 @@ class AgentPG(Agent):
         into global means: sum_r (n_r * g_r) / sum_r n_r, with one all-reduce over a flat buffer."""
         if not _dist_on():
             return
+        self._finish_grad_exchange(self._start_grad_exchange(params_and_scale, slot=0))
+
+    def _start_grad_exchange(self, params_and_scale, slot=0):
+        """Pack the local gradient means (times the rank's sample count) and the counts into flat buffer `slot` and START the all-reduce
+        (`async_op`: over RCCL it runs on the process group's own stream, so whatever the caller enqueues next -- the surrogate's backward
+        pass -- overlaps with it).  Returns what `_finish_grad_exchange` needs."""
         plist = [p for ps, _ in params_and_scale for p in ps if p.grad is not None]
         total = sum(p.numel() for p in plist) + len(params_and_scale)
-        # the wire: the parameters' own dtype (float64 like the reference's arithmetic: the 2-rank update then equals the single-process
-        # one to rounding), or float32 when asked (`grad_allreduce_dtype: float32` -- SURVEY 8e's 32 MB per exchange instead of 64;
-        # the local gradient MEANS go on the wire scaled by the rank's share n_r / 1024-ths are not needed: |n g| stays far inside float32)
+        # the wire: float32 by default (`grad_allreduce_dtype`, SURVEY 8e's 32 MB per epoch), or the parameters' own dtype (float64 like
+        # the reference's arithmetic: the 2-rank update then equals the single-process one to rounding).  The local gradient MEANS go on
+        # the wire scaled by the rank's sample count: |n g| stays far inside float32.
         wire = getattr(self, "grad_wire_dtype", None) or plist[0].dtype
-        if self._flat_grad is None or self._flat_grad.numel() != total or self._flat_grad.dtype != wire:
-            self._flat_grad = torch.empty(total, dtype=wire, device=plist[0].device)
-        buf, off = self._flat_grad, 0
+        if self._flat_grad is None:
+            self._flat_grad = {}
+        buf = self._flat_grad.get(slot)
+        if buf is None or buf.numel() != total or buf.dtype != wire:
+            buf = self._flat_grad[slot] = torch.empty(total, dtype=wire, device=plist[0].device)
+        off = 0
         for ps, n in params_and_scale:
             for p in ps:
                 if p.grad is None:
@@ -374,15 +383,23 @@ class AgentPG(Agent):
                 off += k
         for i, (_, n) in enumerate(params_and_scale):
             buf[off + i] = float(n)  # (sample counts up to 2^24 per rank are exact in float32)
-        timed = getattr(self, "time_comm", False) and buf.is_cuda
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        if timed:
-            e1.record()
+        ev = None
+        if getattr(self, "time_comm", False) and buf.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        return work, buf, off, params_and_scale, ev
+
+    def _finish_grad_exchange(self, started):
+        work, buf, off, params_and_scale, ev = started
+        if ev is not None:
+            mid = torch.cuda.Event(enable_timing=True)
+            mid.record()
+        work.wait()
+        if ev is not None:
+            ev[1].record()
             self._comm_events = getattr(self, "_comm_events", [])
-            self._comm_events.append((e0, e1, buf.numel() * buf.element_size()))
+            self._comm_events.append((ev[0], ev[1], buf.numel() * buf.element_size(), mid))
         counts = buf[off:off + len(params_and_scale)]
         off = 0
         for i, (ps, _) in enumerate(params_and_scale):
@@ -394,13 +411,17 @@ class AgentPG(Agent):
                 off += k
 
     def comm_summary(self):
-        """(calls, total ms, bytes per call) of the gradient all-reduces timed since the last summary (time_comm = True)."""
+        """(calls, total ms, mean bytes per call) of the gradient all-reduces timed since the last summary (time_comm = True).  An interval runs
+        from the start of an exchange to the end of the wait for it: with `overlap_grad_exchange` it CONTAINS the backward pass enqueued in
+        between; `self.comm_exposed_ms` is the part the compute stream actually stood still for (wait issued -> wait over)."""
         ev = getattr(self, "_comm_events", [])
         self._comm_events = []
+        self.comm_exposed_ms = 0.0
         if not ev:
             return 0, 0.0, 0
         torch.cuda.synchronize()
-        return len(ev), float(sum(a.elapsed_time(b) for a, b, _ in ev)), int(ev[0][2])
+        self.comm_exposed_ms = float(sum(m.elapsed_time(b) for _, b, _, m in ev))
+        return len(ev), float(sum(a.elapsed_time(b) for a, b, _, _ in ev)), int(sum(e[2] for e in ev) // len(ev))
 
     def update_value(self, states, returns):
         for _ in range(self.value_opt_niter):
@@ -464,9 +485,18 @@ class AgentPPO(AgentPG):
                 self.optimizer_value.zero_grad()
                 self.optimizer_policy.zero_grad()
                 value_loss.backward()
-                surr_loss.backward()
-                self._allreduce_grads([(list(self.value_net.parameters()), states.shape[0]),
-                                       ([p for p in self.policy_net.parameters() if p.requires_grad], ind.shape[0])])
+                if getattr(self, "overlap_grad_exchange", True):
+                    # the value gradient is ready first: its half of the exchange travels while the surrogate's backward pass runs
+                    # (two collectives of half the size each per epoch; the same sums as the single buffer)
+                    first = self._start_grad_exchange([(list(self.value_net.parameters()), states.shape[0])], slot=1)
+                    surr_loss.backward()
+                    second = self._start_grad_exchange([([p for p in self.policy_net.parameters() if p.requires_grad], ind.shape[0])], slot=2)
+                    self._finish_grad_exchange(first)
+                    self._finish_grad_exchange(second)
+                else:
+                    surr_loss.backward()
+                    self._allreduce_grads([(list(self.value_net.parameters()), states.shape[0]),
+                                           ([p for p in self.policy_net.parameters() if p.requires_grad], ind.shape[0])])
                 self.optimizer_value.step()
                 self.clip_policy_grad()
                 self.optimizer_policy.step()

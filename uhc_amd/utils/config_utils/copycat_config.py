@@ -99,6 +99,7 @@ class Config(Base_Config):
         # N-rank update stays within 1e-4 relative of the single-process one over a whole 10-epoch update (tests/test_learner_cpu.py).
         # float64 = the learner's own arithmetic on the wire: the N-rank update equals the single-process one to 1e-10, at twice the bytes
         self.grad_allreduce_dtype = g("grad_allreduce_dtype", "float32")
+        self.overlap_grad_exchange = bool(g("overlap_grad_exchange", True))  # value half of the exchange travels during the surrogate's backward pass
 
     def update_adaptive_params(self, i_iter):
         cp = self.adp_iter_cp
