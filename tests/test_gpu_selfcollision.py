@@ -568,3 +568,70 @@ def test_sticky_queues_hand_an_env_on_to_tier_4(model, standing):
     print(f"sticky queues + tier 4: env-steps through tier 4 {primal} / {6 * n}; next-step tiers {tiers.tolist()}; worst |dqpos| {worst:.2e}")
     assert primal >= 6 and worst < 1e-9, (primal, worst)
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
+
+
+def test_tier_4_consumers_take_what_the_large_tiers_consumers_hand_on(model, standing, monkeypatch, capfd):
+    """Kernel path 2 with ALL the queues running: ten envs standing with the boxes far above them (kept in the general tier by UHC_TIER_MARKS, so that its
+    queue has envs of its own and the consumers of every tier are launched), two face down beside the raft on the floor (large tier by stickiness; its
+    consumer finds them too big in the first substep and appends them to tier 4's queue, whose consumers -- uhc_k_huge_q.hip -- take them up while the
+    other launches still run).  Every env re-posed each step; against the oracle, step by step; the library's own log (UHC_DEBUG bit 6) says whether
+    the tier-4 consumers were launched."""
+    import dataclasses
+    import torch
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
+    from uhc_amd.model.shapes import box_triangles
+    from uhc_amd.sim import make_ctrl
+    if os.environ.get("UHC_FORCE_GENERAL") == "1" or os.environ.get("UHC_TIERS") in ("2", "3"):
+        pytest.skip("needs the fast tier to start from and tier 4 to end in")
+    monkeypatch.setenv("UHC_DEBUG", "64")
+    monkeypatch.setenv("UHC_TIER_MARKS", "8,2,1,4,1,0,8,7")  # up to the general tier beyond 8 rows / 2 contacts / 1 body-body row; down again only below 4 / 1 / 0
+    K = 7
+    m = self_collision_variant(model)
+    yaw = [0.06 * (-1) ** k for k in range(K)]
+    poses = np.array([[1.0 + 0.305 * k, 1.0 + 0.01 * k, 0.1495, np.cos(y / 2), 0, 0, np.sin(y / 2)] for k, y in enumerate(yaw)], dtype=np.float64)
+    m = dataclasses.replace(add_free_bodies(m, [box_triangles(0.15, 0.15, 0.15)] * K, poses, density=5.0 / 0.027), solver=1)
+    ctrl = make_ctrl(model, action_type="torque", residual_force=False, meta_pd=False, tq_mul=4)
+    n, heavy = 12, (3, 9)
+    rng = np.random.default_rng(7)
+    q = np.tile(m.qpos0, (n, 1))
+    for e in range(n):
+        qh = standing["qpos"].copy()
+        qh[7:] += rng.normal(scale=0.01, size=69)
+        if e in heavy:  # face down beside the raft: 300+ rows
+            a = np.pi / 2 + 0.05 * e
+            qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])
+            qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+        else:  # standing, the boxes 5-11 m above the floor: two feet on the ground, nothing else
+            for k in range(K):
+                q[e, 76 + 7 * k + 2] = 5.0 + k
+        q[e, :76] = qh
+    v = np.zeros((n, m.nv))
+    b = S.SimBatch(m, ctrl, n)
+    b.set_kernel_path(2)
+    tb = torch.zeros(n, 69, dtype=torch.float64, device="cuda")
+    act = np.zeros((n, ctrl.action_dim))
+    os_ = [OracleSim(m, ctrl) for _ in range(n)]
+    primal, worst, tiers_seen = 0, 0.0, []
+    for t in range(8):
+        b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        gq = b.field(S.F_QPOS).cpu().numpy()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        tiers_seen.append(b.field(S.F_TIER).cpu().numpy().tolist())
+        for e in range(n):
+            os_[e].set_state(q[e], v[e])
+            os_[e].do_simulation(act[e], np.zeros(69))
+            worst = max(worst, np.abs(gq[e] - os_[e].get("qpos")).max())
+            primal += int((redo[e] & (1 << 30)) != 0)
+            assert bool(redo[e] & (1 << 30)) == (e in heavy), (t, e, hex(int(redo[e])))
+        assert not (redo & 0x80).any() and not (redo & 2).any(), [hex(int(x)) for x in redo]
+    err = capfd.readouterr().err
+    launched = [ln for ln in err.splitlines() if "tier-4 consumers" in ln]
+    print(f"all queues + tier 4's consumers: {len(launched)} of 8 steps had them ({launched[:1]}); env-steps through tier 4 {primal}; next-step tiers {tiers_seen[-1]}; worst |dqpos| {worst:.2e}")
+    assert len(launched) >= 4, (err[-2000:], tiers_seen)
+    assert primal == 8 * len(heavy) and worst < 1e-9, (primal, worst)
+    assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
+    b.close()

@@ -20,13 +20,13 @@
     extern "C" hipError_t fn##_lds(size_t lds_bytes);
 UHC_DECL_LAUNCH(uhc_launch_m0_fast) UHC_DECL_LAUNCH(uhc_launch_m0_fast_dense) UHC_DECL_LAUNCH(uhc_launch_m1_fast) UHC_DECL_LAUNCH(uhc_launch_m1_fast_dense)
 UHC_DECL_LAUNCH(uhc_launch_m2_fast) UHC_DECL_LAUNCH(uhc_launch_m0_gen) UHC_DECL_LAUNCH(uhc_launch_m1_gen) UHC_DECL_LAUNCH(uhc_launch_m2_gen)
-UHC_DECL_LAUNCH(uhc_launch_m0_big) UHC_DECL_LAUNCH(uhc_launch_m1_big) UHC_DECL_LAUNCH(uhc_launch_m0_gen_q) UHC_DECL_LAUNCH(uhc_launch_m0_big_q)
+UHC_DECL_LAUNCH(uhc_launch_m0_big) UHC_DECL_LAUNCH(uhc_launch_m1_big) UHC_DECL_LAUNCH(uhc_launch_m0_gen_q) UHC_DECL_LAUNCH(uhc_launch_m0_big_q) UHC_DECL_LAUNCH(uhc_launch_m0_huge_q)
 // mode 0: control step, 1: forward only, 2: kinematics only; tier 1: the fast kernel, 2: general, 3: large; dense: the model has body-body contacts
 static hipError_t uhc_launch_step(int mode, int tier, const KernelArgs* A, const double* d_action, const double* d_tbase, const int* d_active,
                                   size_t lds_bytes, hipStream_t stream) {
     const bool dense = A->cf.ndense > 0 || A->ball_limits;  // (limited ball joints: the instantiation that carries their rows)
     const bool fast = tier == 1;
-    if (A->list) return (tier == 3 ? uhc_launch_m0_big_q : uhc_launch_m0_gen_q)(A, d_action, d_tbase, d_active, lds_bytes, stream);  // queue consumers (mode 0, tiers 2 / 3)
+    if (A->list) return (tier == 4 ? uhc_launch_m0_huge_q : tier == 3 ? uhc_launch_m0_big_q : uhc_launch_m0_gen_q)(A, d_action, d_tbase, d_active, lds_bytes, stream);  // queue consumers (mode 0, tiers 2 / 3 / 4)
     if (tier == 3) return (mode == 0 ? uhc_launch_m0_big : uhc_launch_m1_big)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (!fast) return (mode == 0 ? uhc_launch_m0_gen : mode == 1 ? uhc_launch_m1_gen : uhc_launch_m2_gen)(A, d_action, d_tbase, d_active, lds_bytes, stream);
     if (mode == 2) return uhc_launch_m2_fast(A, d_action, d_tbase, d_active, lds_bytes, stream);
@@ -35,7 +35,7 @@ static hipError_t uhc_launch_step(int mode, int tier, const KernelArgs* A, const
 }
 static hipError_t uhc_set_lds_limit(size_t lds_bytes, size_t lds_bytes_fast, size_t lds_bytes_big) {
     hipError_t e;
-    if (lds_bytes_big && ((e = uhc_launch_m0_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m1_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m0_big_q_lds(lds_bytes_big)) != hipSuccess)) return e;
+    if (lds_bytes_big && ((e = uhc_launch_m0_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m1_big_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m0_big_q_lds(lds_bytes_big)) != hipSuccess || (e = uhc_launch_m0_huge_q_lds(lds_bytes_big)) != hipSuccess)) return e;
     if ((e = uhc_launch_m0_gen_q_lds(lds_bytes)) != hipSuccess) return e;
     if ((e = uhc_launch_m0_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m1_gen_lds(lds_bytes)) != hipSuccess || (e = uhc_launch_m2_gen_lds(lds_bytes)) != hipSuccess) return e;
     if ((e = uhc_launch_m0_fast_lds(lds_bytes_fast)) != hipSuccess || (e = uhc_launch_m0_fast_dense_lds(lds_bytes_fast)) != hipSuccess) return e;
@@ -155,6 +155,7 @@ struct UhcBatch {
     int q2_wait_min = 16;    // at least so many general-tier consumers wait for hand-ons (UHC_Q2_WAIT)
     int q2_div = 1;          // waiting general-tier consumers per expected env: 1 / q2_div (UHC_Q2_DIV)
     int q2_max = 256;        // most general-tier consumers beside a fast tier that still has most of the envs (UHC_Q2_MAX)
+    int q4_max = 16;         // most tier-4 consumers (UHC_Q4_MAX; 0: none -- what the large tier hands on waits for the chained launch at the end of the step)
     int q3_max = 32;         // most large-tier consumers in that regime (UHC_Q3_MAX)
     int *d_lists = nullptr, *d_counts = nullptr, *d_cursors = nullptr, *d_fin = nullptr;
     bool queues_off = false;
@@ -724,7 +725,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (const char* q = getenv("UHC_Q2_WAIT")) b->q2_wait_min = std::max(1, atoi(q));
     if (const char* q = getenv("UHC_Q2_MAX")) b->q2_max = std::max(16, atoi(q));
     if (const char* q = getenv("UHC_Q3_MAX")) b->q3_max = std::max(2, atoi(q));
-    TRY(dalloc(b, 3 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 4, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
+    if (const char* q = getenv("UHC_Q4_MAX")) b->q4_max = std::max(0, atoi(q));
+    TRY(dalloc(b, 3 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 8, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
     if (A.c.rfc_mode == 2) { TRY(dalloc(b, E * 6 * nv, &S.cdof)); TRY(dalloc(b, E * 3 * nb, &S.rootcom)); }
@@ -838,7 +840,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         else { ev = b->ev_free.back(); b->ev_free.pop_back(); }
     }
     const bool general = b->general_only;
-    const bool big = b->A.last_tier >= 3;  // (tier 4 has no launch of its own: the large tier's workgroups go on with it)
+    const bool big = b->A.last_tier >= 3;  // (tier 4 has no chained launch of its own: the large tier's workgroups go on with it; under sticky tiers it has queue consumers, below)
     // tier chain: every tier works on the envs the previous one flagged (redo / redo2) and left untouched
     HIP_OK(hipMemsetAsync(b->A.s.redo, 0, sizeof(int) * b->n_env * 5, b->stream));  // redo (the step's UHC_F_REDO words), pend2, pend3, resume, why: one allocation
     // (inside a stream capture the sticky launch cannot be used: it sizes its consumer launches from counts the host reads between steps
@@ -855,26 +857,21 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         // BESIDE the fast tier (their launches last several times longer per env; in a chain behind it the step would wait for them);
         // only the envs a tier hands on this very step go through the chain.  All launches filter on one snapshot of the tier table.
         KernelArgs K = b->A;
-        // tier 4 of its own: when the newest queue lengths seen say that envs ended their step in tier 4, those envs get a one-workgroup-per-env launch
-        // from the head of this step (list = d_lists + 2 n_env, flagged pend3 = 2: straight to tier 4) -- a humanoid lying among boxes stays there for
-        // many steps, and through the tier chain it would pay an abandoned large-tier pass and a place at the very end of every step
-        int est4 = 0;
-        if (b->A.last_tier == 4)
+        // tier 4's own consumers: when the newest counts seen say that envs went through tier 4 (counts[7]: hand-ons of the large tier + envs that start there),
+        // a few persistent workgroups wait on a queue of their own (d_lists + 2 n_env) beside everything else, and the large tier's consumers append what
+        // they find too big instead of leaving it for the chained launch at the very end of the step -- where a 10 ms env-step of one env used to be added
+        // to every step in which any env needed tier 4 (configs[4]: 64 k -> 42 k env-steps/s when tier 4 came in).  Envs that START in tier 4
+        // (UHC_DEBUG bit 12) are put at the head of that queue by the list kernel.
+        int est4 = 0, est2_then = 0;
+        if (b->A.last_tier == 4 && b->q4_max > 0)
             for (long long k = b->cnt_step - 1; k >= 0 && k > b->cnt_step - 8; k--)
-                if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) { est4 = b->h_counts[8 * (k % 8) + 7]; break; }
+                if (hipEventQuery(b->cnt_ev[k % 8]) == hipSuccess) { est4 = b->h_counts[8 * (k % 8) + 7]; est2_then = b->h_counts[8 * (k % 8) + 2]; break; }
         (void)hipGetLastError();
-        const bool launch4 = b->A.last_tier == 4 && est4 > 0;
+        const bool launch4 = b->A.last_tier == 4 && est4 > 0 && est2_then > 0 && big && !b->queues_off;  // (the list kernel's view; the consumers need the large tier's beside them: q4 below)
+        K.cnt4 = b->d_counts + 7;
         HIP_OK(uhc_launch_tier_lists(b->A.s.tier, d_active, b->n_env, b->tier_now, b->d_lists, b->d_counts, b->d_cursors, b->d_fin, b->A.s.cost, b->A.s.fresh, b->d_order,
                                      launch4 ? 1 : 0, b->A.s.pend3, b->stream));
         HIP_OK(hipEventRecord(b->ev_fork, b->stream));
-        if (launch4) {
-            KernelArgs K4 = b->A;
-            K4.order = b->d_lists + 2 * b->n_env;
-            K4.grid = std::min(b->n_env, std::max(4, est4 + est4 / 2 + 4));  // (a list longer than the launch: the rest stays flagged for the chained launch)
-            HIP_OK(hipStreamWaitEvent(b->side_stream4, b->ev_fork, 0));
-            HIP_OK(uhc_launch_step(mode, 3, &K4, d_action, d_tbase, b->A.s.pend3, b->lds_bytes_big, b->side_stream4));
-            HIP_OK(hipEventRecord(b->ev_side3, b->side_stream4));
-        }
         // how long the queues got is known on the host with a lag (asynchronous copies of the final counts, never waited for): the newest
         // copy that has landed sizes this step's consumer launches.  While the general tier's queue was empty when last seen there are no
         // consumers at all: an env the fast tier hands on is flagged and goes through the chained launches like in mode 0.
@@ -926,12 +923,24 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         const int cap2 = (b->A.dbg & 2048) ? b->q2_max : std::max(b->q2_max, std::min((7 * bal) / 8, (3 * b->n_cu) / 2));
         const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, cap2) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0) | (launch4 ? 16 : 0);
+        const bool q4 = launch4 && q3;
+        const int grid4 = std::min(b->q4_max, est4 + est4 / 2 + 2);
+        if (q4) {  // (first of the side launches: a whole CU's LDS each, only to be had before the fast tier's launch has filled the chip)
+            HIP_OK(hipStreamWaitEvent(b->side_stream4, b->ev_fork, 0));
+            K.tier_want = 0; K.list = b->d_lists + 2 * b->n_env; K.list_count = b->d_counts + 6; K.list_cursor = b->d_cursors + 4;
+            K.grid = grid4; K.n_wait = grid4; K.spares = nullptr; K.started = nullptr;
+            K.prod_fin = b->d_fin + 5; K.prod_total = grid3;  // the large tier's consumers
+            K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
+            if (b->A.dbg & 64) fprintf(stderr, "uhc step %lld: %d tier-4 consumers (%d env-steps went through tier 4 when last seen)\n", b->cnt_step, grid4, est4);
+            HIP_OK(uhc_launch_step(mode, 4, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream4));
+            HIP_OK(hipEventRecord(b->ev_side3, b->side_stream4));
+        }
         auto launch_large = [&]() -> int {
             HIP_OK(hipStreamWaitEvent(b->side_stream3, b->ev_fork, 0));
             K.tier_want = 0; K.list = b->d_lists + b->n_env; K.list_count = b->d_counts + 3; K.list_cursor = b->d_cursors + 3;
             K.grid = grid3; K.n_wait = grid3; K.spares = nullptr; K.started = b->d_fin + 4;
             K.prod_fin = b->d_fin + 2; K.prod_total = grid2;  // the general tier's workgroups: they never wait for this launch
-            K.fin = nullptr; K.q_next = nullptr; K.q_next_count = nullptr;
+            K.fin = q4 ? b->d_fin + 5 : nullptr; K.q_next = q4 ? b->d_lists + 2 * b->n_env : nullptr; K.q_next_count = q4 ? b->d_counts + 6 : nullptr;
             HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, nullptr, b->lds_bytes_big, b->side_stream3));
             HIP_OK(hipEventRecord(b->ev_side2, b->side_stream3));
             return 0;
@@ -973,7 +982,7 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         if (queues) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side1, 0));
         HIP_OK(uhc_launch_step(mode, 2, &K, d_action, d_tbase, b->A.s.pend2, b->lds_bytes, b->stream));
         if (q3) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side2, 0));
-        if (launch4) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side3, 0));
+        if (q4) HIP_OK(hipStreamWaitEvent(b->stream, b->ev_side3, 0));
         if (big) HIP_OK(uhc_launch_step(mode, 3, &K, d_action, d_tbase, b->A.s.pend3, b->lds_bytes_big, b->stream));
         // the final queue lengths of this step, for the steps to come
         const int slot = (int)(b->cnt_step % 8);

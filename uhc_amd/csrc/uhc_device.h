@@ -164,11 +164,12 @@ struct KernelArgs {
     int* fin;             // this launch's own exit counter (bumped once per workgroup), or NULL
     int* q_next;          // hand-on target: the next tier's queue (NULL: flag the env in redo / redo2 for a chained launch)
     int* q_next_count;
+    int* cnt4;            // sticky tiers: bumped once per env the large tier hands on to tier 4 (the host sizes the tier-4 consumers of the next steps by it), or NULL
     int grid;  // workgroups of a list launch (0: one per env)
     int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int ball_limits;  // the model has limited ball joints: the fast tier launches its DENSE instantiation (which carries the ball-limit rows)
-    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step, bit 7 = no box cull of the convex pairs, bit 8 (256) = the general tier's first working set is NOT filled by rank (k_as_general; A/B of DESIGN 2), bits 9 / 10 (512 / 1024) = fill 48 / 56 lanes instead of 64, bit 11 (2048) = fixed cap UHC_Q2_MAX on the general tier's consumers (launch()).  bit 12 (4096) = sticky tier 4: an env whose step ended in tier 4 starts its next step there, in a one-workgroup-per-env launch of its own from the head of the step (uhc_capi.cpp launch(); measured and not the default, see uhc_step_env).  Bits 8-11 change which envs report windows / sweeps in UHC_F_REDO: measurement switches, never set in a parity run
+    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step, bit 7 = no box cull of the convex pairs, bit 8 (256) = the general tier's first working set is NOT filled by rank (k_as_general; A/B of DESIGN 2), bits 9 / 10 (512 / 1024) = fill 48 / 56 lanes instead of 64, bit 11 (2048) = fixed cap UHC_Q2_MAX on the general tier's consumers (launch()).  bit 12 (4096) = sticky tier 4: an env whose step ended in tier 4 starts its next step there, at the head of the tier-4 consumers' queue (uhc_capi.cpp launch(); measured and not the default, see uhc_step_env).  Bits 8-11 change which envs report windows / sweeps in UHC_F_REDO: measurement switches, never set in a parity run
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     int adjdeg;              // stride of the per-model hull adjacency table (largest vertex degree over the batch's models)
     DevCtrl c;

@@ -68,7 +68,8 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
 __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
                                       const int* cost, const int* fresh, int* order, int launch4, int* pend3) {
     __shared__ int nb[UHC_ORDER_BUCKETS + 1];
-    if (threadIdx.x < 4) { counts[threadIdx.x] = 0; cursors[threadIdx.x] = 0; }
+    if (threadIdx.x < 4) counts[threadIdx.x] = 0;
+    if (threadIdx.x < 8) cursors[threadIdx.x] = 0;
     if (threadIdx.x >= 6 && threadIdx.x < 8) counts[threadIdx.x] = 0;
     if (threadIdx.x < 8) fin[threadIdx.x] = 0;  // exit counters of the fast / general tier's workgroups [1], [2]; spare seats taken [0]; consumers resident [3], [4]
     if (threadIdx.x <= UHC_ORDER_BUCKETS) nb[threadIdx.x] = 0;
@@ -90,7 +91,7 @@ __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int 
         int t = tier[env];
         const bool on = !d_active || d_active[env];
         if (t == 4) {
-            if (on) atomicAdd(&counts[7], 1);  // (what the host sizes the NEXT steps' tier-4 launch by, and decides launch4 from)
+            if (on) atomicAdd(&counts[7], 1);  // (counts[7]: the step's tier-4 envs -- these and every hand-on to tier 4 (KernelArgs::cnt4); the host sizes the NEXT steps' tier-4 consumers by it)
             if (launch4 && on) { lists[2 * n_env + atomicAdd(&counts[6], 1)] = env; pend3[env] = 2; }
             else if (!launch4) t = 3;
         }

@@ -2837,6 +2837,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             if (TIER <= 2) A.s.why[env] = (A.s.why[env] & (TIER == 1 ? 0xff00 : 0x00ff)) | (((overflow >> 16) & 0xff) << (TIER == 1 ? 0 : 8)) | ((it & 0xff) << 16);  // diagnostic: why, and at which substep
             else A.s.why[env] |= ((overflow >> 16) & 0xff) << 24;  // bits 24+: why the large tier handed the env on to tier 4
             __threadfence();
+            if (TIER == 3 && A.cnt4) atomicAdd(A.cnt4, 1);
             if (A.q_next) {  // the next tier's consumers are running beside this launch: straight into their queue
                 const int k = atomicAdd(A.q_next_count, 1);
                 __hip_atomic_store(A.q_next + k, env, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2942,7 +2943,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
 // is a SPARE: it takes one of n_wait seats and waits for the producers' hand-ons until they have all finished; with no seat left it
 // leaves too (with one consumer per expected env and all of them waiting, an overestimate starved the fast tier to the point that the
 // idle consumers ran into their time-out).
-__device__ __forceinline__ int queue_claim(const KernelArgs& A, int& role) {  // lane 0 only; role: 0 undecided, 1 worker, 2 spare
+__device__ __forceinline__ int queue_claim(const KernelArgs& A, int& role, const bool quiet) {  // lane 0 only; role: 0 undecided, 1 worker, 2 spare
     const unsigned long long t0 = wall_clock64();  // 100 MHz
     for (;;) {
         const int f = A.prod_fin ? __hip_atomic_load(A.prod_fin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -2963,7 +2964,9 @@ __device__ __forceinline__ int queue_claim(const KernelArgs& A, int& role) {  //
         // Never wait for ever: if the producers' launch cannot run beside this one (streams that share a hardware queue run in order) the
         // wait would not end.  After 50 ms with nothing to do the consumer leaves; what is handed on later stays flagged for the chained
         // launches, and the host stops starting consumers when it sees the count (DevState::q_abort).
-        if (wall_clock64() - t0 > 5000000ull) { atomicAdd(A.s.q_abort, 1); return -1; }
+        // (quiet: tier 4's consumers -- they wait behind the large tier's, which in a step of the general tier's majority regime may last longer than that
+        //  without anything being wrong; when one leaves, what is handed on later stays flagged for the chained launch as well)
+        if (wall_clock64() - t0 > 5000000ull) { if (!quiet) atomicAdd(A.s.q_abort, 1); return -1; }
         __builtin_amdgcn_s_sleep(64);
     }
 }
@@ -3000,18 +3003,19 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, 
     if (A.started && LANE == 0) atomicAdd(A.started, 1);  // resident: holds its LDS from here on
     // (tier trace, UHC_DEBUG bit 4: the consumer's own record -- entry, first env claimed, exit, envs processed -- in words 8 .. 11 (general
     //  tier) / 12 .. 15 (large tier) of the stage-profile record of env blockIdx.x)
-    long long* tr = ((A.dbg & 16) && (int)blockIdx.x < A.n_env) ? A.s.prof + (size_t)blockIdx.x * UHC_NPROF + 8 + 4 * (TIER - 2) : nullptr;
+    long long* tr = (TIER < 4 && (A.dbg & 16) && (int)blockIdx.x < A.n_env) ? A.s.prof + (size_t)blockIdx.x * UHC_NPROF + 8 + 4 * (TIER - 2) : nullptr;
     if (tr && LANE == 0) { tr[0] = (long long)wall_clock64(); tr[1] = 0; tr[3] = 0; }
     int role = 0;
     for (;;) {
         int env = -1;
-        if (LANE == 0) env = queue_claim(A, role);
+        if (LANE == 0) env = queue_claim(A, role, TIER == 4);
         env = __builtin_amdgcn_readfirstlane(env);
         if (env < 0) break;
         if (tr && LANE == 0) { if (tr[1] == 0) tr[1] = (long long)wall_clock64(); tr[3]++; }
-        // (a large-tier consumer that finds its env too big leaves it flagged, pend3 = 2: the step's chained large-tier launch takes it to tier 4.  Tier 4
-        //  inside the persistent consumer hung the rollout at its first use -- the 619-spill instantiation, never explained; and it would hold a whole
-        //  CU for a 20-40 ms env-step while the queue waits behind it)
+        // (a large-tier consumer that finds its env too big flags it, pend3 = 2, and appends it to TIER 4's OWN queue when that has consumers this step
+        //  (uhc_k_huge_q.hip: this kernel instantiated for tier 4 alone); without them the step's chained large-tier launch takes it to tier 4.  Tier 4
+        //  INLINE in the large tier's persistent consumer hung the rollout at its first use -- the 619-spill instantiation, never explained; and it
+        //  would hold the large tier's queue up for a 10-40 ms env-step)
         uhc_step_env<MODE, TIER, DENSE>(A, d_action, d_tbase, env);
         wsync();
     }
