@@ -3,6 +3,7 @@ slow.  Runs a bench.py rollout (the headline, or a probe by key) on libuhc_amd_p
 (UHC_F_STAGE_PROF) after every step and prints, per stage, the mean over the general-tier envs and the mean over each step's slowest one.
 
   python tools/diag_slowest.py [probe key | headline] [steps] [warmup]
+  SELECT=tier4: the envs whose step went through tier 4 (UHC_F_REDO bit 30) instead of all general / large-tier envs
 """
 import os
 import sys
@@ -47,7 +48,7 @@ def main():
         redo = env.sim.field(S.F_REDO).cpu().numpy()
         nefc = env.sim.field(S.F_NEFC).cpu().numpy()
         top = p[:, :16].sum(1)
-        g = np.nonzero((redo & 1) != 0)[0]
+        g = np.nonzero((redo & (1 << 30)) != 0)[0] if os.environ.get("SELECT") == "tier4" else np.nonzero((redo & 1) != 0)[0]
         if len(g) == 0:
             continue
         e = g[np.argmax(top[g])]
@@ -55,6 +56,8 @@ def main():
         n_all += len(g)
         acc_slow += p[e]
         tot_slow.append(top[e]); tot_all.append(top[g].mean()); tot_fast.append(top[(redo & 1) == 0].mean()); nefc_slow.append(int(nefc[e]))
+        if os.environ.get("SELECT") == "tier4":
+            print(f"  step: {len(g)} envs through tier 4; cycles {sorted(int(x) for x in top[g])}; nefc {[int(nefc[x]) for x in g]}; substeps swept/resumed word {[hex(int(redo[x])) for x in g][:4]}", flush=True)
     agent.rollout_end()
     k = len(tot_slow)
     print(f"{key}: {k} control steps x {n} envs after {warmup} warm-up steps; cycles per env-step in the top-level stages: fast-tier envs {np.mean(tot_fast):.3g}, "
