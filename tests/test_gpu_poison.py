@@ -21,9 +21,16 @@ def test_parity_holds_with_poisoned_lds():
     dbg = ctypes.CDLL(POISON_LIB)
     if any(not hasattr(dbg, sym) for sym in _lib.SYMBOLS) or dbg.uhc_abi_version() != _lib.lib().uhc_abi_version():
         pytest.skip("debug library is older than the sources (python tools/poison_build.py)")
-    env = dict(os.environ, UHC_LIB=POISON_LIB)
+    # ... and with guard words behind every LDS region (UHC_GUARD_LDS=1 + the debug build's -DUHC_GUARD_LDS, round 5): a write past a region's end is
+    # reported on stderr ("uhc guard: ... OVERWRITTEN") by uhc_batch_sync / uhc_batch_free
+    env = dict(os.environ, UHC_LIB=POISON_LIB, UHC_GUARD_LDS="1")
     sel = ["tests/test_gpu_physics.py", "tests/test_gpu_selfcollision.py", "tests/test_gpu_ball.py", "tests/test_gpu_behaviour.py", "tests/test_gpu_env.py",
            "tests/test_gpu_env_objects.py"]
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "--tb=short", "-m", "gpu"] + sel, cwd=ROOT, env=env,
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "--tb=short", "-m", "gpu"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:]
+    assert "uhc guard: LDS guard words on" in r.stdout, "the guard words were not laid out (UHC_GUARD_LDS)"
+    hits = [ln for ln in r.stdout.splitlines() if "OVERWRITTEN" in ln]
+    assert not hits, hits[:5]
+    freed = [ln for ln in r.stdout.splitlines() if ln.startswith("uhc guard: batch of")]
+    print(f"poisoned LDS + guard words: {len(freed)} batches created and freed in {len(sel)} test files, 0 guard words overwritten")

@@ -149,6 +149,8 @@ struct UhcBatch {
     int* tier_now = nullptr;
     bool large_first = false;  // the large tier's consumers are launched (and resident) before the general tier's
     int n_cu = 256;
+    int* d_guard_hits = nullptr;  // UHC_GUARD_LDS=1: the kernels' report (KernelArgs::guard_hits), printed by uhc_batch_sync / uhc_batch_free
+    int guard_reported = 0;
     int* d_order = nullptr;  // launch order of the fast tier under sticky tiers (uhc_tier_lists_kernel)
     int aborts_seen = 0, abort_events = 0;
     long long queues_off_until = 0;
@@ -438,10 +440,19 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     //      body poses, cdof) and ONE region shared by the dynamics temporaries (first half of a forward pass) and the constraint data
     //      (second half).  M itself is parked in registers between substeps (MPark), so no tier keeps a second copy in LDS.
     int off = 0;
-    auto carve = [&](int n) { int o = off; off += (n + 1) & ~1; return o; };
+    // Guard words (debug): with UHC_GUARD_LDS=1 every region carved below is followed by two doubles nobody owns.  A library built
+    // with -DUHC_GUARD_LDS (tools/poison_build.py) fills them with the poison pattern -- the persistent regions' once per env, the constraint
+    // phase's after the dynamics temporaries that overlay them are dead -- and reports any that changed (KernelArgs::guard_hits).  The regions
+    // move by a few doubles; capacities and tiers stay as they are.  MPR's vertex staging, which runs across three regions on purpose, is off.
+    const bool guard_on = getenv("UHC_GUARD_LDS") && getenv("UHC_GUARD_LDS")[0] == '1';
+    std::vector<int> g_persist[4], g_phase2[4];
+    std::vector<int>* grec = nullptr;
+    int gt = 0;  // the layout being carved: 0 fast, 1 general, 2 large, 3 tier 4
+    auto carve = [&](int n) { int o = off; off += (n + 1) & ~1; if (guard_on && grec) { grec->push_back(off); off += 2; } return o; };
+    auto end_guard = [&]() { if (guard_on) { g_phase2[gt].push_back(off); off += 2; } };
     if (T.nM > 64 * 24) { delete b; return fail("uhc_batch_create: nM %d > 1536 (the register tile that carries M between substeps)", T.nM); }
     A.nvp = (nv + 1) & ~1;
-    { const char* dbg = getenv("UHC_DEBUG"); A.dbg = dbg ? atoi(dbg) : 0; }
+    { const char* dbg = getenv("UHC_DEBUG"); A.dbg = dbg ? atoi(dbg) : 0; if (guard_on) A.dbg |= 2; }
     {   // sticky-tier marks: an env goes up a tier when it no longer fits (64 rows / 16 contacts / 12 body-body rows; the general tier's
         // capacities) and comes down again at 56 / 14 / 10 and at 7/8 of the general tier's.  Going up EARLIER (at 3/4 of a capacity, so
         // that no env finds out in mid-step) was measured on the self-colliding rollout: 51-55 k env-steps/s against 57 k -- the envs
@@ -454,6 +465,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     int end1 = 0;
     auto common = [&](DevLds& F, bool fast) {  // persistent part + phase 1; returns the offset where phase 2 starts (fast: with the (row, col) table of M in LDS)
         off = 0;
+        g_persist[gt].clear(); g_phase2[gt].clear(); grec = &g_persist[gt];
         F.qpos = carve(d.nq); F.qvel = carve(nv); F.qacc = carve(nv); F.ctrl = carve(d.nu); F.applied = carve(nv);
         F.bias = carve(nv); F.smooth = carve(nv); F.z = carve(nv); F.dinv = carve(nv); F.sdinv = carve(nv);
         F.zero = carve(2);
@@ -463,6 +475,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.xpos = carve(3 * nb); F.xquat = carve(4 * nb); F.xmat = carve(9 * nb); F.xipos = carve(3 * nb); F.rootcom = carve(3 * nb);
         F.vec = fast ? F.z : carve(nv);  // the working sets accumulate z over islands in vec
         const int base = off;
+        grec = nullptr;  // (phase 1: overlaid by the constraint data, no guards)
         // phase 1
         F.cinert = carve(10 * nb);
         const int r2 = off;
@@ -477,11 +490,13 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.cvel = carve(6 * nb); F.cacc = carve(6 * nb); F.cfrc = carve(6 * nb);         // k_com_vel .. k_rne
         end1 = std::max(std::max(endA, endB), off);
         off = base;
+        grec = &g_phase2[gt];
         return base;
     };
     // ---- fast tier: target 40 KiB per workgroup => 4 workgroups (one per SIMD) per CU
     {
         DevLds& F = A.lf;
+        gt = 0;
         common(F, T.ncpair == 0);  // (the DENSE instantiations read the (row, col) table of M from L2, like the larger tiers: 2.4 KiB for rows)
         // UHC_FAST_DENSE = "KiB,dense rows[,contacts]": the dense fast tier's LDS budget, body-body row slots and contact capacity (experiments)
         int dense_kib = 52, fast_maxcon = UHC_FAST_MAXCON, fast_ndense = UHC_FAST_MAXTWO;
@@ -522,13 +537,14 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         // (52 KiB, not 160 / 3 = 53.3: the LDS is handed out in granules, and 54 608 B rounded up no longer fits three times -- the tier
         //  trace showed 512 of 1 024 workgroups resident, two per CU; 52 KiB is a whole number of every granule up to 4 KiB)
         const int budget = T.ncpair > 0 ? (dense_kib * 1024) / 8 : 40 * 1024 / 8;
-        int ycap = budget - off;
+        int ycap = budget - off - (guard_on ? 2 : 0);
         const int need1 = end1 - off;  // phase 1 may need more than the constraint data
         if (ycap < need1) ycap = need1;
         if (ycap < 8 * YS) ycap = 8 * YS;
         A.cf.ycap = ycap;
         A.cf.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= A.cf.ndense * A.nvp + (dcol_alias ? 0 : A.cf.ndense * UHC_WAVE) + ycap) ? F.dense : -1;  // dense, (dcol,) Y are contiguous
         off += ycap;
+        end_guard();
         F.rowR = F.rowAref = F.rowB = F.rowF = F.rowDa = F.rowW = F.rowY = F.dsc = F.Y;  // unused by the fast kernel
         F.total = off;
         if (A.marks[2] < 0) {  // the marks follow the layout: up at the capacity, down with a little room to spare
@@ -564,12 +580,13 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         F.dsc = carve(cp.ndense * 4);  // (vel, jas, jaw, |Yhat|^2) of every dense row
         F.Y = off;
         const int full = maxefc * YS + 8;
-        int ycap = full_y ? full : std::min(budget_doubles - off, full);
+        int ycap = full_y ? full : std::min(budget_doubles - off - (guard_on ? 2 : 0), full);
         if (!full_y && ycap < 64 * 18) return false;  // too little left for rows: not worth a tier of its own
         if (ycap < end1 - off) ycap = end1 - off;     // (the region also holds the dynamics temporaries of phase 1)
         cp.ycap = ycap & ~1;
         cp.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= cp.ndense * A.nvp + cp.ndense * 4 + cp.ycap) ? F.dense : -1;
         off += cp.ycap;
+        end_guard();
         F.total = off;
         return off <= budget_doubles;
     };
@@ -598,6 +615,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         // MPR's hull vertices: staged where the Hessian will be (nothing of it exists during the collision pass) when they fit
         cp.vstage = ((A.dbg & 2) == 0 && T.ncpair > 0 && 3 * d.nmeshvert <= (nv * (nv + 1)) / 2) ? F.H : -1;
         if (off < end1) off = end1;  // (the region also holds the dynamics temporaries of phase 1)
+        end_guard();
         F.total = off;
         return off <= 160 * 1024 / 8;
     };
@@ -606,6 +624,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         A.last_tier = (tv && tv[0] == '2') ? 2 : 3;
         if (A.last_tier == 3) {  // the large tier: as many rows (<= 256) as a CU's 160 KiB hold at full length
             bool ok = false;
+            gt = 2;
             for (int me = UHC_BIG_MAXEFC; me > UHC_GEN_MAXEFC && !ok; me -= 32) {
                 ok = rows_layout(A.lh, A.ch, me, me / 2, UHC_BIG_MAXTWO, 160 * 1024 / 8, true);
             }
@@ -613,6 +632,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             else A.last_tier = 2;
         }
         const int two_per_cu = 79 * 1024 / 8;
+        gt = 1;
         bool ok = A.last_tier == 3 && rows_layout(A.l, A.cg, UHC_GEN_MAXEFC, UHC_GEN_MAXCON, UHC_GEN_MAXTWO, two_per_cu, false);
         if (!ok) {  // the last tier must hold every row at full length: a whole CU's LDS if need be (32 dense slots as before)
             if (!rows_layout(A.l, A.cg, UHC_GEN_MAXEFC, UHC_GEN_MAXCON, A.last_tier == 2 ? UHC_MAXTWO : UHC_GEN_MAXTWO, 160 * 1024 / 8, true)) {
@@ -623,6 +643,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         A.lx = A.lh; A.cx = A.ch; A.gY = A.gD = nullptr; A.gy_stride = A.gd_stride = 0;
         if (A.last_tier == 3 && !(tv && tv[0] == '3')) {  // (UHC_TIERS=3: the three-tier chain of rounds 3-4, windows and all)
             bool ok4 = false;
+            gt = 3;
             for (int me = UHC_HUGE_MAXEFC; me >= 384 && !ok4; me -= 128) ok4 = huge_layout(A.lx, A.cx, me);
             if (ok4) {
                 A.last_tier = 4;
@@ -631,6 +652,23 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
                 A.gd_stride = std::max(A.cx.ndense, 1) * A.nvp;
             } else { A.lx = A.lh; A.cx = A.ch; }
         }
+    }
+    A.guard_tab = nullptr; A.guard_hits = nullptr;
+    if (guard_on) {
+        std::vector<int> tab(4 * 64, 0);
+        for (int t = 0; t < 4; t++) {
+            if (g_persist[t].size() > 30 || g_phase2[t].size() > 32) { delete b; return fail("uhc_batch_create: UHC_GUARD_LDS: more guard words than the table holds"); }
+            tab[64 * t] = (int)g_persist[t].size(); tab[64 * t + 1] = (int)g_phase2[t].size();
+            for (size_t k = 0; k < g_persist[t].size(); k++) tab[64 * t + 2 + k] = g_persist[t][k];
+            for (size_t k = 0; k < g_phase2[t].size(); k++) tab[64 * t + 32 + k] = g_phase2[t][k];
+        }
+        int* d_tab = nullptr;
+        TRY(dalloc(b, tab.size(), &d_tab)); TRY(dalloc(b, 4, &b->d_guard_hits));
+        HIP_OK(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemset(b->d_guard_hits, 0, 4 * sizeof(int)));
+        A.guard_tab = d_tab; A.guard_hits = b->d_guard_hits;
+        fprintf(stderr, "uhc guard: LDS guard words on -- fast %zu + %zu, general %zu + %zu, large %zu + %zu, tier 4 %zu + %zu (persistent + constraint phase)\n", g_persist[0].size(), g_phase2[0].size(),
+                g_persist[1].size(), g_phase2[1].size(), g_persist[2].size(), g_phase2[2].size(), g_persist[3].size(), g_phase2[3].size());
     }
     // ---- static schedules for the factorisation and the triangular solves (see DevTopo).  Addresses are LDS byte
     //      addresses of the FAST layout's LD buffer (the general kernel adds its own LD offset, KernelArgs::ld_delta).
@@ -756,10 +794,22 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     return 0;
 }
 
+static void guard_report(UhcBatch* b) {  // UHC_GUARD_LDS=1: what the kernels found (once per new finding)
+    if (!b->d_guard_hits) return;
+    int h[4] = {0, 0, 0, 0};
+    if (hipMemcpy(h, b->d_guard_hits, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (h[0] > b->guard_reported) {
+        b->guard_reported = h[0];
+        fprintf(stderr, "uhc guard: %d LDS guard words OVERWRITTEN so far; the first: tier %d, %s region %d (offset %d doubles), env %d\n", h[0], h[1] >> 16,
+                ((h[1] >> 8) & 0xff) ? "constraint-phase" : "persistent", h[1] & 0xff, h[3], h[2]);
+    }
+}
 extern "C" void uhc_batch_free(UhcBatch* b) {
     if (!b) return;
     hipSetDevice(b->device);
     hipDeviceSynchronize();
+    guard_report(b);
+    if (b->d_guard_hits) fprintf(stderr, "uhc guard: batch of %d envs freed, %d guard words overwritten in its lifetime\n", b->n_env, b->guard_reported);
     for (void* p : b->allocs) hipFree(p);
     for (auto& ev : b->ev_used) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& ev : b->ev_free) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -780,6 +830,7 @@ extern "C" int32_t uhc_batch_set_stream(UhcBatch* b, void* s) {
 extern "C" int32_t uhc_batch_sync(UhcBatch* b) {
     if (!b) return fail("uhc_batch_sync: null batch");
     HIP_OK(hipStreamSynchronize(b->stream));
+    guard_report(b);
     return 0;
 }
 extern "C" int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double s) {

@@ -164,6 +164,9 @@ struct KernelArgs {
     int* fin;             // this launch's own exit counter (bumped once per workgroup), or NULL
     int* q_next;          // hand-on target: the next tier's queue (NULL: flag the env in redo / redo2 for a chained launch)
     int* q_next_count;
+    const int* guard_tab;  // debug (UHC_GUARD_LDS=1 at batch creation, a library built with -DUHC_GUARD_LDS): per tier 64 ints -- [0] / [1] number of guard
+                           // words after the persistent / the constraint-phase LDS regions, [2 ..] / [32 ..] their offsets (doubles); NULL otherwise
+    int* guard_hits;       // ... [0] guard words found overwritten, [1] the first one: tier << 16 | kind << 8 | index, [2] its env, [3] its offset
     int* cnt4;            // sticky tiers: bumped once per env the large tier hands on to tier 4 (the host sizes the tier-4 consumers of the next steps by it), or NULL
     int grid;  // workgroups of a list launch (0: one per env)
     int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)

@@ -2376,6 +2376,35 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
 
 // ------------------------------------------------------------------ mj_forward
 struct FwdOut { int ncon, nefc, iters, overflow, nact; };  // nact (tier 4): rows that carry a force at the optimum  // overflow bit 0: the env does not fit this tier => redone by the next one
+// LDS guard words (debug builds, -DUHC_GUARD_LDS on top of -DUHC_POISON_LDS; the host lays them out with UHC_GUARD_LDS=1 -- uhc_capi.cpp): two doubles after
+// every region, holding the poison pattern; kind 0 = after the persistent regions (poisoned once per env with the rest of the LDS), kind 1 = after the
+// regions of the constraint phase (armed when the dynamics temporaries that overlay them are dead, checked when the forward pass returns)
+#define UHC_POISON_BITS 0x7ff8dead7fffbeefll
+template <int TIER>
+__device__ __forceinline__ void guard_arm(const KernelArgs& A, double* S) {
+#ifdef UHC_GUARD_LDS
+    if (!A.guard_tab) return;
+    const int* g = A.guard_tab + 64 * (TIER - 1);
+    wsync();
+    if (LANE < g[1]) { S[g[32 + LANE]] = __longlong_as_double(UHC_POISON_BITS); S[g[32 + LANE] + 1] = __longlong_as_double(UHC_POISON_BITS); }
+    wsync();
+#endif
+}
+template <int TIER>
+__device__ __forceinline__ void guard_check(const KernelArgs& A, const double* S, int env, int kind) {
+#ifdef UHC_GUARD_LDS
+    if (!A.guard_tab) return;
+    const int* g = A.guard_tab + 64 * (TIER - 1);
+    const int* o = g + (kind ? 32 : 2);
+    wsync();
+    if (LANE < g[kind]) {
+        if (__double_as_longlong(S[o[LANE]]) != UHC_POISON_BITS || __double_as_longlong(S[o[LANE] + 1]) != UHC_POISON_BITS) {
+            if (atomicAdd(A.guard_hits, 1) == 0) { A.guard_hits[1] = (TIER << 16) | (kind << 8) | LANE; A.guard_hits[2] = env; A.guard_hits[3] = o[LANE]; }
+        }
+    }
+#endif
+}
+
 template <int TIER, bool DENSE>
 __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP, const int env PROF_ARGS) {
     const DevTopo& T = A.t;
@@ -2395,6 +2424,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
     PROF(6)
     k_smooth<TIER>(A, mb, S, LC);
     PROF(7)
+    guard_arm<TIER>(A, S);
     out.ncon = k_collision<TIER, DENSE>(A, mb, S, &out.overflow, PC PROF_PASS);
     PROF(8)
     out.nefc = k_enumerate_rows<TIER, DENSE>(A, mb, S, out.ncon, &out.overflow);
@@ -2674,7 +2704,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
     const DevLds& L = lds_of<TIER>(A);
     double* S = smem;
 #ifdef UHC_POISON_LDS  // debug builds (tools/poison_build.py): any read of LDS the kernel did not write first meets a NaN / a huge int
-    for (int i = LANE; i < L.total; i += UHC_WAVE) S[i] = __longlong_as_double(0x7ff8dead7fffbeefll);
+    for (int i = LANE; i < L.total; i += UHC_WAVE) S[i] = __longlong_as_double(UHC_POISON_BITS);
     wsync();
 #endif
     const double* mb = A.s.model_blob + (size_t)(A.s.env_model ? A.s.env_model[env] : 0) * A.o.stride;
@@ -2761,6 +2791,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
         if (wave_or(b)) fail = 1;
         else {
             fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP, env PROF_PASS);
+            guard_check<TIER>(A, S, env, 1);
             overflow |= fo.overflow;
             ran = true;
         }
@@ -2789,6 +2820,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             if (wave_or(b)) { fail = 1; break; }
             PROF(0)
             fo = k_forward<TIER, DENSE>(A, mb, S, LC, BC, PC, MP, env PROF_PASS);
+            guard_check<TIER>(A, S, env, 1);
             PROF(13)
             overflow |= fo.overflow;
             if (overflow & 1) break;
@@ -2845,8 +2877,10 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             if (TIER == 1 && MODE == 0) atomicAdd(A.s.path_stats, 1ull);
         }
         TRACE(2 * (TIER - 1) + 1, wall_clock64())
+        guard_check<TIER>(A, S, env, 0);
         return 1;
     }
+    guard_check<TIER>(A, S, env, 0);
     // ---- store state
     for (int i = LANE; i < T.nq; i += UHC_WAVE) A.s.qpos[(size_t)env * T.nq + i] = S[L.qpos + i];
     for (int i = LANE; i < T.nv; i += UHC_WAVE) {
