@@ -605,10 +605,14 @@ def main():
     env.sim.set_timing(True)
     redo0 = agent._ro.redo_counts.clone()  # env-steps the general kernel had to redo: counted on the device by the step's own bookkeeping launch
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    t_half = t0
+    for k in range(args.steps):
+        if k == args.steps // 2:
+            t_half = time.perf_counter()  # (no synchronisation of its own: the host waits for every step's snapshot, so it is never more than one step ahead)
         agent.rollout_step()
     fence()
     elapsed = time.perf_counter() - t0
+    half_ms = (1e3 * (t_half - t0) / max(1, args.steps // 2), 1e3 * (t0 + elapsed - t_half) / max(1, args.steps - args.steps // 2))
     redo_d = (agent._ro.redo_counts - redo0).cpu().tolist()
     kern_total_ms, kern_n = env.sim.kernel_time()
     env.sim.set_timing(False)
@@ -717,6 +721,8 @@ def main():
         out = {
             "metric": "env-steps/sec (69-DoF SMPL humanoid, 15 substeps/step)", "value": n_env * args.steps * world / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "per_rank_env_steps_per_s": per_rank, "steps": args.steps, "warmup": args.warmup, "preroll": args.preroll, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            # steady state: the two halves of the timed region, on rank 0's clock -- a timed region still inside the restart transient shows as a drift
+            "steady_state": {"first_half_ms_per_step": half_ms[0], "second_half_ms_per_step": half_ms[1], "drift": half_ms[1] / half_ms[0] - 1.0 if half_ms[0] > 0 else None},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: copycat rollout step (obs filter, policy MLP 657-2048-1024-512-105 sampling, PD target, fused "
                                    f"physics, termination, reward, obs v2, resets), {n_env} batched envs/GPU, {args.clips} synthetic clips/rank, "

@@ -45,6 +45,23 @@ def test_bench_json_contract():
     assert d["workload_stats"]["nefc_mean"] >= d["floor_only"]["nefc_mean"] - 8  # (the headline's body-body rows add to the floor rows)
 
 
+def test_headline_is_measured_at_steady_state():
+    """with the default pre-roll (40 untimed steps, two episode lengths of the random-init policy) the timed region is past the transient
+    of the common restart: its two halves agree (15 %: 25 steps of a stochastic episode turnover each; inside the transient the first half is 20-40 % off),
+    and the fast tier's HIP-event time per launch is within 35 % of the committed kernel trace (boxes of the pool differ by up to a quarter on the same binary)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-probes", "--no-cpu-baseline", "--no-ppo", "--no-pgs-probe"],
+                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    ss = d["steady_state"]
+    print(f"headline {d['value']:.0f} env-steps/s, {d['ms_per_step']:.2f} ms per step; halves {ss['first_half_ms_per_step']:.2f} / {ss['second_half_ms_per_step']:.2f} ms; "
+          f"kernel {d['roofline']['kernel_ms']:.2f} ms, committed trace {d['roofline'].get('rocprofv3_avg_ms')}")
+    assert d["preroll"] == 40 and abs(ss["drift"]) < 0.15, ss
+    if d["roofline"].get("rocprofv3_avg_ms"):
+        assert abs(d["roofline"]["kernel_ms"] / d["roofline"]["rocprofv3_avg_ms"] - 1.0) < 0.35, d["roofline"]
+
+
+
 def test_bench_two_ranks_over_rccl():
     """Multi-GPU readiness: `bench.py --gpus 2` over RCCL (backend nccl), one rank per GPU -- runs wherever two devices are visible and
     skips on the one-GPU test box.  The gradient all-reduce is then a real xGMI exchange and its bus bandwidth is reported."""

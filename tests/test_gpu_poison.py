@@ -34,3 +34,29 @@ def test_parity_holds_with_poisoned_lds():
     assert not hits, hits[:5]
     freed = [ln for ln in r.stdout.splitlines() if ln.startswith("uhc guard: batch of")]
     print(f"poisoned LDS + guard words: {len(freed)} batches created and freed in {len(sel)} test files, 0 guard words overwritten")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(POISON_LIB), reason="debug library not built (python tools/poison_build.py)")
+def test_guard_words_report_an_overwrite():
+    """The guard mechanism itself: UHC_GUARD_LDS=2 declares the first two doubles of the fast tier's qpos a guard word; the first control step writes
+    them, and uhc_batch_sync must say so -- an overwritten guard word cannot go unnoticed in the run above."""
+    code = ("import numpy as np, torch\n"
+            "from uhc_amd import sim as S\n"
+            "m = S.load_asset_model(); c = S.make_ctrl(m)\n"
+            "z = np.load('uhc_amd/assets/standing_neutral.npz')\n"
+            "b = S.SimBatch(m, c, 4)\n"
+            "b.set_state(torch.from_numpy(np.tile(z['qpos'], (4, 1))), torch.zeros(4, m.nv, dtype=torch.float64))\n"
+            "b.simulate(torch.zeros(4, c.action_dim, dtype=torch.float64, device='cuda'), torch.zeros(4, m.nu, dtype=torch.float64, device='cuda'))\n"
+            "b.sync(); b.close()\n")
+    out = {}
+    for mode in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, UHC_LIB=POISON_LIB, UHC_GUARD_LDS=mode),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        out[mode] = r.stdout
+    if "uhc guard: LDS guard words on" not in out["1"]:
+        pytest.skip("debug library is older than the guard words (python tools/poison_build.py)")
+    assert "OVERWRITTEN" not in out["1"], out["1"][-2000:]
+    assert "OVERWRITTEN" in out["2"] and "tier 1, persistent region" in out["2"], out["2"][-2000:]
+

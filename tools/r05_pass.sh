@@ -5,6 +5,7 @@
 #               gpurun_out/parity200.jsonl and are copied to ${TAG}_parity200.jsonl
 #   occupancy   tools/occupancy_sweep.sh (instrumented library): the fast tier's kernel at 1 / 2 / 3 / 4 workgroups per CU
 #   tests_fast  the GPU suite without the 200-step file (which `parity200` runs)
+#   probes4096  the two ball-joint probes at 4096 envs (efc_overflow must stay 0)
 #   ppo_prof    kernel trace of one PPO update (bench.py --no-probes --no-cpu-baseline --no-pgs-probe with a short rollout): which kernels the update spends its time in
 # every other stage name is handed to tools/r04_pass.sh (tests, loop, bench, prof_headline, prof_floor, prof_configs4, prof_shapes, slowest, stage, meta).
 set -u
@@ -41,6 +42,16 @@ probe_configs4)
   python bench.py --only-probe configs4 > ${O}_probe_configs4.json 2> ${O}_probe_configs4.err
   python bench.py --only-probe ball_rollout > ${O}_probe_ball_rollout.json 2>> ${O}_probe_configs4.err
   cut -c1-1500 ${O}_probe_configs4.json ;;
+probes4096)
+  # no dropped row at 4096 envs either (one repetition of 30 steps after 30: the queues of a general-tier-heavy workload are not tuned at that size)
+  for pr in configs4 ball_rollout; do
+    timeout 600 python bench.py --only-probe $pr --envs 4096 --probe-warmup 30 --probe-steps 30 --probe-reps 1 > ${O}_${pr}_4096.json 2>> ${O}_probe4096.err
+    python - <<P
+import json
+d=json.load(open("${O}_${pr}_4096.json"))
+print("${pr} @4096:", round(d["env_steps_per_s"]), "env-steps/s, ms", round(d["ms_per_step"],1), "overflow", d["efc_overflow_env_steps_all_reps"], "sweeps", d["sweeps_fallback_share_of_env_steps"], "tier4 share", round(d["tier4_primal_newton_share_of_env_steps"],5), "cap", d["tier4_newton_hit_its_cap_env_steps"], "nefc max", d["nefc_max_at_rep_ends"])
+P
+  done ;;
 tests_fast)
   (timeout 1700 python -m pytest tests -m gpu -q --tb=short -rs --deselect tests/test_gpu_parity_200.py 2>&1 | grep -v amdgpu | tail -45) > ${O}_pytest_gpu.txt 2>&1
   tail -4 ${O}_pytest_gpu.txt ;;

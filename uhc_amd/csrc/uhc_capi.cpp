@@ -444,7 +444,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     // with -DUHC_GUARD_LDS (tools/poison_build.py) fills them with the poison pattern -- the persistent regions' once per env, the constraint
     // phase's after the dynamics temporaries that overlay them are dead -- and reports any that changed (KernelArgs::guard_hits).  The regions
     // move by a few doubles; capacities and tiers stay as they are.  MPR's vertex staging, which runs across three regions on purpose, is off.
-    const bool guard_on = getenv("UHC_GUARD_LDS") && getenv("UHC_GUARD_LDS")[0] == '1';
+    const bool guard_selftest = getenv("UHC_GUARD_LDS") && getenv("UHC_GUARD_LDS")[0] == '2';  // (2: one "guard" sits ON qpos of the fast tier -- the report must fire: tests/test_gpu_poison.py)
+    const bool guard_on = guard_selftest || (getenv("UHC_GUARD_LDS") && getenv("UHC_GUARD_LDS")[0] == '1');
     std::vector<int> g_persist[4], g_phase2[4];
     std::vector<int>* grec = nullptr;
     int gt = 0;  // the layout being carved: 0 fast, 1 general, 2 large, 3 tier 4
@@ -656,6 +657,7 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     A.guard_tab = nullptr; A.guard_hits = nullptr;
     if (guard_on) {
         std::vector<int> tab(4 * 64, 0);
+        if (guard_selftest) g_persist[0].push_back(A.lf.qpos);
         for (int t = 0; t < 4; t++) {
             if (g_persist[t].size() > 30 || g_phase2[t].size() > 32) { delete b; return fail("uhc_batch_create: UHC_GUARD_LDS: more guard words than the table holds"); }
             tab[64 * t] = (int)g_persist[t].size(); tab[64 * t + 1] = (int)g_phase2[t].size();
