@@ -45,12 +45,12 @@ prof_headline)
   (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $B > $GRAFT_REPO_ROOT/${O}_bench_under_rocprof.json 2> /tmp/kt.err)
   python tools/rocpd_summary.py /tmp/prof_kt/kt_results.db ${O}_kernel_stats_selfcol.txt "$TAG: rocprofv3 --kernel-trace --stats -- bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-pgs-probe --no-probes (headline: self-colliding model class)" > /dev/null
   P="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-ppo --no-pgs-probe --no-probes"
-  pmc hf "FETCH_SIZE" -- $P;  python tools/pmc_summary.py /tmp/prof_hf/p_results.db ${O}_pmc_FETCH_SIZE_selfcol.txt "$TAG: --pmc FETCH_SIZE, headline (self-colliding model class), 11 control steps of 1024 envs" > /dev/null
+  pmc hf "FETCH_SIZE" -- $P;  python tools/pmc_summary.py /tmp/prof_hf/p_results.db ${O}_pmc_FETCH_SIZE_selfcol.txt "$TAG: --pmc FETCH_SIZE, headline (self-colliding model class), 51 control steps of 1024 envs (40 pre-roll + 3 + 8)" > /dev/null
   pmc hw "WRITE_SIZE" -- $P;  python tools/pmc_summary.py /tmp/prof_hw/p_results.db ${O}_pmc_WRITE_SIZE_selfcol.txt "$TAG: --pmc WRITE_SIZE, headline" > /dev/null
   pmc hv "$VALU" -- $P;       python tools/pmc_summary.py /tmp/prof_hv/p_results.db ${O}_pmc_VALU_F64_selfcol.txt "$TAG: --pmc $VALU, headline" > /dev/null
   pmc hc "$WAVE" -- $P;       python tools/pmc_summary.py /tmp/prof_hc/p_results.db ${O}_pmc_SQ_WAVE_CYCLES_selfcol.txt "$TAG: --pmc $WAVE, headline" > /dev/null
   pmc hl "$LDS" -- $P;        python tools/pmc_summary.py /tmp/prof_hl/p_results.db ${O}_pmc_SQ_INSTS_LDS_selfcol.txt "$TAG: --pmc $LDS, headline" > /dev/null
-  python tools/pmc_alu.py ${O}_alu_headline.json 11264 /tmp/prof_hv/p_results.db /tmp/prof_hf/p_results.db /tmp/prof_hw/p_results.db -- "$TAG: headline (self-colliding model class), bench.py --steps 8 --warmup 3: 11 control steps x 1024 envs"
+  python tools/pmc_alu.py ${O}_alu_headline.json 52224 /tmp/prof_hv/p_results.db /tmp/prof_hf/p_results.db /tmp/prof_hw/p_results.db -- "$TAG: headline (self-colliding model class), bench.py --steps 8 --warmup 3 behind the default 40-step pre-roll: 51 control steps x 1024 envs"
   grep "uhc_step" ${O}_kernel_stats_selfcol.txt | cut -c1-160 ;;
 prof_floor)
   B="python $GRAFT_REPO_ROOT/bench.py --floor-only --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-pgs-probe --no-probes"
@@ -62,7 +62,7 @@ prof_floor)
   pmc fv "$VALU" -- $P;       python tools/pmc_summary.py /tmp/prof_fv/p_results.db ${O}_pmc_VALU_F64.txt "$TAG: --pmc $VALU, --floor-only" > /dev/null
   pmc fc "$WAVE" -- $P;       python tools/pmc_summary.py /tmp/prof_fc/p_results.db ${O}_pmc_SQ_WAVE_CYCLES.txt "$TAG: --pmc $WAVE, --floor-only" > /dev/null
   pmc fl "$LDS" -- $P;        python tools/pmc_summary.py /tmp/prof_fl/p_results.db ${O}_pmc_SQ_INSTS_LDS.txt "$TAG: --pmc $LDS, --floor-only" > /dev/null
-  python tools/pmc_alu.py ${O}_alu_floor_only.json 11264 /tmp/prof_fv/p_results.db /tmp/prof_ff/p_results.db /tmp/prof_fw/p_results.db -- "$TAG: --floor-only, 11 control steps x 1024 envs"
+  python tools/pmc_alu.py ${O}_alu_floor_only.json 52224 /tmp/prof_fv/p_results.db /tmp/prof_ff/p_results.db /tmp/prof_fw/p_results.db -- "$TAG: --floor-only, 51 control steps x 1024 envs (40-step pre-roll + 3 + 8)"
   grep "uhc_step" ${O}_kernel_stats.txt | cut -c1-160 ;;
 prof_configs4|prof_shapes)
   if [ $stage = prof_shapes ]; then WL="shapes"; else WL="configs4 ball_rollout"; fi
