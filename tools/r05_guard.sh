@@ -10,6 +10,7 @@ export UHC_LIB=$PWD/uhc_amd/csrc/libuhc_amd_poison.so UHC_GUARD_LDS=1
 timeout 900 python -m pytest tests/test_gpu_agent.py tests/test_gpu_env_objects.py tests/test_gpu_selfcollision.py tests/test_gpu_ball.py -m gpu -q -s --tb=short > /tmp/guard_suite.txt 2>&1
 echo "agent-level + objects + self-collision + ball-joint tests on the debug library: $(tail -1 /tmp/guard_suite.txt)" >> $O
 echo "  batches created with guard words: $(grep -c 'uhc guard: LDS guard words on' /tmp/guard_suite.txt); freed: $(grep -c 'uhc guard: batch of' /tmp/guard_suite.txt); lines reporting an overwritten guard word: $(grep -c OVERWRITTEN /tmp/guard_suite.txt)" >> $O
+echo "  fenced HBM arrays: $(grep 'fenced HBM arrays checked' /tmp/guard_suite.txt | awk '{n+=$3; b+=$8} END {print n " checked over all batches, " b " with an overwritten fence"}')" >> $O
 grep -m3 "uhc guard: LDS guard words on" /tmp/guard_suite.txt | sort -u >> $O
 grep -m5 OVERWRITTEN /tmp/guard_suite.txt >> $O
 grep -i "failed\|error" /tmp/guard_suite.txt | head -5 >> $O

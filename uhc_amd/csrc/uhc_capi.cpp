@@ -149,6 +149,7 @@ struct UhcBatch {
     int* tier_now = nullptr;
     bool large_first = false;  // the large tier's consumers are launched (and resident) before the general tier's
     int n_cu = 256;
+    std::vector<std::pair<char*, size_t>> fences;  // UHC_GUARD_LDS=1: (base, payload bytes) of every fenced device array
     int* d_guard_hits = nullptr;  // UHC_GUARD_LDS=1: the kernels' report (KernelArgs::guard_hits), printed by uhc_batch_sync / uhc_batch_free
     int guard_reported = 0;
     int* d_order = nullptr;  // launch order of the fast tier under sticky tiers (uhc_tier_lists_kernel)
@@ -186,11 +187,28 @@ static int upload(UhcBatch* b, const std::vector<T>& h, const T** dptr) {
     *dptr = (const T*)p;
     return 0;
 }
+// UHC_GUARD_LDS=1 (debug, with the guard words in LDS): every zero-initialised device array of a batch -- the state the kernels WRITE -- sits between two
+// 256-byte fences of 0xA5; uhc_batch_free checks them ("uhc guard: ... HBM ...")
+static bool hbm_guard_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UHC_GUARD_LDS"); v = (e && (e[0] == '1' || e[0] == '2')) ? 1 : 0; }
+    return v == 1;
+}
 template <class T>
 static int dalloc(UhcBatch* b, size_t n, T** dptr) {
     void* p = nullptr;
-    HIP_OK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
-    HIP_OK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (hbm_guard_on()) {
+        HIP_OK(hipMalloc(&p, bytes + 512));
+        HIP_OK(hipMemset(p, 0xA5, bytes + 512));
+        HIP_OK(hipMemset((char*)p + 256, 0, bytes));
+        b->allocs.push_back(p);
+        b->fences.push_back({(char*)p, bytes});
+        *dptr = (T*)((char*)p + 256);
+        return 0;
+    }
+    HIP_OK(hipMalloc(&p, bytes));
+    HIP_OK(hipMemset(p, 0, bytes));
     b->allocs.push_back(p);
     *dptr = (T*)p;
     return 0;
@@ -811,6 +829,18 @@ extern "C" void uhc_batch_free(UhcBatch* b) {
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     guard_report(b);
+    if (!b->fences.empty()) {
+        int bad = 0;
+        unsigned char h[512];
+        for (size_t k = 0; k < b->fences.size(); k++) {
+            const auto& f = b->fences[k];
+            bool hit = false;
+            if (hipMemcpy(h, f.first, 256, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h + 256, f.first + 256 + f.second, 256, hipMemcpyDeviceToHost) != hipSuccess) continue;
+            for (int i = 0; i < 512; i++) hit = hit || h[i] != 0xA5;
+            if (hit) { if (!bad) fprintf(stderr, "uhc guard: HBM array %zu (%zu bytes) has an OVERWRITTEN fence\n", k, f.second); bad++; }
+        }
+        fprintf(stderr, "uhc guard: %zu fenced HBM arrays checked, %d with an overwritten fence\n", b->fences.size(), bad);
+    }
     if (b->d_guard_hits) fprintf(stderr, "uhc guard: batch of %d envs freed, %d guard words overwritten in its lifetime\n", b->n_env, b->guard_reported);
     for (void* p : b->allocs) hipFree(p);
     for (auto& ev : b->ev_used) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
