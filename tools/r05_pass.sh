@@ -5,6 +5,7 @@
 #               gpurun_out/parity200.jsonl and are copied to ${TAG}_parity200.jsonl
 #   occupancy   tools/occupancy_sweep.sh (instrumented library): the fast tier's kernel at 1 / 2 / 3 / 4 workgroups per CU
 #   tests_fast  the GPU suite without the 200-step file (which `parity200` runs)
+#   soak        long synchronised rollouts of configs4 / ball_rollout / shapes (+ configs4 at 4096 envs): tier-4 env-steps, cap hits, dropped rows, step times
 #   probes4096  the two ball-joint probes at 4096 envs (efc_overflow must stay 0)
 #   ppo_prof    kernel trace of one PPO update (bench.py --no-probes --no-cpu-baseline --no-pgs-probe with a short rollout): which kernels the update spends its time in
 # every other stage name is handed to tools/r04_pass.sh (tests, loop, bench, prof_headline, prof_floor, prof_configs4, prof_shapes, slowest, stage, meta).
@@ -42,6 +43,18 @@ probe_configs4)
   python bench.py --only-probe configs4 > ${O}_probe_configs4.json 2> ${O}_probe_configs4.err
   python bench.py --only-probe ball_rollout > ${O}_probe_ball_rollout.json 2>> ${O}_probe_configs4.err
   cut -c1-1500 ${O}_probe_configs4.json ;;
+soak)
+  # stability of the tier chain with tier 4 and its consumers: long rollouts, every step synchronised (tools/diag_tier4_rollout.py SUMMARY=1)
+  : > ${O}_soak.txt
+  for w in configs4 ball_rollout; do  # (what tier 4 holds on these models: one line of the library's own log)
+    (UHC_DEBUG=64 timeout 200 python tools/diag_tier4_rollout.py $w 64 2 2>&1 | grep "uhc tier 4" | sort -u | sed "s/^/$w: /") >> ${O}_soak.txt
+  done
+  for spec in "configs4 1024 1500" "ball_rollout 1024 1000" "shapes 1024 400" "configs4 4096 120"; do
+    set -- $spec
+    if [ "${SOAK:-full}" = short ] && [ "$1 $2" != "configs4 1024" ] && [ "$1" != ball_rollout ]; then continue; fi
+    (SUMMARY=1 timeout 600 python tools/diag_tier4_rollout.py $1 $2 $3 2>&1 | grep -v amdgpu | tail -2; echo "rc=$?") >> ${O}_soak.txt
+  done
+  cut -c1-700 ${O}_soak.txt ;;
 probes4096)
   # no dropped row at 4096 envs either (one repetition of 30 steps after 30: the queues of a general-tier-heavy workload are not tuned at that size)
   for pr in configs4 ball_rollout; do

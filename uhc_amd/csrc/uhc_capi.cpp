@@ -614,9 +614,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     //      primal problem (packed lower triangle) in LDS; the Yhat rows themselves -- chain rows packed, body-body rows as dense nv-vectors --
     //      in HBM (KernelArgs::gY / gD, one slice per env, L2-resident while the env's workgroup runs).  Rows: the largest multiple of 128 up
     //      to UHC_HUGE_MAXEFC that the LDS holds (nv 75: 1024; nv 99, the humanoid among four boxes: 768).
-    auto huge_layout = [&](DevLds& F, TierCap& cp, int maxefc) -> bool {
+    auto huge_layout = [&](DevLds& F, TierCap& cp, int maxefc, int maxcon) -> bool {
         common(F, false);
-        cp.maxefc = maxefc; cp.maxcon = UHC_HUGE_MAXCON; cp.ndense = T.ncpair > 0 ? UHC_HUGE_MAXTWO : 0;
+        cp.maxefc = maxefc; cp.maxcon = maxcon; cp.ndense = T.ncpair > 0 ? UHC_HUGE_MAXTWO : 0;
         cp.ld_delta = (F.LD - A.lf.LD) * 8;
         // (after the rows are built the contacts' storage serves the Newton iteration: the dof-chain table, the run of chain rows the wave is adding
         //  to the Hessian, the dense group's D y, the pair table -- uhc_primal.h)
@@ -663,7 +663,22 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         if (A.last_tier == 3 && !(tv && tv[0] == '3')) {  // (UHC_TIERS=3: the three-tier chain of rounds 3-4, windows and all)
             bool ok4 = false;
             gt = 3;
-            for (int me = UHC_HUGE_MAXEFC; me >= 384 && !ok4; me -= 128) ok4 = huge_layout(A.lx, A.cx, me);
+            // Rows and contacts share what the LDS has left beside the Hessian (128 rows = 8.7 KB = 45 contacts).  A contact brings at most four rows, a
+            // body-body contact one; the extremes seen in 2.5 M env-steps of the ball-joint rollouts are 504 rows with 192+ contacts (2.6 rows per
+            // contact) -- and 4 of those env-steps met a fixed 192-contact cap with 768 rows allotted.  So: for every row count that fits (multiples of
+            // 128), the most contacts that fit beside it (>= UHC_HUGE_MAXCON, <= UHC_HUGE_MAXCON_MOST); the pair with the largest
+            // min(rows / 2.75, contacts) wins (nv 99, the humanoid among four boxes: 640 rows / 237 contacts instead of 768 / 192).
+            int best_me = 0, best_mc = 0;
+            double best = -1.0;
+            for (int me = UHC_HUGE_MAXEFC; me >= 384; me -= 128) {
+                if (!huge_layout(A.lx, A.cx, me, UHC_HUGE_MAXCON)) continue;
+                int mc = UHC_HUGE_MAXCON_MOST;
+                while (mc > UHC_HUGE_MAXCON && !huge_layout(A.lx, A.cx, me, mc)) mc -= 8;
+                const double score = std::min(me / 2.75, (double)mc);
+                if (score > best) { best = score; best_me = me; best_mc = mc; }
+            }
+            ok4 = best_me > 0 && huge_layout(A.lx, A.cx, best_me, best_mc);
+            if (ok4 && (A.dbg & 64)) fprintf(stderr, "uhc tier 4: %d rows / %d contacts / %d body-body rows, %d B of LDS\n", A.cx.maxefc, A.cx.maxcon, A.cx.ndense, A.lx.total * 8);
             if (ok4) {
                 A.last_tier = 4;
                 b->lds_bytes_big = std::max(b->lds_bytes_big, (size_t)A.lx.total * sizeof(double));

@@ -25,6 +25,7 @@
 #define UHC_MAXTWO 32        // dense-row slots of the largest of the first three tiers (sizes the slot tables of their layouts)
 #define UHC_HUGE_MAXEFC 1024 // tier 4: at most 16 rows per lane; the layout takes the largest multiple of 128 its LDS holds beside the Hessian
 #define UHC_HUGE_MAXCON 192  // (a humanoid of 24 hulls lying among four boxes: <= 4 floor contacts per hull = 112, + body-body contacts)
+#define UHC_HUGE_MAXCON_MOST 320  // ... and up to this many where the LDS has room left beside the rows and the Hessian (uhc_capi.cpp)
 #define UHC_HUGE_MAXTWO 128
 #define UHC_DOF_MAXACT 4
 #define UHC_CON_STRIDE 24
