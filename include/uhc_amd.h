@@ -125,7 +125,7 @@ enum UhcField {
     UHC_F_STAGE_PROF = 15,   /* int64 [n_env][40] per-stage shader-cycle counters (profiling builds only) */
     UHC_F_REDO = 16,         /* int32 [n_env] bit 0: the env's last step / forward pass exceeded the fast tier's capacity (64 rows, 16 contacts, packed
                               * row storage, 12 body-body rows) and was computed by the general tier (128 rows, 64 contacts, 20 body-body rows), the
-                              * large one (256 / 128 / 32; bit 6) or tier 4 (up to 1024 rows / 192 contacts / 128 body-body rows; bits 6 and 30), all of
+                              * large one (256 / 128 / 32; bit 6) or tier 4 (up to 1024 rows / 192-320 contacts / 128 body-body rows, by what the LDS holds beside the Hessian; bits 6 and 30), all of
                               * which solve the problem exactly: working sets of <= 64 rows on the dual QP in the general / large tier; Newton's method
                               * on the primal problem -- the reference's MuJoCo default -- in tier 4, which takes whatever the large tier cannot hold
                               * or whose working sets it cannot finish (an island with more than 64 force-carrying rows).  Bit 30: (part of) the step
@@ -171,7 +171,7 @@ int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
 
 /* Which kernel tier computes a step.  The fused step kernel exists in four tiers: fast (<= 64 constraint rows / 16 contacts / 12
  * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 20; working sets; two workgroups per CU), large
- * (<= 256 / 128 / 32; a whole CU's LDS) and tier 4 (<= 1024 / 192 / 128, rows in HBM, the Hessian of MuJoCo's primal problem in LDS,
+ * (<= 256 / 128 / 32; a whole CU's LDS) and tier 4 (<= 1024 / 192-320 / 128, rows in HBM, the Hessian of MuJoCo's primal problem in LDS,
  * Newton's method -- the reference's default solver, whose cost does not depend on the number of rows).  A tier that cannot hold an env
  * leaves it untouched and hands it to the next one, from the substep that did not fit; tier 4 has no launch of its own (the large
  * tier's workgroup goes on with it).  What exceeds the LAST tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask
