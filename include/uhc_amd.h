@@ -173,8 +173,8 @@ int32_t uhc_batch_set_rfc_scale(UhcBatch* b, double rfc_scale);
  * body-body rows per env; Delassus matrix in registers), general (<= 128 / 64 / 20; working sets; two workgroups per CU), large
  * (<= 256 / 128 / 32; a whole CU's LDS) and tier 4 (<= 1024 / 192-320 / 128, rows in HBM, the Hessian of MuJoCo's primal problem in LDS,
  * Newton's method -- the reference's default solver, whose cost does not depend on the number of rows).  A tier that cannot hold an env
- * leaves it untouched and hands it to the next one, from the substep that did not fit; tier 4 has no launch of its own (the large
- * tier's workgroup goes on with it).  What exceeds the LAST tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask
+ * leaves it untouched and hands it to the next one, from the substep that did not fit; in the chained launches tier 4 has no launch of its own (the large
+ * tier's workgroup goes on with it); under sticky tiers (mode 2) it has queue consumers like the general and the large tier.  What exceeds the LAST tier is dropped and flagged (UHC_F_EFC_OVERFLOW; the reference's models ask
  * MuJoCo for njmax 2500 / nconmax 500, uhc/khrylib/mocap/skeleton_mesh.py:46).  UHC_TIERS=2 | 3 in the environment of uhc_batch_create
  * ends the chain at the general / large tier (rounds 2-4's behaviour, kept for A/B measurements).
  *   0 (default) = chain: the fast tier on every env, then the general tier on the envs it handed on, then the large tier;

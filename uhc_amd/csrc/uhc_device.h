@@ -149,8 +149,9 @@ struct KernelArgs {
     double* gY;  // tier 4: [n_env][gy_stride] packed Yhat rows of the env (L2-resident while its workgroup runs)
     double* gD;  // tier 4: [n_env][gd_stride] dense Yhat rows (slot-major, nvp doubles each)
     int gy_stride, gd_stride;
-    int last_tier;  // 2, 3 or 4: the tier that drops what exceeds it instead of handing the env on.  Tier 4 has no launch of its own: the large
-                    // tier's workgroup goes on with it (same LDS allocation, other carve) when its env does not fit or its working sets give up
+    int last_tier;  // 2, 3 or 4: the tier that drops what exceeds it instead of handing the env on.  In the chained launches tier 4 has no launch of its own: the large
+                    // tier's workgroup goes on with it (same LDS allocation, other carve) when its env does not fit or its working sets give up; under sticky tiers
+                    // it has queue consumers (uhc_k_huge_q.hip) that take what the large tier's consumers hand on
     const int* order;  // launch order: workgroup k works on env order[k] (null: env k)
     int tier_want;  // 0: the launch works on every active env; else (sticky tiers) it leaves out the envs whose tier_now differs AND has its own launch
     int sticky_mask;  // bit t: tier t has its own (list) launch this step

@@ -63,8 +63,8 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
 // envs that begin the step there (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; free slots = -1),
 // the cursors the persistent launches share and the producers' exit counters (fin[1]: fast tier's workgroups, fin[2]: general tier's)
 #define UHC_ORDER_BUCKETS 6
-// (tier 4, `launch4` != 0: the envs whose last step ended in tier 4 get a launch of their own this step -- lists[2 n_env ..), counts[6] -- and are flagged
-//  pend3 = 2, "straight to tier 4"; with launch4 == 0 they are the large tier's like any tier-3 env and the snapshot says 3)
+// (tier 4, `launch4` != 0: tier 4's queue consumers run this step; the envs whose last step ended in tier 4 (UHC_DEBUG bit 12 only) head their queue -- lists[2 n_env ..),
+//  counts[6] -- and are flagged pend3 = 2, "straight to tier 4"; with launch4 == 0 they are the large tier's like any tier-3 env and the snapshot says 3)
 __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
                                       const int* cost, const int* fresh, int* order, int launch4, int* pend3) {
     __shared__ int nb[UHC_ORDER_BUCKETS + 1];

@@ -2943,11 +2943,10 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             else if (TIER == 2) next = (up3 && big == 3) ? 3 : (dn1 ? 1 : 2);
             else next = !dn2 ? 3 : (dn1 ? 1 : 2);
             // an env that needed tier 4 (beyond the large tier's capacities, or more force-carrying rows than its working sets finish) starts its next
-            // step THERE: a launch of its own from the head of the step (uhc_capi.cpp) instead of an abandoned large-tier attempt and a place at the
-            // step's very end.  It comes down with room to spare: 3/4 of the large tier's capacities and <= 48 rows with a force.
+            // step THERE: at the head of the queue of tier 4's consumers (uhc_capi.cpp) instead of an abandoned large-tier attempt first.  It comes down with room to spare: 3/4 of the large tier's capacities and <= 48 rows with a force.
             // OPT-IN (UHC_DEBUG bit 12): measured on the random-policy ball-joint rollouts it LOSES -- configs[4] 41.6 k -> 27.1 k env-steps/s: the envs that
-            // reach tier 4 there are diverging ones that reset within two or three steps, a reset env then runs its first step in tier 4 too, and the
-            // whole-CU workgroups at the head of the step take CUs from the fast tier -- so by default such an env starts its next step in the large tier.
+            // reach tier 4 there are diverging ones that reset within two or three steps, a reset env then runs its first step in tier 4 too, and a whole step of
+            // primal solves costs more than the large-tier attempt it saves -- so by default such an env starts its next step in the large tier.
             if (TIER == 4 && (A.dbg & 4096) && A.last_tier == 4 && !(pk_nefc <= (3 * A.ch.maxefc) / 4 && pk_ncon <= (3 * A.ch.maxcon) / 4 && pk_ntwo <= (3 * A.ch.ndense) / 4 && pk_act <= 48)) next = 4;
             A.s.tier[env] = next;
             A.s.cost[env] = max(pk_nefc, max((pk_ncon * UHC_FAST_MAXEFC) / max(A.cf.maxcon, 1), (pk_ntwo * UHC_FAST_MAXEFC) / max(A.cf.ndense, 1)));
