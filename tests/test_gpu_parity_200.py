@@ -70,7 +70,7 @@ def _class(name, model, standing):
     return ball, ctrl, q, v, 0.003, np.zeros((n, 69))  # (x a_scale x 100: torques of a few N m; the hands weigh 0.4 kg)
 
 
-def _run(name, model, standing, mode, handover, steps=N_STEPS, act_scale=None, seed=7, resync=False):
+def _run(name, model, standing, mode, handover, steps=N_STEPS, act_scale=None, seed=7, resync=False, restart_failed=False):
     import torch
     from oracle.physics import OracleSim
     from uhc_amd import sim as S
@@ -97,6 +97,7 @@ def _run(name, model, standing, mode, handover, steps=N_STEPS, act_scale=None, s
     rng = np.random.default_rng(seed)
     err = np.zeros((steps, n))
     ties = []  # resync runs: steps at which the contact model itself is discontinuous (see below)
+    failed = []  # restart_failed runs: (env, step) of every bad-value flag, device and oracle
     where = np.zeros((steps, n), dtype=int)  # the qpos coordinate that carries the step's largest position error
     info = []
     for t in range(steps):
@@ -112,24 +113,44 @@ def _run(name, model, standing, mode, handover, steps=N_STEPS, act_scale=None, s
                 os_[e].set_state(prev[0][e], prev[1][e])
             os_[e].do_simulation(act[e], tb[e], redo=redo[e] if handover else 0)
             dq = np.abs(gq[e] - os_[e].get("qpos"))
-            err[t, e] = max(dq.max(), np.abs(gv[e] - os_[e].get("qvel")).max())
+            dv = np.abs(gv[e] - os_[e].get("qvel"))
+            if restart_failed:  # saturated random torques spin limbs up to 1e3-1e5 rad/s before the bad-value flag ends the episode: the error is taken
+                dv = dv / np.maximum(1.0, np.abs(os_[e].get("qvel")))  # relative to the coordinate's size there (absolute wherever |qvel| <= 1)
+            err[t, e] = max(dq.max(), dv.max())
             where[t, e] = int(dq.argmax())
+            if restart_failed and (fail[e] or os_[e].geti("fail")):
+                # a simulation that blew up (mj_checkPos / checkVel / checkAcc -> `fail`, uhc/envs/humanoid_im.py:1207-1211): both sides must say so in the
+                # same control step; the env is put back to its start state below, as the env layer's reset would
+                failed.append(dict(env=e, step=t, device=int(fail[e]), oracle=int(os_[e].geti("fail"))))
+                err[t, e] = 0.0
+                continue
             if resync and err[t, e] > 1e-7:
                 # one control step from the SAME state, and still apart: either a defect, or a step at which the model itself is discontinuous -- a
                 # support query or MPR's portal choosing between vertices that tie to the last bit (a box flat on the floor, face on face).  The
                 # checker decides which: the oracle against itself, started 1e-15 away from that state.  If ITS answer moves by more than 1e-8 in
-                # that one step, the step is a discontinuity of the (MuJoCo-restated) contact model and rounding picks the branch.
-                sens = 0.0
-                for sign in (1.0, -1.0):
+                # that one step, the step is a discontinuity of the (MuJoCo-restated) contact model and rounding picks the branch -- and the device must
+                # then have landed ON one of the oracle's own branches (or, with several ties at once, inside their spread): err becomes the distance
+                # to the nearest branch found, which the tests bound like every other step's error.
+                sens, near = 0.0, float(err[t, e])
+                pert = [s_ * 1e-15 * np.cos(k_ * np.arange(prev[0][e].shape[0] - 7)) for k_ in (1, 2, 3) for s_ in (1.0, -1.0)]
+                for dp in pert:
                     pq = prev[0][e].copy()
-                    pq[7:] += sign * 1e-15 * np.cos(np.arange(pq.shape[0] - 7))
+                    pq[7:] += dp
                     twin = OracleSim(m, ctrl)
                     twin.set_state(pq, prev[1][e])
                     twin.do_simulation(act[e], tb[e])
                     sens = max(sens, np.abs(twin.get("qpos") - os_[e].get("qpos")).max(), np.abs(twin.get("qvel") - os_[e].get("qvel")).max())
-                ties.append(dict(env=e, step=t, err=float(err[t, e]), oracle_self_sensitivity=float(sens), coordinate=int(where[t, e])))
+                    near = min(near, max(np.abs(gq[e] - twin.get("qpos")).max(), np.abs(gv[e] - twin.get("qvel")).max()))
+                ties.append(dict(env=e, step=t, err=float(err[t, e]), oracle_self_sensitivity=float(sens), err_to_nearest_oracle_branch=float(near), coordinate=int(where[t, e]),
+                                 rows=int(nefc[e])))
                 if sens > 1e-8:
-                    err[t, e] = 0.0  # (accounted for in rep["ties"]; not a parity failure)
+                    err[t, e] = near if near < 1e-7 else min(float(err[t, e]), near)  # (a tie the device resolved like one of the oracle's branches counts as that branch's error)
+        if restart_failed and fail.any():
+            ids = np.nonzero(fail)[0]
+            b.set_state(torch.from_numpy(q0[ids]), torch.from_numpy(v0[ids]), torch.from_numpy(ids.astype(np.int32)))
+            b.sync()
+            for e in ids:
+                os_[e].set_state(q0[e], v0[e])
         info.append(dict(redo=redo.copy(), ncon=ncon.copy(), nefc=nefc.copy(), fail=fail.copy(),
                          o_ncon=np.array([o.geti("ncon") for o in os_]), o_nefc=np.array([o.geti("nefc") for o in os_]),
                          o_fail=np.array([o.geti("fail") for o in os_])))
@@ -139,7 +160,8 @@ def _run(name, model, standing, mode, handover, steps=N_STEPS, act_scale=None, s
                worst_first_50=float(np.nanmax(err[:50])), nefc_max=int(max(i["nefc"].max() for i in info)), ncon_max=int(max(i["ncon"].max() for i in info)),
                env_steps_general_or_large=int(sum((i["redo"] & 1).sum() for i in info)), env_steps_large=int(sum(((i["redo"] & 0x40) != 0).sum() for i in info)),
                env_steps_swept=int(sum(((i["redo"] & 2) != 0).sum() for i in info)), env_steps_windowed=int(sum(((i["redo"] & 8) != 0).sum() for i in info)),
-               env_steps_rows_dropped=int(sum(((i["redo"] & 0x80) != 0).sum() for i in info)), ties=ties, leaves=[])
+               env_steps_rows_dropped=int(sum(((i["redo"] & 0x80) != 0).sum() for i in info)), ties=ties, failed=failed,
+               env_steps_primal_by_rows=[int(x) for i in info for x in i["nefc"][(i["redo"] & (1 << 30)) != 0]], leaves=[])
     for e in range(n):
         bad = np.nonzero(~(err[:, e] < TOL))[0]
         if bad.size == 0:
@@ -202,7 +224,9 @@ def test_200_steps_of_the_ball_joint_classes(model, standing, name, mode):
     # every control step within 1e-7 (qvel carries the step's largest error: 1e-9 in qpos), except steps the oracle itself marks as discontinuities of the
     # contact model (rep["ties"]: its own answer moves by > 1e-8 under a 1e-15 perturbation of the start state) -- a handful per 800 env-steps
     assert step["worst"] < 1e-7 and not step["leaves"], step
-    assert all(t["oracle_self_sensitivity"] > 1e-8 for t in step["ties"]) and len(step["ties"]) <= 40, step["ties"]
+    # (round 6: a tie is no longer written off -- its error is the distance to the nearest branch the oracle itself takes under 1e-15 perturbations, bounded
+    #  by `worst` above like every other step; what is left to bound here is how many there are, and that each really is a discontinuity of the checker)
+    assert all(t["oracle_self_sensitivity"] > 1e-8 and t["err_to_nearest_oracle_branch"] <= max(1e-7, 2 * t["oracle_self_sensitivity"]) for t in step["ties"]) and len(step["ties"]) <= 40, step["ties"]
 
 
 @pytest.mark.parametrize("name", ["ball", "ball_objects"])
@@ -216,3 +240,19 @@ def test_ball_joint_rollout_at_policy_scale_torques_reports_where_it_leaves(mode
     assert rep["env_steps_rows_dropped"] == 0 and rep["env_steps_swept"] == 0, rep
     first = min([l["step"] for l in rep["leaves"]] + [60])
     assert first >= 10, rep
+
+
+@pytest.mark.parametrize("name", ["ball", "ball_objects"])
+def test_ball_joint_rollout_at_policy_scale_torques_step_by_step(model, standing, name):
+    """VERDICT r5 "next" 4: parity evidence at the action scale bench.py's `ball_rollout` / `configs4` probes run (sigma 0.1: every motor saturated,
+    `torque = ctrl * a_scale * 100` clipped, uhc/envs/humanoid_im.py:1158-1160), not only for the first ten steps of a free run.  60 control steps through the
+    sticky queues, the oracle re-started from the device's state before every step: every control step within 1e-7, hundreds of rows through tier 4
+    (Newton on the primal, the four-wave consumers when the host has started them); an env whose simulation blows up raises `fail` on BOTH sides in the
+    same step, is left out of that step's error and restarted (as the env layer's reset does).  No rows dropped, no sweeps, Newton never at its cap."""
+    rep = _run(name, model, standing, "sticky", False, steps=60, act_scale=0.1, seed=9, resync=True, restart_failed=True)
+    assert rep["env_steps_rows_dropped"] == 0 and rep["env_steps_swept"] == 0 and rep["env_steps_primal_cap"] == 0, rep
+    assert all(f["device"] == 1 and f["oracle"] == 1 for f in rep["failed"]), rep["failed"]
+    assert rep["worst"] < 1e-7 and not rep["leaves"], rep
+    assert all(t["oracle_self_sensitivity"] > 1e-8 and t["err_to_nearest_oracle_branch"] <= max(1e-7, 2 * t["oracle_self_sensitivity"]) for t in rep["ties"]) and len(rep["ties"]) <= 12, rep["ties"]
+    # the point of the test: tier 4 did the work, on hundreds of rows
+    assert rep["env_steps_primal"] >= 20 and max(rep["env_steps_primal_by_rows"] + [0]) >= 300, (rep["env_steps_primal"], rep["nefc_max"])

@@ -67,6 +67,33 @@ def test_policy_value_ppo_loss_and_grads_match_reference():
     assert n_pol == 4024530  # policy parameter count at 657 -> 105
 
 
+@pytest.mark.parametrize("branch", ["full", "mini"])
+def test_ppo_update_policy_matches_the_reference_update(branch):
+    """Fixture G8b: the reference's own AgentPPO.update_policy (uhc/khrylib/rl/agents/agent_ppo.py:16-51) run end to end -- three epochs of the full-batch
+    branch and of the mini-batch branch (:23-43; numpy's global generator shuffles, the permutations compose, the ragged tail is dropped): parameters of both
+    nets after the update."""
+    g = np.load(os.path.join(G, "g8b_ppo_update.npz"))
+    pol, val = _nets(17, 6, (24, 12))
+    pol.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("pol0_")})
+    val.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("val0_")})
+    from uhc_amd.khrylib.rl.agents import AgentPPO
+    opt_p = torch.optim.Adam([p for p in pol.parameters() if p.requires_grad], lr=float(g["policy_lr"]))
+    opt_v = torch.optim.Adam(val.parameters(), lr=float(g["value_lr"]))
+    ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None,
+                  optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=int(g["epochs"]), value_opt_niter=1, clip_epsilon=float(g["clip_epsilon"]),
+                  mini_batch_size=int(g["mini_batch_size"]), use_mini_batch=branch == "mini", policy_grad_clip=[(list(pol.parameters()), float(g["grad_clip"]))])
+    np.random.seed(int(g["np_seed"]))
+    ag.update_policy(*(torch.from_numpy(g[k]).clone() for k in ("x", "a", "rets", "advs", "exps")))
+    moved = 0.0
+    for n, p in pol.named_parameters():
+        np.testing.assert_allclose(p.detach().numpy(), g[f"pol_{branch}_" + n], atol=1e-12, err_msg=n)
+        moved = max(moved, float(np.abs(g[f"pol_{branch}_" + n] - g["pol0_" + n]).max()))
+    for n, p in val.named_parameters():
+        np.testing.assert_allclose(p.detach().numpy(), g[f"val_{branch}_" + n], atol=1e-12, err_msg=n)
+    assert moved > 1e-3  # (the update did something)
+    assert len(ag.last_losses) == (3 if branch == "full" else 3 * (70 // 16))
+
+
 def test_policy_mcp_matches_reference():
     from uhc_amd.models.policy_mcp import PolicyMCP
 

@@ -59,7 +59,9 @@ if prof:
     p = b.field(S.F_STAGE_PROF).cpu().numpy().astype(np.float64) / steps
     names = {0: "pd+rfc / torque", 1: "kinematics", 2: "com_pos", 3: "crb", 4: "factor", 5: "com_vel", 6: "rne", 7: "smooth", 8: "collision", 9: "rows (to HBM)",
              11: "solve: rest", 13: "qacc", 14: "euler", 15: "store", 30: "newton: start point (u0, jar0, cost)", 31: "newton: jar, gradient, Hessian build", 26: "newton: Cholesky",
-             27: "newton: substitutions", 28: "newton: p = Yhat dir, line search", 32: "col: plane-mesh", 33: "col: cull", 34: "col: staging", 35: "col: MPR"}
+             27: "newton: substitutions", 28: "newton: p = Yhat dir, line search", 32: "col: plane-mesh", 33: "col: cull", 34: "col: staging", 35: "col: MPR",
+             36: "newton: jar = Yhat u + b", 37: "newton: active set + rank-one updates", 38: "newton: chain rows -> gradient (+ Hessian)", 39: "newton: dense rows -> gradient + Hessian"}
+    names[31] = "newton: gradient norm / rest"
     tot = p.sum(1)
     print(f"instrumented: mean cycles per env-step {tot.mean():.3e} (all tiers' work on the env, the large tier's abandoned passes included)")
     for k in sorted(names):

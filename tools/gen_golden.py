@@ -378,6 +378,47 @@ def g7_g8_learner():
     save("g8_ppo_small", **arrs)
 
 
+def g8b_ppo_update():
+    """The reference's own AgentPPO.update_policy (uhc/khrylib/rl/agents/agent_ppo.py:16-51) run end to end on a small actor-critic: three optimisation
+    epochs of the full-batch branch and of the MINI-BATCH branch (`use_mini_batch`, :23-43: numpy-global-RNG permutation per epoch, applied cumulatively;
+    floor(N / mini_batch_size) Adam steps of value and policy each) -- start parameters, inputs and the parameters after the update."""
+    from uhc.khrylib.rl.agents.agent_ppo import AgentPPO
+    from uhc.khrylib.rl.core.policy_gaussian import PolicyGaussian
+    from uhc.khrylib.rl.core.critic import Value
+    from uhc.khrylib.models.mlp import MLP
+    rng = np.random.default_rng(808)
+    sd, ad, N = 17, 6, 70
+    x = torch.from_numpy(rng.normal(size=(N, sd)))
+    a = torch.from_numpy(rng.normal(scale=0.2, size=(N, ad)))
+    advs = torch.from_numpy(rng.normal(size=(N, 1)))
+    rets = torch.from_numpy(rng.normal(size=(N, 1)))
+    exps = torch.from_numpy((rng.uniform(size=N) > 0.2).astype(np.float64))
+    arrs = dict(x=x.numpy(), a=a.numpy(), advs=advs.numpy(), rets=rets.numpy(), exps=exps.numpy(), mini_batch_size=16, epochs=3, np_seed=33,
+                policy_lr=5e-3, value_lr=3e-3, clip_epsilon=0.2, grad_clip=0.5)
+    for tag, mini in (("full", False), ("mini", True)):
+        torch.manual_seed(21)
+        pcfg = types.SimpleNamespace(policy_hsize=(24, 12), policy_htype="gelu", fix_std=True, log_std=-2.3)
+        pol = PolicyGaussian(pcfg, action_dim=ad, state_dim=sd)
+        val = Value(MLP(sd, (24, 12), "gelu"))
+        if not mini:
+            for n, p in pol.named_parameters():
+                arrs["pol0_" + n] = p.detach().numpy().copy()
+            for n, p in val.named_parameters():
+                arrs["val0_" + n] = p.detach().numpy().copy()
+        opt_p = torch.optim.Adam([p for p in pol.parameters() if p.requires_grad], lr=5e-3)
+        opt_v = torch.optim.Adam(val.parameters(), lr=3e-3)
+        ag = AgentPPO(env=None, policy_net=pol, value_net=val, dtype=torch.float64, device=torch.device("cpu"), gamma=0.95, data_loader=None,
+                      optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=3, value_opt_niter=1, clip_epsilon=0.2, mini_batch_size=16, use_mini_batch=mini,
+                      policy_grad_clip=[(list(pol.parameters()), 0.5)])  # (a LIST here: the generator quirk of agent_copycat.py is pinned elsewhere)
+        np.random.seed(33)
+        ag.update_policy(x.clone(), a.clone(), rets.clone(), advs.clone(), exps.clone())
+        for n, p in pol.named_parameters():
+            arrs[f"pol_{tag}_" + n] = p.detach().numpy().copy()
+        for n, p in val.named_parameters():
+            arrs[f"val_{tag}_" + n] = p.detach().numpy().copy()
+    save("g8b_ppo_update", **arrs)
+
+
 def g12_policy_mcp():
     """PolicyMCP (uhc/models/policy_mcp.py:9-37) at reduced width: parameters, mean, log-prob and gradients."""
     from uhc.models.policy_mcp import PolicyMCP
@@ -621,6 +662,11 @@ def g14_ball_env():
 
 
 def main():
+    if len(sys.argv) > 1:  # python tools/gen_golden.py g8b_ppo_update ...: only the named fixtures (the others are not rewritten)
+        for name in sys.argv[1:]:
+            globals()[name]()
+        return
+    g8b_ppo_update()
     g14_ball_env()
     g1_math()
     dm, qpos, feat = g2_g3_expert()

@@ -13,7 +13,9 @@ NAMES = ["pd+rfc", "kinematics", "com_pos", "crb", "factor", "com_vel", "rne", "
          "pgs-sweeps", "z+rest/pgs-general", "qacc-solve", "euler", "store",
          "pd: M->LD + gains", "pd: factor", "pd: solve", "kin: pass 1 (local poses)", "kin: pass 2 (levels)", "crb: subtree sums", "crb: I*cdof",
          "rne: levels", "pd: M -> LD", "as: W load (+loop tail)", "as: elimination", "as: back substitution", "as: y = A f + b", "as: pre-sweeps", "ws: islands + compaction + row load", "ws: y on the other rows",
-         "col: plane-mesh pairs", "col: convex pairs sphere cull", "col: vertex staging", "col: MPR"]
+         "col: plane-mesh pairs", "col: convex pairs sphere cull", "col: vertex staging", "col: MPR",
+         "t4: jar = Yhat u + b", "t4: active set + rank-one updates", "t4: chain rows -> gradient (+ Hessian)", "t4: dense rows -> gradient + Hessian"]
+# (tier 4 reuses the slots of the dual solver's stages: 26 = Cholesky, 27 = substitutions, 28 = p = Yhat dir + line search, 30 = start point, 31 = gradient norm / rest)
 
 
 def build():

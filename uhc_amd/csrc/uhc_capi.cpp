@@ -620,8 +620,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         cp.ld_delta = (F.LD - A.lf.LD) * 8;
         // (after the rows are built the contacts' storage serves the Newton iteration: the dof-chain table, the run of chain rows the wave is adding
         //  to the Hessian, the dense group's D y, the pair table -- uhc_primal.h)
-        const int primal_scratch = (nv * YS + 3) / 4 + 1 + 16 * 32 + nv * 8 + 1 + 496 / 4 + 32 + 2;  // table | [16][32] run of rows | [nv][8] dense group | 496 pairs | [2][16] run coefficients
-        F.con = carve(std::max(cp.maxcon * UHC_CON_STRIDE, primal_scratch));
+        const int scratch4 = primal_scratch(nv, YS).total;  // uhc_device.h: table | per-wave runs of rows | dense group | pair tables | run coefficients | mailbox
+        F.con = carve(std::max(cp.maxcon * UHC_CON_STRIDE, scratch4));
         F.dcol = F.con;
         F.rowMisc = carve(std::max(maxefc * 2, 128));  // (the collision pass keeps its candidate-pair list here: 256 ints)
         F.ncon_nefc = carve(2 + (cp.ndense + 1) / 2 + 1);  // ints: truncated flag, nefc, number of two-body rows, spare, their row ids

@@ -127,6 +127,27 @@ struct DevState {  // HBM, env-major
     const double* model_blob;
 };
 
+// Tier 4's Newton iteration (uhc_primal.h) re-uses the contacts' storage once the rows are built: offsets in doubles from DevLds::con, the same on the
+// host (which sizes the region) and in every wave of the workgroup (the helper waves of the four-wave consumer build their own view of it).
+#define UHC_PRIMAL_WAVES 4       // waves of a tier-4 queue consumer (uhc_k_huge_q.hip); the one-workgroup-per-env kernels run the same stages on one wave
+#define UHC_PRIMAL_CLS_STRIDE 144  // entries of one ownership class of the pair table: sum_{q < 32} (q / 4 + 1)
+struct PrimalScratch { int anc, stY, dstage, pair_all, pair_cls, pair_cnt, cw, mbx, total; };
+__host__ __device__ inline PrimalScratch primal_scratch(int nv, int YS) {
+    PrimalScratch p;
+    int o = 0;
+    auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
+    p.anc = take((nv * YS + 3) / 4 + 1);                  // shorts [nv][YS]: the dof chains
+    p.stY = take(UHC_PRIMAL_WAVES * 16 * 32);             // per wave [16][32]: the run of chain rows being added
+    p.dstage = take(nv * 8);                              // [nv][8]: D y of the dense rows being added, dof-major
+    p.pair_all = take(528 / 4);                           // shorts [528]: pair p = q (q + 1) / 2 + q2 -> q << 8 | q2, q2 <= q < 32
+    p.pair_cls = take(4 * UHC_PRIMAL_CLS_STRIDE / 4);     // shorts [4][144]: the same pairs by ownership class q2 & 3, q-major
+    p.pair_cnt = take((4 * 33 + 3) / 4);                  // shorts [4][33]: pairs of a class with q < len
+    p.cw = take(UHC_PRIMAL_WAVES * 32);                   // per wave [2][16]: coefficients and weights of the run
+    p.mbx = take(4);                                      // ints [8]: the command the helper waves read behind the barrier
+    p.total = o;
+    return p;
+}
+
 // capacities of one tier's LDS layout
 struct TierCap {
     int maxefc, maxcon;

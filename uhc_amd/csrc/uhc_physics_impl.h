@@ -16,7 +16,13 @@
 
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
+// UHC_NW4 (uhc_k_huge_q.hip only): the workgroup has four waves -- wave 0 runs everything below as if it were alone, waves 1-3 are helpers of tier 4's
+// Newton iteration (uhc_primal.h) and see nothing else of this file
+#ifdef UHC_NW4
+#define LANE ((int)(threadIdx.x & 63u))
+#else
 #define LANE ((int)threadIdx.x)
+#endif
 // optional per-stage cycle accounting (build with -DUHC_STAGE_PROF; see tools/stage_profile.py)
 #define UHC_NPROF 40  // int64 words per env of the stage-profile record (UHC_F_STAGE_PROF)
 #ifdef UHC_STAGE_PROF
@@ -41,7 +47,17 @@ template <int TIER> __device__ __forceinline__ const TierCap& cap_of(const Kerne
 }
 // does this tier hand an env it cannot hold to the next one (true), or drop the excess and flag it (false)?
 template <int TIER> __device__ __forceinline__ bool hands_on(const KernelArgs& A) { return TIER == 1 ? !A.truncate : TIER < A.last_tier; }
+// wsync: the LANES OF ONE WAVE have exchanged data through LDS (or global memory).  With one wave per workgroup that is __syncthreads() (whose s_barrier the
+// backend drops); in a four-wave workgroup the same fences without the barrier -- the other waves are not coming
+#ifdef UHC_NW4
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#else
 __device__ __forceinline__ void wsync() { __syncthreads(); }
+#endif
 // where a tier keeps its constraint rows: LDS (tiers 1-3), or the env's slice of the HBM row store (tier 4: the LDS is the Hessian's, uhc_primal.h)
 template <int TIER> __device__ __forceinline__ double* y_store(const KernelArgs& A, double* S, int env) {
     if constexpr (TIER == 4) return A.gY + (size_t)env * A.gy_stride; else return S + lds_of<TIER>(A).Y;
@@ -3031,8 +3047,17 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer bookkeeping of the queues
 }
 // (2): its own entry point, so that the one-workgroup-per-env kernels keep the register allocation of a straight-line body
+#ifdef UHC_NW4
+#define UHC_QUEUE_THREADS (UHC_WAVE * UHC_PRIMAL_WAVES)
+#else
+#define UHC_QUEUE_THREADS UHC_WAVE
+#endif
 template <int MODE, int TIER, bool DENSE>
-__global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, const double* __restrict__ d_action, const double* __restrict__ d_tbase) {
+__global__ void __launch_bounds__(UHC_QUEUE_THREADS) uhc_step_queue_kernel(KernelArgs A, const double* __restrict__ d_action, const double* __restrict__ d_tbase) {
+#ifdef UHC_NW4
+    static_assert(TIER == 4, "the four-wave form is tier 4's");
+    if (threadIdx.x >= UHC_WAVE) { primal_helper<TIER>(A, smem); return; }  // (before anything that says LANE == 0: the helpers' lanes count from 0 too)
+#endif
     if (A.started && LANE == 0) atomicAdd(A.started, 1);  // resident: holds its LDS from here on
     // (tier trace, UHC_DEBUG bit 4: the consumer's own record -- entry, first env claimed, exit, envs processed -- in words 8 .. 11 (general
     //  tier) / 12 .. 15 (large tier) of the stage-profile record of env blockIdx.x)
@@ -3054,4 +3079,7 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_queue_kernel(KernelArgs A, 
     }
     if (tr && LANE == 0) tr[2] = (long long)wall_clock64();
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // consumer bookkeeping (the next tier's consumers wait for it)
+#ifdef UHC_NW4
+    primal_release_helpers<TIER>(A, smem);
+#endif
 }

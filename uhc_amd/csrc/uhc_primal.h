@@ -15,55 +15,107 @@
 // Newton's method with an exact line search is invariant under the change of variables, so the test suite's checker (dense algebra in a-space)
 // runs the same iteration:
 //   start   u0 = sum f_ws Yhat (the forces the warm-start acceleration implies, k_rows) if its cost is below cost(0), else 0
-//   step    active = {jar < 0};  H (packed lower, column-major, LDS) = I + sum_active D Yhat Yhat^T;  left-looking Cholesky by one wave;
+//   step    active = {jar < 0};  H (packed lower, column-major, LDS) = I + sum_active D Yhat Yhat^T;  blocked right-looking Cholesky;
 //           dir = -H^-1 g;  p = Yhat dir;  exact line search on the piecewise-quadratic cost (safeguarded Newton on its derivative);
 //           u += alpha dir, jar += alpha p
 //   stop    a full step (|alpha - 1| <= 1e-12) that leaves the active set as it was, or |g| <= 1e-14 |g_0|;  UHC_PRIMAL_MAXIT otherwise.
 // Rows: chain rows lie packed in Yb (offsets rowY, dofs T.dof_anc), rows between two moving bodies as dense nv-vectors in Db (slot = type >> 8).
 // Both live in HBM / L2 for this tier (KernelArgs::gY, gD): the LDS is the Hessian's.
+//
+// FOUR WAVES (round 6).  A tier-4 env-step is what ends a control step of the ball-joint rollouts, and on one wave it was 14 M cycles of which the
+// row passes (jar, gradient, Hessian) took 58 % and the factorisation 18 %.  The queue consumers of this tier (uhc_k_huge_q.hip, -DUHC_NW4) are
+// workgroups of UHC_PRIMAL_WAVES waves, one per SIMD of the CU whose LDS the workgroup owns anyway: wave 0 runs the step as every other tier does
+// (all of uhc_physics_impl.h assumes workgroup = wave) and the three HELPERS sleep in s_barrier until wave 0 posts a command in the LDS mailbox:
+//   * row dots (jar = Yhat u + b, p = Yhat dir): rows dealt out in blocks of 64, dense rows in groups of four;
+//   * gradient + Hessian: every dof -- an entry of the gradient, a COLUMN of the Hessian -- is OWNED by wave (depth of the dof) & 3.  A chain row's
+//     entry at chain position q belongs to the dof of depth q, so the pair (q, q2) of its outer product goes to wave q2 & 3 whichever row it comes
+//     from: every wave walks ALL runs of rows (its own staging strip, no barrier between runs) and adds its own pairs -- no two waves ever touch the
+//     same word, no atomics; the dense rows' columns are dealt out by the same rule;
+//   * Cholesky: right-looking in panels of UHC_PRIMAL_NB columns: wave 0 factorises the panel in registers (lane = row), all waves share the
+//     trailing update column by column.
+// The one-workgroup-per-env kernels (set_state's forward pass, the chained launches) run the SAME stage functions on their one wave (NW = 1: it owns
+// everything); every word of H and of the gradient receives the same additions in the same order whatever NW is, so the two forms agree to the bit.
 #define UHC_PRIMAL_MAXIT 100
 #define UHC_PRIMAL_LS_MAXIT 60
 #define UHC_PRIMAL_DGROUP 8  // dense rows per pass over the Hessian
 #define UHC_PRIMAL_MAXFLIP 10  // rows that may change sides between two iterations for the factor to be updated instead of rebuilt
+#define UHC_PRIMAL_NB 16  // columns per panel of the factorisation
+#ifdef UHC_NW4
+#define UHC_PRIMAL_NW UHC_PRIMAL_WAVES
+#else
+#define UHC_PRIMAL_NW 1
+#endif
+enum { PCMD_EXIT = 0, PCMD_SCATTER_U, PCMD_DOTS_U_JAR, PCMD_GRAD, PCMD_GRAD_HESS, PCMD_CHOL, PCMD_DOTS_DIR_P };
 
 // packed lower triangle, column by column: column j holds rows j .. n-1
 __device__ __forceinline__ int hcol(int j, int n) { return j * n - (j * (j - 1)) / 2; }
+// all waves of the workgroup (NW > 1: a real barrier; the one-wave kernels: the wave-local fence every other stage uses)
+template <int NW> __device__ __forceinline__ void mw_barrier() { if constexpr (NW > 1) __syncthreads(); else wsync(); }
 
-// y = Yhat_r . v for every row (v: an nv-vector in LDS), into out[r] (+ add[r] when add != nullptr); dense rows wave-cooperatively first.
-// anc: the dof-chain table ([nv][YS] shorts), staged in LDS by k_primal (the rows' own entries stream from L2: four independent loads per round --
-// a loop of dependent single loads pays the L2 latency once per entry)
+struct PrimalCtx {
+    const RowMisc* RM; const int* RY; const int* NI; const int* dof_depth;
+    int YS, n, nvp, nefc, nslot;
+    double *u, *vec, *jar, *pp, *Dr, *cf, *H, *dsc;
+    const double* bb;
+    short* anc_tab; double *stY, *dstage, *cw;
+    unsigned short *pair_all, *pair_cls, *pair_cnt;
+    int* mbx;
+    const double *Yb, *Db;
+};
 template <int TIER>
-__device__ __forceinline__ void primal_row_dots(const KernelArgs& A, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db,
-                                                const short* anc_tab, const double* v, double* out, const double* add) {
+__device__ __forceinline__ PrimalCtx primal_ctx(const KernelArgs& A, double* S, int nefc, const double* Yb, const double* Db) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
-    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
-    const int* RY = (const int*)(S + L.rowY);
-    const int* NI = (const int*)(S + L.ncon_nefc);
-    const int YS = T.maxdepth + 1;
-    const int nslot = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
-    const double va = LC.v0 ? v[LANE] : 0.0, vb = LC.v1 ? v[LANE + UHC_WAVE] : 0.0;
-    for (int k0 = 0; k0 < nslot; k0 += 4) {  // four dense rows per round: their loads and reductions overlap
+    PrimalCtx C;
+    C.RM = (const RowMisc*)(S + L.rowMisc); C.RY = (const int*)(S + L.rowY); C.NI = (const int*)(S + L.ncon_nefc); C.dof_depth = T.dof_depth;
+    C.YS = T.maxdepth + 1; C.n = T.nv; C.nvp = A.nvp; C.nefc = nefc;
+    C.nslot = cap_of<TIER>(A).ndense > 0 ? __builtin_amdgcn_readfirstlane(C.NI[2]) : 0;
+    C.u = S + L.z;
+    C.vec = S + L.vec;       // gradient, then the Newton direction
+    C.jar = S + L.rowAref;   // Yhat_r . u + b_r  (the slot held D jar of the warm start for the working sets' ranking: not used in this tier)
+    C.pp = S + L.rowDa;      // the rows' weights in the Hessian, then Yhat_r . dir  (the slot held diag(A): only the sweeps read it, and they do not run after this)
+    C.Dr = S + L.rowW;       // 1 / R_r
+    C.cf = S + L.rowF;       // per-row coefficient of the current scatter; the forces at the end
+    C.bb = S + L.rowB;
+    C.H = S + L.H; C.dsc = S + L.dsc;
+    // the contacts' storage: nothing reads the contacts once the rows are built (the host sizes it for all of this: uhc_device.h primal_scratch)
+    const PrimalScratch ps = primal_scratch(T.nv, C.YS);
+    double* X = S + L.con;
+    C.anc_tab = (short*)(X + ps.anc); C.stY = X + ps.stY; C.dstage = X + ps.dstage; C.cw = X + ps.cw;
+    C.pair_all = (unsigned short*)(X + ps.pair_all); C.pair_cls = (unsigned short*)(X + ps.pair_cls); C.pair_cnt = (unsigned short*)(X + ps.pair_cnt);
+    C.mbx = (int*)(X + ps.mbx);
+    C.Yb = Yb; C.Db = Db;
+    return C;
+}
+
+// y = Yhat_r . v for every row (v: an nv-vector in LDS), into out[r] (+ add[r] when add != nullptr); dense rows wave-cooperatively first (four rows
+// per round: their loads and reductions overlap), then lane = row: its packed entries stream from L2 four independent loads per round -- a loop of
+// dependent single loads pays the L2 latency once per entry -- and the dof indices come from the LDS copy of the chain table.
+template <int NW>
+__device__ __forceinline__ void primal_row_dots(const PrimalCtx& C, int wid, const double* v, double* out, const double* add) {
+    const bool v0 = LANE < C.n, v1 = LANE + UHC_WAVE < C.n;
+    const double va = v0 ? v[LANE] : 0.0, vb = v1 ? v[LANE + UHC_WAVE] : 0.0;
+    for (int k0 = 4 * wid; k0 < C.nslot; k0 += 4 * NW) {
         double s[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const double* Dk = Db + (size_t)min(k0 + j, nslot - 1) * A.nvp;
-            s[j] = (LC.v0 ? Dk[LANE] * va : 0.0) + (LC.v1 ? Dk[LANE + UHC_WAVE] * vb : 0.0);
+            const double* Dk = C.Db + (size_t)min(k0 + j, C.nslot - 1) * C.nvp;
+            s[j] = (v0 ? Dk[LANE] * va : 0.0) + (v1 ? Dk[LANE + UHC_WAVE] * vb : 0.0);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) s[j] = wave_sum(s[j]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (LANE == 0 && k0 + j < nslot) S[L.dsc + 4 * (k0 + j)] = s[j];
+        for (int j = 0; j < 4; j++) if (LANE == 0 && k0 + j < C.nslot) C.dsc[4 * (k0 + j)] = s[j];
     }
-    wsync();
-    for (int r = LANE; r < nefc; r += UHC_WAVE) {
-        const RowMisc rm = RM[r];
+    mw_barrier<NW>();
+    for (int r = wid * UHC_WAVE + LANE; r < C.nefc; r += UHC_WAVE * NW) {
+        const RowMisc rm = C.RM[r];
         double y = add ? add[r] : 0.0;
-        if (rm.type & ROW_TWO) y += S[L.dsc + 4 * (rm.type >> 8)];
+        if (rm.type & ROW_TWO) y += C.dsc[4 * (rm.type >> 8)];
         else {
-            const int len = RY[r + 1] - RY[r];
-            const short* anc = anc_tab + rm.last * YS;
-            const double* Yr = Yb + RY[r];
+            const int len = C.RY[r + 1] - C.RY[r];
+            const short* anc = C.anc_tab + rm.last * C.YS;
+            const double* Yr = C.Yb + C.RY[r];
             double y1 = 0.0;
             int q = 0;
             for (; q + 4 <= len; q += 4) {
@@ -76,68 +128,60 @@ __device__ __forceinline__ void primal_row_dots(const KernelArgs& A, double* S, 
         }
         out[r] = y;
     }
-    wsync();
+    mw_barrier<NW>();
 }
 
-// The chain rows' share of the gradient and of the Hessian, WITHOUT atomics.  (A first version let every lane push its own row's len^2 / 2 products
-// into H with LDS float64 atomics: measured at ~12 cycles per lane and instruction, 1.3 M cycles per Hessian -- hidden in the profile behind the
-// Cholesky that had to wait for the LDS queue to drain.)  Rows that share a dof chain -- the 4 pyramid edges of a contact, all contacts of one
-// hull: runs of up to 16 consecutive rows with the same last dof -- are taken TOGETHER by the whole wave: their entries are staged in LDS
-// ([16][32]), then lane = chain position q adds sum_t c_t y_t[q] to vec[dof(q)], and lane = pair (q, q2) of the chain's len (len + 1) / 2 pairs adds
-// sum_t w_t y_t[q] y_t[q2] to H[dof(q)][dof(q2)] -- distinct addresses inside a run, and the LDS queue of the wave keeps runs in order: plain
-// read-modify-write.  c: per-row coefficients (0 = the row does not contribute), w: per-row weights of the outer products (WITH_H).
-template <int TIER, bool WITH_H>
-__device__ __forceinline__ void primal_chain_pass(const KernelArgs& A, double* S, int nefc, const double* Yb, const short* anc_tab, const unsigned short* pair_tab,
-                                                  double* stY, double* cw, const double* c, const double* w, double* vec, double* H, int n) {
-    const DevTopo& T = A.t;
-    const DevLds& L = lds_of<TIER>(A);
-    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
-    const int* RY = (const int*)(S + L.rowY);
-    const int YS = T.maxdepth + 1;
+// The chain rows' share of a scatter (vec += sum_r c_r Yhat_r) and of the Hessian (H += sum_r w_r Yhat_r Yhat_r^T), WITHOUT atomics.  (A first version
+// let every lane push its own row's len^2 / 2 products into H with LDS float64 atomics: measured at ~12 cycles per lane and instruction, 1.3 M cycles per
+// Hessian.)  Rows that share a dof chain -- the 4 pyramid edges of a contact, all contacts of one hull: runs of up to 16 consecutive rows with the same
+// last dof -- are taken TOGETHER: their entries are staged in the wave's own LDS strip ([16][32]), then lane = chain position q adds sum_t c_t y_t[q] to
+// vec[dof(q)], and lane = pair (q, q2) adds sum_t w_t y_t[q] y_t[q2] to H[dof(q)][dof(q2)] -- distinct addresses inside a run, and the LDS queue of the
+// wave keeps runs in order: plain read-modify-write.  With four waves every wave stages every run and takes the positions q with q & 3 == wid and the
+// pairs with q2 & 3 == wid (the class tables): the dof at chain position q has depth q, so these are exactly the words the wave owns.
+template <int NW, bool WITH_H>
+__device__ __forceinline__ void primal_chain_pass(const PrimalCtx& C, int wid, const double* c, const double* w, double* vec) {
+    double* stY = C.stY + wid * (16 * 32);
+    double* cw = C.cw + wid * 32;
+    const unsigned short* ptab = NW == 1 ? C.pair_all : C.pair_cls + wid * UHC_PRIMAL_CLS_STRIDE;
+    const int n = C.n, nefc = C.nefc;
     int r0 = 0;
-#ifdef UHC_PRIMAL_GUARD
-    int guard = 0;
-#endif
     while (r0 < nefc) {
-#ifdef UHC_PRIMAL_GUARD
-        if (++guard > 4096) { if (LANE == 0) printf("primal_chain_pass: no progress at row %d of %d\n", r0, nefc); break; }
-#endif
         const int rr = r0 + LANE;
         int last_l = -2, two_l = 1;
-        if (LANE < 16 && rr < nefc) { const RowMisc rm = RM[rr]; last_l = rm.last; two_l = (rm.type & ROW_TWO) ? 1 : 0; }
+        if (LANE < 16 && rr < nefc) { const RowMisc rm = C.RM[rr]; last_l = rm.last; two_l = (rm.type & ROW_TWO) ? 1 : 0; }
         const int last0 = __builtin_amdgcn_readfirstlane(last_l);
-        if (__builtin_amdgcn_readfirstlane(two_l)) { r0++; continue; }  // (dense rows: primal_dense_*)
+        if (__builtin_amdgcn_readfirstlane(two_l)) { r0++; continue; }  // (dense rows: the stage function's own loops)
         const unsigned long long same = __builtin_amdgcn_ballot_w64(LANE < 16 && rr < nefc && !two_l && last_l == last0);
         const int nb = __builtin_ctzll(~same);  // the run's length: consecutive rows from r0 on with this chain (>= 1, <= 16)
         double c_l = 0.0, w_l = 0.0;
         if (LANE < nb) { c_l = c[rr]; if (WITH_H) w_l = w[rr]; }
         if (__builtin_amdgcn_ballot_w64(c_l != 0.0 || w_l != 0.0)) {
-            const int len = __builtin_amdgcn_readfirstlane(RY[r0 + 1] - RY[r0]);
+            const int len = __builtin_amdgcn_readfirstlane(C.RY[r0 + 1] - C.RY[r0]);
             for (int idx = LANE; idx < nb * 32; idx += UHC_WAVE) {
                 const int t = idx >> 5, q = idx & 31;
-                if (q < len) stY[idx] = Yb[RY[r0 + t] + q];
+                if (q < len) stY[idx] = C.Yb[C.RY[r0 + t] + q];
             }
             // (the run's coefficients go through LDS, not v_readlane: the readers below sit in divergent branches -- lanes < len, lanes < np -- and a
             //  register the compiler spilled and reloads INSIDE such a branch holds garbage in the lanes the branch switched off, which are exactly the
-            //  lanes a readlane of row t >= len would read.  The 552-spill instantiation <0, 3> did that and produced NaNs; <1, 3>, 6 spills, did not.)
+            //  lanes a readlane of row t >= len would read.  The 552-spill instantiation <0, 3> of round 5 did that and produced NaNs.)
             if (LANE < 16) { cw[LANE] = c_l; cw[16 + LANE] = w_l; }
             wsync();
-            const short* anc = anc_tab + last0 * YS;
-            if (LANE < len) {
+            const short* anc = C.anc_tab + last0 * C.YS;
+            if (LANE < len && (NW == 1 || (LANE & 3) == wid)) {
                 double sg = 0.0;
                 for (int t = 0; t < nb; t++) sg = fma(cw[t], stY[t * 32 + LANE], sg);
                 vec[anc[LANE]] += sg;
             }
             if (WITH_H) {
-                const int np = (len * (len + 1)) / 2;
+                const int np = NW == 1 ? (len * (len + 1)) / 2 : (int)C.pair_cnt[wid * 33 + len];
                 for (int p0 = 0; p0 < np; p0 += UHC_WAVE) {
                     const int pi = p0 + LANE;
                     if (pi < np) {
-                        const int qq = pair_tab[pi], q = qq >> 8, q2 = qq & 0xff;
+                        const int qq = ptab[pi], q = qq >> 8, q2 = qq & 0xff;
                         double sh = 0.0;
                         for (int t = 0; t < nb; t++) sh = fma(cw[16 + t] * stY[t * 32 + q], stY[t * 32 + q2], sh);
                         const int i = anc[q], jc = anc[q2];
-                        H[hcol(jc, n) - jc + i] += sh;
+                        C.H[hcol(jc, n) - jc + i] += sh;
                     }
                 }
             }
@@ -146,81 +190,172 @@ __device__ __forceinline__ void primal_chain_pass(const KernelArgs& A, double* S
         r0 += nb;
     }
 }
-// the dense rows' share of a scatter: vec += sum_k c_k Yhat_k, lane = dof
-template <int TIER>
-__device__ __forceinline__ void primal_dense_scatter(const KernelArgs& A, double* S, const LaneConst& LC, const double* Db, const double* c, double* vec) {
-    const DevLds& L = lds_of<TIER>(A);
-    const int* NI = (const int*)(S + L.ncon_nefc);
-    const int nslot = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
-    double ga = 0.0, gb = 0.0;
-    for (int k = 0; k < nslot; k++) {
-        const double ck = c[__builtin_amdgcn_readfirstlane(NI[4 + k])];
-        if (ck == 0.0) continue;
-        const double* Dk = Db + (size_t)k * A.nvp;
-        if (LC.v0) ga = fma(ck, Dk[LANE], ga);
-        if (LC.v1) gb = fma(ck, Dk[LANE + UHC_WAVE], gb);
+
+// One stage of a Newton iteration, run by every wave of the workgroup on the dofs it owns (NW == 1: all of them):
+//     target = init (or 0) + sum_r cf_r Yhat_r          and, WITH_H,        H = I + sum_r pp_r Yhat_r Yhat_r^T
+// cf: the rows' coefficients (gradient: D jar of the active rows; start point: the warm-start forces), pp: their weights (D of the active rows, else 0).
+template <int NW, bool WITH_H>
+__device__ __forceinline__ void primal_grad_hess(const PrimalCtx& C, int wid, double* target, const double* init) {
+    const int n = C.n;
+    const bool v0 = LANE < n, v1 = LANE + UHC_WAVE < n;
+    const int ia = min(LANE, n - 1), ib = min(LANE + UHC_WAVE, n - 1);
+    const bool own0 = v0 && (NW == 1 || (C.dof_depth[ia] & 3) == wid), own1 = v1 && (NW == 1 || (C.dof_depth[ib] & 3) == wid);
+    const unsigned long long own_m[2] = {__builtin_amdgcn_ballot_w64(own0), __builtin_amdgcn_ballot_w64(own1)};
+    if (own0) target[LANE] = init ? init[LANE] : 0.0;
+    if (own1) target[LANE + UHC_WAVE] = init ? init[LANE + UHC_WAVE] : 0.0;
+    if (WITH_H) {  // the owned columns: zero below the diagonal, one on it
+        for (int h = 0; h < 2; h++) {
+            unsigned long long m = own_m[h];
+            while (m) {
+                const int j = UHC_WAVE * h + __builtin_ctzll(m);
+                m &= m - 1;
+                double* Hj = C.H + hcol(j, n) - j;
+                if (LANE >= j && v0) Hj[LANE] = LANE == j ? 1.0 : 0.0;
+                if (LANE + UHC_WAVE >= j && v1) Hj[LANE + UHC_WAVE] = LANE + UHC_WAVE == j ? 1.0 : 0.0;
+            }
+        }
     }
-    if (LC.v0) vec[LANE] += ga;
-    if (LC.v1) vec[LANE + UHC_WAVE] += gb;
     wsync();
+    primal_chain_pass<NW, WITH_H>(C, wid, C.cf, C.pp, target);
+    {   // the dense rows' share of the scatter: lane = owned dof, four rows' loads in flight
+        double ga = 0.0, gb = 0.0;
+        for (int k0 = 0; k0 < C.nslot; k0 += 4) {
+            double ck[4], da[4], db[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = min(k0 + j, C.nslot - 1);
+                ck[j] = k0 + j < C.nslot ? C.cf[__builtin_amdgcn_readfirstlane(C.NI[4 + k])] : 0.0;
+                const double* Dk = C.Db + (size_t)k * C.nvp;
+                da[j] = own0 ? Dk[LANE] : 0.0; db[j] = own1 ? Dk[LANE + UHC_WAVE] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ga = fma(ck[j], da[j], ga); gb = fma(ck[j], db[j], gb); }
+        }
+        if (own0) target[LANE] += ga;
+        if (own1) target[LANE + UHC_WAVE] += gb;
+    }
+    if (WITH_H) {
+        // dense rows, UHC_PRIMAL_DGROUP at a time: lane = row index i of the Hessian (its own y_i of the group's rows in registers), the wave's columns j
+        // in turn: the column is contiguous in i, D y_j of every row of the group comes by one broadcast LDS read from the staged copy (of which every
+        // wave writes and reads the dofs it owns)
+        int k = 0;
+        while (k < C.nslot) {
+            DofVec y[UHC_PRIMAL_DGROUP];
+            int got = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) { y[s2].a = y[s2].b = 0.0; }
+            while (k < C.nslot && got < UHC_PRIMAL_DGROUP) {
+                const int rid = __builtin_amdgcn_readfirstlane(C.NI[4 + k]);
+                const double dd = C.pp[rid];  // (wave-uniform address: D of an active row, else 0)
+                if (__builtin_amdgcn_readfirstlane(__double2hiint(dd)) != 0 || __builtin_amdgcn_readfirstlane(__double2loint(dd)) != 0) {
+                    const double* Dk = C.Db + (size_t)k * C.nvp;
+                    const double ya = v0 ? Dk[LANE] : 0.0, yb = v1 ? Dk[LANE + UHC_WAVE] : 0.0;
+#pragma unroll
+                    for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) if (s2 == got) { y[s2].a = ya; y[s2].b = yb; }
+                    if (own0) C.dstage[LANE * UHC_PRIMAL_DGROUP + got] = dd * ya;   // [dof][row of the group]: one 64-byte line per column j
+                    if (own1) C.dstage[(LANE + UHC_WAVE) * UHC_PRIMAL_DGROUP + got] = dd * yb;
+                    got++;
+                }
+                k++;
+            }
+            if (got == 0) break;
+            for (int g = got; g < UHC_PRIMAL_DGROUP; g++) {  // (unused places of the last group: zero multipliers)
+                if (own0) C.dstage[LANE * UHC_PRIMAL_DGROUP + g] = 0.0;
+                if (own1) C.dstage[(LANE + UHC_WAVE) * UHC_PRIMAL_DGROUP + g] = 0.0;
+            }
+            wsync();
+            for (int h = 0; h < 2; h++) {
+                unsigned long long m = own_m[h];
+                while (m) {
+                    const int j = UHC_WAVE * h + __builtin_ctzll(m);
+                    m &= m - 1;
+                    double* Hj = C.H + hcol(j, n) - j;
+                    double yj[UHC_PRIMAL_DGROUP];
+#pragma unroll
+                    for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) yj[s2] = C.dstage[j * UHC_PRIMAL_DGROUP + s2];
+                    double ha = Hj[ia], hb = Hj[ib];  // (rows above the diagonal: in-range garbage, never stored)
+#pragma unroll
+                    for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) { ha = fma(yj[s2], y[s2].a, ha); hb = fma(yj[s2], y[s2].b, hb); }
+                    if (LANE >= j && v0) Hj[LANE] = ha;
+                    if (LANE + UHC_WAVE >= j && v1) Hj[LANE + UHC_WAVE] = hb;
+                }
+            }
+            wsync();
+        }
+    }
+    mw_barrier<NW>();
 }
 
-// Two columns (j, j + 1) of the left-looking Cholesky factorisation of the packed Hessian: lane = row (rows LANE and LANE + 64), the two columns'
-// running values in registers, every earlier column k read ONCE for both (its rows: two vector reads; its entries (j, k), (j + 1, k): two broadcast
-// reads), four columns per round so that eight reads are in flight before the first FMA needs one -- a loop of one column per round is bound by the
-// LDS round trip (measured: 190 cycles per column and (j, k) pair, 1.3 M cycles per factorisation at nv = 117: 64 % of a tier-4 env-step).  LO: the
-// pair still has rows below 64 (j < 64); later pairs skip that half.  Rows above the diagonal compute garbage from in-range reads and are not stored.
-template <bool LO>
-__device__ __forceinline__ void primal_chol2(double* H, int n, int j) {
-    const int ia = LANE, ib = min(LANE + UHC_WAVE, n - 1), j1 = min(j + 1, n - 1);
-    const bool two = j + 1 < n;
-    double* Hj = H + hcol(j, n) - j;
-    double* Hj1 = H + hcol(j1, n) - j1;
-    double a0 = LO ? Hj[ia] : 0.0, b0 = Hj[ib], a1 = LO ? Hj1[ia] : 0.0, b1 = Hj1[ib];
-    double a0x = 0.0, b0x = 0.0, a1x = 0.0, b1x = 0.0;  // second accumulators: independent FMA chains
-    int base = 0, k = 0;  // base = hcol(k) - k
-    for (; k + 4 <= j; k += 4) {
-        const int o0 = base, o1 = o0 + n - k - 1, o2 = o1 + n - k - 2, o3 = o2 + n - k - 3;
-        base = o3 + n - k - 4;
-        const double c0 = H[o0 + j], c1 = H[o1 + j], c2 = H[o2 + j], c3 = H[o3 + j];
-        const double d0 = H[o0 + j1], d1 = H[o1 + j1], d2 = H[o2 + j1], d3 = H[o3 + j1];
-        const double q0 = H[o0 + ib], q1 = H[o1 + ib], q2 = H[o2 + ib], q3 = H[o3 + ib];
-        if (LO) {
-            const double p0 = H[o0 + ia], p1 = H[o1 + ia], p2 = H[o2 + ia], p3 = H[o3 + ia];
-            a0 = fma(-p0, c0, a0); a0x = fma(-p1, c1, a0x); a0 = fma(-p2, c2, a0); a0x = fma(-p3, c3, a0x);
-            a1 = fma(-p0, d0, a1); a1x = fma(-p1, d1, a1x); a1 = fma(-p2, d2, a1); a1x = fma(-p3, d3, a1x);
+// Cholesky H = C C^T of the packed Hessian, right-looking in panels of UHC_PRIMAL_NB columns; the diagonal keeps 1 / C_jj (H >= I: the pivots are >= 1 up
+// to rounding).  Panel: wave 0, lane = row (rows LANE and LANE + 64), the panel's NB entries of either row in registers; a column is scaled by the
+// reciprocal root of its diagonal entry and taken off the later columns of the panel, the multipliers by v_readlane (wave-uniform control flow
+// throughout).  Trailing update: the columns behind the panel are dealt out to the waves; per column NB broadcast reads (row j of the panel), the lane's
+// two entries read-modify-written.  Rows above the diagonal compute garbage from in-range reads and are not stored.
+// (Round 5's left-looking factorisation by one wave: 150 k cycles at nv = 117, 18-44 % of a tier-4 env-step.)
+template <int NW>
+__device__ __forceinline__ void primal_chol(double* H, int n, int wid) {
+    const int ia = min(LANE, n - 1), ib = min(LANE + UHC_WAVE, n - 1);
+    for (int jb = 0; jb < n; jb += UHC_PRIMAL_NB) {
+        const int nbk = min(UHC_PRIMAL_NB, n - jb);
+        if (wid == 0) {
+            double Pa[UHC_PRIMAL_NB], Pb[UHC_PRIMAL_NB];
+#pragma unroll
+            for (int p = 0; p < UHC_PRIMAL_NB; p++) {
+                const int j = min(jb + p, n - 1);
+                const double* Hj = H + hcol(j, n) - j;
+                Pa[p] = Hj[ia]; Pb[p] = Hj[ib];
+            }
+#pragma unroll
+            for (int p = 0; p < UHC_PRIMAL_NB; p++) {
+                if (p < nbk) {
+                    const int j = jb + p;
+                    DofVec col = {Pa[p], Pb[p]};
+                    const double rc = 1.0 / sqrt(dv_get_nb(col, j));
+                    col.a *= rc; col.b *= rc;
+                    Pa[p] = col.a; Pb[p] = col.b;
+#pragma unroll
+                    for (int p2 = p + 1; p2 < UHC_PRIMAL_NB; p2++) {
+                        if (p2 < nbk) {
+                            const double l = dv_get_nb(col, jb + p2);  // C[jb + p2][j]
+                            Pa[p2] = fma(-col.a, l, Pa[p2]); Pb[p2] = fma(-col.b, l, Pb[p2]);
+                        }
+                    }
+                    double* Hj = H + hcol(j, n) - j;
+                    if (LANE >= j && LANE < n) Hj[LANE] = LANE == j ? rc : col.a;
+                    if (LANE + UHC_WAVE >= j && LANE + UHC_WAVE < n) Hj[LANE + UHC_WAVE] = LANE + UHC_WAVE == j ? rc : col.b;
+                }
+            }
         }
-        b0 = fma(-q0, c0, b0); b0x = fma(-q1, c1, b0x); b0 = fma(-q2, c2, b0); b0x = fma(-q3, c3, b0x);
-        b1 = fma(-q0, d0, b1); b1x = fma(-q1, d1, b1x); b1 = fma(-q2, d2, b1); b1x = fma(-q3, d3, b1x);
-    }
-    for (; k < j; k++) {
-        const int o0 = base;
-        base = o0 + n - k - 1;
-        const double c0 = H[o0 + j], d0 = H[o0 + j1], q0 = H[o0 + ib];
-        if (LO) { const double p0 = H[o0 + ia]; a0 = fma(-p0, c0, a0); a1 = fma(-p0, d0, a1); }
-        b0 = fma(-q0, c0, b0); b1 = fma(-q0, d0, b1);
-    }
-    a0 += a0x; b0 += b0x; a1 += a1x; b1 += b1x;
-    // column j: scale by 1 / sqrt of its diagonal; column j + 1: one more update by the finished column j, then the same
-    DofVec v0 = {a0, b0};
-    const double rc0 = 1.0 / sqrt(dv_get_nb(v0, j));  // (H >= I: the pivot is >= 1 up to rounding)
-    v0.a *= rc0; v0.b *= rc0;
-    const double cj1 = dv_get_nb(v0, j1);  // C[j + 1][j]
-    DofVec v1 = {fma(-v0.a, cj1, a1), fma(-v0.b, cj1, b1)};
-    const double rc1 = 1.0 / sqrt(dv_get_nb(v1, j1));
-    v1.a *= rc1; v1.b *= rc1;
-    if (LO && ia >= j && ia < n) Hj[ia] = ia == j ? rc0 : v0.a;
-    if (LANE + UHC_WAVE >= j && LANE + UHC_WAVE < n) Hj[LANE + UHC_WAVE] = LANE + UHC_WAVE == j ? rc0 : v0.b;
-    if (two) {
-        if (LO && ia >= j1 && ia < n) Hj1[ia] = ia == j1 ? rc1 : v1.a;
-        if (LANE + UHC_WAVE >= j1 && LANE + UHC_WAVE < n) Hj1[LANE + UHC_WAVE] = LANE + UHC_WAVE == j1 ? rc1 : v1.b;
+        mw_barrier<NW>();
+        const int j0 = jb + nbk;
+        if (j0 < n) {
+            double La[UHC_PRIMAL_NB], Lb[UHC_PRIMAL_NB];  // the lane's rows of the panel (zero beyond the panel's width)
+#pragma unroll
+            for (int p = 0; p < UHC_PRIMAL_NB; p++) {
+                const int j = min(jb + p, n - 1);
+                const double* Hj = H + hcol(j, n) - j;
+                La[p] = p < nbk ? Hj[ia] : 0.0; Lb[p] = p < nbk ? Hj[ib] : 0.0;
+            }
+            for (int j = j0 + wid; j < n; j += NW) {
+                double* Hj = H + hcol(j, n) - j;
+                double lj[UHC_PRIMAL_NB];
+#pragma unroll
+                for (int p = 0; p < UHC_PRIMAL_NB; p++) { const int jp = min(jb + p, n - 1); lj[p] = H[hcol(jp, n) - jp + j]; }  // C[j][jb + p]
+                double ha = Hj[ia], hb = Hj[ib];
+#pragma unroll
+                for (int p = 0; p < UHC_PRIMAL_NB; p++) { ha = fma(-La[p], lj[p], ha); hb = fma(-Lb[p], lj[p], hb); }
+                if (LANE >= j && LANE < n) Hj[LANE] = ha;
+                if (LANE + UHC_WAVE >= j && LANE + UHC_WAVE < n) Hj[LANE + UHC_WAVE] = hb;
+            }
+        }
+        mw_barrier<NW>();
     }
 }
 
 // Rank-one update (sigma = +1) or downdate (-1) of the packed Cholesky factor, C C^T <- C C^T + sigma x x^T, column by column (the LINPACK rotation
-// scheme): lane = row, x in registers, one column read and written per step.  ~150 cycles per column against a fresh factorisation's 3 000: when a
-// Newton iteration moves a handful of rows across jar = 0, the factor follows them instead of being rebuilt.  Returns false when a downdate
-// loses positive definiteness to rounding (r^2 <= 0): the caller rebuilds.  The diagonal holds 1 / C_kk throughout.
+// scheme): lane = row, x in registers, one column read and written per step.  ~150 cycles per column: when a Newton iteration moves a handful of rows
+// across jar = 0, the factor follows them instead of being rebuilt.  Returns false when a downdate loses positive definiteness to rounding
+// (r^2 <= 0): the caller rebuilds.  The diagonal holds 1 / C_kk throughout.  (Wave 0 alone.)
 __device__ __forceinline__ bool primal_chol_rank1(double* H, int n, DofVec x, double sigma) {
     const int ib = min(LANE + UHC_WAVE, n - 1);
     bool good = true;
@@ -247,46 +382,92 @@ __device__ __forceinline__ bool primal_chol_rank1(double* H, int n, DofVec x, do
     return good;
 }
 
+// wave 0 hands a stage to the helper waves (NW > 1): the command goes into the mailbox, the barrier releases them; the stage function itself -- which
+// wave 0 runs too, as wid 0 -- ends in the barrier that collects them again
+template <int NW>
+__device__ __forceinline__ void primal_post(const PrimalCtx& C, int cmd) {
+    if constexpr (NW > 1) {
+        if (LANE == 0) C.mbx[0] = cmd;
+        __syncthreads();
+    }
+}
+#ifdef UHC_NW4
+// The helper waves of a four-wave consumer: asleep in the barrier until wave 0 posts a command; they know nothing of the env but what the mailbox says.
+template <int TIER>
+__device__ __forceinline__ void primal_helper(const KernelArgs& A, double* S) {
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const PrimalScratch ps = primal_scratch(A.t.nv, A.t.maxdepth + 1);
+    const int* mbx = (const int*)(S + lds_of<TIER>(A).con + ps.mbx);
+    for (;;) {
+        __syncthreads();
+        const int cmd = __builtin_amdgcn_readfirstlane(mbx[0]);
+        if (cmd == PCMD_EXIT) return;
+        const int nefc = __builtin_amdgcn_readfirstlane(mbx[1]);
+        const unsigned long long yb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbx[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbx[2]);
+        const unsigned long long db = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbx[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbx[4]);
+        const PrimalCtx C = primal_ctx<TIER>(A, S, nefc, (const double*)yb, (const double*)db);
+        if (cmd == PCMD_SCATTER_U) primal_grad_hess<UHC_PRIMAL_NW, false>(C, wid, C.u, nullptr);
+        else if (cmd == PCMD_DOTS_U_JAR) primal_row_dots<UHC_PRIMAL_NW>(C, wid, C.u, C.jar, C.bb);
+        else if (cmd == PCMD_GRAD) primal_grad_hess<UHC_PRIMAL_NW, false>(C, wid, C.vec, C.u);
+        else if (cmd == PCMD_GRAD_HESS) primal_grad_hess<UHC_PRIMAL_NW, true>(C, wid, C.vec, C.u);
+        else if (cmd == PCMD_CHOL) primal_chol<UHC_PRIMAL_NW>(C.H, C.n, wid);
+        else if (cmd == PCMD_DOTS_DIR_P) primal_row_dots<UHC_PRIMAL_NW>(C, wid, C.vec, C.pp, nullptr);
+    }
+}
+// wave 0, at the end of the kernel: the helpers leave
+template <int TIER>
+__device__ __forceinline__ void primal_release_helpers(const KernelArgs& A, double* S) {
+    const PrimalScratch ps = primal_scratch(A.t.nv, A.t.maxdepth + 1);
+    int* mbx = (int*)(S + lds_of<TIER>(A).con + ps.mbx);
+    if (LANE == 0) mbx[0] = PCMD_EXIT;
+    __syncthreads();
+}
+#endif
+
 // returns the Newton iterations taken (>= 1), negated when the iteration cap was reached; z = u in S[L.z], the forces in S[L.rowF]
 template <int TIER>
 __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, const double* Yb, const double* Db, int* nact PROF_ARGS) {
+    constexpr int NW = UHC_PRIMAL_NW;
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
-    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
-    const int* RY = (const int*)(S + L.rowY);
-    const int* NI = (const int*)(S + L.ncon_nefc);
-    const int YS = T.maxdepth + 1, n = T.nv;
-    const int nslot = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
-    double* u = S + L.z;
-    double* vec = S + L.vec;     // gradient, then the Newton direction
-    double* jar = S + L.rowAref;  // Yhat_r . u + b_r  (the slot held D jar of the warm start for the working sets' ranking: not used in this tier)
-    double* pp = S + L.rowDa;     // Yhat_r . dir      (the slot held diag(A): only the sweeps read it, and they do not run after this)
-    double* Dr = S + L.rowW;      // 1 / R_r
-    double* cf = S + L.rowF;      // per-row coefficient of the current scatter; the forces at the end
-    double* H = S + L.H;
+    const PrimalCtx C = primal_ctx<TIER>(A, S, nefc, Yb, Db);
+    const RowMisc* RM = C.RM;
+    const int* RY = C.RY;
+    const int YS = C.YS, n = C.n;
+    double *u = C.u, *vec = C.vec, *jar = C.jar, *pp = C.pp, *Dr = C.Dr, *cf = C.cf, *H = C.H;
     // the dof chains (which dof sits at position q of the chain that ends in dof i), from L2 into the contacts' storage: nothing reads the contacts
-    // once the rows are built, and every row pass of every Newton iteration walks this table
-    // (the host sizes the contacts' storage for all three: table, the lanes' row strips, the dense group -- uhc_capi.cpp huge_layout)
-    short* anc_l = (short*)(S + L.con);
-    for (int i = LANE; i < n * YS; i += UHC_WAVE) anc_l[i] = T.dof_anc[i];
-    const short* anc_tab = anc_l;
-    double* stY = S + L.con + ((n * YS + 3) / 4 + 1);                   // [16][32]: the run of chain rows being added (primal_chain_pass)
-    double* dstage = stY + 16 * 32;                                     // [nv][UHC_PRIMAL_DGROUP]: D y of the dense rows being added, dof-major
-    unsigned short* pair_tab = (unsigned short*)(dstage + n * UHC_PRIMAL_DGROUP + 1);  // [496] pair p = q (q + 1) / 2 + q2 -> (q << 8 | q2), q2 <= q < 32
-    double* cw = (double*)(pair_tab + 496);                             // [2][16]: coefficients and weights of the run of rows being added
-    if (LANE < 32) for (int q2 = 0; q2 <= LANE; q2++) pair_tab[(LANE * (LANE + 1)) / 2 + q2] = (unsigned short)((LANE << 8) | q2);
-    wsync();
+    // once the rows are built, and every row pass of every Newton iteration walks this table; the pair tables of the chain pass
+    for (int i = LANE; i < n * YS; i += UHC_WAVE) C.anc_tab[i] = T.dof_anc[i];
+    if (LANE < 32) {
+        for (int q2 = 0; q2 <= LANE; q2++) C.pair_all[(LANE * (LANE + 1)) / 2 + q2] = (unsigned short)((LANE << 8) | q2);
+        for (int c = 0; c < 4; c++) {  // class c: the pairs with q2 & 3 == c, q-major; lane = q
+            int o = 0;
+            for (int q = c; q < LANE; q++) o += (q - c) / 4 + 1;
+            for (int q2 = c; q2 <= LANE; q2 += 4) C.pair_cls[c * UHC_PRIMAL_CLS_STRIDE + o++] = (unsigned short)((LANE << 8) | q2);
+        }
+    }
+    if (LANE < 33)
+        for (int c = 0; c < 4; c++) {  // pairs of class c with q < LANE
+            int o = 0;
+            for (int q = c; q < LANE; q++) o += (q - c) / 4 + 1;
+            C.pair_cnt[c * 33 + LANE] = (unsigned short)o;
+        }
+    if (NW > 1 && LANE == 0) {
+        C.mbx[1] = nefc;
+        C.mbx[2] = (int)((unsigned long long)Yb & 0xffffffffull); C.mbx[3] = (int)((unsigned long long)Yb >> 32);
+        C.mbx[4] = (int)((unsigned long long)Db & 0xffffffffull); C.mbx[5] = (int)((unsigned long long)Db >> 32);
+    }
     // ---- start point: u0 = sum f_ws Yhat, kept if its cost is below the cost of u = 0
-    for (int i = LANE; i < n; i += UHC_WAVE) u[i] = 0.0;
     for (int r = LANE; r < nefc; r += UHC_WAVE) Dr[r] = 1.0 / S[L.rowR + r];
     wsync();
-    primal_chain_pass<TIER, false>(A, S, nefc, Yb, anc_tab, pair_tab, stY, cw, cf, nullptr, u, H, n);  // (cf = the warm-start forces k_rows left in rowF)
-    primal_dense_scatter<TIER>(A, S, LC, Db, cf, u);
-    primal_row_dots<TIER>(A, S, nefc, LC, Yb, Db, anc_tab, u, jar, S + L.rowB);
+    primal_post<NW>(C, PCMD_SCATTER_U);
+    primal_grad_hess<NW, false>(C, 0, u, nullptr);  // (cf = the warm-start forces k_rows left in rowF)
+    primal_post<NW>(C, PCMD_DOTS_U_JAR);
+    primal_row_dots<NW>(C, 0, u, jar, C.bb);
     {
         double c1 = 0.0, c0 = 0.0;
         for (int r = LANE; r < nefc; r += UHC_WAVE) {
-            const double x = jar[r], b = S[L.rowB + r], d = Dr[r];
+            const double x = jar[r], b = C.bb[r], d = Dr[r];
             if (x < 0) c1 = fma(0.5 * d * x, x, c1);
             if (b < 0) c0 = fma(0.5 * d * b, b, c0);
         }
@@ -294,7 +475,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
         c1 = wave_sum(c1); c0 = wave_sum(c0);
         if (!(c1 < c0)) {
             for (int i = LANE; i < n; i += UHC_WAVE) u[i] = 0.0;
-            for (int r = LANE; r < nefc; r += UHC_WAVE) jar[r] = S[L.rowB + r];
+            for (int r = LANE; r < nefc; r += UHC_WAVE) jar[r] = C.bb[r];
         }
         wsync();
     }
@@ -307,8 +488,9 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
     for (; it < UHC_PRIMAL_MAXIT; it++) {
         // ---- jar from u itself in every iteration (not jar += alpha p): a row that sits at jar = 0 -- touching, no force -- would otherwise carry the
         //      rounding noise of the updates, change sides from one iteration to the next and keep the "same active set" test from ever holding
-        if (it > 0) primal_row_dots<TIER>(A, S, nefc, LC, Yb, Db, anc_tab, u, jar, S + L.rowB);
-        // ---- active set, gradient
+        if (it > 0) { primal_post<NW>(C, PCMD_DOTS_U_JAR); primal_row_dots<NW>(C, 0, u, jar, C.bb); }
+        PROF(36)
+        // ---- active set, gradient coefficients, Hessian weights
         unsigned act = 0u;  // bit h: row LANE + 64 h is active
         for (int r = LANE; r < nefc; r += UHC_WAVE) {
             const double x = jar[r];
@@ -317,7 +499,6 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
             cf[r] = a ? Dr[r] * x : 0.0;   // gradient coefficient
             pp[r] = a ? Dr[r] : 0.0;       // weight of the row's outer product in the Hessian (pp holds p only after the factorisation)
         }
-        for (int i = LANE; i < n; i += UHC_WAVE) vec[i] = u[i];
         // ---- a few rows changed sides since the last factorisation: the factor follows them by rank-one updates (rows that joined) and downdates
         //      (rows that left) instead of a rebuild -- typical of the second and later iterations of a warm-started solve
         if (have_factor) {
@@ -325,6 +506,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
             int nflip = 0;
             for (int h = 0; h * UHC_WAVE < nefc; h++) nflip += __builtin_popcountll(__builtin_amdgcn_ballot_w64((flips >> h) & 1u));
             if (nflip > UHC_PRIMAL_MAXFLIP) have_factor = false;
+            double* stY = C.stY;  // (wave 0's strip: a dense copy of the chain row)
             for (int pass = 0; pass < 2 && have_factor; pass++) {  // joins first: the matrix only grows before it shrinks
                 for (int h = 0; h * UHC_WAVE < nefc && have_factor; h++) {
                     unsigned long long m = __builtin_amdgcn_ballot_w64(((flips >> h) & 1u) && ((((act >> h) & 1u) != 0u) == (pass == 0)));
@@ -340,7 +522,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
                             if (LC.v1) xv.b = sq * Dk[LANE + UHC_WAVE];
                         } else {
                             const int len = RY[r + 1] - RY[r];
-                            const short* anc = anc_tab + rm.last * YS;
+                            const short* anc = C.anc_tab + rm.last * YS;
                             for (int i = LANE; i < n; i += UHC_WAVE) stY[i] = 0.0;
                             wsync();
                             if (LANE < len) stY[anc[LANE]] = sq * Yb[RY[r] + LANE];
@@ -354,81 +536,20 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
                 }
             }
         }
-        if (have_factor) {  // gradient alone
-            primal_chain_pass<TIER, false>(A, S, nefc, Yb, anc_tab, pair_tab, stY, cw, cf, nullptr, vec, H, n);
-            primal_dense_scatter<TIER>(A, S, LC, Db, cf, vec);
-        } else {
-        // ---- Hessian: identity + the active rows' outer products; gradient: u + sum_active D jar Yhat -- one pass over the rows for both
-        const int nH = (n * (n + 1)) / 2;
-        for (int e = LANE; e < nH; e += UHC_WAVE) H[e] = 0.0;
         wsync();
-        for (int j = LANE; j < n; j += UHC_WAVE) H[hcol(j, n)] = 1.0;
-        wsync();
-        primal_chain_pass<TIER, true>(A, S, nefc, Yb, anc_tab, pair_tab, stY, cw, cf, pp, vec, H, n);
-        primal_dense_scatter<TIER>(A, S, LC, Db, cf, vec);
-        {   // dense rows, UHC_PRIMAL_DGROUP at a time: lane = row index i of the Hessian (its own y_i of the group's rows in registers), columns j in
-            // turn: the column is contiguous in i, D y_j of every row of the group comes by one broadcast LDS read from the staged copy
-            int k = 0;
-#ifdef UHC_PRIMAL_GUARD
-            int guard2 = 0;
-#endif
-            while (k < nslot) {
-#ifdef UHC_PRIMAL_GUARD
-                if (++guard2 > 1024) { if (LANE == 0) printf("k_primal: dense loop stuck at slot %d of %d\n", k, nslot); break; }
-#endif
-                DofVec y[UHC_PRIMAL_DGROUP];
-                int got = 0;
-#pragma unroll
-                for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) { y[s2].a = y[s2].b = 0.0; }
-                while (k < nslot && got < UHC_PRIMAL_DGROUP) {
-                    const int rid = __builtin_amdgcn_readfirstlane(NI[4 + k]);
-                    const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)act, rid & 63);
-                    if ((bits >> (rid >> 6)) & 1u) {
-                        const double* Dk = Db + (size_t)k * A.nvp;
-                        const double ya = LC.v0 ? Dk[LANE] : 0.0, yb = LC.v1 ? Dk[LANE + UHC_WAVE] : 0.0, dd = Dr[rid];
-#pragma unroll
-                        for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) if (s2 == got) { y[s2].a = ya; y[s2].b = yb; }
-                        if (LC.v0) dstage[LANE * UHC_PRIMAL_DGROUP + got] = dd * ya;   // [dof][row of the group]: one 64-byte line per column j
-                        if (LC.v1) dstage[(LANE + UHC_WAVE) * UHC_PRIMAL_DGROUP + got] = dd * yb;
-                        got++;
-                    }
-                    k++;
-                }
-                if (got == 0) break;
-                for (int g = got; g < UHC_PRIMAL_DGROUP; g++) {  // (unused places of the last group: zero multipliers)
-                    if (LC.v0) dstage[LANE * UHC_PRIMAL_DGROUP + g] = 0.0;
-                    if (LC.v1) dstage[(LANE + UHC_WAVE) * UHC_PRIMAL_DGROUP + g] = 0.0;
-                }
-                wsync();
-                const int ib = min(LANE + UHC_WAVE, n - 1);
-                int base = 0;  // hcol(j) - j
-                for (int j = 0; j < n; j++) {
-                    double yj[UHC_PRIMAL_DGROUP];
-#pragma unroll
-                    for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) yj[s2] = dstage[j * UHC_PRIMAL_DGROUP + s2];
-                    double ha = H[base + LANE], hb = H[base + ib];
-#pragma unroll
-                    for (int s2 = 0; s2 < UHC_PRIMAL_DGROUP; s2++) { ha = fma(yj[s2], y[s2].a, ha); hb = fma(yj[s2], y[s2].b, hb); }
-                    if (LANE >= j && LC.v0) H[base + LANE] = ha;
-                    if (LANE + UHC_WAVE >= j && LC.v1) H[base + LANE + UHC_WAVE] = hb;
-                    base += n - j - 1;
-                }
-                wsync();
-            }
-        }
-        }
+        PROF(37)
+        // ---- gradient u + sum_active D jar Yhat -- and, without a factor to keep, the Hessian I + sum_active D Yhat Yhat^T in the same pass over the rows
+        if (have_factor) { primal_post<NW>(C, PCMD_GRAD); primal_grad_hess<NW, false>(C, 0, vec, u); }
+        else { primal_post<NW>(C, PCMD_GRAD_HESS); primal_grad_hess<NW, true>(C, 0, vec, u); }
+        PROF(38)
         DofVec x;
         x.a = LC.v0 ? vec[LANE] : 0.0; x.b = LC.v1 ? vec[LANE + UHC_WAVE] : 0.0;
         const double gn = sqrt(wave_sum(x.a * x.a + x.b * x.b));
         if (g0 < 0) g0 = gn;
         PROF(31)
         if (gn <= 1e-14 * g0 || gn == 0.0) { ok = true; break; }
-        // ---- left-looking Cholesky H = C C^T, two columns per pass (primal_chol2); the diagonal keeps 1 / C_jj
-        if (!have_factor)
-            for (int j = 0; j < n; j += 2) {
-                if (j < UHC_WAVE) primal_chol2<true>(H, n, j); else primal_chol2<false>(H, n, j);
-                wsync();  // (the next pair reads what other lanes wrote here)
-            }
+        // ---- Cholesky H = C C^T (primal_chol); the diagonal keeps 1 / C_jj
+        if (!have_factor) { primal_post<NW>(C, PCMD_CHOL); primal_chol<NW>(H, n, 0); }
         have_factor = true;
         act_prev = act;
         PROF(26)
@@ -467,7 +588,8 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
         wsync();
         PROF(27)
         // ---- exact line search along dir: phi'(alpha) = u . dir + alpha |dir|^2 + sum_r D_r min(0, jar_r + alpha p_r) p_r
-        primal_row_dots<TIER>(A, S, nefc, LC, Yb, Db, anc_tab, vec, pp, nullptr);
+        primal_post<NW>(C, PCMD_DOTS_DIR_P);
+        primal_row_dots<NW>(C, 0, vec, pp, nullptr);
         const double ua = LC.v0 ? u[LANE] : 0.0, ub = LC.v1 ? u[LANE + UHC_WAVE] : 0.0;
         const double lin0 = wave_sum(ua * x.a + ub * x.b), quad = wave_sum(x.a * x.a + x.b * x.b);
         if (quad <= 1e-26 * (1.0 + wave_sum(ua * ua + ub * ub))) { ok = true; it++; break; }  // a step below the rounding of u: converged
@@ -499,9 +621,6 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
         PROF(28)
         if (same && !wave_or(flip)) { ok = true; it++; break; }
     }
-#ifdef UHC_PRIMAL_GUARD
-    if (LANE == 0 && (it >= 20 || !ok)) printf("k_primal: env block %d nefc %d nslot %d: %d iterations, ok %d, g0 %.3e\n", (int)blockIdx.x, nefc, nslot, it, (int)ok, g0);
-#endif
     // ---- forces (z = u is in place)
     int na = 0;
     for (int r = LANE; r < nefc; r += UHC_WAVE) { const double x = jar[r]; cf[r] = x < 0 ? -Dr[r] * x : 0.0; na += x < 0 ? 1 : 0; }

@@ -370,19 +370,30 @@ class AgentPG(Agent):
         wire = getattr(self, "grad_wire_dtype", None) or plist[0].dtype
         if self._flat_grad is None:
             self._flat_grad = {}
-        buf = self._flat_grad.get(slot)
-        if buf is None or buf.numel() != total or buf.dtype != wire:
-            buf = self._flat_grad[slot] = torch.empty(total, dtype=wire, device=plist[0].device)
-        off = 0
-        for ps, n in params_and_scale:
-            for p in ps:
-                if p.grad is None:
-                    continue
-                k = p.numel()
-                buf[off:off + k] = (p.grad.reshape(-1) * float(n)).to(wire)
-                off += k
-        for i, (_, n) in enumerate(params_and_scale):
-            buf[off + i] = float(n)  # (sample counts up to 2^24 per rank are exact in float32)
+        cached = self._flat_grad.get(slot)
+        key = tuple(id(p) for p in plist)
+        if cached is None or cached[0].numel() != total or cached[0].dtype != wire or cached[2] != key:
+            # the wire buffer and, once, the parameter-shaped views into it: packing and unpacking are then a handful of multi-tensor launches
+            # (`torch._foreach_*`: one horizontally fused kernel per group) instead of two small launches per parameter -- 16 per exchange, 20
+            # exchanges per update, which an 8-GPU step that SURVEY 8e calls latency-bound would see
+            buf = torch.empty(total, dtype=wire, device=plist[0].device)
+            views, off = [], 0
+            for ps, _ in params_and_scale:
+                group = []
+                for p in ps:
+                    if p.grad is None:
+                        continue
+                    group.append(buf[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+                views.append(group)
+            cached = self._flat_grad[slot] = (buf, views, key)
+        buf, views, _ = cached
+        off = total - len(params_and_scale)
+        for (ps, n), group in zip(params_and_scale, views):
+            grads = [p.grad for p in ps if p.grad is not None]
+            if grads:
+                torch._foreach_copy_(group, torch._foreach_mul(grads, float(n)))  # (the copy casts to the wire's dtype)
+        buf[off:].copy_(torch.tensor([float(n) for _, n in params_and_scale], dtype=wire), non_blocking=True)  # (sample counts up to 2^24 per rank are exact in float32)
         ev = None
         if getattr(self, "time_comm", False) and buf.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -401,14 +412,12 @@ class AgentPG(Agent):
             self._comm_events = getattr(self, "_comm_events", [])
             self._comm_events.append((ev[0], ev[1], buf.numel() * buf.element_size(), mid))
         counts = buf[off:off + len(params_and_scale)]
-        off = 0
-        for i, (ps, _) in enumerate(params_and_scale):
-            for p in ps:
-                if p.grad is None:
-                    continue
-                k = p.numel()
-                p.grad.copy_((buf[off:off + k].to(p.grad.dtype) / counts[i].to(p.grad.dtype).clamp(min=1.0)).view_as(p.grad))
-                off += k
+        views = next(v for b, v, _ in self._flat_grad.values() if b is buf)
+        for i, ((ps, _), group) in enumerate(zip(params_and_scale, views)):
+            grads = [p.grad for p in ps if p.grad is not None]
+            if grads:
+                torch._foreach_copy_(grads, group)  # (back to the parameters' dtype first: the division is the reference's float64 one)
+                torch._foreach_div_(grads, counts[i].to(grads[0].dtype).clamp(min=1.0))
 
     def comm_summary(self):
         """(calls, total ms, mean bytes per call) of the gradient all-reduces timed since the last summary (time_comm = True).  An interval runs
@@ -467,11 +476,11 @@ class AgentPPO(AgentPG):
         self.policy_grad_clip = policy_grad_clip
 
     def update_policy(self, states, actions, returns, advantages, exps):
-        """agent_ppo.py:16-51, full-batch branch (use_mini_batch is False for every copycat config)."""
-        if self.use_mini_batch:
-            raise NotImplementedError("mini-batch PPO is not used by AgentCopycat (agent_copycat.py:95-96)")
+        """agent_ppo.py:16-51: the full-batch branch (every copycat config) and the mini-batch one (`use_mini_batch`, :23-43)."""
         with to_test(*self.update_modules), torch.no_grad():
             fixed_log_probs = self.policy_net.get_log_prob(self.trans_policy(states), actions)
+        if self.use_mini_batch:
+            return self._update_policy_mini_batch(states, actions, returns, advantages, fixed_log_probs, exps)
         ind = exps.nonzero(as_tuple=False).squeeze(1)
         self.last_losses = []
         fused = _dist_on() and self.value_opt_niter == 1 and getattr(self, "fuse_grad_exchange", True)
@@ -510,6 +519,36 @@ class AgentPPO(AgentPG):
             self.clip_policy_grad()
             self.optimizer_policy.step()
             self.last_losses.append((vl, surr_loss.detach()))
+
+    def _update_policy_mini_batch(self, states, actions, returns, advantages, fixed_log_probs, exps):
+        """agent_ppo.py:23-43.  Per optimisation epoch: a permutation of the batch drawn from numpy's GLOBAL generator (`np.random.shuffle`) and applied to the
+        ALREADY permuted arrays (the reference reassigns its arguments: the permutations compose over the epochs), then floor(N / mini_batch_size) steps --
+        the ragged tail is dropped -- each a value step on the mini-batch followed by a surrogate step on its `exps != 0` rows.  Data-parallel: every
+        rank permutes its own rows, the ranks take the same number of steps (the fewest any rank has) and exchange gradients in every one of them."""
+        self.last_losses = []
+        mbs = self.mini_batch_size
+        for _ in range(self.opt_num_epochs):
+            perm = np.arange(states.shape[0])
+            np.random.shuffle(perm)
+            perm = torch.as_tensor(perm, dtype=torch.long, device=states.device)
+            states, actions, returns, advantages, fixed_log_probs, exps = (v[perm].clone() for v in (states, actions, returns, advantages, fixed_log_probs, exps))
+            n_it = int(math.floor(states.shape[0] / mbs))
+            if _dist_on():
+                t = torch.tensor([n_it], device=states.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                n_it = int(t.item())
+            for i in range(n_it):
+                sl = slice(i * mbs, min((i + 1) * mbs, states.shape[0]))
+                states_b, actions_b, advantages_b, returns_b, fixed_b, exps_b = states[sl], actions[sl], advantages[sl], returns[sl], fixed_log_probs[sl], exps[sl]
+                ind = exps_b.nonzero(as_tuple=False).squeeze(1)
+                vl = self.update_value(states_b, returns_b)
+                surr_loss = self.ppo_loss(states_b, actions_b, advantages_b, fixed_b, ind)
+                self.optimizer_policy.zero_grad()
+                surr_loss.backward()
+                self._allreduce_grads([([p for p in self.policy_net.parameters() if p.requires_grad], ind.shape[0])])
+                self.clip_policy_grad()
+                self.optimizer_policy.step()
+                self.last_losses.append((vl, surr_loss.detach()))
 
     def clip_policy_grad(self):
         if self.policy_grad_clip is not None:
