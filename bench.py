@@ -111,7 +111,11 @@ def valu_f64_counters(kernel, tag=""):
     if not all(k in c for k in need):
         return None
     flop = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
-    return {"flop_per_launch": flop, "counters": {k: v for k, v in c.items() if "F64" in k or k == "SQ_INSTS_VALU"}, "source": os.path.basename(f)}
+    # active lanes: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = lanes switched on per VALU cycle, averaged over ALL VALU instructions of the
+    # kernel (the counters do not split it by type): flop x that / 64 is the estimate of the useful flops beside the every-lane-counts upper bound
+    lanes = (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU") else None
+    return {"flop_per_launch": flop, "active_lanes_per_valu_cycle": lanes, "flop_per_launch_active_lanes": (flop * min(lanes, 64.0) / 64.0) if lanes else None,
+            "counters": {k: v for k, v in c.items() if "F64" in k or k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")}, "source": os.path.basename(f)}
 
 
 def alu_per_env_step(name):
@@ -733,6 +737,10 @@ def main():
                          "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": tflops / 78.6,
                          "flop_per_launch": flop_launch, "flop_source": (vc["source"] + ": 64 x (ADD + MUL + TRANS + 2 FMA) f64 wave-instructions of this kernel, per launch") if vc else "estimate (SURVEY 8d: ~20 MFLOP per env-step)",
                          "counters_per_launch": vc["counters"] if vc else None,
+                         # `frac` counts every f64 wave-instruction at 64 lanes (an upper bound); the same with the counters' average of lanes switched on per VALU cycle:
+                         "active_lanes_per_valu_cycle": vc["active_lanes_per_valu_cycle"] if vc else None,
+                         "flop_per_launch_active_lanes": vc["flop_per_launch_active_lanes"] if vc else None,
+                         "frac_active_lanes": (vc["flop_per_launch_active_lanes"] / (kern_ms * 1e-3) / 1e12 / 78.6) if vc and vc["flop_per_launch_active_lanes"] else None,
                          "kernel_ms": kern_ms, "launches": kern_n, "kernel_only_env_steps_per_s": n_env / (kern_ms * 1e-3),
                          "rocprofv3_avg_ms": rocprof_avg_ms(kname, tag)[0] if n_env == 1024 else None, "rocprofv3_source": rocprof_avg_ms(kname, tag)[1] if n_env == 1024 else None,
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -29,7 +29,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UHC_ABI_VERSION 9  /* 9: UHC_F_REDO bits 29 / 30 (tier 4), swept-substep bits 8 .. 28; uhc_rollout_record counts int64 [7] */
+#define UHC_ABI_VERSION 10  /* 10: uhc_build_flags; 9: UHC_F_REDO bits 29 / 30 (tier 4), swept-substep bits 8 .. 28; uhc_rollout_record counts int64 [7] */
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
@@ -141,11 +141,17 @@ enum UhcField {
     UHC_F_TIER = 17,         /* int32 [n_env] 1 | 2 | 3 | 4: the tier the env's next step starts in under uhc_batch_set_kernel_path(2) */
     UHC_F_HANDON_WHY = 18    /* int32 [n_env] diagnostic of the last step: bits 0-7 why the fast tier handed the env on, bits 8-15 why the general tier did
                               * (1 contacts, 2 constraint rows, 4 body-body row slots, 8 packed row storage, 16 MPR candidate list beyond the tier's
-                              * capacity), bits 16+ the substep of the last hand-on; 0 = the env stayed in the tier it started in */
+                              * capacity, 32 the working sets did not finish: more force-carrying rows in an island than a working set holds), bits 16-23 the
+                              * substep of the last hand-on, bits 24-31 why the LARGE tier handed the env on to tier 4 (the same reason bits);
+                              * 0 = the env stayed in the tier it started in */
 };
 
 const char* uhc_last_error(void);
 int32_t uhc_abi_version(void);
+/* Which kind of build the library is: bit 0 = the solver's measurement switches (UHC_DEBUG bits 8-12) are compiled in (-DUHC_EXPERIMENTS, tools/ builds only),
+ * bit 1 = per-stage cycle counters (-DUHC_STAGE_PROF), bit 2 = poisoned LDS, bit 3 = LDS guard words.  0 for the shipped library: a stray UHC_DEBUG cannot
+ * change which solver path an env takes (tests/test_capi_symbols.py). */
+int32_t uhc_build_flags(void);
 
 /* model lifetime (host side) */
 int32_t uhc_model_create(const UhcModelDesc* desc, UhcModel** out);

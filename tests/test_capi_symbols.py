@@ -30,6 +30,21 @@ def test_header_symbols_are_exported_and_listed():
     L.uhc_abi_version.restype = ctypes.c_int32
     header = open(os.path.join(ROOT, "include", "uhc_amd.h")).read()
     assert L.uhc_abi_version() == int(re.search(r"#define UHC_ABI_VERSION (\d+)", header).group(1))
+    # the shipped library is a release build: no measurement switches (UHC_DEBUG bits 8-12 are compiled out and masked), no stage counters, no poison / guards
+    L.uhc_build_flags.restype = ctypes.c_int32
+    assert L.uhc_build_flags() == 0
+
+
+def test_experiment_switches_exist_only_behind_the_build_flag():
+    """UHC_DEBUG bits 8-12 (working-set fill, consumer cap, sticky tier 4) change which envs report windows / sweeps: every read of them in the kernels goes
+    through UHC_EXP(bit), which is `false` unless the library is built with -DUHC_EXPERIMENTS, and the host masks the bits otherwise."""
+    csrc = os.path.join(ROOT, "uhc_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".hip", ".cpp")):
+            txt = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+            for m in re.finditer(r"dbg\s*&\s*(0x[0-9a-fA-F]+|\d+)", txt):
+                bit = int(m.group(1), 0)
+                assert bit & 0x1f00 == 0 or (f == "uhc_capi.cpp" and "UHC_EXPERIMENTS" in txt[max(0, m.start() - 400):m.end() + 400]), (f, m.group(0))
 
 
 def test_product_package_never_imports_the_oracle():

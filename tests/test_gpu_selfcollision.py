@@ -458,7 +458,7 @@ def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing
     from uhc_amd.model.shapes import box_triangles
     from uhc_amd.sim import make_ctrl
     if sticky4:
-        monkeypatch.setenv("UHC_DEBUG", "4096")  # (bit 12: the env starts its next step in tier 4, at the head of its consumers' queue; not the default -- uhc_device.h)
+        monkeypatch.setenv("UHC_T4_ROWS", "200")  # (an env whose step peaked at 200 rows or more starts its next step in tier 4, at the head of its consumers' queue -- KernelArgs::t4_rows)
     K = 7
     m = self_collision_variant(model)
     yaw = [0.06 * (-1) ** k for k in range(K)]

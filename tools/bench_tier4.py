@@ -1,7 +1,10 @@
 """Tier 4 alone: a batch of humanoids face down beside the seven-box raft (tests/test_gpu_selfcollision.py: 300-330 rows, 150+ with a force), every env
 of it beyond the large tier from the first forward pass on -- per-control-step wall time (HIP events are the fast tier's; here the whole step is
 synchronised) and, on the instrumented library (UHC_LIB=uhc_amd/csrc/libuhc_amd_prof.so), the stage cycles of the Newton iteration.
-    python tools/bench_tier4.py [n_env] [steps]"""
+    python tools/bench_tier4.py [n_env] [steps]
+KPATH=2: sticky tiers -- after the first step every env starts in the large tier, whose consumers hand it to tier 4's FOUR-WAVE consumers (uhc_k_huge_q.hip);
+give them a workgroup per env (UHC_Q4_MAX=128) to time the four-wave Newton iteration itself.  Default: the tier chain (tier 4 on one wave, behind the large
+tier's workgroup)."""
 import dataclasses
 import os
 import sys
@@ -36,6 +39,8 @@ for e in range(n):
     qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
     q[e, :76] = qh
 b = S.SimBatch(m, ctrl, n)
+if os.environ.get("KPATH"):
+    b.set_kernel_path(int(os.environ["KPATH"]))
 b.set_state(torch.from_numpy(q), torch.zeros(n, m.nv, dtype=torch.float64))
 b.sync()
 print(f"{n} envs, nv {m.nv}; after set_state: nefc mean {b.field(S.F_NEFC).float().mean().item():.0f} max {int(b.field(S.F_NEFC).max().item())}, Newton iterations of that pass mean "

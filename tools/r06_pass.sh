@@ -27,7 +27,7 @@ P
 for stage in "$@"; do
 case $stage in
 t4_tests)
-  (timeout 1200 python -m pytest tests/test_gpu_selfcollision.py tests/test_gpu_env_objects.py -m gpu -q --tb=short -rs -s -k "tier_4 or solved_exactly or drops_rows or lying or objects" 2>&1 | grep -v amdgpu | tail -60) > ${O}_tier4_pytest.txt 2>&1
+  (timeout 700 python -m pytest tests/test_gpu_selfcollision.py tests/test_gpu_env_objects.py -m gpu -q --tb=short -rs -s -k "tier_4 or solved_exactly or drops_rows or lying or objects" 2>&1 | grep -v amdgpu | tail -60) > ${O}_tier4_pytest.txt 2>&1
   tail -30 ${O}_tier4_pytest.txt | cut -c1-300 ;;
 t4_bench)
   timeout 300 python tools/bench_tier4.py 128 6 2>&1 | grep -v amdgpu > ${O}_bench_tier4_new.txt; cat ${O}_bench_tier4_new.txt | cut -c1-260
@@ -54,6 +54,16 @@ ab_headline)
     python -c "import json,sys; d=json.load(open('${O}_headline_${v}.json')); print('headline $v:', round(d['value']), 'ms', round(d['ms_per_step'],2), 'kernel ms', d['roofline'].get('kernel_ms_per_launch'))"
   done
   unset UHC_LIB ;;
+sweep_t4rows)
+  # UHC_T4_ROWS (KernelArgs::t4_rows): from how many rows on an env of the general / large tier starts its NEXT step in tier 4 (0: never)
+  for v in ${T4ROWS:-0 96 128 160 200 256}; do
+    for pr in ${PROBES:-configs4 ball_rollout}; do
+      UHC_T4_ROWS=$v timeout 300 python bench.py --only-probe $pr --probe-reps 2 > ${O}_t4rows${v}_${pr}.json 2>> ${O}_probe.err
+      probe_line ${O}_t4rows${v}_${pr}.json "UHC_T4_ROWS=$v $pr"
+    done
+    UHC_T4_ROWS=$v timeout 300 python bench.py --steps 40 --warmup 5 --no-probes --no-cpu-baseline --no-ppo --no-pgs-probe > ${O}_t4rows${v}_headline.json 2>> ${O}_probe.err
+    python -c "import json,sys; d=json.load(open('${O}_t4rows${v}_headline.json')); w=d['workload_stats']; print('UHC_T4_ROWS=$v headline:', round(d['value']), 'ms', round(d['ms_per_step'],2), 'kernel ms', round(d['roofline']['kernel_ms'],2), 'tier4 env-steps', w['tier4_primal_newton_env_steps_timed_region'], 'general/large', w['general_or_large_tier_env_steps_timed_region'])"
+  done ;;
 *)
   bash tools/r05_pass.sh "$TAG" "$stage" ;;
 esac

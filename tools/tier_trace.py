@@ -44,6 +44,14 @@ def analyze(prof, n, step, lines):
         wait = ms[h2, 4] - ms[h2, 3]
         lines.append(f"handed on by tier 2: {h2.sum()} envs; at substep (mean) {t[h2, 7].mean():.1f}; hand-on time {np.percentile(ms[h2, 3], [0, 50, 100]).round(2).tolist()} ms;"
                      f" wait for a consumer {np.percentile(wait, [0, 50, 100]).round(2).tolist()} ms")
+    t4 = prof[:, 21:24].cpu().numpy().astype(np.float64)  # tier 4's own stamps (taken up, let go) and the substep at which the large tier handed the env on
+    m4 = t4[:, 0] > 0
+    if m4.any():
+        s4, e4 = (t4[m4, 0] - t0) * 1e-5, (t4[m4, 1] - t0) * 1e-5
+        lines.append(f"tier 4: {int(m4.sum()):4d} envs | start {np.round(np.sort(s4), 2).tolist()} | end {np.round(np.sort(e4), 2).tolist()} | duration {np.round(np.sort(e4 - s4), 2).tolist()} ms"
+                     f" | handed on by the large tier at substep {t4[m4, 2].astype(int).tolist()}")
+        end = np.where(m4, np.fmax(end, (t4[:, 1] - t0) * 1e-5), end)
+        lines.append(f"        (with tier 4's envs the step ends at {np.nanmax(end):.2f} ms)")
     full = prof[:, :16].cpu().numpy().astype(np.float64)
     for tier, o in ((2, 8), (3, 12)):
         c = full[:, o:o + 4]

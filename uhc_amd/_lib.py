@@ -13,7 +13,7 @@ _lib = None
 
 # every symbol include/uhc_amd.h declares
 SYMBOLS = [
-    "uhc_last_error", "uhc_abi_version", "uhc_model_create", "uhc_model_free", "uhc_model_nM",
+    "uhc_last_error", "uhc_abi_version", "uhc_build_flags", "uhc_model_create", "uhc_model_free", "uhc_model_nM",
     "uhc_batch_create", "uhc_batch_free", "uhc_batch_set_stream", "uhc_batch_sync", "uhc_batch_set_rfc_scale",
     "uhc_batch_field", "uhc_batch_set_state", "uhc_batch_simulate", "uhc_batch_forward", "uhc_batch_set_timing",
     "uhc_batch_kernel_time", "uhc_batch_set_overflow_mode", "uhc_batch_set_solver", "uhc_batch_set_kernel_path",
@@ -41,6 +41,8 @@ def lib():
     P = C.c_void_p
     L.uhc_last_error.restype = C.c_char_p
     L.uhc_abi_version.restype = C.c_int32
+    if hasattr(L, "uhc_build_flags"):  # (ABI 10; tools/ A/B runs load older builds through UHC_LIB)
+        L.uhc_build_flags.restype = C.c_int32
     L.uhc_model_create.argtypes = [C.POINTER(UhcModelDesc), C.POINTER(P)]
     L.uhc_model_free.argtypes = [P]
     L.uhc_model_free.restype = None

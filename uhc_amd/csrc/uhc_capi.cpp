@@ -66,6 +66,24 @@ static int fail(const char* fmt, ...) {
 
 extern "C" const char* uhc_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t uhc_abi_version(void) { return UHC_ABI_VERSION; }
+// what kind of build this library is: bit 0 = the solver's measurement switches are compiled in (-DUHC_EXPERIMENTS: UHC_DEBUG bits 8-12 act), bit 1 = stage
+// cycle counters (-DUHC_STAGE_PROF), bit 2 = poisoned LDS (-DUHC_POISON_LDS), bit 3 = LDS guard words (-DUHC_GUARD_LDS).  The shipped library returns 0.
+extern "C" int32_t uhc_build_flags(void) {
+    int32_t f = 0;
+#ifdef UHC_EXPERIMENTS
+    f |= 1;
+#endif
+#ifdef UHC_STAGE_PROF
+    f |= 2;
+#endif
+#ifdef UHC_POISON_LDS
+    f |= 4;
+#endif
+#ifdef UHC_GUARD_LDS
+    f |= 8;
+#endif
+    return f;
+}
 
 // ------------------------------------------------------------------ model (host copy)
 struct UhcModel {
@@ -472,6 +490,9 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (T.nM > 64 * 24) { delete b; return fail("uhc_batch_create: nM %d > 1536 (the register tile that carries M between substeps)", T.nM); }
     A.nvp = (nv + 1) & ~1;
     { const char* dbg = getenv("UHC_DEBUG"); A.dbg = dbg ? atoi(dbg) : 0; if (guard_on) A.dbg |= 2; }
+#ifndef UHC_EXPERIMENTS
+    A.dbg &= ~0x1f00;  // bits 8-12 (working-set fill, consumer cap, sticky tier 4) are measurement switches of tools/ builds: the shipped library does not read them
+#endif
     {   // sticky-tier marks: an env goes up a tier when it no longer fits (64 rows / 16 contacts / 12 body-body rows; the general tier's
         // capacities) and comes down again at 56 / 14 / 10 and at 7/8 of the general tier's.  Going up EARLIER (at 3/4 of a capacity, so
         // that no env finds out in mid-step) was measured on the self-colliding rollout: 51-55 k env-steps/s against 57 k -- the envs
@@ -799,6 +820,8 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
     if (const char* q = getenv("UHC_Q2_MAX")) b->q2_max = std::max(16, atoi(q));
     if (const char* q = getenv("UHC_Q3_MAX")) b->q3_max = std::max(2, atoi(q));
     if (const char* q = getenv("UHC_Q4_MAX")) b->q4_max = std::max(0, atoi(q));
+    A.t4_rows = 0;
+    if (const char* q = getenv("UHC_T4_ROWS")) A.t4_rows = std::max(0, atoi(q));
     TRY(dalloc(b, 3 * E, &b->d_lists)); TRY(dalloc(b, 8, &b->d_counts)); TRY(dalloc(b, 8, &b->d_cursors)); TRY(dalloc(b, 8, &b->d_fin));
     { std::vector<int> one(E, 1); HIP_OK(hipMemcpy(S.tier, one.data(), E * sizeof(int), hipMemcpyHostToDevice)); } TRY(dalloc(b, E, &S.fresh)); TRY(dalloc(b, E * 40, &S.prof)); TRY(dalloc(b, E * nv, &S.bias)); TRY(dalloc(b, E * d.nu, &S.ctrl));
     TRY(dalloc(b, E * nv, &S.applied));
@@ -1018,7 +1041,12 @@ static int launch(UhcBatch* b, int mode, const double* d_action, const double* d
         const int s1 = std::max(1, std::min(4, (int)(160 * 1024 / std::max<size_t>(b->lds_bytes_fast, 1))));
         const int est1 = std::max(0, b->n_env - est2 - est3);
         const int bal = (int)(((long long)est2 * s1 * b->n_cu) / std::max(1, est1 + (est2 * s1) / 2));
-        const int cap2 = (b->A.dbg & 2048) ? b->q2_max : std::max(b->q2_max, std::min((7 * bal) / 8, (3 * b->n_cu) / 2));
+#ifdef UHC_EXPERIMENTS
+        const bool fixed_cap2 = (b->A.dbg & 2048) != 0;  // (measurement switch: a fixed cap UHC_Q2_MAX on the general tier's consumers)
+#else
+        const bool fixed_cap2 = false;
+#endif
+        const int cap2 = fixed_cap2 ? b->q2_max : std::max(b->q2_max, std::min((7 * bal) / 8, (3 * b->n_cu) / 2));
         const int grid2 = waiting ? std::min(est2 / b->q2_div + 8, cap2) : std::min(est2 + est2 / 4 + 8, std::min(b->n_env, std::max(64, room2)));
         K.sticky_mask = (queues ? 4 : 0) | (q3 ? 8 : 0) | (launch4 ? 16 : 0);
         const bool q4 = launch4 && q3;

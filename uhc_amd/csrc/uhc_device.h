@@ -131,7 +131,7 @@ struct DevState {  // HBM, env-major
 // host (which sizes the region) and in every wave of the workgroup (the helper waves of the four-wave consumer build their own view of it).
 #define UHC_PRIMAL_WAVES 4       // waves of a tier-4 queue consumer (uhc_k_huge_q.hip); the one-workgroup-per-env kernels run the same stages on one wave
 #define UHC_PRIMAL_CLS_STRIDE 144  // entries of one ownership class of the pair table: sum_{q < 32} (q / 4 + 1)
-struct PrimalScratch { int anc, stY, dstage, pair_all, pair_cls, pair_cnt, cw, mbx, total; };
+struct PrimalScratch { int anc, stY, dstage, pair_all, pair_cls, pair_cnt, cw, mbx, part, runs, total; };
 __host__ __device__ inline PrimalScratch primal_scratch(int nv, int YS) {
     PrimalScratch p;
     int o = 0;
@@ -144,6 +144,8 @@ __host__ __device__ inline PrimalScratch primal_scratch(int nv, int YS) {
     p.pair_cnt = take((4 * 33 + 3) / 4);                  // shorts [4][33]: pairs of a class with q < len
     p.cw = take(UHC_PRIMAL_WAVES * 32);                   // per wave [2][16]: coefficients and weights of the run
     p.mbx = take(4);                                      // ints [8]: the command the helper waves read behind the barrier
+    p.part = take(UHC_PRIMAL_WAVES * 128);                // per wave [128]: partial sums of a scatter whose rows are dealt out to the waves
+    p.runs = take(UHC_HUGE_MAXEFC / 2);                   // ints [maxefc]: the runs of chain rows (primal_run_table)
     p.total = o;
     return p;
 }
@@ -193,9 +195,11 @@ struct KernelArgs {
     int* cnt4;            // sticky tiers: bumped once per env the large tier hands on to tier 4 (the host sizes the tier-4 consumers of the next steps by it), or NULL
     int grid;  // workgroups of a list launch (0: one per env)
     int marks[8];  // sticky tiers: when an env starts its next step a tier up / down (uhc_step_env; UHC_TIER_MARKS)
+    int t4_rows;   // sticky tiers: an env of the general / large tier whose step peaked at this many rows or more starts its NEXT step in tier 4, at the head of the
+                   // four-wave consumers' queue, and stays there while it peaks above 3/4 of the mark (0: never; UHC_T4_ROWS)
     int truncate;  // fast kernel: drop contacts / rows beyond its capacity instead of handing the env to the general kernel
     int ball_limits;  // the model has limited ball joints: the fast tier launches its DENSE instantiation (which carries the ball-limit rows)
-    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step, bit 7 = no box cull of the convex pairs, bit 8 (256) = the general tier's first working set is NOT filled by rank (k_as_general; A/B of DESIGN 2), bits 9 / 10 (512 / 1024) = fill 48 / 56 lanes instead of 64, bit 11 (2048) = fixed cap UHC_Q2_MAX on the general tier's consumers (launch()).  bit 12 (4096) = sticky tier 4: an env whose step ended in tier 4 starts its next step there, at the head of the tier-4 consumers' queue (uhc_capi.cpp launch(); measured and not the default, see uhc_step_env).  Bits 8-11 change which envs report windows / sweeps in UHC_F_REDO: measurement switches, never set in a parity run
+    int dbg;                 // debug switches (UHC_DEBUG env var): bit 0 = working sets never merge islands, bit 1 = MPR vertices not staged in LDS, bit 2 = a handed-on env restarts its step instead of resuming at the substep, bit 3 = sticky fast tier launches in env order, bit 4 = tier trace in the stage-profile record, bit 5 = no gate before the fast tier's launch, bit 6 = log the queue lengths and the gate's wait per step, bit 7 = no box cull of the convex pairs, bit 8 (256) = the general tier's first working set is NOT filled by rank (k_as_general; A/B of DESIGN 2), bits 9 / 10 (512 / 1024) = fill 48 / 56 lanes instead of 64, bit 11 (2048) = fixed cap UHC_Q2_MAX on the general tier's consumers (launch()).  bit 12 (4096) = sticky tier 4: an env whose step ended in tier 4 starts its next step there, at the head of the tier-4 consumers' queue (uhc_capi.cpp launch(); measured and not the default, see uhc_step_env).  Bits 8-12 change which envs report windows / sweeps in UHC_F_REDO: measurement switches that exist only in libraries built with -DUHC_EXPERIMENTS (tools/ A/B builds) -- the shipped library compiles their reads out (UHC_EXP in uhc_physics_impl.h) and masks the bits (uhc_capi.cpp); uhc_build_flags() bit 0 tells which kind a library is
     int nvp;                 // stride of a dense row (nv rounded up to 2 doubles)
     int adjdeg;              // stride of the per-model hull adjacency table (largest vertex degree over the batch's models)
     DevCtrl c;

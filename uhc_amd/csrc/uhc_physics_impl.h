@@ -36,6 +36,14 @@ extern __shared__ __attribute__((aligned(16))) double smem[];
 #define PROF_PASS
 #define PROF(i)
 #endif
+// Measurement switches of the solver (UHC_DEBUG bits 8-10 and 12: working-set fill, sticky tier 4) exist only in libraries built with -DUHC_EXPERIMENTS
+// (tools/ A/B builds); the shipped library compiles them out -- a stray environment variable cannot change which envs report windows / sweeps
+// (uhc_build_flags() bit 0 says which kind a library is; tests/test_capi_symbols.py asserts the shipped one is not).
+#ifdef UHC_EXPERIMENTS
+#define UHC_EXP(bit) ((A.dbg & (bit)) != 0)
+#else
+#define UHC_EXP(bit) false
+#endif
 // Three tiers of one kernel: TIER 1 = fast (compact LDS, <= 64 rows, Delassus matrix in registers), TIER 2 = general (<= 128 rows, working
 // sets, two workgroups per CU), TIER 3 = large (<= 256 rows, a whole CU's LDS).  A tier that cannot hold an env leaves it untouched and
 // hands it to the next one; only the last tier of a batch (KernelArgs::last_tier) drops what exceeds it and flags the env.
@@ -1476,7 +1484,7 @@ struct FastRow { int type, last, len, yoff, two /* dense slot or -1 */; double R
 // finite data and meet Y = 0.  The finished rows are also stored to LDS (packed) for the A build of the other lanes.
 #define UHC_YM 32
 template <bool DENSE>
-__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int& nefc, FastRow& row, double (&Y)[UHC_YM], const LaneConst& LC) {
+__device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb, double* S, int& nefc, FastRow& row, double (&Y)[UHC_YM], const LaneConst& LC, int* ytot) {
     const DevTopo& T = A.t;
     const DevLds& L = A.lf;
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
@@ -1494,6 +1502,7 @@ __device__ __forceinline__ int k_rows_fast(const KernelArgs& A, const double* mb
     row.len = (valid && !two) ? T.dof_depth[rm.last] + 1 : 0;
     int total, status = 0;
     row.yoff = wave_excl_scan(row.len, &total);
+    *ytot = total;
     row.R = 1; row.b = 0; row.f = 0; row.floss = 0; row.diag = 1;
     if (total + 8 > A.cf.ycap) {
         if (!A.truncate) return 1;
@@ -2119,7 +2128,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
     int rk[NRL];
 #pragma unroll
     for (int h = 0; h < NRL; h++) rk[h] = 0;
-    if (!(A.dbg & 256)) {
+    if (!UHC_EXP(256)) {
 #pragma unroll
         for (int h2 = 0; h2 < NRL; h2++) {
             const int n2 = min(UHC_WAVE, nefc - h2 * UHC_WAVE);
@@ -2135,7 +2144,7 @@ __device__ __forceinline__ int k_as_general(const KernelArgs& A, const double* m
 #pragma unroll
         for (int h = 0; h < NRL; h++) rk[h] = 1 << 20;
     }
-    const int nfill = (A.dbg & 512) ? 48 : (A.dbg & 1024) ? 56 : UHC_WS_FILL;  // (UHC_DEBUG bits 9 / 10: experiments)
+    const int nfill = UHC_EXP(512) ? 48 : UHC_EXP(1024) ? 56 : UHC_WS_FILL;  // (UHC_DEBUG bits 9 / 10: experiments)
 #pragma unroll
     for (int h = 0; h < NRL; h++) fpos[h] = fpos[h] || (vv[h] && rk[h] < nfill);  // from here on: the first candidates
     wsync();  // (the dense rows' Delassus columns may live where the contacts were: nothing reads the contacts from here on)
@@ -2391,7 +2400,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
 #endif
 
 // ------------------------------------------------------------------ mj_forward
-struct FwdOut { int ncon, nefc, iters, overflow, nact; };  // nact (tier 4): rows that carry a force at the optimum  // overflow bit 0: the env does not fit this tier => redone by the next one
+struct FwdOut { int ncon, nefc, iters, overflow, nact, ytot; };  // ytot (fast tier): packed Yhat entries the pass's rows take  // nact (tier 4): rows that carry a force at the optimum  // overflow bit 0: the env does not fit this tier => redone by the next one
 // LDS guard words (debug builds, -DUHC_GUARD_LDS on top of -DUHC_POISON_LDS; the host lays them out with UHC_GUARD_LDS=1 -- uhc_capi.cpp): two doubles after
 // every region, holding the poison pattern; kind 0 = after the persistent regions (poisoned once per env with the rest of the LDS), kind 1 = after the
 // regions of the constraint phase (armed when the dynamics temporaries that overlay them are dead, checked when the forward pass returns)
@@ -2425,7 +2434,7 @@ template <int TIER, bool DENSE>
 __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* mb, double* S, const LaneConst& LC, const BodyConst& BC, const PairConst& PC, MPark& MP, const int env PROF_ARGS) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
-    FwdOut out = {0, 0, 0, 0, 0};
+    FwdOut out = {0, 0, 0, 0, 0, 0};
     k_kinematics<TIER>(A, mb, S, BC PROF_PASS);
     PROF(1)
     k_com_pos<TIER>(A, mb, S, BC);
@@ -2450,7 +2459,7 @@ __device__ __forceinline__ FwdOut k_forward(const KernelArgs& A, const double* m
         if constexpr (TIER == 1) {
             FastRow row;
             double Yreg[UHC_YM];
-            const int st = k_rows_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
+            const int st = k_rows_fast<DENSE>(A, mb, S, out.nefc, row, Yreg, LC, &out.ytot);  // 1: needs the general kernel, 2: rows dropped (truncate mode)
             out.overflow |= st | (st == 1 ? UHC_WHY_ROW_STORAGE : 0);
             if (st == 1) return out;
             PROF(9)
@@ -2727,7 +2736,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
     // tier trace (UHC_DEBUG bit 4, product builds; tools/tier_trace.py): when each tier took the env up and let it go (100 MHz wall clock)
     // and the substep of a hand-on, in the first words of the env's stage-profile record
 #ifndef UHC_STAGE_PROF
-#define TRACE(slot, v) if (MODE == 0 && TIER < 4 && (A.dbg & 16) && LANE == 0) A.s.prof[(size_t)env * UHC_NPROF + (slot)] = (long long)(v);
+#define TRACE(slot, v) if (MODE == 0 && (A.dbg & 16) && LANE == 0) A.s.prof[(size_t)env * UHC_NPROF + (TIER < 4 ? (slot) : 21 + ((slot) & 1))] = (long long)(v);  // (tier 4's stamps: words 21 / 22; the substep at which the large tier handed on: word 23)
 #else
 #define TRACE(slot, v)
 #endif
@@ -2782,7 +2791,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
         agpr_put(MP.lo[m], __double2loint(v)); agpr_put(MP.hi[m], __double2hiint(v));
     }
     wsync();
-    FwdOut fo = {0, 0, 0, 0, 0};
+    FwdOut fo = {0, 0, 0, 0, 0, 0};
     int it = 0;
     int overflow = 0, swept = 0;  // swept: bit 8 + k = substep k of this step was solved by the sweeps (general kernel, solver 1)
     bool ran = false, fits = true;  // fits (general / large tier): every substep of this step was within the fast kernel's capacity
@@ -2847,6 +2856,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
                 const int ntwo = (DENSE && cap_of<TIER>(A).ndense > 0) ? ((const int*)(S + L.ncon_nefc))[2] : 0;
                 pk_nefc = max(pk_nefc, fo.nefc); pk_ncon = max(pk_ncon, fo.ncon); pk_ntwo = max(pk_ntwo, ntwo); pk_act = max(pk_act, fo.nact);
                 if (TIER != 1 && fo.nefc > 0) pk_y = max(pk_y, ((const int*)(S + L.rowY))[fo.nefc]);
+                if (TIER == 1) pk_y = max(pk_y, fo.ytot);
             }
             ran = true;
             if (it < 0) {  // mj_forward alone leaves qacc_warmstart (zero after the reset) for the first real substep
@@ -2873,7 +2883,7 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             }
             for (int i = LANE; i < T.nu; i += UHC_WAVE) A.s.ctrl[(size_t)env * T.nu + i] = S[L.ctrl + i];
             if (LANE == 0) A.s.resume[env] = it;
-            TRACE(5 + TIER, it)
+            TRACE(TIER < 3 ? 5 + TIER : 23, it)
             __threadfence();  // (the queue append below publishes the env: its state must be visible first)
         }
         if (LANE == 0) {
@@ -2933,6 +2943,11 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
     }
 #endif
     TRACE(2 * (TIER - 1) + 1, wall_clock64())
+    double vmax_end = 0.0;  // largest |qvel| at the end of the step (the launch order of the next one)
+    if (MODE == 0) {
+        for (int i = LANE; i < T.nv; i += UHC_WAVE) vmax_end = fmax(vmax_end, fabs(S[L.qvel + i]));
+        vmax_end = -wave_min(-vmax_end);
+    }
     if (LANE == 0) {
         if (ran) { A.s.ncon[env] = fo.ncon; A.s.nefc[env] = fo.nefc; A.s.solver_iter[env] = fo.iters; }
         A.s.fail[env] = fail;
@@ -2963,9 +2978,20 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             // OPT-IN (UHC_DEBUG bit 12): measured on the random-policy ball-joint rollouts it LOSES -- configs[4] 41.6 k -> 27.1 k env-steps/s: the envs that
             // reach tier 4 there are diverging ones that reset within two or three steps, a reset env then runs its first step in tier 4 too, and a whole step of
             // primal solves costs more than the large-tier attempt it saves -- so by default such an env starts its next step in the large tier.
-            if (TIER == 4 && (A.dbg & 4096) && A.last_tier == 4 && !(pk_nefc <= (3 * A.ch.maxefc) / 4 && pk_ncon <= (3 * A.ch.maxcon) / 4 && pk_ntwo <= (3 * A.ch.ndense) / 4 && pk_act <= 48)) next = 4;
+            // Heavy envs go STRAIGHT to tier 4 (round 6): the four-wave Newton iteration on the primal costs the same whatever the number of rows, while a
+            // general- or large-tier env-step grows with every working-set round -- and the step's slowest env is what a control step waits for.  An env
+            // whose step peaked at KernelArgs::t4_rows rows or more starts its next step at the head of tier 4's queue and stays while it peaks above 3/4 of that.
+            if (A.last_tier == 4 && A.t4_rows > 0 && ((TIER == 2 || TIER == 3) ? pk_nefc >= A.t4_rows : (TIER == 4 && 4 * pk_nefc >= 3 * A.t4_rows))) next = 4;
+            if (TIER == 4 && UHC_EXP(4096) && A.last_tier == 4 && !(pk_nefc <= (3 * A.ch.maxefc) / 4 && pk_ncon <= (3 * A.ch.maxcon) / 4 && pk_ntwo <= (3 * A.ch.ndense) / 4 && pk_act <= 48)) next = 4;
             A.s.tier[env] = next;
-            A.s.cost[env] = max(pk_nefc, max((pk_ncon * UHC_FAST_MAXEFC) / max(A.cf.maxcon, 1), (pk_ntwo * UHC_FAST_MAXEFC) / max(A.cf.ndense, 1)));
+            // the fast tier's launch order (uhc_tier_lists_kernel): how close the step came to ANY of the fast tier's capacities, in sixty-fourths -- rows, contacts,
+            // body-body rows and (round 6) the packed row storage, which names 2 of 3 hand-ons of the ball-joint rollouts (tools/tier_trace.py) -- and at the top of
+            // the scale an env whose joints spin faster than any tracked motion's: a simulation on its way to the bad-value flag piles up rows within a few
+            // substeps, goes through every tier and ends the step if it starts in the launch's last round (profiles/r06_b_tier_trace_configs4.txt)
+            int cost = max(pk_nefc, max((pk_ncon * UHC_FAST_MAXEFC) / max(A.cf.maxcon, 1), (pk_ntwo * UHC_FAST_MAXEFC) / max(A.cf.ndense, 1)));
+            cost = max(cost, (int)(((long long)pk_y * UHC_FAST_MAXEFC) / max(A.cf.ycap, 1)));
+            if (vmax_end > 60.0) cost = max(cost, UHC_FAST_MAXEFC); else if (vmax_end > 30.0) cost = max(cost, 40);
+            A.s.cost[env] = cost;
         }
         if (TIER != 1) A.s.redo[env] = 1 | ((overflow & 4) ? 2 : 0) | ((overflow >> 1) & 0x3c) | (TIER >= 3 ? 0x40 : 0) | ((overflow & 2) ? 0x80 : 0) | swept |
                                        ((overflow & 128) ? (1 << 30) : 0) | ((overflow & 256) ? (1 << 29) : 0);

@@ -34,7 +34,8 @@
 //   * Cholesky: right-looking in panels of UHC_PRIMAL_NB columns: wave 0 factorises the panel in registers (lane = row), all waves share the
 //     trailing update column by column.
 // The one-workgroup-per-env kernels (set_state's forward pass, the chained launches) run the SAME stage functions on their one wave (NW = 1: it owns
-// everything); every word of H and of the gradient receives the same additions in the same order whatever NW is, so the two forms agree to the bit.
+// everything); every word of H receives the same additions in the same order whatever NW is; a gradient is summed per wave over the rows dealt to it and the
+// partial sums are added in wave order, so the two forms agree to rounding (1e-16 relative), not to the bit.
 #define UHC_PRIMAL_MAXIT 100
 #define UHC_PRIMAL_LS_MAXIT 60
 #define UHC_PRIMAL_DGROUP 8  // dense rows per pass over the Hessian
@@ -47,6 +48,14 @@
 #endif
 enum { PCMD_EXIT = 0, PCMD_SCATTER_U, PCMD_DOTS_U_JAR, PCMD_GRAD, PCMD_GRAD_HESS, PCMD_CHOL, PCMD_DOTS_DIR_P };
 
+// 1 / sqrt(x) to full double precision without the IEEE sqrt + division sequences (~170 cycles together, on the column-to-column critical path of the
+// factorisation and of the rank-one updates): v_rsq_f64 + three Newton steps in fused form (e = 1 - x r^2; r += r e / 2)
+__device__ __forceinline__ double rsqrt_newton(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const double e = fma(-x * r, r, 1.0); r = fma(0.5 * r, e, r); }
+    return r;
+}
 // packed lower triangle, column by column: column j holds rows j .. n-1
 __device__ __forceinline__ int hcol(int j, int n) { return j * n - (j * (j - 1)) / 2; }
 // all waves of the workgroup (NW > 1: a real barrier; the one-wave kernels: the wave-local fence every other stage uses)
@@ -54,10 +63,11 @@ template <int NW> __device__ __forceinline__ void mw_barrier() { if constexpr (N
 
 struct PrimalCtx {
     const RowMisc* RM; const int* RY; const int* NI; const int* dof_depth;
-    int YS, n, nvp, nefc, nslot;
+    int YS, n, nvp, nefc, nslot, nruns;
     double *u, *vec, *jar, *pp, *Dr, *cf, *H, *dsc;
     const double* bb;
-    short* anc_tab; double *stY, *dstage, *cw;
+    short* anc_tab; double *stY, *dstage, *cw, *part;
+    int* runs;
     unsigned short *pair_all, *pair_cls, *pair_cnt;
     int* mbx;
     const double *Yb, *Db;
@@ -84,6 +94,8 @@ __device__ __forceinline__ PrimalCtx primal_ctx(const KernelArgs& A, double* S, 
     C.anc_tab = (short*)(X + ps.anc); C.stY = X + ps.stY; C.dstage = X + ps.dstage; C.cw = X + ps.cw;
     C.pair_all = (unsigned short*)(X + ps.pair_all); C.pair_cls = (unsigned short*)(X + ps.pair_cls); C.pair_cnt = (unsigned short*)(X + ps.pair_cnt);
     C.mbx = (int*)(X + ps.mbx);
+    C.part = X + ps.part; C.runs = (int*)(X + ps.runs);
+    C.nruns = 0;  // (k_primal: after primal_run_table; the helpers: from the mailbox)
     C.Yb = Yb; C.Db = Db;
     return C;
 }
@@ -133,41 +145,94 @@ __device__ __forceinline__ void primal_row_dots(const PrimalCtx& C, int wid, con
 
 // The chain rows' share of a scatter (vec += sum_r c_r Yhat_r) and of the Hessian (H += sum_r w_r Yhat_r Yhat_r^T), WITHOUT atomics.  (A first version
 // let every lane push its own row's len^2 / 2 products into H with LDS float64 atomics: measured at ~12 cycles per lane and instruction, 1.3 M cycles per
-// Hessian.)  Rows that share a dof chain -- the 4 pyramid edges of a contact, all contacts of one hull: runs of up to 16 consecutive rows with the same
+// Hessian.)  Rows that share a dof chain -- the 4 pyramid edges of a contact, all contacts of one hull: RUNS of up to 16 consecutive rows with the same
 // last dof -- are taken TOGETHER: their entries are staged in the wave's own LDS strip ([16][32]), then lane = chain position q adds sum_t c_t y_t[q] to
 // vec[dof(q)], and lane = pair (q, q2) adds sum_t w_t y_t[q] y_t[q2] to H[dof(q)][dof(q2)] -- distinct addresses inside a run, and the LDS queue of the
-// wave keeps runs in order: plain read-modify-write.  With four waves every wave stages every run and takes the positions q with q & 3 == wid and the
-// pairs with q2 & 3 == wid (the class tables): the dof at chain position q has depth q, so these are exactly the words the wave owns.
+// wave keeps runs in order: plain read-modify-write.
+// The runs are a property of the rows, not of the iterate: k_primal tabulates them once per solve (primal_run_table).  A pass first marks the runs with a
+// non-zero coefficient or weight (lane = run, one ballot per 64 runs), then walks the marked ones with the NEXT run's entries already on their way from L2
+// into registers while the current one is added -- the first version paid one exposed L2 round trip per run, and that, not the arithmetic, was its cost
+// (four waves that each walked every run were no faster than one: profiles/r06_c_diag_tier4_configs4_*.txt).
+//   WITH_H (four waves): every wave walks every marked run and takes the positions q with q & 3 == wid and the pairs with q2 & 3 == wid (the class
+//     tables): the dof at chain position q has depth q, so these are exactly the words the wave owns -- no two waves touch the same word.
+//   gradient alone (four waves): the marked runs are DEALT OUT to the waves, every wave adds its runs into a partial vector of its own, and the stage
+//     function sums the partials in wave order behind a barrier.
+#define PRUN_R0(pk) ((pk) & 1023)
+#define PRUN_NB(pk) (((pk) >> 10) & 31)
+#define PRUN_LEN(pk) (((pk) >> 15) & 63)
+#define PRUN_LAST(pk) (((pk) >> 21) & 255)
+// wave 0, once per solve: runs[k] = r0 | nb << 10 | len << 15 | last dof << 21 for every run of chain rows; returns their number
+__device__ __forceinline__ int primal_run_table(const PrimalCtx& C) {
+    int nr = 0, r0 = 0;
+    while (r0 < C.nefc) {
+        const int rr = r0 + LANE;
+        int last_l = -2, two_l = 1;
+        if (LANE < 16 && rr < C.nefc) { const RowMisc rm = C.RM[rr]; last_l = rm.last; two_l = (rm.type & ROW_TWO) ? 1 : 0; }
+        const int last0 = __builtin_amdgcn_readfirstlane(last_l);
+        if (__builtin_amdgcn_readfirstlane(two_l)) { r0++; continue; }  // (dense rows: the stage function's own loops)
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(LANE < 16 && rr < C.nefc && !two_l && last_l == last0);
+        const int nb = __builtin_ctzll(~same);  // consecutive rows from r0 on with this chain (>= 1, <= 16)
+        const int len = __builtin_amdgcn_readfirstlane(C.RY[r0 + 1] - C.RY[r0]);
+        if (LANE == 0) C.runs[nr] = r0 | (nb << 10) | (len << 15) | (last0 << 21);
+        nr++;
+        r0 += nb;
+    }
+    return nr;
+}
 template <int NW, bool WITH_H>
 __device__ __forceinline__ void primal_chain_pass(const PrimalCtx& C, int wid, const double* c, const double* w, double* vec) {
     double* stY = C.stY + wid * (16 * 32);
     double* cw = C.cw + wid * 32;
     const unsigned short* ptab = NW == 1 ? C.pair_all : C.pair_cls + wid * UHC_PRIMAL_CLS_STRIDE;
-    const int n = C.n, nefc = C.nefc;
-    int r0 = 0;
-    while (r0 < nefc) {
-        const int rr = r0 + LANE;
-        int last_l = -2, two_l = 1;
-        if (LANE < 16 && rr < nefc) { const RowMisc rm = C.RM[rr]; last_l = rm.last; two_l = (rm.type & ROW_TWO) ? 1 : 0; }
-        const int last0 = __builtin_amdgcn_readfirstlane(last_l);
-        if (__builtin_amdgcn_readfirstlane(two_l)) { r0++; continue; }  // (dense rows: the stage function's own loops)
-        const unsigned long long same = __builtin_amdgcn_ballot_w64(LANE < 16 && rr < nefc && !two_l && last_l == last0);
-        const int nb = __builtin_ctzll(~same);  // the run's length: consecutive rows from r0 on with this chain (>= 1, <= 16)
-        double c_l = 0.0, w_l = 0.0;
-        if (LANE < nb) { c_l = c[rr]; if (WITH_H) w_l = w[rr]; }
-        if (__builtin_amdgcn_ballot_w64(c_l != 0.0 || w_l != 0.0)) {
-            const int len = __builtin_amdgcn_readfirstlane(C.RY[r0 + 1] - C.RY[r0]);
-            for (int idx = LANE; idx < nb * 32; idx += UHC_WAVE) {
-                const int t = idx >> 5, q = idx & 31;
-                if (q < len) stY[idx] = C.Yb[C.RY[r0 + t] + q];
+    const int n = C.n, nr = C.nruns;
+    int dealt = 0;  // gradient alone, NW > 1: marked runs seen so far (run k of them is wave k % NW's)
+    for (int rb = 0; rb < nr; rb += UHC_WAVE) {
+        // ---- which of these 64 runs contribute
+        int pk = 0;
+        bool any = false;
+        if (rb + LANE < nr) {
+            pk = C.runs[rb + LANE];
+            const int r0 = PRUN_R0(pk), nb = PRUN_NB(pk);
+            for (int t = 0; t < nb; t++) any = any || c[r0 + t] != 0.0 || (WITH_H && w[r0 + t] != 0.0);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(any);
+        if (!WITH_H && NW > 1) {  // this wave's share of the marked runs
+            unsigned long long mine = 0ull, mm = m;
+            while (mm) { const unsigned long long bit = mm & (0ull - mm); mm ^= bit; if ((dealt++ % NW) == wid) mine |= bit; }
+            m = mine;
+        }
+        if (!m) continue;
+        // ---- the marked runs in turn, the next one's entries in flight
+        double y[8];  // entries idx = LANE + 64 j of the run's [nb][32] strip
+        auto fetch = [&](int pkr) __attribute__((always_inline)) {
+            const int r0 = PRUN_R0(pkr), nb = PRUN_NB(pkr), len = PRUN_LEN(pkr);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                y[j] = 0.0;
+                if (2 * j < nb) {  // (wave-uniform: rows 2 j and 2 j + 1 of the run)
+                    const int t = 2 * j + (LANE >> 5), q = LANE & 31;
+                    if (t < nb && q < len) y[j] = C.Yb[C.RY[r0 + t] + q];
+                }
             }
+        };
+        int cur = __builtin_ctzll(m);
+        m &= m - 1;
+        int pkc = __builtin_amdgcn_readlane(pk, cur);
+        fetch(pkc);
+        for (;;) {
+            const int r0 = PRUN_R0(pkc), nb = PRUN_NB(pkc), len = PRUN_LEN(pkc), last0 = PRUN_LAST(pkc);
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (2 * j < nb) stY[LANE + UHC_WAVE * j] = y[j];
             // (the run's coefficients go through LDS, not v_readlane: the readers below sit in divergent branches -- lanes < len, lanes < np -- and a
             //  register the compiler spilled and reloads INSIDE such a branch holds garbage in the lanes the branch switched off, which are exactly the
             //  lanes a readlane of row t >= len would read.  The 552-spill instantiation <0, 3> of round 5 did that and produced NaNs.)
-            if (LANE < 16) { cw[LANE] = c_l; cw[16 + LANE] = w_l; }
+            if (LANE < 16) { cw[LANE] = LANE < nb ? c[r0 + LANE] : 0.0; cw[16 + LANE] = (WITH_H && LANE < nb) ? w[r0 + LANE] : 0.0; }
+            const bool more = m != 0ull;
+            int pkn = 0;
+            if (more) { const int nx = __builtin_ctzll(m); m &= m - 1; pkn = __builtin_amdgcn_readlane(pk, nx); fetch(pkn); }  // (y is free again: its values are on their way to LDS)
             wsync();
             const short* anc = C.anc_tab + last0 * C.YS;
-            if (LANE < len && (NW == 1 || (LANE & 3) == wid)) {
+            if (LANE < len && (!WITH_H || NW == 1 || (LANE & 3) == wid)) {
                 double sg = 0.0;
                 for (int t = 0; t < nb; t++) sg = fma(cw[t], stY[t * 32 + LANE], sg);
                 vec[anc[LANE]] += sg;
@@ -186,37 +251,72 @@ __device__ __forceinline__ void primal_chain_pass(const PrimalCtx& C, int wid, c
                 }
             }
             wsync();
+            if (!more) break;
+            pkc = pkn;
         }
-        r0 += nb;
     }
 }
 
-// One stage of a Newton iteration, run by every wave of the workgroup on the dofs it owns (NW == 1: all of them):
+// One stage of a Newton iteration, run by every wave of the workgroup:
 //     target = init (or 0) + sum_r cf_r Yhat_r          and, WITH_H,        H = I + sum_r pp_r Yhat_r Yhat_r^T
 // cf: the rows' coefficients (gradient: D jar of the active rows; start point: the warm-start forces), pp: their weights (D of the active rows, else 0).
+// WITH_H: every wave works on the dofs it OWNS (NW == 1: all of them) -- entries of target, columns of H.  Without: the rows are dealt out, every wave sums
+// its rows into its own partial vector, and the partials are added up in wave order.
 template <int NW, bool WITH_H>
 __device__ __forceinline__ void primal_grad_hess(const PrimalCtx& C, int wid, double* target, const double* init) {
     const int n = C.n;
     const bool v0 = LANE < n, v1 = LANE + UHC_WAVE < n;
     const int ia = min(LANE, n - 1), ib = min(LANE + UHC_WAVE, n - 1);
+    if constexpr (!WITH_H) {
+        double* part = C.part + wid * 128;
+        if (v0) part[LANE] = 0.0;
+        if (v1) part[LANE + UHC_WAVE] = 0.0;
+        wsync();
+        primal_chain_pass<NW, false>(C, wid, C.cf, C.pp, part);
+        {   // the dense rows' share: four rows per wave and round, lane = dof
+            double ga = 0.0, gb = 0.0;
+            for (int k0 = 4 * wid; k0 < C.nslot; k0 += 4 * NW) {
+                double ck[4], da[4], db[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k = min(k0 + j, C.nslot - 1);
+                    ck[j] = k0 + j < C.nslot ? C.cf[__builtin_amdgcn_readfirstlane(C.NI[4 + k])] : 0.0;
+                    const double* Dk = C.Db + (size_t)k * C.nvp;
+                    da[j] = v0 ? Dk[LANE] : 0.0; db[j] = v1 ? Dk[LANE + UHC_WAVE] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ga = fma(ck[j], da[j], ga); gb = fma(ck[j], db[j], gb); }
+            }
+            if (v0) part[LANE] += ga;
+            if (v1) part[LANE + UHC_WAVE] += gb;
+        }
+        mw_barrier<NW>();
+        for (int i = wid * 32 + (LANE & 31); i < n; i += 32 * NW) {  // (lanes 32-63 repeat lanes 0-31: the same value to the same word)
+            double sum = init ? init[i] : 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) sum += C.part[w2 * 128 + i];
+            target[i] = sum;
+        }
+        mw_barrier<NW>();
+        return;
+    } else {
     const bool own0 = v0 && (NW == 1 || (C.dof_depth[ia] & 3) == wid), own1 = v1 && (NW == 1 || (C.dof_depth[ib] & 3) == wid);
     const unsigned long long own_m[2] = {__builtin_amdgcn_ballot_w64(own0), __builtin_amdgcn_ballot_w64(own1)};
     if (own0) target[LANE] = init ? init[LANE] : 0.0;
     if (own1) target[LANE + UHC_WAVE] = init ? init[LANE + UHC_WAVE] : 0.0;
-    if (WITH_H) {  // the owned columns: zero below the diagonal, one on it
-        for (int h = 0; h < 2; h++) {
-            unsigned long long m = own_m[h];
-            while (m) {
-                const int j = UHC_WAVE * h + __builtin_ctzll(m);
-                m &= m - 1;
-                double* Hj = C.H + hcol(j, n) - j;
-                if (LANE >= j && v0) Hj[LANE] = LANE == j ? 1.0 : 0.0;
-                if (LANE + UHC_WAVE >= j && v1) Hj[LANE + UHC_WAVE] = LANE + UHC_WAVE == j ? 1.0 : 0.0;
-            }
+    // the owned columns: zero below the diagonal, one on it
+    for (int h = 0; h < 2; h++) {
+        unsigned long long m = own_m[h];
+        while (m) {
+            const int j = UHC_WAVE * h + __builtin_ctzll(m);
+            m &= m - 1;
+            double* Hj = C.H + hcol(j, n) - j;
+            if (LANE >= j && v0) Hj[LANE] = LANE == j ? 1.0 : 0.0;
+            if (LANE + UHC_WAVE >= j && v1) Hj[LANE + UHC_WAVE] = LANE + UHC_WAVE == j ? 1.0 : 0.0;
         }
     }
     wsync();
-    primal_chain_pass<NW, WITH_H>(C, wid, C.cf, C.pp, target);
+    primal_chain_pass<NW, true>(C, wid, C.cf, C.pp, target);
     {   // the dense rows' share of the scatter: lane = owned dof, four rows' loads in flight
         double ga = 0.0, gb = 0.0;
         for (int k0 = 0; k0 < C.nslot; k0 += 4) {
@@ -234,7 +334,7 @@ __device__ __forceinline__ void primal_grad_hess(const PrimalCtx& C, int wid, do
         if (own0) target[LANE] += ga;
         if (own1) target[LANE + UHC_WAVE] += gb;
     }
-    if (WITH_H) {
+    {
         // dense rows, UHC_PRIMAL_DGROUP at a time: lane = row index i of the Hessian (its own y_i of the group's rows in registers), the wave's columns j
         // in turn: the column is contiguous in i, D y_j of every row of the group comes by one broadcast LDS read from the staged copy (of which every
         // wave writes and reads the dofs it owns)
@@ -284,6 +384,7 @@ __device__ __forceinline__ void primal_grad_hess(const PrimalCtx& C, int wid, do
         }
     }
     mw_barrier<NW>();
+    }
 }
 
 // Cholesky H = C C^T of the packed Hessian, right-looking in panels of UHC_PRIMAL_NB columns; the diagonal keeps 1 / C_jj (H >= I: the pivots are >= 1 up
@@ -310,7 +411,7 @@ __device__ __forceinline__ void primal_chol(double* H, int n, int wid) {
                 if (p < nbk) {
                     const int j = jb + p;
                     DofVec col = {Pa[p], Pb[p]};
-                    const double rc = 1.0 / sqrt(dv_get_nb(col, j));
+                    const double rc = rsqrt_newton(dv_get_nb(col, j));
                     col.a *= rc; col.b *= rc;
                     Pa[p] = col.a; Pb[p] = col.b;
 #pragma unroll
@@ -357,26 +458,29 @@ __device__ __forceinline__ void primal_chol(double* H, int n, int wid) {
 // across jar = 0, the factor follows them instead of being rebuilt.  Returns false when a downdate loses positive definiteness to rounding
 // (r^2 <= 0): the caller rebuilds.  The diagonal holds 1 / C_kk throughout.  (Wave 0 alone.)
 __device__ __forceinline__ bool primal_chol_rank1(double* H, int n, DofVec x, double sigma) {
+    // With rd = 1 / C_kk (what the diagonal stores) and s = x_k rd:  r^2 = C_kk^2 q,  q = 1 + sigma s^2;  w = 1 / sqrt(q);  the rotation is c = q w, s;  the new
+    // column (C_ik + sigma s x_i) w, the new diagonal's reciprocal rd w, x_i <- c x_i - s C_ik(new): one reciprocal root per column and no division.  The next
+    // column is fetched while this one's chain (read -> root -> write) runs.
     const int ib = min(LANE + UHC_WAVE, n - 1);
     bool good = true;
     int base = 0;  // hcol(k) - k
+    double ca = H[base + LANE], cb = H[base + ib], rd = H[base + 0];  // column k (rows above the diagonal: in-range garbage, never stored)
     for (int k = 0; k < n; k++) {
-        const double ca = H[base + LANE], cb = H[base + ib], rd = H[base + k];  // column k (rows above the diagonal: in-range garbage, never stored)
-        const double xk = dv_get_nb(x, k);
-        const double ckk = 1.0 / rd;
-        const double r2 = fma(sigma * xk, xk, ckk * ckk);
-        good = good && (r2 > 0.0);
-        const double r = sqrt(r2 > 0.0 ? r2 : 1.0);
-        const double ic = ckk / r, sg = sigma * xk * rd;  // 1 / c,  sigma s
-        const double sx = xk * rd, c = r * rd;            // s, c
-        const double na = (ca + sg * x.a) * ic, nb = (cb + sg * x.b) * ic;
+        const int nbase = k + 1 < n ? base + n - k - 1 : base, kn = min(k + 1, n - 1);
+        const double na_ = H[nbase + LANE], nb_ = H[nbase + ib], nrd = H[nbase + kn];
+        const double sk = dv_get_nb(x, k) * rd;
+        const double q = fma(sigma * sk, sk, 1.0);
+        good = good && (q > 0.0);
+        const double w = rsqrt_newton(q > 0.0 ? q : 1.0);
+        const double c = q * w, sg = sigma * sk;
+        const double na = fma(sg, x.a, ca) * w, nb = fma(sg, x.b, cb) * w;
         if (LANE > k && LANE < n) H[base + LANE] = na;
         if (LANE + UHC_WAVE > k && LANE + UHC_WAVE < n) H[base + LANE + UHC_WAVE] = nb;
-        if (LANE == (k & 63)) { if (k < UHC_WAVE) H[base + k] = 1.0 / r; }
-        if (k >= UHC_WAVE && LANE + UHC_WAVE == k) H[base + k] = 1.0 / r;
-        x.a = fma(c, x.a, -sx * na);
-        x.b = fma(c, x.b, -sx * nb);
-        base += n - k - 1;
+        if (LANE == (k & 63)) { if (k < UHC_WAVE) H[base + k] = rd * w; }
+        if (k >= UHC_WAVE && LANE + UHC_WAVE == k) H[base + k] = rd * w;
+        x.a = fma(c, x.a, -sk * na);
+        x.b = fma(c, x.b, -sk * nb);
+        ca = na_; cb = nb_; rd = nrd; base = nbase;
     }
     wsync();
     return good;
@@ -405,7 +509,8 @@ __device__ __forceinline__ void primal_helper(const KernelArgs& A, double* S) {
         const int nefc = __builtin_amdgcn_readfirstlane(mbx[1]);
         const unsigned long long yb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbx[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbx[2]);
         const unsigned long long db = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbx[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbx[4]);
-        const PrimalCtx C = primal_ctx<TIER>(A, S, nefc, (const double*)yb, (const double*)db);
+        PrimalCtx C = primal_ctx<TIER>(A, S, nefc, (const double*)yb, (const double*)db);
+        C.nruns = __builtin_amdgcn_readfirstlane(mbx[6]);
         if (cmd == PCMD_SCATTER_U) primal_grad_hess<UHC_PRIMAL_NW, false>(C, wid, C.u, nullptr);
         else if (cmd == PCMD_DOTS_U_JAR) primal_row_dots<UHC_PRIMAL_NW>(C, wid, C.u, C.jar, C.bb);
         else if (cmd == PCMD_GRAD) primal_grad_hess<UHC_PRIMAL_NW, false>(C, wid, C.vec, C.u);
@@ -430,7 +535,7 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
     constexpr int NW = UHC_PRIMAL_NW;
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
-    const PrimalCtx C = primal_ctx<TIER>(A, S, nefc, Yb, Db);
+    PrimalCtx C = primal_ctx<TIER>(A, S, nefc, Yb, Db);
     const RowMisc* RM = C.RM;
     const int* RY = C.RY;
     const int YS = C.YS, n = C.n;
@@ -452,8 +557,9 @@ __device__ __forceinline__ int k_primal(const KernelArgs& A, const double* mb, d
             for (int q = c; q < LANE; q++) o += (q - c) / 4 + 1;
             C.pair_cnt[c * 33 + LANE] = (unsigned short)o;
         }
+    C.nruns = primal_run_table(C);
     if (NW > 1 && LANE == 0) {
-        C.mbx[1] = nefc;
+        C.mbx[1] = nefc; C.mbx[6] = C.nruns;
         C.mbx[2] = (int)((unsigned long long)Yb & 0xffffffffull); C.mbx[3] = (int)((unsigned long long)Yb >> 32);
         C.mbx[4] = (int)((unsigned long long)Db & 0xffffffffull); C.mbx[5] = (int)((unsigned long long)Db >> 32);
     }
