@@ -509,7 +509,8 @@ def test_more_rows_than_the_dual_tiers_hold_are_solved_by_tier_4(model, standing
         assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
         assert worst_q < 1e-9 and worst_v < 1e-7, (worst_q, worst_v)
         if mode == 2 and sticky4:  # opt-in: an env that needed tier 4 starts its next step there (its own launch from the head of the step once the host has seen the count)
-            assert (b.field(S.F_TIER).cpu().numpy() == 4).all(), b.field(S.F_TIER).tolist()
+            tiers, rows = b.field(S.F_TIER).cpu().numpy(), b.field(S.F_NEFC).cpu().numpy()
+            assert (tiers[rows >= 200] == 4).all() and (tiers == 4).any() and (tiers >= 3).all(), (tiers.tolist(), rows.tolist())
         b.close()
 
 

@@ -62,7 +62,7 @@ extern "C" hipError_t uhc_launch_set_state(const DevState* s, int nq, int nv, in
 // sticky tiers, head of a control step: snapshot of the tier table + the queues of the general / large tier, which start with the active
 // envs that begin the step there (lists[0 .. n_env) = tier 2, lists[n_env .. 2 n_env) = tier 3; counts[2], counts[3]; free slots = -1),
 // the cursors the persistent launches share and the producers' exit counters (fin[1]: fast tier's workgroups, fin[2]: general tier's)
-#define UHC_ORDER_BUCKETS 8
+#define UHC_ORDER_BUCKETS 9
 // (tier 4, `launch4` != 0: tier 4's queue consumers run this step; the envs whose last step ended in tier 4 (UHC_DEBUG bit 12 only) head their queue -- lists[2 n_env ..),
 //  counts[6] -- and are flagged pend3 = 2, "straight to tier 4"; with launch4 == 0 they are the large tier's like any tier-3 env and the snapshot says 3)
 __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int n_env, int* tier_now, int* lists, int* counts, int* cursors, int* fin,
@@ -83,11 +83,11 @@ __global__ void uhc_tier_lists_kernel(const int* tier, const int* d_active, int 
         if (tier[env] != 1 || (d_active && !d_active[env])) return UHC_ORDER_BUCKETS;
         // (an env restarted since its last step has no history: its reset pose may not fit the tier at all -- many do not -- and it is handed
         //  on in its first forward pass; at the head of the launch that happens while the next tier's consumers still have the step ahead)
-        if (fresh[env]) return 0;
+        if (fresh[env]) return 0;  // (a bucket of their own, ahead of everything: with the row storage in the cost, the next bucket holds hundreds of envs)
         // (round 6: the cost counts the packed row storage too, which on the ball-joint / object models puts most envs within an eighth of the capacity:
         //  the scale is fine where the hand-ons are -- an env that no longer fits in its first forward pass must not start in the launch's last round)
         const int c = cost[env];  // 0 .. 64+ (sixty-fourths of the capacity)
-        return c >= 62 ? 0 : c >= 59 ? 1 : c >= 56 ? 2 : c >= 52 ? 3 : c >= 48 ? 4 : c >= 40 ? 5 : c >= 24 ? 6 : 7;
+        return c >= 62 ? 1 : c >= 59 ? 2 : c >= 56 ? 3 : c >= 52 ? 4 : c >= 48 ? 5 : c >= 40 ? 6 : c >= 24 ? 7 : 8;
     };
     for (int env = threadIdx.x; env < n_env; env += blockDim.x) {
         int t = tier[env];
