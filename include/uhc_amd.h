@@ -245,7 +245,8 @@ typedef struct UhcEnv UhcEnv;
 typedef struct UhcEnvDesc {
     int32_t obs_v;               /* 2: get_full_obs_v2 (humanoid_im.py:419-503); 1: get_full_obs_v1 (:323-417); 6: get_full_obs_v6 (:596-666);
                                   * 3: get_full_obs_v3 (:758-767) = fut_frames v2 blocks, look-ahead 0, skip, 2 skip, ...;
-                                  * 5: get_full_obs_v5 (:505-594); 0: get_full_obs (:290-317), shaped by obs_flags */
+                                  * 5: get_full_obs_v5 (:505-594); 0: get_full_obs (:290-317), shaped by obs_flags;
+                                  * 4: get_full_obs_v4 (:769-861): its obs_full = global block (28) | shape (17) | one row of 26 per non-root body (hinge models) */
     int32_t has_shape;           /* append beta(16) + gender to the observation (humanoid_im.py:1390-1406) */
     int32_t env_episode_len;     /* cfg.env_episode_len */
     int32_t env_expert_trail_steps;

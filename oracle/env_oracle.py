@@ -150,6 +150,57 @@ def full_obs_v3(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, 
     return np.concatenate([full_obs_v2(qpos, qvel, xpos, xquat, expert, cur_t + i, start_ind, beta, gender, base_rot) for i in range(0, fut_frames * skip, skip)])
 
 
+def full_obs_v4(qpos, qvel, xpos, xquat, expert, cur_t, start_ind=0, beta=None, gender=None, base_rot=BASE_ROT):
+    """humanoid_im.py:769-861 (obs_coord='root', obs_vel='full'): the v2 quantities with the GLOBAL part (heading, root heights / quaternions, root velocity,
+    heading difference, relative root position -- here the real offset target_body_qpos[:3] - qpos[:3], not v2's slip --, shape) and the per-body LOCAL part
+    (one row of 26 per non-root body: target / current / difference of its three joint angles, its joint velocities, its position and its position error in the
+    root frame, its de-headed world quaternion, its quaternion error) separated.  Returns (obs_full, local_obs (23, 26), global_obs) like the reference."""
+    qpos, qvel = qpos.copy(), qvel.copy()
+    qvel[:3] = transform_vec(qvel[:3], qpos[3:7], "root")
+    curr_root_quat = remove_base_rot(qpos[3:7], base_rot)
+    hq = get_heading_q(curr_root_quat)
+    glob, loc = [hq], []
+    ind = expert_index(cur_t + 1, start_ind, expert["len"])
+    target_body_qpos = expert["qpos"][ind].copy()
+    target_quat = expert["wbquat"][ind].reshape(-1, 4)
+    target_jpos = expert["wbpos"][ind]
+    target_root_quat = remove_base_rot(target_body_qpos[3:7], base_rot)
+    qpos[3:7] = de_heading(curr_root_quat)
+    diff_qpos = target_body_qpos.copy()
+    diff_qpos[2] -= qpos[2]
+    diff_qpos[7:] -= qpos[7:]
+    diff_qpos[3:7] = quaternion_multiply(target_root_quat, quaternion_inverse(curr_root_quat))
+    glob += [target_body_qpos[2:7], qpos[2:7], diff_qpos[2:7]]
+    loc += [target_body_qpos[7:].reshape(-1, 3), qpos[7:].reshape(-1, 3), diff_qpos[7:].reshape(-1, 3)]
+    qvel[:3] = transform_vec(qvel[:3], curr_root_quat, "root")  # the second rotation, as in v2 (:805)
+    glob.append(qvel[:6])
+    loc.append(qvel[6:].reshape(-1, 3))
+    rel_h = get_heading(target_root_quat) - get_heading(curr_root_quat)
+    if rel_h > np.pi:
+        rel_h -= 2 * np.pi
+    if rel_h < -np.pi:
+        rel_h += 2 * np.pi
+    glob.append(np.array([rel_h]))
+    rel_pos = target_body_qpos[:3] - qpos[:3]
+    glob.append(transform_vec(rel_pos, curr_root_quat, "root")[:2])
+    curr_jpos = xpos[1:].copy()
+    r_jpos = transform_vec_batch(curr_jpos - qpos[None, :3], curr_root_quat, "root").T
+    loc.append(r_jpos.reshape(-1, 3)[1:, :])
+    diff_jpos = transform_vec_batch(target_jpos.reshape(-1, 3) - curr_jpos, curr_root_quat, "root").T
+    loc.append(diff_jpos.reshape(-1, 3)[1:, :])
+    cur_quat = xquat[1:].copy()
+    if cur_quat[0, 0] == 0:
+        cur_quat = target_quat.copy()
+    hq_inv = np.repeat(quaternion_inverse(hq)[None], cur_quat.shape[0], axis=0)
+    loc.append(quaternion_multiply_batch(hq_inv, cur_quat)[1:, :])
+    loc.append(quaternion_multiply_batch(quaternion_inverse_batch(cur_quat), target_quat)[1:, :])
+    if beta is not None:
+        glob.append(np.concatenate([beta, [gender]]))
+    local_obs = np.hstack(loc)
+    global_obs = np.concatenate(glob)
+    return np.concatenate([global_obs, local_obs.ravel()]), local_obs, global_obs
+
+
 def get_heading_new(q):
     return math.atan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] * q[2] + q[3] * q[3]))  # math_utils.py:185-190
 

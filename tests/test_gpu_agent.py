@@ -81,6 +81,34 @@ def test_single_env_facade_matches_batched_env(tmp_path):
     env.vec.close()
 
 
+def test_single_env_facade_hands_out_the_obs_v4_tuple(tmp_path):
+    """obs_v 4 (uhc/envs/humanoid_im.py:769-861; config/smpl_shape/copycat_disc_1.yml, config/bigfoot/bigfoot_10.yml): the env's observation is the reference's
+    obs_full, get_full_obs_v4() returns the reference's tuple (obs_full, local_obs, global_obs), and an agent iteration runs on it."""
+    import torch
+    from uhc_amd.agents import agent_dict
+    from uhc_amd.envs import env_dict
+    torch.set_default_dtype(torch.float64)
+    cfg = _cfg(tmp_path, n_env=8, batch=8 * 4)
+    cfg.obs_v = 4
+    dl = _loader(cfg)
+    np.random.seed(1)
+    env = env_dict["humanoid_im"](cfg, init_expert=dl.sample_seq(), data_specs=cfg.data_specs, mode="test")
+    assert env.observation_space.shape == (643,)
+    obs = env.reset()
+    obs, _, _, _ = env.step(np.zeros(105))
+    full, local, glob = env.get_full_obs_v4()
+    assert full.shape == (643,) and local.shape == (23, 26) and glob.shape == (45,)
+    np.testing.assert_array_equal(full, obs)
+    np.testing.assert_array_equal(np.concatenate([glob, local.ravel()]), full)
+    np.testing.assert_allclose(np.linalg.norm(local[:, 18:22], axis=1), 1.0, atol=1e-9)  # de-headed world quaternions of the 23 non-root bodies
+    np.testing.assert_allclose(local[:, 6:9], local[:, 0:3] - local[:, 3:6], atol=1e-14)  # joint-angle differences
+    env.vec.close()
+    agent = agent_dict[cfg.agent_name](cfg, torch.float64, torch.device("cuda", 0), data_loader=_loader(cfg, n=5))
+    agent.optimize_policy(0, save_model=False)
+    assert agent.env.obs_dim == 643
+    agent.env.close()
+
+
 def test_eval_policy_reports_reference_metrics(tmp_path):
     import torch
     from uhc_amd.agents import agent_dict

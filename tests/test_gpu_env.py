@@ -56,10 +56,12 @@ def _oracle_obs(E, obs_v, o, w, t, beta):
         return E.full_obs_v5(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)
     if obs_v == 0:
         return E.full_obs_v0(o.get("qpos"), o.get("qvel"), w, t, 0, obs_heading=True, root_deheading=True, obs_phase=True)
+    if obs_v == 4:
+        return E.full_obs_v4(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)[0]
     return E.full_obs_v2(o.get("qpos"), o.get("qvel"), xpos, xquat, w, t, 0, beta, 2.0)
 
 
-@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1), (3, 0), (5, 2), (0, 4), (2, 5), (2, 3)])
+@pytest.mark.parametrize("obs_v,reward_v", [(2, 0), (1, 0), (6, 1), (3, 0), (5, 2), (0, 4), (2, 5), (2, 3), (4, 0)])
 def test_env_rollout_matches_oracles(model, ctrl, obs_v, reward_v):
     _rollout_check(model, ctrl, obs_v, reward_v)
 
@@ -108,7 +110,7 @@ def _rollout_check(model, ctrl, obs_v, reward_v):
     gobs = eb.field(S.E_OBS).cpu().numpy()
     for e in range(n):
         np.testing.assert_allclose(gobs[e], _oracle_obs(E, obs_v, os_[e], wins[e], 0, beta), atol=1e-11)
-    assert eb.obs_dim == {2: 657, 1: 784, 6: 401, 3: 3 * 657, 5: 653, 0: 220}[obs_v]
+    assert eb.obs_dim == {2: 657, 1: 784, 6: 401, 3: 3 * 657, 5: 653, 0: 220, 4: 643}[obs_v]
     # ---- steps
     cur_t = np.zeros(n, dtype=int)
     alive = np.ones(n, dtype=bool)

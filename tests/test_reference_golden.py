@@ -241,6 +241,21 @@ def test_config_attributes_match_reference(tmp_path):
             np.testing.assert_allclose([cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr], [nr, ls, lr], rtol=1e-15, atol=0)
 
 
+def test_env_oracle_obs_v4():
+    """G4d: get_full_obs_v4 of the imported reference (uhc/envs/humanoid_im.py:769-861) -- the full vector, the (23, 26) local block and the global block."""
+    from oracle import env_oracle as E
+    g, f = load("g4d_obs_v4"), load("g3_qpos_fk")
+    expert = {k[2:]: f[k] for k in f.files if k.startswith("f_")}
+    expert["len"] = expert["qpos"].shape[0]
+    for c in range(int(g["ncase"])):
+        p, t = f"c{c}_", int(g[f"c{c}_cur_t"])
+        full, local, glob = E.full_obs_v4(g[p + "qpos"], g[p + "qvel"], g[p + "xpos"], g[p + "xquat"], expert, t, 0, g[p + "beta"], float(g["gender"]))
+        assert full.shape == (643,) and local.shape == (23, 26) and glob.shape == (45,)
+        np.testing.assert_allclose(full, g[p + "obs_full"], atol=1e-13)
+        np.testing.assert_allclose(local, g[p + "local_obs"], atol=1e-13)
+        np.testing.assert_allclose(glob, g[p + "global_obs"], atol=1e-13)
+
+
 def test_env_oracle_obs_v0_v5_and_remaining_rewards(model):
     """G4c: get_full_obs (v0), get_full_obs_v5 and the reward ids implicit_quat, v1_mul, explicit_mul, v2, v3 of the imported reference."""
     from oracle import env_oracle as E

@@ -20,6 +20,11 @@ from uhc_amd.model.mjcf import add_free_bodies, quat_mul, self_collision_variant
 from uhc_amd.model.shapes import box_triangles  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+# EXTRA=k (with KPATH=2): k more envs STANDING beside the raft -- with UHC_TIER_MARKS="16,4,2,8,2,1,8,7" they live in the general tier, so that the host starts the
+# queue consumers of every tier, and with UHC_T4_ROWS=200 UHC_Q4_MAX=<n> the face-down envs start every step in tier 4's four-wave consumers
+extra = int(os.environ.get("EXTRA", "0"))
+n_down = n
+n += extra
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 model = S.load_asset_model()
 z = np.load(os.path.join(ROOT, "uhc_amd", "assets", "standing_neutral.npz"))
@@ -34,9 +39,12 @@ q = np.tile(m.qpos0, (n, 1))
 for e in range(n):
     qh = z["qpos"].copy()
     qh[7:] += rng.normal(scale=0.02, size=69)
-    a = np.pi / 2 + 0.1 * rng.uniform(-1, 1)
-    qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])
-    qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+    if e < n_down:
+        a = np.pi / 2 + 0.1 * rng.uniform(-1, 1)
+        qh[3:7] = quat_mul(np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]), qh[3:7])
+        qh[0], qh[1], qh[2] = -0.8, -0.8, 0.14
+    else:
+        qh[0], qh[1] = -2.0, -2.0
     q[e, :76] = qh
 b = S.SimBatch(m, ctrl, n)
 if os.environ.get("KPATH"):
@@ -61,7 +69,7 @@ for t in range(steps):
           f"nefc (last substep) mean {b.field(S.F_NEFC).float().mean().item():.0f} max {int(b.field(S.F_NEFC).max().item())}; Newton iterations (last substep) mean "
           f"{b.field(S.F_SOLVER_ITER).float().mean().item():.1f} max {int(b.field(S.F_SOLVER_ITER).max().item())}")
 if prof:
-    p = b.field(S.F_STAGE_PROF).cpu().numpy().astype(np.float64) / steps
+    p = b.field(S.F_STAGE_PROF).cpu().numpy().astype(np.float64)[:n_down] / steps
     names = {0: "pd+rfc / torque", 1: "kinematics", 2: "com_pos", 3: "crb", 4: "factor", 5: "com_vel", 6: "rne", 7: "smooth", 8: "collision", 9: "rows (to HBM)",
              11: "solve: rest", 13: "qacc", 14: "euler", 15: "store", 30: "newton: start point (u0, jar0, cost)", 31: "newton: jar, gradient, Hessian build", 26: "newton: Cholesky",
              27: "newton: substitutions", 28: "newton: p = Yhat dir, line search", 32: "col: plane-mesh", 33: "col: cull", 34: "col: staging", 35: "col: MPR",

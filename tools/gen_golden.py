@@ -293,6 +293,28 @@ def g4c_more_variants(dm, feat):
     save("g4c_more_variants", **cases)
 
 
+def g4d_obs_v4():
+    """get_full_obs_v4 (uhc/envs/humanoid_im.py:769-861): the observation with its global and its per-body local part separated -- returns (obs_full, local_obs,
+    global_obs).  The expert features are those of fixture G3 (read back from it: nothing else is rewritten)."""
+    from uhc.envs.humanoid_im import HumanoidEnv
+    dm = DuckModel(MODEL)
+    g3 = np.load(os.path.join(OUT, "g3_qpos_fk.npz"))
+    feat = {k[2:]: g3[k] for k in g3.files if k.startswith("f_")}
+    rng = np.random.default_rng(1414)
+    cases = {}
+    for c, cur_t in enumerate([2, 11, 36]):
+        env = fake_env(dm, feat, rng, cur_t=cur_t)
+        env.expert["len"] = feat["qpos"].shape[0]
+        env.cc_cfg.update(obs_v=4)
+        full, local, glob = HumanoidEnv.get_full_obs_v4(env)
+        pre = f"c{c}_"
+        cases.update({pre + "cur_t": cur_t, pre + "qpos": env.data.qpos, pre + "qvel": env.data.qvel, pre + "xpos": env.data.body_xpos, pre + "xquat": env.data.body_xquat,
+                      pre + "obs_full": full, pre + "local_obs": local, pre + "global_obs": glob, pre + "beta": env.expert["beta"][0]})
+    cases["gender"] = env.expert["gender"][0]
+    cases["ncase"] = 3
+    save("g4d_obs_v4", **cases)
+
+
 # --------------------------------------------------------------------------- G5 stable PD + implicit residual force
 def g5_pd(dm, feat):
     from uhc.envs import humanoid_im
@@ -668,6 +690,7 @@ def main():
         return
     g8b_ppo_update()
     g14_ball_env()
+    g4d_obs_v4()  # (after g2_g3_expert in a full run would be tidier; it reads the committed G3 fixture, which a full run rewrites identically first below)
     g1_math()
     dm, qpos, feat = g2_g3_expert()
     g4_g6_obs_reward(dm, feat)

@@ -281,6 +281,59 @@ __global__ void __launch_bounds__(WAVE) uhc_env_post_kernel(EnvArgs E, const dou
             }
         }
         shape_base = o4 + 4 * (nb - 1);
+    } else if (E.obs_v == 4) {
+        // get_full_obs_v4 (:769-861): the v2 quantities with the global part first -- heading quaternion | target z + raw target root quaternion | z + de-headed
+        // root quaternion | dz + root quaternion difference | qvel[:6] (the first three rotated twice, as in v2) | heading difference | relative root position
+        // (here the real offset target_body_qpos[:3] - qpos[:3]) | shape -- and then one row of 26 per non-root body: target / current / difference of its three
+        // joint angles, its joint velocities, its position and position error in the root frame, hq^-1 x its world quaternion, its quaternion error.
+        const int LB = 28 + (E.has_shape ? 17 : 0);
+        heading_q(hq, crq);
+        qinv(hqi, hq);
+        qmat(Rr, rootq);
+        qmat(Rc, crq);
+        if (LANE == 0) {
+            double dh[4], ci[4], dr[4], v0[3], v1[3], rel[3], rl[3];
+            for (int k = 0; k < 4; k++) obs[k] = hq[k];
+            qmul(dh, hqi, crq);                      // de_heading(curr_root_quat)
+            qinv(ci, crq);
+            qmul(dr, trq, ci);
+            obs[4] = fr[UHC_FR_QPOS + 2]; obs[9] = s_qpos[2]; obs[14] = fr[UHC_FR_QPOS + 2] - s_qpos[2];
+            for (int k = 0; k < 4; k++) { obs[5 + k] = tq[k]; obs[10 + k] = dh[k]; obs[15 + k] = dr[k]; }
+            const double qv[3] = {qvel[0], qvel[1], qvel[2]};
+            rotT(v0, Rr, qv);
+            rotT(v1, Rc, v0);
+            for (int k = 0; k < 3; k++) { obs[19 + k] = v1[k]; obs[22 + k] = qvel[3 + k]; }
+            double rel_h = heading(trq) - heading(crq);
+            if (rel_h > M_PI) rel_h -= 2 * M_PI;
+            if (rel_h < -M_PI) rel_h += 2 * M_PI;
+            obs[25] = rel_h;
+            for (int k = 0; k < 3; k++) rel[k] = fr[UHC_FR_QPOS + k] - s_qpos[k];
+            rotT(rl, Rc, rel);
+            obs[26] = rl[0]; obs[27] = rl[1];
+        }
+        if (LANE >= 1 && LANE < nb) {
+            const int b = LANE;
+            double* row = obs + LB + 26 * (b - 1);
+            double d[3], r[3], cq[4], tb[4], o[4], ci[4];
+            for (int k = 0; k < 3; k++) {
+                const double t = fr[UHC_FR_QPOS + 7 + 3 * (b - 1) + k], c = s_qpos[7 + 3 * (b - 1) + k];
+                row[k] = t; row[3 + k] = c; row[6 + k] = t - c; row[9 + k] = qvel[6 + 3 * (b - 1) + k];
+            }
+            for (int k = 0; k < 3; k++) d[k] = xpos[3 * (b + 1) + k] - s_qpos[k];
+            rotT(r, Rc, d);
+            for (int k = 0; k < 3; k++) row[12 + k] = r[k];
+            for (int k = 0; k < 3; k++) d[k] = fr[UHC_FR_WBPOS + 3 * b + k] - xpos[3 * (b + 1) + k];
+            rotT(r, Rc, d);
+            for (int k = 0; k < 3; k++) row[15 + k] = r[k];
+            const bool unset = xquat[4] == 0.0;                                  // cur_quat[0, 0] == 0 (:839-840)
+            for (int k = 0; k < 4; k++) { tb[k] = fr[UHC_FR_WBQUAT + 4 * b + k]; cq[k] = unset ? tb[k] : xquat[4 * (b + 1) + k]; }
+            qmul(o, hqi, cq);
+            for (int k = 0; k < 4; k++) row[18 + k] = o[k];
+            qinv_batch(ci, cq);
+            qmul(o, ci, tb);
+            for (int k = 0; k < 4; k++) row[22 + k] = o[k];
+        }
+        shape_base = 28;
     } else if (E.ball) {
         // get_full_obs_v2_quat (:668-756), fed with the quaternion expert pose (the reference hands it the Euler one and raises):
         // [0:4] heading quaternion | target z, z, dz | inv(current quaternions, root without base rotation) x target quaternions (4 nb) |

@@ -53,7 +53,7 @@ static int dalloc(UhcEnv* e, size_t n, T** p) {
 
 extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out) {
     if (!b || !d || !out) return uhc_internal_set_error("uhc_env_create: null argument");
-    if (d->obs_v != 0 && d->obs_v != 1 && d->obs_v != 2 && d->obs_v != 3 && d->obs_v != 5 && d->obs_v != 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 0, 1, 2, 3, 5 or 6");
+    if (d->obs_v < 0 || d->obs_v > 6) return uhc_internal_set_error("uhc_env_create: obs_v must be 0 .. 6");
     if (d->obs_v == 3 && (d->fut_frames < 1 || d->fut_frames > 64 || d->fut_skip < 0)) return uhc_internal_set_error("uhc_env_create: obs_v 3 needs 1 <= fut_frames <= 64, skip >= 0");
     if (d->term_body != 0 && d->term_body != 1) return uhc_internal_set_error("uhc_env_create: term_body must be 0 (cfg.env_term_body 'body') or 1 ('root')");
     if (d->reward_v < 0 || d->reward_v > 5) return uhc_internal_set_error("uhc_env_create: reward_v must be 0 .. 5 (implicit, explicit, implicit_v1_mul, explicit_mul, implicit_v2, implicit_v3)");
@@ -84,6 +84,7 @@ extern "C" int32_t uhc_env_create(UhcBatch* b, const UhcEnvDesc* d, UhcEnv** out
         E.obs_dim = (d->obs_flags & 1) + (E.nqh - 2) + ((d->obs_flags & 8) ? 6 : E.nvh) + E.nu + ((d->obs_flags >> 2) & 1);
     else
         E.obs_dim = (d->obs_v == 6 ? 8 + E.nvh + 2 * nb + 11 * (nb - 1) : (d->obs_v == 5 ? 300 : 304) + (d->obs_v == 1 ? 20 : 14) * nb) + (d->has_shape ? 17 : 0);
+    if (d->obs_v == 4) E.obs_dim = 28 + 26 * (nb - 1) + (d->has_shape ? 17 : 0);  // get_full_obs_v4 (:769-861): global block | shape | one row of 26 per non-root body
     if (E.ball) E.obs_dim = 7 + 4 * nb + (E.nu + 6) + 3 + 6 * nb + 8 * nb + (d->has_shape ? 17 : 0);  // get_full_obs_v2_quat (:668-756)
     if (d->obs_v == 0) E.has_shape = 0;
     E.fut_frames = d->obs_v == 3 ? d->fut_frames : 1;

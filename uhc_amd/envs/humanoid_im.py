@@ -98,8 +98,10 @@ class VecHumanoidEnv:
         reward_v = REWARD_IDS.get(cfg.reward_id)
         if reward_v is None:
             raise NotImplementedError(f"reward_id {cfg.reward_id!r}: built are {sorted(REWARD_IDS)} (the local_rfc_* rewards are not)")
-        if cfg.obs_v == 4:
-            raise NotImplementedError("obs_v 4 returns a (full, local, global) tuple in the reference (humanoid_im.py:769-861), which AgentCopycat cannot consume")
+        # (obs_v 4, humanoid_im.py:769-861, returns a (obs_full, local_obs, global_obs) tuple in the reference, which its own observation_space / ZFilter cannot
+        #  consume; here the env's observation is obs_full -- global block | shape | one row of 26 per non-root body -- and HumanoidEnv.get_full_obs_v4 hands out the tuple)
+        if cfg.obs_v == 4 and cfg.get("robot_cfg", {}).get("ball", False):
+            raise NotImplementedError("obs_v 4 reads three hinge angles per body: not defined for the ball-joint humanoid")
         if cfg.obs_coord != "root" or (cfg.obs_v != 0 and cfg.obs_vel != "full"):
             raise NotImplementedError("obs_coord 'root' (every reference config) and, for obs_v >= 1, obs_vel 'full' are built")
         self.n_reward_parts = REWARD_PARTS[reward_v]
@@ -381,6 +383,15 @@ class HumanoidEnv(MujocoEnv):
                 "percent": float(self.vec.env.field(S.E_PERCENT)[0].item())}
         self.last_reward = (float(self.vec.reward[0].item()), self.vec.reward_parts[0].cpu().numpy())
         return self.vec.obs[0].cpu().numpy(), 1.0, bool(self.vec.done[0].item()), info
+
+    def get_full_obs_v4(self, delta_t=0):
+        """humanoid_im.py:769-861: (obs_full, local_obs (23, 26), global_obs).  The device kernel writes obs_full for the current step (cfg.obs_v == 4);
+        the two parts are cut out of it."""
+        if self.cc_cfg.obs_v != 4 or delta_t != 0:
+            raise NotImplementedError("get_full_obs_v4: the env computes it for cfg.obs_v == 4, delta_t == 0")
+        full = self.vec.obs[0].cpu().numpy().copy()
+        ng = full.shape[0] - 26 * (self.vec.body_lim - 2)
+        return full, full[ng:].reshape(-1, 26).copy(), full[:ng].copy()
 
     def get_expert_index(self, t):
         return min(self.start_ind + t, self.expert["len"] - 1)
