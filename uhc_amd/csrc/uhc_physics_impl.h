@@ -2982,6 +2982,8 @@ __device__ __forceinline__ int uhc_step_env(const KernelArgs& A, const double* _
             // general- or large-tier env-step grows with every working-set round -- and the step's slowest env is what a control step waits for.  An env
             // whose step peaked at KernelArgs::t4_rows rows or more starts its next step at the head of tier 4's queue and stays while it peaks above 3/4 of that.
             if (A.last_tier == 4 && A.t4_rows > 0 && ((TIER == 2 || TIER == 3) ? pk_nefc >= A.t4_rows : (TIER == 4 && 4 * pk_nefc >= 3 * A.t4_rows))) next = 4;
+            // (Sending SLOW envs there too -- by the duration of their last general-tier step -- was built and measured in round 6 and is gone again: a tier-4 env-step of a
+            //  60-80-row env is no shorter than its general-tier one, and a whole CU per env is what the fast tier's second round needs: profiles/r06_q_t4ticks_sweep.txt.)
             if (TIER == 4 && UHC_EXP(4096) && A.last_tier == 4 && !(pk_nefc <= (3 * A.ch.maxefc) / 4 && pk_ncon <= (3 * A.ch.maxcon) / 4 && pk_ntwo <= (3 * A.ch.ndense) / 4 && pk_act <= 48)) next = 4;
             A.s.tier[env] = next;
             // the fast tier's launch order (uhc_tier_lists_kernel): how close the step came to ANY of the fast tier's capacities, in sixty-fourths -- rows, contacts,
