@@ -468,3 +468,201 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
         if (to_pen) { dir = portal_dir(p1, p2, p3); it = 0; st = MPR_PEN; }  // head of findPenetr
     }
 }
+
+#if defined(UHC_NW2)
+// ------------------------------------------------------------------ the same rounds, the requests of a round served by TWO waves (round 6)
+// The general tier's queue consumers are two-wave workgroups (uhc_k_general_q.hip, -DUHC_NW2): two 79 KiB consumers share a CU whose other two SIMDs idled, and a
+// quarter of the cycles of the step's slowest env are support requests.  Wave 0 owns the pairs' state machines as in mpr_wave; per round it writes every live pair's
+// direction into an LDS mailbox, posts the round (barrier), BOTH waves walk the live mask in the order mpr_wave does and serve alternate groups of two requests
+// (pair_support_wave2 / pair_support_wave: the per-pair arithmetic of mpr_wave, operation for operation -- same bits), lane 0 of the serving wave writes the point
+// (v1 - v2, v1 + v2) back, barrier, the pairs' lanes pick their points up and advance.  The helper sleeps in s_barrier between rounds and between MPR passes.
+enum { MCMD_EXIT = 0, MCMD_ROUND = 1 };
+// The mailbox sits on the rows' scalar arrays (free until the rows are enumerated), every piece INSIDE one of them (the debug layout puts guard words between the arrays):
+//   rowR: ints cmd, live lo, live hi, vertex base (LDS offset in doubles, or -1: the global pointer in ints 4, 5) | x of the direction in / of v1 - v2 out, per pair
+//   rowAref: y, z | rowB: x, y of v1 + v2 | rowF: its z, the pair's margin | rowDa: ints b1, b2, voff1, vn1 per pair | rowW: ints voff2, vn2 per pair
+struct MprMB { int* hdr; double* io[6]; double* margin; int* st4; int* st2; };
+template <int TIER>
+__device__ __forceinline__ MprMB mpr_mb(const KernelArgs& A, double* S) {
+    const DevLds& L = lds_of<TIER>(A);
+    MprMB m;
+    m.hdr = (int*)(S + L.rowR);
+    m.io[0] = S + L.rowR + 4;
+    m.io[1] = S + L.rowAref; m.io[2] = S + L.rowAref + UHC_WAVE;
+    m.io[3] = S + L.rowB; m.io[4] = S + L.rowB + UHC_WAVE;
+    m.io[5] = S + L.rowF; m.margin = S + L.rowF + UHC_WAVE;
+    m.st4 = (int*)(S + L.rowDa); m.st2 = (int*)(S + L.rowW);
+    return m;
+}
+__device__ __forceinline__ SupArgs mpr_mb_args(const MprMB& MB, const double* xmat, const double* xpos, int p) {
+    SupArgs a;
+    const int b1 = __builtin_amdgcn_readfirstlane(MB.st4[4 * p]), b2 = __builtin_amdgcn_readfirstlane(MB.st4[4 * p + 1]);
+    a.R1 = xmat + 9 * b1; a.P1 = xpos + 3 * b1; a.R2 = xmat + 9 * b2; a.P2 = xpos + 3 * b2;
+    a.voff1 = __builtin_amdgcn_readfirstlane(MB.st4[4 * p + 2]); a.vn1 = __builtin_amdgcn_readfirstlane(MB.st4[4 * p + 3]);
+    a.voff2 = __builtin_amdgcn_readfirstlane(MB.st2[2 * p]); a.vn2 = __builtin_amdgcn_readfirstlane(MB.st2[2 * p + 1]);
+    a.margin = MB.margin[p];
+    a.d = v3(MB.io[0][p], MB.io[1][p], MB.io[2][p]);
+    return a;
+}
+__device__ __forceinline__ void mpr_mb_put(const MprMB& MB, int p, const V3& a, const V3& b) {
+    if (LANE == 0) {
+        MB.io[0][p] = a.x - b.x; MB.io[1][p] = a.y - b.y; MB.io[2][p] = a.z - b.z; MB.io[3][p] = a.x + b.x; MB.io[4][p] = a.y + b.y; MB.io[5][p] = a.z + b.z;
+    }
+}
+// one round's requests: every wave walks the live mask as mpr_wave does (two requests per group when all four hulls fit one trip) and serves the groups g with g % nw == wid
+__device__ __forceinline__ void mpr_serve_round(const double* __restrict__ VB, const double* __restrict__ xmat, const double* __restrict__ xpos, const MprMB& MB, unsigned long long live, int wid, int nw) {
+    int g = 0;
+    while (live) {
+        const int p = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        const bool mine = (g % nw) == wid;
+        g++;
+        const SupArgs Ap = mpr_mb_args(MB, xmat, xpos, p);
+        V3 a, b;
+        if (live && UHC_MPR_PAIRWISE) {
+            const int q = __ffsll((long long)live) - 1;
+            const SupArgs Aq = mpr_mb_args(MB, xmat, xpos, q);
+            if (max(max(Ap.vn1, Ap.vn2), max(Aq.vn1, Aq.vn2)) <= UHC_WAVE) {
+                live &= live - 1;
+                if (mine) {
+                    V3 a2, b2v;
+                    pair_support_wave2(VB, Ap, Aq, a, b, a2, b2v);
+                    mpr_mb_put(MB, p, a, b);
+                    mpr_mb_put(MB, q, a2, b2v);
+                }
+                continue;
+            }
+        }
+        if (mine) {
+            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.margin, a, b);
+            mpr_mb_put(MB, p, a, b);
+        }
+    }
+}
+// wave 0's side: mpr_wave with the serving loop replaced by mailbox + barrier + shared serving + barrier
+template <bool LDSV>
+__device__ __forceinline__ void mpr_wave_mw(const double* __restrict__ VB, const double* __restrict__ xmat, const double* __restrict__ xpos, bool active, MprLane& M, const MprMB& MB, int vstage,
+                                            const double* vb_global) {
+    CcdSup p0, p1, p2, p3, v4;
+    V3 dir = v3(0, 0, 0);
+    double dt;
+    int st = MPR_DONE, it = 0;
+    M.hit = false; M.depth = 0; M.dir = v3(0, 0, 0); M.pos = v3(0, 0, 0);
+    p0.v = p0.s = p1.v = p1.s = p2.v = p2.s = p3.v = p3.s = v4.v = v4.s = v3(0, 0, 0);
+    if (active) {
+        p0.s = M.c1 + M.c2; p0.v = M.c1 - M.c2;
+        if (ccd_eq(p0.v.x, 0) && ccd_eq(p0.v.y, 0) && ccd_eq(p0.v.z, 0)) p0.v.x += UHC_CCD_EPS * 10;
+        dir = vnorm(neg(p0.v));
+        st = MPR_D1;
+        MB.st4[4 * LANE] = M.b1; MB.st4[4 * LANE + 1] = M.b2; MB.st4[4 * LANE + 2] = M.voff1; MB.st4[4 * LANE + 3] = M.vn1;
+        MB.st2[2 * LANE] = M.voff2; MB.st2[2 * LANE + 1] = M.vn2;
+        MB.margin[LANE] = M.margin;
+    }
+    int* mbi = MB.hdr;
+    if (LANE == 0) {
+        mbi[3] = LDSV ? vstage : -1;
+        mbi[4] = (int)((unsigned long long)vb_global & 0xffffffffull); mbi[5] = (int)((unsigned long long)vb_global >> 32);
+    }
+    for (int round = 0;; round++) {
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(st != MPR_DONE);
+        if (!live || round == UHC_MPR_MAXSUP) break;
+        if (st != MPR_DONE) { MB.io[0][LANE] = dir.x; MB.io[1][LANE] = dir.y; MB.io[2][LANE] = dir.z; }
+        if (LANE == 0) { mbi[0] = MCMD_ROUND; mbi[1] = (int)(live & 0xffffffffull); mbi[2] = (int)(live >> 32); }
+        __syncthreads();
+        mpr_serve_round(VB, xmat, xpos, MB, live, 0, UHC_NWG);
+        __syncthreads();
+        if (st != MPR_DONE) { v4.v = v3(MB.io[0][LANE], MB.io[1][LANE], MB.io[2][LANE]); v4.s = v3(MB.io[3][LANE], MB.io[4][LANE], MB.io[5][LANE]); }
+        // ---- every live pair advances to its next request (or finishes): mpr_wave's state machine, unchanged
+        bool to_refine = false, to_pen = false;
+        if (st == MPR_D1) {
+            p1 = v4;
+            dt = vdot(p1.v, dir);
+            if (ccd_zero(dt) || dt < 0) st = MPR_DONE;
+            else {
+                dir = vcross(p0.v, p1.v);
+                if (ccd_zero(vdot(dir, dir))) {
+                    if (ccd_eq(p1.v.x, 0) && ccd_eq(p1.v.y, 0) && ccd_eq(p1.v.z, 0)) { M.depth = 0; M.dir = v3(0, 0, 0); }
+                    else { M.depth = sqrt(vdot(p1.v, p1.v)); M.dir = vnorm(p1.v); }
+                    M.pos = v3(0.5 * p1.s.x, 0.5 * p1.s.y, 0.5 * p1.s.z);
+                    M.hit = true;
+                    st = MPR_DONE;
+                } else { dir = vnorm(dir); st = MPR_D2; }
+            }
+        } else if (st == MPR_D2) {
+            p2 = v4;
+            dt = vdot(p2.v, dir);
+            if (ccd_zero(dt) || dt < 0) st = MPR_DONE;
+            else {
+                dir = vnorm(vcross(p1.v - p0.v, p2.v - p0.v));
+                if (vdot(dir, p0.v) > 0) { const CcdSup t = p1; p1 = p2; p2 = t; dir = neg(dir); }
+                st = MPR_D3;
+            }
+        } else if (st == MPR_D3) {
+            dt = vdot(v4.v, dir);
+            if (ccd_zero(dt) || dt < 0) st = MPR_DONE;
+            else {
+                bool cont = false;
+                dt = vdot(vcross(p1.v, v4.v), p0.v);
+                if (dt < 0 && !ccd_zero(dt)) { p2 = v4; cont = true; }
+                if (!cont) {
+                    dt = vdot(vcross(v4.v, p2.v), p0.v);
+                    if (dt < 0 && !ccd_zero(dt)) { p1 = v4; cont = true; }
+                }
+                if (cont) dir = vnorm(vcross(p1.v - p0.v, p2.v - p0.v));
+                else { p3 = v4; to_refine = true; }
+            }
+        } else if (st == MPR_REFINE) {
+            dt = vdot(v4.v, dir);
+            if (!(ccd_zero(dt) || dt > 0) || portal_reach_tolerance(p1, p2, p3, v4, dir)) st = MPR_DONE;
+            else { expand_portal(p0, p1, p2, p3, v4); to_refine = true; }
+        } else if (st == MPR_PEN) {
+            if (portal_reach_tolerance(p1, p2, p3, v4, dir) || it > UHC_MPR_MAXIT) {
+                V3 pd;
+                M.depth = sqrt(point_tri_dist2(p1.v, p2.v, p3.v, pd));
+                if (ccd_zero(pd.x) && ccd_zero(pd.y) && ccd_zero(pd.z)) pd = dir;
+                M.dir = vnorm(pd);
+                M.pos = find_pos(p0, p1, p2, p3);
+                M.hit = true;
+                st = MPR_DONE;
+            } else {
+                expand_portal(p0, p1, p2, p3, v4);
+                it++;
+                dir = portal_dir(p1, p2, p3);
+            }
+        }
+        if (to_refine) {
+            dir = portal_dir(p1, p2, p3);
+            dt = vdot(dir, p1.v);
+            if (ccd_zero(dt) || dt > 0) to_pen = true;
+            else st = MPR_REFINE;
+        }
+        if (to_pen) { dir = portal_dir(p1, p2, p3); it = 0; st = MPR_PEN; }
+    }
+}
+// the helper wave of a two-wave consumer: asleep in the barrier until wave 0 posts a round
+template <int TIER>
+__device__ __forceinline__ void mpr_helper(const KernelArgs& A, double* S) {
+    const DevLds& L = lds_of<TIER>(A);
+    const MprMB MB = mpr_mb<TIER>(A, S);
+    const int* mbi = MB.hdr;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (;;) {
+        __syncthreads();
+        const int cmd = __builtin_amdgcn_readfirstlane(mbi[0]);
+        if (cmd == MCMD_EXIT) return;
+        const unsigned long long live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbi[2]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbi[1]);
+        const int vst = __builtin_amdgcn_readfirstlane(mbi[3]);
+        if (vst >= 0) mpr_serve_round(S + vst, S + L.xmat, S + L.xpos, MB, live, wid, UHC_NWG);
+        else {
+            const unsigned long long vb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbi[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbi[4]);
+            mpr_serve_round((const double*)vb, S + L.xmat, S + L.xpos, MB, live, wid, UHC_NWG);
+        }
+        __syncthreads();
+    }
+}
+template <int TIER>
+__device__ __forceinline__ void mpr_release_helpers(const KernelArgs& A, double* S) {
+    int* mbi = mpr_mb<TIER>(A, S).hdr;
+    if (LANE == 0) mbi[0] = MCMD_EXIT;
+    __syncthreads();
+}
+#endif

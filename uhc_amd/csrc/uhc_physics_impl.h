@@ -16,9 +16,18 @@
 
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
-// UHC_NW4 (uhc_k_huge_q.hip only): the workgroup has four waves -- wave 0 runs everything below as if it were alone, waves 1-3 are helpers of tier 4's
-// Newton iteration (uhc_primal.h) and see nothing else of this file
-#ifdef UHC_NW4
+// Multi-wave workgroups (queue consumers only).  UHC_NW4 (uhc_k_huge_q.hip): four waves -- wave 0 runs everything below as if it were alone, waves 1-3 are helpers of
+// tier 4's Newton iteration (uhc_primal.h).  UHC_NW2 (uhc_k_general_q.hip): two waves -- the helper serves half of the support requests of every MPR round
+// (uhc_mpr.h: mpr_wave_mw): the general tier's slowest env is what a control step of the headline waits for, a quarter of its cycles are MPR, and with two
+// 79 KiB consumers per CU two of the CU's four SIMDs idle.  In both, helpers see nothing else of this file.
+#if defined(UHC_NW4)
+#define UHC_NWG 4
+#elif defined(UHC_NW2)
+#define UHC_NWG 2
+#else
+#define UHC_NWG 1
+#endif
+#if UHC_NWG > 1
 #define LANE ((int)(threadIdx.x & 63u))
 #else
 #define LANE ((int)threadIdx.x)
@@ -57,7 +66,7 @@ template <int TIER> __device__ __forceinline__ const TierCap& cap_of(const Kerne
 template <int TIER> __device__ __forceinline__ bool hands_on(const KernelArgs& A) { return TIER == 1 ? !A.truncate : TIER < A.last_tier; }
 // wsync: the LANES OF ONE WAVE have exchanged data through LDS (or global memory).  With one wave per workgroup that is __syncthreads() (whose s_barrier the
 // backend drops); in a four-wave workgroup the same fences without the barrier -- the other waves are not coming
-#ifdef UHC_NW4
+#if UHC_NWG > 1
 __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1037,6 +1046,12 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 M.margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
                 gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
             }
+#if defined(UHC_NW2)
+            if constexpr (TIER == 2) {  // the two-wave consumer: the helper wave serves every second pair of requests (mailbox on the rows' scalars, free until the rows are enumerated)
+                if (vstage >= 0) mpr_wave_mw<true>(S + vstage, S + L.xmat, S + L.xpos, act, M, mpr_mb<TIER>(A, S), vstage, mb + A.o.mesh_vert);
+                else mpr_wave_mw<false>(mb + A.o.mesh_vert, S + L.xmat, S + L.xpos, act, M, mpr_mb<TIER>(A, S), -1, mb + A.o.mesh_vert);
+            } else
+#endif
             // two copies of the refinement so that each knows its address space at compile time (ds_read vs global_load)
             if (vstage >= 0) mpr_wave(S + vstage, S + L.xmat, S + L.xpos, act, M);
             else mpr_wave(mb + A.o.mesh_vert, S + L.xmat, S + L.xpos, act, M);
@@ -3075,16 +3090,15 @@ __global__ void __launch_bounds__(UHC_WAVE) uhc_step_kernel(KernelArgs A, const 
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // producer bookkeeping of the queues
 }
 // (2): its own entry point, so that the one-workgroup-per-env kernels keep the register allocation of a straight-line body
-#ifdef UHC_NW4
-#define UHC_QUEUE_THREADS (UHC_WAVE * UHC_PRIMAL_WAVES)
-#else
-#define UHC_QUEUE_THREADS UHC_WAVE
-#endif
+#define UHC_QUEUE_THREADS (UHC_WAVE * UHC_NWG)
 template <int MODE, int TIER, bool DENSE>
 __global__ void __launch_bounds__(UHC_QUEUE_THREADS) uhc_step_queue_kernel(KernelArgs A, const double* __restrict__ d_action, const double* __restrict__ d_tbase) {
-#ifdef UHC_NW4
+#if defined(UHC_NW4)
     static_assert(TIER == 4, "the four-wave form is tier 4's");
     if (threadIdx.x >= UHC_WAVE) { primal_helper<TIER>(A, smem); return; }  // (before anything that says LANE == 0: the helpers' lanes count from 0 too)
+#elif defined(UHC_NW2)
+    static_assert(TIER == 2, "the two-wave form is the general tier's");
+    if (threadIdx.x >= UHC_WAVE) { mpr_helper<TIER>(A, smem); return; }
 #endif
     if (A.started && LANE == 0) atomicAdd(A.started, 1);  // resident: holds its LDS from here on
     // (tier trace, UHC_DEBUG bit 4: the consumer's own record -- entry, first env claimed, exit, envs processed -- in words 8 .. 11 (general
@@ -3107,7 +3121,9 @@ __global__ void __launch_bounds__(UHC_QUEUE_THREADS) uhc_step_queue_kernel(Kerne
     }
     if (tr && LANE == 0) tr[2] = (long long)wall_clock64();
     if (A.fin && LANE == 0) { __threadfence(); atomicAdd(A.fin, 1); }  // consumer bookkeeping (the next tier's consumers wait for it)
-#ifdef UHC_NW4
+#if defined(UHC_NW4)
     primal_release_helpers<TIER>(A, smem);
+#elif defined(UHC_NW2)
+    mpr_release_helpers<TIER>(A, smem);
 #endif
 }
