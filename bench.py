@@ -663,7 +663,10 @@ def main():
                                 # value half first, the surrogate's backward pass enqueued behind it: an interval (start of an exchange -> its
                                 # wait over) then contains that backward pass, the bandwidths above are lower bounds, and what the update pays is
                                 "overlapped_with_policy_backward": ovl, "exposed_ms": agent.comm_exposed_ms,
-                                "exposed_share_of_update": agent.comm_exposed_ms * 1e-3 / t_up}
+                                "exposed_share_of_update": agent.comm_exposed_ms * 1e-3 / t_up,
+                                # 1 - exposed / total: the share of the exchanges' wall time (start of the collective -> end of the wait) during which the compute stream was NOT
+                                # standing still -- over RCCL the answer to "does the all-reduce overlap the surrogate's backward pass" (over gloo there is no side stream: ~0)
+                                "hidden_share_of_exchange_time": (1.0 - agent.comm_exposed_ms / comm_ms) if comm_ms > 0 else None}
     # ---- the same rollout with MuJoCo-style PGS sweeps (solver 0), kernel time only: what north_star's "PGS contact solve" costs
     pgs = None
     if world == 1 and not args.no_pgs_probe:

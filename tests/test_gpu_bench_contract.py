@@ -76,6 +76,11 @@ def test_bench_two_ranks_over_rccl():
     assert d["n_gpus"] == 2 and len(d["per_rank_env_steps_per_s"]) == 2
     ar = d["ppo"]["allreduce"]  # (two halves per epoch: the value gradient's travels during the surrogate's backward pass)
     assert ar["calls"] == 20 and ar["busbw_GBs"] > 0 and ar["overlapped_with_policy_backward"] and 0 <= ar["exposed_ms"] <= ar["total_ms"]
+    # the first two-GPU box answers the open question (does RCCL's stream overlap the surrogate's backward pass?) in this one run: the record is kept
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_overlap.json"), "w") as f:
+        json.dump({"allreduce": ar, "hidden_share_of_exchange_time": ar["hidden_share_of_exchange_time"]}, f)
+    print("RCCL gradient exchange:", json.dumps(ar))
 
 
 def test_bench_spawns_its_own_ranks():
