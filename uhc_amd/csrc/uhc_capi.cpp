@@ -552,6 +552,13 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
         bool hinge_only = n_trail == 0;
         for (int j = 0; j < d.njnt; j++) hinge_only = hinge_only && d.jnt_type[j] != UHC_JNT_BALL;
         if (T.ncpair > 0 && n_env >= 3072 && hinge_only) { dense_kib = 40; fast_ndense = 6; }
+        // A BALL-JOINT humanoid gets 9 body-body row slots instead of 12 (round 6): three dense rows less are 370 doubles more for the packed rows, whose storage names
+        // two of three hand-ons of the ball-joint rollouts (long dof chains, three dofs per joint).  Measured on one box, 3 x 60 steps, env-steps/s with 12 / 9 / 8 / 7 slots:
+        // `ball_rollout` 54.1 k / 65.8 k / 65.6 k / 62.4 k, `configs4` 57.3 k / 58.4 k / 57.5 k / 54.5 k (profiles/r06_fd_dense_slots.txt); the hinge models keep 12
+        // (headline 96.5 k with 12, 96.4 k with 10, 95.4 k with 8; `shapes` 101.1 / 100.7 / 98.7 k).
+        bool any_ball = false;
+        for (int j = 0; j < d.njnt; j++) any_ball = any_ball || d.jnt_type[j] == UHC_JNT_BALL;
+        if (T.ncpair > 0 && any_ball && dense_kib == 52) fast_ndense = 9;
         if (const char* fd = getenv("UHC_FAST_DENSE")) {
             int kib = 0, nd = 0, nc = 0;
             const int got = sscanf(fd, "%d,%d,%d", &kib, &nd, &nc);
