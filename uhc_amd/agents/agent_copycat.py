@@ -24,6 +24,10 @@ from ..khrylib.utils.zfilter import ZFilter
 from ..losses.reward_function import DEVICE_REWARD_IDS
 
 
+def cfg_get(cfg, key, default):
+    return getattr(cfg, key, default)
+
+
 class AgentCopycat(AgentPPO):
     def __init__(self, cfg, dtype, device, training=True, checkpoint_epoch=0, data_loader=None, shape_models=None, clip_model=None, body_provider=None,
                  objects=None):
@@ -61,6 +65,10 @@ class AgentCopycat(AgentPPO):
                          policy_grad_clip=[(self.policy_net.parameters(), 40)], end_reward=cfg.end_reward, use_mini_batch=False,
                          mini_batch_size=0)
         self.grad_wire_dtype = {"float32": torch.float32, "float64": torch.float64}[str(getattr(cfg, "grad_allreduce_dtype", "float32"))]
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 and torch.distributed.get_rank() == 0:
+            # (the wire defaults to float32 since round 5 -- an unchanged multi-rank yml is then within 1e-4 relative of the single-process update, not 1e-10)
+            print(f"[uhc_amd] gradient exchange over {torch.distributed.get_world_size()} ranks: wire dtype {cfg_get(cfg, 'grad_allreduce_dtype', 'float32')}, "
+                  f"overlap_grad_exchange {cfg_get(cfg, 'overlap_grad_exchange', True)} (set grad_allreduce_dtype: float64 for parity / regression runs)", flush=True)
         self.overlap_grad_exchange = bool(getattr(cfg, "overlap_grad_exchange", True))
         if getattr(self, "_loaded_shared_filter", False):
             self.mark_running_state_shared()  # every rank loaded the same filter statistics: they are not new samples
