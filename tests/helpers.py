@@ -116,3 +116,38 @@ def two_box_model(ha=0.1, hb=0.06):
     """Two free boxes (meshes) above the plane: box-box contacts go through the convex-convex (MPR) narrow phase, two kinematic trees."""
     from uhc_amd.model.mjcf import compile_mjcf
     return compile_mjcf(TWO_BOX_XML, meshes={"a": box_triangles(ha, ha, ha), "b": box_triangles(hb, hb, hb)})
+
+
+def caterpillar_model(n_seg=27, half=0.1, gap=0.02):
+    """A serial chain lying on the floor: a free root box and n_seg - 1 boxes behind it, each on ONE hinge about y -- the dof chain of the last box has 6 + (n_seg - 1) entries
+    (32 with 27 segments: the deepest chain uhc_batch_create accepts).  Every box meets the floor with its four bottom vertices at slightly different heights (no exact ties for the
+    plane-mesh narrow phase), the boxes do not collide with each other (contype 0): 16 pyramid rows per resting box, 432 for the whole animal."""
+    from uhc_amd.model.mjcf import compile_mjcf
+    tris = box_triangles(half, half, half)
+    v = tris.reshape(-1, 3).copy()
+    dz = {(-1, -1): 0.0, (1, -1): -0.0003, (1, 1): -0.0006, (-1, 1): 0.0003}
+    for k in range(v.shape[0]):
+        if v[k, 2] < 0:
+            v[k, 2] += dz[(int(np.sign(v[k, 0])), int(np.sign(v[k, 1])))]
+    tris = v.reshape(-1, 3, 3)
+    step = 2 * half + gap
+    body = ""
+    for k in range(n_seg - 1, 0, -1):
+        body = f'<body name="s{k}" pos="{step} 0 0"><joint name="j{k}" type="hinge" axis="0 1 0" pos="{-step / 2} 0 0"/><geom type="mesh" mesh="seg"/>{body}</body>'
+    xml = f"""
+<mujoco>
+  <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
+  <option timestep="0.002"/>
+  <default><geom contype="0" conaffinity="1" condim="3" margin="0.001"/></default>
+  <asset><mesh name="seg" file="unused.stl"/></asset>
+  <worldbody>
+    <geom name="floor" type="plane" size="20 20 0.1" pos="0 0 0" contype="1" conaffinity="1"/>
+    <body name="s0" pos="0 0 {half}">
+      <joint name="root" type="free"/>
+      <geom type="mesh" mesh="seg"/>
+      {body}
+    </body>
+  </worldbody>
+</mujoco>
+"""
+    return compile_mjcf(xml, meshes={"seg": tris})

@@ -636,3 +636,84 @@ def test_tier_4_consumers_take_what_the_large_tiers_consumers_hand_on(model, sta
     assert primal == 8 * len(heavy) and worst < 1e-9, (primal, worst)
     assert int(b.field(S.F_EFC_OVERFLOW).sum().item()) == 0 and int(b.field(S.F_FAIL).sum().item()) == 0
     b.close()
+
+
+def test_a_dof_chain_of_32_entries_goes_through_tier_4(monkeypatch, capfd):
+    """uhc_batch_create accepts dof chains of maxdepth + 1 == 32 entries, the SMPL models stop at 30 -- and tier 4's pair tables (528 pairs; the four
+    ownership classes of the four-wave pass) were sized by them.  A synthetic 27-segment chain on the floor: depth 32, 432 rows (beyond the large tier), against the oracle's
+    own primal solver -- through the chained launches (tier 4 on one wave: the 528-entry pair table) and, in a batch with two half-lifted animals that live in the general tier so
+    that every tier's consumers are launched, through tier 4's four-wave consumers (the class tables at len 32)."""
+    import dataclasses
+    import torch
+    from tests.helpers import caterpillar_model
+    from oracle.physics import OracleSim
+    from uhc_amd import sim as S
+    if os.environ.get("UHC_FORCE_GENERAL") == "1" or os.environ.get("UHC_TIERS") in ("2", "3"):
+        pytest.skip("needs the fast tier to start from and tier 4 to end in")
+    m = dataclasses.replace(caterpillar_model(27), solver=1)
+    assert m.nv == 32 and int(max(m.dof_depth) if hasattr(m, "dof_depth") else 31) + 1 == 32
+    ctrl = passive_ctrl(m, n_substeps=15)
+    rng = np.random.default_rng(3)
+
+    def pose(lifted):
+        q = m.qpos0.copy()
+        q[2] -= 0.0004  # resting a little inside the floor's margin: every bottom vertex within it
+        q[7:] = rng.normal(scale=1e-4, size=m.nq - 7)
+        if lifted:  # the first six segments on the floor (96 rows: the general tier), the rest lifted off it
+            q[7 + 5] = -1.1
+        return q
+
+    # ---- chained launches: tier 4 behind the large tier's workgroup, one wave
+    n = 2
+    q = np.stack([pose(False) for _ in range(n)])
+    v = np.zeros((n, m.nv))  # (at rest: a velocity of a few cm/s lifts the animal out of the floor's margin within a step, and the lower tiers take it)
+    b = S.SimBatch(m, ctrl, n)
+    b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+    b.sync()
+    os_ = [OracleSim(m, ctrl) for _ in range(n)]
+    for e in range(n):
+        os_[e].set_state(q[e], v[e])
+        assert os_[e].geti("nefc") > 256 and int(b.field(S.F_NEFC)[e].item()) == os_[e].geti("nefc")
+        np.testing.assert_allclose(b.field(S.F_QACC)[e].cpu().numpy(), os_[e].get("qacc"), atol=1e-7 * (1 + np.abs(os_[e].get("qacc")).max()))
+    act = np.zeros((n, ctrl.action_dim))
+    tb = torch.zeros(n, max(m.nu, 1), dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for t in range(3):
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        assert ((redo >> 30) & 1).all() and not (redo & 0x80).any() and not (redo & 2).any() and not ((redo >> 29) & 1).any(), [hex(int(x)) for x in redo]
+        for e in range(n):
+            os_[e].do_simulation(act[e], np.zeros(max(m.nu, 1)))
+            worst = max(worst, np.abs(b.field(S.F_QPOS)[e].cpu().numpy() - os_[e].get("qpos")).max(), np.abs(b.field(S.F_QVEL)[e].cpu().numpy() - os_[e].get("qvel")).max())
+    assert worst < 1e-8, worst
+    b.close()
+    # ---- sticky queues with every tier's consumers: the flat animals through tier 4's four-wave consumers
+    monkeypatch.setenv("UHC_DEBUG", "64")
+    n, flat = 6, (1, 4)
+    q = np.stack([pose(e not in flat) for e in range(n)])
+    v = np.zeros((n, m.nv))
+    b = S.SimBatch(m, ctrl, n)
+    b.set_kernel_path(2)
+    act = np.zeros((n, ctrl.action_dim))
+    tb = torch.zeros(n, max(m.nu, 1), dtype=torch.float64, device="cuda")
+    os_ = [OracleSim(m, ctrl) for _ in range(n)]
+    worst2, primal = 0.0, 0
+    for t in range(8):  # every env re-posed each step, so that the scene stays what it is
+        b.set_state(torch.from_numpy(q), torch.from_numpy(v))
+        b.simulate(torch.from_numpy(act).cuda(), tb)
+        b.sync()
+        redo = b.field(S.F_REDO).cpu().numpy()
+        assert not (redo & 0x80).any() and not (redo & 2).any() and not ((redo >> 29) & 1).any(), [hex(int(x)) for x in redo]
+        for e in range(n):
+            os_[e].set_state(q[e], v[e])
+            os_[e].do_simulation(act[e], np.zeros(max(m.nu, 1)))
+            worst2 = max(worst2, np.abs(b.field(S.F_QPOS)[e].cpu().numpy() - os_[e].get("qpos")).max())
+            primal += int((redo[e] >> 30) & 1)
+            assert bool((redo[e] >> 30) & 1) == (e in flat), (t, e, hex(int(redo[e])), int(b.field(S.F_NEFC)[e].item()))
+    err = capfd.readouterr().err
+    launched = [ln for ln in err.splitlines() if "tier-4 consumers" in ln]
+    print(f"32-entry dof chains: chained launches worst {worst:.2e}; sticky queues: {len(launched)} of 8 steps with tier-4 consumers, {primal} env-steps through tier 4, worst |dqpos| {worst2:.2e}")
+    assert len(launched) >= 3, err[-1500:]
+    assert primal == 8 * len(flat) and worst2 < 1e-9, (primal, worst2)
+    b.close()
