@@ -33,7 +33,11 @@ extern "C" {
 
 /* joint / geom type codes (MuJoCo numbering) */
 enum { UHC_JNT_FREE = 0, UHC_JNT_BALL = 1, UHC_JNT_SLIDE = 2, UHC_JNT_HINGE = 3 };
-enum { UHC_GEOM_PLANE = 0, UHC_GEOM_SPHERE = 2, UHC_GEOM_BOX = 6, UHC_GEOM_MESH = 7 };
+enum { UHC_GEOM_PLANE = 0, UHC_GEOM_SPHERE = 2, UHC_GEOM_CAPSULE = 3, UHC_GEOM_BOX = 6, UHC_GEOM_MESH = 7 };
+/* Geoms that collide: the plane against CONVEX HULLS, and hulls against each other (MPR).  A hull is a mesh geom or a ROUNDED hull: a sphere (one core vertex, its
+ * centre) or a capsule (two core vertices, the ends of its segment: geom_pos +- half length along the geom's z axis, in that order), whose surface lies geom_size[0]
+ * (the radius) beyond the core along the query direction -- [MJ-ext] mjc_PlaneSphere / mjc_PlaneCapsule for the plane, mjc_Convex's support callbacks for the rest.
+ * The core vertices live in the mesh tables (geom_vertadr / geom_vertnum / mesh_vert / mesh_adj) like a mesh's hull vertices, in the BODY frame; boxes carry mass only. */
 
 /*
  * Flat description of one compiled model (host arrays, copied by uhc_model_create).

@@ -367,13 +367,34 @@ static int bodies_filtered(const UhcModelDesc* m, int b1, int b2) {
     }
     return 0;
 }
-static void add_contact(const UhcModelDesc* m, OrcData* d, int g1, int g2, const double pos[3],
-                        const double normal[3], double dist, double margin) {
+/* Geoms that collide as convex hulls: meshes and the ROUNDED hulls -- a sphere (one core vertex) and a capsule (the two end points of its segment), pushed out by
+ * their radius geom_size[0] along the query direction ([MJ-ext] mjc_Convex's support callbacks for mjGEOM_SPHERE / mjGEOM_CAPSULE: centre or segment end + radius * dir).
+ * The model compiler (uhc_amd/model/mjcf.py) puts the core vertices into the mesh tables. */
+static int is_hull(int t) { return t == UHC_GEOM_MESH || t == UHC_GEOM_SPHERE || t == UHC_GEOM_CAPSULE; }
+static double hull_radius(const UhcModelDesc* m, int g) {
+    int t = m->geom_type[g];
+    return (t == UHC_GEOM_SPHERE || t == UHC_GEOM_CAPSULE) ? m->geom_size[3 * g] : 0.0;
+}
+/* [MJ-ext] mju_makeFrame with a y axis supplied (mjc_PlaneCapsule aligns the contact frame with the capsule's axis): y made orthogonal to x and
+ * normalised, z = x cross y; a y (nearly) parallel to x falls back to the picked axis of make_frame */
+static void make_frame_hint(double f[9], const double y[3]) {
+    double n = sqrt(dot3(f, f));
+    f[0] /= n; f[1] /= n; f[2] /= n;
+    double dp = dot3(f, y), t[3];
+    for (int k = 0; k < 3; k++) t[k] = y[k] - f[k] * dp;
+    n = sqrt(dot3(t, t));
+    if (n < 1e-8) { make_frame(f); return; }
+    for (int k = 0; k < 3; k++) f[3 + k] = t[k] / n;
+    cross3(f + 6, f, f + 3);
+}
+static void add_contact_hint(const UhcModelDesc* m, OrcData* d, int g1, int g2, const double pos[3],
+                             const double normal[3], double dist, double margin, const double* yhint) {
     if (d->ncon >= ORC_MAXCON) return;
     int c = d->ncon++;
     memcpy(d->con_pos + 3 * c, pos, 24);
     memcpy(d->con_frame + 9 * c, normal, 24);
-    make_frame(d->con_frame + 9 * c);
+    if (yhint) make_frame_hint(d->con_frame + 9 * c, yhint);
+    else make_frame(d->con_frame + 9 * c);
     d->con_dist[c] = dist;
     d->con_margin[c] = margin; /* includemargin = margin - gap; gap handled by caller */
     d->con_geom1[c] = g1; d->con_geom2[c] = g2;
@@ -384,7 +405,14 @@ static void add_contact(const UhcModelDesc* m, OrcData* d, int g1, int g2, const
     for (int k = 0; k < 2; k++) d->con_solref[2 * c + k] = 0.5 * (m->geom_solref[2 * g1 + k] + m->geom_solref[2 * g2 + k]);
     for (int k = 0; k < 5; k++) d->con_solimp[5 * c + k] = 0.5 * (m->geom_solimp[5 * g1 + k] + m->geom_solimp[5 * g2 + k]);
 }
-/* plane (g1) vs convex mesh (g2): support vertex, then hull-graph neighbours within margin */
+static void add_contact(const UhcModelDesc* m, OrcData* d, int g1, int g2, const double pos[3],
+                        const double normal[3], double dist, double margin) {
+    add_contact_hint(m, d, g1, g2, pos, normal, dist, margin, NULL);
+}
+/* plane (g1) vs convex hull (g2): support vertex, then hull-graph neighbours within margin.  A rounded hull (sphere, capsule) is its core vertices lowered by the
+ * radius: [MJ-ext] _PlaneSphere -- dist = n . (centre - plane) - radius, kept while dist <= margin, pos = centre - n (radius + dist / 2) -- at the sphere's centre or
+ * the capsule's two segment ends (mjc_PlaneCapsule, which also aligns the contact frame's second axis with the capsule's axis).  The support vertex (the lower end) is
+ * emitted first, the other end -- its only neighbour -- after it. */
 static void collide_plane_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2, double margin, double gap) {
     int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
     double pR[9], pq[4], ppos[3], t[3];
@@ -409,19 +437,29 @@ static void collide_plane_mesh(const UhcModelDesc* m, OrcData* d, int g1, int g2
         for (int k = 0; k < 3; k++) { w[k] += d->xpos[3 * b2 + k]; dist += n[k] * (w[k] - ppos[k]); }
         if (best < 0 || dist < bestd) { best = v; bestd = dist; memcpy(bw, w, 24); }
     }
+    const double rr = hull_radius(m, g2);
+    bestd -= rr;
     if (best < 0 || bestd > margin) return;
-    double cp[3];
-    for (int k = 0; k < 3; k++) cp[k] = bw[k] - 0.5 * bestd * n[k];
-    add_contact(m, d, g1, g2, cp, n, bestd, margin - gap);
+    double cp[3], axis[3];
+    const double* yh = NULL;
+    if (m->geom_type[g2] == UHC_GEOM_CAPSULE && vn == 2) { /* the capsule's axis in the world: from its second core vertex to its first */
+        double dl[3];
+        for (int k = 0; k < 3; k++) dl[k] = m->mesh_vert[3 * va + k] - m->mesh_vert[3 * (va + 1) + k];
+        mat_vec(axis, d->xmat + 9 * b2, dl);
+        yh = axis;
+    }
+    for (int k = 0; k < 3; k++) cp[k] = bw[k] - (rr + 0.5 * bestd) * n[k];
+    add_contact_hint(m, d, g1, g2, cp, n, bestd, margin - gap, yh);
     int cnt = 1;
     for (int e = m->mesh_adjadr[best]; e < m->mesh_adjadr[best + 1] && cnt < m->plane_mesh_maxcon; e++) {
         int v = m->mesh_adj[e];
         double w[3], dist = 0;
         mat_vec(w, d->xmat + 9 * b2, m->mesh_vert + 3 * v);
         for (int k = 0; k < 3; k++) { w[k] += d->xpos[3 * b2 + k]; dist += n[k] * (w[k] - ppos[k]); }
+        dist -= rr;
         if (dist <= margin) {
-            for (int k = 0; k < 3; k++) cp[k] = w[k] - 0.5 * dist * n[k];
-            add_contact(m, d, g1, g2, cp, n, dist, margin - gap);
+            for (int k = 0; k < 3; k++) cp[k] = w[k] - (rr + 0.5 * dist) * n[k];
+            add_contact_hint(m, d, g1, g2, cp, n, dist, margin - gap, yh);
             cnt++;
         }
     }
@@ -483,7 +521,8 @@ static void mesh_support(const UhcModelDesc* m, const OrcData* d, int g, const d
         if (s > bd) { bd = s; best = v; }
     }
     mat_vec(out, R, m->mesh_vert + 3 * best);
-    for (int k = 0; k < 3; k++) out[k] += d->xpos[3 * b + k] + dir[k] * 0.5 * margin;
+    const double hm = 0.5 * margin + hull_radius(m, g); /* a rounded hull's surface lies its radius beyond the core vertex */
+    for (int k = 0; k < 3; k++) out[k] += d->xpos[3 * b + k] + dir[k] * hm;
 }
 static void geom_centre(const UhcModelDesc* m, const OrcData* d, int g, double out[3]) {
     int b = m->geom_bodyid[g];
@@ -671,9 +710,9 @@ void orc_collision(const UhcModelDesc* m, OrcData* d) {
                 double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
                 int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
                 if (pass == 0) {
-                    if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g1, g2, margin, gap);
-                    else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH) collide_plane_mesh(m, d, g2, g1, margin, gap);
-                } else if (t1 == UHC_GEOM_MESH && t2 == UHC_GEOM_MESH) collide_mesh_mesh(m, d, g1, g2, margin, gap);
+                    if (t1 == UHC_GEOM_PLANE && is_hull(t2)) collide_plane_mesh(m, d, g1, g2, margin, gap);
+                    else if (t2 == UHC_GEOM_PLANE && is_hull(t1)) collide_plane_mesh(m, d, g2, g1, margin, gap);
+                } else if (is_hull(t1) && is_hull(t2)) collide_mesh_mesh(m, d, g1, g2, margin, gap);
             }
 }
 
@@ -1459,6 +1498,11 @@ int orc_get(const UhcModelDesc* m, const OrcData* d, const char* name, double* o
             memcpy(out, tab[i].p, (size_t)n * 8);
             return tab[i].cnt;
         }
+    if (!strcmp(name, "con_geom1") || !strcmp(name, "con_geom2")) { /* the contacts' geom ids, as doubles */
+        const int* g = name[8] == '1' ? d->con_geom1 : d->con_geom2;
+        for (int c = 0; c < d->ncon && c < max; c++) out[c] = g[c];
+        return d->ncon;
+    }
     return -1;
 }
 int orc_get_int(const OrcData* d, const char* name) {

@@ -271,12 +271,17 @@ static void build_blob(const UhcModelDesc& d, DevNumOff& o, std::vector<double>&
             const int v0 = d.geom_vertadr ? d.geom_vertadr[g] : 0, nvt = d.geom_vertnum ? d.geom_vertnum[g] : 0;
             for (int v = v0; v < v0 + nvt; v++)
                 for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], d.mesh_vert[3 * v + k]); hi[k] = std::max(hi[k], d.mesh_vert[3 * v + k]); }
+            const double rr = (d.geom_type[g] == UHC_GEOM_SPHERE || d.geom_type[g] == UHC_GEOM_CAPSULE) ? d.geom_size[3 * g] : 0.0;  // a rounded hull reaches its radius beyond the core
             for (int k = 0; k < 3; k++) {
-                if (nvt > 0) { box[6 * g + k] = 0.5 * (lo[k] + hi[k]); box[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]); }
+                if (nvt > 0) { box[6 * g + k] = 0.5 * (lo[k] + hi[k]); box[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]) + rr; }
                 else { box[6 * g + k] = d.geom_center[3 * g + k]; box[6 * g + 3 + k] = d.geom_rbound[g]; }  // (no hull: the bounding sphere's box)
             }
         }
         o.geom_box = put(box.data(), box.size());
+        std::vector<double> rad((size_t)std::max(d.ngeom, 1), 0.0);
+        for (int g = 0; g < d.ngeom; g++)
+            if (d.geom_type[g] == UHC_GEOM_SPHERE || d.geom_type[g] == UHC_GEOM_CAPSULE) rad[g] = d.geom_size[3 * g];
+        o.geom_radius = put(rad.data(), rad.size());
     }
     o.actuator_gear = put(d.actuator_gear, 3 * (size_t)d.nu);
     o.meaninertia = put(&d.meaninertia, 1);
@@ -399,12 +404,14 @@ extern "C" int32_t uhc_batch_create(const UhcModel* const* models, int32_t n_mod
             if (ex) continue;
             int t1 = d.geom_type[g1], t2 = d.geom_type[g2];
             if (body_lastdof[b1] < 0 && body_lastdof[b2] < 0) continue;  // two static bodies never collide ([MJ-ext] same weld id)
-            if (t1 == UHC_GEOM_PLANE && t2 == UHC_GEOM_MESH && b1 == 0) { pg1.push_back(g1); pg2.push_back(g2); }
-            else if (t2 == UHC_GEOM_PLANE && t1 == UHC_GEOM_MESH && b2 == 0) { pg1.push_back(g2); pg2.push_back(g1); }
-            else if (t1 == UHC_GEOM_MESH && t2 == UHC_GEOM_MESH) { cg1.push_back(g1); cg2.push_back(g2); }
+            // hulls: meshes and the rounded hulls (sphere = one core vertex, capsule = two, + a radius: include/uhc_amd.h) -- with vertices in the mesh tables
+            auto hull = [&](int g, int t) { return (t == UHC_GEOM_MESH || t == UHC_GEOM_SPHERE || t == UHC_GEOM_CAPSULE) && d.geom_vertnum[g] > 0; };
+            if (t1 == UHC_GEOM_PLANE && hull(g2, t2) && b1 == 0) { pg1.push_back(g1); pg2.push_back(g2); }
+            else if (t2 == UHC_GEOM_PLANE && hull(g1, t1) && b2 == 0) { pg1.push_back(g2); pg2.push_back(g1); }
+            else if (hull(g1, t1) && hull(g2, t2)) { cg1.push_back(g1); cg2.push_back(g2); }
             else skipped_pairs++;
         }
-    if (skipped_pairs) { delete b; return fail("uhc_batch_create: %d collision pairs of unsupported geom types (built: plane-mesh, mesh-mesh)", skipped_pairs); }
+    if (skipped_pairs) { delete b; return fail("uhc_batch_create: %d collision pairs of unsupported geom types (built: plane-hull, hull-hull; a hull is a mesh, a sphere or a capsule)", skipped_pairs); }
     T.npair = (int)pg1.size();
     T.ncpair = (int)cg1.size();
     std::vector<int> dof_rootid(nv, 0);

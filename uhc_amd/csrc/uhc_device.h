@@ -76,6 +76,7 @@ struct DevNumOff {
     int jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_margin, qpos0, qpos_spring;
     int dof_armature, dof_damping, dof_frictionloss, dof_invweight0;
     int geom_pos, geom_quat, geom_friction, geom_margin, geom_gap, geom_solref, geom_solimp, geom_rbound, geom_center, geom_box;
+    int geom_radius;  // [ngeom] inflation radius of a ROUNDED hull (sphere, capsule: geom_size[0]), 0 for a mesh (include/uhc_amd.h)
     int mesh_vert, actuator_gear, meaninertia;
     int mesh_adj;  // int32 [nmeshvert][adjdeg] neighbours of every hull vertex (global vertex ids, -1 = none), packed two per double
     int stride;  // doubles per model

@@ -41,7 +41,7 @@ __device__ __forceinline__ bool ccd_eq(double a, double b) {
 }
 
 // A point of the Minkowski difference, v = v1 - v2, and the SUM s = v1 + v2 of its witnesses on hull 1 / hull 2: the contact position is
-// the only consumer of the witnesses and it reads them as (v1 + v2) / 2 (findPos; the margin push along +-dir cancels in the sum), so the
+// the only consumer of the witnesses and it reads them as (v1 + v2) / 2 (findPos; the margin push along +-dir cancels in the sum, the radii of two rounded hulls leave their difference there), so the
 // portal carries 6 doubles per point instead of libccd's 9 -- 15 doubles less live state through the refinement loops of every lane.
 struct CcdSup { V3 v, s; };
 __device__ __forceinline__ CcdSup sup_sel(bool c, const CcdSup& a, const CcdSup& b) {
@@ -52,8 +52,9 @@ __device__ __forceinline__ CcdSup sup_sel(bool c, const CcdSup& a, const CcdSup&
 // one convex hull posed in the world: rotation (row major), position, vertex range of the model blob
 struct CcdHull { double R[9]; V3 p; int voff, vn; };  // voff: offset (doubles) of the hull's first vertex in the vertex array
 
-// hull vertex with the largest projection on `dir` (first maximum wins), in the world, pushed out by margin / 2 along dir
-__device__ __forceinline__ V3 hull_support(const double* __restrict__ VB, const CcdHull& H, const V3& dir, double margin) {
+// hull vertex with the largest projection on `dir` (first maximum wins), in the world, pushed out by hm = margin / 2 (+ the radius of a ROUNDED hull -- a
+// sphere is one core vertex, a capsule the two ends of its segment: include/uhc_amd.h) along dir
+__device__ __forceinline__ V3 hull_support(const double* __restrict__ VB, const CcdHull& H, const V3& dir, double hm) {
     const double* vert = VB + H.voff;
     const double lx = H.R[0] * dir.x + H.R[3] * dir.y + H.R[6] * dir.z;  // R^T dir
     const double ly = H.R[1] * dir.x + H.R[4] * dir.y + H.R[7] * dir.z;
@@ -75,13 +76,12 @@ __device__ __forceinline__ V3 hull_support(const double* __restrict__ VB, const 
             if (s > bd) { bd = s; bx = c[k][0]; by = c[k][1]; bz = c[k][2]; }
         }
     }
-    const double hm = 0.5 * margin;
     return v3((H.R[0] * bx + H.R[1] * by + H.R[2] * bz) + (H.p.x + dir.x * hm), (H.R[3] * bx + H.R[4] * by + H.R[5] * bz) + (H.p.y + dir.y * hm),
               (H.R[6] * bx + H.R[7] * by + H.R[8] * bz) + (H.p.z + dir.z * hm));
 }
-__device__ __forceinline__ CcdSup ccd_support(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& dir, double margin) {
+__device__ __forceinline__ CcdSup ccd_support(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& dir, double hm1, double hm2) {
     CcdSup s;
-    const V3 v1 = hull_support(VB, H1, dir, margin), v2 = hull_support(VB, H2, neg(dir), margin);
+    const V3 v1 = hull_support(VB, H1, dir, hm1), v2 = hull_support(VB, H2, neg(dir), hm2);
     s.v = v1 - v2;
     s.s = v1 + v2;
     return s;
@@ -149,9 +149,9 @@ __device__ __forceinline__ V3 find_pos(const CcdSup& p0, const CcdSup& p1, const
     return v3(a.x * inv * 0.5, a.y * inv * 0.5, a.z * inv * 0.5);
 }
 
-// true: the hulls (each inflated by margin / 2) penetrate; depth, dir (from hull 1 to hull 2, zero if undefined) and pos are set.
+// true: the hulls (each inflated by hm = margin / 2 + its radius) penetrate; depth, dir (from hull 1 to hull 2, zero if undefined) and pos are set.
 // c1, c2: the hulls' centres (MuJoCo: geom_xpos = the mesh's centre of mass).
-__device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& c1, const V3& c2, double margin, double& depth,
+__device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, const CcdHull& H1, const CcdHull& H2, const V3& c1, const V3& c2, double hm1, double hm2, double& depth,
                                                 V3& dir, V3& pos) {
     CcdSup p0, p1, p2, p3, v4;
     double dt;
@@ -159,7 +159,7 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
     p0.s = c1 + c2; p0.v = c1 - c2;
     if (ccd_eq(p0.v.x, 0) && ccd_eq(p0.v.y, 0) && ccd_eq(p0.v.z, 0)) p0.v.x += UHC_CCD_EPS * 10;
     dir = vnorm(neg(p0.v));
-    p1 = ccd_support(VB, H1, H2, dir, margin);
+    p1 = ccd_support(VB, H1, H2, dir, hm1, hm2);
     dt = vdot(p1.v, dir);
     if (ccd_zero(dt) || dt < 0) return false;
     dir = vcross(p0.v, p1.v);
@@ -170,13 +170,13 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
         return true;
     }
     dir = vnorm(dir);
-    p2 = ccd_support(VB, H1, H2, dir, margin);
+    p2 = ccd_support(VB, H1, H2, dir, hm1, hm2);
     dt = vdot(p2.v, dir);
     if (ccd_zero(dt) || dt < 0) return false;
     dir = vnorm(vcross(p1.v - p0.v, p2.v - p0.v));
     if (vdot(dir, p0.v) > 0) { const CcdSup t = p1; p1 = p2; p2 = t; dir = neg(dir); }
     for (;;) {
-        v4 = ccd_support(VB, H1, H2, dir, margin);
+        v4 = ccd_support(VB, H1, H2, dir, hm1, hm2);
         dt = vdot(v4.v, dir);
         if (ccd_zero(dt) || dt < 0) return false;
         bool cont = false;
@@ -194,7 +194,7 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
         dir = portal_dir(p1, p2, p3);
         dt = vdot(dir, p1.v);
         if (ccd_zero(dt) || dt > 0) break;  // the portal encapsulates the origin
-        v4 = ccd_support(VB, H1, H2, dir, margin);
+        v4 = ccd_support(VB, H1, H2, dir, hm1, hm2);
         dt = vdot(v4.v, dir);
         if (!(ccd_zero(dt) || dt > 0) || portal_reach_tolerance(p1, p2, p3, v4, dir)) return false;
         expand_portal(p0, p1, p2, p3, v4);
@@ -202,7 +202,7 @@ __device__ __forceinline__ bool mpr_penetration(const double* __restrict__ VB, c
     // ---- findPenetr
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
-        v4 = ccd_support(VB, H1, H2, dir, margin);
+        v4 = ccd_support(VB, H1, H2, dir, hm1, hm2);
         if (portal_reach_tolerance(p1, p2, p3, v4, dir) || it > UHC_MPR_MAXIT) {
             V3 pd;
             depth = sqrt(point_tri_dist2(p1.v, p2.v, p3.v, pd));
@@ -229,7 +229,7 @@ struct MprLane {     // one candidate pair (valid in lanes whose `st` is not MPR
     int b1, b2;      // bodies of the two hulls (poses are read from LDS: xmat, xpos)
     int voff1, vn1, voff2, vn2;  // vertex ranges (doubles offset into VB, count)
     V3 c1, c2;       // hull centres in the world
-    double margin;
+    double hm1, hm2; // how far each hull's surface lies beyond its vertices along a query direction: margin / 2, + the radius of a rounded hull (sphere, capsule)
     // results
     bool hit;
     double depth;
@@ -243,9 +243,9 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return fmax(fmax(bcast(v, 0), bcast(v, 16)), fmax(bcast(v, 32), bcast(v, 48)));
 }
 // support point of one hull for the pair owned by lane p (all arguments wave-uniform): the hull vertex with the largest projection on
-// dir (first maximum), in the world, pushed out by margin / 2 along dir -- bit for bit hull_support's value
+// dir (first maximum), in the world, pushed out by hm (margin / 2 + the hull's radius) along dir -- bit for bit hull_support's value
 __device__ __forceinline__ V3 hull_support_wave(const double* __restrict__ VB, const double* __restrict__ R, const double* __restrict__ P, int voff, int vn, const V3& dir,
-                                                double margin) {
+                                                double hm) {
     const double lx = R[0] * dir.x + R[3] * dir.y + R[6] * dir.z;  // R^T dir
     const double ly = R[1] * dir.x + R[4] * dir.y + R[7] * dir.z;
     const double lz = R[2] * dir.x + R[5] * dir.y + R[8] * dir.z;
@@ -262,17 +262,16 @@ __device__ __forceinline__ V3 hull_support_wave(const double* __restrict__ VB, c
             bd = mx; bx = bcast(cx, k); by = bcast(cy, k); bz = bcast(cz, k);
         }
     }
-    const double hm = 0.5 * margin;
     return v3((R[0] * bx + R[1] * by + R[2] * bz) + (P[0] + dir.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (P[1] + dir.y * hm),
               (R[6] * bx + R[7] * by + R[8] * bz) + (P[2] + dir.z * hm));
 }
 // Both hulls of a pair at once when each fits one trip (<= 64 vertices: every generated model): straight-line code, the two loads, dot
 // products and DPP reductions interleave instead of running one after the other through a loop branch.
 __device__ __forceinline__ void pair_support_wave(const double* __restrict__ VB, const double* __restrict__ R1, const double* __restrict__ P1, int voff1, int vn1,
-                                                  const double* __restrict__ R2, const double* __restrict__ P2, int voff2, int vn2, const V3& d, double margin, V3& a, V3& b) {
+                                                  const double* __restrict__ R2, const double* __restrict__ P2, int voff2, int vn2, const V3& d, double hm1, double hm2, V3& a, V3& b) {
     if (vn1 > UHC_WAVE || vn2 > UHC_WAVE) {
-        a = hull_support_wave(VB, R1, P1, voff1, vn1, d, margin);
-        b = hull_support_wave(VB, R2, P2, voff2, vn2, neg(d), margin);
+        a = hull_support_wave(VB, R1, P1, voff1, vn1, d, hm1);
+        b = hull_support_wave(VB, R2, P2, voff2, vn2, neg(d), hm2);
         return;
     }
     const bool in1 = LANE < vn1, in2 = LANE < vn2;
@@ -293,11 +292,10 @@ __device__ __forceinline__ void pair_support_wave(const double* __restrict__ VB,
     m2 = fmax(fmax(bcast(m2, 0), bcast(m2, 16)), fmax(bcast(m2, 32), bcast(m2, 48)));
     const int k1 = __ffsll((long long)__builtin_amdgcn_ballot_w64(s1 == m1)) - 1, k2 = __ffsll((long long)__builtin_amdgcn_ballot_w64(s2 == m2)) - 1;
     const double b1x = bcast(x1, k1), b1y = bcast(y1, k1), b1z = bcast(z1, k1), b2x = bcast(x2, k2), b2y = bcast(y2, k2), b2z = bcast(z2, k2);
-    const double hm = 0.5 * margin;
-    a = v3((R1[0] * b1x + R1[1] * b1y + R1[2] * b1z) + (P1[0] + d.x * hm), (R1[3] * b1x + R1[4] * b1y + R1[5] * b1z) + (P1[1] + d.y * hm),
-           (R1[6] * b1x + R1[7] * b1y + R1[8] * b1z) + (P1[2] + d.z * hm));
-    b = v3((R2[0] * b2x + R2[1] * b2y + R2[2] * b2z) + (P2[0] + e.x * hm), (R2[3] * b2x + R2[4] * b2y + R2[5] * b2z) + (P2[1] + e.y * hm),
-           (R2[6] * b2x + R2[7] * b2y + R2[8] * b2z) + (P2[2] + e.z * hm));
+    a = v3((R1[0] * b1x + R1[1] * b1y + R1[2] * b1z) + (P1[0] + d.x * hm1), (R1[3] * b1x + R1[4] * b1y + R1[5] * b1z) + (P1[1] + d.y * hm1),
+           (R1[6] * b1x + R1[7] * b1y + R1[8] * b1z) + (P1[2] + d.z * hm1));
+    b = v3((R2[0] * b2x + R2[1] * b2y + R2[2] * b2z) + (P2[0] + e.x * hm2), (R2[3] * b2x + R2[4] * b2y + R2[5] * b2z) + (P2[1] + e.y * hm2),
+           (R2[6] * b2x + R2[7] * b2y + R2[8] * b2z) + (P2[2] + e.z * hm2));
 }
 // Two pairs' requests at once (every hull <= 64 vertices): four independent load / dot / reduction chains in straight-line code.  A support
 // query is a dependent chain of ~300 cycles that keeps the VALU busy a third of the time; the second pair's chain fills the gaps.  Per pair
@@ -305,7 +303,7 @@ __device__ __forceinline__ void pair_support_wave(const double* __restrict__ VB,
 #ifndef UHC_MPR_PAIRWISE
 #define UHC_MPR_PAIRWISE 1
 #endif
-struct SupArgs { const double *R1, *P1, *R2, *P2; int voff1, vn1, voff2, vn2; V3 d; double margin; };
+struct SupArgs { const double *R1, *P1, *R2, *P2; int voff1, vn1, voff2, vn2; V3 d; double hm1, hm2; };
 __device__ __forceinline__ void pair_support_wave2(const double* __restrict__ VB, const SupArgs& A, const SupArgs& B, V3& aA, V3& bA, V3& aB, V3& bB) {
     const bool iA1 = LANE < A.vn1, iA2 = LANE < A.vn2, iB1 = LANE < B.vn1, iB2 = LANE < B.vn2;
     const double* cA1 = VB + A.voff1 + 3 * (iA1 ? LANE : 0);
@@ -336,13 +334,13 @@ __device__ __forceinline__ void pair_support_wave2(const double* __restrict__ VB
     const int kA1 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sA1 == mA1)) - 1, kA2 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sA2 == mA2)) - 1;
     const int kB1 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sB1 == mB1)) - 1, kB2 = __ffsll((long long)__builtin_amdgcn_ballot_w64(sB2 == mB2)) - 1;
     double bx, by, bz, hm;
-    bx = bcast(xA1, kA1); by = bcast(yA1, kA1); bz = bcast(zA1, kA1); hm = 0.5 * A.margin; R = A.R1;
+    bx = bcast(xA1, kA1); by = bcast(yA1, kA1); bz = bcast(zA1, kA1); hm = A.hm1; R = A.R1;
     aA = v3((R[0] * bx + R[1] * by + R[2] * bz) + (A.P1[0] + dA.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (A.P1[1] + dA.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (A.P1[2] + dA.z * hm));
-    bx = bcast(xA2, kA2); by = bcast(yA2, kA2); bz = bcast(zA2, kA2); R = A.R2;
+    bx = bcast(xA2, kA2); by = bcast(yA2, kA2); bz = bcast(zA2, kA2); hm = A.hm2; R = A.R2;
     bA = v3((R[0] * bx + R[1] * by + R[2] * bz) + (A.P2[0] + eA.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (A.P2[1] + eA.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (A.P2[2] + eA.z * hm));
-    bx = bcast(xB1, kB1); by = bcast(yB1, kB1); bz = bcast(zB1, kB1); hm = 0.5 * B.margin; R = B.R1;
+    bx = bcast(xB1, kB1); by = bcast(yB1, kB1); bz = bcast(zB1, kB1); hm = B.hm1; R = B.R1;
     aB = v3((R[0] * bx + R[1] * by + R[2] * bz) + (B.P1[0] + dB.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (B.P1[1] + dB.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (B.P1[2] + dB.z * hm));
-    bx = bcast(xB2, kB2); by = bcast(yB2, kB2); bz = bcast(zB2, kB2); R = B.R2;
+    bx = bcast(xB2, kB2); by = bcast(yB2, kB2); bz = bcast(zB2, kB2); hm = B.hm2; R = B.R2;
     bB = v3((R[0] * bx + R[1] * by + R[2] * bz) + (B.P2[0] + eB.x * hm), (R[3] * bx + R[4] * by + R[5] * bz) + (B.P2[1] + eB.y * hm), (R[6] * bx + R[7] * by + R[8] * bz) + (B.P2[2] + eB.z * hm));
 }
 // xmat / xpos: the bodies' poses in LDS ([nbody][9], [nbody][3])
@@ -372,7 +370,7 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
                 Ap.R1 = xmat + 9 * b1; Ap.P1 = xpos + 3 * b1; Ap.R2 = xmat + 9 * b2; Ap.P2 = xpos + 3 * b2;
                 Ap.voff1 = __builtin_amdgcn_readlane(M.voff1, p); Ap.vn1 = __builtin_amdgcn_readlane(M.vn1, p);
                 Ap.voff2 = __builtin_amdgcn_readlane(M.voff2, p); Ap.vn2 = __builtin_amdgcn_readlane(M.vn2, p);
-                Ap.d = v3(bcast(dir.x, p), bcast(dir.y, p), bcast(dir.z, p)); Ap.margin = bcast(M.margin, p);
+                Ap.d = v3(bcast(dir.x, p), bcast(dir.y, p), bcast(dir.z, p)); Ap.hm1 = bcast(M.hm1, p); Ap.hm2 = bcast(M.hm2, p);
             }
             V3 a, b;
             if (live && UHC_MPR_PAIRWISE) {  // a second request of this round: served together with the first
@@ -382,7 +380,7 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
                 Aq.R1 = xmat + 9 * b1; Aq.P1 = xpos + 3 * b1; Aq.R2 = xmat + 9 * b2; Aq.P2 = xpos + 3 * b2;
                 Aq.voff1 = __builtin_amdgcn_readlane(M.voff1, q); Aq.vn1 = __builtin_amdgcn_readlane(M.vn1, q);
                 Aq.voff2 = __builtin_amdgcn_readlane(M.voff2, q); Aq.vn2 = __builtin_amdgcn_readlane(M.vn2, q);
-                Aq.d = v3(bcast(dir.x, q), bcast(dir.y, q), bcast(dir.z, q)); Aq.margin = bcast(M.margin, q);
+                Aq.d = v3(bcast(dir.x, q), bcast(dir.y, q), bcast(dir.z, q)); Aq.hm1 = bcast(M.hm1, q); Aq.hm2 = bcast(M.hm2, q);
                 if (max(max(Ap.vn1, Ap.vn2), max(Aq.vn1, Aq.vn2)) <= UHC_WAVE) {
                     live &= live - 1;
                     V3 a2, b2v;
@@ -396,7 +394,7 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
                     continue;
                 }
             }
-            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.margin, a, b);
+            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.hm1, Ap.hm2, a, b);
             const bool mine = LANE == p;
             v4.v = vsel(mine, a - b, v4.v);
             v4.s = vsel(mine, a + b, v4.s);
@@ -479,8 +477,8 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
 enum { MCMD_EXIT = 0, MCMD_ROUND = 1 };
 // The mailbox sits on the rows' scalar arrays (free until the rows are enumerated), every piece INSIDE one of them (the debug layout puts guard words between the arrays):
 //   rowR: ints cmd, live lo, live hi, vertex base (LDS offset in doubles, or -1: the global pointer in ints 4, 5) | x of the direction in / of v1 - v2 out, per pair
-//   rowAref: y, z | rowB: x, y of v1 + v2 | rowF: its z, the pair's margin | rowDa: ints b1, b2, voff1, vn1 per pair | rowW: ints voff2, vn2 per pair
-struct MprMB { int* hdr; double* io[6]; double* margin; int* st4; int* st2; };
+//   rowAref: y, z | rowB: x, y of v1 + v2 | rowF: its z, the pair's hm1 | rowDa: ints b1, b2, voff1, vn1 per pair | rowW: ints voff2, vn2 per pair, then the pair's hm2
+struct MprMB { int* hdr; double* io[6]; double* hm1; double* hm2; int* st4; int* st2; };
 template <int TIER>
 __device__ __forceinline__ MprMB mpr_mb(const KernelArgs& A, double* S) {
     const DevLds& L = lds_of<TIER>(A);
@@ -489,8 +487,8 @@ __device__ __forceinline__ MprMB mpr_mb(const KernelArgs& A, double* S) {
     m.io[0] = S + L.rowR + 4;
     m.io[1] = S + L.rowAref; m.io[2] = S + L.rowAref + UHC_WAVE;
     m.io[3] = S + L.rowB; m.io[4] = S + L.rowB + UHC_WAVE;
-    m.io[5] = S + L.rowF; m.margin = S + L.rowF + UHC_WAVE;
-    m.st4 = (int*)(S + L.rowDa); m.st2 = (int*)(S + L.rowW);
+    m.io[5] = S + L.rowF; m.hm1 = S + L.rowF + UHC_WAVE;
+    m.st4 = (int*)(S + L.rowDa); m.st2 = (int*)(S + L.rowW); m.hm2 = S + L.rowW + UHC_WAVE;  // (st2: 128 ints = the first 64 doubles of rowW)
     return m;
 }
 __device__ __forceinline__ SupArgs mpr_mb_args(const MprMB& MB, const double* xmat, const double* xpos, int p) {
@@ -499,7 +497,7 @@ __device__ __forceinline__ SupArgs mpr_mb_args(const MprMB& MB, const double* xm
     a.R1 = xmat + 9 * b1; a.P1 = xpos + 3 * b1; a.R2 = xmat + 9 * b2; a.P2 = xpos + 3 * b2;
     a.voff1 = __builtin_amdgcn_readfirstlane(MB.st4[4 * p + 2]); a.vn1 = __builtin_amdgcn_readfirstlane(MB.st4[4 * p + 3]);
     a.voff2 = __builtin_amdgcn_readfirstlane(MB.st2[2 * p]); a.vn2 = __builtin_amdgcn_readfirstlane(MB.st2[2 * p + 1]);
-    a.margin = MB.margin[p];
+    a.hm1 = MB.hm1[p]; a.hm2 = MB.hm2[p];
     a.d = v3(MB.io[0][p], MB.io[1][p], MB.io[2][p]);
     return a;
 }
@@ -533,7 +531,7 @@ __device__ __forceinline__ void mpr_serve_round(const double* __restrict__ VB, c
             }
         }
         if (mine) {
-            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.margin, a, b);
+            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.hm1, Ap.hm2, a, b);
             mpr_mb_put(MB, p, a, b);
         }
     }
@@ -555,7 +553,7 @@ __device__ __forceinline__ void mpr_wave_mw(const double* __restrict__ VB, const
         st = MPR_D1;
         MB.st4[4 * LANE] = M.b1; MB.st4[4 * LANE + 1] = M.b2; MB.st4[4 * LANE + 2] = M.voff1; MB.st4[4 * LANE + 3] = M.vn1;
         MB.st2[2 * LANE] = M.voff2; MB.st2[2 * LANE + 1] = M.vn2;
-        MB.margin[LANE] = M.margin;
+        MB.hm1[LANE] = M.hm1; MB.hm2[LANE] = M.hm2;
     }
     int* mbi = MB.hdr;
     if (LANE == 0) {

@@ -785,6 +785,19 @@ __device__ __forceinline__ void make_frame(double* f) {
     f[3] /= n; f[4] /= n; f[5] /= n;
     cross3(f + 6, f, f + 3);
 }
+// [MJ-ext] mju_makeFrame with the y axis supplied (mjc_PlaneCapsule aligns the contact frame with the capsule's axis): y made orthogonal to x and normalised,
+// z = x cross y; a y (nearly) parallel to x falls back to make_frame's pick (oracle/physics_oracle.c: make_frame_hint)
+__device__ __forceinline__ void make_frame_hint(double* f, const double* y) {
+    double n = sqrt(dot3(f, f));
+    f[0] /= n; f[1] /= n; f[2] /= n;
+    const double dp = dot3(f, y);
+    double t[3];
+    for (int k = 0; k < 3; k++) t[k] = y[k] - f[k] * dp;
+    n = sqrt(dot3(t, t));
+    if (n < 1e-8) { make_frame(f); return; }
+    for (int k = 0; k < 3; k++) f[3 + k] = t[k] / n;
+    cross3(f + 6, f, f + 3);
+}
 __device__ __forceinline__ double impedance(const double* si, double pos, double margin) {
     double dmin = clampd(si[0], 0.0001, 0.9999), dmax = clampd(si[1], 0.0001, 0.9999), width = si[2];
     double mid = clampd(si[3], 0.0001, 0.9999), power = si[4] < 1 ? 1 : si[4];
@@ -801,14 +814,17 @@ __device__ __forceinline__ double impedance(const double* si, double pos, double
 // Per-lane constants of the statically filtered collision pairs (lane = pair, first 64 pairs): geom / body ids, hull vertex
 // range and contact dimension, loaded once per kernel; a wave-uniform pair index fetches them with v_readlane instead of a
 // chain of dependent global table loads every substep.
-struct PairConst { int g1, g2, b1, b2, va, vn, dim; };
+struct PairConst { int g1, g2, b1, b2, va, vn, dim; };  // dim: bit 8 set = the hull is a capsule (its contact frames lie along its axis)
+__device__ __forceinline__ int pair_dim(const DevTopo& T, int g1, int g2) {
+    return max(T.geom_condim[g1], T.geom_condim[g2]) | ((T.geom_type[g2] == UHC_GEOM_CAPSULE && T.geom_vertnum[g2] == 2) ? 256 : 0);
+}
 __device__ __forceinline__ PairConst pair_const(const DevTopo& T) {
     PairConst c = {0, 0, 0, 0, 0, 0, 0};
     if (LANE < T.npair) {
         c.g1 = T.pair_g1[LANE]; c.g2 = T.pair_g2[LANE];
         c.b1 = T.geom_bodyid[c.g1]; c.b2 = T.geom_bodyid[c.g2];
         c.va = T.geom_vertadr[c.g2]; c.vn = T.geom_vertnum[c.g2];
-        c.dim = max(T.geom_condim[c.g1], T.geom_condim[c.g2]);
+        c.dim = pair_dim(T, c.g1, c.g2);
     }
     return c;
 }
@@ -823,18 +839,19 @@ __device__ __forceinline__ PairConst pair_of(const DevTopo& T, const PairConst& 
         c.g1 = T.pair_g1[pi]; c.g2 = T.pair_g2[pi];
         c.b1 = T.geom_bodyid[c.g1]; c.b2 = T.geom_bodyid[c.g2];
         c.va = T.geom_vertadr[c.g2]; c.vn = T.geom_vertnum[c.g2];
-        c.dim = max(T.geom_condim[c.g1], T.geom_condim[c.g2]);
+        c.dim = pair_dim(T, c.g1, c.g2);
     }
     return c;
 }
 template <int TIER>
 __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const double* mb, double* S, int c, int g1, int g2, int b1, int b2, int dim,
-                                                const double* pos, const double* n, double dist, double margin, double gap) {
+                                                const double* pos, const double* n, double dist, double margin, double gap, const double* yhint = nullptr) {
     const DevTopo& T = A.t;
     double* C = S + lds_of<TIER>(A).con + c * UHC_CON_STRIDE;
     double fr[9];
     for (int k = 0; k < 3; k++) { C[k] = pos[k]; fr[k] = n[k]; }
-    make_frame(fr);
+    if (yhint) make_frame_hint(fr, yhint);
+    else make_frame(fr);
     for (int k = 0; k < 9; k++) C[3 + k] = fr[k];
     const double inc = margin - gap;
     double solref[2], solimp[5];
@@ -914,6 +931,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             for (int k = 0; k < 3; k++) ppos[k] = S[L.xpos + 3 * b1 + k] + t[k];
             const double margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
             const double gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
+            const double rr = mb[A.o.geom_radius + g2];  // a rounded hull's radius (0 for a mesh); loaded here, with the margin and the gap: nothing waits for it before the arg-min is through
             const int va = P.va, vn = P.vn;
             // support vertex along -normal: lane-local min then wave arg-min (ties -> lowest vertex id)
             double bd = 1e300;
@@ -936,7 +954,17 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 }
                 bd = mn; bv = cand;
             }
+            // a ROUNDED hull (sphere: one core vertex, capsule: the two ends of its segment) is its core lowered by the radius: [MJ-ext] _PlaneSphere at the centre / at
+            // both segment ends (mjc_PlaneCapsule, which also lays the contact frame's second axis along the capsule); 0 for a mesh
+            bd -= rr;
             if (bd > margin || bv == 0x7fffffff) continue;
+            double cax[3] = {0, 0, 0};
+            const bool capsule = (P.dim & 256) != 0;
+            if (capsule) {  // the capsule's axis in the world: from its second core vertex to its first
+                double dl[3];
+                for (int k = 0; k < 3; k++) dl[k] = mb[A.o.mesh_vert + 3 * va + k] - mb[A.o.mesh_vert + 3 * (va + 1) + k];
+                mat_vec(cax, m2, dl);
+            }
             // candidate 0 = support vertex, candidates 1.. = its hull neighbours (adjacency order)
             // (the hull graph belongs to the env's model: body shapes generated from different betas have different hulls.  Fixed-stride
             //  table of neighbour ids in the model blob, -1 past a vertex's own degree)
@@ -948,13 +976,15 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 double lv[3] = {mb[A.o.mesh_vert + 3 * v], mb[A.o.mesh_vert + 3 * v + 1], mb[A.o.mesh_vert + 3 * v + 2]};
                 mat_vec(w, m2, lv);
                 for (int k = 0; k < 3; k++) { w[k] += xp2[k]; dist += n[k] * (w[k] - ppos[k]); }
+                dist -= rr;
                 ok = LANE == 0 || dist <= margin;
             }
             const unsigned long long cm = __ballot(ok);
             const int rank = __popcll(cm & ((1ull << LANE) - 1ull));
             if (ok && rank < T.plane_mesh_maxcon && ncon + rank < cap_of<TIER>(A).maxcon) {
-                const double cp[3] = {w[0] - 0.5 * dist * n[0], w[1] - 0.5 * dist * n[1], w[2] - 0.5 * dist * n[2]};
-                k_write_contact<TIER>(A, mb, S, ncon + rank, P.g1, P.g2, P.b1, P.b2, P.dim, cp, n, dist, margin, gap);
+                const double push = rr + 0.5 * dist;
+                const double cp[3] = {w[0] - push * n[0], w[1] - push * n[1], w[2] - push * n[2]};
+                k_write_contact<TIER>(A, mb, S, ncon + rank, P.g1, P.g2, P.b1, P.b2, P.dim & 255, cp, n, dist, margin, gap, capsule ? cax : nullptr);
             }
             const int want = ncon + min((int)__popcll(cm), T.plane_mesh_maxcon);
             if (want > cap_of<TIER>(A).maxcon) *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_CONTACTS;  // 1: needs the next tier, 2: dropped
@@ -1030,7 +1060,8 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             double gap = 0;
             MprLane M;
             M.b1 = M.b2 = M.voff1 = M.vn1 = M.voff2 = M.vn2 = 0;
-            M.margin = 0; M.c1 = M.c2 = v3(0, 0, 0);
+            M.hm1 = M.hm2 = 0; M.c1 = M.c2 = v3(0, 0, 0);
+            double margin = 0;
             if (act) {
                 const int p = cand[ci];
                 g1 = T.cpair_g1[p]; g2 = T.cpair_g2[p];
@@ -1043,7 +1074,8 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
                 mat_vec(t1, R1, ce1); mat_vec(t2, R2, ce2);
                 M.c1 = v3(t1[0] + S[L.xpos + 3 * M.b1], t1[1] + S[L.xpos + 3 * M.b1 + 1], t1[2] + S[L.xpos + 3 * M.b1 + 2]);
                 M.c2 = v3(t2[0] + S[L.xpos + 3 * M.b2], t2[1] + S[L.xpos + 3 * M.b2 + 1], t2[2] + S[L.xpos + 3 * M.b2 + 2]);
-                M.margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                margin = fmax(mb[A.o.geom_margin + g1], mb[A.o.geom_margin + g2]);
+                M.hm1 = 0.5 * margin + mb[A.o.geom_radius + g1]; M.hm2 = 0.5 * margin + mb[A.o.geom_radius + g2];  // how far each hull's surface lies beyond its (core) vertices
                 gap = fmax(mb[A.o.geom_gap + g1], mb[A.o.geom_gap + g2]);
             }
 #if defined(UHC_NW2)
@@ -1060,7 +1092,7 @@ __device__ __forceinline__ int k_collision(const KernelArgs& A, const double* mb
             const int rank = __popcll(hm & ((1ull << LANE) - 1ull));
             if (hit && ncon + rank < cap_of<TIER>(A).maxcon) {
                 const double cp[3] = {M.pos.x, M.pos.y, M.pos.z}, nn[3] = {M.dir.x, M.dir.y, M.dir.z};
-                k_write_contact<TIER>(A, mb, S, ncon + rank, g1, g2, M.b1, M.b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, M.margin - M.depth, M.margin, gap);
+                k_write_contact<TIER>(A, mb, S, ncon + rank, g1, g2, M.b1, M.b2, max(T.geom_condim[g1], T.geom_condim[g2]), cp, nn, margin - M.depth, margin, gap);
             }
             const int want = ncon + (int)__popcll(hm);
             if (want > cap_of<TIER>(A).maxcon) *overflow |= (hands_on<TIER>(A) ? 1 : 2) | UHC_WHY_CONTACTS;

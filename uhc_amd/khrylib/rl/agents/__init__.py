@@ -222,10 +222,21 @@ class Agent:
         env, R = self.env, self._ro
         torch.cuda.synchronize()
         g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_pre):
-            self._seg_pre()
-        with torch.cuda.graph(g_post, pool=g_pre.pool()):
-            self._seg_post()
+        # No finaliser may run while a stream is capturing: the cyclic garbage of an EARLIER agent / env (a test suite makes several per process) ends in
+        # uhc_batch_free / uhc_env_free -- hipFree, event and stream destruction -- which a capture in global mode does not allow.  Collect what is pending first,
+        # then hold the collector back until both captures are over (uhc_amd/sim.py defers such a free as well, should one come from elsewhere).
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g_pre):
+                self._seg_pre()
+            with torch.cuda.graph(g_post, pool=g_pre.pool()):
+                self._seg_post()
+        finally:
+            if gc_was_on:
+                gc.enable()
         env.sim.use_current_stream()  # back from the capture stream
         R.graphs = (g_pre, g_post)
         R.graph_gen = getattr(getattr(env, "env", None), "generation", 0)

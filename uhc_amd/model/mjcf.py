@@ -8,7 +8,7 @@ assets/mujoco_models/template/humanoid_template.xml, test.xml):
 
   compiler(angle, coordinate, inertiafromgeom) / default(joint, geom, motor)
   option(timestep, gravity, iterations, tolerance) / asset(mesh file=)
-  worldbody -> nested body(name,pos,quat) { joint(free|ball|hinge), geom(plane|mesh|box|sphere) }
+  worldbody -> nested body(name,pos,quat) { joint(free|ball|hinge), geom(plane|mesh|box|sphere|capsule [size + pos/quat, or fromto]) }
   contact/exclude(body1, body2) / actuator/motor(joint, gear)
 
 MuJoCo 2.1.0 itself is not available to this build; every
@@ -28,7 +28,16 @@ from typing import Dict, List, Optional
 import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3  # [MJ-ext] mjtJoint order
-GEOM_PLANE, GEOM_SPHERE, GEOM_BOX, GEOM_MESH = 0, 2, 6, 7  # [MJ-ext] mjtGeom values
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH = 0, 2, 3, 6, 7  # [MJ-ext] mjtGeom values
+# Geoms that collide as convex hulls: meshes, and the ROUNDED hulls -- a sphere is one vertex, a capsule the two end points of its segment, each pushed out by
+# geom_size[0] (the radius) along the query direction.  They share the mesh geoms' vertex tables (geom_vertadr / geom_vertnum / mesh_vert / mesh_adj).
+HULL_TYPES = (GEOM_MESH, GEOM_SPHERE, GEOM_CAPSULE)
+
+
+def geom_radius(m: "Model") -> np.ndarray:
+    """Inflation radius of every geom's hull: geom_size[0] of spheres and capsules, 0 for meshes (whose `size` MuJoCo ignores) and everything else."""
+    t = np.asarray(m.geom_type)
+    return np.where((t == GEOM_SPHERE) | (t == GEOM_CAPSULE), np.asarray(m.geom_size)[:, 0], 0.0)
 
 MINVAL = 1e-15  # [MJ-ext] mjMINVAL
 
@@ -360,6 +369,18 @@ class _Defaults:
 # constants MuJoCo's mj_setConst derives at qpos0: dof_invweight0,
 # body_invweight0, stat.meaninertia [MJ-ext])
 # --------------------------------------------------------------------------- #
+def _z_to_quat(vec):
+    """[MJ-ext] mjuu_z2quat: the rotation that takes the z axis onto `vec` (about z x vec)."""
+    v = np.asarray(vec, dtype=np.float64)
+    v = v / np.linalg.norm(v)
+    ax = np.cross([0.0, 0.0, 1.0], v)
+    sn = np.linalg.norm(ax)
+    if sn < 1e-10:
+        return np.array([1.0, 0, 0, 0]) if v[2] > 0 else np.array([0.0, 1.0, 0, 0])
+    ang = np.arctan2(sn, v[2])
+    return np.r_[np.cos(0.5 * ang), np.sin(0.5 * ang) * ax / sn]
+
+
 def _axis_angle_quat(axis, angle):
     s = np.sin(angle * 0.5)
     return np.array([np.cos(angle * 0.5), axis[0] * s, axis[1] * s, axis[2] * s])
@@ -541,11 +562,24 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
     def parse_geom(e, bid):
         g = dict(body=bid, name=e.attrib.get("name", ""))
         t = dfl.get("geom", e, "type", "sphere")
-        g["type"] = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "box": GEOM_BOX, "mesh": GEOM_MESH}[t]
+        g["type"] = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX, "mesh": GEOM_MESH}[t]
         g["mesh"] = e.attrib.get("mesh")
         g["pos"] = _floats(e.attrib.get("pos"), 3, [0, 0, 0])
         g["quat"] = _floats(e.attrib.get("quat"), 4, [1, 0, 0, 0])
-        g["size"] = _floats(dfl.get("geom", e, "size"), 3, [0, 0, 0])
+        sz = _floats(dfl.get("geom", e, "size"))
+        sz = np.zeros(0) if sz is None else np.atleast_1d(sz)
+        g["size"] = np.r_[sz, np.zeros(3)][:3]
+        if "fromto" in e.attrib:  # [MJ-ext] capsule between two points: pos = their middle, z axis along the segment, size = (radius, half length)
+            if g["type"] != GEOM_CAPSULE:
+                raise ValueError("fromto is supported for capsules only")
+            ft = _floats(e.attrib["fromto"], 6)
+            d = ft[3:] - ft[:3]
+            hl = 0.5 * np.linalg.norm(d)
+            if hl < MINVAL:
+                raise ValueError("capsule fromto: the two points coincide")
+            g["pos"] = 0.5 * (ft[:3] + ft[3:])
+            g["quat"] = _z_to_quat(d)
+            g["size"] = np.array([g["size"][0], hl, 0.0])
         g["contype"] = int(dfl.get("geom", e, "contype", 1))
         g["conaffinity"] = int(dfl.get("geom", e, "conaffinity", 1))
         g["condim"] = int(dfl.get("geom", e, "condim", 3))
@@ -791,12 +825,35 @@ def compile_mjcf(xml: str, asset_dir: str = ".", meshes: Optional[Dict[str, np.n
             I, com = Rg @ Il @ Rg.T, g["pos"]
             m.geom_center[gi] = com
             m.geom_rbound[gi] = np.linalg.norm(g["size"])
-        elif g["type"] == GEOM_SPHERE:
+        elif g["type"] in (GEOM_SPHERE, GEOM_CAPSULE):
+            # [MJ-ext] mjCGeom::SetInertia; for collisions the geom is a ROUNDED HULL: its core vertices (body frame) share the mesh tables
             r = g["size"][0]
-            mass = g["density"] * 4.0 / 3.0 * np.pi * r ** 3
-            I, com = 0.4 * mass * r * r * np.eye(3), g["pos"]
+            if g["type"] == GEOM_SPHERE:
+                mass = g["density"] * 4.0 / 3.0 * np.pi * r ** 3
+                Il = 0.4 * mass * r * r * np.eye(3)
+                core = np.array([g["pos"]])
+                nb = [[]]
+            else:
+                h = 2.0 * g["size"][1]
+                mass = g["density"] * (np.pi * r * r * h + 4.0 / 3.0 * np.pi * r ** 3)
+                ms = mass * 4 * r / (4 * r + 3 * h)  # the two half spheres
+                mc = mass - ms
+                ixx = mc * (3 * r * r + h * h) / 12 + 2 * ms * r * r / 5 + ms * h * (3 * r + 2 * h) / 8
+                Il = np.diag([ixx, ixx, mc * r * r / 2 + 2 * ms * r * r / 5])
+                axis = Rg[:, 2]
+                core = np.array([g["pos"] + g["size"][1] * axis, g["pos"] - g["size"][1] * axis])  # [MJ-ext] mjc_PlaneCapsule's order: pos + segment first
+                nb = [[1], [0]]
+            I, com = Rg @ Il @ Rg.T, g["pos"]
+            m.geom_vertadr[gi] = vbase
+            m.geom_vertnum[gi] = len(core)
+            all_verts.append(core)
+            deg = np.array([len(l) for l in nb], dtype=np.int32)
+            adj_adr.append((np.r_[0, np.cumsum(deg)][:-1] + abase).astype(np.int32))
+            adj_idx.append(np.array([j for l in nb for j in l], dtype=np.int32) + vbase)
+            vbase += len(core)
+            abase += int(deg.sum())
             m.geom_center[gi] = com
-            m.geom_rbound[gi] = r
+            m.geom_rbound[gi] = r + (g["size"][1] if g["type"] == GEOM_CAPSULE else 0.0)
         else:  # plane: massless, unbounded
             continue
         if bid > 0:
@@ -885,6 +942,7 @@ def scale_model(m: Model, s: float) -> Model:
     for name in ("body_pos", "body_ipos", "jnt_pos", "geom_pos", "geom_center", "mesh_vert"):
         setattr(o, name, getattr(m, name) * s)
     o.geom_rbound = m.geom_rbound * s
+    o.geom_size = np.where(np.isin(m.geom_type, (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX))[:, None], m.geom_size * s, m.geom_size)
     o.body_mass = m.body_mass * s ** 3
     o.body_inertia = m.body_inertia * s ** 5
     o.qpos0 = m.qpos0.copy()
@@ -1124,9 +1182,10 @@ def scale_model_per_body(m: Model, scales) -> Model:
     o.geom_pos = m.geom_pos * s[gb][:, None]
     o.geom_center = m.geom_center * s[gb][:, None]
     o.geom_rbound = m.geom_rbound * s[gb]
+    o.geom_size = np.where(np.isin(m.geom_type, (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX))[:, None], m.geom_size * s[gb][:, None], m.geom_size)
     mv = m.mesh_vert.copy()
     for g in range(m.ngeom):
-        if m.geom_type[g] == GEOM_MESH:
+        if m.geom_type[g] in HULL_TYPES:
             a, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
             mv[a:a + n] *= s[gb[g]]
     o.mesh_vert = mv
@@ -1157,7 +1216,7 @@ def export_mjcf(m: Model, density: Optional[float] = None) -> str:
     children: List[List[int]] = [[] for _ in range(m.nbody)]
     for b in range(1, m.nbody):
         children[int(m.body_parentid[b])].append(b)
-    gtype = {GEOM_PLANE: "plane", GEOM_SPHERE: "sphere", GEOM_BOX: "box", GEOM_MESH: "mesh"}
+    gtype = {GEOM_PLANE: "plane", GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box", GEOM_MESH: "mesh"}
 
     def geoms_of(b, ind):
         for g in range(m.ngeom):
@@ -1239,7 +1298,7 @@ def common_mesh_layout(models: List[Model]) -> List[Model]:
         verts, adr_new, remap = [], np.full(ng, -1, dtype=np.int32), np.full(m.nmeshvert, -1, dtype=np.int64)
         base = 0
         for g in range(ng):
-            if m.geom_type[g] != GEOM_MESH:
+            if m.geom_type[g] not in HULL_TYPES:
                 continue
             a, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
             v = m.mesh_vert[a:a + n]

@@ -25,6 +25,29 @@ class _DevView:
         self._owner = owner
 
 
+_DEFERRED = []  # handles whose owner was finalised while a stream was capturing: freed by the next close() / SimBatch creation outside a capture
+
+
+def _capturing() -> bool:
+    try:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:
+        return False
+
+
+def _drain_deferred() -> None:
+    if not _DEFERRED or _capturing():
+        return
+    pending, _DEFERRED[:] = list(_DEFERRED), []
+    for L, kind, h, models in sorted(pending, key=lambda x: x[1] != "env"):  # env layers before the batches they sit on
+        if kind == "env":
+            L.uhc_env_free(h)
+        else:
+            L.uhc_batch_free(h)
+            for mh in models:
+                L.uhc_model_free(mh)
+
+
 class SimBatch:
     def __init__(self, models, ctrl: UhcCtrlDesc, n_env: int, env_model: Optional[Sequence[int]] = None, device: int = 0):
         if not isinstance(models, (list, tuple)):
@@ -38,6 +61,7 @@ class SimBatch:
         self.device = torch.device("cuda", device)
         self.ctrl = ctrl
         self._descs = [model_desc(m) for m in self.models]
+        _drain_deferred()
         self._mh = []
         for d in self._descs:
             h = C.c_void_p()
@@ -57,6 +81,11 @@ class SimBatch:
 
     def close(self):
         if getattr(self, "_b", None) is not None and self._b:
+            if _capturing():  # (a finaliser that fires inside a stream capture: hipFree is not allowed there -- the handles wait for the next close / creation)
+                _DEFERRED.append((self.L, "batch", self._b, list(self._mh)))
+                self._b, self._mh = None, []
+                return
+            _drain_deferred()
             self.L.uhc_batch_free(self._b)
             self._b = None
             for h in self._mh:
@@ -192,6 +221,10 @@ class EnvBatch:
 
     def close(self):
         if getattr(self, "_e", None) is not None and self._e:
+            if _capturing():
+                _DEFERRED.append((self.L, "env", self._e, []))
+                self._e = None
+                return
             self.L.uhc_env_free(self._e)
             self._e = None
 

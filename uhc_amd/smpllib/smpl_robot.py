@@ -254,6 +254,8 @@ class Robot:
         self.flatfoot = self.cfg.get("flatfoot", False)
         self.rel_joint_lm = self.cfg.get("rel_joint_lm", True)
         self.smpl_model = self.cfg.get("model", "smpl")
+        self.masterfoot = bool(self.cfg.get("masterfoot", False))  # twelve capsule bodies under each ankle (smpl_robot.py:1174-1175, :1336-1414)
+        self.master_range = float(self.cfg.get("master_range", 30))
         if not self.mesh:
             raise NotImplementedError("capsule (non-mesh) humanoids are outside the hot path: every copycat / smpl_shape config sets mesh: True")
         self.body_provider = body_provider or SMPLBody(data_dir)
@@ -312,12 +314,50 @@ class Robot:
                 s += f'{ind}  <geom type="mesh" mesh="{name}" contype="1" conaffinity="1"/>\n'
             for c in children[name]:
                 s += body(c, depth + 1)
+            if self.masterfoot and name in ("L_Ankle", "R_Ankle"):
+                s += self._masterfoot_bodies(name, pos, children, depth + 1, motors)
             return s + f"{ind}</body>\n"
 
         bodies = body(self.joint_names[0], 0)
         assets = "".join(f'<mesh name="{n}" file="{n}.stl"/>' for n in self.meshes)
         ex = '<exclude name="add01" body1="L_Shoulder" body2="Chest"/><exclude name="add02" body1="R_Shoulder" body2="Chest"/>'  # smpl_robot.py:1177-1198
         return TEMPLATE.format(assets=assets, bodies=bodies, excludes=ex, motors="".join(motors))
+
+    # the reference's template of the twelve toe capsules of one foot, before scaling (smpl_robot.py:1343-1356)
+    MASTERFOOT_TEMPLATE = np.array([[0, -0.15, 0], [-0.08, -0.15, 0.1], [0.08, -0.15, 0.1], [-0.1, -0.15, 0.2], [0.1, -0.15, 0.2], [-0.1, -0.15, 0.35], [0.1, -0.15, 0.35],
+                                    [-0.1, -0.17, 0.6], [0.1, -0.17, 0.6], [0, -0.17, 0.6], [0.05, -0.17, 0.6], [-0.05, -0.17, 0.6]])
+
+    def _masterfoot_bodies(self, ankle, pos, children, depth, motors):
+        """`Robot.add_masterfoot` (uhc/smpllib/smpl_robot.py:1336-1414): twelve child bodies per ankle, each a CLONE of the ankle's body node -- its origin and its three
+        hinges at the ankle joint -- with the hull replaced by one capsule (radius 0.035, 0.1 long along x, contype 0 / conaffinity 1: the toes meet the floor and the
+        other bodies' hulls, not each other), the hinges limited to +-master_range degrees and one motor per hinge.  The capsules' start points follow the template
+        scaled by the foot's length (ankle-to-toe distance over 0.1343...) and sit at the height of the ankle hull's lowest vertex.  49 bodies / 147 dofs with both
+        feet -- beyond what the HIP step kernels hold (nv <= 128: uhc_batch_create refuses the model and says so); model compiler and oracle take it."""
+        ind = "  " * (depth + 2)
+        p = pos[ankle]
+        toe = children[ankle][0]
+        diff_mul = float(np.linalg.norm(p - pos[toe]) / 0.13432456960660616)
+        t = self.MASTERFOOT_TEMPLATE.copy()
+        t[:, 2] -= 0.08 * diff_mul
+        t[:, 0] -= 0.05 * diff_mul if ankle == "R_Ankle" else -0.05 * diff_mul
+        t /= 3 / diff_mul
+        t += p
+        t[:, 1] = float(self.meshes[ankle].reshape(-1, 3)[:, 1].min())
+        pstr = f"{p[0]:.4f} {p[1]:.4f} {p[2]:.4f}"
+        fmt = lambda x: f"{x:.6f}".rstrip("0").rstrip(".")
+        out = ""
+        for i, a in enumerate(t):
+            name = f"{ankle}_master{i}"
+            out += f'{ind}<body name="{name}" pos="{pstr}">\n'
+            for k, ch in enumerate("zyx"):
+                ax = ["0 0 1", "0 1 0", "1 0 0"][k]
+                out += (f'{ind}  <joint name="{name}_{ch}" type="hinge" pos="{pstr}" axis="{ax}" stiffness="0" damping="0" armature="0.01" '
+                        f'range="-{self.master_range:g} {self.master_range:g}"/>\n')
+                motors.append(f'<motor name="{name}_{ch}" joint="{name}_{ch}" gear="1"/>')
+            out += (f'{ind}  <geom type="capsule" size="0.035" fromto="{fmt(a[0])} {fmt(a[1])} {fmt(a[2])} {fmt(a[0] + 0.1)} {fmt(a[1])} {fmt(a[2])}" '
+                    f'contype="0" conaffinity="1"/>\n')
+            out += f"{ind}</body>\n"
+        return out
 
     def export_xml_string(self) -> bytes:
         return self.xml.encode("utf-8")
