@@ -774,28 +774,23 @@ __device__ __forceinline__ void k_smooth(const KernelArgs& A, const double* mb, 
 }
 
 // ------------------------------------------------------------------ P4 collision: plane vs convex mesh
-__device__ __forceinline__ void make_frame(double* f) {
+// [MJ-ext] mju_makeFrame: x given; y = the supplied axis when there is one (mjc_PlaneCapsule lays the contact frame's second axis along the capsule) and it is not
+// (nearly) parallel to x, else picked -- (0, 1, 0), or (0, 0, 1) where x is close to it; y made orthogonal to x and normalised, z = x cross y.  One orthogonalisation
+// for both cases: without a hint the arithmetic is what it always was.
+__device__ __forceinline__ void make_frame(double* f, const double* yh = nullptr) {
     double n = sqrt(dot3(f, f));
     f[0] /= n; f[1] /= n; f[2] /= n;
     f[3] = f[4] = f[5] = 0;
     if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+    if (yh) {
+        const double dh = dot3(f, yh);
+        const double t0 = yh[0] - f[0] * dh, t1 = yh[1] - f[1] * dh, t2 = yh[2] - f[2] * dh;
+        if (sqrt(t0 * t0 + t1 * t1 + t2 * t2) >= 1e-8) { f[3] = yh[0]; f[4] = yh[1]; f[5] = yh[2]; }
+    }
     const double dp = dot3(f, f + 3);
     for (int k = 0; k < 3; k++) f[3 + k] -= f[k] * dp;
     n = sqrt(dot3(f + 3, f + 3));
     f[3] /= n; f[4] /= n; f[5] /= n;
-    cross3(f + 6, f, f + 3);
-}
-// [MJ-ext] mju_makeFrame with the y axis supplied (mjc_PlaneCapsule aligns the contact frame with the capsule's axis): y made orthogonal to x and normalised,
-// z = x cross y; a y (nearly) parallel to x falls back to make_frame's pick (oracle/physics_oracle.c: make_frame_hint)
-__device__ __forceinline__ void make_frame_hint(double* f, const double* y) {
-    double n = sqrt(dot3(f, f));
-    f[0] /= n; f[1] /= n; f[2] /= n;
-    const double dp = dot3(f, y);
-    double t[3];
-    for (int k = 0; k < 3; k++) t[k] = y[k] - f[k] * dp;
-    n = sqrt(dot3(t, t));
-    if (n < 1e-8) { make_frame(f); return; }
-    for (int k = 0; k < 3; k++) f[3 + k] = t[k] / n;
     cross3(f + 6, f, f + 3);
 }
 __device__ __forceinline__ double impedance(const double* si, double pos, double margin) {
@@ -850,8 +845,7 @@ __device__ __forceinline__ void k_write_contact(const KernelArgs& A, const doubl
     double* C = S + lds_of<TIER>(A).con + c * UHC_CON_STRIDE;
     double fr[9];
     for (int k = 0; k < 3; k++) { C[k] = pos[k]; fr[k] = n[k]; }
-    if (yhint) make_frame_hint(fr, yhint);
-    else make_frame(fr);
+    make_frame(fr, yhint);
     for (int k = 0; k < 9; k++) C[3 + k] = fr[k];
     const double inc = margin - gap;
     double solref[2], solimp[5];
