@@ -474,7 +474,7 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
 // direction into an LDS mailbox, posts the round (barrier), BOTH waves walk the live mask in the order mpr_wave does and serve alternate groups of two requests
 // (pair_support_wave2 / pair_support_wave: the per-pair arithmetic of mpr_wave, operation for operation -- same bits), lane 0 of the serving wave writes the point
 // (v1 - v2, v1 + v2) back, barrier, the pairs' lanes pick their points up and advance.  The helper sleeps in s_barrier between rounds and between MPR passes.
-enum { MCMD_EXIT = 0, MCMD_ROUND = 1 };
+enum { MCMD_EXIT = 0, MCMD_ROUND = 1, MCMD_ROWS = 2 };  // ROWS: the helper builds the constraint rows 64 .. nefc - 1 (uhc_physics_impl.h: k_rows), header ints: 1 = nefc, 4 / 5 = the env's model blob
 // The mailbox sits on the rows' scalar arrays (free until the rows are enumerated), every piece INSIDE one of them (the debug layout puts guard words between the arrays):
 //   rowR: ints cmd, live lo, live hi, vertex base (LDS offset in doubles, or -1: the global pointer in ints 4, 5) | x of the direction in / of v1 - v2 out, per pair
 //   rowAref: y, z | rowB: x, y of v1 + v2 | rowF: its z, the pair's hm1 | rowDa: ints b1, b2, voff1, vn1 per pair | rowW: ints voff2, vn2 per pair, then the pair's hm2
@@ -647,6 +647,14 @@ __device__ __forceinline__ void mpr_helper(const KernelArgs& A, double* S) {
         __syncthreads();
         const int cmd = __builtin_amdgcn_readfirstlane(mbi[0]);
         if (cmd == MCMD_EXIT) return;
+        if (cmd == MCMD_ROWS) {
+            const int nefc = __builtin_amdgcn_readfirstlane(mbi[1]);
+            const unsigned long long mbp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbi[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbi[4]);
+            __syncthreads();  // the command is in registers: the rows may overwrite the header (it sits on rowR)
+            if (UHC_WAVE + LANE < nefc) k_row_one<TIER>(A, (const double*)mbp, S, UHC_WAVE + LANE, S + L.Y);
+            __syncthreads();
+            continue;
+        }
         const unsigned long long live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbi[2]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbi[1]);
         const int vst = __builtin_amdgcn_readfirstlane(mbi[3]);
         if (vst >= 0) mpr_serve_round(S + vst, S + L.xmat, S + L.xpos, MB, live, wid, UHC_NWG);

@@ -117,6 +117,7 @@ __device__ __forceinline__ double wave_min(double v) {
     return fmin(fmin(bcast(v, 0), bcast(v, 16)), fmin(bcast(v, 32), bcast(v, 48)));
 }
 __device__ __forceinline__ int wave_or(int v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }  // used as "any lane set"
+template <int TIER> __device__ __forceinline__ void k_row_one(const KernelArgs& A, const double* mb, double* S, const int r, double* Yb);  // (the helper wave of a two-wave consumer builds rows too: uhc_mpr.h mpr_helper)
 #include "uhc_mpr.h"  // (uses the lane helpers above)
 
 // ------------------------------------------------------------------ small math (registers)
@@ -1260,39 +1261,16 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 // force, and Yhat = D^-1/2 L^-T J^T stored chain-sparse (index = depth of the dof).
 // Returns 0, or 1 when the packed rows do not fit this tier's Yhat storage (-> the env goes to the next tier; the last tier's storage holds
 // maxefc full-length rows, so it cannot happen there).
+// One constraint row: Jacobian along the dof chain, reference acceleration, the half-solved row Yhat = D^-1/2 L^-T J' and its scalars.  Reads state, contacts,
+// factor and the rows' enumeration (RM, RY) from LDS, writes the row's own packed entries and its own slots of the scalar arrays: rows are independent of each other,
+// which is what lets the helper wave of a two-wave consumer take every second block of 64 rows (k_rows below).
 template <int TIER>
-__device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, double* Yb, double* Db) {
+__device__ __forceinline__ void k_row_one(const KernelArgs& A, const double* mb, double* S, const int r, double* Yb) {
     const DevTopo& T = A.t;
     const DevLds& L = lds_of<TIER>(A);
     const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
-    const int* NI = (const int*)(S + L.ncon_nefc);
-    // packed storage: row r starts at RY[r] and is as long as its dof chain (0 for dense rows); offsets by a scan in row order
-    int* RY = (int*)(S + L.rowY);
-    int ytot = 0;
-    for (int r0 = 0; r0 < nefc; r0 += UHC_WAVE) {
-        const int r = r0 + LANE;
-        int len = 0;
-        if (r < nefc) { const RowMisc rm = RM[r]; len = (rm.type & ROW_TWO) ? 0 : T.dof_depth[rm.last] + 1; }
-        int tot;
-        const int off = wave_excl_scan(len, &tot);
-        if (r < nefc) RY[r] = ytot + off;
-        ytot += tot;
-    }
-    if (ytot + 8 > cap_of<TIER>(A).ycap) return 1;
-    if (LANE == 0) RY[nefc] = ytot;  // (so that a row's length is RY[r + 1] - RY[r])
-    const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
-    for (int k0 = 0; k0 < ntwo; k0 += UHC_DENSE_GROUP) {  // dense rows first (wave-cooperative); their scalars wait in dsc for the lane that owns the row
-        int rr[UHC_DENSE_GROUP];
-#pragma unroll
-        for (int j = 0; j < UHC_DENSE_GROUP; j++) rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
-        DenseOut o[UHC_DENSE_GROUP];
-        k_dense_rows<TIER>(A, S, rr, k0, LC, o, Db);
-#pragma unroll
-        for (int j = 0; j < UHC_DENSE_GROUP; j++)
-            if (rr[j] >= 0 && LANE == 0) { const int k = k0 + j; S[L.dsc + 4 * k] = o[j].vel; S[L.dsc + 4 * k + 1] = o[j].jas; S[L.dsc + 4 * k + 2] = o[j].jaw; S[L.dsc + 4 * k + 3] = o[j].yy; }
-    }
-    wsync();
-    for (int r = LANE; r < nefc; r += UHC_WAVE) {
+    const int* RY = (const int*)(S + L.rowY);
+    {
         const RowMisc rm = RM[r];
         const int rt = RTYPE(rm.type);
         const bool two = (rm.type & ROW_TWO) != 0;
@@ -1399,6 +1377,58 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
         S[L.rowF + r] = f;
         S[L.rowDa + r] = da;             // diagonal of A + R
     }
+}
+
+template <int TIER>
+__device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, double* S, int nefc, const LaneConst& LC, double* Yb, double* Db) {
+    const DevTopo& T = A.t;
+    const DevLds& L = lds_of<TIER>(A);
+    const RowMisc* RM = (const RowMisc*)(S + L.rowMisc);
+    const int* NI = (const int*)(S + L.ncon_nefc);
+    // packed storage: row r starts at RY[r] and is as long as its dof chain (0 for dense rows); offsets by a scan in row order
+    int* RY = (int*)(S + L.rowY);
+    int ytot = 0;
+    for (int r0 = 0; r0 < nefc; r0 += UHC_WAVE) {
+        const int r = r0 + LANE;
+        int len = 0;
+        if (r < nefc) { const RowMisc rm = RM[r]; len = (rm.type & ROW_TWO) ? 0 : T.dof_depth[rm.last] + 1; }
+        int tot;
+        const int off = wave_excl_scan(len, &tot);
+        if (r < nefc) RY[r] = ytot + off;
+        ytot += tot;
+    }
+    if (ytot + 8 > cap_of<TIER>(A).ycap) return 1;
+    if (LANE == 0) RY[nefc] = ytot;  // (so that a row's length is RY[r + 1] - RY[r])
+    const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
+    for (int k0 = 0; k0 < ntwo; k0 += UHC_DENSE_GROUP) {  // dense rows first (wave-cooperative); their scalars wait in dsc for the lane that owns the row
+        int rr[UHC_DENSE_GROUP];
+#pragma unroll
+        for (int j = 0; j < UHC_DENSE_GROUP; j++) rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
+        DenseOut o[UHC_DENSE_GROUP];
+        k_dense_rows<TIER>(A, S, rr, k0, LC, o, Db);
+#pragma unroll
+        for (int j = 0; j < UHC_DENSE_GROUP; j++)
+            if (rr[j] >= 0 && LANE == 0) { const int k = k0 + j; S[L.dsc + 4 * k] = o[j].vel; S[L.dsc + 4 * k + 1] = o[j].jas; S[L.dsc + 4 * k + 2] = o[j].jaw; S[L.dsc + 4 * k + 3] = o[j].yy; }
+    }
+    wsync();
+#if defined(UHC_NW2)
+    if constexpr (TIER == 2) {
+        if (nefc > UHC_WAVE) {
+            // the two-wave consumer: rows 64 .. 127 are the helper wave's (uhc_mpr.h: mpr_helper, MCMD_ROWS).  The command sits in the mailbox's header on rowR, which the rows
+            // overwrite: a barrier of its own between the helper's reading it and anybody's first row
+            int* mbi = mpr_mb<TIER>(A, S).hdr;
+            if (LANE == 0) {
+                mbi[0] = MCMD_ROWS; mbi[1] = nefc;
+                mbi[4] = (int)((unsigned long long)mb & 0xffffffffull); mbi[5] = (int)((unsigned long long)mb >> 32);
+            }
+            __syncthreads();  // the helper reads the command
+            __syncthreads();  // ... and has it in registers: the header may go
+            if (LANE < nefc) k_row_one<TIER>(A, mb, S, LANE, Yb);
+            __syncthreads();  // both halves written
+        } else if (LANE < nefc) k_row_one<TIER>(A, mb, S, LANE, Yb);
+    } else
+#endif
+    for (int r = LANE; r < nefc; r += UHC_WAVE) k_row_one<TIER>(A, mb, S, r, Yb);
     // the register-resident solves of the working sets (k_as_general) read rows in chunks of 8 entries, past the row's own length and into
     // the next row: everything there must be finite (it meets a zero multiplier) -- the rows are, and so is the slack after the last one
     if (LANE < 8) Yb[ytot + LANE] = 0.0;
