@@ -474,7 +474,7 @@ __device__ __forceinline__ void mpr_wave(const double* __restrict__ VB, const do
 // direction into an LDS mailbox, posts the round (barrier), BOTH waves walk the live mask in the order mpr_wave does and serve alternate groups of two requests
 // (pair_support_wave2 / pair_support_wave: the per-pair arithmetic of mpr_wave, operation for operation -- same bits), lane 0 of the serving wave writes the point
 // (v1 - v2, v1 + v2) back, barrier, the pairs' lanes pick their points up and advance.  The helper sleeps in s_barrier between rounds and between MPR passes.
-enum { MCMD_EXIT = 0, MCMD_ROUND = 1, MCMD_ROWS = 2 };  // ROWS: the helper builds the constraint rows 64 .. nefc - 1 (uhc_physics_impl.h: k_rows), header ints: 1 = nefc, 4 / 5 = the env's model blob
+enum { MCMD_EXIT = 0, MCMD_ROUND = 1, MCMD_ROWS = 2 };  // ROWS: the helper builds every second group of dense rows and the constraint rows 64 .. nefc - 1 (uhc_physics_impl.h: k_rows), header ints: 1 = nefc, 2 = number of dense rows (0: they are wave 0's alone), 4 / 5 = the env's model blob
 // The mailbox sits on the rows' scalar arrays (free until the rows are enumerated), every piece INSIDE one of them (the debug layout puts guard words between the arrays):
 //   rowR: ints cmd, live lo, live hi, vertex base (LDS offset in doubles, or -1: the global pointer in ints 4, 5) | x of the direction in / of v1 - v2 out, per pair
 //   rowAref: y, z | rowB: x, y of v1 + v2 | rowF: its z, the pair's hm1 | rowDa: ints b1, b2, voff1, vn1 per pair | rowW: ints voff2, vn2 per pair, then the pair's hm2
@@ -643,14 +643,17 @@ __device__ __forceinline__ void mpr_helper(const KernelArgs& A, double* S) {
     const MprMB MB = mpr_mb<TIER>(A, S);
     const int* mbi = MB.hdr;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LaneConst HLC = lane_const<true>(A.t);  // (the per-lane dof constants of the dense rows' back substitution: model topology, the same for every env)
     for (;;) {
         __syncthreads();
         const int cmd = __builtin_amdgcn_readfirstlane(mbi[0]);
         if (cmd == MCMD_EXIT) return;
         if (cmd == MCMD_ROWS) {
-            const int nefc = __builtin_amdgcn_readfirstlane(mbi[1]);
+            const int nefc = __builtin_amdgcn_readfirstlane(mbi[1]), ntwo = __builtin_amdgcn_readfirstlane(mbi[2]);  // ntwo: 0 = the dense rows are wave 0's alone
             const unsigned long long mbp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mbi[5]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(mbi[4]);
             __syncthreads();  // the command is in registers: the rows may overwrite the header (it sits on rowR)
+            if (ntwo > 0) k_dense_groups<TIER>(A, S, HLC, S + L.dense, ntwo, 1, 2);  // every second group of dense rows
+            __syncthreads();  // the dense rows' scalars are there
             if (UHC_WAVE + LANE < nefc) k_row_one<TIER>(A, (const double*)mbp, S, UHC_WAVE + LANE, S + L.Y);
             __syncthreads();
             continue;

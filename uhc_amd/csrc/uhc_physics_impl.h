@@ -118,6 +118,9 @@ __device__ __forceinline__ double wave_min(double v) {
 }
 __device__ __forceinline__ int wave_or(int v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }  // used as "any lane set"
 template <int TIER> __device__ __forceinline__ void k_row_one(const KernelArgs& A, const double* mb, double* S, const int r, double* Yb);  // (the helper wave of a two-wave consumer builds rows too: uhc_mpr.h mpr_helper)
+struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1, r0, r1; bool v0, v1; };  // r0, r1: tree-root body of the lane's dofs (dense rows only)
+template <int TIER> __device__ __forceinline__ void k_dense_groups(const KernelArgs& A, double* S, const LaneConst& LC, double* Db, const int ntwo, const int first, const int stride);
+template <bool DENSE> __device__ __forceinline__ LaneConst lane_const(const DevTopo& T);
 #include "uhc_mpr.h"  // (uses the lane helpers above)
 
 // ------------------------------------------------------------------ small math (registers)
@@ -464,7 +467,6 @@ __device__ __forceinline__ void k_crb(const KernelArgs& A, const double* mb, dou
 // Per-lane topology constants, loaded once per kernel: the lane owns dofs LANE and LANE+64.
 // pk packs (madr | depth << 16 | ndesc << 24) so that a wave-uniform dof index i can fetch its row
 // address / depth / descendant count with one v_readlane instead of a table load.
-struct LaneConst { int d0, d1, n0, n1, m0, m1, pk0, pk1, r0, r1; bool v0, v1; };  // r0, r1: tree-root body of the lane's dofs (dense rows only)
 template <bool DENSE>
 __device__ __forceinline__ LaneConst lane_const(const DevTopo& T) {
     LaneConst c;
@@ -1261,6 +1263,24 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
 // force, and Yhat = D^-1/2 L^-T J^T stored chain-sparse (index = depth of the dof).
 // Returns 0, or 1 when the packed rows do not fit this tier's Yhat storage (-> the env goes to the next tier; the last tier's storage holds
 // maxefc full-length rows, so it cannot happen there).
+// The dense rows (contacts between two moving bodies) of the groups first, first + stride, ...: a group = UHC_DENSE_GROUP rows through one back substitution, the whole
+// wave on it (lane = dof); the rows' Yhat go to their dense slots, their scalars to dsc for the lane that owns the row.
+template <int TIER>
+__device__ __forceinline__ void k_dense_groups(const KernelArgs& A, double* S, const LaneConst& LC, double* Db, const int ntwo, const int first, const int stride) {
+    const DevLds& L = lds_of<TIER>(A);
+    const int* NI = (const int*)(S + L.ncon_nefc);
+    for (int k0 = first * UHC_DENSE_GROUP; k0 < ntwo; k0 += stride * UHC_DENSE_GROUP) {
+        int rr[UHC_DENSE_GROUP];
+#pragma unroll
+        for (int j = 0; j < UHC_DENSE_GROUP; j++) rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
+        DenseOut o[UHC_DENSE_GROUP];
+        k_dense_rows<TIER>(A, S, rr, k0, LC, o, Db);
+#pragma unroll
+        for (int j = 0; j < UHC_DENSE_GROUP; j++)
+            if (rr[j] >= 0 && LANE == 0) { const int k = k0 + j; S[L.dsc + 4 * k] = o[j].vel; S[L.dsc + 4 * k + 1] = o[j].jas; S[L.dsc + 4 * k + 2] = o[j].jaw; S[L.dsc + 4 * k + 3] = o[j].yy; }
+    }
+}
+
 // One constraint row: Jacobian along the dof chain, reference acceleration, the half-solved row Yhat = D^-1/2 L^-T J' and its scalars.  Reads state, contacts,
 // factor and the rows' enumeration (RM, RY) from LDS, writes the row's own packed entries and its own slots of the scalar arrays: rows are independent of each other,
 // which is what lets the helper wave of a two-wave consumer take every second block of 64 rows (k_rows below).
@@ -1400,35 +1420,38 @@ __device__ __forceinline__ int k_rows(const KernelArgs& A, const double* mb, dou
     if (ytot + 8 > cap_of<TIER>(A).ycap) return 1;
     if (LANE == 0) RY[nefc] = ytot;  // (so that a row's length is RY[r + 1] - RY[r])
     const int ntwo = cap_of<TIER>(A).ndense > 0 ? NI[2] : 0;
-    for (int k0 = 0; k0 < ntwo; k0 += UHC_DENSE_GROUP) {  // dense rows first (wave-cooperative); their scalars wait in dsc for the lane that owns the row
-        int rr[UHC_DENSE_GROUP];
-#pragma unroll
-        for (int j = 0; j < UHC_DENSE_GROUP; j++) rr[j] = k0 + j < ntwo ? __builtin_amdgcn_readfirstlane(NI[4 + k0 + j]) : -1;
-        DenseOut o[UHC_DENSE_GROUP];
-        k_dense_rows<TIER>(A, S, rr, k0, LC, o, Db);
-#pragma unroll
-        for (int j = 0; j < UHC_DENSE_GROUP; j++)
-            if (rr[j] >= 0 && LANE == 0) { const int k = k0 + j; S[L.dsc + 4 * k] = o[j].vel; S[L.dsc + 4 * k + 1] = o[j].jas; S[L.dsc + 4 * k + 2] = o[j].jaw; S[L.dsc + 4 * k + 3] = o[j].yy; }
-    }
-    wsync();
 #if defined(UHC_NW2)
     if constexpr (TIER == 2) {
-        if (nefc > UHC_WAVE) {
-            // the two-wave consumer: rows 64 .. 127 are the helper wave's (uhc_mpr.h: mpr_helper, MCMD_ROWS).  The command sits in the mailbox's header on rowR, which the rows
-            // overwrite: a barrier of its own between the helper's reading it and anybody's first row
+        // The two-wave consumer (uhc_k_general_q.hip): the helper wave -- asleep in a barrier outside MPR's rounds -- takes every second GROUP of dense rows (a group is one
+        // back substitution over all dofs for four rows) and the rows 64 .. 127 (uhc_mpr.h: mpr_helper, MCMD_ROWS).  Rows and groups are independent of each other: they
+        // read state, contacts, factor and the enumeration from LDS and write their own slots.  The command sits in the mailbox's header on rowR, which the ROWS overwrite:
+        // the helper has it in registers behind the second barrier, the dense phase leaves rowR alone, a third barrier separates the phases (a row of two bodies reads its
+        // scalars from dsc), a fourth ends the pass.
+        const bool split_dense = ntwo > UHC_DENSE_GROUP, split_rows = nefc > UHC_WAVE;
+        if (split_dense || split_rows) {
             int* mbi = mpr_mb<TIER>(A, S).hdr;
             if (LANE == 0) {
-                mbi[0] = MCMD_ROWS; mbi[1] = nefc;
+                mbi[0] = MCMD_ROWS; mbi[1] = nefc; mbi[2] = split_dense ? ntwo : 0;
                 mbi[4] = (int)((unsigned long long)mb & 0xffffffffull); mbi[5] = (int)((unsigned long long)mb >> 32);
             }
             __syncthreads();  // the helper reads the command
-            __syncthreads();  // ... and has it in registers: the header may go
+            __syncthreads();  // ... and has it in registers
+            k_dense_groups<TIER>(A, S, LC, Db, ntwo, 0, split_dense ? 2 : 1);
+            __syncthreads();  // every dense row and its scalars are there
             if (LANE < nefc) k_row_one<TIER>(A, mb, S, LANE, Yb);
-            __syncthreads();  // both halves written
-        } else if (LANE < nefc) k_row_one<TIER>(A, mb, S, LANE, Yb);
+            __syncthreads();  // every row is there
+        } else {
+            k_dense_groups<TIER>(A, S, LC, Db, ntwo, 0, 1);
+            wsync();
+            if (LANE < nefc) k_row_one<TIER>(A, mb, S, LANE, Yb);
+        }
     } else
 #endif
-    for (int r = LANE; r < nefc; r += UHC_WAVE) k_row_one<TIER>(A, mb, S, r, Yb);
+    {
+        k_dense_groups<TIER>(A, S, LC, Db, ntwo, 0, 1);  // dense rows first (wave-cooperative); their scalars wait in dsc for the lane that owns the row
+        wsync();
+        for (int r = LANE; r < nefc; r += UHC_WAVE) k_row_one<TIER>(A, mb, S, r, Yb);
+    }
     // the register-resident solves of the working sets (k_as_general) read rows in chunks of 8 entries, past the row's own length and into
     // the next row: everything there must be finite (it meets a zero multiplier) -- the rows are, and so is the slack after the last one
     if (LANE < 8) Yb[ytot + LANE] = 0.0;
