@@ -506,34 +506,34 @@ __device__ __forceinline__ void mpr_mb_put(const MprMB& MB, int p, const V3& a, 
         MB.io[0][p] = a.x - b.x; MB.io[1][p] = a.y - b.y; MB.io[2][p] = a.z - b.z; MB.io[3][p] = a.x + b.x; MB.io[4][p] = a.y + b.y; MB.io[5][p] = a.z + b.z;
     }
 }
-// one round's requests: every wave walks the live mask as mpr_wave does (two requests per group when all four hulls fit one trip) and serves the groups g with g % nw == wid
+// one round's requests, dealt out in CONTIGUOUS shares: wave wid serves the live pairs of rank [wid h, (wid + 1) h), h = ceil(n / nw) -- two at a time where all four hulls fit one
+// trip (pair_support_wave2), a last odd one singly (pair_support_wave).  (Round 6, first form: alternate groups of two -- with two live pairs, the commonest late-round count, the
+// helper had nothing to do and wave 0 a pairwise query of ~400 cycles; now each wave has one single query of ~300.)  Per pair the arithmetic of either form is mpr_wave's: same bits.
 __device__ __forceinline__ void mpr_serve_round(const double* __restrict__ VB, const double* __restrict__ xmat, const double* __restrict__ xpos, const MprMB& MB, unsigned long long live, int wid, int nw) {
-    int g = 0;
-    while (live) {
+    const int n = __builtin_popcountll(live), h = (n + nw - 1) / nw;
+    int take = min(h, n - wid * h);
+    for (int k = 0; k < wid * h && live; k++) live &= live - 1;  // the shares of the waves before this one
+    while (live && take > 0) {
         const int p = __ffsll((long long)live) - 1;
         live &= live - 1;
-        const bool mine = (g % nw) == wid;
-        g++;
         const SupArgs Ap = mpr_mb_args(MB, xmat, xpos, p);
         V3 a, b;
-        if (live && UHC_MPR_PAIRWISE) {
+        if (take >= 2 && live && UHC_MPR_PAIRWISE) {
             const int q = __ffsll((long long)live) - 1;
             const SupArgs Aq = mpr_mb_args(MB, xmat, xpos, q);
             if (max(max(Ap.vn1, Ap.vn2), max(Aq.vn1, Aq.vn2)) <= UHC_WAVE) {
                 live &= live - 1;
-                if (mine) {
-                    V3 a2, b2v;
-                    pair_support_wave2(VB, Ap, Aq, a, b, a2, b2v);
-                    mpr_mb_put(MB, p, a, b);
-                    mpr_mb_put(MB, q, a2, b2v);
-                }
+                take -= 2;
+                V3 a2, b2v;
+                pair_support_wave2(VB, Ap, Aq, a, b, a2, b2v);
+                mpr_mb_put(MB, p, a, b);
+                mpr_mb_put(MB, q, a2, b2v);
                 continue;
             }
         }
-        if (mine) {
-            pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.hm1, Ap.hm2, a, b);
-            mpr_mb_put(MB, p, a, b);
-        }
+        pair_support_wave(VB, Ap.R1, Ap.P1, Ap.voff1, Ap.vn1, Ap.R2, Ap.P2, Ap.voff2, Ap.vn2, Ap.d, Ap.hm1, Ap.hm2, a, b);
+        mpr_mb_put(MB, p, a, b);
+        take -= 1;
     }
 }
 // wave 0's side: mpr_wave with the serving loop replaced by mailbox + barrier + shared serving + barrier
