@@ -276,3 +276,12 @@ def test_masterfoot_model_is_generated_compiled_and_stepped_by_the_oracle(model,
     h = C.c_void_p()
     with pytest.raises(UhcError, match="nv=147"):
         check(lib().uhc_model_create(C.byref(model_desc(m)), C.byref(h)))
+
+
+def test_a_masterfoot_config_is_refused_by_the_env_with_the_reason():
+    """`masterfoot: true` (config/smpl_shape/copycat_master_1.yml) must not run the plain humanoid silently: the env says what exists and what does not."""
+    from types import SimpleNamespace
+    from uhc_amd.envs.humanoid_im import VecHumanoidEnv
+    cfg = SimpleNamespace(masterfoot=True, robot_cfg={"mesh": True})
+    with pytest.raises(NotImplementedError, match="masterfoot.*nv <= 128"):
+        VecHumanoidEnv(cfg, 4)

@@ -39,6 +39,11 @@ class VecHumanoidEnv:
         self.cc_cfg = self.cfg = cfg
         self.mode = mode
         self.n_env = int(n_env)
+        if getattr(cfg, "masterfoot", False) or dict(cfg.robot_cfg or {}).get("masterfoot", False):
+            # uhc/envs/humanoid_im.py:54-58: Robot(cfg.robot_cfg, masterfoot=cfg.masterfoot).  The generator builds that model (uhc_amd/smpllib/smpl_robot.py:
+            # Robot({"masterfoot": True}): 49 bodies / 147 dofs, capsule toes) and the CPU checker steps it; the HIP step kernels hold 128 dofs
+            raise NotImplementedError("masterfoot: the 147-dof model (12 capsule bodies of three hinges under each ankle) is generated and compiled -- "
+                                      "uhc_amd.smpllib.smpl_robot.Robot({'mesh': True, 'masterfoot': True}) -- but the HIP step kernels hold nv <= 128: not runnable on the device")
         if model is None:
             # the reference never loads the asset file: its env model comes out of Robot(cfg.robot_cfg) (humanoid_im.py:52-64) -- body-body
             # collisions on, rel_joint_lm ranges, ball joints if asked.  Without the licensed SMPL files the shipped asset stands in for
